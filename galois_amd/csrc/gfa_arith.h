@@ -1,0 +1,449 @@
+// gfa_arith.h -- scalar finite-field arithmetic for gfx950 kernels (and, compiled with g++, for the
+// host-side formula tests in tests/csrc/).  Everything here is exact integer arithmetic: any correct
+// formula yields the reference's bits, so the device uses reductions that suit the CDNA4 VALU
+// (Barrett / Montgomery / Goldilocks folding, clz-driven binary EGCD) instead of the reference's
+// `%`, extended Euclid and shift-xor loops (reference: src/galois/_domains/_calculate.py:133-592,
+// _lookup.py:31-270).  Zero-handling and error semantics follow the reference exactly.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GFA_HD __host__ __device__ __forceinline__
+#else
+#define GFA_HD inline
+#endif
+
+namespace gfa {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int64_t i64;
+
+enum Kind : u32 {
+    KIND_PRIME32 = 0,    // GF(p), p < 2^32: Barrett reduction of the 64-bit product
+    KIND_PRIME64 = 1,    // GF(p), odd p < 2^64: Montgomery
+    KIND_GOLDILOCKS = 2, // GF(2^64 - 2^32 + 1): folding reduction
+    KIND_BIN = 3,        // GF(2^m), m <= 63: carry-less shift/xor, clz-driven polynomial EGCD inverse
+    KIND_LUT = 4,        // any GF(p^m) with q <= 2^20: EXP/LOG/Zech tables (the reference's lookup mode)
+    KIND_EXT = 5,        // GF(p^m), p odd < 2^32, m <= 16, q < 2^64: base-p digit vectors
+};
+
+#define GFA_MAX_EXT_DEGREE 16
+
+// Passed by value as a kernel argument (fits comfortably in kernarg space).
+struct FieldDev {
+    u64 p;      // characteristic
+    u64 q;      // order p^m (0 for 2^64, which is not supported)
+    u32 m;      // degree
+    u32 kind;   // Kind used for explicit calculation
+    u64 irr;    // GF(2^m): full irreducible polynomial (bit m set)
+    u64 mu;     // PRIME32/EXT: floor(2^64 / p)
+    u64 nprime; // PRIME64: -p^-1 mod 2^64
+    u64 r2;     // PRIME64: 2^128 mod p
+    u32 qm1;    // LUT: q - 1
+    u32 zech_e; // LUT: (q-1)/2 for odd characteristic, 0 for characteristic 2
+    const u32 *exp_tab;  // LUT: 2q entries (second half = EXP[1..q], as _lookup.py:371)
+    const u32 *log_tab;  // LUT: q entries, LOG[0] = 0 placeholder
+    const u32 *zech_tab; // LUT: q entries
+    u32 ext_irr[GFA_MAX_EXT_DEGREE]; // EXT: irreducible polynomial minus x^m, digits of degree m-1..0
+};
+
+GFA_HD u64 mulhi64(u64 a, u64 b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (u64)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+GFA_HD int clz64(u64 x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clzll((long long)x);
+#else
+    return x ? __builtin_clzll(x) : 64;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// GF(p), p < 2^32
+// ------------------------------------------------------------------------------------------------
+struct Prime32 {
+    typedef u32 elem;
+    static GFA_HD u32 reduce64(const FieldDev &f, u64 t)
+    {
+        // Barrett: qh = floor(t * mu / 2^64) underestimates floor(t / p) by at most 2
+        u64 qh = mulhi64(t, f.mu);
+        u64 r = t - qh * f.p;
+        if (r >= f.p) r -= f.p;
+        if (r >= f.p) r -= f.p;
+        return (u32)r;
+    }
+    static GFA_HD u32 add(const FieldDev &f, u32 a, u32 b)
+    {
+        u64 c = (u64)a + b;
+        if (c >= f.p) c -= f.p;
+        return (u32)c;
+    }
+    static GFA_HD u32 sub(const FieldDev &f, u32 a, u32 b) { return a >= b ? a - b : (u32)(f.p + a - b); }
+    static GFA_HD u32 neg(const FieldDev &f, u32 a) { return a == 0 ? 0 : (u32)(f.p - a); }
+    static GFA_HD u32 mul(const FieldDev &f, u32 a, u32 b) { return reduce64(f, (u64)a * b); }
+    static GFA_HD u32 one(const FieldDev &) { return 1; }
+    static GFA_HD u32 pow_u(const FieldDev &f, u32 a, u64 e)
+    {
+        u32 r = 1;
+        while (e) {
+            if (e & 1) r = mul(f, r, a);
+            a = mul(f, a, a);
+            e >>= 1;
+        }
+        return r;
+    }
+    // a != 0.  Fermat: a^(p-2).  (Same value as the reference's extended Euclid, _calculate.py:395-417.)
+    static GFA_HD u32 inv(const FieldDev &f, u32 a) { return pow_u(f, a, f.p - 2); }
+    static GFA_HD u32 from_int(const FieldDev &f, i64 k)
+    { // integer -> prime subfield (np.mod(int, characteristic), _ufunc.py:399)
+        i64 r = k % (i64)f.p;
+        if (r < 0) r += (i64)f.p;
+        return (u32)r;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// GF(p), odd p < 2^64 (Montgomery; operands and results are plain residues)
+// ------------------------------------------------------------------------------------------------
+struct Prime64 {
+    typedef u64 elem;
+    static GFA_HD u64 redc(const FieldDev &f, u64 lo, u64 hi)
+    { // (hi*2^64 + lo) * 2^-64 mod p, for hi*2^64+lo < p*2^64
+        u64 mq = lo * f.nprime;
+        u64 mph = mulhi64(mq, f.p);
+        // lo + (mq*p mod 2^64) == 0 mod 2^64, carrying 1 unless lo == 0
+        u64 carry = lo != 0;
+        u64 r = hi + mph;
+        bool ov = r < hi;
+        u64 r2 = r + carry;
+        ov |= r2 < r;
+        if (ov || r2 >= f.p) r2 -= f.p;
+        return r2;
+    }
+    static GFA_HD u64 montmul(const FieldDev &f, u64 a, u64 b) { return redc(f, a * b, mulhi64(a, b)); }
+    static GFA_HD u64 add(const FieldDev &f, u64 a, u64 b)
+    {
+        u64 c = a + b;
+        if (c < a || c >= f.p) c -= f.p;
+        return c;
+    }
+    static GFA_HD u64 sub(const FieldDev &f, u64 a, u64 b) { return a >= b ? a - b : a + (f.p - b); }
+    static GFA_HD u64 neg(const FieldDev &f, u64 a) { return a == 0 ? 0 : f.p - a; }
+    static GFA_HD u64 mul(const FieldDev &f, u64 a, u64 b) { return montmul(f, montmul(f, a, b), f.r2); }
+    static GFA_HD u64 one(const FieldDev &) { return 1; }
+    static GFA_HD u64 pow_u(const FieldDev &f, u64 a, u64 e)
+    {
+        u64 r = 1;
+        while (e) {
+            if (e & 1) r = mul(f, r, a);
+            a = mul(f, a, a);
+            e >>= 1;
+        }
+        return r;
+    }
+    static GFA_HD u64 inv(const FieldDev &f, u64 a) { return pow_u(f, a, f.p - 2); }
+    static GFA_HD u64 from_int(const FieldDev &f, i64 k)
+    {
+        if (k >= 0) return (u64)k % f.p;
+        u64 r = ((u64)0 - (u64)k) % f.p; // |k| mod p
+        return r == 0 ? 0 : f.p - r;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// GF(2^64 - 2^32 + 1)
+// ------------------------------------------------------------------------------------------------
+struct Goldilocks {
+    typedef u64 elem;
+    static constexpr u64 P = 0xFFFFFFFF00000001ull;
+    static constexpr u64 EPS = 0xFFFFFFFFull; // 2^32 - 1 == 2^64 mod p
+    static GFA_HD u64 reduce128(u64 lo, u64 hi)
+    {
+        // 2^64 == 2^32 - 1 and 2^96 == -1 (mod p)
+        u64 hi_hi = hi >> 32, hi_lo = hi & EPS;
+        u64 t0 = lo - hi_hi;
+        if (lo < hi_hi) t0 -= EPS; // borrowed 2^64 == EPS (mod p)
+        u64 t1 = hi_lo * EPS;
+        u64 t2 = t0 + t1;
+        if (t2 < t0) t2 += EPS;
+        if (t2 >= P) t2 -= P;
+        return t2;
+    }
+    static GFA_HD u64 add(const FieldDev &, u64 a, u64 b)
+    {
+        u64 c = a + b;
+        if (c < a || c >= P) c -= P;
+        return c;
+    }
+    static GFA_HD u64 sub(const FieldDev &, u64 a, u64 b) { return a >= b ? a - b : a + (P - b); }
+    static GFA_HD u64 neg(const FieldDev &, u64 a) { return a == 0 ? 0 : P - a; }
+    static GFA_HD u64 mul(const FieldDev &, u64 a, u64 b) { return reduce128(a * b, mulhi64(a, b)); }
+    static GFA_HD u64 one(const FieldDev &) { return 1; }
+    static GFA_HD u64 pow_u(const FieldDev &f, u64 a, u64 e)
+    {
+        u64 r = 1;
+        while (e) {
+            if (e & 1) r = mul(f, r, a);
+            a = mul(f, a, a);
+            e >>= 1;
+        }
+        return r;
+    }
+    static GFA_HD u64 inv(const FieldDev &f, u64 a) { return pow_u(f, a, P - 2); }
+    static GFA_HD u64 from_int(const FieldDev &, i64 k)
+    {
+        if (k >= 0) return (u64)k % P;
+        u64 r = ((u64)0 - (u64)k) % P;
+        return r == 0 ? 0 : P - r;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// GF(2^m), m <= 63
+// ------------------------------------------------------------------------------------------------
+struct Bin {
+    typedef u64 elem;
+    static GFA_HD u64 add(const FieldDev &, u64 a, u64 b) { return a ^ b; }
+    static GFA_HD u64 sub(const FieldDev &, u64 a, u64 b) { return a ^ b; }
+    static GFA_HD u64 neg(const FieldDev &, u64 a) { return a; }
+    static GFA_HD u64 mul(const FieldDev &f, u64 a, u64 b)
+    { // shift-and-xor with reduction by the irreducible polynomial (value-identical to _calculate.py:308-324)
+        u64 c = 0;
+        const u64 top = (u64)1 << (f.m - 1);
+        const u64 red = f.irr ^ ((u64)1 << f.m); // low m bits of the irreducible polynomial
+        while (b) {
+            if (b & 1) c ^= a;
+            b >>= 1;
+            u64 carry = a & top;
+            a = (a ^ carry) << 1;
+            if (carry) a ^= red;
+        }
+        return c;
+    }
+    static GFA_HD u64 one(const FieldDev &) { return 1; }
+    static GFA_HD u64 pow_u(const FieldDev &f, u64 a, u64 e)
+    {
+        u64 r = 1;
+        while (e) {
+            if (e & 1) r = mul(f, r, a);
+            a = mul(f, a, a);
+            e >>= 1;
+        }
+        return r;
+    }
+    // a != 0: polynomial extended Euclid over GF(2), one clz per step (replaces Itoh-Tsujii, _calculate.py:469-489)
+    static GFA_HD u64 inv(const FieldDev &f, u64 a)
+    {
+        u64 u = a, v = f.irr, g1 = 1, g2 = 0;
+        while (u != 1) {
+            int j = clz64(v) - clz64(u); // deg(u) - deg(v)
+            if (j < 0) {
+                u64 t = u; u = v; v = t;
+                t = g1; g1 = g2; g2 = t;
+                j = -j;
+            }
+            u ^= v << j;
+            g1 ^= g2 << j;
+        }
+        return g1;
+    }
+    static GFA_HD u64 from_int(const FieldDev &, i64 k) { return (u64)(k & 1); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Lookup tables (EXP / LOG / Zech), q <= 2^20.  Formulas are the reference's, _lookup.py:31-270.
+// ------------------------------------------------------------------------------------------------
+struct Lut {
+    typedef u32 elem;
+    static GFA_HD u32 add(const FieldDev &f, u32 a, u32 b)
+    {
+        if (f.p == 2) return a ^ b;
+        if (f.m == 1) { u64 c = (u64)a + b; if (c >= f.p) c -= f.p; return (u32)c; }
+        if (a == 0) return b;
+        if (b == 0) return a;
+        u32 mm = f.log_tab[a], nn = f.log_tab[b];
+        if (mm > nn) { u32 t = mm; mm = nn; nn = t; }
+        if (nn - mm == f.zech_e) return 0;
+        return f.exp_tab[mm + f.zech_tab[nn - mm]];
+    }
+    static GFA_HD u32 neg(const FieldDev &f, u32 a)
+    {
+        if (f.p == 2) return a;
+        if (f.m == 1) return a == 0 ? 0 : (u32)(f.p - a);
+        if (a == 0) return 0;
+        return f.exp_tab[f.zech_e + f.log_tab[a]];
+    }
+    static GFA_HD u32 sub(const FieldDev &f, u32 a, u32 b)
+    {
+        if (f.p == 2) return a ^ b;
+        if (f.m == 1) return a >= b ? a - b : (u32)(f.p + a - b);
+        if (b == 0) return a;
+        u32 nn = f.log_tab[b] + f.zech_e;
+        if (a == 0) return f.exp_tab[nn];
+        u32 mm = f.log_tab[a];
+        if (mm > nn) { u32 t = mm; mm = nn; nn = t; }
+        u32 z = nn - mm;
+        if (z == f.zech_e) return 0;
+        if (z >= f.qm1) z -= f.qm1;
+        return f.exp_tab[mm + f.zech_tab[z]];
+    }
+    static GFA_HD u32 mul(const FieldDev &f, u32 a, u32 b)
+    {
+        if (a == 0 || b == 0) return 0;
+        return f.exp_tab[f.log_tab[a] + f.log_tab[b]];
+    }
+    static GFA_HD u32 one(const FieldDev &) { return 1; }
+    static GFA_HD u32 inv(const FieldDev &f, u32 a) { return f.exp_tab[f.qm1 - f.log_tab[a]]; }
+    static GFA_HD u32 div_nz(const FieldDev &f, u32 a, u32 b)
+    { // b != 0
+        if (a == 0) return 0;
+        return f.exp_tab[f.qm1 + f.log_tab[a] - f.log_tab[b]];
+    }
+    // a != 0, any signed exponent: EXP[(LOG[a] * b) mod (q-1)] with a floor modulo (power_ufunc.lookup, _lookup.py:247-270)
+    static GFA_HD u32 pow_nz(const FieldDev &f, u32 a, i64 e)
+    {
+        i64 em = e % (i64)f.qm1; // reduce first: mathematically identical, cannot overflow (the reference's TODO)
+        if (em < 0) em += f.qm1;
+        u64 idx = ((u64)f.log_tab[a] * (u64)em) % f.qm1;
+        return f.exp_tab[idx];
+    }
+    static GFA_HD u32 pow_u(const FieldDev &f, u32 a, u64 e)
+    {
+        if (e == 0) return 1;
+        if (a == 0) return 0;
+        u64 em = e % f.qm1;
+        u64 idx = ((u64)f.log_tab[a] * em) % f.qm1;
+        return f.exp_tab[idx];
+    }
+    static GFA_HD u32 from_int(const FieldDev &f, i64 k)
+    {
+        i64 r = k % (i64)f.p;
+        if (r < 0) r += (i64)f.p;
+        return (u32)r;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// GF(p^m), p odd, explicit digit-vector arithmetic (reference: *_vector.calculate, _calculate.py:150-383)
+// ------------------------------------------------------------------------------------------------
+struct Ext {
+    typedef u64 elem;
+    static GFA_HD void to_vec(const FieldDev &f, u64 a, u32 *v)
+    { // most significant digit first, like int_to_vector (_calculate.py:22-33)
+        for (int i = (int)f.m - 1; i >= 0; i--) {
+            v[i] = (u32)(a % f.p);
+            a /= f.p;
+        }
+    }
+    static GFA_HD u64 from_vec(const FieldDev &f, const u32 *v)
+    {
+        u64 a = 0;
+        for (u32 i = 0; i < f.m; i++) a = a * f.p + v[i];
+        return a;
+    }
+    static GFA_HD u64 add(const FieldDev &f, u64 a, u64 b)
+    {
+        u32 av[GFA_MAX_EXT_DEGREE], bv[GFA_MAX_EXT_DEGREE];
+        to_vec(f, a, av); to_vec(f, b, bv);
+        for (u32 i = 0; i < f.m; i++) av[i] = Prime32::add(f, av[i], bv[i]);
+        return from_vec(f, av);
+    }
+    static GFA_HD u64 sub(const FieldDev &f, u64 a, u64 b)
+    {
+        u32 av[GFA_MAX_EXT_DEGREE], bv[GFA_MAX_EXT_DEGREE];
+        to_vec(f, a, av); to_vec(f, b, bv);
+        for (u32 i = 0; i < f.m; i++) av[i] = Prime32::sub(f, av[i], bv[i]);
+        return from_vec(f, av);
+    }
+    static GFA_HD u64 neg(const FieldDev &f, u64 a)
+    {
+        u32 av[GFA_MAX_EXT_DEGREE];
+        to_vec(f, a, av);
+        for (u32 i = 0; i < f.m; i++) av[i] = Prime32::neg(f, av[i]);
+        return from_vec(f, av);
+    }
+    static GFA_HD u64 mul(const FieldDev &f, u64 a, u64 b)
+    {
+        u32 av[GFA_MAX_EXT_DEGREE], bv[GFA_MAX_EXT_DEGREE], cv[GFA_MAX_EXT_DEGREE];
+        const u32 m = f.m;
+        to_vec(f, a, av); to_vec(f, b, bv);
+        for (u32 i = 0; i < m; i++) cv[i] = 0;
+        // consume b from its lowest digit upward; keep a(x) * x^it reduced modulo the irreducible polynomial
+        for (u32 it = 0; it < m; it++) {
+            u32 bl = bv[m - 1 - it];
+            if (bl)
+                for (u32 i = 0; i < m; i++) cv[i] = Prime32::add(f, cv[i], Prime32::mul(f, bl, av[i]));
+            u32 qd = av[0];
+            for (u32 i = 0; i + 1 < m; i++) av[i] = av[i + 1];
+            av[m - 1] = 0;
+            if (qd)
+                for (u32 i = 0; i < m; i++) av[i] = Prime32::sub(f, av[i], Prime32::mul(f, qd, f.ext_irr[i]));
+        }
+        return from_vec(f, cv);
+    }
+    static GFA_HD u64 one(const FieldDev &) { return 1; }
+    static GFA_HD u64 pow_u(const FieldDev &f, u64 a, u64 e)
+    {
+        u64 r = 1;
+        while (e) {
+            if (e & 1) r = mul(f, r, a);
+            a = mul(f, a, a);
+            e >>= 1;
+        }
+        return r;
+    }
+    // a != 0.  Itoh-Tsujii as the reference (_calculate.py:469-489): a^-1 = (a^r)^-1 * a^(r-1), r = (q-1)/(p-1), a^r in GF(p)
+    static GFA_HD u64 inv(const FieldDev &f, u64 a)
+    {
+        u64 r = (f.q - 1) / (f.p - 1);
+        u64 a_r1 = pow_u(f, a, r - 1);
+        u64 a_r = mul(f, a_r1, a);
+        u32 norm_inv = Prime32::inv(f, (u32)a_r);
+        return mul(f, (u64)norm_inv, a_r1);
+    }
+    static GFA_HD u64 from_int(const FieldDev &f, i64 k)
+    {
+        i64 r = k % (i64)f.p;
+        if (r < 0) r += (i64)f.p;
+        return (u64)r;
+    }
+};
+
+// a^e for signed e on the explicit-calculation kinds (power_square_and_multiply.calculate, _calculate.py:579-592).
+// Returns false when the reference would raise ZeroDivisionError (0 ** negative).
+template <class F>
+GFA_HD bool pow_signed(const FieldDev &f, typename F::elem a, i64 e, typename F::elem *out)
+{
+    if (e == 0) { *out = F::one(f); return true; }
+    if (a == 0) { *out = 0; return e > 0; }
+    u64 ue;
+    if (e < 0) {
+        a = F::inv(f, a);
+        ue = (u64)0 - (u64)e;
+    } else {
+        ue = (u64)e;
+    }
+    // a != 0: reduce the exponent modulo the multiplicative group order when it is known to fit
+    if (f.q != 0) ue %= (f.q - 1);
+    *out = F::pow_u(f, a, ue);
+    return true;
+}
+template <>
+GFA_HD bool pow_signed<Lut>(const FieldDev &f, u32 a, i64 e, u32 *out)
+{
+    if (e == 0) { *out = 1; return true; }
+    if (a == 0) { *out = 0; return e > 0; }
+    *out = Lut::pow_nz(f, a, e);
+    return true;
+}
+
+} // namespace gfa

@@ -1,0 +1,725 @@
+// gfa_elementwise.hip -- element-wise field ufuncs as HBM-streaming integer kernels for gfx950.
+//
+// Replaces the numba.vectorize'd scalar loops behind UFunc.ufunc (reference: src/galois/_domains/_ufunc.py:97-144
+// with the scalar bodies of _lookup.py:31-270 and _calculate.py:133-592).
+//
+// Two kernel families:
+//   * tab8_*  : fields with order <= 256 stored as uint8 (GF(2^8) is the headline case).  A full 64 KiB
+//               binary-operation table (index (a<<8)|b) is staged into LDS once per 1024-thread workgroup, so each
+//               element costs ONE LDS byte gather instead of the three dependent gathers of EXP[LOG a + LOG b].
+//               Unary tables (reciprocal / negative) are replicated 32x so that lane l only ever touches LDS
+//               bank l%32: conflict-free by construction.  Loads/stores are 16 B per lane, fully coalesced.
+//   * ew_*    : every other field / dtype, templated on the arithmetic (gfa_arith.h) and the storage width.
+#include <algorithm>
+
+#include "gfa_internal.h"
+
+using namespace gfa;
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct alignas(16) Vec16 {
+    static constexpr int N = 16 / sizeof(T);
+    T v[N];
+};
+
+__device__ __forceinline__ void flag_error(int32_t *err, bool bad)
+{
+    // one atomic per wave at most
+    if (__any(bad)) {
+        if ((threadIdx.x & 63) == 0 && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic element-wise kernels
+// ------------------------------------------------------------------------------------------------
+template <class F, int OP>
+__device__ __forceinline__ typename F::elem apply_binary(const FieldDev &fd, typename F::elem x, typename F::elem y, bool &bad)
+{
+    if constexpr (OP == GFA_OP_ADD) return F::add(fd, x, y);
+    else if constexpr (OP == GFA_OP_SUB) return F::sub(fd, x, y);
+    else if constexpr (OP == GFA_OP_MUL) return F::mul(fd, x, y);
+    else { // DIV: reciprocal of the divisor then multiply (divide_ufunc.__call__, _ufunc.py:433-437)
+        if (y == 0) { bad = true; return 0; }
+        if (x == 0) return 0;
+        if constexpr (std::is_same<F, Lut>::value) return Lut::div_nz(fd, x, y);
+        else return F::mul(fd, x, F::inv(fd, y));
+    }
+}
+
+template <class F, int OP>
+__device__ __forceinline__ typename F::elem apply_unary(const FieldDev &fd, typename F::elem x, bool &bad)
+{
+    if constexpr (OP == GFA_OP_NEG) return F::neg(fd, x);
+    else { // RECIP
+        if (x == 0) { bad = true; return 0; }
+        return F::inv(fd, x);
+    }
+}
+
+template <class F, typename T, int OP, bool VEC>
+__global__ __launch_bounds__(256) void ew_binary_kernel(FieldDev fd, const T *__restrict__ a, int sa,
+                                                        const T *__restrict__ b, int sb, T *__restrict__ out, i64 n,
+                                                        int32_t *err)
+{
+    typedef typename F::elem E;
+    bool bad = false;
+    const i64 tid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 nth = (i64)gridDim.x * blockDim.x;
+    if constexpr (VEC) {
+        constexpr int V = Vec16<T>::N;
+        const i64 nvec = n / V;
+        const E a0 = sa ? 0 : (E)a[0];
+        const E b0 = sb ? 0 : (E)b[0];
+        for (i64 i = tid; i < nvec; i += nth) {
+            Vec16<T> av, bv, ov;
+            if (sa) av = reinterpret_cast<const Vec16<T> *>(a)[i];
+            if (sb) bv = reinterpret_cast<const Vec16<T> *>(b)[i];
+#pragma unroll
+            for (int j = 0; j < V; j++) {
+                E x = sa ? (E)av.v[j] : a0;
+                E y = sb ? (E)bv.v[j] : b0;
+                ov.v[j] = (T)apply_binary<F, OP>(fd, x, y, bad);
+            }
+            reinterpret_cast<Vec16<T> *>(out)[i] = ov;
+        }
+        for (i64 i = nvec * V + tid; i < n; i += nth)
+            out[i] = (T)apply_binary<F, OP>(fd, (E)a[sa ? i : 0], (E)b[sb ? i : 0], bad);
+    } else {
+        for (i64 i = tid; i < n; i += nth)
+            out[i] = (T)apply_binary<F, OP>(fd, (E)a[sa ? i : 0], (E)b[sb ? i : 0], bad);
+    }
+    if constexpr (OP == GFA_OP_DIV) flag_error(err, bad);
+}
+
+template <class F, typename T, int OP, bool VEC>
+__global__ __launch_bounds__(256) void ew_unary_kernel(FieldDev fd, const T *__restrict__ a, T *__restrict__ out, i64 n,
+                                                       int32_t *err)
+{
+    typedef typename F::elem E;
+    bool bad = false;
+    const i64 tid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 nth = (i64)gridDim.x * blockDim.x;
+    if constexpr (VEC) {
+        constexpr int V = Vec16<T>::N;
+        const i64 nvec = n / V;
+        for (i64 i = tid; i < nvec; i += nth) {
+            Vec16<T> av = reinterpret_cast<const Vec16<T> *>(a)[i], ov;
+#pragma unroll
+            for (int j = 0; j < V; j++) ov.v[j] = (T)apply_unary<F, OP>(fd, (E)av.v[j], bad);
+            reinterpret_cast<Vec16<T> *>(out)[i] = ov;
+        }
+        for (i64 i = nvec * V + tid; i < n; i += nth) out[i] = (T)apply_unary<F, OP>(fd, (E)a[i], bad);
+    } else {
+        for (i64 i = tid; i < n; i += nth) out[i] = (T)apply_unary<F, OP>(fd, (E)a[i], bad);
+    }
+    if constexpr (OP == GFA_OP_RECIP) flag_error(err, bad);
+}
+
+// np.power(x, e) with an int64 exponent array, and field * integer (both operands array or broadcast scalar)
+template <class F, typename T, bool IS_POW>
+__global__ __launch_bounds__(256) void ew_intarg_kernel(FieldDev fd, const T *__restrict__ a, int sa,
+                                                        const i64 *__restrict__ e, int se, T *__restrict__ out, i64 n,
+                                                        int32_t *err)
+{
+    typedef typename F::elem E;
+    bool bad = false;
+    const i64 tid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 nth = (i64)gridDim.x * blockDim.x;
+    for (i64 i = tid; i < n; i += nth) {
+        E x = (E)a[sa ? i : 0];
+        i64 k = e[se ? i : 0];
+        E r;
+        if constexpr (IS_POW) {
+            if (!pow_signed<F>(fd, x, k, &r)) bad = true;
+        } else {
+            r = F::mul(fd, x, (E)F::from_int(fd, k));
+        }
+        out[i] = (T)r;
+    }
+    if constexpr (IS_POW) flag_error(err, bad);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Order <= 256, uint8: full-table kernels
+// ------------------------------------------------------------------------------------------------
+constexpr int TAB8_THREADS = 1024;
+
+__device__ __forceinline__ u32 lookup4(const uint8_t *lds, u32 aw, u32 bw)
+{
+    // index = (a_k << 8) | b_k assembled with one v_perm_b32 per element
+    u32 i0 = __builtin_amdgcn_perm(aw, bw, 0x0c0c0400u);
+    u32 i1 = __builtin_amdgcn_perm(aw, bw, 0x0c0c0501u);
+    u32 i2 = __builtin_amdgcn_perm(aw, bw, 0x0c0c0602u);
+    u32 i3 = __builtin_amdgcn_perm(aw, bw, 0x0c0c0703u);
+    u32 r0 = lds[i0], r1 = lds[i1], r2 = lds[i2], r3 = lds[i3];
+    return r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
+}
+
+// out = TABLE[a][b].  `zero_b_is_error`: division flags b == 0.
+template <int UNROLL, bool CHECK_ZERO_B>
+__global__ __launch_bounds__(TAB8_THREADS) void tab8_binary_kernel(const uint8_t *__restrict__ table,
+                                                                    const uint8_t *__restrict__ a,
+                                                                    const uint8_t *__restrict__ b,
+                                                                    uint8_t *__restrict__ out, i64 n, int32_t *err)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(table);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds);
+        for (int i = threadIdx.x; i < 65536 / 16; i += TAB8_THREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    bool bad = false;
+    const i64 nvec = n >> 4;
+    const u32x4 *av = reinterpret_cast<const u32x4 *>(a);
+    const u32x4 *bv = reinterpret_cast<const u32x4 *>(b);
+    u32x4 *ov = reinterpret_cast<u32x4 *>(out);
+    const i64 stride = (i64)gridDim.x * TAB8_THREADS;
+    i64 i = (i64)blockIdx.x * TAB8_THREADS + threadIdx.x;
+    // main loop: UNROLL independent 16-byte loads per operand in flight per lane
+    for (; i + (UNROLL - 1) * stride < nvec; i += UNROLL * stride) {
+        u32x4 x[UNROLL], y[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            x[u] = __builtin_nontemporal_load(av + i + u * stride);
+            y[u] = __builtin_nontemporal_load(bv + i + u * stride);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            u32x4 r;
+            r.x = lookup4(lds, x[u].x, y[u].x);
+            r.y = lookup4(lds, x[u].y, y[u].y);
+            r.z = lookup4(lds, x[u].z, y[u].z);
+            r.w = lookup4(lds, x[u].w, y[u].w);
+            if constexpr (CHECK_ZERO_B) {
+                // a byte of y is zero  <=>  (v - 0x01010101) & ~v & 0x80808080 != 0
+                u32 z = ((y[u].x - 0x01010101u) & ~y[u].x) | ((y[u].y - 0x01010101u) & ~y[u].y) |
+                        ((y[u].z - 0x01010101u) & ~y[u].z) | ((y[u].w - 0x01010101u) & ~y[u].w);
+                bad |= (z & 0x80808080u) != 0;
+            }
+            __builtin_nontemporal_store(r, ov + i + u * stride);
+        }
+    }
+    for (; i < nvec; i += stride) {
+        u32x4 x = av[i], y = bv[i], r;
+        r.x = lookup4(lds, x.x, y.x);
+        r.y = lookup4(lds, x.y, y.y);
+        r.z = lookup4(lds, x.z, y.z);
+        r.w = lookup4(lds, x.w, y.w);
+        if constexpr (CHECK_ZERO_B) {
+            u32 z = ((y.x - 0x01010101u) & ~y.x) | ((y.y - 0x01010101u) & ~y.y) | ((y.z - 0x01010101u) & ~y.z) |
+                    ((y.w - 0x01010101u) & ~y.w);
+            bad |= (z & 0x80808080u) != 0;
+        }
+        ov[i] = r;
+    }
+    // tail (< 16 elements)
+    for (i64 j = (nvec << 4) + (i64)blockIdx.x * TAB8_THREADS + threadIdx.x; j < n; j += stride) {
+        uint8_t y = b[j];
+        if (CHECK_ZERO_B && y == 0) bad = true;
+        out[j] = lds[((u32)a[j] << 8) | y];
+    }
+    if constexpr (CHECK_ZERO_B) flag_error(err, bad);
+}
+
+// Unary / scalar-operand form: out = TABLE256[a].  The 256-entry table is replicated 32x in LDS as dwords,
+// entry v of copy c at dword v*32 + c, and lane l reads copy l%32 => every lane of a 32-lane LDS group hits its
+// own bank, no conflicts for any data.
+template <int UNROLL, bool CHECK_ZERO>
+__global__ __launch_bounds__(TAB8_THREADS) void tab8_unary_kernel(const uint8_t *__restrict__ table256,
+                                                                   const uint8_t *__restrict__ a,
+                                                                   uint8_t *__restrict__ out, i64 n, int32_t *err)
+{
+    __shared__ u32 rep[256 * 32];
+    for (int i = threadIdx.x; i < 256 * 32; i += TAB8_THREADS) rep[i] = table256[i >> 5];
+    __syncthreads();
+    const u32 *my = rep + (threadIdx.x & 31);
+    bool bad = false;
+    const i64 nvec = n >> 4;
+    const u32x4 *av = reinterpret_cast<const u32x4 *>(a);
+    u32x4 *ov = reinterpret_cast<u32x4 *>(out);
+    const i64 stride = (i64)gridDim.x * TAB8_THREADS;
+    auto map4 = [&](u32 w) -> u32 {
+        u32 r0 = my[(w & 0xff) << 5], r1 = my[((w >> 8) & 0xff) << 5], r2 = my[((w >> 16) & 0xff) << 5],
+            r3 = my[(w >> 24) << 5];
+        return r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
+    };
+    auto haszero = [](u32 v) -> u32 { return (v - 0x01010101u) & ~v & 0x80808080u; };
+    i64 i = (i64)blockIdx.x * TAB8_THREADS + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < nvec; i += UNROLL * stride) {
+        u32x4 x[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) x[u] = __builtin_nontemporal_load(av + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) {
+            u32x4 r;
+            r.x = map4(x[u].x); r.y = map4(x[u].y); r.z = map4(x[u].z); r.w = map4(x[u].w);
+            if constexpr (CHECK_ZERO) bad |= (haszero(x[u].x) | haszero(x[u].y) | haszero(x[u].z) | haszero(x[u].w)) != 0;
+            __builtin_nontemporal_store(r, ov + i + u * stride);
+        }
+    }
+    for (; i < nvec; i += stride) {
+        u32x4 x = av[i], r;
+        r.x = map4(x.x); r.y = map4(x.y); r.z = map4(x.z); r.w = map4(x.w);
+        if constexpr (CHECK_ZERO) bad |= (haszero(x.x) | haszero(x.y) | haszero(x.z) | haszero(x.w)) != 0;
+        ov[i] = r;
+    }
+    for (i64 j = (nvec << 4) + (i64)blockIdx.x * TAB8_THREADS + threadIdx.x; j < n; j += stride) {
+        uint8_t x = a[j];
+        if (CHECK_ZERO && x == 0) bad = true;
+        out[j] = (uint8_t)my[(u32)x << 5];
+    }
+    if constexpr (CHECK_ZERO) flag_error(err, bad);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+int num_cus()
+{
+    static int cached[64] = {0};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return 256;
+    if (!cached[d]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess) return 256;
+        cached[d] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cached[d];
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+inline int grid_for(i64 work_items, int threads, int blocks_per_cu)
+{
+    i64 blocks = (work_items + threads - 1) / threads;
+    i64 cap = (i64)num_cus() * blocks_per_cu;
+    if (blocks < 1) blocks = 1;
+    return (int)(blocks < cap ? blocks : cap);
+}
+
+template <class F, typename T>
+int launch_binary_ft(const FieldDev &fd, int op, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n,
+                     hipStream_t st, int32_t *err)
+{
+    const T *pa = (const T *)a, *pb = (const T *)b;
+    T *po = (T *)out;
+    const bool vec = aligned16(out) && (sa == 0 || aligned16(a)) && (sb == 0 || aligned16(b));
+    constexpr int V = Vec16<T>::N;
+    const int grid = grid_for(vec ? (n + V - 1) / V : n, 256, 8);
+#define GFA_LAUNCH_B(OPC)                                                                                              \
+    if (vec) hipLaunchKernelGGL((ew_binary_kernel<F, T, OPC, true>), dim3(grid), dim3(256), 0, st, fd, pa, (int)sa, pb, \
+                                (int)sb, po, n, err);                                                                  \
+    else hipLaunchKernelGGL((ew_binary_kernel<F, T, OPC, false>), dim3(grid), dim3(256), 0, st, fd, pa, (int)sa, pb,    \
+                            (int)sb, po, n, err);
+    switch (op) {
+    case GFA_OP_ADD: GFA_LAUNCH_B(GFA_OP_ADD) break;
+    case GFA_OP_SUB: GFA_LAUNCH_B(GFA_OP_SUB) break;
+    case GFA_OP_MUL: GFA_LAUNCH_B(GFA_OP_MUL) break;
+    case GFA_OP_DIV: GFA_LAUNCH_B(GFA_OP_DIV) break;
+    default: set_error("gfa_binary: bad op"); return GFA_ERR_INVALID;
+    }
+#undef GFA_LAUNCH_B
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+template <class F, typename T>
+int launch_unary_ft(const FieldDev &fd, int op, const void *a, void *out, i64 n, hipStream_t st, int32_t *err)
+{
+    const T *pa = (const T *)a;
+    T *po = (T *)out;
+    const bool vec = aligned16(out) && aligned16(a);
+    constexpr int V = Vec16<T>::N;
+    const int grid = grid_for(vec ? (n + V - 1) / V : n, 256, 8);
+#define GFA_LAUNCH_U(OPC)                                                                                             \
+    if (vec) hipLaunchKernelGGL((ew_unary_kernel<F, T, OPC, true>), dim3(grid), dim3(256), 0, st, fd, pa, po, n, err); \
+    else hipLaunchKernelGGL((ew_unary_kernel<F, T, OPC, false>), dim3(grid), dim3(256), 0, st, fd, pa, po, n, err);
+    switch (op) {
+    case GFA_OP_NEG: GFA_LAUNCH_U(GFA_OP_NEG) break;
+    case GFA_OP_RECIP: GFA_LAUNCH_U(GFA_OP_RECIP) break;
+    default: set_error("gfa_unary: bad op"); return GFA_ERR_INVALID;
+    }
+#undef GFA_LAUNCH_U
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+template <class F, typename T>
+int launch_intarg_ft(const FieldDev &fd, bool is_pow, const void *a, i64 sa, const i64 *e, i64 se, void *out, i64 n,
+                     hipStream_t st, int32_t *err)
+{
+    const int grid = grid_for(n, 256, 8);
+    if (is_pow)
+        hipLaunchKernelGGL((ew_intarg_kernel<F, T, true>), dim3(grid), dim3(256), 0, st, fd, (const T *)a, (int)sa, e,
+                           (int)se, (T *)out, n, err);
+    else
+        hipLaunchKernelGGL((ew_intarg_kernel<F, T, false>), dim3(grid), dim3(256), 0, st, fd, (const T *)a, (int)sa, e,
+                           (int)se, (T *)out, n, err);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+// dispatch on (arithmetic kind, storage dtype)
+#define GFA_DISPATCH_FT(FUNC, fd, dtype, ...)                                                              \
+    do {                                                                                                   \
+        switch ((fd).kind) {                                                                               \
+        case KIND_PRIME32:                                                                                 \
+            switch (dtype) {                                                                               \
+            case GFA_U8: return FUNC<Prime32, uint8_t>(__VA_ARGS__);                                       \
+            case GFA_U16: return FUNC<Prime32, uint16_t>(__VA_ARGS__);                                     \
+            case GFA_U32: return FUNC<Prime32, uint32_t>(__VA_ARGS__);                                     \
+            case GFA_U64: return FUNC<Prime32, uint64_t>(__VA_ARGS__);                                     \
+            }                                                                                              \
+            break;                                                                                         \
+        case KIND_LUT:                                                                                     \
+            switch (dtype) {                                                                               \
+            case GFA_U8: return FUNC<Lut, uint8_t>(__VA_ARGS__);                                           \
+            case GFA_U16: return FUNC<Lut, uint16_t>(__VA_ARGS__);                                         \
+            case GFA_U32: return FUNC<Lut, uint32_t>(__VA_ARGS__);                                         \
+            case GFA_U64: return FUNC<Lut, uint64_t>(__VA_ARGS__);                                         \
+            }                                                                                              \
+            break;                                                                                         \
+        case KIND_BIN:                                                                                     \
+            switch (dtype) {                                                                               \
+            case GFA_U8: return FUNC<Bin, uint8_t>(__VA_ARGS__);                                           \
+            case GFA_U16: return FUNC<Bin, uint16_t>(__VA_ARGS__);                                         \
+            case GFA_U32: return FUNC<Bin, uint32_t>(__VA_ARGS__);                                         \
+            case GFA_U64: return FUNC<Bin, uint64_t>(__VA_ARGS__);                                         \
+            }                                                                                              \
+            break;                                                                                         \
+        case KIND_EXT:                                                                                     \
+            switch (dtype) {                                                                               \
+            case GFA_U8: return FUNC<Ext, uint8_t>(__VA_ARGS__);                                           \
+            case GFA_U16: return FUNC<Ext, uint16_t>(__VA_ARGS__);                                         \
+            case GFA_U32: return FUNC<Ext, uint32_t>(__VA_ARGS__);                                         \
+            case GFA_U64: return FUNC<Ext, uint64_t>(__VA_ARGS__);                                         \
+            }                                                                                              \
+            break;                                                                                         \
+        case KIND_PRIME64:                                                                                 \
+            if (dtype == GFA_U64) return FUNC<Prime64, uint64_t>(__VA_ARGS__);                             \
+            break;                                                                                         \
+        case KIND_GOLDILOCKS:                                                                              \
+            if (dtype == GFA_U64) return FUNC<Goldilocks, uint64_t>(__VA_ARGS__);                          \
+            break;                                                                                         \
+        }                                                                                                  \
+        set_error("unsupported (field kind, dtype) combination");                                          \
+        return GFA_ERR_UNSUPPORTED;                                                                        \
+    } while (0)
+
+int dispatch_binary(const FieldDev &fd, int dtype, int op, const void *a, i64 sa, const void *b, i64 sb, void *out,
+                    i64 n, hipStream_t st, int32_t *err)
+{
+    GFA_DISPATCH_FT(launch_binary_ft, fd, dtype, fd, op, a, sa, b, sb, out, n, st, err);
+}
+int dispatch_unary(const FieldDev &fd, int dtype, int op, const void *a, void *out, i64 n, hipStream_t st,
+                   int32_t *err)
+{
+    GFA_DISPATCH_FT(launch_unary_ft, fd, dtype, fd, op, a, out, n, st, err);
+}
+int dispatch_intarg(const FieldDev &fd, int dtype, bool is_pow, const void *a, i64 sa, const i64 *e, i64 se,
+                    void *out, i64 n, hipStream_t st, int32_t *err)
+{
+    GFA_DISPATCH_FT(launch_intarg_ft, fd, dtype, fd, is_pow, a, sa, e, se, out, n, st, err);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// ufunc.reduce over the last axis (add / multiply are commutative monoids -> tree reduction; subtract / divide are
+// the reference's left folds a0 - a1 - ... = a0 - sum(rest), a0 / a1 / ... = a0 / prod(rest))
+// ------------------------------------------------------------------------------------------------
+template <class F, typename T, bool IS_MUL>
+__global__ __launch_bounds__(256) void reduce_segments_kernel(FieldDev fd, const T *__restrict__ in, i64 n_inner,
+                                                              i64 col_begin, i64 seg_len, i64 nseg,
+                                                              u64 *__restrict__ partial)
+{
+    typedef typename F::elem E;
+    __shared__ u64 sh[256];
+    const i64 row = blockIdx.x / nseg, seg = blockIdx.x % nseg;
+    const i64 lo = col_begin + seg * seg_len;
+    i64 hi = lo + seg_len;
+    if (hi > n_inner) hi = n_inner;
+    const T *x = in + row * n_inner;
+    E acc = IS_MUL ? F::one(fd) : (E)0;
+    for (i64 i = lo + threadIdx.x; i < hi; i += 256) {
+        E v = (E)x[i];
+        acc = IS_MUL ? F::mul(fd, acc, v) : F::add(fd, acc, v);
+    }
+    sh[threadIdx.x] = (u64)acc;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            E a = (E)sh[threadIdx.x], b = (E)sh[threadIdx.x + off];
+            sh[threadIdx.x] = (u64)(IS_MUL ? F::mul(fd, a, b) : F::add(fd, a, b));
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+// mode 0: out = reduce(partials); 1: out = a0 - sum(partials); 2: out = a0 / prod(partials)
+template <class F, typename T, bool IS_MUL>
+__global__ void reduce_finalize_kernel(FieldDev fd, const T *__restrict__ in, i64 n_inner, const u64 *__restrict__ partial,
+                                       i64 nseg, T *__restrict__ out, i64 n_outer, int mode, int32_t *err)
+{
+    typedef typename F::elem E;
+    const i64 row = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (row < n_outer) {
+        E acc = IS_MUL ? F::one(fd) : (E)0;
+        for (i64 s = 0; s < nseg; s++) {
+            E v = (E)partial[row * nseg + s];
+            acc = IS_MUL ? F::mul(fd, acc, v) : F::add(fd, acc, v);
+        }
+        if (mode == 1) acc = F::sub(fd, (E)in[row * n_inner], acc);
+        if (mode == 2) {
+            E a0 = (E)in[row * n_inner];
+            if (acc == 0) { bad = true; acc = 0; }
+            else if (a0 == 0) acc = 0;
+            else {
+                if constexpr (std::is_same<F, Lut>::value) acc = Lut::div_nz(fd, a0, acc);
+                else acc = F::mul(fd, a0, F::inv(fd, acc));
+            }
+        }
+        out[row] = (T)acc;
+    }
+    flag_error(err, bad);
+}
+
+struct ReduceScratch {
+    u64 *p = nullptr;
+    size_t n = 0;
+};
+ReduceScratch g_reduce_scratch[64];
+
+template <class F, typename T>
+int launch_reduce_ft(const FieldDev &fd, int op, const void *a, void *out, i64 n_outer, i64 n_inner, hipStream_t st,
+                     int32_t *err)
+{
+    const bool is_mul = op == GFA_OP_MUL || op == GFA_OP_DIV;
+    const int mode = op == GFA_OP_SUB ? 1 : op == GFA_OP_DIV ? 2 : 0;
+    const i64 col_begin = mode ? 1 : 0;
+    const i64 len = n_inner - col_begin;
+    // enough segments to fill the chip when there are few rows, at least 4096 elements each
+    i64 nseg = 1;
+    const i64 want_blocks = (i64)num_cus() * 8;
+    if (n_outer < want_blocks && len > 8192) {
+        nseg = std::min<i64>((want_blocks + n_outer - 1) / n_outer, (len + 4095) / 4096);
+        if (nseg > 4096) nseg = 4096;
+    }
+    if (nseg < 1) nseg = 1;
+    const i64 seg_len = len > 0 ? (len + nseg - 1) / nseg : 1;
+    int d = 0;
+    GFA_HIP(hipGetDevice(&d));
+    ReduceScratch &rs = g_reduce_scratch[d & 63];
+    const size_t need = (size_t)(n_outer * nseg);
+    if (rs.n < need) {
+        if (rs.p) (void)hipFree(rs.p);
+        rs.p = nullptr; rs.n = 0;
+        GFA_HIP(hipMalloc((void **)&rs.p, need * sizeof(u64)));
+        rs.n = need;
+    }
+    const unsigned grid = (unsigned)(n_outer * nseg);
+    if (is_mul) {
+        hipLaunchKernelGGL((reduce_segments_kernel<F, T, true>), dim3(grid), dim3(256), 0, st, fd, (const T *)a, n_inner,
+                           col_begin, seg_len, nseg, rs.p);
+        hipLaunchKernelGGL((reduce_finalize_kernel<F, T, true>), dim3((unsigned)((n_outer + 255) / 256)), dim3(256), 0, st,
+                           fd, (const T *)a, n_inner, rs.p, nseg, (T *)out, n_outer, mode, err);
+    } else {
+        hipLaunchKernelGGL((reduce_segments_kernel<F, T, false>), dim3(grid), dim3(256), 0, st, fd, (const T *)a, n_inner,
+                           col_begin, seg_len, nseg, rs.p);
+        hipLaunchKernelGGL((reduce_finalize_kernel<F, T, false>), dim3((unsigned)((n_outer + 255) / 256)), dim3(256), 0, st,
+                           fd, (const T *)a, n_inner, rs.p, nseg, (T *)out, n_outer, mode, err);
+    }
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+int dispatch_reduce(const FieldDev &fd, int dtype, int op, const void *a, void *out, i64 n_outer, i64 n_inner,
+                    hipStream_t st, int32_t *err)
+{
+    GFA_DISPATCH_FT(launch_reduce_ft, fd, dtype, fd, op, a, out, n_outer, n_inner, st, err);
+}
+
+bool dtype_holds(int dtype, u64 q)
+{
+    switch (dtype) {
+    case GFA_U8: return q - 1 <= 0xffull;
+    case GFA_U16: return q - 1 <= 0xffffull;
+    case GFA_U32: return q - 1 <= 0xffffffffull;
+    case GFA_U64: return true;
+    default: return false;
+    }
+}
+
+constexpr int TAB8_UNROLL = 2;
+
+int tab8_grid(i64 n)
+{
+    i64 blocks = ((n >> 4) + TAB8_THREADS - 1) / TAB8_THREADS;
+    i64 cap = (i64)num_cus() * 2; // 64 KiB of LDS per workgroup -> two resident workgroups per CU
+    if (blocks < 1) blocks = 1;
+    return (int)(blocks < cap ? blocks : cap);
+}
+
+int launch_tab8_binary(const uint8_t *table, bool check_zero_b, const void *a, const void *b, void *out, i64 n,
+                       hipStream_t st, int32_t *err)
+{
+    static bool attr_set[2] = {false, false};
+    auto k0 = tab8_binary_kernel<TAB8_UNROLL, false>;
+    auto k1 = tab8_binary_kernel<TAB8_UNROLL, true>;
+    if (!attr_set[check_zero_b]) {
+        GFA_HIP(hipFuncSetAttribute(check_zero_b ? (const void *)k1 : (const void *)k0,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        attr_set[check_zero_b] = true;
+    }
+    const int grid = tab8_grid(n);
+    if (check_zero_b)
+        hipLaunchKernelGGL(k1, dim3(grid), dim3(TAB8_THREADS), 65536, st, table, (const uint8_t *)a, (const uint8_t *)b,
+                           (uint8_t *)out, n, err);
+    else
+        hipLaunchKernelGGL(k0, dim3(grid), dim3(TAB8_THREADS), 65536, st, table, (const uint8_t *)a, (const uint8_t *)b,
+                           (uint8_t *)out, n, err);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+int launch_tab8_unary(const uint8_t *table256, bool check_zero, const void *a, void *out, i64 n, hipStream_t st,
+                      int32_t *err)
+{
+    i64 blocks = ((n >> 4) + TAB8_THREADS - 1) / TAB8_THREADS;
+    i64 cap = (i64)num_cus() * 2;
+    if (blocks < 1) blocks = 1;
+    const int grid = (int)(blocks < cap ? blocks : cap);
+    if (check_zero)
+        hipLaunchKernelGGL((tab8_unary_kernel<TAB8_UNROLL, true>), dim3(grid), dim3(TAB8_THREADS), 0, st, table256,
+                           (const uint8_t *)a, (uint8_t *)out, n, err);
+    else
+        hipLaunchKernelGGL((tab8_unary_kernel<TAB8_UNROLL, false>), dim3(grid), dim3(TAB8_THREADS), 0, st, table256,
+                           (const uint8_t *)a, (uint8_t *)out, n, err);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b, int64_t sb, void *out, int64_t n,
+               int dtype, gfa_stream_t stream, int32_t *dev_err)
+{
+    if (!f || !a || !b || !out || n < 0 || (sa != 0 && sa != 1) || (sb != 0 && sb != 1)) {
+        set_error("gfa_binary: bad arguments");
+        return GFA_ERR_INVALID;
+    }
+    if (op < GFA_OP_ADD || op > GFA_OP_DIV) { set_error("gfa_binary: bad op"); return GFA_ERR_INVALID; }
+    if (!dtype_holds(dtype, f->calc.q)) { set_error("dtype cannot hold the field's elements"); return GFA_ERR_INVALID; }
+    if (n == 0) return GFA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    FieldDeviceState *ds;
+    int rc = f->ensure_device(nullptr, &ds);
+    if (rc) return rc;
+    if (f->use_lookup()) {
+        const FieldDev &c = f->calc;
+        const bool trivial_addsub = (op == GFA_OP_ADD || op == GFA_OP_SUB) && (c.p == 2 || c.m == 1);
+        if (f->has_tab8 && dtype == GFA_U8 && sa == 1 && sb == 1 && !trivial_addsub && aligned16(a) && aligned16(b) &&
+            aligned16(out)) {
+            const uint8_t *tab = op == GFA_OP_MUL ? ds->mul8 : op == GFA_OP_DIV ? ds->div8 : op == GFA_OP_ADD ? ds->add8 : ds->sub8;
+            return launch_tab8_binary(tab, op == GFA_OP_DIV, a, b, out, n, st, dev_err);
+        }
+        return dispatch_binary(f->lut_desc(*ds), dtype, op, a, sa, b, sb, out, n, st, dev_err);
+    }
+    return dispatch_binary(f->calc, dtype, op, a, sa, b, sb, out, n, st, dev_err);
+}
+
+int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int dtype, gfa_stream_t stream,
+              int32_t *dev_err)
+{
+    if (!f || !a || !out || n < 0) { set_error("gfa_unary: bad arguments"); return GFA_ERR_INVALID; }
+    if (op != GFA_OP_NEG && op != GFA_OP_RECIP) { set_error("gfa_unary: bad op"); return GFA_ERR_INVALID; }
+    if (!dtype_holds(dtype, f->calc.q)) { set_error("dtype cannot hold the field's elements"); return GFA_ERR_INVALID; }
+    if (n == 0) return GFA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    FieldDeviceState *ds;
+    int rc = f->ensure_device(nullptr, &ds);
+    if (rc) return rc;
+    if (f->use_lookup()) {
+        const FieldDev &c = f->calc;
+        const bool trivial_neg = op == GFA_OP_NEG && (c.p == 2 || c.m == 1);
+        if (f->has_tab8 && dtype == GFA_U8 && !trivial_neg && aligned16(a) && aligned16(out))
+            return launch_tab8_unary(op == GFA_OP_RECIP ? ds->inv8 : ds->neg8, op == GFA_OP_RECIP, a, out, n, st, dev_err);
+        return dispatch_unary(f->lut_desc(*ds), dtype, op, a, out, n, st, dev_err);
+    }
+    return dispatch_unary(f->calc, dtype, op, a, out, n, st, dev_err);
+}
+
+int gfa_power(gfa_field_t *f, const void *a, int64_t sa, const int64_t *exps, int64_t se, void *out, int64_t n, int dtype,
+              gfa_stream_t stream, int32_t *dev_err)
+{
+    if (!f || !a || !exps || !out || n < 0 || (sa != 0 && sa != 1) || (se != 0 && se != 1)) {
+        set_error("gfa_power: bad arguments");
+        return GFA_ERR_INVALID;
+    }
+    if (!dtype_holds(dtype, f->calc.q)) { set_error("dtype cannot hold the field's elements"); return GFA_ERR_INVALID; }
+    if (n == 0) return GFA_OK;
+    FieldDeviceState *ds;
+    int rc = f->ensure_device(nullptr, &ds);
+    if (rc) return rc;
+    if (f->use_lookup())
+        return dispatch_intarg(f->lut_desc(*ds), dtype, true, a, sa, exps, se, out, n, (hipStream_t)stream, dev_err);
+    return dispatch_intarg(f->calc, dtype, true, a, sa, exps, se, out, n, (hipStream_t)stream, dev_err);
+}
+
+int gfa_scalar_multiply(gfa_field_t *f, const void *a, int64_t sa, const int64_t *ks, int64_t sk, void *out, int64_t n,
+                        int dtype, gfa_stream_t stream)
+{
+    if (!f || !a || !ks || !out || n < 0 || (sa != 0 && sa != 1) || (sk != 0 && sk != 1)) {
+        set_error("gfa_scalar_multiply: bad arguments");
+        return GFA_ERR_INVALID;
+    }
+    if (!dtype_holds(dtype, f->calc.q)) { set_error("dtype cannot hold the field's elements"); return GFA_ERR_INVALID; }
+    if (n == 0) return GFA_OK;
+    FieldDeviceState *ds;
+    int rc = f->ensure_device(nullptr, &ds);
+    if (rc) return rc;
+    if (f->use_lookup())
+        return dispatch_intarg(f->lut_desc(*ds), dtype, false, a, sa, ks, sk, out, n, (hipStream_t)stream, nullptr);
+    return dispatch_intarg(f->calc, dtype, false, a, sa, ks, sk, out, n, (hipStream_t)stream, nullptr);
+}
+
+int gfa_reduce(gfa_field_t *f, int op, const void *a, void *out, int64_t n_outer, int64_t n_inner, int dtype,
+               gfa_stream_t stream, int32_t *dev_err)
+{
+    if (!f || !a || !out || n_outer < 0 || n_inner < 1 || op < GFA_OP_ADD || op > GFA_OP_DIV) {
+        set_error("gfa_reduce: bad arguments");
+        return GFA_ERR_INVALID;
+    }
+    if (!dtype_holds(dtype, f->calc.q)) { set_error("dtype cannot hold the field's elements"); return GFA_ERR_INVALID; }
+    if (n_outer == 0) return GFA_OK;
+    FieldDeviceState *ds;
+    int rc = f->ensure_device(nullptr, &ds);
+    if (rc) return rc;
+    if (f->use_lookup()) return dispatch_reduce(f->lut_desc(*ds), dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
+    return dispatch_reduce(f->calc, dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
+}
+
+int gfa_time_binary(gfa_field_t *f, int op, const void *a, const void *b, void *out, int64_t n, int dtype,
+                    gfa_stream_t stream, int iters, float *ms_out)
+{
+    return gfa::time_loop((hipStream_t)stream, iters, ms_out,
+                     [&]() { return gfa_binary(f, op, a, 1, b, 1, out, n, dtype, stream, nullptr); });
+}
+
+int gfa_time_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int dtype, gfa_stream_t stream, int iters,
+                   float *ms_out)
+{
+    return gfa::time_loop((hipStream_t)stream, iters, ms_out,
+                     [&]() { return gfa_unary(f, op, a, out, n, dtype, stream, nullptr); });
+}
+
+} // extern "C"

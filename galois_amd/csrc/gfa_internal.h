@@ -1,0 +1,87 @@
+// gfa_internal.h -- host-side objects behind the opaque C-ABI handles.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <functional>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/galois_amd.h"
+#include "gfa_arith.h"
+
+struct gfa_field;
+
+namespace gfa {
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what);
+// average milliseconds per call of `launch` over `iters` calls, HIP events recorded on `st` itself
+int time_loop(hipStream_t st, int iters, float *ms_out, const std::function<int()> &launch);
+
+#define GFA_HIP(call)                                        \
+    do {                                                     \
+        hipError_t _e = (call);                              \
+        if (_e != hipSuccess) return gfa::hip_fail(_e, #call); \
+    } while (0)
+
+void ntt_forget_field(const struct ::gfa_field *f); // drops cached NTT plans of a field being destroyed
+
+// Host scalar arithmetic on a field, dispatched on FieldDev::kind with the same formulas the kernels use.
+struct HostArith {
+    static u64 add(const FieldDev &f, u64 a, u64 b);
+    static u64 sub(const FieldDev &f, u64 a, u64 b);
+    static u64 neg(const FieldDev &f, u64 a);
+    static u64 mul(const FieldDev &f, u64 a, u64 b);
+    static bool inv(const FieldDev &f, u64 a, u64 *out);
+    static bool pow(const FieldDev &f, u64 a, i64 e, u64 *out);
+};
+
+// Per-device copies of a field's tables.
+struct FieldDeviceState {
+    bool ready = false;
+    u32 *exp_tab = nullptr, *log_tab = nullptr, *zech_tab = nullptr; // LUT kind (q <= 2^20)
+    // q <= 256: full binary-operation tables, row stride 256, index (a << 8) | b
+    uint8_t *mul8 = nullptr, *add8 = nullptr, *sub8 = nullptr, *div8 = nullptr;
+    uint8_t *inv8 = nullptr, *neg8 = nullptr; // 256-entry unary tables (inv8[0] = 0)
+    uint8_t *exp8 = nullptr, *log8 = nullptr; // byte EXP (512) / LOG (256) for the RS kernels
+};
+
+} // namespace gfa
+
+struct gfa_field {
+    gfa::FieldDev calc;   // descriptor for explicit calculation (kind = PRIME32/PRIME64/GOLDILOCKS/BIN/EXT)
+    bool has_lut = false; // q <= 2^20: host tables exist
+    bool has_tab8 = false; // q <= 256
+    int mode = GFA_MODE_AUTO;
+    uint64_t alpha = 0;
+    std::vector<uint64_t> irr_coeffs; // m+1, highest degree first
+    // host tables in the device layout
+    std::vector<uint32_t> h_exp, h_log, h_zech;
+    uint32_t zech_e = 0;
+    std::vector<uint8_t> h_mul8, h_add8, h_sub8, h_div8, h_inv8, h_neg8, h_exp8, h_log8;
+    std::mutex mu;
+    std::vector<gfa::FieldDeviceState> dev; // indexed by HIP device ordinal
+
+    // true if the lookup path is the one to launch for this field in its current mode
+    bool use_lookup() const;
+    int ensure_device(int *device_out, gfa::FieldDeviceState **st_out); // lazy upload to the current device
+    gfa::FieldDev lut_desc(const gfa::FieldDeviceState &st) const;      // descriptor with kind = KIND_LUT
+};
+
+struct gfa_rs {
+    gfa_field *field = nullptr;
+    int64_t n = 0, k = 0, c = 1;
+    uint64_t alpha = 0;
+    bool systematic = true;
+    std::vector<uint64_t> roots, gpoly, P; // P: k x (n-k) row-major
+    struct Dev {
+        bool ready = false;
+        uint8_t *P8 = nullptr;     // k x (n-k)
+        uint8_t *roots8 = nullptr; // n-k
+        uint8_t *lfsr = nullptr;   // 256 x (n-k): f * g_j rows for the LFSR (systematic) encoder, binary fields
+    };
+    std::mutex mu;
+    std::vector<Dev> dev;
+    int ensure_device(int *device_out, Dev **out);
+};

@@ -1,0 +1,656 @@
+// gfa_ntt.hip -- number-theoretic / finite-field Fourier transforms for gfx950.
+//
+// Replaces fft_jit / ifft_jit (reference: src/galois/_domains/_function.py:177-392): X[k] = sum_j x[j] w^(jk),
+// natural order in and out, any n | q-1 over any field.  Field arithmetic is exact, so any correct DFT algorithm
+// reproduces the reference's bits; the device does NOT follow the reference's stage order:
+//
+//   * power-of-two n over GF(p) (p < 2^32 as uint32, Goldilocks / 64-bit primes as uint64):
+//       n <= TILE_MAX : one kernel; each 256-thread workgroup keeps a tile of whole transforms in LDS, radix-2
+//                       decimation-in-time with the bit reversal folded into the LDS staging, twiddles (plus their
+//                       Shoup quotients for p < 2^31) in LDS.
+//       n  > TILE_MAX : four-step (Bailey) = two such passes.  n = n1*n2; pass 1 transforms the n2 columns (length
+//                       n1, stride n2) in tiles of adjacent columns so that every global access is a contiguous
+//                       segment, and multiplies by w^(j2*k1) from a two-level power table; pass 2 transforms the n1
+//                       rows (contiguous) in tiles of adjacent rows and stores transposed, giving natural order.
+//                       => 2 reads + 2 writes of the array in total (the intermediate is normally L2/MALL resident).
+//   * anything else (mixed radix, extension fields): one global-memory Stockham stage per prime factor, same index
+//     maps as the reference's stages (_function.py:315-384), twiddles from a w^t table.
+#include <algorithm>
+#include <map>
+#include <tuple>
+
+#include "gfa_internal.h"
+
+using namespace gfa;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// twiddle multiplication
+// ------------------------------------------------------------------------------------------------
+template <class F>
+struct Tw { // generic: plain field multiply
+    typedef typename F::elem E;
+    static constexpr bool HAS_SHOUP = false;
+    struct W { E w; };
+    static __device__ __forceinline__ W load(const E *tab, const E *, u32 i) { return W{tab[i]}; }
+    static __device__ __forceinline__ E mul(const FieldDev &fd, E x, W t) { return F::mul(fd, x, t.w); }
+};
+
+// GF(p), p < 2^31: Shoup multiplication by a constant w with wq = floor(w * 2^32 / p):
+//   q = hi32(wq * x);  r = w*x - q*p  in [0, 2p)  (all in 32-bit wrap-around arithmetic)
+struct TwShoup32 {
+    typedef u32 E;
+    static constexpr bool HAS_SHOUP = true;
+    struct W { u32 w, wq; };
+    static __device__ __forceinline__ W load(const u32 *tab, const u32 *tabq, u32 i) { return W{tab[i], tabq[i]}; }
+    static __device__ __forceinline__ u32 mul(const FieldDev &fd, u32 x, W t)
+    {
+        u32 q = __umulhi(t.wq, x);
+        u32 r = t.w * x - q * (u32)fd.p;
+        u32 p = (u32)fd.p;
+        return r >= p ? r - p : r;
+    }
+};
+
+__device__ __forceinline__ u32 bitrev(u32 x, int bits) { return __brev(x) >> (32 - bits); }
+
+// ------------------------------------------------------------------------------------------------
+// table builders
+// ------------------------------------------------------------------------------------------------
+template <class F>
+__global__ void pow_table_kernel(FieldDev fd, typename F::elem base, u64 exp_stride, typename F::elem *out, i64 count)
+{
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = F::pow_u(fd, base, (u64)i * exp_stride);
+}
+
+__global__ void shoup_table_kernel(u32 p, const u32 *w, u32 *wq, i64 count)
+{
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) wq[i] = (u32)((((u64)w[i]) << 32) / p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS tile transform
+// ------------------------------------------------------------------------------------------------
+// One workgroup transforms `lines` lines of length L = 2^logL held in LDS as lds[line*L + pos].
+// Global addressing of element (line c, position t): base + c*stride_c + t*stride_t   (in and out separately).
+// LOAD_ALONG_LINE / STORE_ALONG_LINE select which index runs fastest across lanes (the contiguous one in memory).
+struct TileArgs {
+    i64 in_stride_c, in_stride_t;   // elements
+    i64 out_stride_c, out_stride_t; // elements
+    i64 in_batch_stride, out_batch_stride;
+    int logL;
+    int lines_per_tile;  // C
+    int tiles_per_batch; // total lines per batch item / C
+    // optional post-multiplication by w_N^((line0 + c) * k): two-level power table A[e >> lo_bits] * B[e & lo_mask]
+    int post_twiddle;
+    int lo_bits;
+    u64 n_mask; // N - 1
+    i64 line_offset; // added to the line index in the post-twiddle exponent (distributed column pass)
+    // optional scalar scale
+    int do_scale;
+    u64 scale;
+    int tw_in_lds; // stage the L/2 twiddles (and Shoup quotients) in LDS; long lines read them through L1/L2
+};
+
+template <class F, class TW, bool LOAD_ALONG_LINE, bool STORE_ALONG_LINE>
+__global__ __launch_bounds__(256) void ntt_tile_kernel(FieldDev fd, const typename F::elem *__restrict__ in,
+                                                       typename F::elem *__restrict__ out, TileArgs ta,
+                                                       const typename F::elem *__restrict__ wtab,
+                                                       const typename F::elem *__restrict__ wtabq,
+                                                       const typename F::elem *__restrict__ powA,
+                                                       const typename F::elem *__restrict__ powB)
+{
+    typedef typename F::elem E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int logL = ta.logL;
+    const u32 L = 1u << logL;
+    const u32 C = (u32)ta.lines_per_tile; // power of two
+    const int logC = __ffs((int)C) - 1;
+    const u32 LP = L + 1;                         // line pitch: +1 element so that a column of the tile spreads over banks
+    E *data = reinterpret_cast<E *>(smem_raw);    // C * LP
+    E *twl = data + (size_t)C * LP;               // L/2 twiddles
+    E *twql = twl + (L >> 1);                     // L/2 Shoup quotients (only if TW::HAS_SHOUP)
+    const E *tw = ta.tw_in_lds ? twl : wtab;
+    const E *twq = ta.tw_in_lds ? twql : wtabq;
+
+    const u32 tid = threadIdx.x;
+    const i64 batch = blockIdx.x / ta.tiles_per_batch;
+    const u32 tile = blockIdx.x % ta.tiles_per_batch;
+    const i64 line0 = (i64)tile * C;
+    const E *gin = in + batch * ta.in_batch_stride;
+    E *gout = out + batch * ta.out_batch_stride;
+
+    if (ta.tw_in_lds)
+        for (u32 i = tid; i < (L >> 1); i += 256) {
+            twl[i] = wtab[i];
+            if constexpr (TW::HAS_SHOUP) twql[i] = wtabq[i];
+        }
+    // ---- load (bit-reversed position inside each line) ----
+    const u32 total = C * L;
+    if constexpr (LOAD_ALONG_LINE) {
+        for (u32 e = tid; e < total; e += 256) {
+            u32 c = e >> logL, t = e & (L - 1);
+            data[c * LP + bitrev(t, logL)] = gin[(line0 + c) * ta.in_stride_c + (i64)t * ta.in_stride_t];
+        }
+    } else {
+        for (u32 e = tid; e < total; e += 256) {
+            u32 t = e >> logC, c = e & (C - 1);
+            data[c * LP + bitrev(t, logL)] = gin[(line0 + c) * ta.in_stride_c + (i64)t * ta.in_stride_t];
+        }
+    }
+    __syncthreads();
+    // ---- log2(L) radix-2 decimation-in-time stages, in place ----
+    const u32 nbf = total >> 1;
+    for (int s = 0; s < logL; s++) {
+        const u32 half = 1u << s;
+        const int tshift = logL - 1 - s; // twiddle index = j << tshift
+        for (u32 u = tid; u < nbf; u += 256) {
+            u32 line = u >> (logL - 1);
+            u32 w = u & ((L >> 1) - 1);
+            u32 j = w & (half - 1);
+            u32 i0 = line * LP + ((w >> s) << (s + 1)) + j;
+            u32 i1 = i0 + half;
+            E a = data[i0];
+            E b = data[i1];
+            if (s > 0) b = TW::mul(fd, b, TW::load(tw, twq, j << tshift));
+            data[i0] = F::add(fd, a, b);
+            data[i1] = F::sub(fd, a, b);
+        }
+        __syncthreads();
+    }
+    // ---- store ----
+    const E scale = (E)ta.scale;
+    auto finish = [&](u32 c, u32 k) -> E {
+        E v = data[c * LP + k];
+        if (ta.post_twiddle) {
+            u64 e = ((u64)(ta.line_offset + line0 + c) * (u64)k) & ta.n_mask;
+            E t = F::mul(fd, powA[e >> ta.lo_bits], powB[e & ((1ull << ta.lo_bits) - 1)]);
+            v = F::mul(fd, v, t);
+        }
+        if (ta.do_scale) v = F::mul(fd, v, scale);
+        return v;
+    };
+    if constexpr (STORE_ALONG_LINE) {
+        for (u32 e = tid; e < total; e += 256) {
+            u32 c = e >> logL, k = e & (L - 1);
+            gout[(line0 + c) * ta.out_stride_c + (i64)k * ta.out_stride_t] = finish(c, k);
+        }
+    } else {
+        for (u32 e = tid; e < total; e += 256) {
+            u32 k = e >> logC, c = e & (C - 1);
+            gout[(line0 + c) * ta.out_stride_c + (i64)k * ta.out_stride_t] = finish(c, k);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic Stockham stage (any radix, any field)
+// ------------------------------------------------------------------------------------------------
+// in viewed as (r, q, m), out as (q, r, m); out[qi, f, b] = sum_k in[k, qi, b] * tw^k, tw = w^(q*(f*m + b))
+template <class F>
+__global__ __launch_bounds__(256) void ntt_stage_kernel(FieldDev fd, const typename F::elem *__restrict__ in,
+                                                        typename F::elem *__restrict__ out, i64 N, i64 r, i64 m, i64 q,
+                                                        const typename F::elem *__restrict__ wpow, i64 batch,
+                                                        int do_scale, typename F::elem scale)
+{
+    typedef typename F::elem E;
+    const i64 total = N * batch;
+    for (i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (i64)gridDim.x * blockDim.x) {
+        const i64 bi = g / N, o = g % N;
+        const E *x = in + bi * N;
+        const i64 b = o % m;
+        const i64 f = (o / m) % r;
+        const i64 qi = o / (m * r);
+        const E tw = wpow[(q * (f * m + b)) % N];
+        E acc = x[((r - 1) * q + qi) * m + b];
+        for (i64 k = r - 2; k >= 0; k--) acc = F::add(fd, F::mul(fd, acc, tw), x[(k * q + qi) * m + b]);
+        if (do_scale) acc = F::mul(fd, acc, scale);
+        out[bi * N + o] = acc;
+    }
+}
+
+template <typename E>
+__global__ void convert_in_kernel(const void *src, int dtype, E *dst, i64 n)
+{
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        E v;
+        switch (dtype) {
+        case GFA_U8: v = (E)((const uint8_t *)src)[i]; break;
+        case GFA_U16: v = (E)((const uint16_t *)src)[i]; break;
+        case GFA_U32: v = (E)((const uint32_t *)src)[i]; break;
+        default: v = (E)((const uint64_t *)src)[i]; break;
+        }
+        dst[i] = v;
+    }
+}
+template <typename E>
+__global__ void convert_out_kernel(const E *src, void *dst, int dtype, i64 n)
+{
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        E v = src[i];
+        switch (dtype) {
+        case GFA_U8: ((uint8_t *)dst)[i] = (uint8_t)v; break;
+        case GFA_U16: ((uint16_t *)dst)[i] = (uint16_t)v; break;
+        case GFA_U32: ((uint32_t *)dst)[i] = (uint32_t)v; break;
+        default: ((uint64_t *)dst)[i] = (uint64_t)v; break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// plans (device tables per (field, n, omega)), cached per process
+// ------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need)
+    {
+        if (need <= bytes) return GFA_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        GFA_HIP(hipMalloc(&p, need));
+        bytes = need;
+        return GFA_OK;
+    }
+};
+
+struct Plan {
+    // power-of-two tile path
+    int logn = 0, log1 = 0, log2 = 0; // n = 2^logn = 2^log1 * 2^log2 ; log2 == 0 => single pass
+    void *w1 = nullptr, *w1q = nullptr; // twiddles of the length-2^log1 transform (and Shoup quotients)
+    void *w2 = nullptr, *w2q = nullptr; // twiddles of the length-2^log2 transform
+    void *powA = nullptr, *powB = nullptr;
+    int lo_bits = 0;
+    // generic path
+    void *wpow = nullptr; // n entries
+    std::vector<i64> factors;
+    DevBuf ws0, ws1, cvt;
+};
+
+struct PlanKey {
+    const gfa_field *f; int device; i64 n; u64 omega; int lookup;
+    i64 variant; // 0: full transform; n1 > 0: distributed column pass with lines of length n1
+    bool operator<(const PlanKey &o) const
+    {
+        return std::tie(f, device, n, omega, lookup, variant) < std::tie(o.f, o.device, o.n, o.omega, o.lookup, o.variant);
+    }
+};
+
+std::mutex g_plan_mu;
+std::map<PlanKey, Plan *> g_plans;
+
+template <class F>
+int build_pow_table(const FieldDev &fd, u64 base, u64 exp_stride, i64 count, void **out, hipStream_t st)
+{
+    typedef typename F::elem E;
+    GFA_HIP(hipMalloc(out, sizeof(E) * (size_t)std::max<i64>(count, 1)));
+    hipLaunchKernelGGL((pow_table_kernel<F>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, fd, (E)base,
+                       exp_stride, (E *)*out, count);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+int build_shoup(const FieldDev &fd, const void *w, i64 count, void **out, hipStream_t st)
+{
+    GFA_HIP(hipMalloc(out, sizeof(u32) * (size_t)std::max<i64>(count, 1)));
+    hipLaunchKernelGGL(shoup_table_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, (u32)fd.p,
+                       (const u32 *)w, (u32 *)*out, count);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+std::vector<i64> prime_factors(i64 n)
+{ // ascending with multiplicity, as fft_jit._prime_factors (_function.py:214-229)
+    std::vector<i64> out;
+    for (i64 d = 2; d * d <= n; d++)
+        while (n % d == 0) { out.push_back(d); n /= d; }
+    if (n > 1) out.push_back(n);
+    return out;
+}
+
+constexpr size_t TILE_LDS_BYTES = 64 * 1024; // data part of the tile; two workgroups per CU
+
+template <class F>
+int max_log_tile()
+{ // longest line that fits the LDS budget with one line per tile
+    int lg = 0;
+    while ((sizeof(typename F::elem) << (lg + 1)) <= TILE_LDS_BYTES) lg++;
+    return lg; // u32: 14, u64: 13
+}
+
+template <class F, class TW>
+int launch_tile(const FieldDev &fd, bool load_along, bool store_along, const void *in, void *out, const TileArgs &ta,
+                i64 batch, const void *w, const void *wq, const void *pa, const void *pb, hipStream_t st)
+{
+    typedef typename F::elem E;
+    const size_t L = (size_t)1 << ta.logL;
+    const size_t lds = sizeof(E) * ((size_t)ta.lines_per_tile * (L + 1) + (ta.tw_in_lds ? L : 0));
+    const unsigned grid = (unsigned)(batch * ta.tiles_per_batch);
+#define GFA_TILE(LA, SA)                                                                                          \
+    do {                                                                                                          \
+        auto kern = ntt_tile_kernel<F, TW, LA, SA>;                                                               \
+        static bool attr = false;                                                                                 \
+        if (!attr) {                                                                                              \
+            GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr = true;                                                                                          \
+        }                                                                                                         \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, fd, (const E *)in, (E *)out, ta, (const E *)w,   \
+                           (const E *)wq, (const E *)pa, (const E *)pb);                                          \
+    } while (0)
+    if (load_along && store_along) GFA_TILE(true, true);
+    else if (load_along && !store_along) GFA_TILE(true, false);
+    else if (!load_along && store_along) GFA_TILE(false, true);
+    else GFA_TILE(false, false);
+#undef GFA_TILE
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+int choose_lines(int logL, size_t esize, i64 total_lines)
+{
+    size_t c = TILE_LDS_BYTES / (esize << logL);
+    if (c < 8) c = (2 * TILE_LDS_BYTES - 4096) / (esize << logL); // long lines: one 128 KiB workgroup per CU instead
+    if (c < 1) c = 1;
+    if (c > 32) c = 32;
+    while (c > 1 && (total_lines % (i64)c) != 0) c >>= 1;
+    // round down to a power of two
+    size_t p2 = 1;
+    while (p2 * 2 <= c) p2 *= 2;
+    return (int)p2;
+}
+
+// Runs the transform on element-typed (F::elem) buffers.
+template <class F, class TW>
+int run_pow2(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n, i64 batch, u64 omega,
+             int do_scale, u64 scale, hipStream_t st)
+{
+    typedef typename F::elem E;
+    if (!pl->w1) {
+        const int maxlg = std::min(max_log_tile<F>(), 12); // keep >= 4 lines per tile for the strided passes
+        pl->logn = 0;
+        while (((i64)1 << pl->logn) < n) pl->logn++;
+        if (pl->logn <= max_log_tile<F>() - 1 && pl->logn <= 13) {
+            pl->log1 = pl->logn; pl->log2 = 0;
+        } else {
+            pl->log1 = (pl->logn + 1) / 2; pl->log2 = pl->logn - pl->log1;
+            if (pl->log1 > maxlg) { set_error("gfa_ntt: power-of-two length beyond the two-pass range"); return GFA_ERR_UNSUPPORTED; }
+        }
+        int rc;
+        const i64 n1 = (i64)1 << pl->log1, n2 = (i64)1 << pl->log2;
+        // w_{n1} = omega^(n2): table of w_{n1}^t, t < n1/2
+        if ((rc = build_pow_table<F>(fd, omega, (u64)n2, std::max<i64>(n1 / 2, 1), &pl->w1, st))) return rc;
+        if (TW::HAS_SHOUP && (rc = build_shoup(fd, pl->w1, std::max<i64>(n1 / 2, 1), &pl->w1q, st))) return rc;
+        if (pl->log2) {
+            if ((rc = build_pow_table<F>(fd, omega, (u64)n1, n2 / 2, &pl->w2, st))) return rc;
+            if (TW::HAS_SHOUP && (rc = build_shoup(fd, pl->w2, n2 / 2, &pl->w2q, st))) return rc;
+            pl->lo_bits = (pl->logn + 1) / 2;
+            const i64 nb = (i64)1 << pl->lo_bits, na = n >> pl->lo_bits;
+            if ((rc = build_pow_table<F>(fd, omega, (u64)nb, na, &pl->powA, st))) return rc;
+            if ((rc = build_pow_table<F>(fd, omega, 1, nb, &pl->powB, st))) return rc;
+        }
+    }
+    (void)f;
+    if (pl->log2 == 0) {
+        TileArgs ta{};
+        ta.logL = pl->log1;
+        ta.lines_per_tile = choose_lines(pl->log1, sizeof(E), batch);
+        ta.tiles_per_batch = 1;
+        // treat the whole batch as `batch` lines of one "batch item"
+        ta.in_stride_c = n; ta.in_stride_t = 1; ta.out_stride_c = n; ta.out_stride_t = 1;
+        ta.in_batch_stride = 0; ta.out_batch_stride = 0;
+        ta.tiles_per_batch = (int)(batch / ta.lines_per_tile);
+        ta.do_scale = do_scale; ta.scale = scale;
+        ta.tw_in_lds = pl->log1 <= 12;
+        return launch_tile<F, TW>(fd, true, true, in, out, ta, 1, pl->w1, pl->w1q, nullptr, nullptr, st);
+    }
+    const i64 n1 = (i64)1 << pl->log1, n2 = (i64)1 << pl->log2;
+    int rc;
+    if ((rc = pl->ws0.ensure(sizeof(E) * (size_t)(n * batch)))) return rc;
+    // pass 1: columns j2 (lines), position j1 with stride n2; output A[k1*n2 + j2] * w^(j2*k1)
+    {
+        TileArgs ta{};
+        ta.logL = pl->log1;
+        ta.lines_per_tile = choose_lines(pl->log1, sizeof(E), n2);
+        ta.tiles_per_batch = (int)(n2 / ta.lines_per_tile);
+        ta.in_stride_c = 1; ta.in_stride_t = n2; ta.out_stride_c = 1; ta.out_stride_t = n2;
+        ta.in_batch_stride = n; ta.out_batch_stride = n;
+        ta.post_twiddle = 1; ta.lo_bits = pl->lo_bits; ta.n_mask = (u64)n - 1;
+        ta.tw_in_lds = pl->log1 <= 12;
+        if ((rc = launch_tile<F, TW>(fd, false, false, in, pl->ws0.p, ta, batch, pl->w1, pl->w1q, pl->powA, pl->powB, st)))
+            return rc;
+    }
+    // pass 2: rows k1 (lines), contiguous along j2; output X[k1 + n1*k2]
+    {
+        TileArgs ta{};
+        ta.logL = pl->log2;
+        ta.lines_per_tile = choose_lines(pl->log2, sizeof(E), n1);
+        ta.tiles_per_batch = (int)(n1 / ta.lines_per_tile);
+        ta.in_stride_c = n2; ta.in_stride_t = 1; ta.out_stride_c = 1; ta.out_stride_t = n1;
+        ta.in_batch_stride = n; ta.out_batch_stride = n;
+        ta.do_scale = do_scale; ta.scale = scale;
+        ta.tw_in_lds = pl->log2 <= 12;
+        if ((rc = launch_tile<F, TW>(fd, true, false, pl->ws0.p, out, ta, batch, pl->w2, pl->w2q, nullptr, nullptr, st)))
+            return rc;
+    }
+    return GFA_OK;
+}
+
+template <class F>
+int run_generic(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n, i64 batch, u64 omega, int do_scale,
+                u64 scale, hipStream_t st)
+{
+    typedef typename F::elem E;
+    int rc;
+    if (!pl->wpow) {
+        pl->factors = prime_factors(n);
+        if ((rc = build_pow_table<F>(fd, omega, 1, n, &pl->wpow, st))) return rc;
+    }
+    const size_t bytes = sizeof(E) * (size_t)(n * batch);
+    const int S = (int)pl->factors.size();
+    if (S == 0) { // n == 1
+        if (in != out) GFA_HIP(hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, st));
+        return GFA_OK;
+    }
+    if ((rc = pl->ws0.ensure(bytes))) return rc;
+    if ((rc = pl->ws1.ensure(bytes))) return rc;
+    const E *src = (const E *)in;
+    i64 m = 1;
+    const int grid = (int)std::min<i64>((n * batch + 255) / 256, 256 * 16);
+    for (int s = 0; s < S; s++) {
+        const i64 r = pl->factors[S - 1 - s];
+        const i64 q = n / (m * r);
+        const bool last = s == S - 1;
+        E *dst = last ? ((S == 1 && in == out) ? (E *)pl->ws0.p : (E *)out) : (E *)((s & 1) ? pl->ws1.p : pl->ws0.p);
+        hipLaunchKernelGGL((ntt_stage_kernel<F>), dim3(grid), dim3(256), 0, st, fd, src, dst, n, r, m, q,
+                           (const E *)pl->wpow, batch, (last && do_scale) ? 1 : 0, (E)scale);
+        GFA_HIP(hipGetLastError());
+        if (last && dst != (E *)out) GFA_HIP(hipMemcpyAsync(out, dst, bytes, hipMemcpyDeviceToDevice, st));
+        src = dst;
+        m *= r;
+    }
+    return GFA_OK;
+}
+
+bool is_pow2(i64 n) { return n > 0 && (n & (n - 1)) == 0; }
+
+template <class F>
+int run_typed(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n, i64 batch, u64 omega,
+              int do_scale, u64 scale, int dtype, hipStream_t st)
+{
+    typedef typename F::elem E;
+    const int native = sizeof(E) == 4 ? GFA_U32 : GFA_U64;
+    const void *ein = in;
+    void *eout = out;
+    int rc;
+    if (dtype != native) { // widen / narrow through a scratch buffer in the arithmetic's element type
+        if ((rc = pl->cvt.ensure(sizeof(E) * (size_t)(n * batch)))) return rc;
+        const int grid = (int)std::min<i64>((n * batch + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL((convert_in_kernel<E>), dim3(grid), dim3(256), 0, st, in, dtype, (E *)pl->cvt.p, n * batch);
+        GFA_HIP(hipGetLastError());
+        ein = pl->cvt.p; eout = pl->cvt.p;
+    }
+    constexpr bool prime_kind = std::is_same<F, Prime32>::value || std::is_same<F, Prime64>::value ||
+                                std::is_same<F, Goldilocks>::value;
+    bool done = false;
+    if (prime_kind && is_pow2(n) && n >= 2) {
+        int lg = 0;
+        while (((i64)1 << lg) < n) lg++;
+        if (lg <= 24) {
+            if constexpr (std::is_same<F, Prime32>::value) {
+                if (fd.p < (1ull << 31)) rc = run_pow2<F, TwShoup32>(f, fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+                else rc = run_pow2<F, Tw<F>>(f, fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+            } else {
+                rc = run_pow2<F, Tw<F>>(f, fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+            }
+            if (rc) return rc;
+            done = true;
+        }
+    }
+    if (!done && (rc = run_generic<F>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st))) return rc;
+    if (dtype != native) {
+        const int grid = (int)std::min<i64>((n * batch + 255) / 256, 256 * 16);
+        hipLaunchKernelGGL((convert_out_kernel<E>), dim3(grid), dim3(256), 0, st, (const E *)pl->cvt.p, out, dtype, n * batch);
+        GFA_HIP(hipGetLastError());
+    }
+    return GFA_OK;
+}
+
+} // namespace
+
+namespace gfa {
+void ntt_forget_field(const gfa_field *f)
+{
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    for (auto it = g_plans.begin(); it != g_plans.end();) {
+        if (it->first.f == f) {
+            Plan *pl = it->second;
+            for (void *p : {pl->w1, pl->w1q, pl->w2, pl->w2q, pl->powA, pl->powB, pl->wpow, pl->ws0.p, pl->ws1.p, pl->cvt.p})
+                if (p) (void)hipFree(p);
+            delete pl;
+            it = g_plans.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+} // namespace gfa
+
+extern "C" {
+
+int gfa_ntt(gfa_field_t *f, const void *in, void *out, int64_t n, int64_t batch, uint64_t omega, int scale_by_n_inverse,
+            int dtype, gfa_stream_t stream)
+{
+    if (!f || !in || !out || n < 1 || batch < 0 || dtype < GFA_U8 || dtype > GFA_U64) {
+        set_error("gfa_ntt: bad arguments");
+        return GFA_ERR_INVALID;
+    }
+    const FieldDev &c = f->calc;
+    if ((c.q - 1) % (u64)n != 0) { set_error("gfa_ntt: n must divide q - 1"); return GFA_ERR_INVALID; }
+    if (omega == 0 || omega >= c.q) { set_error("gfa_ntt: omega out of range"); return GFA_ERR_INVALID; }
+    if (batch == 0) return GFA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    FieldDeviceState *ds;
+    int dev = 0;
+    int rc = f->ensure_device(&dev, &ds);
+    if (rc) return rc;
+    u64 scale = 1;
+    if (scale_by_n_inverse) {
+        // y /= GF(n % characteristic) (_function.py:209-210)
+        u64 nm = (u64)n % c.p;
+        if (!HostArith::inv(c, nm, &scale)) { set_error("gfa_ntt: n is not invertible in the field"); return GFA_ERR_INVALID; }
+    }
+    const bool lookup = f->use_lookup();
+    Plan *pl;
+    {
+        std::lock_guard<std::mutex> lock(g_plan_mu);
+        PlanKey key{f, dev, n, omega, lookup ? 1 : 0, 0};
+        auto it = g_plans.find(key);
+        if (it == g_plans.end()) it = g_plans.emplace(key, new Plan()).first;
+        pl = it->second;
+    }
+    if (lookup) return run_typed<Lut>(f, f->lut_desc(*ds), pl, in, out, n, batch, omega, scale_by_n_inverse, scale, dtype, st);
+    switch (c.kind) {
+    case KIND_PRIME32: return run_typed<Prime32>(f, c, pl, in, out, n, batch, omega, scale_by_n_inverse, scale, dtype, st);
+    case KIND_PRIME64: return run_typed<Prime64>(f, c, pl, in, out, n, batch, omega, scale_by_n_inverse, scale, dtype, st);
+    case KIND_GOLDILOCKS: return run_typed<Goldilocks>(f, c, pl, in, out, n, batch, omega, scale_by_n_inverse, scale, dtype, st);
+    case KIND_BIN: return run_typed<Bin>(f, c, pl, in, out, n, batch, omega, scale_by_n_inverse, scale, dtype, st);
+    case KIND_EXT: return run_typed<Ext>(f, c, pl, in, out, n, batch, omega, scale_by_n_inverse, scale, dtype, st);
+    default: set_error("gfa_ntt: unsupported field kind"); return GFA_ERR_UNSUPPORTED;
+    }
+}
+
+int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64_t cols, int64_t col0, int64_t n_total,
+                    uint64_t omega, int dtype, gfa_stream_t stream)
+{
+    if (!f || !in || !out || n1 < 2 || cols < 1 || col0 < 0 || n_total < n1 || (n_total % n1) != 0 || !is_pow2(n1) ||
+        !is_pow2(n_total) || !is_pow2(cols)) {
+        set_error("gfa_ntt_columns: bad arguments (power-of-two n1, cols, n_total required)");
+        return GFA_ERR_INVALID;
+    }
+    const FieldDev &c = f->calc;
+    if ((c.q - 1) % (u64)n_total != 0) { set_error("gfa_ntt_columns: n_total must divide q - 1"); return GFA_ERR_INVALID; }
+    hipStream_t st = (hipStream_t)stream;
+    FieldDeviceState *ds;
+    int dev = 0;
+    int rc = f->ensure_device(&dev, &ds);
+    if (rc) return rc;
+    Plan *pl;
+    {
+        std::lock_guard<std::mutex> lock(g_plan_mu);
+        PlanKey key{f, dev, n_total, omega, 0, n1};
+        auto it = g_plans.find(key);
+        if (it == g_plans.end()) it = g_plans.emplace(key, new Plan()).first;
+        pl = it->second;
+    }
+    auto run = [&](auto Ftag, auto TWtag) -> int {
+        typedef decltype(Ftag) F;
+        typedef decltype(TWtag) TW;
+        typedef typename F::elem E;
+        if ((sizeof(E) == 4 ? GFA_U32 : GFA_U64) != dtype) {
+            set_error("gfa_ntt_columns: dtype must be the field's native device width (uint32 for p < 2^32, else uint64)");
+            return GFA_ERR_UNSUPPORTED;
+        }
+        int lg1 = 0, lgn = 0;
+        while (((i64)1 << lg1) < n1) lg1++;
+        while (((i64)1 << lgn) < n_total) lgn++;
+        if (lg1 > 13 || (sizeof(E) << lg1) > 2 * TILE_LDS_BYTES - 4096) { set_error("gfa_ntt_columns: n1 too long for one LDS tile"); return GFA_ERR_UNSUPPORTED; }
+        int rc2;
+        if (!pl->w1) {
+            pl->log1 = lg1; pl->logn = lgn;
+            if ((rc2 = build_pow_table<F>(c, omega, (u64)(n_total / n1), n1 / 2, &pl->w1, st))) return rc2;
+            if (TW::HAS_SHOUP && (rc2 = build_shoup(c, pl->w1, n1 / 2, &pl->w1q, st))) return rc2;
+            pl->lo_bits = (lgn + 1) / 2;
+            const i64 nb = (i64)1 << pl->lo_bits, na = n_total >> pl->lo_bits;
+            if ((rc2 = build_pow_table<F>(c, omega, (u64)nb, na, &pl->powA, st))) return rc2;
+            if ((rc2 = build_pow_table<F>(c, omega, 1, nb, &pl->powB, st))) return rc2;
+        }
+        TileArgs ta{};
+        ta.logL = lg1;
+        ta.lines_per_tile = choose_lines(lg1, sizeof(E), cols);
+        ta.tiles_per_batch = (int)(cols / ta.lines_per_tile);
+        ta.in_stride_c = 1; ta.in_stride_t = cols; ta.out_stride_c = 1; ta.out_stride_t = cols;
+        ta.post_twiddle = 1; ta.lo_bits = pl->lo_bits; ta.n_mask = (u64)n_total - 1; ta.line_offset = col0;
+        ta.tw_in_lds = lg1 <= 12;
+        return launch_tile<F, TW>(c, false, false, in, out, ta, 1, pl->w1, pl->w1q, pl->powA, pl->powB, st);
+    };
+    switch (c.kind) {
+    case KIND_PRIME32:
+        if (c.p < (1ull << 31)) return run(Prime32{}, TwShoup32{});
+        return run(Prime32{}, Tw<Prime32>{});
+    case KIND_PRIME64: return run(Prime64{}, Tw<Prime64>{});
+    case KIND_GOLDILOCKS: return run(Goldilocks{}, Tw<Goldilocks>{});
+    default: set_error("gfa_ntt_columns: prime fields only"); return GFA_ERR_UNSUPPORTED;
+    }
+}
+
+int gfa_time_ntt(gfa_field_t *f, const void *in, void *out, int64_t n, int64_t batch, uint64_t omega, int dtype,
+                 gfa_stream_t stream, int iters, float *ms_out)
+{
+    return gfa::time_loop((hipStream_t)stream, iters, ms_out,
+                          [&]() { return gfa_ntt(f, in, out, n, batch, omega, 0, dtype, stream); });
+}
+
+} // extern "C"

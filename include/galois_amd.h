@@ -1,0 +1,164 @@
+/*
+ * galois_amd.h -- C-ABI of the MI355X (gfx950) finite-field engine.
+ *
+ * The reference (mhostetter/galois) is pure Python with no FFI; its internal operator seam is the set
+ * of per-field dispatcher objects that __array_ufunc__/__array_function__ call with int64 views of the
+ * data.  Each entry point below names the reference interface it replaces
+ * (paths relative to /root/reference/src/galois).  INTEGRATION.md shows the ctypes binding a maintainer
+ * of the reference would add at those seams.
+ *
+ * Conventions
+ *  - All array pointers are DEVICE pointers owned by the caller (e.g. torch tensors); nothing is copied
+ *    to or from the host by the data-path calls.  `stream` is a hipStream_t (NULL = default stream).
+ *  - Elements are non-negative integers < order stored in `dtype` (an unsigned storage width; the
+ *    reference's signed dtypes of the same width hold the same bit patterns).
+ *  - Every function returns a gfa_status.  No C++ exceptions cross the boundary.
+ *  - Arithmetic errors raised by the reference from inside its scalar kernels (ZeroDivisionError) are
+ *    reported through `dev_err`, a caller-owned device int32 that kernels OR GFA_DEVERR_* bits into;
+ *    the host checks it after synchronising and raises the reference's exception type.
+ *  - A gfa_field_t is immutable after creation (tables, constants) => safe to share between threads and
+ *    streams.  Unlike the reference, no module-level globals are involved (_domains/_ufunc.py:110,137).
+ */
+#ifndef GALOIS_AMD_H
+#define GALOIS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GFA_ABI_VERSION 1
+
+typedef struct gfa_field gfa_field_t; /* one finite field GF(p^m) */
+typedef struct gfa_rs gfa_rs_t;       /* one Reed-Solomon code over a field */
+typedef void *gfa_stream_t;           /* hipStream_t */
+
+typedef enum {
+    GFA_OK = 0,
+    GFA_ERR_INVALID = 1,     /* bad argument (ValueError/TypeError on the Python side) */
+    GFA_ERR_UNSUPPORTED = 2, /* field / dtype / size combination has no device path */
+    GFA_ERR_HIP = 3,         /* a HIP runtime call failed; see gfa_last_error() */
+    GFA_ERR_NOMEM = 4
+} gfa_status;
+
+typedef enum { GFA_U8 = 0, GFA_U16 = 1, GFA_U32 = 2, GFA_U64 = 3 } gfa_dtype;
+
+/* ufuncs overridden by the reference: _domains/_ufunc.py:616-631 */
+typedef enum {
+    GFA_OP_ADD = 0,   /* np.add        -> cls._add        (_fields/_ufunc.py:23,59,85) */
+    GFA_OP_SUB = 1,   /* np.subtract   -> cls._subtract */
+    GFA_OP_MUL = 2,   /* np.multiply   -> cls._multiply */
+    GFA_OP_DIV = 3,   /* np.true_divide/floor_divide -> cls._divide (reciprocal+multiply, _ufunc.py:433-437) */
+    GFA_OP_NEG = 4,   /* np.negative   -> cls._negative */
+    GFA_OP_RECIP = 5, /* np.reciprocal -> cls._reciprocal */
+    GFA_OP_POW = 6    /* np.power      -> cls._power */
+} gfa_op;
+
+/* FieldArray.compile(mode) (_domains/_array.py:322-362).  LOOKUP = EXP/LOG/Zech (or full product)
+ * tables, the reference's "jit-lookup"; CALCULATE = explicit arithmetic, the reference's "jit-calculate". */
+typedef enum { GFA_MODE_AUTO = 0, GFA_MODE_LOOKUP = 1, GFA_MODE_CALCULATE = 2 } gfa_mode;
+
+#define GFA_DEVERR_ZERO_DIVISION 1 /* reciprocal(0), x/0, 0**negative (_lookup.py:194-195, _calculate.py:403-404,536-537) */
+
+/* ---- library -------------------------------------------------------------------------------------- */
+int gfa_abi_version(void);
+const char *gfa_last_error(void); /* thread-local description of the last non-OK status */
+int gfa_device_count(void);       /* number of visible HIP devices (0 if none / no driver) */
+
+/* ---- fields: replaces the class factory's arithmetic set-up --------------------------------------- *
+ * galois.GF(...) -> _GF_prime/_GF_extension (_fields/_factory.py:364-532) and
+ * UFuncMixin._build_lookup_tables (_domains/_lookup.py:319-371).  The field is defined by exactly what
+ * defines a reference field class: characteristic p, degree m, irreducible polynomial (m+1 coefficients
+ * in GF(p), highest degree first; ignored when m == 1) and primitive element (integer representation).
+ * Host-side only; device tables are uploaded lazily on the first data-path call. */
+int gfa_field_create(uint64_t p, uint32_t m, const uint64_t *irreducible_poly_coeffs, uint64_t primitive_element,
+                     gfa_field_t **out);
+void gfa_field_destroy(gfa_field_t *f);
+int gfa_field_set_mode(gfa_field_t *f, int mode); /* gfa_mode; GFA_ERR_UNSUPPORTED if the mode is illegal for the field */
+int gfa_field_get_mode(const gfa_field_t *f);     /* resolved mode: GFA_MODE_LOOKUP or GFA_MODE_CALCULATE */
+uint64_t gfa_field_order(const gfa_field_t *f);   /* p^m (0 if it does not fit in 64 bits) */
+/* Host copies of the lookup tables in the reference's layout (int64: EXP 2q, LOG q, ZECH_LOG q entries;
+ * cls._EXP/_LOG/_ZECH_LOG/_ZECH_E, _domains/_meta.py:60-63).  Any pointer may be NULL. */
+int gfa_field_tables(gfa_field_t *f, int64_t *exp_out, int64_t *log_out, int64_t *zech_out, int64_t *zech_e_out);
+/* One scalar operation on the host (class-construction-time maths: roots of unity, generator polynomials).
+ * For GFA_OP_POW `b` is an int64 exponent passed as its two's-complement bits. */
+int gfa_scalar(const gfa_field_t *f, int op, uint64_t a, uint64_t b, uint64_t *out);
+
+/* ---- element-wise ufuncs: replaces `getattr(self.ufunc, "__call__")(*inputs)` (_domains/_ufunc.py:403) *
+ * i.e. the numba.vectorize'd int64(int64,int64) loops of _lookup.py:31-270 and _calculate.py:133-592.
+ * Strides are in elements and must be 0 (broadcast one scalar) or 1 (contiguous). */
+int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t a_stride, const void *b, int64_t b_stride, void *out,
+               int64_t n, int dtype, gfa_stream_t stream, int32_t *dev_err);
+int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int dtype, gfa_stream_t stream,
+              int32_t *dev_err);
+/* np.power(x, e): `exps` is a device int64 array (stride 0 or 1) -- power_ufunc, _ufunc.py:477-490 */
+int gfa_power(gfa_field_t *f, const void *a, int64_t a_stride, const int64_t *exps, int64_t e_stride, void *out,
+              int64_t n, int dtype, gfa_stream_t stream, int32_t *dev_err);
+/* field * integer = repeated addition (multiply_ufunc.__call__, _ufunc.py:392-401): out = a * (k mod p) with the
+ * integer taken in the prime subfield.  `ks` is a device int64 array (stride 0 or 1). */
+int gfa_scalar_multiply(gfa_field_t *f, const void *a, int64_t a_stride, const int64_t *ks, int64_t k_stride, void *out,
+                        int64_t n, int dtype, gfa_stream_t stream);
+/* ufunc.reduce over the last axis of an (n_outer, n_inner) array for op in {ADD, SUB, MUL, DIV}
+ * (_domains/_ufunc.py:180-198 allows reduce/accumulate only for the binary ops).  SUB/DIV are left folds. */
+int gfa_reduce(gfa_field_t *f, int op, const void *a, void *out, int64_t n_outer, int64_t n_inner, int dtype,
+               gfa_stream_t stream, int32_t *dev_err);
+
+/* ---- NTT: replaces fft_jit/ifft_jit `self.jit(x.astype(int64), int64(omega), factors)` (_domains/_function.py:201) *
+ * Computes out[k] = sum_j in[j] * omega^(j*k) for each of `batch` contiguous length-n rows, natural order in and
+ * out.  `omega` must be a primitive n-th root of unity (for the inverse pass omega^-1, as fft_jit.__call__ does at
+ * _function.py:194-195).  If scale_by_n_inverse != 0 the result is multiplied by (n mod p)^-1 (_function.py:209-210).
+ * in == out is allowed.  Any n with n | q-1 is accepted; powers of two take the LDS radix path. */
+int gfa_ntt(gfa_field_t *f, const void *in, void *out, int64_t n, int64_t batch, uint64_t omega, int scale_by_n_inverse,
+            int dtype, gfa_stream_t stream);
+/* Per-rank kernel of the distributed four-step transform of ONE length-n_total sequence over G GPUs (n_total =
+ * n1 * n2, all powers of two; new design -- the reference has no distributed path).
+ * The rank holds `cols` adjacent columns [col0, col0+cols) of the (n1 x n2) row-major view x[j1*n2 + j2] as a local
+ * (n1 x cols) row-major array.  Each local column is transformed (length n1, root omega^(n_total/n1)) and multiplied
+ * by omega^((col0 + c) * k1).  The host then performs the single RCCL all-to-all (torch.distributed) that turns the
+ * column-block layout into a row-block layout, and finishes with a plain batched gfa_ntt of length n2 on its rows
+ * (root omega^n1).  Result layout: rank g holds X[k1 + n1*k2] for its n1/G values of k1, all k2.
+ * dtype must be the field's native device width (GFA_U32 for p < 2^32, GFA_U64 otherwise). */
+int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64_t cols, int64_t col0, int64_t n_total,
+                    uint64_t omega, int dtype, gfa_stream_t stream);
+
+/* ---- Reed-Solomon -------------------------------------------------------------------------------- *
+ * gfa_rs_create replaces the arithmetic part of ReedSolomon.__init__ (_codes/_reed_solomon.py:111-218) and
+ * _poly_to_generator_matrix (_codes/_cyclic.py:198-226): roots alpha^(c..c+d-2), g(x), systematic parity matrix. */
+int gfa_rs_create(gfa_field_t *f, int64_t n, int64_t k, int64_t c, uint64_t alpha, int systematic, gfa_rs_t **out);
+void gfa_rs_destroy(gfa_rs_t *code);
+/* Host copies: roots (n-k), generator polynomial (n-k+1, highest degree first), parity matrix P (k x (n-k)). */
+int gfa_rs_describe(const gfa_rs_t *code, uint64_t *roots, uint64_t *generator_poly, uint64_t *parity_matrix);
+/* _LinearCode._encode_message -> matmul_jit (_codes/_linear.py:270-284, _domains/_linalg.py:286-308).
+ * msg: (batch, ks) row-major, ks <= k (shortened codes pass fewer symbols).  out: (batch, ks + n - k) codewords, or
+ * (batch, n - k) parity symbols when parity_only != 0.  Systematic codes only on the device. */
+int gfa_rs_encode(gfa_rs_t *code, const void *msg, int64_t ks, void *out, int64_t batch, int parity_only, int dtype,
+                  gfa_stream_t stream);
+/* _LinearCode._detect_errors (_codes/_linear.py:286-298): detected[i] = any(syndrome_i != 0). cw: (batch, ns). */
+int gfa_rs_detect(gfa_rs_t *code, const void *cw, int64_t ns, uint8_t *detected, int64_t batch, int dtype,
+                  gfa_stream_t stream);
+/* bch_decode_jit.implementation (_codes/_bch.py:1337-1578) via reed_solomon_decode_jit (_reed_solomon.py:1105-1113).
+ * recv: (batch, ns) received words, index 0 = highest degree; erasures: (batch, ns) bytes (non-zero = erased) or NULL;
+ * out_codeword: (batch, ns) corrected codewords (the received row unchanged where decoding fails);
+ * out_n_errors: (batch) int64, number of corrected errors (not erasures), -1 on failure. */
+int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int64_t ns, void *out_codeword,
+                  int64_t *out_n_errors, int64_t batch, int dtype, gfa_stream_t stream);
+
+/* ---- measurement support (bench.py) --------------------------------------------------------------- *
+ * Times `iters` back-to-back launches of the named hot kernel on `stream` with HIP events recorded on that same
+ * stream and returns the average milliseconds per launch in *ms_out. */
+int gfa_time_binary(gfa_field_t *f, int op, const void *a, const void *b, void *out, int64_t n, int dtype,
+                    gfa_stream_t stream, int iters, float *ms_out);
+int gfa_time_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int dtype, gfa_stream_t stream,
+                   int iters, float *ms_out);
+int gfa_time_ntt(gfa_field_t *f, const void *in, void *out, int64_t n, int64_t batch, uint64_t omega, int dtype,
+                 gfa_stream_t stream, int iters, float *ms_out);
+int gfa_time_rs_encode(gfa_rs_t *code, const void *msg, int64_t ks, void *out, int64_t batch, int dtype,
+                       gfa_stream_t stream, int iters, float *ms_out);
+int gfa_time_rs_decode(gfa_rs_t *code, const void *recv, int64_t ns, void *out_codeword, int64_t *out_n_errors,
+                       int64_t batch, int dtype, gfa_stream_t stream, int iters, float *ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GALOIS_AMD_H */
