@@ -1,0 +1,262 @@
+#!/usr/bin/env python
+"""
+bench.py -- headline benchmark of the finite-field hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU; RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* from the env)
+
+Workload (BASELINE.json configs[1]): GF(2^8) multiply, EXP/LOG-class lookup mode (full LDS product table), 1e8 uint8
+elements PER GPU, inputs resident in HBM (x: seed 1, y: seed 2, as SURVEY.md section 8(d)).  A "step" is one pass of
+np.multiply over the 1e8-element batch through the C-ABI (gfa_binary).  Weak scaling: every rank owns an independent
+1e8-element shard; there is no data-path collective, only the timing barrier and a MAX all-reduce of the elapsed time.
+
+One JSON line is printed by rank 0.  Besides the contract keys it carries
+  "roofline":     dominant kernel (tab8_binary_kernel) -- algorithmic 3 B/element x 1e8 per launch / HIP-event time
+  "cpu_baseline": the C port of the reference's lookup ufunc (oracle/gf_oracle.c, 1 thread) on the same data
+  "extra":        the other two parts of BASELINE.json's composite metric (2^20-point NTT/s, RS(255,223) GB/s),
+                  measured after the timed region on this rank's GPU, each with its own roofline fraction.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+N_ELEMENTS = 100_000_000
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-extras", action="store_true", help="skip the NTT / Reed-Solomon side measurements")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import galois_amd as ga
+    from galois_amd import _lib as L
+
+    lib = L.lib()
+    GF = ga.GF(2**8)  # irreducible x^8+x^4+x^3+x^2+1, alpha = 2; default mode = lookup
+    assert GF.ufunc_mode == "jit-lookup"
+    n = N_ELEMENTS
+    # identical bits to the reference's GF.Random(seed=...) = default_rng(seed).integers(0, 256, n, uint8)
+    x_h = np.random.default_rng(1 + 1000 * rank).integers(0, 256, n, dtype=np.uint8)
+    y_h = np.random.default_rng(2 + 1000 * rank).integers(0, 256, n, dtype=np.uint8)
+    x = torch.from_numpy(x_h).cuda()
+    y = torch.from_numpy(y_h).cuda()
+    out = torch.empty_like(x)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        rc = lib.gfa_binary(GF._handle, L.OP_MUL, x.data_ptr(), 1, y.data_ptr(), 1, out.data_ptr(), n, L.U8, stream, None)
+        if rc:
+            L.check(rc, "gfa_binary")
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # parity gate on this rank's shard (sampled every 997th element + both ends) against the oracle port
+    from oracle import gf_oracle as O
+
+    F = O.OracleField(2, 8, 285, 2, lookup=True)
+    idx = np.unique(np.concatenate([np.arange(0, n, 997), np.arange(0, 4096), np.arange(n - 4096, n)]))
+    got = out.cpu().numpy()[idx]
+    assert np.array_equal(got, F.ufunc_u8(O.MUL, x_h[idx], y_h[idx])), "GPU result differs from the oracle"
+
+    # roofline of the dominant kernel: HIP events on the launch stream, inside the library (gfa_time_binary)
+    ms = ctypes.c_float()
+    L.check(lib.gfa_time_binary(GF._handle, L.OP_MUL, x.data_ptr(), y.data_ptr(), out.data_ptr(), n, L.U8, stream, 50,
+                                ctypes.byref(ms)), "gfa_time_binary")
+    alg_bytes = 3.0 * n
+    achieved = alg_bytes / (ms.value * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "tab8_binary_kernel",
+                "kernel_ms": round(ms.value, 5), "algorithmic_bytes_per_launch": alg_bytes}
+
+    result = None
+    if rank == 0:
+        value = world * n * args.steps / elapsed / 1e9
+        result = {
+            "metric": "GF(2^8) multiply throughput (lookup mode, uint8, 1e8 elements per GPU)",
+            "value": round(value, 2),
+            "unit": "Gop/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "GF(2^8) mul, EXP/LOG-table (lookup) mode, 1e8 uint8 elements per GPU, "
+                                   "irreducible poly 0x11D (BASELINE.json configs[1])",
+                       "elements_per_gpu": n, "parallelism": f"batch-shard x{world}, no collectives"},
+            "roofline": roofline,
+        }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # bounded CPU sample: the same 1e8-element batch, repeated until >= 10 s of single-thread work
+        t_cpu, reps = 0.0, 0
+        F.ufunc_u8(O.MUL, x_h[:1_000_000], y_h[:1_000_000])
+        while t_cpu < 10.0 and reps < 64:
+            t1 = time.perf_counter()
+            F.ufunc_u8(O.MUL, x_h, y_h)
+            t_cpu += time.perf_counter() - t1
+            reps += 1
+        result["cpu_baseline"] = {"value": round(n * reps / t_cpu / 1e9, 4), "unit": "Gop/s", "cores": 1, "kind": "port",
+                                  "sample": f"{reps} x the full 1e8-element batch through oracle/gf_oracle.c "
+                                            f"(C restatement of the reference's jit-lookup multiply, -O3, 1 thread; "
+                                            f"host has {os.cpu_count()} cores)"}
+
+    if rank == 0 and not args.no_extras:
+        result["extra"] = extras(ga, L, lib, stream, world == 1 and not args.no_cpu_baseline)
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def extras(ga, L, lib, stream, with_cpu):
+    """The NTT and Reed-Solomon parts of the composite metric, on this rank's GPU (not part of the timed region)."""
+    from oracle import gf_oracle as O
+
+    ex = {}
+    ms = ctypes.c_float()
+    # ---- reciprocal, 2 B/element ----
+    GF = ga.GF(2**8)
+    n = N_ELEMENTS
+    a = torch.from_numpy(np.random.default_rng(2).integers(1, 256, n, dtype=np.uint8)).cuda()
+    o = torch.empty_like(a)
+    L.check(lib.gfa_time_unary(GF._handle, L.OP_RECIP, a.data_ptr(), o.data_ptr(), n, L.U8, stream, 50, ctypes.byref(ms)))
+    gbs = 2.0 * n / (ms.value * 1e-3) / 1e9
+    ex["gf256_reciprocal"] = {"Gop/s": round(n / (ms.value * 1e-3) / 1e9, 2), "kernel_ms": round(ms.value, 5),
+                              "roofline_frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_GB/s": round(gbs, 1)}
+    del a, o
+    # ---- NTT: 2^20 points over GF(7340033) (the modulus galois.ntt picks for that size), batch of 64 ----
+    for tag, p, logn, batch in (("ntt_2^20_gf7340033", 7340033, 20, 64), ("ntt_16x2^16_gf65537", 65537, 16, 16 * 64)):
+        P = ga.GF(p)
+        N = 1 << logn
+        omega = P._root_of_unity_int(N)
+        xh = np.random.default_rng(3).integers(0, p, (batch, N), dtype=np.uint32)
+        xd = torch.from_numpy(xh.view(np.int32)).cuda()
+        od = torch.empty_like(xd)
+        L.check(lib.gfa_time_ntt(P._handle, xd.data_ptr(), od.data_ptr(), N, batch, omega, L.U32, stream, 10, ctypes.byref(ms)))
+        points = batch * N
+        gbs = 8.0 * points / (ms.value * 1e-3) / 1e9
+        entry = {"transforms_per_s": round(batch / (ms.value * 1e-3), 1), "points_per_s": round(points / (ms.value * 1e-3), 0),
+                 "ms_per_launch": round(ms.value, 4), "batch": batch, "algorithmic_GB/s": round(gbs, 1),
+                 "roofline_frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_point": 8}
+        if logn == 20:
+            entry["2^20_pt_ntt_per_s"] = entry["transforms_per_s"]
+        else:
+            entry["2^20_points_per_s_equiv"] = round(points / (1 << 20) / (ms.value * 1e-3), 1)
+        # parity of one transform against the oracle port
+        FP = O.OracleField(p, 1, None, P._primitive_element_int)
+        ref = FP.ntt_u32_pow2(xh[0], omega)
+        assert np.array_equal(od[0].cpu().numpy().view(np.uint32), ref), "NTT differs from the oracle"
+        if with_cpu:
+            t1 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - t1 < 3.0:
+                FP.ntt_u32_pow2(xh[reps % batch], omega)
+                reps += 1
+            dt = time.perf_counter() - t1
+            entry["cpu_baseline"] = {"transforms_per_s": round(reps / dt, 2), "cores": 1, "kind": "port",
+                                     "sample": f"{reps} transforms of 2^{logn} points, oracle/gf_oracle.c"}
+        ex[tag] = entry
+        del xd, od
+    # ---- RS(255,223): 2^17 codewords per GPU (= 2^20 over 8 GPUs), e ~ U{0..16} errors per codeword ----
+    rs = ga.ReedSolomon(255, 223)
+    B = 1 << 17
+    rng = np.random.default_rng(4)
+    M = rng.integers(0, 256, (B, 223), dtype=np.uint8)
+    Md = torch.from_numpy(M).cuda()
+    Cd = torch.empty((B, 255), dtype=torch.uint8, device="cuda")
+    L.check(lib.gfa_time_rs_encode(rs._handle, Md.data_ptr(), 223, Cd.data_ptr(), B, L.U8, stream, 5, ctypes.byref(ms)))
+    enc_ms = ms.value
+    C = Cd.cpu().numpy()
+    rng5 = np.random.default_rng(5)
+    R = C.copy()
+    ne = rng5.integers(0, 17, B)
+    for i in range(B):
+        if ne[i]:
+            pos = rng5.choice(255, ne[i], replace=False)
+            R[i, pos] ^= rng5.integers(1, 256, ne[i], dtype=np.uint8)
+    Rd = torch.from_numpy(R).cuda()
+    Dd = torch.empty_like(Rd)
+    Ed = torch.empty(B, dtype=torch.int64, device="cuda")
+    L.check(lib.gfa_time_rs_decode(rs._handle, Rd.data_ptr(), 255, Dd.data_ptr(), Ed.data_ptr(), B, L.U8, stream, 5,
+                                   ctypes.byref(ms)))
+    dec_ms = ms.value
+    assert np.array_equal(Dd.cpu().numpy(), C) and np.array_equal(Ed.cpu().numpy(), ne), "RS round trip failed"
+    F = O.OracleField(2, 8, 285, 2, lookup=True)
+    OR = O.OracleRS(F, 255, 223)
+    assert np.array_equal(OR.encode_u8(M[:256]), C[:256]), "RS encode differs from the oracle"
+    ex["rs_255_223"] = {
+        "codewords": B, "errors_per_codeword": "uniform 0..16",
+        "encode_GB/s": round(255.0 * B / (enc_ms * 1e-3) / 1e9, 2), "encode_ms": round(enc_ms, 4),
+        "decode_GB/s": round(255.0 * B / (dec_ms * 1e-3) / 1e9, 2), "decode_ms": round(dec_ms, 4),
+        "encode+decode_GB/s": round(255.0 * B / ((enc_ms + dec_ms) * 1e-3) / 1e9, 2),
+        "encode_algorithmic_GB/s": round(478.0 * B / (enc_ms * 1e-3) / 1e9, 2),
+        "decode_algorithmic_GB/s": round(486.0 * B / (dec_ms * 1e-3) / 1e9, 2),
+        "encode_roofline_frac": round(478.0 * B / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+        "decode_roofline_frac": round(486.0 * B / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+        "note": "decode is LDS-gather bound, not HBM bound (SURVEY.md section 7)",
+    }
+    if with_cpu:
+        t1 = time.perf_counter()
+        OR.encode_u8(M[:2048])
+        te = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        OR.decode_u8(R[:2048])
+        td = time.perf_counter() - t1
+        ex["rs_255_223"]["cpu_baseline"] = {"encode_GB/s": round(255.0 * 2048 / te / 1e9, 5), "decode_GB/s": round(255.0 * 2048 / td / 1e9, 5),
+                                            "cores": 1, "kind": "port", "sample": "2048 codewords, oracle/gf_oracle.c"}
+    return ex
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,769 @@
+"""
+FieldArray: a finite-field array whose data lives in HBM (a PyTorch-ROCm tensor) and whose arithmetic runs in the
+HIP kernels behind the C-ABI (include/galois_amd.h).
+
+Host-side mirror of the reference's array domain -- same names, argument meaning and error behaviour for the hot
+path (reference paths relative to /root/reference/src/galois):
+  * construction / verification ........ _domains/_array.py:38-59, _fields/_array.py:129-215
+  * Zeros/Ones/Range/Random/Identity .... _domains/_array.py:159-316
+  * operator <-> ufunc routing .......... _domains/_ufunc.py:660-719 (UFuncMixin.__array_ufunc__) and the dispatcher
+                                          rules of _ufunc.py:180-266, 384-508
+  * np.fft.fft / np.fft.ifft ........... _domains/_function.py:177-212, 453-482
+The reference's FieldArray *is* an np.ndarray (host memory); this one *wraps* device memory and implements the NumPy
+protocols (__array_ufunc__, __array_function__, __array__), so `x * y`, `np.multiply(x, y)`, `np.reciprocal(x)`,
+`x ** 3`, `np.add.reduce(x)`, `np.fft.fft(x)` keep working.  There is no CPU arithmetic path: without the HIP library
+or a GPU every data operation raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Any
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+# NumPy dtypes in the reference's preference order (_domains/_meta.py:19)
+DTYPES = [np.uint8, np.uint16, np.uint32, np.int8, np.int16, np.int32, np.int64]
+
+# storage: unsigned 16/32/64-bit patterns are kept in the signed torch dtype of the same width (all torch ops exist
+# for those); the C-ABI only cares about the width
+_TORCH_STORAGE = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}
+_NP_SIGNED = {1: np.uint8, 2: np.int16, 4: np.int32, 8: np.int64}
+_GFA_DTYPE = {1: L.U8, 2: L.U16, 4: L.U32, 8: L.U64}
+
+
+def _device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "galois_amd needs a ROCm GPU: field arrays live in HBM and all arithmetic runs in HIP kernels "
+            "(there is deliberately no CPU fallback)."
+        )
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: torch.Tensor) -> int:
+    return t.data_ptr()
+
+
+class FieldArrayMeta(type):
+    """Class properties of a field (the reference keeps these on its metaclass too: _domains/_meta.py:112-203,
+    _fields/_meta.py:73-752)."""
+
+    def __repr__(cls) -> str:
+        if getattr(cls, "_order", 0) == 0:
+            return f"<class 'galois_amd.{cls.__name__}'>"
+        return f"<class 'galois_amd.{cls.name}'>"
+
+    @property
+    def name(cls) -> str:
+        if cls._degree == 1:
+            return f"GF({cls._characteristic})"
+        return f"GF({cls._characteristic}^{cls._degree})"
+
+    @property
+    def characteristic(cls) -> int:
+        return cls._characteristic
+
+    @property
+    def degree(cls) -> int:
+        return cls._degree
+
+    @property
+    def order(cls) -> int:
+        return cls._order
+
+    @property
+    def irreducible_poly(cls):
+        return cls._irreducible_poly
+
+    @property
+    def primitive_element(cls):
+        return cls(cls._primitive_element_int) if torch.cuda.is_available() else cls._primitive_element_int
+
+    @property
+    def is_prime_field(cls) -> bool:
+        return cls._degree == 1
+
+    @property
+    def is_extension_field(cls) -> bool:
+        return cls._degree > 1
+
+    @property
+    def prime_subfield(cls):
+        return cls._prime_subfield if cls._degree > 1 else cls
+
+    @property
+    def is_primitive_poly(cls) -> bool:
+        return cls._is_primitive_poly
+
+    @property
+    def dtypes(cls) -> list:
+        return list(cls._dtypes)
+
+    @property
+    def ufunc_mode(cls) -> str:
+        return "jit-lookup" if L.lib().gfa_field_get_mode(cls._handle) == L.MODE_LOOKUP else "jit-calculate"
+
+    @property
+    def ufunc_modes(cls) -> list[str]:
+        return list(cls._ufunc_modes)
+
+    @property
+    def default_ufunc_mode(cls) -> str:
+        return cls._default_ufunc_mode
+
+    @property
+    def properties(cls) -> str:
+        return (
+            f"Galois Field:\n  name: {cls.name}\n  characteristic: {cls.characteristic}\n  degree: {cls.degree}\n"
+            f"  order: {cls.order}\n  irreducible_poly: {cls._irreducible_poly}\n"
+            f"  is_primitive_poly: {cls._is_primitive_poly}\n  primitive_element: {cls._primitive_element_str}"
+        )
+
+
+class FieldArray(metaclass=FieldArrayMeta):
+    """An array over GF(p^m) resident on the GPU.  Instantiate through a class returned by `galois_amd.GF(...)`."""
+
+    # filled in by the factory (galois_amd/_factory.py)
+    _characteristic = 0
+    _degree = 1
+    _order = 0
+    _irreducible_poly = None
+    _primitive_element_int = 0
+    _primitive_element_str = ""
+    _is_primitive_poly = True
+    _prime_subfield = None
+    _dtypes: list = []
+    _ufunc_modes: list = []
+    _default_ufunc_mode = "jit-calculate"
+    _handle = None
+    _object_dtype = False  # True when the reference would use dtype=object (order-1)^2 > int64 max: stored as uint64
+
+    __array_priority__ = 100
+
+    # ------------------------------------------------------------------------------------------------------------
+    # construction
+    # ------------------------------------------------------------------------------------------------------------
+    def __init__(self, x: Any, dtype=None, copy: bool = True):
+        cls = type(self)
+        if cls._order == 0:
+            raise NotImplementedError(
+                "FieldArray is an abstract base class that cannot be directly instantiated. Instead, create a "
+                "FieldArray subclass for GF(p^m) arithmetic using `GF = galois_amd.GF(p**m)` and instantiate an array "
+                "using `x = GF(array_like)`."
+            )
+        np_dtype = cls._get_dtype(dtype)
+        if isinstance(x, FieldArray):
+            if type(x) is not cls:
+                raise TypeError(f"Cannot convert an array over {type(x).name} into an array over {cls.name}.")
+            t = x._t.clone() if copy else x._t
+            self._np_dtype = x._np_dtype
+            self._t = t
+            if dtype is not None and np.dtype(np_dtype) != np.dtype(x._np_dtype):
+                y = x.astype(np_dtype)
+                self._t, self._np_dtype = y._t, y._np_dtype
+            return
+        if isinstance(x, torch.Tensor):
+            self._t, self._np_dtype = cls._from_torch(x, np_dtype if dtype is not None else None, copy)
+            return
+        self._t, self._np_dtype = cls._from_host(x, np_dtype)
+
+    @classmethod
+    def _wrap(cls, t: torch.Tensor, np_dtype) -> "FieldArray":
+        obj = object.__new__(cls)
+        obj._t = t
+        obj._np_dtype = np.dtype(np_dtype)
+        return obj
+
+    @classmethod
+    def _get_dtype(cls, dtype):
+        if dtype is None:
+            return cls._dtypes[0]
+        if dtype is object or (not cls._object_dtype and np.dtype(dtype) == np.dtype(object)):
+            if cls._object_dtype:
+                return np.object_
+        if np.dtype(dtype) not in [np.dtype(d) for d in cls._dtypes]:
+            raise TypeError(
+                f"{cls.name} arrays only support dtypes {[np.dtype(d).name for d in cls._dtypes]}, not {np.dtype(dtype).name!r}."
+            )
+        return dtype
+
+    @classmethod
+    def _itemsize(cls, np_dtype) -> int:
+        return 8 if np.dtype(np_dtype) == np.dtype(object) else np.dtype(np_dtype).itemsize
+
+    @classmethod
+    def _verify_host(cls, x) -> np.ndarray:
+        """Element verification of array-likes (_fields/_array.py:129-180): integers in [0, order)."""
+        if isinstance(x, (int, np.integer)):
+            arr = np.array(int(x), dtype=object)
+        elif isinstance(x, np.ndarray):
+            arr = x
+        elif isinstance(x, (list, tuple)):
+            arr = np.array(x, dtype=object) if cls._object_dtype else np.array(x)
+            if arr.dtype == object and not cls._object_dtype:
+                arr = np.array(x, dtype=object)
+        else:
+            raise TypeError(
+                f"{cls.name} arrays can be created with scalars of type int, not {type(x)}."
+                if np.isscalar(x) else f"{cls.name} arrays cannot be created from {type(x)}."
+            )
+        if arr.dtype == object:
+            flat = arr.ravel()
+            for v in flat:
+                if not isinstance(v, (int, np.integer)):
+                    raise TypeError(f"{cls.name} arrays must have integer dtypes, not object elements of {type(v)}.")
+            if flat.size and (min(int(v) for v in flat) < 0 or max(int(v) for v in flat) >= cls._order):
+                raise ValueError(f"{cls.name} arrays must have elements in `0 <= x < {cls._order}`.")
+            if cls._order <= 2**63:
+                arr = arr.astype(np.int64)
+            else:
+                arr = np.array([int(v) for v in flat], dtype=np.uint64).reshape(arr.shape)
+            return arr
+        if not np.issubdtype(arr.dtype, np.integer):
+            raise TypeError(f"{cls.name} arrays must have integer dtypes, not {arr.dtype}.")
+        if arr.size:
+            mn, mx = arr.min(), arr.max()
+            if int(mn) < 0 or int(mx) >= cls._order:
+                raise ValueError(f"{cls.name} arrays must have elements in `0 <= x < {cls._order}`, not {[int(mn), int(mx)]}.")
+        return arr
+
+    @classmethod
+    def _from_host(cls, x, np_dtype):
+        arr = cls._verify_host(x)
+        size = cls._itemsize(np_dtype)
+        if np.dtype(np_dtype) == np.dtype(object):
+            store = arr.astype(np.uint64).view(np.int64)
+        else:
+            store = np.ascontiguousarray(arr.astype(np_dtype, copy=False)).view(_NP_SIGNED[size])
+        t = torch.from_numpy(np.ascontiguousarray(store)).to(_device())
+        return t, np.dtype(np_dtype)
+
+    @classmethod
+    def _from_torch(cls, x: torch.Tensor, np_dtype, copy: bool):
+        """Adopts a device tensor (zero-copy unless a cast is needed); verifies the range on the device."""
+        if x.is_floating_point() or x.is_complex() or x.dtype == torch.bool:
+            raise TypeError(f"{cls.name} arrays must have integer dtypes, not {x.dtype}.")
+        if np_dtype is None:
+            guess = {torch.uint8: np.uint8, torch.int8: np.int8, torch.int16: np.int16, torch.uint16: np.uint16,
+                     torch.int32: np.int32, torch.uint32: np.uint32, torch.int64: np.int64, torch.uint64: np.uint64}[x.dtype]
+            if cls._object_dtype:
+                np_dtype = np.object_
+            elif np.dtype(guess) in [np.dtype(d) for d in cls._dtypes]:
+                np_dtype = guess
+            else:
+                raise TypeError(f"{cls.name} arrays only support dtypes {[np.dtype(d).name for d in cls._dtypes]}, not {x.dtype}.")
+        size = cls._itemsize(np_dtype)
+        if x.element_size() == size:
+            t = x.view(_TORCH_STORAGE[size]) if x.dtype != _TORCH_STORAGE[size] else x
+        else:
+            t = x.to(torch.int64).to(_TORCH_STORAGE[size])
+            copy = False
+        if t.device.type != "cuda":
+            t = t.to(_device())
+            copy = False
+        if copy:
+            t = t.clone()
+        if not t.is_contiguous():
+            t = t.contiguous()
+        if t.numel():
+            if size == 8 and cls._order > 2**63:
+                ok = True  # full uint64 range check below
+                u = t
+                hi = cls._order
+                # unsigned compare via bias
+                bias = torch.tensor(-(2**63), dtype=torch.int64, device=t.device)
+                ok = bool(((u + bias) < (hi - 2**63)).all().item()) if hi < 2**64 else True
+            else:
+                tt = t if t.dtype != torch.uint8 else t.to(torch.int16)
+                ok = bool(((tt >= 0) & (tt < cls._order)).all().item()) if cls._order <= 2**63 - 1 else bool((tt >= 0).all().item())
+            if not ok:
+                raise ValueError(f"{cls.name} arrays must have elements in `0 <= x < {cls._order}`.")
+        return t, np.dtype(np_dtype)
+
+    # ---- alternate constructors (_domains/_array.py:159-316) -----------------------------------------------
+    @classmethod
+    def Zeros(cls, shape, dtype=None) -> "FieldArray":
+        np_dtype = cls._get_dtype(dtype)
+        shape = (shape,) if isinstance(shape, (int, np.integer)) else tuple(shape)
+        return cls._wrap(torch.zeros(shape, dtype=_TORCH_STORAGE[cls._itemsize(np_dtype)], device=_device()), np_dtype)
+
+    @classmethod
+    def Ones(cls, shape, dtype=None) -> "FieldArray":
+        np_dtype = cls._get_dtype(dtype)
+        shape = (shape,) if isinstance(shape, (int, np.integer)) else tuple(shape)
+        return cls._wrap(torch.ones(shape, dtype=_TORCH_STORAGE[cls._itemsize(np_dtype)], device=_device()), np_dtype)
+
+    @classmethod
+    def Range(cls, start: int, stop: int, step: int = 1, dtype=None) -> "FieldArray":
+        if not 0 <= start <= cls._order:
+            raise ValueError(f"Argument 'start' must be within the field's order {cls._order}, not {start}.")
+        if not 0 <= stop <= cls._order:
+            raise ValueError(f"Argument 'stop' must be within the field's order {cls._order}, not {stop}.")
+        np_dtype = cls._get_dtype(dtype)
+        if cls._order > 2**63:
+            return cls(np.array(list(range(start, stop, step)), dtype=object), dtype=dtype)
+        return cls(np.arange(start, stop, step, dtype=np.int64), dtype=np_dtype)
+
+    @classmethod
+    def Random(cls, shape=(), low: int = 0, high: int | None = None, seed=None, dtype=None) -> "FieldArray":
+        """Same bits as the reference for the same seed: rng.integers(low, high, shape, dtype) (_domains/_array.py:278-298)."""
+        np_dtype = cls._get_dtype(dtype)
+        high = cls._order if high is None else high
+        if not 0 <= low < high <= cls._order:
+            raise ValueError(f"Arguments must satisfy `0 <= low < high <= order`, not `0 <= {low} < {high} <= {cls._order}`.")
+        rng = np.random.default_rng(seed)
+        if np.dtype(np_dtype) != np.dtype(object):
+            arr = rng.integers(low, high, shape, dtype=np_dtype)
+        else:
+            # object dtype in the reference: random.randint per element seeded from the generator (_array.py:283-296)
+            import random as _random
+
+            _seed = int(rng.integers(0, 2**63))
+            _random.seed(_seed)
+            n = int(np.prod(shape)) if shape != () else 1
+            vals = [_random.randint(low, high - 1) for _ in range(n)]
+            arr = np.array(vals, dtype=object).reshape(shape)
+        return cls(arr, dtype=np_dtype)
+
+    @classmethod
+    def Identity(cls, size: int, dtype=None) -> "FieldArray":
+        np_dtype = cls._get_dtype(dtype)
+        return cls._wrap(torch.eye(size, dtype=_TORCH_STORAGE[cls._itemsize(np_dtype)], device=_device()), np_dtype)
+
+    # ---- field-level helpers ------------------------------------------------------------------------------
+    @classmethod
+    def compile(cls, mode: str):
+        """FieldArray.compile (_domains/_array.py:322-362).  "jit-lookup" = table kernels, "jit-calculate" = explicit
+        arithmetic kernels, "auto" = the device default.  "python-calculate" does not exist here."""
+        if mode not in ["auto"] + list(cls._ufunc_modes):
+            raise ValueError(f"Argument 'mode' must be in {['auto'] + list(cls._ufunc_modes)} for {cls.name}, not {mode!r}.")
+        m = {"auto": L.MODE_AUTO, "jit-lookup": L.MODE_LOOKUP, "jit-calculate": L.MODE_CALCULATE}[mode]
+        L.check(L.lib().gfa_field_set_mode(cls._handle, m), "compile")
+
+    @classmethod
+    def _scalar(cls, op: int, a: int, b: int = 0) -> int:
+        out = ctypes.c_uint64()
+        rc = L.lib().gfa_scalar(cls._handle, op, int(a), int(b) & (2**64 - 1), ctypes.byref(out))
+        if rc == L.ERR_INVALID and "division by zero" in L.last_error():
+            raise ZeroDivisionError("Cannot compute the multiplicative inverse of 0 in a Galois field.")
+        L.check(rc, "scalar arithmetic")
+        return out.value
+
+    @classmethod
+    def primitive_root_of_unity(cls, n: int):
+        """_fields/_array.py:1127-1187: alpha ** ((order - 1) // n)."""
+        if not isinstance(n, (int, np.integer)):
+            raise TypeError(f"Argument 'n' must be an instance of int, not {type(n)}.")
+        if not 1 <= n < cls._order:
+            raise ValueError(f"Argument 'n' must be in [1, {cls._order}), not {n}.")
+        if not (cls._order - 1) % n == 0:
+            raise ValueError(f"There are no primitive {n}-th roots of unity in {cls.name}.")
+        return cls._root_of_unity_int(int(n))
+
+    @classmethod
+    def _root_of_unity_int(cls, n: int) -> int:
+        e = (cls._order - 1) // n
+        # exponent may exceed int64 only if order > 2^63: reduce by square-and-multiply on the host in that case
+        if e < 2**63:
+            return cls._scalar(L.OP_POW, cls._primitive_element_int, e)
+        result, base = 1, cls._primitive_element_int
+        while e:
+            if e & 1:
+                result = cls._scalar(L.OP_MUL, result, base)
+            base = cls._scalar(L.OP_MUL, base, base)
+            e >>= 1
+        return result
+
+    @classmethod
+    def _tables(cls):
+        """(EXP, LOG, ZECH_LOG, ZECH_E) as int64 arrays in the reference's layout (cls._EXP etc.)."""
+        q = cls._order
+        E = np.zeros(2 * q, dtype=np.int64)
+        Lg = np.zeros(q, dtype=np.int64)
+        Z = np.zeros(q, dtype=np.int64)
+        ze = ctypes.c_int64()
+        L.check(L.lib().gfa_field_tables(cls._handle, E.ctypes.data_as(L._i64p), Lg.ctypes.data_as(L._i64p),
+                                         Z.ctypes.data_as(L._i64p), ctypes.byref(ze)), "tables")
+        return E, Lg, Z, ze.value
+
+    # ------------------------------------------------------------------------------------------------------------
+    # ndarray-like surface
+    # ------------------------------------------------------------------------------------------------------------
+    @property
+    def shape(self):
+        return tuple(self._t.shape)
+
+    @property
+    def ndim(self) -> int:
+        return self._t.dim()
+
+    @property
+    def size(self) -> int:
+        return self._t.numel()
+
+    @property
+    def dtype(self):
+        return self._np_dtype
+
+    @property
+    def device(self):
+        return self._t.device
+
+    @property
+    def T(self):
+        return type(self)._wrap(self._t.t().contiguous() if self._t.dim() == 2 else self._t.permute(*reversed(range(self._t.dim()))).contiguous(), self._np_dtype)
+
+    def __len__(self) -> int:
+        if self._t.dim() == 0:
+            raise TypeError("len() of unsized object")
+        return self._t.shape[0]
+
+    def torch(self) -> torch.Tensor:
+        """The underlying device tensor (storage dtype: same width as `dtype`; unsigned patterns in signed tensors)."""
+        return self._t
+
+    def numpy(self) -> np.ndarray:
+        host = self._t.cpu().numpy()
+        if self._np_dtype == np.dtype(object):
+            u = host.view(np.uint64)
+            out = np.empty(u.shape, dtype=object)
+            flat = out.ravel()
+            for i, v in enumerate(u.ravel()):
+                flat[i] = int(v)
+            return out
+        return host.view(self._np_dtype)
+
+    def __array__(self, dtype=None, copy=None):
+        arr = self.numpy()
+        return arr.astype(dtype) if dtype is not None else arr
+
+    def __int__(self) -> int:
+        if self.size != 1:
+            raise TypeError("only size-1 arrays can be converted to Python scalars")
+        return int(self.numpy().reshape(-1)[0])
+
+    __index__ = __int__
+
+    def __repr__(self) -> str:
+        body = np.array2string(self.numpy(), separator=", ", threshold=50)
+        order = f"{self._characteristic}^{self._degree}" if self._degree > 1 else f"{self._characteristic}"
+        return f"GF({body}, order={order})"
+
+    def __str__(self) -> str:
+        return np.array2string(self.numpy(), threshold=50)
+
+    def copy(self) -> "FieldArray":
+        return type(self)._wrap(self._t.clone(), self._np_dtype)
+
+    def reshape(self, *shape) -> "FieldArray":
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+        return type(self)._wrap(self._t.reshape(tuple(shape)), self._np_dtype)
+
+    def flatten(self) -> "FieldArray":
+        return type(self)._wrap(self._t.reshape(-1).clone(), self._np_dtype)
+
+    ravel = flatten
+
+    def astype(self, dtype) -> "FieldArray":
+        cls = type(self)
+        np_dtype = cls._get_dtype(dtype)  # TypeError for dtypes the field does not allow (_domains/_array.py:445-451)
+        size = cls._itemsize(np_dtype)
+        if size == self._t.element_size():
+            return cls._wrap(self._t.clone(), np_dtype)
+        return cls._wrap(self._t.to(torch.int64).to(_TORCH_STORAGE[size]), np_dtype)
+
+    def __getitem__(self, key) -> "FieldArray":
+        key = self._convert_key(key)
+        return type(self)._wrap(self._t[key], self._np_dtype)
+
+    def __setitem__(self, key, value):
+        cls = type(self)
+        key = self._convert_key(key)
+        if isinstance(value, FieldArray):
+            if type(value) is not cls:
+                raise TypeError(f"Cannot assign an array over {type(value).name} into an array over {cls.name}.")
+            v = value._t.to(self._t.dtype) if value._t.dtype != self._t.dtype else value._t
+        else:
+            v = cls(value, dtype=self._np_dtype if self._np_dtype != np.dtype(object) else None)._t  # verifies the range
+        self._t[key] = v
+
+    @staticmethod
+    def _convert_key(key):
+        def conv(k):
+            if isinstance(k, np.ndarray):
+                return torch.from_numpy(k).to("cuda")
+            if isinstance(k, FieldArray):
+                raise IndexError("field arrays are not valid indices")
+            return k
+        if isinstance(key, tuple):
+            return tuple(conv(k) for k in key)
+        return conv(key)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    def __eq__(self, other):
+        cls = type(self)
+        if isinstance(other, FieldArray):
+            if type(other) is not cls:
+                return NotImplemented
+            o = other._t if other._t.dtype == self._t.dtype else other._t.to(torch.int64).to(self._t.dtype)
+            return (self._t == o).cpu().numpy()
+        return self.numpy() == np.asarray(other)
+
+    def __ne__(self, other):
+        r = self.__eq__(other)
+        return r if r is NotImplemented else ~r
+
+    __hash__ = None
+
+    # ------------------------------------------------------------------------------------------------------------
+    # arithmetic
+    # ------------------------------------------------------------------------------------------------------------
+    def _gfa_dtype(self) -> int:
+        return _GFA_DTYPE[self._t.element_size()]
+
+    def _same_storage(self, other: "FieldArray") -> torch.Tensor:
+        """Other operand's tensor in this array's storage width (the result keeps `self.dtype`, _ufunc.py:675)."""
+        if other._t.element_size() == self._t.element_size():
+            return other._t
+        return other._t.to(torch.int64).to(self._t.dtype)
+
+    @staticmethod
+    def _broadcast(a: torch.Tensor, b: torch.Tensor):
+        """Returns (a, stride_a, b, stride_b, out_shape) with strides in {0, 1} for the C-ABI."""
+        if a.shape == b.shape:
+            return a.contiguous(), 1, b.contiguous(), 1, a.shape
+        out_shape = torch.broadcast_shapes(a.shape, b.shape)
+        if b.numel() == 1:
+            return a.expand(out_shape).contiguous() if a.shape != out_shape else a.contiguous(), 1, b.reshape(1), 0, out_shape
+        if a.numel() == 1:
+            return a.reshape(1), 0, b.expand(out_shape).contiguous() if b.shape != out_shape else b.contiguous(), 1, out_shape
+        return a.expand(out_shape).contiguous(), 1, b.expand(out_shape).contiguous(), 1, out_shape
+
+    def _check_err(self, err: torch.Tensor):
+        if int(err.item()) & L.DEVERR_ZERO_DIVISION:
+            raise ZeroDivisionError("Cannot compute the multiplicative inverse of 0 in a Galois field.")
+
+    def _binary(self, op: int, a: "FieldArray", b: "FieldArray") -> "FieldArray":
+        cls = type(self)
+        ta, tb = (a._t if a is self else self._same_storage(a)), (b._t if b is self else self._same_storage(b))
+        ta, sa, tb, sb, shape = self._broadcast(ta, tb)
+        out = torch.empty(shape, dtype=self._t.dtype, device=self._t.device)
+        n = out.numel()
+        err = torch.zeros(1, dtype=torch.int32, device=self._t.device) if op == L.OP_DIV else None
+        L.check(L.lib().gfa_binary(cls._handle, op, _ptr(ta), sa, _ptr(tb), sb, _ptr(out), n, self._gfa_dtype(), _stream(),
+                                   _ptr(err) if err is not None else None), "gfa_binary")
+        if err is not None:
+            self._check_err(err)
+        return cls._wrap(out, self._np_dtype)
+
+    def _unary(self, op: int) -> "FieldArray":
+        cls = type(self)
+        t = self._t.contiguous()
+        out = torch.empty_like(t)
+        err = torch.zeros(1, dtype=torch.int32, device=t.device) if op == L.OP_RECIP else None
+        L.check(L.lib().gfa_unary(cls._handle, op, _ptr(t), _ptr(out), t.numel(), self._gfa_dtype(), _stream(),
+                                  _ptr(err) if err is not None else None), "gfa_unary")
+        if err is not None:
+            self._check_err(err)
+        return cls._wrap(out, self._np_dtype)
+
+    def _int_operand(self, k, what: str) -> torch.Tensor:
+        """Integer scalar / integer ndarray -> device int64 tensor (np.power exponents, field*int multiplicands)."""
+        if isinstance(k, (int, np.integer)):
+            if not -(2**63) <= int(k) < 2**63:
+                raise ValueError(f"{what} must fit in int64 on the device, not {k}.")
+            return torch.tensor([int(k)], dtype=torch.int64, device=self._t.device).reshape(())
+        if isinstance(k, np.ndarray):
+            if k.dtype == object:
+                k = np.array([int(v) for v in k.ravel()], dtype=np.int64).reshape(k.shape)
+            if not np.issubdtype(k.dtype, np.integer):
+                raise ValueError(f"Operation requires operands with type np.ndarray to have integer dtype, not {k.dtype}.")
+            return torch.from_numpy(np.ascontiguousarray(k.astype(np.int64))).to(self._t.device)
+        if isinstance(k, torch.Tensor) and not k.is_floating_point():
+            return k.to(device=self._t.device, dtype=torch.int64)
+        raise TypeError(f"{what} must be an integer or an integer np.ndarray, not {type(k)}.")
+
+    def _with_int(self, k, is_pow: bool) -> "FieldArray":
+        cls = type(self)
+        tk = self._int_operand(k, "The exponent" if is_pow else "The integer multiplicand")
+        ta, sa, tk, sk, shape = self._broadcast(self._t, tk)
+        out = torch.empty(shape, dtype=self._t.dtype, device=self._t.device)
+        if is_pow:
+            err = torch.zeros(1, dtype=torch.int32, device=self._t.device)
+            L.check(L.lib().gfa_power(cls._handle, _ptr(ta), sa, _ptr(tk), sk, _ptr(out), out.numel(), self._gfa_dtype(),
+                                      _stream(), _ptr(err)), "gfa_power")
+            self._check_err(err)
+        else:
+            L.check(L.lib().gfa_scalar_multiply(cls._handle, _ptr(ta), sa, _ptr(tk), sk, _ptr(out), out.numel(),
+                                                self._gfa_dtype(), _stream()), "gfa_scalar_multiply")
+        return cls._wrap(out, self._np_dtype)
+
+    def _reduce(self, op: int, axis, keepdims: bool) -> "FieldArray":
+        cls = type(self)
+        t = self._t
+        if t.dim() == 0:
+            raise TypeError("cannot reduce on a scalar")
+        if axis is None:
+            t2 = t.reshape(1, -1)
+            out_shape = ()
+        else:
+            axis = axis % t.dim()
+            t2 = t.movedim(axis, -1).contiguous()
+            out_shape = tuple(t2.shape[:-1])
+            t2 = t2.reshape(-1, t2.shape[-1])
+        t2 = t2.contiguous()
+        out = torch.empty(t2.shape[0], dtype=t.dtype, device=t.device)
+        err = torch.zeros(1, dtype=torch.int32, device=t.device) if op == L.OP_DIV else None
+        L.check(L.lib().gfa_reduce(cls._handle, op, _ptr(t2), _ptr(out), t2.shape[0], t2.shape[1], self._gfa_dtype(),
+                                   _stream(), _ptr(err) if err is not None else None), "gfa_reduce")
+        if err is not None:
+            self._check_err(err)
+        out = out.reshape(out_shape)
+        if keepdims:
+            out = out.unsqueeze(axis if axis is not None else 0) if axis is not None else out.reshape((1,) * t.dim())
+        return cls._wrap(out, self._np_dtype)
+
+    # ---- NumPy ufunc protocol (UFuncMixin.__array_ufunc__, _domains/_ufunc.py:660-713) ----------------------
+    _UNARY_ONLY = (np.negative, np.reciprocal, np.square)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        cls = type(self)
+        if kwargs.get("out") is not None:
+            raise NotImplementedError("The `out=` keyword is not supported for device-resident field arrays.")
+        operands = list(range(len(inputs)))
+        field_ops = [i for i in operands if isinstance(inputs[i], cls)]
+        non_field = [i for i in operands if not isinstance(inputs[i], cls)]
+
+        def same_field():
+            if non_field:
+                raise TypeError(
+                    f"Operation {ufunc.__name__!r} requires both operands to be instances of {cls!r}, "
+                    f"not {[type(inputs[i]) for i in operands]}."
+                )
+
+        if ufunc in (np.add, np.subtract, np.multiply, np.true_divide, np.floor_divide):
+            op = {np.add: L.OP_ADD, np.subtract: L.OP_SUB, np.multiply: L.OP_MUL, np.true_divide: L.OP_DIV,
+                  np.floor_divide: L.OP_DIV}[ufunc]
+            if method == "__call__":
+                if ufunc is np.multiply and non_field:
+                    # field * integer = repeated addition with the integer reduced mod p (_ufunc.py:392-401)
+                    k = inputs[non_field[0]]
+                    if not isinstance(k, (int, np.integer, np.ndarray)):
+                        raise TypeError(
+                            f"Operation 'multiply' requires operands that are not {cls!r} arrays to be integers or an "
+                            f"integer np.ndarray, not {type(k)}."
+                        )
+                    return inputs[field_ops[0]]._with_int(k, is_pow=False)
+                same_field()
+                return self._binary(op, inputs[0], inputs[1])
+            if method == "reduce":
+                same_field()
+                return inputs[0]._reduce(op, kwargs.get("axis", 0), bool(kwargs.get("keepdims", False)))
+            if method == "outer":
+                same_field()
+                a, b = inputs
+                ta = a._t.reshape(tuple(a.shape) + (1,) * b.ndim)
+                tb = b._t.reshape((1,) * a.ndim + tuple(b.shape))
+                return self._binary(op, cls._wrap(ta, a._np_dtype), cls._wrap(tb, b._np_dtype))
+            raise NotImplementedError(f"Ufunc method {method!r} of {ufunc.__name__!r} is not implemented on the device.")
+        if ufunc in (np.negative, np.reciprocal):
+            if method != "__call__":
+                raise ValueError(
+                    f"Ufunc method {method!r} is not supported on {ufunc.__name__!r}. Reduction methods are only "
+                    "supported on binary functions."
+                )
+            return inputs[0]._unary(L.OP_NEG if ufunc is np.negative else L.OP_RECIP)
+        if ufunc is np.positive and method == "__call__":
+            return inputs[0].copy()
+        if ufunc is np.power or ufunc is np.square:
+            if ufunc is np.square:
+                if method != "__call__":
+                    raise ValueError(f"Ufunc method {method!r} is not supported on 'square'.")
+                return inputs[0]._with_int(2, is_pow=True)
+            if method in ("reduce", "accumulate", "reduceat"):
+                raise ValueError(
+                    f"Ufunc method {method!r} is not supported on 'power' because it takes inputs with type {cls!r} "
+                    "array and integer array. Different types do not support reduction."
+                )
+            if not isinstance(inputs[0], cls):
+                raise TypeError(f"Operation 'power' requires the first operand to be a {cls!r} array, not {type(inputs[0])}.")
+            if isinstance(inputs[1], FieldArray):
+                raise TypeError(f"Operation 'power' requires the second operand to be an integer array, not {type(inputs[1])}.")
+            if method != "__call__":
+                raise NotImplementedError(f"Ufunc method {method!r} of 'power' is not implemented on the device.")
+            return inputs[0]._with_int(inputs[1], is_pow=True)
+        if ufunc is np.divmod and method == "__call__":
+            same_field()
+            q = self._binary(L.OP_DIV, inputs[0], inputs[1])
+            return q, cls.Zeros(q.shape, dtype=self._np_dtype if self._np_dtype != np.dtype(object) else None)
+        if ufunc is np.remainder and method == "__call__":
+            same_field()
+            shape = torch.broadcast_shapes(inputs[0].shape, inputs[1].shape)
+            return cls.Zeros(tuple(shape), dtype=self._np_dtype if self._np_dtype != np.dtype(object) else None)
+        if ufunc in (np.equal, np.not_equal) and method == "__call__":
+            r = inputs[0].__eq__(inputs[1]) if isinstance(inputs[0], cls) else inputs[1].__eq__(inputs[0])
+            return r if ufunc is np.equal else ~r
+        raise NotImplementedError(
+            f"The NumPy ufunc {ufunc.__name__!r} is not supported on {cls.name} arrays."
+        )
+
+    # ---- NumPy function protocol (FunctionMixin.__array_function__, _domains/_function.py:453-482) ---------
+    def __array_function__(self, func, types, args, kwargs):
+        if func is np.fft.fft or func is np.fft.ifft:
+            from ._ntt import _field_fft
+
+            return _field_fft(args[0], inverse=func is np.fft.ifft, **{k: v for k, v in kwargs.items()},
+                              **({"n": args[1]} if len(args) > 1 else {}))
+        if func is np.convolve:
+            from ._ntt import _field_convolve
+
+            return _field_convolve(*args, **kwargs)
+        # anything else: plain NumPy on host copies (returns ndarrays, not field arrays)
+        def host(v):
+            if isinstance(v, FieldArray):
+                return v.numpy()
+            if isinstance(v, (list, tuple)):
+                return type(v)(host(e) for e in v)
+            return v
+        return func(*[host(a) for a in args], **{k: host(v) for k, v in kwargs.items()})
+
+    # ---- Python operators ---------------------------------------------------------------------------------
+    def __add__(self, o): return np.add(self, o)
+    def __radd__(self, o): return np.add(o, self)
+    def __iadd__(self, o):
+        r = np.add(self, o); self._t = r._t; return self
+    def __sub__(self, o): return np.subtract(self, o)
+    def __rsub__(self, o): return np.subtract(o, self)
+    def __isub__(self, o):
+        r = np.subtract(self, o); self._t = r._t; return self
+    def __mul__(self, o): return np.multiply(self, o)
+    def __rmul__(self, o): return np.multiply(o, self)
+    def __imul__(self, o):
+        r = np.multiply(self, o); self._t = r._t; return self
+    def __truediv__(self, o): return np.true_divide(self, o)
+    def __rtruediv__(self, o): return np.true_divide(o, self)
+    def __itruediv__(self, o):
+        r = np.true_divide(self, o); self._t = r._t; return self
+    def __floordiv__(self, o): return np.floor_divide(self, o)
+    def __rfloordiv__(self, o): return np.floor_divide(o, self)
+    def __mod__(self, o): return np.remainder(self, o)
+    def __divmod__(self, o): return np.divmod(self, o)
+    def __neg__(self): return np.negative(self)
+    def __pos__(self): return np.positive(self)
+    def __pow__(self, o): return np.power(self, o)  # _ufunc.py:715-719
+
+    def __matmul__(self, o):
+        raise NotImplementedError(
+            "General field matrix multiplication is outside this engine's hot path (SURVEY.md section 8(f) item 2); "
+            "Reed-Solomon encoding uses its own kernel (galois_amd.ReedSolomon.encode)."
+        )

@@ -1,0 +1,108 @@
+"""
+Multi-GPU use of the engine: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).
+
+New design -- the reference has no distributed path at all:
+  * element-wise ufuncs, batched NTTs and Reed-Solomon codewords are independent units: `shard_range` hands each
+    rank a contiguous slice, and there is NO data-path collective;
+  * one sequence too long for a single GPU uses the four-step decomposition with exactly one all-to-all
+    (`ntt_four_step_distributed`), with documented distributed input / output layouts.
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous [start, stop) slice of `total` independent units owned by `rank` (sizes differ by at most one)."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} out of range for world size {world}")
+    base, rem = divmod(total, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# distributed four-step NTT
+# ---------------------------------------------------------------------------------------------------------------------
+# View the length-N input as an (n1 x n2) row-major matrix x[j1*n2 + j2] (N = n1*n2, powers of two).
+#   input layout  ("column blocks"): rank g holds columns j2 in [g*n2/G, (g+1)*n2/G) as a local (n1 x n2/G) array.
+#   output layout ("row blocks of the transposed result"): rank g holds X[k1 + n1*k2] for k1 in [g*n1/G, (g+1)*n1/G),
+#                 all k2, as a local (n1/G x n2) array indexed [k1_local][k2].
+# Steps: (1) local length-n1 transforms of the owned columns and multiplication by w^(j2*k1)  [gfa_ntt_columns]
+#        (2) ONE all-to-all that turns column blocks into row blocks                          [RCCL over xGMI]
+#        (3) local length-n2 transforms of the owned rows                                     [gfa_ntt, batched]
+# `columns_to_local` / `local_to_natural` define the layouts for tests and for users who hold the data on one host.
+
+def columns_to_local(x_full: np.ndarray, rank: int, world: int, n1: int, n2: int) -> np.ndarray:
+    cols = n2 // world
+    return np.ascontiguousarray(x_full.reshape(n1, n2)[:, rank * cols:(rank + 1) * cols])
+
+
+def local_to_natural(parts: list[np.ndarray], n1: int, n2: int) -> np.ndarray:
+    """Reassembles the natural-order spectrum from every rank's (n1/G x n2) output block."""
+    world = len(parts)
+    rows = n1 // world
+    out = np.empty(n1 * n2, dtype=parts[0].dtype)
+    view = out.reshape(n2, n1)  # X[k1 + n1*k2] -> view[k2, k1]
+    for g, blk in enumerate(parts):
+        view[:, g * rows:(g + 1) * rows] = blk.reshape(rows, n2).T
+    return out
+
+
+def _device_column_pass(field, local: torch.Tensor, n1: int, cols: int, col0: int, n_total: int, omega: int) -> torch.Tensor:
+    from ._array import _GFA_DTYPE, _ptr, _stream
+
+    out = torch.empty_like(local)
+    L.check(L.lib().gfa_ntt_columns(field._handle, _ptr(local), _ptr(out), n1, cols, col0, n_total, omega,
+                                    _GFA_DTYPE[local.element_size()], _stream()), "gfa_ntt_columns")
+    return out
+
+
+def _device_row_pass(field, rows: torch.Tensor, n2: int, omega_n2: int) -> torch.Tensor:
+    from ._array import _GFA_DTYPE, _ptr, _stream
+
+    out = torch.empty_like(rows)
+    L.check(L.lib().gfa_ntt(field._handle, _ptr(rows), _ptr(out), n2, rows.numel() // n2, omega_n2, 0,
+                            _GFA_DTYPE[rows.element_size()], _stream()), "gfa_ntt")
+    return out
+
+
+def ntt_four_step_distributed(field, local_cols: torch.Tensor, n1: int, n2: int, omega: int | None = None, group=None,
+                              column_pass: Callable | None = None, row_pass: Callable | None = None) -> torch.Tensor:
+    """
+    One rank's part of a single length-(n1*n2) NTT over `field` spread over the ranks of `group`.
+
+    local_cols: (n1, n2/G) tensor in the field's device storage dtype (column-block input layout above).
+    Returns the (n1/G, n2) row-block output layout.  `column_pass` / `row_pass` default to the HIP kernels; the
+    CPU (gloo) tests inject oracle-backed stand-ins to exercise the exchange and the layout bookkeeping.
+    """
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_total = n1 * n2
+    cols = n2 // world
+    rows = n1 // world
+    if n2 % world or n1 % world:
+        raise ValueError("n1 and n2 must be divisible by the number of ranks")
+    if tuple(local_cols.shape) != (n1, cols):
+        raise ValueError(f"local_cols must have shape {(n1, cols)}, not {tuple(local_cols.shape)}")
+    if omega is None:
+        omega = field._root_of_unity_int(n_total)
+    column_pass = column_pass or _device_column_pass
+    row_pass = row_pass or _device_row_pass
+    # (1) columns: A[k1][c] = w^((col0+c)*k1) * sum_j1 x[j1][c] * w_n1^(j1*k1)
+    a = column_pass(field, local_cols.contiguous(), n1, cols, rank * cols, n_total, omega)
+    # (2) the one exchange: rank r receives, from every rank s, rows [r*rows, (r+1)*rows) of s's column block
+    recv = torch.empty((world, rows, cols), dtype=a.dtype, device=a.device)
+    dist.all_to_all_single(recv.view(-1), a.reshape(-1), group=group)
+    # recv[s][k1_local][c] is column s*cols + c of row k1_local -> (rows, n2) row-major
+    mine = recv.permute(1, 0, 2).reshape(rows, n2).contiguous()
+    # (3) rows: X[k1 + n1*k2] = sum_j2 A[k1][j2] * w_n2^(j2*k2),  w_n2 = w^n1
+    omega_n2 = field._scalar(L.OP_POW, omega, n1)
+    return row_pass(field, mine, n2, omega_n2)

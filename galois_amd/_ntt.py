@@ -1,0 +1,135 @@
+"""
+galois_amd.ntt / intt and the np.fft.fft / np.fft.ifft override on field arrays.
+
+Host-side mirror of the reference front ends (paths relative to /root/reference/src/galois):
+  * ntt, intt, _ntt .................. _ntt.py:16-278  (argument checks, default modulus, norm bookkeeping)
+  * fft_jit.__call__ / ifft_jit ....... _domains/_function.py:177-212 (pad/truncate to n, omega = alpha^((q-1)/n) or its
+                                        inverse, optional division by n)
+The transform itself is gfa_ntt (include/galois_amd.h) on the device.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from ._array import FieldArray, _ptr, _stream
+from ._numtheory import is_prime
+
+
+def _field_fft(x: FieldArray, n=None, axis=-1, norm=None, inverse: bool = False) -> FieldArray:
+    """np.fft.fft / np.fft.ifft on a 1-D field array (fft_jit.__call__, _domains/_function.py:177-212)."""
+    if not isinstance(x, FieldArray):
+        raise TypeError(f"Argument 'x' must be a field array, not {type(x)}.")
+    norm = "backward" if norm is None else norm
+    if not axis == -1:
+        raise ValueError("The FFT is only implemented on 1-D arrays.")
+    if norm not in ["forward", "backward"]:
+        raise ValueError("DFT normalization can only be applied to the forward or backward transform, not 'ortho'.")
+    if x.ndim != 1:
+        raise ValueError("The FFT is only implemented on 1-D arrays.")
+    scale = norm == ("backward" if inverse else "forward")
+    return _transform_rows(x, n, inverse, scale)
+
+
+def _transform_rows(x: FieldArray, n, inverse: bool, scale: bool) -> FieldArray:
+    """Transforms every row (last axis) of `x`; 1-D input = one row.  Rows are padded / truncated to n."""
+    cls = type(x)
+    t = x._t
+    length = t.shape[-1]
+    if n is None:
+        n = length
+    n = int(n)
+    if n < length:
+        t = t[..., :n]
+    elif n > length:
+        pad = torch.zeros(tuple(t.shape[:-1]) + (n - length,), dtype=t.dtype, device=t.device)
+        t = torch.cat([t, pad], dim=-1)
+    t = t.contiguous()
+    omega = cls.primitive_root_of_unity(n)  # ValueError if n does not divide q - 1 (_fields/_array.py:1182-1185)
+    if inverse:
+        omega = cls._scalar(L.OP_RECIP, omega)
+    out = torch.empty_like(t)
+    batch = t.numel() // n if n else 0
+    L.check(L.lib().gfa_ntt(cls._handle, _ptr(t), _ptr(out), n, batch, omega, 1 if scale else 0, x._gfa_dtype(), _stream()),
+            "gfa_ntt")
+    return cls._wrap(out, x._np_dtype)
+
+
+def fft_batched(x: FieldArray, inverse: bool = False, scaled: bool | None = None) -> FieldArray:
+    """Device extension (not in the reference, whose FFT is 1-D only): independent transforms of every row of a 2-D
+    array in one launch.  `scaled` defaults to the reference's convention (inverse divides by n)."""
+    if x.ndim != 2:
+        raise ValueError("fft_batched expects a 2-D array (batch, n).")
+    scale = inverse if scaled is None else bool(scaled)
+    return _transform_rows(x, None, inverse, scale)
+
+
+def _field_convolve(a: FieldArray, b: FieldArray, mode: str = "full"):
+    raise NotImplementedError(
+        "np.convolve on device field arrays is a 'next' row of the scope table (SURVEY.md section 8(f) item 1)."
+    )
+
+
+def _max_value(x) -> int:
+    if isinstance(x, FieldArray):
+        return int(x.numpy().max()) if x.size else 0
+    arr = np.asarray(x, dtype=object if not isinstance(x, np.ndarray) else None)
+    return int(max(int(v) for v in np.asarray(arr).ravel()))
+
+
+def _ntt(x, size=None, modulus=None, forward=True, scaled=True):
+    from ._factory import GF
+
+    for name, val in (("size", size), ("modulus", modulus)):
+        if val is not None and not isinstance(val, (int, np.integer)):
+            raise TypeError(f"Argument {name!r} must be an instance of int, not {type(val)}.")
+    if not isinstance(scaled, (bool, np.bool_)):
+        raise TypeError(f"Argument 'scaled' must be an instance of bool, not {type(scaled)}.")
+    if size is None:
+        size = len(x)
+    size = int(size)
+    max_x = _max_value(x)
+    if modulus is None:
+        m = int(np.ceil(max_x / size))  # the smallest m such that modulus > max(x) (_ntt.py:250-254)
+        while not is_prime(m * size + 1):
+            m += 1
+        modulus = m * size + 1
+    modulus = int(modulus)
+    if not size >= len(x):
+        raise ValueError(f"Argument 'size' must be at least the length of the input which is {len(x)}, not {size}.")
+    if not is_prime(modulus):
+        raise ValueError(f"Argument 'modulus' must be prime, {modulus} is not.")
+    if not (modulus - 1) % size == 0:
+        raise ValueError("Argument 'modulus' must equal m * size + 1, where 'size' is the size of the NTT transform.")
+    if not modulus > max_x:
+        raise ValueError(f"Argument 'modulus' must be at least the max value of the input which is {max_x}, not {modulus}.")
+    field = GF(modulus)
+    if isinstance(x, FieldArray) and type(x) is not field:
+        x = x.numpy()
+    xf = x if isinstance(x, FieldArray) else field(np.asarray(x, dtype=object) if modulus > 2**63 else x)
+    if forward:
+        return _field_fft(xf, n=size, inverse=False)
+    return _field_fft(xf, n=size, inverse=True, norm="backward" if scaled else "forward")
+
+
+def ntt(x, size: int | None = None, modulus: int | None = None) -> FieldArray:
+    """Number-theoretic transform of x over GF(p) (galois.ntt, _ntt.py:16-118)."""
+    if not isinstance(x, (tuple, list, np.ndarray, FieldArray)):
+        raise TypeError(f"Argument 'x' must be an instance of (tuple, list, np.ndarray, FieldArray), not {type(x)}.")
+    if isinstance(x, FieldArray) and not type(x).is_prime_field:
+        raise ValueError(f"If argument 'x' is a FieldArray, it must be a prime field, not {type(x)}.")
+    if modulus is None and isinstance(x, FieldArray):
+        modulus = type(x).characteristic
+    return _ntt(x, size=size, modulus=modulus, forward=True)
+
+
+def intt(X, size: int | None = None, modulus: int | None = None, scaled: bool = True) -> FieldArray:
+    """Inverse number-theoretic transform (galois.intt, _ntt.py:122-236)."""
+    if not isinstance(X, (tuple, list, np.ndarray, FieldArray)):
+        raise TypeError(f"Argument 'X' must be an instance of (tuple, list, np.ndarray, FieldArray), not {type(X)}.")
+    if isinstance(X, FieldArray) and not type(X).is_prime_field:
+        raise ValueError(f"If argument 'X' is a FieldArray, it must be a prime field, not {type(X)}.")
+    if modulus is None and isinstance(X, FieldArray):
+        modulus = type(X).characteristic
+    return _ntt(X, size=size, modulus=modulus, forward=False, scaled=scaled)

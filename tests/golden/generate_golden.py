@@ -1,0 +1,211 @@
+"""
+Generates the committed golden fixtures under tests/golden/ (run in the build container only):
+
+    PYTHONPATH=/root/repo python tests/golden/generate_golden.py
+
+Two sources, both the reference's own:
+  1. tests/golden/sage_fields_*.npz, sage_rs.npz -- the Sage/SymPy-generated vectors the reference's test-suite pins
+     this path with (/root/reference/tests/fields/data/*/{add,subtract,multiply,divide,additive_inverse,
+     multiplicative_inverse,scalar_multiply,power}.pkl, tests/codes/data/reed_solomon/*.pkl; loaders in
+     tests/fields/conftest.py:160-293 and tests/codes/conftest.py:65-138), re-packed as compressed .npz because the
+     pickles cannot travel to the GPU box.  Fields of order >= 2^64 are skipped (no device representation).
+  2. tests/golden/reference_outputs.npz -- outputs of the reference itself, imported in place from
+     /root/reference/src in its pure-Python mode (oracle/ref_shim), for the configurations that have no upstream
+     fixture: NTTs over GF(65537) / GF(7340033) / Goldilocks (+ the four SymPy KATs of tests/fields/test_ntt.py:13-18),
+     RS(255,223) encode/decode incl. erasures and uncorrectable words, GF(2^8)/GF(31)/Goldilocks element-wise samples.
+"""
+import glob
+import json
+import os
+import pickle
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, os.path.join(ROOT, "oracle", "ref_shim"))
+REF_TESTS = "/root/reference/tests"
+
+warnings.simplefilter("ignore")
+
+
+def small(a):
+    a = np.asarray(a)
+    if a.dtype == object:
+        a = np.array([int(v) for v in a.ravel()], dtype=np.uint64).reshape(a.shape)
+        return a
+    if a.dtype.kind in "iu" and a.size:
+        mx, mn = int(a.max()), int(a.min())
+        for dt in (np.uint8, np.uint16, np.uint32, np.int8, np.int16, np.int32):
+            if np.iinfo(dt).min <= mn and mx <= np.iinfo(dt).max:
+                return a.astype(dt)
+    return a
+
+
+def pack_sage_fields():
+    ops = ["add", "subtract", "multiply", "divide", "additive_inverse", "multiplicative_inverse", "scalar_multiply",
+           "power"]
+    for folder in sorted(os.listdir(os.path.join(REF_TESTS, "fields", "data"))):
+        path = os.path.join(REF_TESTS, "fields", "data", folder)
+        props = json.load(open(os.path.join(path, "properties.json")))
+        if props["order"] >= 2**64:
+            print("skip", folder)
+            continue
+        out = {"properties": np.array(json.dumps(props))}
+        for op in ops:
+            d = pickle.load(open(os.path.join(path, op + ".pkl"), "rb"))
+            for k, v in d.items():
+                out[f"{op}_{k}"] = small(v)
+        name = folder.replace("(", "_").replace(")", "").replace("^", "e").replace(", ", "_")
+        np.savez_compressed(os.path.join(HERE, f"sage_fields_{name}.npz"), **out)
+        print("packed", folder)
+
+
+def pack_sage_rs():
+    out = {}
+    names = []
+    for f in sorted(glob.glob(os.path.join(REF_TESTS, "codes", "data", "reed_solomon", "*.pkl"))):
+        d = pickle.load(open(f, "rb"))
+        key = os.path.basename(f)[:-4]
+        names.append(key)
+        meta = {k: d[k] for k in ("q", "n", "k", "d", "alpha", "c", "is_systematic", "is_primitive", "is_narrow_sense",
+                                  "generator_poly")}
+        out[f"{key}/meta"] = np.array(json.dumps(meta))
+        out[f"{key}/G"] = small(d["G"])
+        out[f"{key}/H"] = small(d["H"])
+        out[f"{key}/messages"] = small(d["encode"]["messages"])
+        out[f"{key}/codewords"] = small(d["encode"]["codewords"])
+        if d["encode_shortened"]:
+            out[f"{key}/short_messages"] = small(d["encode_shortened"]["messages"])
+            out[f"{key}/short_codewords"] = small(d["encode_shortened"]["codewords"])
+    out["names"] = np.array(json.dumps(names))
+    np.savez_compressed(os.path.join(HERE, "sage_rs.npz"), **out)
+    print("packed", len(names), "RS fixtures")
+
+
+def reference_outputs():
+    import load_reference
+
+    galois = load_reference.load()
+    rng = np.random.default_rng(20260925)
+    out = {}
+
+    def GFref(order, **kw):
+        return load_reference.ref_field(order, **kw)
+
+    # ---- element-wise samples (incl. zeros) ----
+    for tag, order, kw in [("gf256", 2**8, {}), ("gf31", 31, {}), ("gf65537", 65537, {}), ("gf7340033", 7340033, {}),
+                           ("goldilocks", 2**64 - 2**32 + 1, {}), ("gf2e32", 2**32, {}), ("gf3e5", 3**5, {}),
+                           ("gf251e3", 251**3, {})]:
+        GF = GFref(order, **kw)
+        n = 512
+        if order < 2**63:
+            a = rng.integers(0, order, n, dtype=np.uint64)
+            b = rng.integers(0, order, n, dtype=np.uint64)
+        else:
+            a = np.array([int(rng.integers(0, 2**63)) * 2 + int(rng.integers(0, 2)) for _ in range(n)], dtype=object) % order
+            b = np.array([int(rng.integers(0, 2**63)) * 2 + int(rng.integers(0, 2)) for _ in range(n)], dtype=object) % order
+            a = np.array([int(v) for v in a], dtype=np.uint64)
+            b = np.array([int(v) for v in b], dtype=np.uint64)
+        a[:4] = 0
+        b[2:6] = 0
+        ga, gb = GF([int(v) for v in a]), GF([int(v) for v in b])
+        bnz = np.where(b == 0, 1, b)
+        gbnz = GF([int(v) for v in bnz])
+        e = rng.integers(-50, 100, n)
+        anz = np.where(a == 0, 1, a)
+        ganz = GF([int(v) for v in anz])
+        out[f"ew/{tag}/meta"] = np.array(json.dumps({"p": int(GF.characteristic), "m": int(GF.degree),
+                                                     "irr": int(GF.irreducible_poly), "alpha": int(GF.primitive_element)}))
+        out[f"ew/{tag}/a"], out[f"ew/{tag}/b"], out[f"ew/{tag}/e"] = a, b, e
+        out[f"ew/{tag}/add"] = small(ga + gb)
+        out[f"ew/{tag}/sub"] = small(ga - gb)
+        out[f"ew/{tag}/mul"] = small(ga * gb)
+        out[f"ew/{tag}/neg"] = small(-ga)
+        out[f"ew/{tag}/div"] = small(ga / gbnz)
+        out[f"ew/{tag}/recip"] = small(gbnz**-1)
+        out[f"ew/{tag}/pow"] = small(ganz**e)
+        out[f"ew/{tag}/smul"] = small(ga * 7)
+        print("elementwise", tag)
+
+    # ---- NTT known answers from the reference's own tests (tests/fields/test_ntt.py:13-18, SymPy) ----
+    kats = [(5, [1, 2, 3, 4], None), (13, [1, 2, 3, 4], None), (17, [1, 2, 3, 4], None), (769, [1, 2, 3, 4], None)]
+    for p, x, _ in kats:
+        out[f"ntt/kat{p}/x"] = np.array(x)
+        out[f"ntt/kat{p}/X"] = small(galois.ntt(x, modulus=p))
+    # ---- reference NTT / INTT outputs ----
+    for tag, order, n in [("gf65537_256", 65537, 256), ("gf65537_4096", 65537, 4096), ("gf7340033_1024", 7340033, 1024),
+                          ("goldilocks_64", 2**64 - 2**32 + 1, 64), ("goldilocks_1024", 2**64 - 2**32 + 1, 1024),
+                          ("gf31_30", 31, 30), ("gf31_15", 31, 15), ("gf256_255", 2**8, 255), ("gf256_85", 2**8, 85),
+                          ("gf3e5_22", 3**5, 22), ("gf769_96", 769, 96)]:
+        GF = GFref(order)
+        if order < 2**63:
+            x = rng.integers(0, order, n, dtype=np.uint64)
+        else:
+            x = np.array([(int(rng.integers(0, 2**63)) * 2 + 1) % order for _ in range(n)], dtype=np.uint64)
+        gx = GF([int(v) for v in x])
+        out[f"ntt/{tag}/order"] = np.array(order, dtype=np.uint64)
+        out[f"ntt/{tag}/x"] = x
+        out[f"ntt/{tag}/fft"] = small(np.fft.fft(gx))
+        out[f"ntt/{tag}/ifft"] = small(np.fft.ifft(gx))
+        print("ntt", tag)
+
+    # ---- Reed-Solomon: RS(255,223) (no upstream fixture) and small codes with erasures ----
+    def rs_case(tag, order, n, k, c=1, N=12, field_kw=None, shorten=0):
+        GF = GFref(order, **(field_kw or {}))
+        rs = galois.ReedSolomon(n, k, field=GF, c=c)
+        ks, ns = k - shorten, n - shorten
+        t = (n - k) // 2
+        M = rng.integers(0, order, (N, ks))
+        C = np.asarray(rs.encode(GF(M))).astype(np.int64)
+        R = C.copy()
+        E = np.zeros((N, ns), dtype=bool)
+        plan = [(0, 0), (t, 0), (t + 1, 0), (t // 2, 0), (1, 0), (t + 3, 0), (0, 2), (t - 1, 2), (0, n - k), (0, n - k + 1),
+                (t // 2, (n - k) - 2 * (t // 2)), (1, n - k)]
+        for i in range(N):
+            ne, nu = plan[i % len(plan)]
+            ne, nu = min(ne, ns), min(nu, ns)
+            pos = rng.choice(ns, ne, replace=False)
+            R[i, pos] = (R[i, pos] + rng.integers(1, order, ne)) % order
+            if nu:
+                rest = np.setdiff1d(np.arange(ns), pos)
+                epos = rng.choice(rest, min(nu, rest.size), replace=False)
+                E[i, epos] = True
+                R[i, epos] = rng.integers(0, order, epos.size)
+        dec, nerr = rs.decode(GF(R), erasures=E, output="codeword", errors=True)
+        out[f"rs/{tag}/meta"] = np.array(json.dumps({"q": order, "n": n, "k": k, "c": c, "alpha": int(rs.alpha),
+                                                     "irr": int(GF.irreducible_poly), "p": int(GF.characteristic),
+                                                     "m": int(GF.degree), "field_alpha": int(GF.primitive_element)}))
+        out[f"rs/{tag}/generator_poly"] = small(rs.generator_poly.coeffs)
+        out[f"rs/{tag}/messages"] = small(M)
+        out[f"rs/{tag}/codewords"] = small(C)
+        out[f"rs/{tag}/received"] = small(R)
+        out[f"rs/{tag}/erasures"] = E
+        out[f"rs/{tag}/decoded"] = small(dec)
+        out[f"rs/{tag}/n_errors"] = np.asarray(nerr, dtype=np.int64)
+        out[f"rs/{tag}/detected"] = np.asarray(rs.detect(GF(R)))
+        print("rs", tag, list(nerr))
+
+    matlab = galois.matlab_primitive_poly(2, 8)
+    rs_case("rs255_223", 2**8, 255, 223, field_kw=dict(irreducible_poly=matlab))
+    rs_case("rs255_223_short", 2**8, 255, 223, field_kw=dict(irreducible_poly=matlab), shorten=55)
+    rs_case("rs15_9", 2**4, 15, 9)
+    rs_case("rs15_11_c3", 2**4, 15, 11, c=3)
+    rs_case("rs80_70_gf81", 3**4, 80, 70, c=2)
+    rs_case("rs26_20_gf27", 3**3, 26, 20)
+    rs_case("rs30_22_gf31", 31, 30, 22)
+    rs_case("rs85_65", 2**8, 85, 65)
+    # parity of message [0..222] (SURVEY.md 8(c) bootstrap KAT)
+    GF = GFref(2**8, irreducible_poly=matlab)
+    rs = galois.ReedSolomon(255, 223, field=GF)
+    out["rs/kat_arange_parity"] = small(rs.encode(GF(np.arange(223)), output="parity"))
+    np.savez_compressed(os.path.join(HERE, "reference_outputs.npz"), **out)
+
+
+if __name__ == "__main__":
+    pack_sage_fields()
+    pack_sage_rs()
+    reference_outputs()
+    print("done")

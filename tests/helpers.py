@@ -1,0 +1,54 @@
+"""Shared test helpers: golden-fixture loading and oracle construction (the oracle is the checker, never the product)."""
+import json
+import os
+
+import numpy as np
+
+from oracle import gf_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDILOCKS = 2**64 - 2**32 + 1
+
+SAGE_FIELDS = sorted(f[len("sage_fields_"):-4] for f in os.listdir(GOLDEN) if f.startswith("sage_fields_"))
+
+
+def load_sage_field(tag):
+    d = np.load(os.path.join(GOLDEN, f"sage_fields_{tag}.npz"))
+    props = json.loads(str(d["properties"]))
+    return props, d
+
+
+def poly_coeffs_to_int(coeffs, p):
+    v = 0
+    for c in coeffs:
+        v = v * p + int(c)
+    return v
+
+
+def oracle_field_from_props(props, lookup):
+    p, m = props["characteristic"], props["degree"]
+    irr = poly_coeffs_to_int(props["irreducible_poly"], p) if m > 1 else None
+    return O.OracleField(p, m, irr, int(props["primitive_element"]), lookup=lookup)
+
+
+def reference_outputs():
+    return np.load(os.path.join(GOLDEN, "reference_outputs.npz"))
+
+
+def sage_rs():
+    d = np.load(os.path.join(GOLDEN, "sage_rs.npz"))
+    names = json.loads(str(d["names"]))
+    return names, d
+
+
+def as_int_list(a):
+    return [int(v) for v in np.asarray(a).ravel()]
+
+
+def assert_equal_ints(actual, expected, msg=""):
+    a, e = np.asarray(actual), np.asarray(expected)
+    assert a.shape == e.shape, f"{msg}: shape {a.shape} != {e.shape}"
+    if a.dtype == object or e.dtype == object or a.dtype.kind != e.dtype.kind:
+        assert as_int_list(a) == as_int_list(e), msg
+    else:
+        assert np.array_equal(a, e), msg

@@ -1,0 +1,258 @@
+"""Parity of the element-wise HIP kernels (through the C-ABI, via the FieldArray API) against the golden fixtures and
+the oracle.  Bit-exact."""
+import json
+
+import numpy as np
+import pytest
+
+import galois_amd as ga
+from oracle import gf_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def field_from_props(props):
+    p, m = props["characteristic"], props["degree"]
+    if m == 1:
+        return ga.GF(p, primitive_element=int(props["primitive_element"]))
+    return ga.GF(p, m, irreducible_poly=[int(c) for c in props["irreducible_poly"]],
+                 primitive_element=int(props["primitive_element"]))
+
+
+@pytest.mark.parametrize("tag", H.SAGE_FIELDS)
+@pytest.mark.parametrize("mode", ["jit-lookup", "jit-calculate"])
+def test_sage_vectors(tag, mode):
+    """The reference's own Sage-generated arithmetic tables (tests/fields/test_arithmetic.py:17-199)."""
+    props, d = H.load_sage_field(tag)
+    GF = field_from_props(props)
+    if mode not in GF.ufunc_modes:
+        pytest.skip(f"{mode} is not legal for {GF.name}")
+    GF.compile(mode)
+    try:
+        rng = np.random.default_rng(1)
+        for dtype in [GF.dtypes[0], GF.dtypes[int(rng.integers(0, len(GF.dtypes)))], GF.dtypes[-1]]:
+            for op, fn in [("add", np.add), ("subtract", np.subtract), ("multiply", np.multiply), ("divide", np.true_divide)]:
+                x = GF(d[f"{op}_X"].astype(np.int64), dtype=dtype)
+                y = GF(d[f"{op}_Y"].astype(np.int64), dtype=dtype)
+                z = fn(x.reshape(-1, 1), y.reshape(1, -1))
+                assert type(z) is GF and z.dtype == np.dtype(dtype)
+                H.assert_equal_ints(z.numpy(), d[f"{op}_Z"], f"{tag} {op} {dtype}")
+            x = GF(d["additive_inverse_X"].astype(np.int64), dtype=dtype)
+            H.assert_equal_ints((-x).numpy(), d["additive_inverse_Z"])
+            x = GF(d["multiplicative_inverse_X"].astype(np.int64), dtype=dtype)
+            H.assert_equal_ints(np.reciprocal(x).numpy(), d["multiplicative_inverse_Z"])
+            H.assert_equal_ints((x**-1).numpy(), d["multiplicative_inverse_Z"])
+            x = GF(d["power_X"].astype(np.int64), dtype=dtype)
+            z = x.reshape(-1, 1) ** d["power_Y"].astype(np.int64).reshape(1, -1)
+            assert z.dtype == np.dtype(dtype)
+            H.assert_equal_ints(z.numpy(), d["power_Z"], f"{tag} power")
+            x = GF(d["scalar_multiply_X"].astype(np.int64), dtype=dtype)
+            z = x.reshape(-1, 1) * d["scalar_multiply_Y"].astype(np.int64).reshape(1, -1)
+            H.assert_equal_ints(z.numpy(), d["scalar_multiply_Z"], f"{tag} scalar multiply")
+    finally:
+        GF.compile("auto")
+
+
+@pytest.mark.parametrize("tag", ["gf256", "gf31", "gf65537", "gf7340033", "goldilocks", "gf2e32", "gf3e5", "gf251e3"])
+def test_reference_outputs(tag):
+    d = H.reference_outputs()
+    meta = json.loads(str(d[f"ew/{tag}/meta"]))
+    p, m = meta["p"], meta["m"]
+    GF = ga.GF(p, m, irreducible_poly=meta["irr"], primitive_element=meta["alpha"]) if m > 1 else ga.GF(p, primitive_element=meta["alpha"])
+    for mode in GF.ufunc_modes:
+        GF.compile(mode)
+        a, b, e = d[f"ew/{tag}/a"], d[f"ew/{tag}/b"], d[f"ew/{tag}/e"]
+        conv = (lambda v: np.array([int(t) for t in v], dtype=object)) if GF.order > 2**63 else (lambda v: v.astype(np.int64))
+        ga_, gb_ = GF(conv(a)), GF(conv(b))
+        gbnz, ganz = GF(conv(np.where(b == 0, 1, b))), GF(conv(np.where(a == 0, 1, a)))
+        H.assert_equal_ints((ga_ + gb_).numpy(), d[f"ew/{tag}/add"], "add")
+        H.assert_equal_ints((ga_ - gb_).numpy(), d[f"ew/{tag}/sub"], "sub")
+        H.assert_equal_ints((ga_ * gb_).numpy(), d[f"ew/{tag}/mul"], "mul")
+        H.assert_equal_ints((-ga_).numpy(), d[f"ew/{tag}/neg"], "neg")
+        H.assert_equal_ints((ga_ / gbnz).numpy(), d[f"ew/{tag}/div"], "div")
+        H.assert_equal_ints((gbnz**-1).numpy(), d[f"ew/{tag}/recip"], "recip")
+        H.assert_equal_ints((ganz**e).numpy(), d[f"ew/{tag}/pow"], "pow")
+        H.assert_equal_ints((ga_ * 7).numpy(), d[f"ew/{tag}/smul"], "smul")
+        H.assert_equal_ints((7 * ga_).numpy(), d[f"ew/{tag}/smul"], "rsmul")
+    GF.compile("auto")
+
+
+def test_gf256_full_size_1e8_bit_exact():
+    """BASELINE.json configs[1] at full size: 1e8 uint8 elements, every output byte compared with the oracle."""
+    n = 100_000_000
+    GF = ga.GF(2**8)
+    F = O.OracleField(2, 8, 285, 2, lookup=True)
+    x = np.random.default_rng(1).integers(0, 256, n, dtype=np.uint8)
+    y = np.random.default_rng(2).integers(0, 256, n, dtype=np.uint8)
+    gx, gy = GF(x), GF(y)
+    assert np.array_equal((gx * gy).numpy(), F.ufunc_u8(O.MUL, x, y))
+    ynz = np.random.default_rng(2).integers(1, 256, n, dtype=np.uint8)
+    gynz = GF(ynz)
+    r = np.reciprocal(gynz)
+    assert np.array_equal(r.numpy(), F.ufunc_u8(O.RECIP, ynz))
+    # size-independent properties: (x*y)/y == x ; x*y + x*z == x*(y+z)
+    assert np.array_equal(((gx * gynz) / gynz).numpy(), x)
+    z = GF(np.random.default_rng(3).integers(0, 256, n, dtype=np.uint8))
+    assert np.array_equal((gx * gy + gx * z).numpy(), (gx * (gy + z)).numpy())
+    with pytest.raises(ZeroDivisionError):
+        np.reciprocal(gy)  # contains zeros
+    with pytest.raises(ZeroDivisionError):
+        gx / gy
+
+
+def test_gf256_calculate_mode_and_wide_dtypes_large():
+    n = 5_000_003  # odd size: exercises the vector tail
+    GF = ga.GF(2**8)
+    F = O.OracleField(2, 8, 285, 2, lookup=True)
+    x = np.random.default_rng(11).integers(0, 256, n, dtype=np.uint8)
+    y = np.random.default_rng(12).integers(1, 256, n, dtype=np.uint8)
+    want_mul, want_div = F.ufunc_u8(O.MUL, x, y), F.ufunc_u8(O.DIV, x, y)
+    try:
+        for mode in ["jit-lookup", "jit-calculate"]:
+            GF.compile(mode)
+            for dtype in [np.uint8, np.int64, np.uint16]:
+                gx, gy = GF(x.astype(dtype)), GF(y.astype(dtype))
+                assert np.array_equal((gx * gy).numpy(), want_mul.astype(dtype)), (mode, dtype)
+                assert np.array_equal((gx / gy).numpy(), want_div.astype(dtype)), (mode, dtype)
+            # unaligned views (offset by one element) take the scalar path
+            gx, gy = GF(x)[1:], GF(y)[1:]
+            assert np.array_equal((gx * gy).numpy(), want_mul[1:])
+    finally:
+        GF.compile("auto")
+
+
+def test_gf31_config_c1_1e6():
+    """BASELINE.json configs[0]: GF(31) add / mul on 1e6 elements."""
+    GF = ga.GF(31)
+    F = O.OracleField(31, 1, None, 3)
+    x = np.random.default_rng(1).integers(0, 31, 1_000_000, dtype=np.uint8)
+    y = np.random.default_rng(2).integers(0, 31, 1_000_000, dtype=np.uint8)
+    for mode in GF.ufunc_modes:
+        GF.compile(mode)
+        assert np.array_equal((GF(x) + GF(y)).numpy(), F.add(x, y).astype(np.uint8))
+        assert np.array_equal((GF(x) * GF(y)).numpy(), F.mul(x, y).astype(np.uint8))
+    GF.compile("auto")
+
+
+@pytest.mark.parametrize("order", [65537, 7340033, 2147483647, 2**64 - 2**32 + 1, 2**32, 2**16, 3**5, 251**3,
+                                   18446744073709551557, 4294967291])
+def test_large_random_against_oracle(order):
+    GF = ga.GF(order)
+    p, m = GF.characteristic, GF.degree
+    F = O.OracleField(p, m, int(GF.irreducible_poly) if m > 1 else None, GF._primitive_element_int, lookup=order <= 2**16)
+    rng = np.random.default_rng(order % 7919)
+    n = 200_001
+    if order <= 2**63:
+        a, b = rng.integers(0, order, n, dtype=np.uint64), rng.integers(1, order, n, dtype=np.uint64)
+    else:
+        a = (rng.integers(0, 2**63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)) % np.uint64(order)
+        b = (rng.integers(0, 2**63, n, dtype=np.uint64) * np.uint64(2) + np.uint64(1)) % np.uint64(order)
+        b[b == 0] = 1
+    a[:3] = 0
+    mk = (lambda v: GF(np.array([int(t) for t in v], dtype=object))) if GF.dtypes == [np.object_] else (lambda v: GF(v.astype(GF.dtypes[-1])))
+    ga_, gb_ = mk(a), mk(b)
+    for mode in GF.ufunc_modes:
+        GF.compile(mode)
+        H.assert_equal_ints((ga_ + gb_).numpy().astype(np.uint64), F.add(a, b))
+        H.assert_equal_ints((ga_ - gb_).numpy().astype(np.uint64), F.sub(a, b))
+        H.assert_equal_ints((ga_ * gb_).numpy().astype(np.uint64), F.mul(a, b))
+        H.assert_equal_ints((ga_ / gb_).numpy().astype(np.uint64), F.div(a, b))
+        H.assert_equal_ints(np.reciprocal(gb_).numpy().astype(np.uint64), F.recip(b))
+        e = rng.integers(-1000, 1000, n)
+        H.assert_equal_ints((gb_**e).numpy().astype(np.uint64), F.pow(b, e))
+        H.assert_equal_ints((ga_**3).numpy().astype(np.uint64), F.pow(a, np.full(n, 3)))
+        H.assert_equal_ints(np.square(ga_).numpy().astype(np.uint64), F.mul(a, a))
+    GF.compile("auto")
+
+
+def test_reductions_and_outer():
+    for order in [2**8, 31, 3**5, 65537]:
+        GF = ga.GF(order)
+        p, m = GF.characteristic, GF.degree
+        F = O.OracleField(p, m, int(GF.irreducible_poly) if m > 1 else None, GF._primitive_element_int)
+        rng = np.random.default_rng(5)
+        a = rng.integers(1, order, (37, 1000)).astype(GF.dtypes[-1])
+        g = GF(a)
+        for mode in GF.ufunc_modes:
+            GF.compile(mode)
+            for ufunc, fold in [(np.add, F.add), (np.multiply, F.mul), (np.subtract, F.sub), (np.true_divide, F.div)]:
+                want = a[:, 0].astype(np.uint64)
+                for j in range(1, a.shape[1]):
+                    want = fold(want, a[:, j].astype(np.uint64))
+                got = ufunc.reduce(g, axis=1)
+                assert type(got) is GF and got.shape == (37,)
+                H.assert_equal_ints(got.numpy().astype(np.uint64), want, f"{order} {ufunc.__name__} reduce")
+            big = GF(rng.integers(1, order, 3_000_000).astype(GF.dtypes[0]))
+            want = 0
+            bh = big.numpy().astype(np.uint64)
+            # tree-vs-fold: add is associative, fold with the oracle in chunks
+            acc = bh[:1000].copy()
+            for s in range(1000, 3_000_000, 1000):
+                acc = F.add(acc, bh[s:s + 1000])
+            tot = np.uint64(0)
+            for v in acc:
+                tot = F.add([tot], [v])[0]
+            assert int(np.add.reduce(big).numpy()) == int(tot)
+            out = np.multiply.outer(GF(a[0, :50]), GF(a[1, :60]))
+            assert out.shape == (50, 60)
+            H.assert_equal_ints(out.numpy().astype(np.uint64), F.mul(a[0, :50, None].astype(np.uint64), a[1, None, :60].astype(np.uint64)))
+        GF.compile("auto")
+        with pytest.raises(ValueError):
+            np.negative.reduce(g)
+        with pytest.raises(ValueError):
+            np.power.reduce(g)
+
+
+def test_api_semantics_and_errors():
+    GF = ga.GF(2**8)
+    x = GF([1, 2, 3, 0], dtype=np.int32)
+    y = GF([5, 6, 7, 9])
+    assert (x * y).dtype == np.int32 and (y * x).dtype == np.uint8  # dtype of `self` is kept (_ufunc.py:675)
+    assert np.array_equal(np.asarray(x + y), [4, 4, 4, 9])
+    assert repr(GF([1, 2])) == "GF([1, 2], order=2^8)"
+    for bad in (lambda: x + 1, lambda: 1 + x, lambda: x - 1, lambda: x / 2, lambda: np.add(x, np.array([1, 2, 3, 4]))):
+        with pytest.raises(TypeError):
+            bad()
+    with pytest.raises(TypeError):
+        x ** y
+    with pytest.raises(TypeError):
+        x * 1.5
+    with pytest.raises(ZeroDivisionError):
+        x ** -1
+    with pytest.raises(ZeroDivisionError):
+        y / x
+    assert int((GF(0) ** 0)) == 1  # 0**0 == 1 (_lookup.py:262-263)
+    with pytest.raises(ValueError):
+        GF([256])
+    with pytest.raises(ValueError):
+        GF([-1])
+    with pytest.raises(TypeError):
+        GF([1.0])
+    with pytest.raises(TypeError):
+        GF([1], dtype=np.int8)
+    with pytest.raises(TypeError):
+        x.astype(np.float32)
+    with pytest.raises(NotImplementedError):
+        np.sin(x)
+    q, r = divmod(y, GF([1, 2, 3, 4]))
+    assert np.array_equal(r.numpy(), [0, 0, 0, 0]) and np.array_equal((y % y).numpy(), [0, 0, 0, 0])
+    # empty and 0-D arrays
+    e = GF(np.array([], dtype=np.uint8))
+    assert (e * e).shape == (0,) and np.reciprocal(e).shape == (0,)
+    s = GF(7)
+    assert s.shape == () and int(s * s) == int(GF([7])[0] * GF([7])[0])
+    z = GF.Zeros((3, 4)); o = GF.Ones((3, 4)); assert np.array_equal((z + o).numpy(), np.ones((3, 4)))
+    r1 = GF.Random((5, 6), seed=3)
+    assert np.array_equal(r1.numpy(), np.random.default_rng(3).integers(0, 256, (5, 6), dtype=np.uint8))
+    x[0] = 200
+    assert int(x[0]) == 200
+    with pytest.raises(ValueError):
+        x[0] = 300
+    # zero-copy adoption of a torch tensor
+    import torch
+    t = torch.arange(0, 256, dtype=torch.uint8, device="cuda")
+    v = GF(t, copy=False)
+    assert v.torch().data_ptr() == t.data_ptr()
+    with pytest.raises(ValueError):
+        ga.GF(31)(t)

@@ -1,0 +1,123 @@
+"""Parity of the device NTT against golden vectors and the oracle.  Bit-exact."""
+import json
+
+import numpy as np
+import pytest
+
+import galois_amd as ga
+from galois_amd import _numtheory as nt
+from galois_amd._ntt import fft_batched
+from oracle import gf_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def test_known_answers_from_reference_tests():
+    d = H.reference_outputs()
+    for p in (5, 13, 17, 769):
+        x = [int(v) for v in d[f"ntt/kat{p}/x"]]
+        X = ga.ntt(x, modulus=p)
+        H.assert_equal_ints(X.numpy(), d[f"ntt/kat{p}/X"], f"kat {p}")
+        assert type(X) is ga.GF(p)
+        H.assert_equal_ints(ga.intt(X).numpy(), x)
+    assert list(ga.ntt([1, 2, 3, 4], modulus=769).numpy()) == [10, 643, 767, 122]  # tests/fields/test_ntt.py:17
+    # default modulus (smallest prime m*N+1 > max) and zero padding (tests/fields/test_ntt.py:63-72)
+    assert type(ga.ntt([1, 2, 3, 4])) is ga.GF(5)
+    H.assert_equal_ints(ga.ntt([1, 2, 3, 4, 5, 6], size=8, modulus=17).numpy(), ga.ntt([1, 2, 3, 4, 5, 6, 0, 0], modulus=17).numpy())
+    # unscaled inverse (tests/fields/test_ntt.py:115-135)
+    X = ga.ntt([1, 2, 3, 4], modulus=13)
+    H.assert_equal_ints(ga.intt(X, scaled=False).numpy(), (np.array([1, 2, 3, 4]) * 4) % 13)
+
+
+def test_reference_generated_vectors():
+    d = H.reference_outputs()
+    tags = sorted({k.split("/")[1] for k in d.files if k.startswith("ntt/") and not k.startswith("ntt/kat")})
+    for tag in tags:
+        order = int(d[f"ntt/{tag}/order"])
+        GF = ga.GF(order)
+        x = d[f"ntt/{tag}/x"]
+        gx = GF(np.array([int(v) for v in x], dtype=object)) if order > 2**63 else GF(x.astype(np.int64))
+        for mode in GF.ufunc_modes:
+            GF.compile(mode)
+            H.assert_equal_ints(np.fft.fft(gx).numpy(), d[f"ntt/{tag}/fft"], tag + mode)
+            H.assert_equal_ints(np.fft.ifft(gx).numpy(), d[f"ntt/{tag}/ifft"], tag + mode + " inverse")
+        GF.compile("auto")
+
+
+@pytest.mark.parametrize("order,logn", [(65537, 1), (65537, 5), (65537, 10), (65537, 13), (65537, 14), (65537, 16),
+                                        (7340033, 12), (7340033, 17), (7340033, 20), (2**64 - 2**32 + 1, 12),
+                                        (2**64 - 2**32 + 1, 13), (2**64 - 2**32 + 1, 16), (2147483647 * 0 + 3221225473, 18),
+                                        (18446744069414584321 - 0, 20)])
+def test_power_of_two_sizes_against_oracle(order, logn):
+    n = 1 << logn
+    GF = ga.GF(order)
+    F = O.OracleField(order, 1, None, GF._primitive_element_int)
+    rng = np.random.default_rng(logn)
+    if order < 2**63:
+        x = rng.integers(0, order, n, dtype=np.uint64)
+        gx = GF(x.astype(GF.dtypes[0] if GF.dtypes != [np.object_] else np.int64))
+    else:
+        x = (rng.integers(0, 2**63, n, dtype=np.uint64) * np.uint64(2) + np.uint64(1)) % np.uint64(order)
+        gx = GF(np.array([int(v) for v in x], dtype=object))
+    omega = GF._root_of_unity_int(n)
+    want = F.ntt_u32_pow2(x.astype(np.uint32), omega).astype(np.uint64) if order < 2**31 else F.ntt(x, omega=omega)
+    X = np.fft.fft(gx)
+    H.assert_equal_ints(X.numpy().astype(np.uint64) if order < 2**63 else np.array([int(v) for v in X.numpy()], dtype=np.uint64), want)
+    back = np.fft.ifft(X)
+    H.assert_equal_ints(np.array([int(v) for v in back.numpy()], dtype=np.uint64), x)
+
+
+def test_batched_and_24bit_sizes():
+    # config C3(i): 16 x 2^16 points over GF(65537)
+    GF = ga.GF(65537)
+    F = O.OracleField(65537, 1, None, 3)
+    x = np.random.default_rng(3).integers(0, 65537, (16, 65536), dtype=np.uint32)
+    X = fft_batched(GF(x))
+    for i in (0, 7, 15):
+        H.assert_equal_ints(X.numpy()[i], F.ntt_u32_pow2(x[i], 3))
+    assert np.array_equal(fft_batched(X, inverse=True).numpy(), x)
+    # 2^24 points: round trip + linearity (size-independent properties; the oracle would take minutes)
+    G = ga.GF(7340033 * 0 + 469762049)  # 7 * 2^26 + 1
+    n = 1 << 24
+    a = G(np.random.default_rng(1).integers(0, 469762049, n, dtype=np.uint32))
+    b = G(np.random.default_rng(2).integers(0, 469762049, n, dtype=np.uint32))
+    A, B = np.fft.fft(a), np.fft.fft(b)
+    assert np.array_equal(np.fft.ifft(A).numpy(), a.numpy())
+    assert np.array_equal(np.fft.fft(a + b).numpy(), (A + B).numpy())
+    # X[0] = sum of inputs
+    assert int(A[0]) == int(np.add.reduce(a))
+
+
+@pytest.mark.parametrize("order,n", [(31, 30), (31, 15), (31, 6), (2**8, 255), (2**8, 85), (2**8, 51), (3**5, 242), (3**5, 22),
+                                     (5**3, 124), (769, 96), (65537, 3 * 0 + 4096), (7340033, 7 * 64), (2**64 - 2**32 + 1, 3 * 5 * 17)])
+def test_mixed_radix_against_oracle(order, n):
+    """tests/fields/test_fft.py:33-104: any length dividing q - 1, any field."""
+    GF = ga.GF(order)
+    p, m = GF.characteristic, GF.degree
+    F = O.OracleField(p, m, int(GF.irreducible_poly) if m > 1 else None, GF._primitive_element_int)
+    rng = np.random.default_rng(n)
+    x = np.array([int(v) % order for v in rng.integers(0, 2**62, n)], dtype=np.uint64)
+    gx = GF(np.array([int(v) for v in x], dtype=object)) if order > 2**63 else GF(x.astype(np.int64))
+    for mode in GF.ufunc_modes:
+        GF.compile(mode)
+        X = np.fft.fft(gx)
+        H.assert_equal_ints(np.array([int(v) for v in X.numpy()], dtype=np.uint64), F.ntt(x))
+        H.assert_equal_ints(np.array([int(v) for v in np.fft.ifft(X).numpy()], dtype=np.uint64), x)
+        # FFT == polynomial evaluation at omega^k (tests/fields/test_fft.py:33-45), checked on a few k
+        omega = GF._root_of_unity_int(n)
+        for k in (0, 1, n - 1):
+            pt = F.pow([omega], [k])
+            assert int(F.poly_eval(x[::-1].copy(), pt)[0]) == int(X[k])
+        # zero padding
+        if n >= 6:
+            Xp = np.fft.fft(gx[: n // 2], n=n)
+            xp = x.copy(); xp[n // 2:] = 0
+            H.assert_equal_ints(np.array([int(v) for v in Xp.numpy()], dtype=np.uint64), F.ntt(xp))
+    GF.compile("auto")
+    with pytest.raises(ValueError):
+        np.fft.fft(gx, n=n + 1 if (order - 1) % (n + 1) else 7 * n + 13)
+    with pytest.raises(ValueError):
+        np.fft.fft(gx, norm="ortho")
+    with pytest.raises(ValueError):
+        np.fft.fft(gx.reshape(1, -1))

@@ -1,0 +1,167 @@
+"""Parity of the Reed-Solomon kernels against golden vectors and the oracle.  Bit-exact."""
+import json
+
+import numpy as np
+import pytest
+
+import galois_amd as ga
+from oracle import gf_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sage_encode_fixtures():
+    """tests/codes/test_reed_solomon.py:98-133 (systematic codes; non-systematic codes have no device path yet)."""
+    names, d = H.sage_rs()
+    n_checked = 0
+    for key in names:
+        meta = json.loads(str(d[f"{key}/meta"]))
+        rs = ga.ReedSolomon(meta["n"], meta["k"], field=ga.GF(meta["q"]), alpha=meta["alpha"], c=meta["c"],
+                            systematic=meta["is_systematic"])
+        msgs = d[f"{key}/messages"].astype(np.int64)
+        if not meta["is_systematic"]:
+            with pytest.raises(NotImplementedError):
+                rs.encode(msgs)
+            continue
+        cw = rs.encode(msgs)
+        assert type(cw) is rs.field
+        H.assert_equal_ints(cw.numpy(), d[f"{key}/codewords"], key)
+        H.assert_equal_ints(rs.encode(msgs[0]).numpy(), d[f"{key}/codewords"][0], key + " 1-D")
+        H.assert_equal_ints(rs.encode(msgs, output="parity").numpy(), d[f"{key}/codewords"][:, meta["k"]:], key + " parity")
+        H.assert_equal_ints(rs.encode(msgs.tolist()).numpy(), d[f"{key}/codewords"], key + " list input")
+        if f"{key}/short_messages" in d:
+            H.assert_equal_ints(rs.encode(d[f"{key}/short_messages"].astype(np.int64)).numpy(), d[f"{key}/short_codewords"], key + " shortened")
+        assert not rs.detect(cw).any()
+        # round trip with <= t errors (tests/codes/conftest.py:174-228)
+        rng = np.random.default_rng(7)
+        R = d[f"{key}/codewords"].astype(np.int64).copy()
+        ne = rng.integers(0, rs.t + 1, R.shape[0])
+        for i in range(R.shape[0]):
+            pos = rng.choice(meta["n"], ne[i], replace=False)
+            R[i, pos] = (R[i, pos] + rng.integers(1, meta["q"], ne[i])) % meta["q"]
+        dec, nerr = rs.decode(R, errors=True)
+        H.assert_equal_ints(dec.numpy(), msgs, key + " decode")
+        assert np.array_equal(nerr, ne)
+        n_checked += 1
+    assert n_checked >= 20
+
+
+def test_reference_generated_cases():
+    d = H.reference_outputs()
+    tags = sorted({k.split("/")[1] for k in d.files if k.startswith("rs/") and k.endswith("/meta")})
+    for tag in tags:
+        meta = json.loads(str(d[f"rs/{tag}/meta"]))
+        GF = ga.GF(meta["p"], meta["m"], irreducible_poly=meta["irr"], primitive_element=meta["field_alpha"]) if meta["m"] > 1 \
+            else ga.GF(meta["p"], primitive_element=meta["field_alpha"])
+        rs = ga.ReedSolomon(meta["n"], meta["k"], field=GF, c=meta["c"], alpha=meta["alpha"])
+        H.assert_equal_ints(rs.generator_poly.coeffs, d[f"rs/{tag}/generator_poly"])
+        M = d[f"rs/{tag}/messages"].astype(np.int64)
+        H.assert_equal_ints(rs.encode(M).numpy(), d[f"rs/{tag}/codewords"], tag + " encode")
+        R, E = d[f"rs/{tag}/received"].astype(np.int64), d[f"rs/{tag}/erasures"]
+        dec, nerr = rs.decode(R, erasures=E, output="codeword", errors=True)
+        assert np.array_equal(nerr, d[f"rs/{tag}/n_errors"]), (tag, nerr, d[f"rs/{tag}/n_errors"])
+        H.assert_equal_ints(dec.numpy(), d[f"rs/{tag}/decoded"], tag + " decoded")
+        assert np.array_equal(rs.detect(R), d[f"rs/{tag}/detected"]), tag + " detect"
+        # 1-D forms
+        d1, n1 = rs.decode(R[1], erasures=E[1], output="codeword", errors=True)
+        assert isinstance(n1, int) and n1 == int(d[f"rs/{tag}/n_errors"][1])
+        H.assert_equal_ints(d1.numpy(), d[f"rs/{tag}/decoded"][1])
+        ks = M.shape[1]
+        H.assert_equal_ints(rs.decode(R[:2], erasures=E[:2]).numpy(), d[f"rs/{tag}/decoded"][:2, :ks])
+    rs = ga.ReedSolomon(255, 223)
+    H.assert_equal_ints(rs.encode(np.arange(223), output="parity").numpy(), d["rs/kat_arange_parity"])
+
+
+@pytest.mark.parametrize("q,n,k,c", [(2**8, 255, 223, 1), (2**8, 255, 239, 0), (2**8, 85, 65, 1), (2**4, 15, 9, 2), (3**4, 80, 60, 1),
+                                     (3**3, 26, 20, 1), (31, 30, 22, 1), (2**8, 255, 127, 1), (5**3, 124, 100, 3)])
+def test_random_batches_against_oracle(q, n, k, c):
+    if q == 2**8:
+        rs = ga.ReedSolomon(n, k, c=c)
+    else:
+        rs = ga.ReedSolomon(n, k, field=ga.GF(q), c=c)
+    GF = rs.field
+    p, m = GF.characteristic, GF.degree
+    F = O.OracleField(p, m, int(GF.irreducible_poly) if m > 1 else None, GF._primitive_element_int, lookup=True)
+    R_ = O.OracleRS(F, n, k, alpha=rs.alpha, c=c)
+    rng = np.random.default_rng(n * 1000 + k)
+    N = 1500
+    for shorten in (0, min(5, k - 1)):
+        ks, ns = k - shorten, n - shorten
+        M = rng.integers(0, q, (N, ks)).astype(np.uint8)
+        C = rs.encode(M).numpy()
+        assert np.array_equal(C, R_.encode_u8(M))
+        R = C.copy()
+        E = np.zeros((N, ns), dtype=bool)
+        t = (n - k) // 2
+        for i in range(N):
+            ne = int(rng.integers(0, t + 3))
+            nu = int(rng.integers(0, n - k + 2)) if i % 3 == 0 else 0
+            pos = rng.choice(ns, min(ne, ns), replace=False)
+            R[i, pos] = (R[i, pos].astype(np.int64) + rng.integers(1, q, pos.size)) % q
+            if nu:
+                epos = rng.choice(ns, min(nu, ns), replace=False)
+                E[i, epos] = True
+                R[i, epos] = rng.integers(0, q, epos.size)
+        dec, nerr = rs.decode(R, erasures=E, output="codeword", errors=True)
+        odec, onerr = R_.decode_u8(R, E)
+        assert np.array_equal(nerr, onerr), np.nonzero(nerr != onerr)[0][:10]
+        assert np.array_equal(dec.numpy(), odec)
+        dec2, nerr2 = rs.decode(R, output="codeword", errors=True)
+        odec2, onerr2 = R_.decode_u8(R)
+        assert np.array_equal(nerr2, onerr2) and np.array_equal(dec2.numpy(), odec2)
+        assert np.array_equal(rs.detect(R), R_.detect(R))
+
+
+def test_full_size_2e20_codewords_round_trip():
+    """BASELINE.json configs[3] at full size (one GPU holds all 2^20 codewords here): encode -> corrupt -> decode."""
+    rs = ga.ReedSolomon(255, 223)
+    B = 1 << 20
+    rng = np.random.default_rng(4)
+    M = rng.integers(0, 256, (B, 223), dtype=np.uint8)
+    C = rs.encode(M)
+    Ch = C.numpy()
+    assert np.array_equal(Ch[:, :223], M)
+    assert not rs.detect(C).any()
+    # errors: e_i ~ U{0..16} at random positions -- vectorised construction (argsort of random keys)
+    ne = rng.integers(0, 17, B)
+    keys = rng.random((B, 255), dtype=np.float32)
+    order = np.argsort(keys, axis=1)[:, :16]
+    R = Ch.copy()
+    mask = np.arange(16)[None, :] < ne[:, None]
+    rows = np.repeat(np.arange(B), 16).reshape(B, 16)
+    vals = rng.integers(1, 256, (B, 16), dtype=np.uint8)
+    R[rows[mask], order[mask]] ^= vals[mask]
+    dec, nerr = rs.decode(R, output="codeword", errors=True)
+    assert np.array_equal(nerr, ne)
+    assert np.array_equal(dec.numpy(), Ch)
+    assert np.array_equal(rs.detect(R), ne > 0)
+    # oracle on a bounded sample
+    F = O.OracleField(2, 8, 285, 2, lookup=True)
+    OR = O.OracleRS(F, 255, 223)
+    sel = rng.choice(B, 512, replace=False)
+    assert np.array_equal(OR.encode_u8(M[sel]), Ch[sel])
+    od, on = OR.decode_u8(R[sel])
+    assert np.array_equal(od, Ch[sel]) and np.array_equal(on, ne[sel])
+
+
+def test_front_end_errors():
+    rs = ga.ReedSolomon(15, 9)
+    with pytest.raises(ValueError):
+        rs.encode(np.zeros(10, dtype=int))
+    with pytest.raises(ValueError):
+        rs.encode(np.zeros((2, 2, 9), dtype=int))
+    with pytest.raises(ValueError):
+        rs.encode([1, 2, 3], output="message")
+    with pytest.raises(ValueError):
+        rs.decode(np.zeros(6, dtype=int))  # shorter than n-k+1
+    with pytest.raises(ValueError):
+        rs.decode(np.zeros(15, dtype=int), output="parity")
+    with pytest.raises(ValueError):
+        rs.encode([16] * 9)
+    with pytest.raises(TypeError):
+        rs.decode(np.zeros(15, dtype=int), erasures=np.zeros(15, dtype=int))
+    with pytest.raises(ValueError):
+        rs.decode(np.zeros(15, dtype=int), erasures=np.zeros(14, dtype=bool))
+    m, n = rs.decode(np.zeros(15, dtype=int), errors=True)
+    assert n == 0 and m.shape == (9,)

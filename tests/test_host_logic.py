@@ -1,0 +1,198 @@
+"""CPU-only tests of the host side: C-ABI surface, field factory, number theory, RS construction.  No compute calls."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import galois_amd as ga
+from galois_amd import _lib as L
+from galois_amd import _numtheory as nt
+from oracle import gf_oracle as O
+from tests import helpers as H
+
+
+def test_library_exports_every_declared_symbol(repo_root):
+    header = open(os.path.join(repo_root, "include", "galois_amd.h")).read()
+    declared = set(re.findall(r"\b(gfa_[a-z0-9_]+)\s*\(", header))
+    declared -= {"gfa_field_t", "gfa_rs_t", "gfa_stream_t"}
+    lib = ctypes.CDLL(L.LIB_PATH)
+    missing = [name for name in sorted(declared) if not hasattr(lib, name)]
+    assert not missing, f"not exported: {missing}"
+    assert declared == set(L.SIGNATURES), f"binding/header mismatch: {declared ^ set(L.SIGNATURES)}"
+    assert lib.gfa_abi_version() == 1
+
+
+def test_product_never_touches_the_oracle(repo_root):
+    pkg = os.path.join(repo_root, "galois_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "gf_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f
+                assert "/root/reference" not in text.replace("/root/reference/src/galois", "REFDOC"), f
+
+
+def test_flyweights_and_properties():
+    GF = ga.GF(2**8)
+    assert ga.GF(2, 8) is GF and ga.GF(256) is GF
+    assert ga.GF2 is ga.GF(2)
+    assert GF.name == "GF(2^8)" and GF.characteristic == 2 and GF.degree == 8 and GF.order == 256
+    assert int(GF.irreducible_poly) == 285 and str(GF.irreducible_poly) == "x^8 + x^4 + x^3 + x^2 + 1"
+    assert GF.is_extension_field and not GF.is_prime_field and GF.prime_subfield is ga.GF(2)
+    assert GF.ufunc_modes == ["jit-lookup", "jit-calculate"] and GF.ufunc_mode == "jit-lookup"
+    GF.compile("jit-calculate")
+    assert GF.ufunc_mode == "jit-calculate"
+    GF.compile("auto")
+    assert GF.ufunc_mode == GF.default_ufunc_mode == "jit-lookup"
+    with pytest.raises(ValueError):
+        GF.compile("python-calculate")
+    aes = ga.GF(2**8, irreducible_poly=283)
+    assert aes is not GF and aes._primitive_element_int == 3 and not aes.is_primitive_poly
+    assert aes is ga.GF(2**8, irreducible_poly="x^8 + x^4 + x^3 + x + 1", primitive_element=3)
+    with pytest.raises(ValueError):
+        ga.GF(2**8, irreducible_poly=0x11D + 1)  # reducible
+    with pytest.raises(ValueError):
+        ga.GF(2**8, primitive_element=1)  # not a generator
+    with pytest.raises(ValueError):
+        ga.GF(6)
+    with pytest.raises(ValueError):
+        ga.GF(31, primitive_element=5)
+    with pytest.raises(TypeError):
+        ga.GF(2.0)
+    with pytest.raises(NotImplementedError):
+        ga.GF(2**100)
+
+
+def test_dtypes_follow_the_reference_rules():
+    # SURVEY.md 8(a1), probed on the reference
+    names = lambda F: [np.dtype(d).name for d in F.dtypes]
+    assert names(ga.GF(31)) == ["uint8", "uint16", "uint32", "int8", "int16", "int32", "int64"]
+    assert names(ga.GF(2**8)) == ["uint8", "uint16", "uint32", "int16", "int32", "int64"]
+    assert names(ga.GF(65537)) == ["uint32", "int32", "int64"]
+    assert names(ga.GF(7340033)) == ["uint32", "int32", "int64"]
+    assert names(ga.GF(2**64 - 2**32 + 1)) == ["object"]
+    assert names(ga.GF(2**32)) == ["uint32", "int64"]
+    assert names(ga.GF(2147483647)) == ["uint32", "int32", "int64"]
+    assert ga.GF(31).ufunc_mode == "jit-calculate" and ga.GF(3**5).ufunc_mode == "jit-lookup"
+
+
+@pytest.mark.parametrize("order", [2**8, 31, 3**5, 5**3, 2**4, 65537])
+def test_lookup_tables_match_oracle(order):
+    GF = ga.GF(order)
+    p, m = GF.characteristic, GF.degree
+    F = O.OracleField(p, m, int(GF.irreducible_poly) if m > 1 else None, GF._primitive_element_int, lookup=True)
+    E, Lg, Z, ze = GF._tables()
+    oe, ol, oz, oze = F.tables()
+    assert np.array_equal(E, oe) and np.array_equal(Lg, ol) and np.array_equal(Z, oz) and ze == oze
+    if order == 2**8:  # SURVEY.md 8(c) constants
+        assert list(E[:10]) == [1, 2, 4, 8, 16, 32, 64, 128, 29, 58] and list(Lg[:10]) == [0, 0, 1, 25, 2, 50, 26, 198, 3, 223]
+
+
+@pytest.mark.parametrize("order", [2**8, 31, 7**3, 65537, 7340033, 2**64 - 2**32 + 1, 2**32, 2147483647, 251**3,
+                                   18446744073709551557])
+def test_host_scalar_arithmetic_matches_oracle(order):
+    """gfa_scalar runs the same formulas as the kernels (gfa_arith.h compiled for the host)."""
+    GF = ga.GF(order)
+    p, m = GF.characteristic, GF.degree
+    F = O.OracleField(p, m, int(GF.irreducible_poly) if m > 1 else None, GF._primitive_element_int)
+    rng = np.random.default_rng(order % 1000)
+    n = 300
+    a = [int(rng.integers(0, 2**63)) * 2 % order for _ in range(n)]
+    b = [(int(rng.integers(0, 2**63)) * 2 + 1) % order for _ in range(n)]
+    a[0] = 0
+    a[1] = order - 1
+    b[1] = order - 1
+    oa, ob = np.array(a, dtype=object), np.array(b, dtype=object)
+    bnz = [v or 1 for v in b]
+    assert [GF._scalar(L.OP_ADD, x, y) for x, y in zip(a, b)] == H.as_int_list(F.add(oa, ob))
+    assert [GF._scalar(L.OP_SUB, x, y) for x, y in zip(a, b)] == H.as_int_list(F.sub(oa, ob))
+    assert [GF._scalar(L.OP_MUL, x, y) for x, y in zip(a, b)] == H.as_int_list(F.mul(oa, ob))
+    assert [GF._scalar(L.OP_NEG, x) for x in a] == H.as_int_list(F.neg(oa))
+    assert [GF._scalar(L.OP_DIV, x, y) for x, y in zip(a, bnz)] == H.as_int_list(F.div(oa, np.array(bnz, dtype=object)))
+    assert [GF._scalar(L.OP_RECIP, y) for y in bnz] == H.as_int_list(F.recip(np.array(bnz, dtype=object)))
+    es = [int(e) for e in rng.integers(-40, 80, n)]
+    anz = [v or 1 for v in a]
+    assert [GF._scalar(L.OP_POW, x, e) for x, e in zip(anz, es)] == H.as_int_list(F.pow(np.array(anz, dtype=object), es))
+    with pytest.raises(ZeroDivisionError):
+        GF._scalar(L.OP_RECIP, 0)
+    with pytest.raises(ZeroDivisionError):
+        GF._scalar(L.OP_POW, 0, -3)
+
+
+def test_roots_of_unity_known_values():
+    # SURVEY.md 8(c)
+    assert ga.GF(65537)._root_of_unity_int(2**16) == 3
+    assert ga.GF(7340033)._root_of_unity_int(2**20) == 2187
+    G = ga.GF(2**64 - 2**32 + 1)
+    assert G._root_of_unity_int(2**20) == 3511170319078647661
+    assert G._root_of_unity_int(2**26) == 17096174751763063430
+    with pytest.raises(ValueError):
+        ga.GF(65537).primitive_root_of_unity(2**20)  # BASELINE config 3 as written does not exist
+
+
+def test_number_theory():
+    assert nt.factors(2**64 - 2**32) == ([2, 3, 5, 17, 257, 65537], [32, 1, 1, 1, 1, 1])
+    assert nt.primitive_root(7340033) == 3 and nt.primitive_root(2**64 - 2**32 + 1) == 7 and nt.primitive_root(31) == 3
+    assert nt.matlab_primitive_poly(2, 8) == 0x11D and nt.matlab_primitive_poly(2, 4) == 0b10011
+    assert nt.matlab_primitive_poly(2, 7) == 0b10001001
+    assert not nt.is_prime(2**32 + 1) and nt.is_prime(2**61 - 1)
+    with pytest.raises(LookupError):
+        nt.conway_poly(65537, 2)
+
+
+def test_reed_solomon_construction_matches_sage_fixtures():
+    names, d = H.sage_rs()
+    for key in names:
+        meta = json.loads(str(d[f"{key}/meta"]))
+        q = meta["q"]
+        rs = ga.ReedSolomon(meta["n"], meta["k"], field=ga.GF(q), alpha=meta["alpha"], c=meta["c"],
+                            systematic=meta["is_systematic"])
+        assert (rs.n, rs.k, rs.d) == (meta["n"], meta["k"], meta["d"])
+        assert rs.is_primitive == meta["is_primitive"] and rs.is_narrow_sense == meta["is_narrow_sense"]
+        assert str(rs.generator_poly) == meta["generator_poly"].replace("*", ""), key  # Sage writes 11*x^4
+        H.assert_equal_ints(rs.G, d[f"{key}/G"], key + " G")
+        H.assert_equal_ints(rs.H, d[f"{key}/H"], key + " H")
+
+
+def test_reed_solomon_255_223_constants():
+    rs = ga.ReedSolomon(255, 223)
+    assert int(rs.field.irreducible_poly) == 0x11D and rs.alpha == 2 and rs.t == 16 and rs.d == 33
+    assert list(rs.roots[:4]) == [2, 4, 8, 16]
+    assert list(rs.generator_poly.coeffs[:4]) == [1, 232, 29, 189] and list(rs.generator_poly.coeffs[-2:]) == [216, 45]
+    d = H.reference_outputs()
+    H.assert_equal_ints(rs.generator_poly.coeffs, d["rs/rs255_223/generator_poly"])
+    assert ga.ReedSolomon(255, d=33).k == 223
+    with pytest.raises(ValueError):
+        ga.ReedSolomon(255, 223, 30)
+    with pytest.raises(ValueError):
+        ga.ReedSolomon(255)
+    with pytest.raises(TypeError):
+        ga.ReedSolomon(255.0, 223)
+
+
+def test_ntt_argument_checks_need_no_gpu():
+    with pytest.raises(ValueError):
+        ga.ntt([1, 2, 3, 4], modulus=7)  # 4 does not divide 6
+    with pytest.raises(ValueError):
+        ga.ntt([1, 2, 3, 4], modulus=15)  # not prime
+    with pytest.raises(ValueError):
+        ga.ntt([1, 2, 3, 4], size=3, modulus=13)
+    with pytest.raises(ValueError):
+        ga.ntt([1, 2, 3, 14], modulus=13)
+    with pytest.raises(TypeError):
+        ga.ntt(np.float32(3.0))
+
+
+def test_shard_range_partitions():
+    from galois_amd import dist
+
+    for total in (0, 1, 7, 8, 2**20, 10**8 + 3):
+        for world in (1, 2, 3, 8):
+            spans = [dist.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,130 @@
+"""The oracle (oracle/gf_oracle.c) pinned against the golden fixtures: the reference's own Sage/SymPy vectors and
+outputs of the reference itself (tests/golden/generate_golden.py).  CPU only."""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import gf_oracle as O
+from tests import helpers as H
+
+
+@pytest.mark.parametrize("tag", H.SAGE_FIELDS)
+@pytest.mark.parametrize("lookup", [False, True])
+def test_sage_field_vectors(tag, lookup):
+    props, d = H.load_sage_field(tag)
+    if lookup and props["order"] > 2**16:
+        pytest.skip("lookup tables only for small orders")
+    F = H.oracle_field_from_props(props, lookup)
+    X, Y = d["add_X"].astype(np.uint64), d["add_Y"].astype(np.uint64)
+    XX, YY = np.meshgrid(X, Y, indexing="ij")
+    H.assert_equal_ints(F.add(XX, YY), d["add_Z"], "add")
+    X, Y = d["subtract_X"].astype(np.uint64), d["subtract_Y"].astype(np.uint64)
+    XX, YY = np.meshgrid(X, Y, indexing="ij")
+    H.assert_equal_ints(F.sub(XX, YY), d["subtract_Z"], "subtract")
+    X, Y = d["multiply_X"].astype(np.uint64), d["multiply_Y"].astype(np.uint64)
+    XX, YY = np.meshgrid(X, Y, indexing="ij")
+    H.assert_equal_ints(F.mul(XX, YY), d["multiply_Z"], "multiply")
+    X, Y = d["divide_X"].astype(np.uint64), d["divide_Y"].astype(np.uint64)
+    XX, YY = np.meshgrid(X, Y, indexing="ij")
+    H.assert_equal_ints(F.div(XX, YY), d["divide_Z"], "divide")
+    H.assert_equal_ints(F.neg(d["additive_inverse_X"].astype(np.uint64)), d["additive_inverse_Z"], "neg")
+    H.assert_equal_ints(F.recip(d["multiplicative_inverse_X"].astype(np.uint64)), d["multiplicative_inverse_Z"], "recip")
+    X, Y = d["power_X"].astype(np.uint64), d["power_Y"].astype(np.int64)
+    XX, YY = np.meshgrid(X, Y, indexing="ij")
+    H.assert_equal_ints(F.pow(XX, YY), d["power_Z"], "power")
+    # scalar multiply: field * int == field * (int mod p) (_ufunc.py:392-401)
+    X, Y = d["scalar_multiply_X"].astype(np.uint64), d["scalar_multiply_Y"].astype(np.int64)
+    XX, YY = np.meshgrid(X, np.mod(Y, props["characteristic"]).astype(np.uint64), indexing="ij")
+    H.assert_equal_ints(F.mul(XX, YY), d["scalar_multiply_Z"], "scalar_multiply")
+
+
+def test_sage_reed_solomon_fixtures():
+    names, d = H.sage_rs()
+    checked = 0
+    for key in names:
+        meta = json.loads(str(d[f"{key}/meta"]))
+        if not meta["is_systematic"]:
+            continue
+        q = meta["q"]
+        p = 2 if q % 2 == 0 else 3
+        m = {16: 4, 81: 4}[q]
+        from galois_amd import _numtheory as nt
+
+        F = O.OracleField(p, m, nt.conway_poly(p, m), p, lookup=True)
+        R = O.OracleRS(F, meta["n"], meta["k"], alpha=meta["alpha"], c=meta["c"])
+        H.assert_equal_ints(R.G, d[f"{key}/G"], key + " G")
+        H.assert_equal_ints(R.H, d[f"{key}/H"], key + " H")
+        H.assert_equal_ints(R.encode(d[f"{key}/messages"]), d[f"{key}/codewords"], key + " encode")
+        if f"{key}/short_messages" in d:
+            H.assert_equal_ints(R.encode(d[f"{key}/short_messages"]), d[f"{key}/short_codewords"], key + " shortened")
+        checked += 1
+    assert checked >= 20
+
+
+def _field_from_meta(meta, lookup):
+    return O.OracleField(meta["p"], meta["m"], meta["irr"] if meta["m"] > 1 else None, meta["alpha"], lookup=lookup)
+
+
+@pytest.mark.parametrize("tag", ["gf256", "gf31", "gf65537", "gf7340033", "goldilocks", "gf2e32", "gf3e5", "gf251e3"])
+def test_reference_elementwise_outputs(tag):
+    d = H.reference_outputs()
+    meta = json.loads(str(d[f"ew/{tag}/meta"]))
+    q = meta["p"] ** meta["m"]
+    for lookup in ([False, True] if q <= 2**16 else [False]):
+        F = _field_from_meta(meta, lookup)
+        a, b, e = d[f"ew/{tag}/a"], d[f"ew/{tag}/b"], d[f"ew/{tag}/e"]
+        bnz, anz = np.where(b == 0, 1, b), np.where(a == 0, 1, a)
+        H.assert_equal_ints(F.add(a, b), d[f"ew/{tag}/add"])
+        H.assert_equal_ints(F.sub(a, b), d[f"ew/{tag}/sub"])
+        H.assert_equal_ints(F.mul(a, b), d[f"ew/{tag}/mul"])
+        H.assert_equal_ints(F.neg(a), d[f"ew/{tag}/neg"])
+        H.assert_equal_ints(F.div(a, bnz), d[f"ew/{tag}/div"])
+        H.assert_equal_ints(F.recip(bnz), d[f"ew/{tag}/recip"])
+        H.assert_equal_ints(F.pow(anz, e), d[f"ew/{tag}/pow"])
+        H.assert_equal_ints(F.mul(a, np.full_like(a, 7 % meta["p"])), d[f"ew/{tag}/smul"])
+        with pytest.raises(ZeroDivisionError):
+            F.recip([0])
+        with pytest.raises(ZeroDivisionError):
+            F.div([1], [0])
+        with pytest.raises(ZeroDivisionError):
+            F.pow([0], [-1])
+
+
+def test_reference_ntt_outputs():
+    from galois_amd import _numtheory as nt
+
+    d = H.reference_outputs()
+    for p in (5, 13, 17, 769):
+        F = O.OracleField(p, 1, None, nt.primitive_root(p))
+        H.assert_equal_ints(F.ntt(d[f"ntt/kat{p}/x"]), d[f"ntt/kat{p}/X"], f"kat {p}")
+    tags = sorted({k.split("/")[1] for k in d.files if k.startswith("ntt/") and not k.startswith("ntt/kat")})
+    assert len(tags) >= 10
+    for tag in tags:
+        order = int(d[f"ntt/{tag}/order"])
+        p, m = nt.prime_power(order)
+        F = O.OracleField(p, m, nt.conway_poly(p, m) if m > 1 else None, p if m > 1 else nt.primitive_root(p),
+                          lookup=order <= 2**16)
+        x = d[f"ntt/{tag}/x"]
+        H.assert_equal_ints(F.ntt(x), d[f"ntt/{tag}/fft"], tag)
+        H.assert_equal_ints(F.ntt(x, inverse=True), d[f"ntt/{tag}/ifft"], tag + " inverse")
+
+
+def test_reference_reed_solomon_outputs():
+    d = H.reference_outputs()
+    tags = sorted({k.split("/")[1] for k in d.files if k.startswith("rs/") and k.endswith("/meta")})
+    assert "rs255_223" in tags
+    for tag in tags:
+        meta = json.loads(str(d[f"rs/{tag}/meta"]))
+        F = O.OracleField(meta["p"], meta["m"], meta["irr"] if meta["m"] > 1 else None, meta["field_alpha"], lookup=True)
+        R = O.OracleRS(F, meta["n"], meta["k"], alpha=meta["alpha"], c=meta["c"])
+        H.assert_equal_ints(R.generator_poly, d[f"rs/{tag}/generator_poly"], tag)
+        H.assert_equal_ints(R.encode(d[f"rs/{tag}/messages"]), d[f"rs/{tag}/codewords"], tag + " encode")
+        dec, nerr = R.decode(d[f"rs/{tag}/received"], d[f"rs/{tag}/erasures"])
+        H.assert_equal_ints(nerr, d[f"rs/{tag}/n_errors"], tag + " n_errors")
+        H.assert_equal_ints(dec, d[f"rs/{tag}/decoded"], tag + " decoded")
+        H.assert_equal_ints(R.detect(d[f"rs/{tag}/received"]), d[f"rs/{tag}/detected"], tag + " detect")
+    F = O.OracleField(2, 8, 285, 2, lookup=True)
+    R = O.OracleRS(F, 255, 223)
+    H.assert_equal_ints(R.encode(np.arange(223))[223:], d["rs/kat_arange_parity"], "arange parity KAT")
+    H.assert_equal_ints(R.encode_u8(np.arange(223, dtype=np.uint8))[0, 223:], d["rs/kat_arange_parity"])

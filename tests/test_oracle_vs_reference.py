@@ -1,0 +1,101 @@
+"""Pins oracle/gf_oracle.c against the reference itself, imported in place (build container only; skipped elsewhere)."""
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import gf_oracle as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle", "ref_shim"))
+import load_reference  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not load_reference.available(), reason="/root/reference is not present on this machine")
+
+
+def _pair(order, lookup=False, **kw):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        GF = load_reference.ref_field(order, **kw)
+    F = O.OracleField(GF.characteristic, GF.degree, int(GF.irreducible_poly) if GF.degree > 1 else None,
+                      int(GF.primitive_element), lookup=lookup)
+    return GF, F
+
+
+def _eq(x, y):
+    return [int(v) for v in np.asarray(x).ravel()] == [int(v) for v in np.asarray(y).ravel()]
+
+
+@pytest.mark.parametrize("order,kw", [(2, {}), (4, {}), (2**8, {}), (5, {}), (31, {}), (3191, {}), (3**4, {}), (7**3, {}),
+                                      (3**5, {}), (65537, {}), (2**8, dict(irreducible_poly=283, primitive_element=19)),
+                                      (7**3, dict(irreducible_poly=643, primitive_element=244)), (2147483647, {}),
+                                      (2**32, {}), (7340033, {}), (2**64 - 2**32 + 1, {}), (251**3, {})])
+def test_elementwise_against_reference(order, kw):
+    rng = np.random.default_rng(order % 9973)
+    n = 120
+    for lookup in ([False, True] if 2 < order <= 2**16 else [False]):
+        GF, F = _pair(order, lookup, **kw)
+        a = [int(rng.integers(0, 2**62)) * 3 % order for _ in range(n)]
+        b = [int(rng.integers(0, 2**62)) * 5 % order for _ in range(n)]
+        a[:3] = [0, 0, 0]
+        b[1:4] = [0, 0, 0]
+        ga, gb = GF(a), GF(b)
+        oa, ob = np.array(a, dtype=object), np.array(b, dtype=object)
+        assert _eq(F.add(oa, ob), ga + gb) and _eq(F.sub(oa, ob), ga - gb) and _eq(F.mul(oa, ob), ga * gb)
+        assert _eq(F.neg(oa), -ga)
+        bnz = [v or 1 for v in b]
+        assert _eq(F.div(oa, np.array(bnz, dtype=object)), ga / GF(bnz))
+        assert _eq(F.recip(np.array(bnz, dtype=object)), GF(bnz) ** -1)
+        e = rng.integers(-20, 40, n)
+        anz = [v or 1 for v in a]
+        assert _eq(F.pow(np.array(anz, dtype=object), e), GF(anz) ** e)
+        if lookup:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                GF.compile("jit-lookup")
+                E, Lg, Z, ze = F.tables()
+                assert np.array_equal(E, GF._EXP) and np.array_equal(Lg, GF._LOG) and np.array_equal(Z, GF._ZECH_LOG)
+                assert ze == GF._ZECH_E
+                GF.compile("python-calculate")
+
+
+@pytest.mark.parametrize("order,n", [(769, 4), (65537, 256), (7340033, 64), (31, 30), (31, 15), (2**8, 255), (3**5, 22),
+                                     (2**64 - 2**32 + 1, 32), (5**3, 124)])
+def test_fft_against_reference(order, n):
+    rng = np.random.default_rng(n)
+    GF, F = _pair(order, lookup=order <= 2**16 and order != 31)
+    x = [int(v) for v in rng.integers(0, min(order, 2**62), n)]
+    assert _eq(F.ntt(x), np.fft.fft(GF(x)))
+    assert _eq(F.ntt(x, inverse=True), np.fft.ifft(GF(x)))
+
+
+@pytest.mark.parametrize("order,n,k,c,shorten", [(16, 15, 9, 1, 0), (16, 15, 9, 1, 3), (16, 15, 11, 3, 0), (81, 16, 10, 1, 0),
+                                                 (27, 26, 20, 1, 0), (27, 13, 7, 1, 2), (256, 255, 223, 1, 0),
+                                                 (31, 30, 22, 1, 0)])
+def test_reed_solomon_against_reference(order, n, k, c, shorten):
+    galois = load_reference.load()
+    rng = np.random.default_rng(n * 100 + k)
+    kw = dict(irreducible_poly=galois.matlab_primitive_poly(2, 8)) if order == 256 else {}
+    GF, F = _pair(order, lookup=True, **kw)
+    rs = galois.ReedSolomon(n, k, field=GF, c=c)
+    R = O.OracleRS(F, n, k, c=c, alpha=int(rs.alpha))
+    assert _eq(rs.generator_poly.coeffs, R.generator_poly) and _eq(rs.G, R.G) and _eq(rs.H, R.H)
+    ks, ns, N = k - shorten, n - shorten, 6
+    M = rng.integers(0, order, (N, ks))
+    C = rs.encode(GF(M))
+    assert _eq(C, R.encode(M))
+    t = (n - k) // 2
+    Rx = np.asarray(C).astype(np.int64).copy()
+    E = np.zeros((N, ns), dtype=bool)
+    for i in range(N):
+        ne = min([0, t, t + 1, t // 2, 1, t + 3][i], ns)
+        pos = rng.choice(ns, ne, replace=False)
+        Rx[i, pos] = (Rx[i, pos] + rng.integers(1, order, ne)) % order
+        if i >= 3:
+            nu = min([2, n - k, n - k + 1][i % 3], ns)
+            E[i, rng.choice(ns, nu, replace=False)] = True
+    dref, nref = rs.decode(GF(Rx), erasures=E, output="codeword", errors=True)
+    dmine, nmine = R.decode(Rx, erasures=E)
+    assert np.array_equal(nref, nmine) and _eq(dref, dmine)
+    assert np.array_equal(rs.detect(GF(Rx)), R.detect(Rx))
