@@ -9,6 +9,11 @@ from __future__ import annotations
 import ctypes
 import os
 
+# PyTorch-ROCm must be loaded BEFORE the extension: both sides then share ONE HIP runtime instance (the one torch
+# ships), so that torch's device pointers and stream handles are valid inside libgalois_amd.so.  Loading the extension
+# first would pull in /opt/rocm's libamdhip64 as a second, separate runtime.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgalois_amd.so")
 
