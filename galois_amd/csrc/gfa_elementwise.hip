@@ -613,6 +613,7 @@ extern "C" {
 int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b, int64_t sb, void *out, int64_t n,
                int dtype, gfa_stream_t stream, int32_t *dev_err)
 {
+    if (f && n == 0) return GFA_OK; // empty arrays: nothing to launch (pointers may be NULL)
     if (!f || !a || !b || !out || n < 0 || (sa != 0 && sa != 1) || (sb != 0 && sb != 1)) {
         set_error("gfa_binary: bad arguments");
         return GFA_ERR_INVALID;
@@ -640,6 +641,7 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
 int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int dtype, gfa_stream_t stream,
               int32_t *dev_err)
 {
+    if (f && n == 0) return GFA_OK;
     if (!f || !a || !out || n < 0) { set_error("gfa_unary: bad arguments"); return GFA_ERR_INVALID; }
     if (op != GFA_OP_NEG && op != GFA_OP_RECIP) { set_error("gfa_unary: bad op"); return GFA_ERR_INVALID; }
     if (!dtype_holds(dtype, f->calc.q)) { set_error("dtype cannot hold the field's elements"); return GFA_ERR_INVALID; }
@@ -661,6 +663,7 @@ int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int d
 int gfa_power(gfa_field_t *f, const void *a, int64_t sa, const int64_t *exps, int64_t se, void *out, int64_t n, int dtype,
               gfa_stream_t stream, int32_t *dev_err)
 {
+    if (f && n == 0) return GFA_OK;
     if (!f || !a || !exps || !out || n < 0 || (sa != 0 && sa != 1) || (se != 0 && se != 1)) {
         set_error("gfa_power: bad arguments");
         return GFA_ERR_INVALID;
@@ -678,6 +681,7 @@ int gfa_power(gfa_field_t *f, const void *a, int64_t sa, const int64_t *exps, in
 int gfa_scalar_multiply(gfa_field_t *f, const void *a, int64_t sa, const int64_t *ks, int64_t sk, void *out, int64_t n,
                         int dtype, gfa_stream_t stream)
 {
+    if (f && n == 0) return GFA_OK;
     if (!f || !a || !ks || !out || n < 0 || (sa != 0 && sa != 1) || (sk != 0 && sk != 1)) {
         set_error("gfa_scalar_multiply: bad arguments");
         return GFA_ERR_INVALID;

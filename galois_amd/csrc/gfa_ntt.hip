@@ -42,6 +42,7 @@ struct Tw { // generic: plain field multiply
 struct TwShoup32 {
     typedef u32 E;
     static constexpr bool HAS_SHOUP = true;
+    static constexpr int QBITS = 32;
     struct W { u32 w, wq; };
     static __device__ __forceinline__ W load(const u32 *tab, const u32 *tabq, u32 i) { return W{tab[i], tabq[i]}; }
     static __device__ __forceinline__ u32 mul(const FieldDev &fd, u32 x, W t)
@@ -50,6 +51,28 @@ struct TwShoup32 {
         u32 r = t.w * x - q * (u32)fd.p;
         u32 p = (u32)fd.p;
         return r >= p ? r - p : r;
+    }
+};
+
+// GF(p), p < 2^23: the same with 24-bit operands, so that every multiply is a full-rate v_mul_u32_u24 /
+// v_mul_hi_u32_u24 instead of the quarter-rate 32-bit multiplies.  wq = floor(w * 2^24 / p) < 2^24, x < p < 2^23:
+//   q = (wq * x) >> 24  (48-bit product, bits 24..47);  r = w*x - q*p  in [0, 2p)
+struct TwShoup24 {
+    typedef u32 E;
+    static constexpr bool HAS_SHOUP = true;
+    static constexpr int QBITS = 24;
+    struct W { u32 w, wq; };
+    static __device__ __forceinline__ W load(const u32 *tab, const u32 *tabq, u32 i) { return W{tab[i], tabq[i]}; }
+    static __device__ __forceinline__ u32 mul(const FieldDev &fd, u32 x, W t)
+    {
+        // operands masked to 24 bits: the AMDGPU back end selects v_mul_u32_u24 / v_mul_hi_u32_u24 for these products
+        const u64 prod = (u64)(t.wq & 0xffffffu) * (u64)(x & 0xffffffu);
+        const u32 q = (u32)(prod >> 24);
+        const u32 p = (u32)fd.p;
+        u32 qp; // q * p: forced to the 24-bit multiplier (the back end otherwise picks v_mul_lo_u32 for a uniform operand)
+        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(qp) : "v"(q), "v"(p));
+        u32 r = __umul24(t.w, x) - qp;
+        return min(r, r - p); // r in [0, 2p): unsigned min picks r - p exactly when r >= p
     }
 };
 
@@ -65,10 +88,10 @@ __global__ void pow_table_kernel(FieldDev fd, typename F::elem base, u64 exp_str
     if (i < count) out[i] = F::pow_u(fd, base, (u64)i * exp_stride);
 }
 
-__global__ void shoup_table_kernel(u32 p, const u32 *w, u32 *wq, i64 count)
+__global__ void shoup_table_kernel(u32 p, const u32 *w, u32 *wq, i64 count, int qbits)
 {
     i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) wq[i] = (u32)((((u64)w[i]) << 32) / p);
+    if (i < count) wq[i] = (u32)((((u64)w[i]) << qbits) / p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -186,6 +209,150 @@ __global__ __launch_bounds__(256) void ntt_tile_kernel(FieldDev fd, const typena
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// register-blocked line transform: L = R1 * R2 points per line, R1, R2 <= 32
+// ------------------------------------------------------------------------------------------------
+// Each thread owns R1 (then R2) points in VGPRs and runs a fully unrolled decimation-in-frequency network on them,
+// so a length-1024 line costs ONE exchange through LDS instead of ten LDS round trips:
+//   step A: thread (line c, r) loads x[r + R2*a], a < R1, transforms over a, multiplies by w_L^(r*ka), writes LDS
+//   step B: thread (line c, ka) reads the R2 values of its ka, transforms over r, stores X[ka + R1*kr]
+// The constants of the in-register networks (w_R^j) are wave-uniform, so they are scalar loads.
+struct RegArgs {
+    i64 in_stride_c, in_stride_t;   // elements: element (line c, position t) at c*stride_c + t*stride_t
+    i64 out_stride_c, out_stride_t;
+    i64 in_batch_stride, out_batch_stride;
+    i64 total_lines; // lines per batch item
+    int tiles_per_batch;
+    int load_along_line, store_along_line; // which index is contiguous in memory (runs fastest across lanes)
+    int post_twiddle; // multiply output (line, k) by w_N^((line_offset + line) * k) = A[e >> lo_bits] * B[e & mask]
+    int lo_bits;
+    u64 n_mask;
+    i64 line_offset;
+    int do_scale;
+    u64 scale;
+};
+
+template <class F, class TW, int LOGR>
+__device__ __forceinline__ void reg_dif(const FieldDev &fd, typename F::elem (&v)[1 << LOGR],
+                                        const typename F::elem *__restrict__ w, const typename F::elem *__restrict__ wq,
+                                        int wstride)
+{ // v[bitrev(k)] <- sum_a v[a] * w_R^(a*k), with w[j * wstride] = w_R^j
+    typedef typename F::elem E;
+    constexpr int R = 1 << LOGR;
+#pragma unroll
+    for (int s = LOGR - 1; s >= 0; s--) {
+        const int half = 1 << s;
+#pragma unroll
+        for (int b = 0; b < R; b += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; j++) {
+                const E u = v[b + j], x = v[b + j + half];
+                v[b + j] = F::add(fd, u, x);
+                E d = F::sub(fd, u, x);
+                const int tj = j << (LOGR - 1 - s);
+                if (tj != 0) d = TW::mul(fd, d, TW::load(w, wq, (u32)(tj * wstride)));
+                v[b + j + half] = d;
+            }
+        }
+    }
+}
+
+constexpr int brev_c(int x, int bits)
+{
+    int r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+template <class F, class TW, int LOGR1, int LOGR2, int THREADS>
+__global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fd, const typename F::elem *__restrict__ in,
+                                                          typename F::elem *__restrict__ out, RegArgs ra,
+                                                          const typename F::elem *__restrict__ wL,
+                                                          const typename F::elem *__restrict__ wLq,
+                                                          const typename F::elem *__restrict__ powA,
+                                                          const typename F::elem *__restrict__ powAq,
+                                                          const typename F::elem *__restrict__ powB,
+                                                          const typename F::elem *__restrict__ powBq)
+{
+    typedef typename F::elem E;
+    constexpr int R1 = 1 << LOGR1, R2 = 1 << LOGR2, L = R1 * R2;
+    constexpr int C = THREADS / R1;           // lines per tile
+    constexpr int LOGC = __builtin_ctz(C);
+    constexpr int ROW = R2 + 1;               // padded row of R2 values
+    constexpr int PC = R1 * ROW + 1;          // padded line pitch
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    E *data = reinterpret_cast<E *>(smem_raw);      // C * PC
+    E *twl = data + C * PC;                          // L middle twiddles w_L^e
+    E *twql = twl + L;                               // their Shoup quotients
+
+    const int tid = threadIdx.x;
+    const i64 batch = blockIdx.x / ra.tiles_per_batch;
+    const i64 line0 = (i64)(blockIdx.x % ra.tiles_per_batch) * C;
+    const E *gin = in + batch * ra.in_batch_stride;
+    E *gout = out + batch * ra.out_batch_stride;
+
+    for (int i = tid; i < L; i += THREADS) {
+        twl[i] = wL[i];
+        if constexpr (TW::HAS_SHOUP) twql[i] = wLq[i];
+    }
+    // ---- step A ----
+    const bool active_a = tid < C * R2;
+    int ca, ra_;
+    if (ra.load_along_line) { ca = tid >> LOGR2; ra_ = tid & (R2 - 1); }
+    else { ra_ = tid >> LOGC; ca = tid & (C - 1); }
+    {
+        E v[R1];
+        if (active_a) {
+            const bool valid = line0 + ca < ra.total_lines;
+            const E *src = gin + (line0 + ca) * ra.in_stride_c + (i64)ra_ * ra.in_stride_t;
+            const i64 step = (i64)R2 * ra.in_stride_t;
+#pragma unroll
+            for (int a = 0; a < R1; a++) v[a] = valid ? src[a * step] : (E)0;
+            reg_dif<F, TW, LOGR1>(fd, v, wL, wLq, R2); // w_R1 = w_L^R2
+        }
+        __syncthreads(); // middle-twiddle table staged
+        if (active_a) {
+            E *dst = data + ca * PC + ra_;
+#pragma unroll
+            for (int ka = 0; ka < R1; ka++) {
+                E x = v[brev_c(ka, LOGR1)];
+                if (ka != 0) x = TW::mul(fd, x, TW::load(twl, twql, (u32)(ra_ * ka)));
+                dst[ka * ROW] = x;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- step B ----
+    {
+        int c, ka;
+        if (ra.store_along_line) { c = tid >> LOGR1; ka = tid & (R1 - 1); }
+        else { ka = tid >> LOGC; c = tid & (C - 1); }
+        const bool valid = line0 + c < ra.total_lines;
+        E v[R2];
+        const E *srcl = data + c * PC + ka * ROW;
+#pragma unroll
+        for (int r = 0; r < R2; r++) v[r] = srcl[r];
+        reg_dif<F, TW, LOGR2>(fd, v, wL, wLq, R1); // w_R2 = w_L^R1
+        const i64 line = line0 + c;
+        E *dst = gout + line * ra.out_stride_c + (i64)ka * ra.out_stride_t;
+        const i64 step = (i64)R1 * ra.out_stride_t;
+        const E scale = (E)ra.scale;
+        const u64 lo_mask = ((u64)1 << ra.lo_bits) - 1;
+#pragma unroll
+        for (int kr = 0; kr < R2; kr++) {
+            E x = v[brev_c(kr, LOGR2)];
+            if (ra.post_twiddle) {
+                const u64 e = ((u64)(ra.line_offset + line) * (u64)(ka + R1 * kr)) & ra.n_mask;
+                x = TW::mul(fd, x, TW::load(powA, powAq, (u32)(e >> ra.lo_bits)));
+                x = TW::mul(fd, x, TW::load(powB, powBq, (u32)(e & lo_mask)));
+            }
+            if (ra.do_scale) x = F::mul(fd, x, scale);
+            if (valid) dst[kr * step] = x;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // generic Stockham stage (any radix, any field)
 // ------------------------------------------------------------------------------------------------
@@ -262,8 +429,11 @@ struct Plan {
     int logn = 0, log1 = 0, log2 = 0; // n = 2^logn = 2^log1 * 2^log2 ; log2 == 0 => single pass
     void *w1 = nullptr, *w1q = nullptr; // twiddles of the length-2^log1 transform (and Shoup quotients)
     void *w2 = nullptr, *w2q = nullptr; // twiddles of the length-2^log2 transform
-    void *powA = nullptr, *powB = nullptr;
+    void *powA = nullptr, *powB = nullptr, *powAq = nullptr, *powBq = nullptr;
     int lo_bits = 0;
+    // register-blocked path: full w_L^e tables (L entries) per pass, with Shoup quotients
+    void *wl1 = nullptr, *wl1q = nullptr, *wl2 = nullptr, *wl2q = nullptr;
+    bool reg_ready = false;
     // generic path
     void *wpow = nullptr; // n entries
     std::vector<i64> factors;
@@ -293,11 +463,18 @@ int build_pow_table(const FieldDev &fd, u64 base, u64 exp_stride, i64 count, voi
     return GFA_OK;
 }
 
-int build_shoup(const FieldDev &fd, const void *w, i64 count, void **out, hipStream_t st)
+template <class TW>
+constexpr int qbits_of()
+{
+    if constexpr (TW::HAS_SHOUP) return TW::QBITS;
+    else return 0;
+}
+
+int build_shoup(const FieldDev &fd, const void *w, i64 count, void **out, hipStream_t st, int qbits)
 {
     GFA_HIP(hipMalloc(out, sizeof(u32) * (size_t)std::max<i64>(count, 1)));
     hipLaunchKernelGGL(shoup_table_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, (u32)fd.p,
-                       (const u32 *)w, (u32 *)*out, count);
+                       (const u32 *)w, (u32 *)*out, count, qbits);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }
@@ -382,10 +559,10 @@ int run_pow2(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *o
         const i64 n1 = (i64)1 << pl->log1, n2 = (i64)1 << pl->log2;
         // w_{n1} = omega^(n2): table of w_{n1}^t, t < n1/2
         if ((rc = build_pow_table<F>(fd, omega, (u64)n2, std::max<i64>(n1 / 2, 1), &pl->w1, st))) return rc;
-        if (TW::HAS_SHOUP && (rc = build_shoup(fd, pl->w1, std::max<i64>(n1 / 2, 1), &pl->w1q, st))) return rc;
+        if (TW::HAS_SHOUP && (rc = build_shoup(fd, pl->w1, std::max<i64>(n1 / 2, 1), &pl->w1q, st, qbits_of<TW>()))) return rc;
         if (pl->log2) {
             if ((rc = build_pow_table<F>(fd, omega, (u64)n1, n2 / 2, &pl->w2, st))) return rc;
-            if (TW::HAS_SHOUP && (rc = build_shoup(fd, pl->w2, n2 / 2, &pl->w2q, st))) return rc;
+            if (TW::HAS_SHOUP && (rc = build_shoup(fd, pl->w2, n2 / 2, &pl->w2q, st, qbits_of<TW>()))) return rc;
             pl->lo_bits = (pl->logn + 1) / 2;
             const i64 nb = (i64)1 << pl->lo_bits, na = n >> pl->lo_bits;
             if ((rc = build_pow_table<F>(fd, omega, (u64)nb, na, &pl->powA, st))) return rc;
@@ -433,6 +610,131 @@ int run_pow2(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *o
         ta.do_scale = do_scale; ta.scale = scale;
         ta.tw_in_lds = pl->log2 <= 12;
         if ((rc = launch_tile<F, TW>(fd, true, false, pl->ws0.p, out, ta, batch, pl->w2, pl->w2q, nullptr, nullptr, st)))
+            return rc;
+    }
+    return GFA_OK;
+}
+
+
+template <class F, class TW, int LOGR1, int LOGR2>
+int launch_reg_t(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64 batch, const void *wl, const void *wlq,
+                 const void *pa, const void *paq, const void *pb, const void *pbq, hipStream_t st)
+{
+    typedef typename F::elem E;
+    constexpr int THREADS = (sizeof(E) == 4 && LOGR1 == 5) ? 512 : 256;
+    constexpr int R1 = 1 << LOGR1, R2 = 1 << LOGR2, L = R1 * R2, C = THREADS / R1;
+    constexpr size_t lds = sizeof(E) * ((size_t)C * (R1 * (R2 + 1) + 1) + 2 * L);
+    ra.tiles_per_batch = (int)((ra.total_lines + C - 1) / C);
+    const unsigned grid = (unsigned)(batch * ra.tiles_per_batch);
+    auto kern = ntt_reg_kernel<F, TW, LOGR1, LOGR2, THREADS>;
+    static bool attr = false;
+    if (!attr) {
+        GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, fd, (const E *)in, (E *)out, ra, (const E *)wl,
+                       (const E *)wlq, (const E *)pa, (const E *)paq, (const E *)pb, (const E *)pbq);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+template <class F, class TW>
+int launch_reg(const FieldDev &fd, int logL, const void *in, void *out, const RegArgs &ra, i64 batch, const void *wl,
+               const void *wlq, const void *pa, const void *paq, const void *pb, const void *pbq, hipStream_t st)
+{
+#define GFA_REG(A, B) return launch_reg_t<F, TW, A, B>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, st)
+    switch (logL) {
+    case 2: GFA_REG(1, 1);
+    case 3: GFA_REG(2, 1);
+    case 4: GFA_REG(2, 2);
+    case 5: GFA_REG(3, 2);
+    case 6: GFA_REG(3, 3);
+    case 7: GFA_REG(4, 3);
+    case 8: GFA_REG(4, 4);
+    case 9: GFA_REG(5, 4);
+    case 10: GFA_REG(5, 5);
+    default: set_error("register NTT: unsupported line length"); return GFA_ERR_UNSUPPORTED;
+    }
+#undef GFA_REG
+}
+
+constexpr int REG_MAX_LOG = 10; // longest line of the register-blocked kernel
+
+template <class F, class TW>
+int build_line_tables(const FieldDev &fd, u64 omega, i64 n_total, int logL, void **wl, void **wlq, hipStream_t st)
+{ // w_L^e for e < L, w_L = omega^(n_total / L)
+    const i64 L = (i64)1 << logL;
+    int rc;
+    if ((rc = build_pow_table<F>(fd, omega, (u64)(n_total / L), L, wl, st))) return rc;
+    if (TW::HAS_SHOUP && (rc = build_shoup(fd, *wl, L, wlq, st, qbits_of<TW>()))) return rc;
+    return GFA_OK;
+}
+
+template <class F, class TW>
+int build_post_tables(const FieldDev &fd, u64 omega, i64 n_total, Plan *pl, hipStream_t st)
+{
+    int logn = 0;
+    while (((i64)1 << logn) < n_total) logn++;
+    pl->lo_bits = (logn + 1) / 2;
+    const i64 nb = (i64)1 << pl->lo_bits, na = n_total >> pl->lo_bits;
+    int rc;
+    if ((rc = build_pow_table<F>(fd, omega, (u64)nb, na, &pl->powA, st))) return rc;
+    if ((rc = build_pow_table<F>(fd, omega, 1, nb, &pl->powB, st))) return rc;
+    if (TW::HAS_SHOUP) {
+        if ((rc = build_shoup(fd, pl->powA, na, &pl->powAq, st, qbits_of<TW>()))) return rc;
+        if ((rc = build_shoup(fd, pl->powB, nb, &pl->powBq, st, qbits_of<TW>()))) return rc;
+    }
+    return GFA_OK;
+}
+
+// power-of-two n, 4 <= n <= 2^20, on the register-blocked kernel: one pass up to 2^10, else four-step in two passes
+template <class F, class TW>
+int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n, i64 batch, u64 omega, int do_scale,
+                 u64 scale, hipStream_t st)
+{
+    typedef typename F::elem E;
+    int rc;
+    if (!pl->reg_ready) {
+        pl->logn = 0;
+        while (((i64)1 << pl->logn) < n) pl->logn++;
+        if (pl->logn <= REG_MAX_LOG) { pl->log1 = pl->logn; pl->log2 = 0; }
+        else { pl->log1 = (pl->logn + 1) / 2; pl->log2 = pl->logn - pl->log1; }
+        if ((rc = build_line_tables<F, TW>(fd, omega, n, pl->log1, &pl->wl1, &pl->wl1q, st))) return rc;
+        if (pl->log2) {
+            if ((rc = build_line_tables<F, TW>(fd, omega, n, pl->log2, &pl->wl2, &pl->wl2q, st))) return rc;
+            if ((rc = build_post_tables<F, TW>(fd, omega, n, pl, st))) return rc;
+        }
+        pl->reg_ready = true;
+    }
+    if (pl->log2 == 0) {
+        RegArgs ra{};
+        ra.in_stride_c = n; ra.in_stride_t = 1; ra.out_stride_c = n; ra.out_stride_t = 1;
+        ra.total_lines = batch;
+        ra.load_along_line = 1; ra.store_along_line = 1;
+        ra.do_scale = do_scale; ra.scale = scale;
+        return launch_reg<F, TW>(fd, pl->log1, in, out, ra, 1, pl->wl1, pl->wl1q, nullptr, nullptr, nullptr, nullptr, st);
+    }
+    const i64 n1 = (i64)1 << pl->log1, n2 = (i64)1 << pl->log2;
+    if ((rc = pl->ws0.ensure(sizeof(E) * (size_t)(n * batch)))) return rc;
+    { // pass 1: the n2 columns (length n1, stride n2), then * w^(j2*k1); same layout out
+        RegArgs ra{};
+        ra.in_stride_c = 1; ra.in_stride_t = n2; ra.out_stride_c = 1; ra.out_stride_t = n2;
+        ra.in_batch_stride = n; ra.out_batch_stride = n;
+        ra.total_lines = n2;
+        ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits; ra.n_mask = (u64)n - 1;
+        if ((rc = launch_reg<F, TW>(fd, pl->log1, in, pl->ws0.p, ra, batch, pl->wl1, pl->wl1q, pl->powA, pl->powAq, pl->powB,
+                                    pl->powBq, st)))
+            return rc;
+    }
+    { // pass 2: the n1 rows (contiguous), stored transposed: X[k1 + n1*k2]
+        RegArgs ra{};
+        ra.in_stride_c = n2; ra.in_stride_t = 1; ra.out_stride_c = 1; ra.out_stride_t = n1;
+        ra.in_batch_stride = n; ra.out_batch_stride = n;
+        ra.total_lines = n1;
+        ra.load_along_line = 1; ra.store_along_line = 0;
+        ra.do_scale = do_scale; ra.scale = scale;
+        if ((rc = launch_reg<F, TW>(fd, pl->log2, pl->ws0.p, out, ra, batch, pl->wl2, pl->wl2q, nullptr, nullptr, nullptr,
+                                    nullptr, st)))
             return rc;
     }
     return GFA_OK;
@@ -495,10 +797,20 @@ int run_typed(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *
     constexpr bool prime_kind = std::is_same<F, Prime32>::value || std::is_same<F, Prime64>::value ||
                                 std::is_same<F, Goldilocks>::value;
     bool done = false;
-    if (prime_kind && is_pow2(n) && n >= 2) {
+    if constexpr (prime_kind) if (is_pow2(n) && n >= 2) {
         int lg = 0;
         while (((i64)1 << lg) < n) lg++;
-        if (lg <= 24) {
+        if (lg >= 2 && lg <= 2 * REG_MAX_LOG) {
+            if constexpr (std::is_same<F, Prime32>::value) {
+                if (fd.p < (1ull << 23)) rc = run_pow2_reg<F, TwShoup24>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+                else if (fd.p < (1ull << 31)) rc = run_pow2_reg<F, TwShoup32>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+                else rc = run_pow2_reg<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+            } else {
+                rc = run_pow2_reg<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+            }
+            if (rc) return rc;
+            done = true;
+        } else if (lg <= 24) {
             if constexpr (std::is_same<F, Prime32>::value) {
                 if (fd.p < (1ull << 31)) rc = run_pow2<F, TwShoup32>(f, fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
                 else rc = run_pow2<F, Tw<F>>(f, fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
@@ -527,7 +839,8 @@ void ntt_forget_field(const gfa_field *f)
     for (auto it = g_plans.begin(); it != g_plans.end();) {
         if (it->first.f == f) {
             Plan *pl = it->second;
-            for (void *p : {pl->w1, pl->w1q, pl->w2, pl->w2q, pl->powA, pl->powB, pl->wpow, pl->ws0.p, pl->ws1.p, pl->cvt.p})
+            for (void *p : {pl->w1, pl->w1q, pl->w2, pl->w2q, pl->powA, pl->powB, pl->powAq, pl->powBq, pl->wl1, pl->wl1q, pl->wl2,
+                            pl->wl2q, pl->wpow, pl->ws0.p, pl->ws1.p, pl->cvt.p})
                 if (p) (void)hipFree(p);
             delete pl;
             it = g_plans.erase(it);
@@ -618,10 +931,23 @@ int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64
         while (((i64)1 << lgn) < n_total) lgn++;
         if (lg1 > 13 || (sizeof(E) << lg1) > 2 * TILE_LDS_BYTES - 4096) { set_error("gfa_ntt_columns: n1 too long for one LDS tile"); return GFA_ERR_UNSUPPORTED; }
         int rc2;
+        if (lg1 >= 2 && lg1 <= REG_MAX_LOG) {
+            if (!pl->reg_ready) {
+                pl->log1 = lg1; pl->logn = lgn;
+                if ((rc2 = build_line_tables<F, TW>(c, omega, n_total, lg1, &pl->wl1, &pl->wl1q, st))) return rc2;
+                if ((rc2 = build_post_tables<F, TW>(c, omega, n_total, pl, st))) return rc2;
+                pl->reg_ready = true;
+            }
+            RegArgs ra{};
+            ra.in_stride_c = 1; ra.in_stride_t = cols; ra.out_stride_c = 1; ra.out_stride_t = cols;
+            ra.total_lines = cols;
+            ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits; ra.n_mask = (u64)n_total - 1; ra.line_offset = col0;
+            return launch_reg<F, TW>(c, lg1, in, out, ra, 1, pl->wl1, pl->wl1q, pl->powA, pl->powAq, pl->powB, pl->powBq, st);
+        }
         if (!pl->w1) {
             pl->log1 = lg1; pl->logn = lgn;
             if ((rc2 = build_pow_table<F>(c, omega, (u64)(n_total / n1), n1 / 2, &pl->w1, st))) return rc2;
-            if (TW::HAS_SHOUP && (rc2 = build_shoup(c, pl->w1, n1 / 2, &pl->w1q, st))) return rc2;
+            if (TW::HAS_SHOUP && (rc2 = build_shoup(c, pl->w1, n1 / 2, &pl->w1q, st, qbits_of<TW>()))) return rc2;
             pl->lo_bits = (lgn + 1) / 2;
             const i64 nb = (i64)1 << pl->lo_bits, na = n_total >> pl->lo_bits;
             if ((rc2 = build_pow_table<F>(c, omega, (u64)nb, na, &pl->powA, st))) return rc2;
@@ -634,10 +960,16 @@ int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64
         ta.in_stride_c = 1; ta.in_stride_t = cols; ta.out_stride_c = 1; ta.out_stride_t = cols;
         ta.post_twiddle = 1; ta.lo_bits = pl->lo_bits; ta.n_mask = (u64)n_total - 1; ta.line_offset = col0;
         ta.tw_in_lds = lg1 <= 12;
-        return launch_tile<F, TW>(c, false, false, in, out, ta, 1, pl->w1, pl->w1q, pl->powA, pl->powB, st);
+        if constexpr (std::is_same<TW, TwShoup24>::value) {
+            set_error("gfa_ntt_columns: internal: 24-bit twiddles are only used by the register kernel");
+            return GFA_ERR_UNSUPPORTED;
+        } else {
+            return launch_tile<F, TW>(c, false, false, in, out, ta, 1, pl->w1, pl->w1q, pl->powA, pl->powB, st);
+        }
     };
     switch (c.kind) {
     case KIND_PRIME32:
+        if (c.p < (1ull << 23) && n1 <= ((i64)1 << REG_MAX_LOG)) return run(Prime32{}, TwShoup24{});
         if (c.p < (1ull << 31)) return run(Prime32{}, TwShoup32{});
         return run(Prime32{}, Tw<Prime32>{});
     case KIND_PRIME64: return run(Prime64{}, Tw<Prime64>{});

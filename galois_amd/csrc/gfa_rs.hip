@@ -128,7 +128,8 @@ __global__ __launch_bounds__(1024) void rs_encode_kernel(RsTables t, RsParams rp
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
     const int lpg = 64 / groups;
     const int grp = lane / lpg, gl = lane % lpg;
-    uint8_t *m_l = free_l + (size_t)wave * groups * 256; // message rows of this wave's codewords
+    const int mpitch = ((ks + 15) / 16) * 16;
+    uint8_t *m_l = free_l + (size_t)wave * groups * mpitch; // message rows of this wave's codewords
     __syncthreads();
     const int ns = ks + nk;
     const i64 cw_per_block = (i64)nwaves * groups;
@@ -140,14 +141,14 @@ __global__ __launch_bounds__(1024) void rs_encode_kernel(RsTables t, RsParams rp
             if (cw < batch)
                 for (int i = lane; i < ks; i += 64) {
                     uint8_t v = msg[cw * ks + i];
-                    m_l[g * 256 + i] = v;
+                    m_l[g * mpitch + i] = v;
                     if (!parity_only) out[cw * ns + i] = v;
                 }
         }
         wave_sync();
         const i64 cw = cw0 + grp;
         if (cw < batch) {
-            const uint8_t *mrow = m_l + grp * 256;
+            const uint8_t *mrow = m_l + grp * mpitch;
             for (int j = gl; j < nk; j += lpg) {
                 u32 acc = 0;
                 for (int tt = 0; tt < ks; tt++) acc = ar.add(acc, ar.mul(mrow[tt], P_l[tt * nk + j]));
@@ -580,10 +581,13 @@ int gfa_rs_encode(gfa_rs_t *code, const void *msg, int64_t ks, void *out, int64_
     }
     int groups = 1;
     while (groups < 64 && (64 / (groups * 2)) >= nk) groups *= 2;
-    const int threads = bin ? 1024 : 512;
-    const int nwaves = threads / 64;
-    const size_t lds = (bin ? 65536 : 131072) + 1280 + (((size_t)ks * nk + 15) / 16) * 16 + (size_t)nwaves * groups * 256;
+    const size_t mpitch = (((size_t)ks + 15) / 16) * 16;
+    const size_t fixed = (bin ? 65536 : 131072) + 1280 + (((size_t)ks * nk + 15) / 16) * 16;
+    int nwaves = 16;
+    while (nwaves > 1 && fixed + (size_t)nwaves * groups * mpitch > 160 * 1024) nwaves /= 2;
+    const size_t lds = fixed + (size_t)nwaves * groups * mpitch;
     if (lds > 160 * 1024) { set_error("gfa_rs_encode: code too large for the LDS-resident encoder"); return GFA_ERR_UNSUPPORTED; }
+    const int threads = nwaves * 64;
     const i64 cw_per_block = (i64)nwaves * groups;
     const int grid = (int)std::min<i64>((batch + cw_per_block - 1) / cw_per_block, (i64)cu_count());
     static bool a0 = false, a1 = false;
