@@ -238,11 +238,12 @@ class FieldArray(metaclass=FieldArrayMeta):
     def _from_host(cls, x, np_dtype):
         arr = cls._verify_host(x)
         size = cls._itemsize(np_dtype)
+        shape = arr.shape  # np.ascontiguousarray promotes 0-D to 1-D: restore the shape afterwards
         if np.dtype(np_dtype) == np.dtype(object):
-            store = arr.astype(np.uint64).view(np.int64)
+            store = np.ascontiguousarray(arr.astype(np.uint64)).view(np.int64)
         else:
             store = np.ascontiguousarray(arr.astype(np_dtype, copy=False)).view(_NP_SIGNED[size])
-        t = torch.from_numpy(np.ascontiguousarray(store)).to(_device())
+        t = torch.from_numpy(store.copy()).reshape(shape).to(_device())
         return t, np.dtype(np_dtype)
 
     @classmethod

@@ -16,6 +16,7 @@
 //   * anything else (mixed radix, extension fields): one global-memory Stockham stage per prime factor, same index
 //     maps as the reference's stages (_function.py:315-384), twiddles from a w^t table.
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <tuple>
 
@@ -35,6 +36,10 @@ struct Tw { // generic: plain field multiply
     struct W { E w; };
     static __device__ __forceinline__ W load(const E *tab, const E *, u32 i) { return W{tab[i]}; }
     static __device__ __forceinline__ E mul(const FieldDev &fd, E x, W t) { return F::mul(fd, x, t.w); }
+    static __device__ __forceinline__ E add(const FieldDev &fd, E a, E b) { return F::add(fd, a, b); }
+    static __device__ __forceinline__ E sub(const FieldDev &fd, E a, E b) { return F::sub(fd, a, b); }
+    // (a - b) * w
+    static __device__ __forceinline__ E submul(const FieldDev &fd, E a, E b, W t) { return F::mul(fd, F::sub(fd, a, b), t.w); }
 };
 
 // GF(p), p < 2^31: Shoup multiplication by a constant w with wq = floor(w * 2^32 / p):
@@ -52,6 +57,19 @@ struct TwShoup32 {
         u32 p = (u32)fd.p;
         return r >= p ? r - p : r;
     }
+    // p < 2^31: all sums stay below 2^32; unsigned min() selects the reduced value
+    static __device__ __forceinline__ u32 add(const FieldDev &fd, u32 a, u32 b)
+    {
+        const u32 c = a + b;
+        return min(c, c - (u32)fd.p);
+    }
+    static __device__ __forceinline__ u32 sub(const FieldDev &fd, u32 a, u32 b)
+    {
+        const u32 d = a - b;
+        return min(d, d + (u32)fd.p);
+    }
+    // (a - b) * w without reducing the difference first: a + p - b lies in (0, 2p), a valid multiplier input
+    static __device__ __forceinline__ u32 submul(const FieldDev &fd, u32 a, u32 b, W t) { return mul(fd, a + (u32)fd.p - b, t); }
 };
 
 // GF(p), p < 2^23: the same with 24-bit operands, so that every multiply is a full-rate v_mul_u32_u24 /
@@ -74,6 +92,19 @@ struct TwShoup24 {
         u32 r = __umul24(t.w, x) - qp;
         return min(r, r - p); // r in [0, 2p): unsigned min picks r - p exactly when r >= p
     }
+    // p < 2^31: all sums stay below 2^32; unsigned min() selects the reduced value
+    static __device__ __forceinline__ u32 add(const FieldDev &fd, u32 a, u32 b)
+    {
+        const u32 c = a + b;
+        return min(c, c - (u32)fd.p);
+    }
+    static __device__ __forceinline__ u32 sub(const FieldDev &fd, u32 a, u32 b)
+    {
+        const u32 d = a - b;
+        return min(d, d + (u32)fd.p);
+    }
+    // (a - b) * w without reducing the difference first: a + p - b lies in (0, 2p), a valid multiplier input
+    static __device__ __forceinline__ u32 submul(const FieldDev &fd, u32 a, u32 b, W t) { return mul(fd, a + (u32)fd.p - b, t); }
 };
 
 __device__ __forceinline__ u32 bitrev(u32 x, int bits) { return __brev(x) >> (32 - bits); }
@@ -248,11 +279,10 @@ __device__ __forceinline__ void reg_dif(const FieldDev &fd, typename F::elem (&v
 #pragma unroll
             for (int j = 0; j < half; j++) {
                 const E u = v[b + j], x = v[b + j + half];
-                v[b + j] = F::add(fd, u, x);
-                E d = F::sub(fd, u, x);
+                v[b + j] = TW::add(fd, u, x);
                 const int tj = j << (LOGR - 1 - s);
-                if (tj != 0) d = TW::mul(fd, d, TW::load(w, wq, (u32)(tj * wstride)));
-                v[b + j + half] = d;
+                if (tj != 0) v[b + j + half] = TW::submul(fd, u, x, TW::load(w, wq, (u32)(tj * wstride)));
+                else v[b + j + half] = TW::sub(fd, u, x);
             }
         }
     }
@@ -343,9 +373,10 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fd, const typ
         for (int kr = 0; kr < R2; kr++) {
             E x = v[brev_c(kr, LOGR2)];
             if (ra.post_twiddle) {
-                const u64 e = ((u64)(ra.line_offset + line) * (u64)(ka + R1 * kr)) & ra.n_mask;
-                x = TW::mul(fd, x, TW::load(powA, powAq, (u32)(e >> ra.lo_bits)));
-                x = TW::mul(fd, x, TW::load(powB, powBq, (u32)(e & lo_mask)));
+                // (line index) * k mod N in 32-bit arithmetic: N is a power of two <= 2^32, so wrap-around is harmless
+                const u32 e = ((u32)(ra.line_offset + line) * (u32)(ka + R1 * kr)) & (u32)ra.n_mask;
+                x = TW::mul(fd, x, TW::load(powA, powAq, e >> ra.lo_bits));
+                x = TW::mul(fd, x, TW::load(powB, powBq, e & (u32)lo_mask));
             }
             if (ra.do_scale) x = F::mul(fd, x, scale);
             if (valid) dst[kr * step] = x;
@@ -616,12 +647,17 @@ int run_pow2(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *o
 }
 
 
-template <class F, class TW, int LOGR1, int LOGR2>
-int launch_reg_t(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64 batch, const void *wl, const void *wlq,
-                 const void *pa, const void *paq, const void *pb, const void *pbq, hipStream_t st)
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <class F, class TW, int LOGR1, int LOGR2, int THREADS>
+int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64 batch, const void *wl, const void *wlq,
+                  const void *pa, const void *paq, const void *pb, const void *pbq, hipStream_t st)
 {
     typedef typename F::elem E;
-    constexpr int THREADS = (sizeof(E) == 4 && LOGR1 == 5) ? 512 : 256;
     constexpr int R1 = 1 << LOGR1, R2 = 1 << LOGR2, L = R1 * R2, C = THREADS / R1;
     constexpr size_t lds = sizeof(E) * ((size_t)C * (R1 * (R2 + 1) + 1) + 2 * L);
     ra.tiles_per_batch = (int)((ra.total_lines + C - 1) / C);
@@ -636,6 +672,21 @@ int launch_reg_t(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64 
                        (const E *)wlq, (const E *)pa, (const E *)paq, (const E *)pb, (const E *)pbq);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
+}
+
+template <class F, class TW, int LOGR1, int LOGR2>
+int launch_reg_t(const FieldDev &fd, const void *in, void *out, const RegArgs &ra, i64 batch, const void *wl,
+                 const void *wlq, const void *pa, const void *paq, const void *pb, const void *pbq, hipStream_t st)
+{
+    typedef typename F::elem E;
+    if constexpr (sizeof(E) == 4 && LOGR1 == 5) {
+        // 32 lines per tile (128-byte global segments, one 1024-thread workgroup per CU) or 16 lines (two 512-thread ones)
+        static const int wide = env_int("GFA_NTT_WIDE", 0);
+        if (wide) return launch_reg_tt<F, TW, LOGR1, LOGR2, 1024>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, st);
+        return launch_reg_tt<F, TW, LOGR1, LOGR2, 512>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, st);
+    } else {
+        return launch_reg_tt<F, TW, LOGR1, LOGR2, 256>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, st);
+    }
 }
 
 template <class F, class TW>
@@ -715,27 +766,41 @@ int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n,
         return launch_reg<F, TW>(fd, pl->log1, in, out, ra, 1, pl->wl1, pl->wl1q, nullptr, nullptr, nullptr, nullptr, st);
     }
     const i64 n1 = (i64)1 << pl->log1, n2 = (i64)1 << pl->log2;
-    if ((rc = pl->ws0.ensure(sizeof(E) * (size_t)(n * batch)))) return rc;
-    { // pass 1: the n2 columns (length n1, stride n2), then * w^(j2*k1); same layout out
-        RegArgs ra{};
-        ra.in_stride_c = 1; ra.in_stride_t = n2; ra.out_stride_c = 1; ra.out_stride_t = n2;
-        ra.in_batch_stride = n; ra.out_batch_stride = n;
-        ra.total_lines = n2;
-        ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits; ra.n_mask = (u64)n - 1;
-        if ((rc = launch_reg<F, TW>(fd, pl->log1, in, pl->ws0.p, ra, batch, pl->wl1, pl->wl1q, pl->powA, pl->powAq, pl->powB,
-                                    pl->powBq, st)))
-            return rc;
+    // Sub-batches keep the pass-1 -> pass-2 intermediate small enough to stay in the 256 MiB Infinity Cache instead of
+    // making a round trip through HBM.
+    static const int sub_mb = env_int("GFA_NTT_SUBBATCH_MB", 64);
+    i64 sub = batch;
+    if (sub_mb > 0) {
+        sub = ((i64)sub_mb << 20) / (i64)(sizeof(E) * (size_t)n);
+        if (sub < 1) sub = 1;
+        if (sub > batch) sub = batch;
     }
-    { // pass 2: the n1 rows (contiguous), stored transposed: X[k1 + n1*k2]
-        RegArgs ra{};
-        ra.in_stride_c = n2; ra.in_stride_t = 1; ra.out_stride_c = 1; ra.out_stride_t = n1;
-        ra.in_batch_stride = n; ra.out_batch_stride = n;
-        ra.total_lines = n1;
-        ra.load_along_line = 1; ra.store_along_line = 0;
-        ra.do_scale = do_scale; ra.scale = scale;
-        if ((rc = launch_reg<F, TW>(fd, pl->log2, pl->ws0.p, out, ra, batch, pl->wl2, pl->wl2q, nullptr, nullptr, nullptr,
-                                    nullptr, st)))
-            return rc;
+    if ((rc = pl->ws0.ensure(sizeof(E) * (size_t)(n * sub)))) return rc;
+    for (i64 b0 = 0; b0 < batch; b0 += sub) {
+        const i64 nb = std::min(sub, batch - b0);
+        const E *src = (const E *)in + b0 * n;
+        E *dst = (E *)out + b0 * n;
+        { // pass 1: the n2 columns (length n1, stride n2), then * w^(j2*k1); same layout out
+            RegArgs ra{};
+            ra.in_stride_c = 1; ra.in_stride_t = n2; ra.out_stride_c = 1; ra.out_stride_t = n2;
+            ra.in_batch_stride = n; ra.out_batch_stride = n;
+            ra.total_lines = n2;
+            ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits; ra.n_mask = (u64)n - 1;
+            if ((rc = launch_reg<F, TW>(fd, pl->log1, src, pl->ws0.p, ra, nb, pl->wl1, pl->wl1q, pl->powA, pl->powAq, pl->powB,
+                                        pl->powBq, st)))
+                return rc;
+        }
+        { // pass 2: the n1 rows (contiguous), stored transposed: X[k1 + n1*k2]
+            RegArgs ra{};
+            ra.in_stride_c = n2; ra.in_stride_t = 1; ra.out_stride_c = 1; ra.out_stride_t = n1;
+            ra.in_batch_stride = n; ra.out_batch_stride = n;
+            ra.total_lines = n1;
+            ra.load_along_line = 1; ra.store_along_line = 0;
+            ra.do_scale = do_scale; ra.scale = scale;
+            if ((rc = launch_reg<F, TW>(fd, pl->log2, pl->ws0.p, dst, ra, nb, pl->wl2, pl->wl2q, nullptr, nullptr, nullptr,
+                                        nullptr, st)))
+                return rc;
+        }
     }
     return GFA_OK;
 }
