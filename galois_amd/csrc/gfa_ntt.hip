@@ -40,6 +40,9 @@ struct Tw { // generic: plain field multiply
     static __device__ __forceinline__ E sub(const FieldDev &fd, E a, E b) { return F::sub(fd, a, b); }
     // (a - b) * w
     static __device__ __forceinline__ E submul(const FieldDev &fd, E a, E b, W t) { return F::mul(fd, F::sub(fd, a, b), t.w); }
+    typedef const FieldDev &Ctx; // the register kernel's per-thread arithmetic context
+    static __device__ __forceinline__ Ctx make_ctx(const FieldDev &fd) { return fd; }
+    static __device__ __forceinline__ W make_w(Ctx, E w, E) { return W{w}; }
 };
 
 // GF(p), p < 2^31: Shoup multiplication by a constant w with wq = floor(w * 2^32 / p):
@@ -70,6 +73,25 @@ struct TwShoup32 {
     }
     // (a - b) * w without reducing the difference first: a + p - b lies in (0, 2p), a valid multiplier input
     static __device__ __forceinline__ u32 submul(const FieldDev &fd, u32 a, u32 b, W t) { return mul(fd, a + (u32)fd.p - b, t); }
+    // Per-thread context for the register kernel: the modulus in a VGPR whose value the optimiser cannot trace back to
+    // the (uniform) kernel argument, so that every use is a plain VALU operand.
+    struct Ctx { u32 p; };
+    static __device__ __forceinline__ Ctx make_ctx(const FieldDev &fd)
+    {
+        u32 pv = (u32)fd.p;
+        asm volatile("" : "+v"(pv));
+        return Ctx{pv};
+    }
+    static __device__ __forceinline__ W make_w(Ctx, u32 w, u32 wq) { return W{w, wq}; }
+    static __device__ __forceinline__ u32 add(Ctx c, u32 a, u32 b) { const u32 s = a + b; return min(s, s - c.p); }
+    static __device__ __forceinline__ u32 sub(Ctx c, u32 a, u32 b) { const u32 d = a - b; return min(d, d + c.p); }
+    static __device__ __forceinline__ u32 submul(Ctx c, u32 a, u32 b, W t) { return mul(c, a + c.p - b, t); }
+    static __device__ __forceinline__ u32 mul(Ctx c, u32 x, W t)
+    {
+        const u32 q = __umulhi(t.wq, x);
+        const u32 r = t.w * x - q * c.p;
+        return min(r, r - c.p);
+    }
 };
 
 // GF(p), p < 2^23: the same with 24-bit operands, so that every multiply is a full-rate v_mul_u32_u24 /
@@ -105,6 +127,28 @@ struct TwShoup24 {
     }
     // (a - b) * w without reducing the difference first: a + p - b lies in (0, 2p), a valid multiplier input
     static __device__ __forceinline__ u32 submul(const FieldDev &fd, u32 a, u32 b, W t) { return mul(fd, a + (u32)fd.p - b, t); }
+    // Per-thread context for the register kernel: the modulus in a VGPR whose value the optimiser cannot trace back to
+    // the (uniform) kernel argument, so that every use is a plain VALU operand.
+    struct Ctx { u32 p; };
+    static __device__ __forceinline__ Ctx make_ctx(const FieldDev &fd)
+    {
+        u32 pv = (u32)fd.p;
+        asm volatile("" : "+v"(pv));
+        return Ctx{pv};
+    }
+    static __device__ __forceinline__ W make_w(Ctx, u32 w, u32 wq) { return W{w, wq}; }
+    static __device__ __forceinline__ u32 add(Ctx c, u32 a, u32 b) { const u32 s = a + b; return min(s, s - c.p); }
+    static __device__ __forceinline__ u32 sub(Ctx c, u32 a, u32 b) { const u32 d = a - b; return min(d, d + c.p); }
+    static __device__ __forceinline__ u32 submul(Ctx c, u32 a, u32 b, W t) { return mul(c, a + c.p - b, t); }
+    static __device__ __forceinline__ u32 mul(Ctx c, u32 x, W t)
+    {
+        const u64 prod = (u64)(t.wq & 0xffffffu) * (u64)(x & 0xffffffu);
+        const u32 q = (u32)(prod >> 24);
+        u32 qp; // q * p on the full-rate 24-bit multiplier (hipcc otherwise lowers this product to v_mul_lo_u32)
+        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(qp) : "v"(q), "v"(c.p));
+        const u32 r = __umul24(t.w, x) - qp;
+        return min(r, r - c.p);
+    }
 };
 
 __device__ __forceinline__ u32 bitrev(u32 x, int bits) { return __brev(x) >> (32 - bits); }
@@ -262,10 +306,11 @@ struct RegArgs {
     i64 line_offset;
     int do_scale;
     u64 scale;
+    u64 scale_q; // Shoup quotient of `scale` for the twiddle class in use
 };
 
 template <class F, class TW, int LOGR>
-__device__ __forceinline__ void reg_dif(const FieldDev &fd, typename F::elem (&v)[1 << LOGR],
+__device__ __forceinline__ void reg_dif(typename TW::Ctx fd, typename F::elem (&v)[1 << LOGR],
                                         const typename F::elem *__restrict__ w, const typename F::elem *__restrict__ wq,
                                         int wstride)
 { // v[bitrev(k)] <- sum_a v[a] * w_R^(a*k), with w[j * wstride] = w_R^j
@@ -296,7 +341,7 @@ constexpr int brev_c(int x, int bits)
 }
 
 template <class F, class TW, int LOGR1, int LOGR2, int THREADS>
-__global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fd, const typename F::elem *__restrict__ in,
+__global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fdk, const typename F::elem *__restrict__ in,
                                                           typename F::elem *__restrict__ out, RegArgs ra,
                                                           const typename F::elem *__restrict__ wL,
                                                           const typename F::elem *__restrict__ wLq,
@@ -319,8 +364,15 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fd, const typ
     const int tid = threadIdx.x;
     const i64 batch = blockIdx.x / ra.tiles_per_batch;
     const i64 line0 = (i64)(blockIdx.x % ra.tiles_per_batch) * C;
-    const E *gin = in + batch * ra.in_batch_stride;
-    E *gout = out + batch * ra.out_batch_stride;
+    // tile base pointers are wave-uniform (scalar 64-bit arithmetic); per-thread offsets inside a tile fit in 32 bits
+    const E *gin = in + batch * ra.in_batch_stride + line0 * ra.in_stride_c;
+    E *gout = out + batch * ra.out_batch_stride + line0 * ra.out_stride_c;
+    // byte strides (the host guarantees that every offset inside a tile stays below 2^31 bytes)
+    const u32 isc = (u32)ra.in_stride_c * (u32)sizeof(E), ist = (u32)ra.in_stride_t * (u32)sizeof(E);
+    const u32 osc = (u32)ra.out_stride_c * (u32)sizeof(E), ost = (u32)ra.out_stride_t * (u32)sizeof(E);
+    const char *ginb = reinterpret_cast<const char *>(gin);
+    char *goutb = reinterpret_cast<char *>(gout);
+    const typename TW::Ctx fd = TW::make_ctx(fdk);
 
     for (int i = tid; i < L; i += THREADS) {
         twl[i] = wL[i];
@@ -334,21 +386,24 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fd, const typ
     {
         E v[R1];
         if (active_a) {
-            const bool valid = line0 + ca < ra.total_lines;
-            const E *src = gin + (line0 + ca) * ra.in_stride_c + (i64)ra_ * ra.in_stride_t;
-            const i64 step = (i64)R2 * ra.in_stride_t;
+            // lines beyond the end of the batch are clamped to the last line (they compute garbage that is never stored)
+            const i64 last = ra.total_lines - 1 - line0;
+            const u32 cl = (u32)((i64)ca <= last ? ca : last);
+            const u32 off = cl * isc + (u32)ra_ * ist;
+            const u32 step = (u32)R2 * ist;
 #pragma unroll
-            for (int a = 0; a < R1; a++) v[a] = valid ? src[a * step] : (E)0;
+            for (int a = 0; a < R1; a++) v[a] = *reinterpret_cast<const E *>(ginb + (off + (u32)a * step));
             reg_dif<F, TW, LOGR1>(fd, v, wL, wLq, R2); // w_R1 = w_L^R2
         }
         __syncthreads(); // middle-twiddle table staged
         if (active_a) {
             E *dst = data + ca * PC + ra_;
+            dst[0] = v[0];
+            u32 idx = 0;
 #pragma unroll
-            for (int ka = 0; ka < R1; ka++) {
-                E x = v[brev_c(ka, LOGR1)];
-                if (ka != 0) x = TW::mul(fd, x, TW::load(twl, twql, (u32)(ra_ * ka)));
-                dst[ka * ROW] = x;
+            for (int ka = 1; ka < R1; ka++) {
+                idx += (u32)ra_; // r * ka
+                dst[ka * ROW] = TW::mul(fd, v[brev_c(ka, LOGR1)], TW::load(twl, twql, idx));
             }
         }
     }
@@ -358,28 +413,37 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fd, const typ
         int c, ka;
         if (ra.store_along_line) { c = tid >> LOGR1; ka = tid & (R1 - 1); }
         else { ka = tid >> LOGC; c = tid & (C - 1); }
-        const bool valid = line0 + c < ra.total_lines;
         E v[R2];
         const E *srcl = data + c * PC + ka * ROW;
 #pragma unroll
         for (int r = 0; r < R2; r++) v[r] = srcl[r];
         reg_dif<F, TW, LOGR2>(fd, v, wL, wLq, R1); // w_R2 = w_L^R1
-        const i64 line = line0 + c;
-        E *dst = gout + line * ra.out_stride_c + (i64)ka * ra.out_stride_t;
-        const i64 step = (i64)R1 * ra.out_stride_t;
-        const E scale = (E)ra.scale;
-        const u64 lo_mask = ((u64)1 << ra.lo_bits) - 1;
+        if (ra.post_twiddle) {
+            // * w_N^(line * k), k = ka + R1*kr: exponent by repeated addition, two-level table A[e >> lo] * B[e & mask]
+            const u32 line = (u32)(ra.line_offset + line0 + c);
+            const u32 nmask = (u32)ra.n_mask, lo_mask = (1u << ra.lo_bits) - 1;
+            u32 e = line * (u32)ka;
+            const u32 de = line * (u32)R1;
 #pragma unroll
-        for (int kr = 0; kr < R2; kr++) {
-            E x = v[brev_c(kr, LOGR2)];
-            if (ra.post_twiddle) {
-                // (line index) * k mod N in 32-bit arithmetic: N is a power of two <= 2^32, so wrap-around is harmless
-                const u32 e = ((u32)(ra.line_offset + line) * (u32)(ka + R1 * kr)) & (u32)ra.n_mask;
-                x = TW::mul(fd, x, TW::load(powA, powAq, e >> ra.lo_bits));
-                x = TW::mul(fd, x, TW::load(powB, powBq, e & (u32)lo_mask));
+            for (int kr = 0; kr < R2; kr++) {
+                const u32 em = e & nmask;
+                E x = v[brev_c(kr, LOGR2)];
+                x = TW::mul(fd, x, TW::load(powA, powAq, em >> ra.lo_bits));
+                x = TW::mul(fd, x, TW::load(powB, powBq, em & lo_mask));
+                v[brev_c(kr, LOGR2)] = x;
+                e += de;
             }
-            if (ra.do_scale) x = F::mul(fd, x, scale);
-            if (valid) dst[kr * step] = x;
+        }
+        if (ra.do_scale) {
+            const typename TW::W sw = TW::make_w(fd, (E)ra.scale, (E)ra.scale_q);
+#pragma unroll
+            for (int kr = 0; kr < R2; kr++) v[kr] = TW::mul(fd, v[kr], sw);
+        }
+        if (line0 + c < ra.total_lines) {
+            const u32 off = (u32)c * osc + (u32)ka * ost;
+            const u32 step = (u32)R1 * ost;
+#pragma unroll
+            for (int kr = 0; kr < R2; kr++) *reinterpret_cast<E *>(goutb + (off + (u32)kr * step)) = v[brev_c(kr, LOGR2)];
         }
     }
 }
@@ -498,6 +562,13 @@ template <class TW>
 constexpr int qbits_of()
 {
     if constexpr (TW::HAS_SHOUP) return TW::QBITS;
+    else return 0;
+}
+
+template <class TW>
+u64 shoup_quotient(const FieldDev &fd, u64 w)
+{
+    if constexpr (TW::HAS_SHOUP) return (w << TW::QBITS) / fd.p;
     else return 0;
 }
 
@@ -662,6 +733,13 @@ int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64
     constexpr size_t lds = sizeof(E) * ((size_t)C * (R1 * (R2 + 1) + 1) + 2 * L);
     ra.tiles_per_batch = (int)((ra.total_lines + C - 1) / C);
     const unsigned grid = (unsigned)(batch * ra.tiles_per_batch);
+    {
+        const i64 lim = ((i64)1 << 31) / (i64)sizeof(E);
+        if ((C - 1) * ra.in_stride_c + (L - 1) * ra.in_stride_t >= lim || (C - 1) * ra.out_stride_c + (L - 1) * ra.out_stride_t >= lim) {
+            set_error("register NTT: tile extent exceeds the 32-bit offset range");
+            return GFA_ERR_UNSUPPORTED;
+        }
+    }
     auto kern = ntt_reg_kernel<F, TW, LOGR1, LOGR2, THREADS>;
     static bool attr = false;
     if (!attr) {
@@ -762,13 +840,13 @@ int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n,
         ra.in_stride_c = n; ra.in_stride_t = 1; ra.out_stride_c = n; ra.out_stride_t = 1;
         ra.total_lines = batch;
         ra.load_along_line = 1; ra.store_along_line = 1;
-        ra.do_scale = do_scale; ra.scale = scale;
+        ra.do_scale = do_scale; ra.scale = scale; ra.scale_q = shoup_quotient<TW>(fd, scale);
         return launch_reg<F, TW>(fd, pl->log1, in, out, ra, 1, pl->wl1, pl->wl1q, nullptr, nullptr, nullptr, nullptr, st);
     }
     const i64 n1 = (i64)1 << pl->log1, n2 = (i64)1 << pl->log2;
     // Sub-batches keep the pass-1 -> pass-2 intermediate small enough to stay in the 256 MiB Infinity Cache instead of
     // making a round trip through HBM.
-    static const int sub_mb = env_int("GFA_NTT_SUBBATCH_MB", 64);
+    static const int sub_mb = env_int("GFA_NTT_SUBBATCH_MB", 0);
     i64 sub = batch;
     if (sub_mb > 0) {
         sub = ((i64)sub_mb << 20) / (i64)(sizeof(E) * (size_t)n);
@@ -796,7 +874,7 @@ int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n,
             ra.in_batch_stride = n; ra.out_batch_stride = n;
             ra.total_lines = n1;
             ra.load_along_line = 1; ra.store_along_line = 0;
-            ra.do_scale = do_scale; ra.scale = scale;
+            ra.do_scale = do_scale; ra.scale = scale; ra.scale_q = shoup_quotient<TW>(fd, scale);
             if ((rc = launch_reg<F, TW>(fd, pl->log2, pl->ws0.p, dst, ra, nb, pl->wl2, pl->wl2q, nullptr, nullptr, nullptr,
                                         nullptr, st)))
                 return rc;
