@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <map>
 #include <tuple>
+#include <type_traits>
 
 #include "gfa_internal.h"
 
@@ -94,61 +95,34 @@ struct TwShoup32 {
     }
 };
 
-// GF(p), p < 2^23: the same with 24-bit operands, so that every multiply is a full-rate v_mul_u32_u24 /
-// v_mul_hi_u32_u24 instead of the quarter-rate 32-bit multiplies.  wq = floor(w * 2^24 / p) < 2^24, x < p < 2^23:
-//   q = (wq * x) >> 24  (48-bit product, bits 24..47);  r = w*x - q*p  in [0, 2p)
-struct TwShoup24 {
+// GF(p), p < 2^30, register kernel only: Harvey-style lazy butterflies.  Values live in [0, 2p); a Shoup product
+// w*x - floor(wq*x / 2^32)*p lands in [0, 2p) for ANY 32-bit x, so neither the difference feeding a multiplication
+// nor its result needs a conditional correction.  (Measured on gfx950: v_mul_lo_u32 / v_mul_hi_u32 issue at the same
+// rate as the 24-bit multiplies, so the 32-bit form -- 3 multiplies -- beats the 24-bit one -- 4 multiplies + alignbit.)
+struct TwShoupLazy {
     typedef u32 E;
     static constexpr bool HAS_SHOUP = true;
-    static constexpr int QBITS = 24;
+    static constexpr int QBITS = 32;
+    static constexpr bool LAZY = true;
     struct W { u32 w, wq; };
+    struct Ctx { u32 p, p2; };
     static __device__ __forceinline__ W load(const u32 *tab, const u32 *tabq, u32 i) { return W{tab[i], tabq[i]}; }
-    static __device__ __forceinline__ u32 mul(const FieldDev &fd, u32 x, W t)
-    {
-        // operands masked to 24 bits: the AMDGPU back end selects v_mul_u32_u24 / v_mul_hi_u32_u24 for these products
-        const u64 prod = (u64)(t.wq & 0xffffffu) * (u64)(x & 0xffffffu);
-        const u32 q = (u32)(prod >> 24);
-        const u32 p = (u32)fd.p;
-        u32 qp; // q * p: forced to the 24-bit multiplier (the back end otherwise picks v_mul_lo_u32 for a uniform operand)
-        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(qp) : "v"(q), "v"(p));
-        u32 r = __umul24(t.w, x) - qp;
-        return min(r, r - p); // r in [0, 2p): unsigned min picks r - p exactly when r >= p
-    }
-    // p < 2^31: all sums stay below 2^32; unsigned min() selects the reduced value
-    static __device__ __forceinline__ u32 add(const FieldDev &fd, u32 a, u32 b)
-    {
-        const u32 c = a + b;
-        return min(c, c - (u32)fd.p);
-    }
-    static __device__ __forceinline__ u32 sub(const FieldDev &fd, u32 a, u32 b)
-    {
-        const u32 d = a - b;
-        return min(d, d + (u32)fd.p);
-    }
-    // (a - b) * w without reducing the difference first: a + p - b lies in (0, 2p), a valid multiplier input
-    static __device__ __forceinline__ u32 submul(const FieldDev &fd, u32 a, u32 b, W t) { return mul(fd, a + (u32)fd.p - b, t); }
-    // Per-thread context for the register kernel: the modulus in a VGPR whose value the optimiser cannot trace back to
-    // the (uniform) kernel argument, so that every use is a plain VALU operand.
-    struct Ctx { u32 p; };
     static __device__ __forceinline__ Ctx make_ctx(const FieldDev &fd)
     {
         u32 pv = (u32)fd.p;
         asm volatile("" : "+v"(pv));
-        return Ctx{pv};
+        return Ctx{pv, 2 * pv};
     }
     static __device__ __forceinline__ W make_w(Ctx, u32 w, u32 wq) { return W{w, wq}; }
-    static __device__ __forceinline__ u32 add(Ctx c, u32 a, u32 b) { const u32 s = a + b; return min(s, s - c.p); }
-    static __device__ __forceinline__ u32 sub(Ctx c, u32 a, u32 b) { const u32 d = a - b; return min(d, d + c.p); }
-    static __device__ __forceinline__ u32 submul(Ctx c, u32 a, u32 b, W t) { return mul(c, a + c.p - b, t); }
     static __device__ __forceinline__ u32 mul(Ctx c, u32 x, W t)
-    {
-        const u64 prod = (u64)(t.wq & 0xffffffu) * (u64)(x & 0xffffffu);
-        const u32 q = (u32)(prod >> 24);
-        u32 qp; // q * p on the full-rate 24-bit multiplier (hipcc otherwise lowers this product to v_mul_lo_u32)
-        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(qp) : "v"(q), "v"(c.p));
-        const u32 r = __umul24(t.w, x) - qp;
-        return min(r, r - c.p);
+    { // x: any u32; result in [0, 2p)
+        const u32 q = __umulhi(t.wq, x);
+        return t.w * x - q * c.p;
     }
+    static __device__ __forceinline__ u32 add(Ctx c, u32 a, u32 b) { const u32 s = a + b; return min(s, s - c.p2); }
+    static __device__ __forceinline__ u32 sub(Ctx c, u32 a, u32 b) { const u32 d = a + c.p2 - b; return min(d, d - c.p2); }
+    static __device__ __forceinline__ u32 submul(Ctx c, u32 a, u32 b, W t) { return mul(c, a + c.p2 - b, t); }
+    static __device__ __forceinline__ u32 canon(Ctx c, u32 a) { return min(a, a - c.p); } // [0, 2p) -> [0, p)
 };
 
 __device__ __forceinline__ u32 bitrev(u32 x, int bits) { return __brev(x) >> (32 - bits); }
@@ -333,6 +307,13 @@ __device__ __forceinline__ void reg_dif(typename TW::Ctx fd, typename F::elem (&
     }
 }
 
+template <class TW, class = void>
+struct LazyTrait { static constexpr bool value = false; };
+template <class TW>
+struct LazyTrait<TW, std::enable_if_t<TW::LAZY>> { static constexpr bool value = true; };
+template <class TW>
+constexpr bool is_lazy() { return LazyTrait<TW>::value; }
+
 constexpr int brev_c(int x, int bits)
 {
     int r = 0;
@@ -438,6 +419,10 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fdk, const ty
             const typename TW::W sw = TW::make_w(fd, (E)ra.scale, (E)ra.scale_q);
 #pragma unroll
             for (int kr = 0; kr < R2; kr++) v[kr] = TW::mul(fd, v[kr], sw);
+        }
+        if constexpr (is_lazy<TW>()) {
+#pragma unroll
+            for (int kr = 0; kr < R2; kr++) v[kr] = TW::canon(fd, v[kr]);
         }
         if (line0 + c < ra.total_lines) {
             const u32 off = (u32)c * osc + (u32)ka * ost;
@@ -945,7 +930,7 @@ int run_typed(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *
         while (((i64)1 << lg) < n) lg++;
         if (lg >= 2 && lg <= 2 * REG_MAX_LOG) {
             if constexpr (std::is_same<F, Prime32>::value) {
-                if (fd.p < (1ull << 23)) rc = run_pow2_reg<F, TwShoup24>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+                if (fd.p < (1ull << 30)) rc = run_pow2_reg<F, TwShoupLazy>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
                 else if (fd.p < (1ull << 31)) rc = run_pow2_reg<F, TwShoup32>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
                 else rc = run_pow2_reg<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
             } else {
@@ -1103,8 +1088,8 @@ int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64
         ta.in_stride_c = 1; ta.in_stride_t = cols; ta.out_stride_c = 1; ta.out_stride_t = cols;
         ta.post_twiddle = 1; ta.lo_bits = pl->lo_bits; ta.n_mask = (u64)n_total - 1; ta.line_offset = col0;
         ta.tw_in_lds = lg1 <= 12;
-        if constexpr (std::is_same<TW, TwShoup24>::value) {
-            set_error("gfa_ntt_columns: internal: 24-bit twiddles are only used by the register kernel");
+        if constexpr (std::is_same<TW, TwShoupLazy>::value) {
+            set_error("gfa_ntt_columns: internal: lazy twiddles are only used by the register kernel");
             return GFA_ERR_UNSUPPORTED;
         } else {
             return launch_tile<F, TW>(c, false, false, in, out, ta, 1, pl->w1, pl->w1q, pl->powA, pl->powB, st);
@@ -1112,7 +1097,7 @@ int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64
     };
     switch (c.kind) {
     case KIND_PRIME32:
-        if (c.p < (1ull << 23) && n1 <= ((i64)1 << REG_MAX_LOG)) return run(Prime32{}, TwShoup24{});
+        if (c.p < (1ull << 30) && n1 <= ((i64)1 << REG_MAX_LOG)) return run(Prime32{}, TwShoupLazy{});
         if (c.p < (1ull << 31)) return run(Prime32{}, TwShoup32{});
         return run(Prime32{}, Tw<Prime32>{});
     case KIND_PRIME64: return run(Prime64{}, Tw<Prime64>{});
