@@ -281,6 +281,7 @@ struct RegArgs {
     int do_scale;
     u64 scale;
     u64 scale_q; // Shoup quotient of `scale` for the twiddle class in use
+    int xcd_remap;
 };
 
 template <class F, class TW, int LOGR>
@@ -343,8 +344,12 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fdk, const ty
     E *twql = twl + L;                               // their Shoup quotients
 
     const int tid = threadIdx.x;
-    const i64 batch = blockIdx.x / ra.tiles_per_batch;
-    const i64 line0 = (i64)(blockIdx.x % ra.tiles_per_batch) * C;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (each XCD has its own L2).  Neighbouring tiles of a strided
+    // pass touch the two halves of the same 128-byte lines, so consecutive tiles are kept on ONE XCD.
+    u32 vb = blockIdx.x;
+    if (ra.xcd_remap) vb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const i64 batch = vb / ra.tiles_per_batch;
+    const i64 line0 = (i64)(vb % ra.tiles_per_batch) * C;
     // tile base pointers are wave-uniform (scalar 64-bit arithmetic); per-thread offsets inside a tile fit in 32 bits
     const E *gin = in + batch * ra.in_batch_stride + line0 * ra.in_stride_c;
     E *gout = out + batch * ra.out_batch_stride + line0 * ra.out_stride_c;
@@ -718,6 +723,8 @@ int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64
     constexpr size_t lds = sizeof(E) * ((size_t)C * (R1 * (R2 + 1) + 1) + 2 * L);
     ra.tiles_per_batch = (int)((ra.total_lines + C - 1) / C);
     const unsigned grid = (unsigned)(batch * ra.tiles_per_batch);
+    static const int xcd = env_int("GFA_NTT_XCD", 1);
+    ra.xcd_remap = (xcd && (grid % 8) == 0 && grid >= 16) ? 1 : 0;
     {
         const i64 lim = ((i64)1 << 31) / (i64)sizeof(E);
         if ((C - 1) * ra.in_stride_c + (L - 1) * ra.in_stride_t >= lim || (C - 1) * ra.out_stride_c + (L - 1) * ra.out_stride_t >= lim) {

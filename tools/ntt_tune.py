@@ -43,9 +43,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         child()
         sys.exit(0)
-    for wide in (0, 1):
-        for sub in (0,):
-            env = dict(os.environ, GFA_NTT_WIDE=str(wide), GFA_NTT_SUBBATCH_MB=str(sub))
+    for wide, sub, xcd in ((0, 0, 0), (0, 0, 1), (1, 0, 1)):
+        if True:
+            env = dict(os.environ, GFA_NTT_WIDE=str(wide), GFA_NTT_SUBBATCH_MB=str(sub), GFA_NTT_XCD=str(xcd))
             r = subprocess.run([sys.executable, __file__, "child"], env=env, capture_output=True, text=True)
             line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:]
-            print(f"wide={wide} sub_mb={sub}: {line}", flush=True)
+            print(f"wide={wide} sub_mb={sub} xcd={xcd}: {line}", flush=True)
