@@ -241,58 +241,12 @@ __global__ __launch_bounds__(1024) void rs_decode_kernel(RsTables t, RsParams rp
         } else {
             // ---- 1. syndromes S_j = r(alpha^(c+j)) (_bch.py:1370) ----
             bool nz = false;
-            if constexpr (BIN) {
-                // All 64 lanes work on independent terms instead of 32 lanes walking a 254-step Horner chain each:
-                // lane l owns the symbols i = l, l+64, ...; S_j = XOR_i r_i * alpha^((c+j)*i) with the product taken in
-                // the log domain, EXP[LOG r_i + ((c+j)*i*LOG alpha mod (q-1))], the exponent advancing by i*LOG alpha
-                // per syndrome.  The 32 partial sums per lane are then reduce-scattered across the wave: 32 lane
-                // exchanges in total (16+8+4+2+1+1) instead of 32 x 6.
-                const int qm1 = rp.qm1;
-                const int cm = rp.c % qm1;
-                for (int jb = 0; jb < dd; jb += 32) {
-                    u32 part[32];
-#pragma unroll
-                    for (int t = 0; t < 32; t++) part[t] = 0;
-                    for (int base = 0; base < n; base += 64) {
-                        const int i = base + lane;
-                        const u32 r = i < n ? ws.recv[i] : 0;
-                        if (r != 0) {
-                            const int lr = ar.log_t[r];
-                            const int step = (rp.log_alpha * i) % qm1;
-                            int e = (step * ((cm + jb) % qm1)) % qm1;
-#pragma unroll
-                            for (int t = 0; t < 32; t++) {
-                                part[t] ^= ar.exp_t[lr + e];
-                                e += step;
-                                e = e >= qm1 ? e - qm1 : e;
-                            }
-                        }
-                    }
-                    // reduce-scatter: after the step with partner lane^m, a lane keeps the half of its values selected
-                    // by its own bit m
-#pragma unroll
-                    for (int h = 16, m = 32; h >= 1; h >>= 1, m >>= 1) {
-                        const bool upper = (lane & m) != 0;
-#pragma unroll
-                        for (int t = 0; t < h; t++) {
-                            const u32 send = upper ? part[t] : part[t + h];
-                            const u32 keep = upper ? part[t + h] : part[t];
-                            part[t] = keep ^ (u32)__shfl_xor((int)send, m);
-                        }
-                    }
-                    u32 sj = part[0] ^ (u32)__shfl_xor((int)part[0], 1);
-                    const int j = jb + (lane >> 1); // bits 5..1 of the lane select the syndrome
-                    if ((lane & 1) == 0 && j < dd) ws.synd[j] = (uint8_t)sj;
-                    nz |= j < dd && sj != 0;
-                }
-            } else {
-                for (int j = lane; j < dd; j += 64) {
-                    const u32 x = roots_l[j];
-                    u32 acc = ws.recv[n - 1];
-                    for (int i = n - 2; i >= 0; i--) acc = ar.add(ar.mul(x, acc), ws.recv[i]);
-                    ws.synd[j] = (uint8_t)acc;
-                    nz |= acc != 0;
-                }
+            for (int j = lane; j < dd; j += 64) {
+                const u32 x = roots_l[j];
+                u32 acc = ws.recv[n - 1];
+                for (int i = n - 2; i >= 0; i--) acc = ar.add(ar.mul(x, acc), ws.recv[i]);
+                ws.synd[j] = (uint8_t)acc;
+                nz |= acc != 0;
             }
             const bool any_nz = __any(nz);
             if constexpr (DETECT_ONLY) {
