@@ -13,6 +13,8 @@
 // area owned by the wave, so there is no divergence between codewords with different error counts.
 // Field arithmetic is one LDS gather per operation from full 64 KiB tables (index (a<<8)|b) shared by the
 // workgroup; characteristic-2 fields use XOR for addition.
+#include <algorithm>
+
 #include "gfa_internal.h"
 
 using namespace gfa;
@@ -435,6 +437,396 @@ __global__ __launch_bounds__(1024) void rs_decode_kernel(RsTables t, RsParams rp
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LFSR remainder kernel (characteristic 2, (n-k) % 4 == 0, n-k <= 64): ONE CODEWORD PER LANE
+// ------------------------------------------------------------------------------------------------
+// Division by the generator polynomial g(x) as a byte-wide LFSR whose (n-k)-byte state lives in NKW VGPRs.  One step
+// per symbol: shift the state up by one byte and XOR in the table row  f * (g_{nk-1}, ..., g_0)  for the feedback
+// byte f -- a single wide LDS read instead of the (n-k) byte gathers a matrix-vector product spends per symbol
+// (16x fewer LDS operations for RS(255,223)).  The same loop serves
+//   ENCODE:  state <- m(x) * x^(n-k) mod g(x)   = the systematic parity symbols   (_LinearCode._encode_message)
+//   !ENCODE: state <- r(x) mod g(x)             = 0 iff all syndromes vanish      (_detect_errors; decoder pre-pass)
+// Identical values to the reference's matrix products: parity = message @ P is by construction -(m x^(n-k) mod g).
+template <int NKW, bool ENCODE>
+__global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ rowtab, const uint8_t *__restrict__ in,
+                                                      const uint8_t *__restrict__ eras, int len, uint8_t *__restrict__ out,
+                                                      int parity_only, uint8_t *__restrict__ rem_out,
+                                                      uint8_t *__restrict__ flag_out, i64 batch, int stage_bytes)
+{
+    constexpr int NK = NKW * 4;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    u32 *T = reinterpret_cast<u32 *>(lds_raw); // 256 rows x NKW words
+    for (int i = threadIdx.x; i < 256 * NKW; i += blockDim.x) T[i] = rowtab[i];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    uint8_t *stage = lds_raw + 256 * NK + (size_t)wave * stage_bytes;
+    __syncthreads();
+    const int ns_out = len + NK;
+    for (i64 cw0 = ((i64)blockIdx.x * nwaves + wave) * 64; cw0 < batch; cw0 += (i64)gridDim.x * nwaves * 64) {
+        const int count = (int)(batch - cw0 < 64 ? batch - cw0 : 64);
+        const uint8_t *src = in + cw0 * len;
+        const int nbytes = count * len;
+        // ---- stage this wave's rows (contiguous in memory) into LDS ----
+        if (ENCODE && !parity_only) {
+            // the message symbols are also the first ks symbols of each output codeword
+            for (int row = 0; row < count; row++) {
+                const uint8_t *rs = src + row * len;
+                uint8_t *rd = out + (cw0 + row) * ns_out;
+                for (int i = lane; i < len; i += 64) {
+                    const uint8_t v = rs[i];
+                    stage[row * len + i] = v;
+                    rd[i] = v;
+                }
+            }
+        } else {
+            const bool al = ((reinterpret_cast<uintptr_t>(src) | (eras ? reinterpret_cast<uintptr_t>(eras + cw0 * len) : 0)) & 15) == 0;
+            int done = 0;
+            if (al) {
+                const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+                const uint4 *e4 = eras ? reinterpret_cast<const uint4 *>(eras + cw0 * len) : nullptr;
+                uint4 *d4 = reinterpret_cast<uint4 *>(stage);
+                const int nv = nbytes >> 4;
+                for (int i = lane; i < nv; i += 64) {
+                    uint4 v = s4[i];
+                    if (e4) { // erased symbols are treated as zeros (_bch.py:1355): byte mask from "non-zero"
+                        const uint4 e = e4[i];
+                        auto mask = [](u32 w) -> u32 { return ((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) >> 7 & 0x01010101u) * 0xffu; };
+                        v.x &= ~mask(e.x); v.y &= ~mask(e.y); v.z &= ~mask(e.z); v.w &= ~mask(e.w);
+                    }
+                    d4[i] = v;
+                }
+                done = nv << 4;
+            }
+            for (int i = done + lane; i < nbytes; i += 64) {
+                uint8_t v = src[i];
+                if (eras && eras[cw0 * len + i]) v = 0;
+                stage[i] = v;
+            }
+        }
+        wave_sync();
+        // ---- the LFSR: lane t divides row t ----
+        u32 st[NKW];
+#pragma unroll
+        for (int d = 0; d < NKW; d++) st[d] = 0;
+        if (lane < count) {
+            const uint8_t *row = stage + lane * len;
+            for (int i = 0; i < len; i++) {
+                const u32 sym = row[i];
+                const u32 top = st[0] >> 24;
+                const u32 f = ENCODE ? (sym ^ top) : top;
+#pragma unroll
+                for (int d = 0; d + 1 < NKW; d++) st[d] = __builtin_amdgcn_alignbit(st[d], st[d + 1], 24);
+                st[NKW - 1] = (st[NKW - 1] << 8) | (ENCODE ? 0u : sym);
+                const u32 *r = T + f * NKW;
+#pragma unroll
+                for (int d = 0; d < NKW; d++) st[d] ^= r[d];
+            }
+        }
+        wave_sync();
+        if (ENCODE) {
+            // parity bytes (highest degree first) -> LDS -> global
+            u32 *ps = reinterpret_cast<u32 *>(stage) + lane * NKW;
+            if (lane < count) {
+#pragma unroll
+                for (int d = 0; d < NKW; d++) ps[d] = __builtin_bswap32(st[d]);
+            }
+            wave_sync();
+            if (parity_only) {
+                u32 *dst = reinterpret_cast<u32 *>(out + cw0 * NK);
+                const u32 *pw = reinterpret_cast<const u32 *>(stage);
+                if ((reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
+                    for (int i = lane; i < count * NKW; i += 64) dst[i] = pw[i];
+                } else {
+                    for (int i = lane; i < count * NK; i += 64) out[cw0 * NK + i] = stage[i];
+                }
+            } else {
+                for (int row = 0; row < count; row++) {
+                    uint8_t *rd = out + (cw0 + row) * ns_out + len;
+                    for (int j = lane; j < NK; j += 64) rd[j] = stage[row * NK + j];
+                }
+            }
+        } else {
+            u32 nzw = 0;
+#pragma unroll
+            for (int d = 0; d < NKW; d++) nzw |= st[d];
+            if (lane < count) {
+                if (rem_out) {
+                    u32 *dst = reinterpret_cast<u32 *>(rem_out) + (cw0 + lane) * NKW; // rem_out is 16-byte aligned scratch
+#pragma unroll
+                    for (int d = 0; d < NKW; d++) dst[d] = __builtin_bswap32(st[d]);
+                }
+                if (flag_out) flag_out[cw0 + lane] = nzw != 0;
+            }
+        }
+        wave_sync();
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Fast decoder for characteristic-2 codes with n-k <= 60: second kernel of the two-kernel decode
+// ------------------------------------------------------------------------------------------------
+// rs_lfsr_kernel has already reduced every received word modulo g(x).  Words with a zero remainder and no erasures
+// are copied through.  The rest are decoded ONE CODEWORD PER WAVEFRONT with the same mathematics and failure exits as
+// rs_decode_kernel / bch_decode_jit, arranged so that almost no step is a chain of dependent LDS gathers:
+//   * syndromes S_j = rem(alpha^(c+j)) from the (n-k)-term remainder, in the log domain (independent gathers);
+//   * Berlekamp-Massey with C(x) and x^m B(x) held one coefficient per lane in VGPRs, the discrepancy folded with DPP;
+//   * Chien search and Forney's formula in the log domain: lambda_k * x^k = EXP[LOG lambda_k + k LOG x], all terms
+//     independent, four codeword positions per lane in flight.
+struct WaveScratch2 {
+    uint8_t *recv, *synd, *gamma, *sprime, *lam, *ltotal, *omega, *epos, *errpos, *errloc;
+    static __host__ __device__ int bytes(int n, int dd) { return ((n + 11 * (dd + 4) + 15) / 16) * 16; }
+    __device__ void carve(uint8_t *p, int n, int dd)
+    {
+        const int s = dd + 4;
+        recv = p; p += n;
+        synd = p; p += s; gamma = p; p += s; sprime = p; p += s; lam = p; p += s; ltotal = p; p += 2 * s;
+        omega = p; p += s; epos = p; p += s; errpos = p; p += s; errloc = p; p += s;
+    }
+};
+
+__device__ __forceinline__ int lane_shift_up1(int v, int lane)
+{ // lane i <- lane i-1, lane 0 <- 0
+    int t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); // row_shr:1, zero fill at each row start
+    const int r15 = __builtin_amdgcn_readlane(v, 15), r31 = __builtin_amdgcn_readlane(v, 31), r47 = __builtin_amdgcn_readlane(v, 47);
+    t = lane == 16 ? r15 : t;
+    t = lane == 32 ? r31 : t;
+    t = lane == 48 ? r47 : t;
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void rs_decode_bin_kernel(RsTables t, RsParams rp, const uint8_t *__restrict__ recv_g,
+                                                             const uint8_t *__restrict__ eras_g,
+                                                             const uint8_t *__restrict__ rem_g, int n,
+                                                             uint8_t *__restrict__ out_g, i64 *__restrict__ nerr_g, i64 batch)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    Arith8<true> ar;
+    uint8_t *free_l = stage_tables<true>(lds_raw, t, ar, rp.qm1, blockDim.x);
+    const int dd = rp.nroots, qm1 = rp.qm1, la = rp.log_alpha;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    WaveScratch2 ws;
+    ws.carve(free_l + (size_t)wave * WaveScratch2::bytes(n, dd), n, dd);
+    __syncthreads();
+    const unsigned long long lt_mask = ((unsigned long long)1 << lane) - 1;
+    const int cm = rp.c % qm1;
+    const int lroot = (la * ((cm + lane) % qm1)) % qm1; // LOG of root_j = alpha^(c+j) for j = lane
+
+    for (i64 cw = (i64)blockIdx.x * nwaves + wave; cw < batch; cw += (i64)gridDim.x * nwaves) {
+        const uint8_t *row = recv_g + cw * n;
+        uint8_t *orow = out_g + cw * n;
+        // remainder coefficient of x^lane (stored highest degree first)
+        const u32 remc = lane < dd ? rem_g[cw * dd + (dd - 1 - lane)] : 0;
+        const bool any_nz = __any(remc != 0);
+        if (!any_nz && !eras_g) { // clean word (_bch.py:1373-1376)
+            for (int j = lane; j < n; j += 64) orow[j] = row[j];
+            if (lane == 0) nerr_g[cw] = 0;
+            continue;
+        }
+        // ---- received word ascending, erased symbols zeroed (_bch.py:1351-1355) ----
+        int u = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            bool er = false;
+            if (i < n) {
+                const u32 r = row[n - 1 - i];
+                if (eras_g) er = eras_g[cw * n + (n - 1 - i)] != 0;
+                ws.recv[i] = er ? 0 : (uint8_t)r;
+            }
+            const unsigned long long m = __ballot(er);
+            if (er && u + __popcll(m & lt_mask) < dd + 4) ws.epos[u + __popcll(m & lt_mask)] = (uint8_t)i;
+            u += __popcll(m);
+        }
+        int status = 0, v = 0;
+        if (u > dd) {
+            status = -1;
+        } else if (!any_nz && u == 0) {
+            status = 1;
+        } else {
+            // ---- 1. syndromes from the remainder: S_j = sum_t rem_t * root_j^t ----
+            {
+                const int lrem = remc ? (int)ar.log_t[remc] : -1;
+                u32 acc = 0;
+                int e = 0;
+                for (int tt = 0; tt < dd; tt++) {
+                    const int lt = __builtin_amdgcn_readlane(lrem, tt);
+                    if (lt >= 0) acc ^= ar.exp_t[lt + e];
+                    e += lroot;
+                    e = e >= qm1 ? e - qm1 : e;
+                }
+                if (lane < dd) ws.synd[lane] = (uint8_t)acc;
+            }
+            wave_sync();
+            // ---- 2. erasure locator (_bch.py:1389-1393) ----
+            int glen = 1;
+            if (lane == 0) ws.gamma[0] = 1;
+            wave_sync();
+            for (int k = 0; k < u; k++) {
+                const int e = ws.epos[k];
+                const u32 Yk = ar.exp_t[(la * e) % qm1];
+                u32 g = 0;
+                if (lane <= glen) {
+                    const u32 gi = lane < glen ? ws.gamma[lane] : 0;
+                    const u32 gm = lane >= 1 ? ws.gamma[lane - 1] : 0;
+                    g = gi ^ ar.mul(gm, Yk);
+                }
+                wave_sync();
+                if (lane <= glen) ws.gamma[lane] = (uint8_t)g;
+                glen++;
+                wave_sync();
+            }
+            // ---- 3. modified syndromes S' = Gamma * S mod x^(d-1) (_bch.py:1408-1409) ----
+            if (lane < dd) {
+                u32 acc = 0;
+                const int imax = lane < glen - 1 ? lane : glen - 1;
+                for (int i = 0; i <= imax; i++) acc ^= ar.mul(ws.gamma[i], ws.synd[lane - i]);
+                ws.sprime[lane] = (uint8_t)acc;
+            }
+            wave_sync();
+            // ---- 4. Berlekamp-Massey on S'[u:], coefficients one per lane (_lfsr.py:1647-1702) ----
+            int llen = 1;
+            const int nsq = dd - u;
+            u32 Creg = lane == 0 ? 1u : 0u;
+            if (nsq > 0) {
+                const int Sall = lane < nsq ? (int)ws.sprime[u + lane] : 0;
+                u32 Bs = (lane == 1 && nsq > 1) ? 1u : 0u; // x^m * B(x) with m = 1, B = 1
+                int Sreg = 0;                               // S[k - lane]
+                int L = 0;
+                u32 binv = 1;
+                for (int k = 0; k < nsq; k++) {
+                    Sreg = lane_shift_up1(Sreg, lane);
+                    const int sk = __builtin_amdgcn_readlane(Sall, k);
+                    if (lane == 0) Sreg = sk;
+                    const u32 term = lane <= L ? ar.mul((u32)Sreg, Creg) : 0u;
+                    const u32 dsc = ar.wave_sum(term);
+                    u32 nextB = Bs;
+                    if (dsc != 0) {
+                        const u32 coef = ar.mul(dsc, binv);
+                        const u32 cnew = Creg ^ ar.mul(coef, Bs);
+                        if (!(2 * L > k)) {
+                            nextB = Creg;
+                            L = k + 1 - L;
+                            binv = ar.inv(dsc);
+                        }
+                        Creg = cnew;
+                    }
+                    const int sh = lane_shift_up1((int)nextB, lane);
+                    Bs = lane < nsq ? (u32)sh : 0u;
+                }
+                const int clen = L + 1 < nsq ? L + 1 : nsq;
+                const unsigned long long mk = __ballot(lane < clen && Creg != 0);
+                llen = mk ? 64 - __clzll((long long)mk) : 1;
+            }
+            if (lane < dd + 4) ws.lam[lane] = lane < llen ? (uint8_t)Creg : 0;
+            v = llen - 1;
+            wave_sync();
+            if (2 * v + u > dd) {
+                status = -1; // _bch.py:1431-1433
+            } else {
+                // ---- 5. Lambda_total = Gamma * Lambda ----
+                const int ltlen = glen + llen - 1;
+                u32 ltk = 0;
+                if (lane < ltlen) {
+                    const int ilo = lane - (llen - 1) > 0 ? lane - (llen - 1) : 0;
+                    const int ihi = lane < glen - 1 ? lane : glen - 1;
+                    for (int i = ilo; i <= ihi; i++) ltk ^= ar.mul(ws.gamma[i], ws.lam[lane - i]);
+                    ws.ltotal[lane] = (uint8_t)ltk;
+                }
+                const int ltl = (lane < ltlen && ltk) ? (int)ar.log_t[ltk] : -1; // LOG of coefficient `lane`
+                // ---- 6. Chien search, log domain, positions lane, lane+64, lane+128, lane+192 ----
+                int stepn[4], ee[4];
+                u32 acc[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) {
+                    const int i = lane + 64 * s4;
+                    stepn[s4] = (qm1 - (la * i) % qm1) % qm1; // LOG alpha^(-i)
+                    ee[s4] = 0;
+                    acc[s4] = 0;
+                }
+                for (int k = 0; k < ltlen; k++) {
+                    const int lk = __builtin_amdgcn_readlane(ltl, k);
+                    if (lk >= 0) {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; s4++) acc[s4] ^= ar.exp_t[lk + ee[s4]];
+                    }
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; s4++) {
+                        ee[s4] += stepn[s4];
+                        ee[s4] = ee[s4] >= qm1 ? ee[s4] - qm1 : ee[s4];
+                    }
+                }
+                int v_total = 0;
+                bool out_of_range_root = false;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) {
+                    const int i = lane + 64 * s4;
+                    const bool root = i < rp.n && acc[s4] == 0;
+                    if (__any(root && i >= n)) out_of_range_root = true;
+                    const bool rec = root && i < n;
+                    const unsigned long long mk = __ballot(rec);
+                    if (rec) {
+                        const int slot = v_total + __popcll(mk & lt_mask);
+                        if (slot < dd + 4) { ws.errpos[slot] = (uint8_t)i; ws.errloc[slot] = (uint8_t)ar.exp_t[stepn[s4]]; }
+                    }
+                    v_total += __popcll(mk);
+                }
+                wave_sync();
+                if (out_of_range_root || v_total != v + u) {
+                    status = -1; // _bch.py:1469-1485
+                } else {
+                    // ---- 7. Omega' = Lambda * S' mod x^(d-1) ----
+                    u32 om = 0;
+                    if (lane < dd) {
+                        const int ihi = lane < llen - 1 ? lane : llen - 1;
+                        for (int i = 0; i <= ihi; i++) om ^= ar.mul(ws.lam[i], ws.sprime[lane - i]);
+                    }
+                    const int lom = om ? (int)ar.log_t[om] : -1;
+                    // ---- 8./9./10. Forney in the log domain, one located symbol per lane ----
+                    // (char 2: the formal derivative keeps the odd-degree coefficients of Lambda_total, _bch.py:1512-1515)
+                    const int L_total = ltlen - 1;
+                    u32 num = 0, den = 0;
+                    int lx = 0;
+                    const bool act = lane < v_total;
+                    if (act) lx = ar.log_t[ws.errloc[lane]];
+                    {
+                        int e = 0;
+                        for (int tt = 0; tt < dd; tt++) {
+                            const int lo = __builtin_amdgcn_readlane(lom, tt);
+                            if (lo >= 0) num ^= ar.exp_t[lo + e];
+                            e += lx;
+                            e = e >= qm1 ? e - qm1 : e;
+                        }
+                        int e2 = 0, lx2 = 2 * lx;
+                        lx2 = lx2 >= qm1 ? lx2 - qm1 : lx2;
+                        for (int j = 1; j <= L_total; j += 2) {
+                            const int lj = __builtin_amdgcn_readlane(ltl, j);
+                            if (lj >= 0) den ^= ar.exp_t[lj + e2];
+                            e2 += lx2;
+                            e2 = e2 >= qm1 ? e2 - qm1 : e2;
+                        }
+                    }
+                    if (act && num != 0 && den != 0) {
+                        int ex = (int)ar.log_t[num] - (int)ar.log_t[den] + ((rp.c - 1) % qm1) * lx;
+                        ex %= qm1;
+                        if (ex < 0) ex += qm1;
+                        const int pos = ws.errpos[lane];
+                        ws.recv[pos] ^= ar.exp_t[ex];
+                    }
+                    wave_sync();
+                    status = 0;
+                }
+            }
+        }
+        if (status == 0) {
+            for (int j = lane; j < n; j += 64) orow[j] = ws.recv[n - 1 - j];
+        } else {
+            for (int j = lane; j < n; j += 64) orow[j] = row[j];
+        }
+        if (lane == 0) nerr_g[cw] = status < 0 ? -1 : (status == 1 ? 0 : v);
+        wave_sync();
+    }
+}
+
 int rs_check_device_path(const gfa_rs *code, int dtype, const char *what)
 {
     if (!code->field->has_tab8 || dtype != GFA_U8) {
@@ -482,6 +874,42 @@ int cu_count()
     return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 }
 
+
+bool lfsr_eligible(const gfa_rs *code)
+{
+    const int64_t nk = code->n - code->k;
+    return code->field->has_tab8 && code->field->calc.p == 2 && code->systematic && nk >= 4 && nk <= 64 && (nk % 4) == 0;
+}
+
+template <bool ENCODE>
+int launch_lfsr(gfa_rs *code, gfa_rs::Dev *cd, const uint8_t *in, const uint8_t *eras, int len, uint8_t *out,
+                int parity_only, uint8_t *rem_out, uint8_t *flag_out, i64 batch, hipStream_t st)
+{
+    const int nk = (int)(code->n - code->k), nkw = nk / 4;
+    const int stage_bytes = ((64 * std::max(len, nk) + 15) / 16) * 16;
+    const int threads = 256;
+    const size_t lds = (size_t)256 * nk + (size_t)(threads / 64) * stage_bytes;
+    const i64 blocks = (batch + threads - 1) / threads;
+    const int grid = (int)std::max<i64>(1, std::min<i64>(blocks, (i64)cu_count() * 2));
+#define GFA_LFSR(W)                                                                                                     \
+    case W: {                                                                                                           \
+        static bool attr = false;                                                                                       \
+        int rc = set_lds_limit(rs_lfsr_kernel<W, ENCODE>, &attr);                                                       \
+        if (rc) return rc;                                                                                              \
+        hipLaunchKernelGGL((rs_lfsr_kernel<W, ENCODE>), dim3(grid), dim3(threads), lds, st, cd->lfsr, in, eras, len, out, \
+                           parity_only, rem_out, flag_out, batch, stage_bytes);                                         \
+        break;                                                                                                          \
+    }
+    switch (nkw) {
+        GFA_LFSR(1) GFA_LFSR(2) GFA_LFSR(3) GFA_LFSR(4) GFA_LFSR(5) GFA_LFSR(6) GFA_LFSR(7) GFA_LFSR(8)
+        GFA_LFSR(9) GFA_LFSR(10) GFA_LFSR(11) GFA_LFSR(12) GFA_LFSR(13) GFA_LFSR(14) GFA_LFSR(15) GFA_LFSR(16)
+    default: set_error("lfsr: unsupported parity length"); return GFA_ERR_UNSUPPORTED;
+    }
+#undef GFA_LFSR
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
 } // namespace
 
 int gfa_rs::ensure_device(int *device_out, Dev **out)
@@ -500,6 +928,21 @@ int gfa_rs::ensure_device(int *device_out, Dev **out)
         GFA_HIP(hipMalloc((void **)&st.roots8, std::max<size_t>(r8.size(), 16)));
         if (!P8.empty()) GFA_HIP(hipMemcpy(st.P8, P8.data(), P8.size(), hipMemcpyHostToDevice));
         if (!r8.empty()) GFA_HIP(hipMemcpy(st.roots8, r8.data(), r8.size(), hipMemcpyHostToDevice));
+        if (field->has_tab8 && field->calc.p == 2 && nk >= 4 && nk <= 64 && nk % 4 == 0) {
+            // LFSR rows: word d of row f packs f * gpoly[1 + 4d .. 4d + 3] (coefficients of x^(nk-1-4d) ..), first in the top byte
+            std::vector<uint32_t> rows(256 * (nk / 4));
+            for (uint32_t fb = 0; fb < 256; fb++)
+                for (size_t d = 0; d < nk / 4; d++) {
+                    uint32_t w = 0;
+                    for (int b = 0; b < 4; b++) {
+                        const uint64_t gc = gpoly[1 + 4 * d + b];
+                        w = (w << 8) | (fb < field->calc.q && gc < field->calc.q ? field->h_mul8[(fb << 8) | gc] : 0);
+                    }
+                    rows[fb * (nk / 4) + d] = w;
+                }
+            GFA_HIP(hipMalloc((void **)&st.lfsr, rows.size() * sizeof(uint32_t)));
+            GFA_HIP(hipMemcpy(st.lfsr, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
         st.ready = true;
     }
     if (device_out) *device_out = d;
@@ -559,7 +1002,7 @@ void gfa_rs_destroy(gfa_rs_t *code)
 {
     if (!code) return;
     for (auto &st : code->dev)
-        if (st.ready) { (void)hipFree(st.P8); (void)hipFree(st.roots8); (void)hipFree(st.lfsr); }
+        if (st.ready) { (void)hipFree(st.P8); (void)hipFree(st.roots8); (void)hipFree(st.lfsr); (void)hipFree(st.rem); }
     delete code;
 }
 
@@ -590,6 +1033,9 @@ int gfa_rs_encode(gfa_rs_t *code, const void *msg, int64_t ks, void *out, int64_
         if (!parity_only) GFA_HIP(hipMemcpyAsync(out, msg, (size_t)(batch * ks), hipMemcpyDeviceToDevice, (hipStream_t)stream));
         return GFA_OK;
     }
+    if (lfsr_eligible(code) && cd->lfsr)
+        return launch_lfsr<true>(code, cd, (const uint8_t *)msg, nullptr, (int)ks, (uint8_t *)out, parity_only, nullptr, nullptr,
+                                 batch, (hipStream_t)stream);
     int groups = 1;
     while (groups < 64 && (64 / (groups * 2)) >= nk) groups *= 2;
     const size_t mpitch = (((size_t)ks + 15) / 16) * 16;
@@ -665,6 +1111,15 @@ int gfa_rs_detect(gfa_rs_t *code, const void *cw, int64_t ns, uint8_t *detected,
         GFA_HIP(hipMemsetAsync(detected, 0, (size_t)batch, (hipStream_t)stream));
         return GFA_OK;
     }
+    if (lfsr_eligible(code)) {
+        FieldDeviceState *ds;
+        gfa_rs::Dev *cd;
+        if ((rc = code->field->ensure_device(nullptr, &ds))) return rc;
+        if ((rc = code->ensure_device(nullptr, &cd))) return rc;
+        if (cd->lfsr)
+            return launch_lfsr<false>(code, cd, (const uint8_t *)cw, nullptr, (int)ns, nullptr, 0, nullptr, detected, batch,
+                                      (hipStream_t)stream);
+    }
     return launch_decode(code, cw, nullptr, ns, nullptr, nullptr, detected, batch, true, (hipStream_t)stream);
 }
 
@@ -682,6 +1137,39 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
         GFA_HIP(hipMemcpyAsync(out_codeword, recv, (size_t)(batch * ns), hipMemcpyDeviceToDevice, (hipStream_t)stream));
         GFA_HIP(hipMemsetAsync(out_n_errors, 0, sizeof(int64_t) * (size_t)batch, (hipStream_t)stream));
         return GFA_OK;
+    }
+    if (lfsr_eligible(code) && code->n - code->k <= 60) {
+        FieldDeviceState *ds;
+        gfa_rs::Dev *cd;
+        if ((rc = code->field->ensure_device(nullptr, &ds))) return rc;
+        if ((rc = code->ensure_device(nullptr, &cd))) return rc;
+        if (cd->lfsr) {
+            hipStream_t st = (hipStream_t)stream;
+            const int nk = (int)(code->n - code->k);
+            const size_t need = (size_t)batch * nk;
+            if (cd->rem_bytes < need) {
+                if (cd->rem) GFA_HIP(hipFree(cd->rem));
+                cd->rem = nullptr; cd->rem_bytes = 0;
+                GFA_HIP(hipMalloc((void **)&cd->rem, need));
+                cd->rem_bytes = need;
+            }
+            if ((rc = launch_lfsr<false>(code, cd, (const uint8_t *)recv, erasures, (int)ns, nullptr, 0, cd->rem, nullptr, batch, st)))
+                return rc;
+            const RsParams rp = make_params(code);
+            const size_t fixed = 65536 + 1280;
+            const size_t per_wave = (size_t)WaveScratch2::bytes((int)ns, nk);
+            const int nwaves = 16;
+            const size_t lds = fixed + nwaves * per_wave;
+            static bool attr = false;
+            if ((rc = set_lds_limit(rs_decode_bin_kernel, &attr))) return rc;
+            const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+            const int grid = (int)std::max<i64>(1, std::min<i64>((batch + nwaves - 1) / nwaves, (i64)cu_count() * per_cu));
+            hipLaunchKernelGGL(rs_decode_bin_kernel, dim3(grid), dim3(nwaves * 64), lds, st, make_tables(*ds), rp,
+                               (const uint8_t *)recv, erasures, cd->rem, (int)ns, (uint8_t *)out_codeword, (i64 *)out_n_errors,
+                               batch);
+            GFA_HIP(hipGetLastError());
+            return GFA_OK;
+        }
     }
     return launch_decode(code, recv, erasures, ns, out_codeword, out_n_errors, nullptr, batch, false, (hipStream_t)stream);
 }
