@@ -611,6 +611,7 @@ __global__ __launch_bounds__(1024) void rs_decode_bin_kernel(RsTables t, RsParam
     const unsigned long long lt_mask = ((unsigned long long)1 << lane) - 1;
     const int cm = rp.c % qm1;
     const int lroot = (la * ((cm + lane) % qm1)) % qm1; // LOG of root_j = alpha^(c+j) for j = lane
+    const int ZIDX = 2 * (qm1 + 1) - 1;                 // EXP[2q-1] == 0
 
     for (i64 cw = (i64)blockIdx.x * nwaves + wave; cw < batch; cw += (i64)gridDim.x * nwaves) {
         const uint8_t *row = recv_g + cw * n;
@@ -648,9 +649,12 @@ __global__ __launch_bounds__(1024) void rs_decode_bin_kernel(RsTables t, RsParam
                 const int lrem = remc ? (int)ar.log_t[remc] : -1;
                 u32 acc = 0;
                 int e = 0;
+                // a zero coefficient is redirected to EXP[2q-1] == 0 (the unused last entry of the doubled table,
+                // _lookup.py:371), which keeps the loop branch-free so that several gathers are in flight at once
+#pragma unroll 8
                 for (int tt = 0; tt < dd; tt++) {
                     const int lt = __builtin_amdgcn_readlane(lrem, tt);
-                    if (lt >= 0) acc ^= ar.exp_t[lt + e];
+                    acc ^= ar.exp_t[lt >= 0 ? lt + e : ZIDX];
                     e += lroot;
                     e = e >= qm1 ? e - qm1 : e;
                 }
@@ -689,10 +693,10 @@ __global__ __launch_bounds__(1024) void rs_decode_bin_kernel(RsTables t, RsParam
             u32 Creg = lane == 0 ? 1u : 0u;
             if (nsq > 0) {
                 const int Sall = lane < nsq ? (int)ws.sprime[u + lane] : 0;
-                u32 Bs = (lane == 1 && nsq > 1) ? 1u : 0u; // x^m * B(x) with m = 1, B = 1
+                // Bs holds x^m * B(x) / b, so the update C -= (d/b) x^m B is ONE table gather on the critical path
+                u32 Bs = (lane == 1 && nsq > 1) ? 1u : 0u; // m = 1, B = 1, b = 1
                 int Sreg = 0;                               // S[k - lane]
                 int L = 0;
-                u32 binv = 1;
                 for (int k = 0; k < nsq; k++) {
                     Sreg = lane_shift_up1(Sreg, lane);
                     const int sk = __builtin_amdgcn_readlane(Sall, k);
@@ -701,12 +705,10 @@ __global__ __launch_bounds__(1024) void rs_decode_bin_kernel(RsTables t, RsParam
                     const u32 dsc = ar.wave_sum(term);
                     u32 nextB = Bs;
                     if (dsc != 0) {
-                        const u32 coef = ar.mul(dsc, binv);
-                        const u32 cnew = Creg ^ ar.mul(coef, Bs);
+                        const u32 cnew = Creg ^ ar.mul(dsc, Bs);
                         if (!(2 * L > k)) {
-                            nextB = Creg;
+                            nextB = ar.mul(ar.inv(dsc), Creg); // new B / new b = C_old / d
                             L = k + 1 - L;
-                            binv = ar.inv(dsc);
                         }
                         Creg = cnew;
                     }
@@ -729,6 +731,7 @@ __global__ __launch_bounds__(1024) void rs_decode_bin_kernel(RsTables t, RsParam
                 if (lane < ltlen) {
                     const int ilo = lane - (llen - 1) > 0 ? lane - (llen - 1) : 0;
                     const int ihi = lane < glen - 1 ? lane : glen - 1;
+#pragma unroll 4
                     for (int i = ilo; i <= ihi; i++) ltk ^= ar.mul(ws.gamma[i], ws.lam[lane - i]);
                     ws.ltotal[lane] = (uint8_t)ltk;
                 }
@@ -743,14 +746,12 @@ __global__ __launch_bounds__(1024) void rs_decode_bin_kernel(RsTables t, RsParam
                     ee[s4] = 0;
                     acc[s4] = 0;
                 }
+#pragma unroll 2
                 for (int k = 0; k < ltlen; k++) {
                     const int lk = __builtin_amdgcn_readlane(ltl, k);
-                    if (lk >= 0) {
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; s4++) acc[s4] ^= ar.exp_t[lk + ee[s4]];
-                    }
 #pragma unroll
                     for (int s4 = 0; s4 < 4; s4++) {
+                        acc[s4] ^= ar.exp_t[lk >= 0 ? lk + ee[s4] : ZIDX];
                         ee[s4] += stepn[s4];
                         ee[s4] = ee[s4] >= qm1 ? ee[s4] - qm1 : ee[s4];
                     }
@@ -778,6 +779,7 @@ __global__ __launch_bounds__(1024) void rs_decode_bin_kernel(RsTables t, RsParam
                     u32 om = 0;
                     if (lane < dd) {
                         const int ihi = lane < llen - 1 ? lane : llen - 1;
+#pragma unroll 4
                         for (int i = 0; i <= ihi; i++) om ^= ar.mul(ws.lam[i], ws.sprime[lane - i]);
                     }
                     const int lom = om ? (int)ar.log_t[om] : -1;
@@ -790,17 +792,19 @@ __global__ __launch_bounds__(1024) void rs_decode_bin_kernel(RsTables t, RsParam
                     if (act) lx = ar.log_t[ws.errloc[lane]];
                     {
                         int e = 0;
+#pragma unroll 8
                         for (int tt = 0; tt < dd; tt++) {
                             const int lo = __builtin_amdgcn_readlane(lom, tt);
-                            if (lo >= 0) num ^= ar.exp_t[lo + e];
+                            num ^= ar.exp_t[lo >= 0 ? lo + e : ZIDX];
                             e += lx;
                             e = e >= qm1 ? e - qm1 : e;
                         }
                         int e2 = 0, lx2 = 2 * lx;
                         lx2 = lx2 >= qm1 ? lx2 - qm1 : lx2;
+#pragma unroll 4
                         for (int j = 1; j <= L_total; j += 2) {
                             const int lj = __builtin_amdgcn_readlane(ltl, j);
-                            if (lj >= 0) den ^= ar.exp_t[lj + e2];
+                            den ^= ar.exp_t[lj >= 0 ? lj + e2 : ZIDX];
                             e2 += lx2;
                             e2 = e2 >= qm1 ? e2 - qm1 : e2;
                         }
