@@ -452,7 +452,7 @@ template <int NKW, bool ENCODE>
 __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ rowtab, const uint8_t *__restrict__ in,
                                                       const uint8_t *__restrict__ eras, int len, uint8_t *__restrict__ out,
                                                       int parity_only, uint8_t *__restrict__ rem_out,
-                                                      uint8_t *__restrict__ flag_out, i64 batch, int stage_bytes)
+                                                      uint8_t *__restrict__ flag_out, i64 batch, int stage_bytes, u32 div_magic)
 {
     constexpr int NK = NKW * 4;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -468,15 +468,27 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
         const int nbytes = count * len;
         // ---- stage this wave's rows (contiguous in memory) into LDS ----
         if (ENCODE && !parity_only) {
-            // the message symbols are also the first ks symbols of each output codeword
-            for (int row = 0; row < count; row++) {
-                const uint8_t *rs = src + row * len;
-                uint8_t *rd = out + (cw0 + row) * ns_out;
-                for (int i = lane; i < len; i += 64) {
-                    const uint8_t v = rs[i];
-                    stage[row * len + i] = v;
-                    rd[i] = v;
+            // Build the output codewords in LDS: message symbols scattered from a flat, coalesced 16-byte read into rows
+            // of pitch ks + (n-k); the parity bytes are appended after the LFSR and the rows leave as one flat copy.
+            const bool al = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+            const int nv = al ? nbytes >> 4 : 0;
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+            for (int i = lane; i < nv; i += 64) {
+                const uint4 v = s4[i];
+                const u32 b0 = (u32)i << 4;
+                u32 row = __umulhi(b0, div_magic); // b0 / len, exact for b0 < 2^16
+                u32 col = b0 - row * (u32)len;
+                const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    stage[row * ns_out + col] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+                    col++;
+                    if (col == (u32)len) { col = 0; row++; }
                 }
+            }
+            for (int b = (nv << 4) + lane; b < nbytes; b += 64) {
+                const u32 row = __umulhi((u32)b, div_magic);
+                stage[row * ns_out + ((u32)b - row * (u32)len)] = src[b];
             }
         } else {
             const bool al = ((reinterpret_cast<uintptr_t>(src) | (eras ? reinterpret_cast<uintptr_t>(eras + cw0 * len) : 0)) & 15) == 0;
@@ -509,7 +521,7 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
 #pragma unroll
         for (int d = 0; d < NKW; d++) st[d] = 0;
         if (lane < count) {
-            const uint8_t *row = stage + lane * len;
+            const uint8_t *row = stage + lane * ((ENCODE && !parity_only) ? ns_out : len);
             for (int i = 0; i < len; i++) {
                 const u32 sym = row[i];
                 const u32 top = st[0] >> 24;
@@ -524,14 +536,14 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
         }
         wave_sync();
         if (ENCODE) {
-            // parity bytes (highest degree first) -> LDS -> global
-            u32 *ps = reinterpret_cast<u32 *>(stage) + lane * NKW;
-            if (lane < count) {
-#pragma unroll
-                for (int d = 0; d < NKW; d++) ps[d] = __builtin_bswap32(st[d]);
-            }
-            wave_sync();
             if (parity_only) {
+                // parity bytes (highest degree first) -> LDS -> global, flat
+                u32 *ps = reinterpret_cast<u32 *>(stage) + lane * NKW;
+                if (lane < count) {
+#pragma unroll
+                    for (int d = 0; d < NKW; d++) ps[d] = __builtin_bswap32(st[d]);
+                }
+                wave_sync();
                 u32 *dst = reinterpret_cast<u32 *>(out + cw0 * NK);
                 const u32 *pw = reinterpret_cast<const u32 *>(stage);
                 if ((reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
@@ -540,10 +552,20 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
                     for (int i = lane; i < count * NK; i += 64) out[cw0 * NK + i] = stage[i];
                 }
             } else {
-                for (int row = 0; row < count; row++) {
-                    uint8_t *rd = out + (cw0 + row) * ns_out + len;
-                    for (int j = lane; j < NK; j += 64) rd[j] = stage[row * NK + j];
+                if (lane < count) {
+                    uint8_t *pp = stage + lane * ns_out + len;
+#pragma unroll
+                    for (int d = 0; d < NKW; d++) {
+                        pp[4 * d + 0] = (uint8_t)(st[d] >> 24); pp[4 * d + 1] = (uint8_t)(st[d] >> 16);
+                        pp[4 * d + 2] = (uint8_t)(st[d] >> 8);  pp[4 * d + 3] = (uint8_t)st[d];
+                    }
                 }
+                wave_sync();
+                uint8_t *dst = out + cw0 * ns_out;
+                const int ob = count * ns_out;
+                const int nv = (reinterpret_cast<uintptr_t>(dst) & 15) == 0 ? ob >> 4 : 0;
+                for (int i = lane; i < nv; i += 64) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(stage)[i];
+                for (int b = (nv << 4) + lane; b < ob; b += 64) dst[b] = stage[b];
             }
         } else {
             u32 nzw = 0;
@@ -890,7 +912,8 @@ int launch_lfsr(gfa_rs *code, gfa_rs::Dev *cd, const uint8_t *in, const uint8_t 
                 int parity_only, uint8_t *rem_out, uint8_t *flag_out, i64 batch, hipStream_t st)
 {
     const int nk = (int)(code->n - code->k), nkw = nk / 4;
-    const int stage_bytes = ((64 * std::max(len, nk) + 15) / 16) * 16;
+    const int stage_bytes = ((64 * (ENCODE ? len + nk : std::max(len, nk)) + 15) / 16) * 16;
+    const u32 div_magic = (u32)((((u64)1 << 32) + (u64)len - 1) / (u64)len); // ceil(2^32 / len): exact quotients below 2^16
     const int threads = 256;
     const size_t lds = (size_t)256 * nk + (size_t)(threads / 64) * stage_bytes;
     const i64 blocks = (batch + threads - 1) / threads;
@@ -901,7 +924,7 @@ int launch_lfsr(gfa_rs *code, gfa_rs::Dev *cd, const uint8_t *in, const uint8_t 
         int rc = set_lds_limit(rs_lfsr_kernel<W, ENCODE>, &attr);                                                       \
         if (rc) return rc;                                                                                              \
         hipLaunchKernelGGL((rs_lfsr_kernel<W, ENCODE>), dim3(grid), dim3(threads), lds, st, cd->lfsr, in, eras, len, out, \
-                           parity_only, rem_out, flag_out, batch, stage_bytes);                                         \
+                           parity_only, rem_out, flag_out, batch, stage_bytes, div_magic);                              \
         break;                                                                                                          \
     }
     switch (nkw) {
@@ -1037,7 +1060,7 @@ int gfa_rs_encode(gfa_rs_t *code, const void *msg, int64_t ks, void *out, int64_
         if (!parity_only) GFA_HIP(hipMemcpyAsync(out, msg, (size_t)(batch * ks), hipMemcpyDeviceToDevice, (hipStream_t)stream));
         return GFA_OK;
     }
-    if (lfsr_eligible(code) && cd->lfsr)
+    if (lfsr_eligible(code) && cd->lfsr && ks >= 2)
         return launch_lfsr<true>(code, cd, (const uint8_t *)msg, nullptr, (int)ks, (uint8_t *)out, parity_only, nullptr, nullptr,
                                  batch, (hipStream_t)stream);
     int groups = 1;
