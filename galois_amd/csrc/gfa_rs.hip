@@ -632,7 +632,8 @@ __global__ __launch_bounds__(1024) void rs_decode_bin_kernel(RsTables t, RsParam
     __syncthreads();
     const unsigned long long lt_mask = ((unsigned long long)1 << lane) - 1;
     const int cm = rp.c % qm1;
-    const int lroot = (la * ((cm + lane) % qm1)) % qm1; // LOG of root_j = alpha^(c+j) for j = lane
+    const int jl = rp.nroots <= 32 ? (lane & 31) : lane;
+    const int lroot = (la * ((cm + jl) % qm1)) % qm1;   // LOG of root_j = alpha^(c+j), j = lane (mod 32 when n-k <= 32)
     const int ZIDX = 2 * (qm1 + 1) - 1;                 // EXP[2q-1] == 0
 
     for (i64 cw = (i64)blockIdx.x * nwaves + wave; cw < batch; cw += (i64)gridDim.x * nwaves) {
@@ -667,18 +668,31 @@ __global__ __launch_bounds__(1024) void rs_decode_bin_kernel(RsTables t, RsParam
             status = 1;
         } else {
             // ---- 1. syndromes from the remainder: S_j = sum_t rem_t * root_j^t ----
+            // For n-k <= 32 the two wave halves each take half of the terms of the same 32 syndromes (one exchange).
             {
                 const int lrem = remc ? (int)ar.log_t[remc] : -1;
                 u32 acc = 0;
-                int e = 0;
-                // a zero coefficient is redirected to EXP[2q-1] == 0 (the unused last entry of the doubled table,
-                // _lookup.py:371), which keeps the loop branch-free so that several gathers are in flight at once
+                if (dd <= 32) {
+                    const bool hi = lane >= 32;
+                    int e = hi ? (16 * lroot) % qm1 : 0;
 #pragma unroll 8
-                for (int tt = 0; tt < dd; tt++) {
-                    const int lt = __builtin_amdgcn_readlane(lrem, tt);
-                    acc ^= ar.exp_t[lt >= 0 ? lt + e : ZIDX];
-                    e += lroot;
-                    e = e >= qm1 ? e - qm1 : e;
+                    for (int it = 0; it < 16; it++) {
+                        const int l0 = __builtin_amdgcn_readlane(lrem, it), l1 = __builtin_amdgcn_readlane(lrem, it + 16);
+                        const int lt = hi ? l1 : l0; // coefficients beyond n-k are zero (-1)
+                        acc ^= ar.exp_t[lt >= 0 ? lt + e : ZIDX];
+                        e += lroot;
+                        e = e >= qm1 ? e - qm1 : e;
+                    }
+                    acc ^= (u32)__shfl_xor((int)acc, 32);
+                } else {
+                    int e = 0;
+#pragma unroll 8
+                    for (int tt = 0; tt < dd; tt++) {
+                        const int lt = __builtin_amdgcn_readlane(lrem, tt);
+                        acc ^= ar.exp_t[lt >= 0 ? lt + e : ZIDX];
+                        e += lroot;
+                        e = e >= qm1 ? e - qm1 : e;
+                    }
                 }
                 if (lane < dd) ws.synd[lane] = (uint8_t)acc;
             }
@@ -810,9 +824,38 @@ __global__ __launch_bounds__(1024) void rs_decode_bin_kernel(RsTables t, RsParam
                     const int L_total = ltlen - 1;
                     u32 num = 0, den = 0;
                     int lx = 0;
-                    const bool act = lane < v_total;
-                    if (act) lx = ar.log_t[ws.errloc[lane]];
-                    {
+                    bool act = lane < v_total;
+                    if (dd <= 32) {
+                        // located symbol e = lane & 31; the wave halves split the terms of both evaluations
+                        const bool hi = lane >= 32;
+                        const int el = lane & 31;
+                        act = el < v_total;
+                        if (act) lx = ar.log_t[ws.errloc[el]];
+                        int e = hi ? (16 * lx) % qm1 : 0;
+#pragma unroll 8
+                        for (int it = 0; it < 16; it++) {
+                            const int l0 = __builtin_amdgcn_readlane(lom, it), l1 = __builtin_amdgcn_readlane(lom, it + 16);
+                            const int lo = hi ? l1 : l0;
+                            num ^= ar.exp_t[lo >= 0 ? lo + e : ZIDX];
+                            e += lx;
+                            e = e >= qm1 ? e - qm1 : e;
+                        }
+                        int lx2 = 2 * lx;
+                        lx2 = lx2 >= qm1 ? lx2 - qm1 : lx2;
+                        int e2 = hi ? (8 * lx2) % qm1 : 0; // odd j = 2*jj + 1, exponent (j-1) = 2*jj; upper half starts at jj = 8
+#pragma unroll 8
+                        for (int it = 0; it < 8; it++) {
+                            const int l0 = __builtin_amdgcn_readlane(ltl, 2 * it + 1), l1 = __builtin_amdgcn_readlane(ltl, 2 * it + 17);
+                            const int lj = hi ? l1 : l0; // lanes >= ltlen hold -1
+                            den ^= ar.exp_t[lj >= 0 ? lj + e2 : ZIDX];
+                            e2 += lx2;
+                            e2 = e2 >= qm1 ? e2 - qm1 : e2;
+                        }
+                        num ^= (u32)__shfl_xor((int)num, 32);
+                        den ^= (u32)__shfl_xor((int)den, 32);
+                        act = act && !hi;
+                    } else {
+                        if (act) lx = ar.log_t[ws.errloc[lane]];
                         int e = 0;
 #pragma unroll 8
                         for (int tt = 0; tt < dd; tt++) {
@@ -835,7 +878,7 @@ __global__ __launch_bounds__(1024) void rs_decode_bin_kernel(RsTables t, RsParam
                         int ex = (int)ar.log_t[num] - (int)ar.log_t[den] + ((rp.c - 1) % qm1) * lx;
                         ex %= qm1;
                         if (ex < 0) ex += qm1;
-                        const int pos = ws.errpos[lane];
+                        const int pos = ws.errpos[lane & 63];
                         ws.recv[pos] ^= ar.exp_t[ex];
                     }
                     wave_sync();
