@@ -617,7 +617,7 @@ __device__ __forceinline__ int lane_shift_up1(int v, int lane)
     return t;
 }
 
-__global__ __launch_bounds__(1024) void rs_decode_bin_kernel(RsTables t, RsParams rp, const uint8_t *__restrict__ recv_g,
+__global__ __launch_bounds__(1024, 8) void rs_decode_bin_kernel(RsTables t, RsParams rp, const uint8_t *__restrict__ recv_g,
                                                              const uint8_t *__restrict__ eras_g,
                                                              const uint8_t *__restrict__ rem_g, int n,
                                                              uint8_t *__restrict__ out_g, i64 *__restrict__ nerr_g, i64 batch)
