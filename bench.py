@@ -109,8 +109,15 @@ def main():
                                 ctypes.byref(ms)), "gfa_time_binary")
     alg_bytes = 3.0 * n
     achieved = alg_bytes / (ms.value * 1e-3) / 1e9
+    # HBM traffic per launch from the PMC counters: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    # tools/headline_only.py (same kernel, same 1e8-element inputs), corrected as MI355X_MICROARCH.md prescribes;
+    # the raw counter files and the derivation are committed under profiles/ (PMC passes cannot run inside this process)
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_headline.json")
+    if os.path.exists(pmc_path):
+        traffic = json.load(open(pmc_path))["traffic_bytes_per_launch"]
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "tab8_binary_kernel",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "tab8_binary_kernel",
                 "kernel_ms": round(ms.value, 5), "algorithmic_bytes_per_launch": alg_bytes}
 
     result = None
