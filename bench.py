@@ -146,7 +146,7 @@ def main():
         # bounded CPU sample: the same 1e8-element batch, repeated until >= 10 s of single-thread work
         t_cpu, reps = 0.0, 0
         F.ufunc_u8(O.MUL, x_h[:1_000_000], y_h[:1_000_000])
-        while t_cpu < 10.0 and reps < 64:
+        while t_cpu < 10.0 and reps < 400:
             t1 = time.perf_counter()
             F.ufunc_u8(O.MUL, x_h, y_h)
             t_cpu += time.perf_counter() - t1
@@ -156,7 +156,7 @@ def main():
                                             f"(C restatement of the reference's jit-lookup multiply, -O3, 1 thread; "
                                             f"host has {os.cpu_count()} cores)"}
 
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:
         result["extra"] = extras(ga, L, lib, stream, world == 1 and not args.no_cpu_baseline)
 
     if rank == 0:

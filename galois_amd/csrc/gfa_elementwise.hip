@@ -11,6 +11,7 @@
 //               bank l%32: conflict-free by construction.  Loads/stores are 16 B per lane, fully coalesced.
 //   * ew_*    : every other field / dtype, templated on the arithmetic (gfa_arith.h) and the storage width.
 #include <algorithm>
+#include <cstdlib>
 
 #include "gfa_internal.h"
 
@@ -161,7 +162,7 @@ __device__ __forceinline__ u32 lookup4(const uint8_t *lds, u32 aw, u32 bw)
 }
 
 // out = TABLE[a][b].  `zero_b_is_error`: division flags b == 0.
-template <int UNROLL, bool CHECK_ZERO_B>
+template <int UNROLL, bool CHECK_ZERO_B, bool NT>
 __global__ __launch_bounds__(TAB8_THREADS) void tab8_binary_kernel(const uint8_t *__restrict__ table,
                                                                     const uint8_t *__restrict__ a,
                                                                     const uint8_t *__restrict__ b,
@@ -186,8 +187,8 @@ __global__ __launch_bounds__(TAB8_THREADS) void tab8_binary_kernel(const uint8_t
         u32x4 x[UNROLL], y[UNROLL];
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
-            x[u] = __builtin_nontemporal_load(av + i + u * stride);
-            y[u] = __builtin_nontemporal_load(bv + i + u * stride);
+            x[u] = NT ? __builtin_nontemporal_load(av + i + u * stride) : av[i + u * stride];
+            y[u] = NT ? __builtin_nontemporal_load(bv + i + u * stride) : bv[i + u * stride];
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; u++) {
@@ -202,7 +203,8 @@ __global__ __launch_bounds__(TAB8_THREADS) void tab8_binary_kernel(const uint8_t
                         ((y[u].z - 0x01010101u) & ~y[u].z) | ((y[u].w - 0x01010101u) & ~y[u].w);
                 bad |= (z & 0x80808080u) != 0;
             }
-            __builtin_nontemporal_store(r, ov + i + u * stride);
+            if (NT) __builtin_nontemporal_store(r, ov + i + u * stride);
+            else ov[i + u * stride] = r;
         }
     }
     for (; i < nvec; i += stride) {
@@ -570,21 +572,40 @@ int tab8_grid(i64 n)
 int launch_tab8_binary(const uint8_t *table, bool check_zero_b, const void *a, const void *b, void *out, i64 n,
                        hipStream_t st, int32_t *err)
 {
-    static bool attr_set[2] = {false, false};
-    auto k0 = tab8_binary_kernel<TAB8_UNROLL, false>;
-    auto k1 = tab8_binary_kernel<TAB8_UNROLL, true>;
-    if (!attr_set[check_zero_b]) {
-        GFA_HIP(hipFuncSetAttribute(check_zero_b ? (const void *)k1 : (const void *)k0,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        attr_set[check_zero_b] = true;
+    // tuning knob (tools/gf256_tune.py): GFA_TAB8_VARIANT = <unroll 1|2|4><n|t>, default "2t" (plain loads/stores, unroll 2:
+    // measured 6.0-6.15 TB/s vs 5.9-5.96 TB/s for the nontemporal forms; the plain XOR stream reaches the same 6.0-6.25)
+    static int variant = -1;
+    if (variant < 0) {
+        const char *v = getenv("GFA_TAB8_VARIANT");
+        int u = 2, nt = 0;
+        if (v && v[0]) { u = v[0] - '0'; nt = v[1] == 't' ? 0 : 1; }
+        variant = (u == 1 ? 0 : u == 4 ? 2 : 1) * 2 + nt;
     }
     const int grid = tab8_grid(n);
-    if (check_zero_b)
-        hipLaunchKernelGGL(k1, dim3(grid), dim3(TAB8_THREADS), 65536, st, table, (const uint8_t *)a, (const uint8_t *)b,
-                           (uint8_t *)out, n, err);
-    else
-        hipLaunchKernelGGL(k0, dim3(grid), dim3(TAB8_THREADS), 65536, st, table, (const uint8_t *)a, (const uint8_t *)b,
-                           (uint8_t *)out, n, err);
+#define GFA_TAB8(U, NTV)                                                                                                   \
+    do {                                                                                                                   \
+        static bool attr[2] = {false, false};                                                                              \
+        if (check_zero_b) {                                                                                                \
+            auto k = tab8_binary_kernel<U, true, NTV>;                                                                     \
+            if (!attr[1]) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr[1] = true; } \
+            hipLaunchKernelGGL(k, dim3(grid), dim3(TAB8_THREADS), 65536, st, table, (const uint8_t *)a, (const uint8_t *)b, \
+                               (uint8_t *)out, n, err);                                                                    \
+        } else {                                                                                                           \
+            auto k = tab8_binary_kernel<U, false, NTV>;                                                                    \
+            if (!attr[0]) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr[0] = true; } \
+            hipLaunchKernelGGL(k, dim3(grid), dim3(TAB8_THREADS), 65536, st, table, (const uint8_t *)a, (const uint8_t *)b, \
+                               (uint8_t *)out, n, err);                                                                    \
+        }                                                                                                                  \
+    } while (0)
+    switch (variant) {
+    case 0: GFA_TAB8(1, false); break;
+    case 1: GFA_TAB8(1, true); break;
+    case 2: GFA_TAB8(2, false); break;
+    case 3: GFA_TAB8(2, true); break;
+    case 4: GFA_TAB8(4, false); break;
+    default: GFA_TAB8(4, true); break;
+    }
+#undef GFA_TAB8
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }
