@@ -123,6 +123,13 @@ struct TwShoupLazy {
     static __device__ __forceinline__ u32 sub(Ctx c, u32 a, u32 b) { const u32 d = a + c.p2 - b; return min(d, d - c.p2); }
     static __device__ __forceinline__ u32 submul(Ctx c, u32 a, u32 b, W t) { return mul(c, a + c.p2 - b, t); }
     static __device__ __forceinline__ u32 canon(Ctx c, u32 a) { return min(a, a - c.p); } // [0, 2p) -> [0, p)
+    // Montgomery product x * y * 2^-32 mod p for x*y < p * 2^32 (pinv = p^-1 mod 2^32); result in (0, 2p)
+    static __device__ __forceinline__ u32 redc(Ctx c, u32 x, u32 y, u32 pinv)
+    {
+        const u32 hi = __umulhi(x, y), lo = x * y;
+        const u32 m = lo * pinv;
+        return hi - __umulhi(m, c.p) + c.p;
+    }
 };
 
 __device__ __forceinline__ u32 bitrev(u32 x, int bits) { return __brev(x) >> (32 - bits); }
@@ -282,6 +289,7 @@ struct RegArgs {
     u64 scale;
     u64 scale_q; // Shoup quotient of `scale` for the twiddle class in use
     int xcd_remap;
+    u64 pinv;    // p^-1 mod 2^32 (lazy 32-bit path)
 };
 
 template <class F, class TW, int LOGR>
@@ -330,7 +338,8 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fdk, const ty
                                                           const typename F::elem *__restrict__ powA,
                                                           const typename F::elem *__restrict__ powAq,
                                                           const typename F::elem *__restrict__ powB,
-                                                          const typename F::elem *__restrict__ powBq)
+                                                          const typename F::elem *__restrict__ powBq,
+                                                          const typename F::elem *__restrict__ powAm)
 {
     typedef typename F::elem E;
     constexpr int R1 = 1 << LOGR1, R2 = 1 << LOGR2, L = R1 * R2;
@@ -405,19 +414,36 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fdk, const ty
         for (int r = 0; r < R2; r++) v[r] = srcl[r];
         reg_dif<F, TW, LOGR2>(fd, v, wL, wLq, R1); // w_R2 = w_L^R1
         if (ra.post_twiddle) {
-            // * w_N^(line * k), k = ka + R1*kr: exponent by repeated addition, two-level table A[e >> lo] * B[e & mask]
             const u32 line = (u32)(ra.line_offset + line0 + c);
             const u32 nmask = (u32)ra.n_mask, lo_mask = (1u << ra.lo_bits) - 1;
-            u32 e = line * (u32)ka;
-            const u32 de = line * (u32)R1;
+            if constexpr (is_lazy<TW>()) {
+                // * w_N^(line * (ka + R1*kr)) for kr = 0..R2-1 is a geometric progression per thread: t_0 = w^(line*ka),
+                // ratio w^(line*R1).  Both are fetched ONCE per thread from the two-level power table (A kept in
+                // Montgomery form, A*2^32 mod p) and every later factor comes from a Montgomery product in registers.
+                // (The first version gathered two table entries per element from global memory; those fully
+                // divergent 4-byte gathers cost more than the whole transform -- pass 1 ran 2x slower than pass 2.)
+                const u32 e0 = (line * (u32)ka) & nmask, es = (line * (u32)R1) & nmask;
+                u32 tm = TW::mul(fd, powAm[e0 >> ra.lo_bits], TW::load(powB, powBq, e0 & lo_mask));               // t_0 * R, [0,2p)
+                const u32 sm = TW::canon(fd, TW::mul(fd, powAm[es >> ra.lo_bits], TW::load(powB, powBq, es & lo_mask))); // ratio * R, [0,p)
+                const u32 pinv = (u32)ra.pinv;
 #pragma unroll
-            for (int kr = 0; kr < R2; kr++) {
-                const u32 em = e & nmask;
-                E x = v[brev_c(kr, LOGR2)];
-                x = TW::mul(fd, x, TW::load(powA, powAq, em >> ra.lo_bits));
-                x = TW::mul(fd, x, TW::load(powB, powBq, em & lo_mask));
-                v[brev_c(kr, LOGR2)] = x;
-                e += de;
+                for (int kr = 0; kr < R2; kr++) {
+                    v[brev_c(kr, LOGR2)] = TW::redc(fd, v[brev_c(kr, LOGR2)], tm, pinv); // x * t_kr, lazy
+                    if (kr + 1 < R2) tm = TW::redc(fd, tm, sm, pinv);                    // t_{kr+1} * R
+                }
+            } else {
+                // two-level table A[e >> lo] * B[e & mask], exponent by repeated addition
+                u32 e = line * (u32)ka;
+                const u32 de = line * (u32)R1;
+#pragma unroll
+                for (int kr = 0; kr < R2; kr++) {
+                    const u32 em = e & nmask;
+                    E x = v[brev_c(kr, LOGR2)];
+                    x = TW::mul(fd, x, TW::load(powA, powAq, em >> ra.lo_bits));
+                    x = TW::mul(fd, x, TW::load(powB, powBq, em & lo_mask));
+                    v[brev_c(kr, LOGR2)] = x;
+                    e += de;
+                }
             }
         }
         if (ra.do_scale) {
@@ -515,6 +541,7 @@ struct Plan {
     void *w1 = nullptr, *w1q = nullptr; // twiddles of the length-2^log1 transform (and Shoup quotients)
     void *w2 = nullptr, *w2q = nullptr; // twiddles of the length-2^log2 transform
     void *powA = nullptr, *powB = nullptr, *powAq = nullptr, *powBq = nullptr;
+    void *powAm = nullptr; // A * 2^32 mod p (Montgomery form), lazy 32-bit path
     int lo_bits = 0;
     // register-blocked path: full w_L^e tables (L entries) per pass, with Shoup quotients
     void *wl1 = nullptr, *wl1q = nullptr, *wl2 = nullptr, *wl2q = nullptr;
@@ -553,6 +580,19 @@ constexpr int qbits_of()
 {
     if constexpr (TW::HAS_SHOUP) return TW::QBITS;
     else return 0;
+}
+
+__global__ void mont_table_kernel(u32 p, const u32 *w, u32 *wm, i64 count)
+{
+    i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) wm[i] = (u32)((((u64)w[i]) << 32) % p);
+}
+
+inline u64 inverse_mod_2_32(u64 p)
+{ // Newton iteration, p odd
+    u32 x = (u32)p;
+    for (int i = 0; i < 5; i++) x *= 2u - (u32)p * x;
+    return x;
 }
 
 template <class TW>
@@ -716,7 +756,7 @@ int env_int(const char *name, int dflt)
 
 template <class F, class TW, int LOGR1, int LOGR2, int THREADS>
 int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64 batch, const void *wl, const void *wlq,
-                  const void *pa, const void *paq, const void *pb, const void *pbq, hipStream_t st)
+                  const void *pa, const void *paq, const void *pb, const void *pbq, const void *pam, hipStream_t st)
 {
     typedef typename F::elem E;
     constexpr int R1 = 1 << LOGR1, R2 = 1 << LOGR2, L = R1 * R2, C = THREADS / R1;
@@ -739,31 +779,31 @@ int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64
         attr = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, fd, (const E *)in, (E *)out, ra, (const E *)wl,
-                       (const E *)wlq, (const E *)pa, (const E *)paq, (const E *)pb, (const E *)pbq);
+                       (const E *)wlq, (const E *)pa, (const E *)paq, (const E *)pb, (const E *)pbq, (const E *)pam);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }
 
 template <class F, class TW, int LOGR1, int LOGR2>
 int launch_reg_t(const FieldDev &fd, const void *in, void *out, const RegArgs &ra, i64 batch, const void *wl,
-                 const void *wlq, const void *pa, const void *paq, const void *pb, const void *pbq, hipStream_t st)
+                 const void *wlq, const void *pa, const void *paq, const void *pb, const void *pbq, const void *pam, hipStream_t st)
 {
     typedef typename F::elem E;
     if constexpr (sizeof(E) == 4 && LOGR1 == 5) {
         // 32 lines per tile (128-byte global segments, one 1024-thread workgroup per CU) or 16 lines (two 512-thread ones)
         static const int wide = env_int("GFA_NTT_WIDE", 0);
-        if (wide) return launch_reg_tt<F, TW, LOGR1, LOGR2, 1024>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, st);
-        return launch_reg_tt<F, TW, LOGR1, LOGR2, 512>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, st);
+        if (wide) return launch_reg_tt<F, TW, LOGR1, LOGR2, 1024>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
+        return launch_reg_tt<F, TW, LOGR1, LOGR2, 512>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
     } else {
-        return launch_reg_tt<F, TW, LOGR1, LOGR2, 256>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, st);
+        return launch_reg_tt<F, TW, LOGR1, LOGR2, 256>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
     }
 }
 
 template <class F, class TW>
 int launch_reg(const FieldDev &fd, int logL, const void *in, void *out, const RegArgs &ra, i64 batch, const void *wl,
-               const void *wlq, const void *pa, const void *paq, const void *pb, const void *pbq, hipStream_t st)
+               const void *wlq, const void *pa, const void *paq, const void *pb, const void *pbq, const void *pam, hipStream_t st)
 {
-#define GFA_REG(A, B) return launch_reg_t<F, TW, A, B>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, st)
+#define GFA_REG(A, B) return launch_reg_t<F, TW, A, B>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st)
     switch (logL) {
     case 2: GFA_REG(1, 1);
     case 3: GFA_REG(2, 1);
@@ -805,6 +845,13 @@ int build_post_tables(const FieldDev &fd, u64 omega, i64 n_total, Plan *pl, hipS
         if ((rc = build_shoup(fd, pl->powA, na, &pl->powAq, st, qbits_of<TW>()))) return rc;
         if ((rc = build_shoup(fd, pl->powB, nb, &pl->powBq, st, qbits_of<TW>()))) return rc;
     }
+    if constexpr (is_lazy<TW>()) {
+        // (w << 32) mod p == floor-free Montgomery form; reuse the quotient kernel's arithmetic: w*2^32 - floor(w*2^32/p)*p
+        GFA_HIP(hipMalloc(&pl->powAm, sizeof(u32) * (size_t)na));
+        hipLaunchKernelGGL(mont_table_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, st, (u32)fd.p,
+                           (const u32 *)pl->powA, (u32 *)pl->powAm, na);
+        GFA_HIP(hipGetLastError());
+    }
     return GFA_OK;
 }
 
@@ -833,7 +880,7 @@ int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n,
         ra.total_lines = batch;
         ra.load_along_line = 1; ra.store_along_line = 1;
         ra.do_scale = do_scale; ra.scale = scale; ra.scale_q = shoup_quotient<TW>(fd, scale);
-        return launch_reg<F, TW>(fd, pl->log1, in, out, ra, 1, pl->wl1, pl->wl1q, nullptr, nullptr, nullptr, nullptr, st);
+        return launch_reg<F, TW>(fd, pl->log1, in, out, ra, 1, pl->wl1, pl->wl1q, nullptr, nullptr, nullptr, nullptr, nullptr, st);
     }
     const i64 n1 = (i64)1 << pl->log1, n2 = (i64)1 << pl->log2;
     // Sub-batches keep the pass-1 -> pass-2 intermediate small enough to stay in the 256 MiB Infinity Cache instead of
@@ -855,9 +902,9 @@ int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n,
             ra.in_stride_c = 1; ra.in_stride_t = n2; ra.out_stride_c = 1; ra.out_stride_t = n2;
             ra.in_batch_stride = n; ra.out_batch_stride = n;
             ra.total_lines = n2;
-            ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits; ra.n_mask = (u64)n - 1;
+            ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits; ra.n_mask = (u64)n - 1; ra.pinv = inverse_mod_2_32(fd.p);
             if ((rc = launch_reg<F, TW>(fd, pl->log1, src, pl->ws0.p, ra, nb, pl->wl1, pl->wl1q, pl->powA, pl->powAq, pl->powB,
-                                        pl->powBq, st)))
+                                        pl->powBq, pl->powAm, st)))
                 return rc;
         }
         { // pass 2: the n1 rows (contiguous), stored transposed: X[k1 + n1*k2]
@@ -868,7 +915,7 @@ int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n,
             ra.load_along_line = 1; ra.store_along_line = 0;
             ra.do_scale = do_scale; ra.scale = scale; ra.scale_q = shoup_quotient<TW>(fd, scale);
             if ((rc = launch_reg<F, TW>(fd, pl->log2, pl->ws0.p, dst, ra, nb, pl->wl2, pl->wl2q, nullptr, nullptr, nullptr,
-                                        nullptr, st)))
+                                        nullptr, nullptr, st)))
                 return rc;
         }
     }
@@ -974,7 +1021,7 @@ void ntt_forget_field(const gfa_field *f)
     for (auto it = g_plans.begin(); it != g_plans.end();) {
         if (it->first.f == f) {
             Plan *pl = it->second;
-            for (void *p : {pl->w1, pl->w1q, pl->w2, pl->w2q, pl->powA, pl->powB, pl->powAq, pl->powBq, pl->wl1, pl->wl1q, pl->wl2,
+            for (void *p : {pl->w1, pl->w1q, pl->w2, pl->w2q, pl->powA, pl->powB, pl->powAq, pl->powBq, pl->powAm, pl->wl1, pl->wl1q, pl->wl2,
                             pl->wl2q, pl->wpow, pl->ws0.p, pl->ws1.p, pl->cvt.p})
                 if (p) (void)hipFree(p);
             delete pl;
@@ -1077,7 +1124,8 @@ int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64
             ra.in_stride_c = 1; ra.in_stride_t = cols; ra.out_stride_c = 1; ra.out_stride_t = cols;
             ra.total_lines = cols;
             ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits; ra.n_mask = (u64)n_total - 1; ra.line_offset = col0;
-            return launch_reg<F, TW>(c, lg1, in, out, ra, 1, pl->wl1, pl->wl1q, pl->powA, pl->powAq, pl->powB, pl->powBq, st);
+            ra.pinv = inverse_mod_2_32(c.p);
+            return launch_reg<F, TW>(c, lg1, in, out, ra, 1, pl->wl1, pl->wl1q, pl->powA, pl->powAq, pl->powB, pl->powBq, pl->powAm, st);
         }
         if (!pl->w1) {
             pl->log1 = lg1; pl->logn = lgn;
