@@ -2,7 +2,7 @@
 ctypes binding of libgalois_amd.so -- the C-ABI declared in include/galois_amd.h.
 
 The library is the product's only compute path.  If it is missing this module raises ImportError (no fallback):
-build it with `python -m galois_amd.build` (hipcc, gfx950).
+build it with `python galois_amd/build.py` (hipcc, gfx950).
 """
 from __future__ import annotations
 
@@ -45,6 +45,7 @@ SIGNATURES = {
     "gfa_power": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "gfa_scalar_multiply": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p]),
     "gfa_reduce": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p]),
+    "gfa_convolve": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p]),
     "gfa_ntt": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_u64, c_int, c_int, c_void_p]),
     "gfa_ntt_columns": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_u64, c_int, c_void_p]),
     "gfa_rs_create": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_u64, c_int, ctypes.POINTER(c_void_p)]),
@@ -70,7 +71,7 @@ def lib() -> ctypes.CDLL:
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} not found: the HIP extension is the only compute path of galois_amd. "
-                "Build it with `python -m galois_amd.build` (hipcc --offload-arch=gfx950)."
+                "Build it with `python galois_amd/build.py` (hipcc --offload-arch=gfx950)."
             )
         L = ctypes.CDLL(LIB_PATH)
         for name, (restype, argtypes) in SIGNATURES.items():

@@ -65,10 +65,35 @@ def fft_batched(x: FieldArray, inverse: bool = False, scaled: bool | None = None
     return _transform_rows(x, None, inverse, scale)
 
 
-def _field_convolve(a: FieldArray, b: FieldArray, mode: str = "full"):
-    raise NotImplementedError(
-        "np.convolve on device field arrays is a 'next' row of the scope table (SURVEY.md section 8(f) item 1)."
-    )
+def _field_convolve(a: FieldArray, b: FieldArray, mode: str = "full") -> FieldArray:
+    """np.convolve on 1-D field arrays = polynomial multiplication (convolve_jit.__call__, _domains/_function.py:116-130).
+
+    Short products run in one direct kernel (gfa_convolve).  Long products over a prime field whose multiplicative
+    group has enough 2-adicity run as three NTTs and a pointwise product -- the direct consumer of the fast transform
+    (SURVEY.md section 8(f) item 1); the result is the same exact polynomial product either way."""
+    if not isinstance(a, FieldArray) or not isinstance(b, FieldArray) or type(a) is not type(b):
+        raise TypeError(f"Arguments of 'convolve' must be arrays over the same field, not {type(a)} and {type(b)}.")
+    if not mode == "full":
+        raise ValueError(f"Operation 'convolve' currently only supports mode of 'full', not {mode!r}.")
+    if a.ndim != 1 or b.ndim != 1 or a.size == 0 or b.size == 0:
+        raise ValueError("Operation 'convolve' requires non-empty 1-D arrays.")
+    cls = type(a)
+    na, nb = a.size, b.size
+    n_out = na + nb - 1
+    n_fft = 1 << (n_out - 1).bit_length()
+    if cls.is_prime_field and min(na, nb) >= 64 and n_out >= 2048 and (cls.order - 1) % n_fft == 0 and n_fft <= 2**24:
+        both = cls.Zeros((2, n_fft), dtype=a.dtype if a.dtype != np.dtype(object) else None)
+        both._t[0, :na] = a._t
+        both._t[1, :nb] = a._same_storage(b)
+        spec = _transform_rows(both, None, inverse=False, scale=False)
+        prod = spec[0] * spec[1]
+        full = _transform_rows(prod.reshape(1, n_fft), None, inverse=True, scale=True)
+        return cls._wrap(full._t[0, :n_out].contiguous(), a._np_dtype)
+    ta = a._t.contiguous()
+    tb = a._same_storage(b).contiguous()
+    out = torch.empty(n_out, dtype=ta.dtype, device=ta.device)
+    L.check(L.lib().gfa_convolve(cls._handle, _ptr(ta), na, _ptr(tb), nb, _ptr(out), a._gfa_dtype(), _stream()), "gfa_convolve")
+    return cls._wrap(out, a._np_dtype)
 
 
 def _max_value(x) -> int:

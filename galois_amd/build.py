@@ -1,6 +1,6 @@
 """Builds galois_amd/libgalois_amd.so (HIP kernels + C-ABI) for gfx950 with hipcc, in-tree.
 
-    python -m galois_amd.build [--force]
+    python galois_amd/build.py [--force]
 
 hipcc cross-compiles without a GPU, so this also runs on the CPU-only build container.
 """

@@ -548,6 +548,39 @@ int dispatch_reduce(const FieldDev &fd, int dtype, int op, const void *a, void *
     GFA_DISPATCH_FT(launch_reduce_ft, fd, dtype, fd, op, a, out, n_outer, n_inner, st, err);
 }
 
+
+// np.convolve(a, b) = polynomial product, direct form (convolve_jit.implementation, _domains/_function.py:141-167):
+// out[k] = sum_i a[i] * b[k - i].  One output coefficient per thread; large prime-field products go through the NTT
+// on the host side (galois_amd/_ntt.py) instead.
+template <class F, typename T>
+__global__ __launch_bounds__(256) void convolve_kernel(FieldDev fd, const T *__restrict__ a, i64 na, const T *__restrict__ b,
+                                                       i64 nb, T *__restrict__ out)
+{
+    typedef typename F::elem E;
+    const i64 n = na + nb - 1;
+    for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (i64)gridDim.x * blockDim.x) {
+        const i64 lo = k - (nb - 1) > 0 ? k - (nb - 1) : 0;
+        const i64 hi = k < na - 1 ? k : na - 1;
+        E acc = 0;
+        for (i64 i = lo; i <= hi; i++) acc = F::add(fd, acc, F::mul(fd, (E)a[i], (E)b[k - i]));
+        out[k] = (T)acc;
+    }
+}
+
+template <class F, typename T>
+int launch_convolve_ft(const FieldDev &fd, const void *a, i64 na, const void *b, i64 nb, void *out, hipStream_t st)
+{
+    const int grid = grid_for(na + nb - 1, 256, 8);
+    hipLaunchKernelGGL((convolve_kernel<F, T>), dim3(grid), dim3(256), 0, st, fd, (const T *)a, na, (const T *)b, nb, (T *)out);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+int dispatch_convolve(const FieldDev &fd, int dtype, const void *a, i64 na, const void *b, i64 nb, void *out, hipStream_t st)
+{
+    GFA_DISPATCH_FT(launch_convolve_ft, fd, dtype, fd, a, na, b, nb, out, st);
+}
+
 bool dtype_holds(int dtype, u64 q)
 {
     switch (dtype) {
@@ -731,6 +764,18 @@ int gfa_reduce(gfa_field_t *f, int op, const void *a, void *out, int64_t n_outer
     if (rc) return rc;
     if (f->use_lookup()) return dispatch_reduce(f->lut_desc(*ds), dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
     return dispatch_reduce(f->calc, dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
+}
+
+int gfa_convolve(gfa_field_t *f, const void *a, int64_t na, const void *b, int64_t nb, void *out, int dtype,
+                 gfa_stream_t stream)
+{
+    if (!f || !a || !b || !out || na < 1 || nb < 1) { set_error("gfa_convolve: bad arguments"); return GFA_ERR_INVALID; }
+    if (!dtype_holds(dtype, f->calc.q)) { set_error("dtype cannot hold the field's elements"); return GFA_ERR_INVALID; }
+    FieldDeviceState *ds;
+    int rc = f->ensure_device(nullptr, &ds);
+    if (rc) return rc;
+    if (f->use_lookup()) return dispatch_convolve(f->lut_desc(*ds), dtype, a, na, b, nb, out, (hipStream_t)stream);
+    return dispatch_convolve(f->calc, dtype, a, na, b, nb, out, (hipStream_t)stream);
 }
 
 int gfa_time_binary(gfa_field_t *f, int op, const void *a, const void *b, void *out, int64_t n, int dtype,

@@ -104,6 +104,12 @@ int gfa_scalar_multiply(gfa_field_t *f, const void *a, int64_t a_stride, const i
 int gfa_reduce(gfa_field_t *f, int op, const void *a, void *out, int64_t n_outer, int64_t n_inner, int dtype,
                gfa_stream_t stream, int32_t *dev_err);
 
+/* np.convolve(a, b), mode "full": out[k] = sum_i a[i] * b[k-i], na + nb - 1 outputs -- convolve_jit
+ * (_domains/_function.py:111-167).  Direct O(na*nb) form for any field; the host routes long prime-field products
+ * through gfa_ntt instead (three transforms + one gfa_binary multiply). */
+int gfa_convolve(gfa_field_t *f, const void *a, int64_t na, const void *b, int64_t nb, void *out, int dtype,
+                 gfa_stream_t stream);
+
 /* ---- NTT: replaces fft_jit/ifft_jit `self.jit(x.astype(int64), int64(omega), factors)` (_domains/_function.py:201) *
  * Computes out[k] = sum_j in[j] * omega^(j*k) for each of `batch` contiguous length-n rows, natural order in and
  * out.  `omega` must be a primitive n-th root of unity (for the inverse pass omega^-1, as fft_jit.__call__ does at

@@ -58,6 +58,10 @@ def pack_sage_fields():
             d = pickle.load(open(os.path.join(path, op + ".pkl"), "rb"))
             for k, v in d.items():
                 out[f"{op}_{k}"] = small(v)
+        d = pickle.load(open(os.path.join(path, "convolve.pkl"), "rb"))  # three polynomial products per field
+        for i in range(len(d["X"])):
+            for k in ("X", "Y", "Z"):
+                out[f"convolve{i}_{k}"] = small(d[k][i])
         name = folder.replace("(", "_").replace(")", "").replace("^", "e").replace(", ", "_")
         np.savez_compressed(os.path.join(HERE, f"sage_fields_{name}.npz"), **out)
         print("packed", folder)

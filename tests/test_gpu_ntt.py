@@ -121,3 +121,64 @@ def test_mixed_radix_against_oracle(order, n):
         np.fft.fft(gx, norm="ortho")
     with pytest.raises(ValueError):
         np.fft.fft(gx.reshape(1, -1))
+
+
+def test_convolve_sage_fixtures_and_ntt_route():
+    """np.convolve = polynomial product: Sage fixtures for every field, then long products
+    that take the three-NTT route, checked against the oracle's direct convolution."""
+    import json
+    from tests.test_gpu_elementwise import field_from_props
+
+    for tag in H.SAGE_FIELDS:
+        props, d = H.load_sage_field(tag)
+        GF = field_from_props(props)
+        for mode in GF.ufunc_modes:
+            GF.compile(mode)
+            for i in range(3):
+                z = np.convolve(GF(d[f"convolve{i}_X"].astype(np.int64)), GF(d[f"convolve{i}_Y"].astype(np.int64)))
+                assert type(z) is GF
+                H.assert_equal_ints(z.numpy(), d[f"convolve{i}_Z"], f"{tag} convolve {mode}")
+        GF.compile("auto")
+    for order, na, nb in [(7340033, 5000, 3000), (65537, 20000, 9000), (2**64 - 2**32 + 1, 3000, 2500), (31, 3000, 2000)]:
+        GF = ga.GF(order)
+        F = O.OracleField(order, 1, None, GF._primitive_element_int)
+        rng = np.random.default_rng(na)
+        a = (rng.integers(0, 2**62, na, dtype=np.uint64) * np.uint64(3)) % np.uint64(order)
+        b = (rng.integers(0, 2**62, nb, dtype=np.uint64) * np.uint64(5)) % np.uint64(order)
+        mk = (lambda v: GF(np.array([int(t) for t in v], dtype=object))) if order > 2**63 else (lambda v: GF(v.astype(np.int64)))
+        z = np.convolve(mk(a), mk(b))
+        H.assert_equal_ints(np.array([int(t) for t in z.numpy()], dtype=np.uint64), F.convolve(a, b), f"convolve {order}")
+    with pytest.raises(ValueError):
+        np.convolve(ga.GF(31)([1, 2]), ga.GF(31)([1, 2]), mode="same")
+    with pytest.raises(TypeError):
+        np.convolve(ga.GF(31)([1, 2]), ga.GF(7)([1, 2]))
+
+
+def test_distributed_column_pass_emulated_on_one_gpu():
+    """gfa_ntt_columns + batched gfa_ntt composed exactly as galois_amd.dist.ntt_four_step_distributed does, with the
+    all-to-all emulated in-process for G ranks on one GPU; result compared with the single-GPU transform."""
+    import torch
+    from galois_amd import dist as gdist
+    from galois_amd import _lib as L
+
+    for order, n1, n2, G in [(7340033, 1 << 10, 1 << 8, 4), (2**64 - 2**32 + 1, 1 << 10, 1 << 6, 8), (65537, 1 << 6, 1 << 10, 2)]:
+        GF = ga.GF(order)
+        n = n1 * n2
+        rng = np.random.default_rng(n1)
+        xs = (rng.integers(0, 2**62, n, dtype=np.uint64) * np.uint64(3)) % np.uint64(order)
+        native = np.uint64 if order > 2**32 else np.uint32
+        omega = GF._root_of_unity_int(n)
+        cols, rows = n2 // G, n1 // G
+        a_parts = []
+        for g in range(G):
+            local = torch.from_numpy(gdist.columns_to_local(xs.astype(native), g, G, n1, n2).view(np.int64 if native is np.uint64 else np.int32)).cuda()
+            a_parts.append(gdist._device_column_pass(GF, local, n1, cols, g * cols, n, omega))
+        omega_n2 = GF._scalar(L.OP_POW, omega, n1)
+        outs = []
+        for r in range(G):
+            mine = torch.cat([a_parts[s][r * rows:(r + 1) * rows, :] for s in range(G)], dim=1).contiguous()
+            outs.append(gdist._device_row_pass(GF, mine, n2, omega_n2).cpu().numpy().view(native))
+        full = gdist.local_to_natural(outs, n1, n2)
+        gx = GF(np.array([int(t) for t in xs], dtype=object)) if order > 2**63 else GF(xs.astype(np.int64))
+        want = np.fft.fft(gx).numpy()
+        H.assert_equal_ints(full.astype(np.uint64), np.array([int(t) for t in want], dtype=np.uint64), f"dist {order}")

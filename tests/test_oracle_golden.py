@@ -37,6 +37,9 @@ def test_sage_field_vectors(tag, lookup):
     X, Y = d["scalar_multiply_X"].astype(np.uint64), d["scalar_multiply_Y"].astype(np.int64)
     XX, YY = np.meshgrid(X, np.mod(Y, props["characteristic"]).astype(np.uint64), indexing="ij")
     H.assert_equal_ints(F.mul(XX, YY), d["scalar_multiply_Z"], "scalar_multiply")
+    for i in range(3):  # tests/fields/test_numpy_functions.py convolve fixtures (polynomial products)
+        H.assert_equal_ints(F.convolve(d[f"convolve{i}_X"].astype(np.uint64), d[f"convolve{i}_Y"].astype(np.uint64)),
+                            d[f"convolve{i}_Z"], "convolve")
 
 
 def test_sage_reed_solomon_fixtures():
