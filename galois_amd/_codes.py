@@ -245,13 +245,12 @@ class ReedSolomon:
         L.check(L.lib().gfa_rs_decode(self._handle, _ptr(t2), _ptr(er_t) if er_t is not None else None, ns, _ptr(out),
                                       _ptr(nerr), N, L.U8, _stream()), "gfa_rs_decode")
         if output == "message":
-            if not self.is_systematic:
-                raise NotImplementedError("Message extraction for non-systematic codes has no device path.")
             ks = self.k - (self.n - ns)
-            dec = out[:, :ks]  # _cyclic.py:129-138
+            dec = torch.empty((N, ks), dtype=torch.uint8, device=out.device)  # _cyclic.py:129-138
+            L.check(L.lib().gfa_rs_extract_message(self._handle, _ptr(out), ns, _ptr(dec), N, L.U8, _stream()),
+                    "gfa_rs_extract_message")
         else:
             dec = out
-        dec = dec.contiguous()
         n_errors = nerr.cpu().numpy()
         if is_1d:
             dec, n_errors = dec[0], int(n_errors[0])

@@ -52,6 +52,7 @@ SIGNATURES = {
     "gfa_rs_destroy": (None, [c_void_p]),
     "gfa_rs_describe": (c_int, [c_void_p, _u64p, _u64p, _u64p]),
     "gfa_rs_encode": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_void_p]),
+    "gfa_rs_extract_message": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p]),
     "gfa_rs_detect": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p]),
     "gfa_rs_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "gfa_time_binary": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_int, _f32p]),

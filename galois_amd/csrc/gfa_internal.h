@@ -79,6 +79,7 @@ struct gfa_rs {
         bool ready = false;
         uint8_t *P8 = nullptr;     // k x (n-k)
         uint8_t *roots8 = nullptr; // n-k
+        uint8_t *g8 = nullptr;     // generator polynomial, highest degree first, n-k+1 coefficients
         uint32_t *lfsr = nullptr;  // 256 x (n-k)/4 words: rows f * (g_{nk-1} .. g_0) of the byte-wide LFSR (binary fields)
         uint8_t *rem = nullptr;    // scratch: r(x) mod g(x) per codeword for the two-kernel decoder
         size_t rem_bytes = 0;

@@ -896,14 +896,75 @@ __global__ __launch_bounds__(1024, 8) void rs_decode_bin_kernel(RsTables t, RsPa
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// non-systematic codes: c(x) = m(x) g(x) (message @ G[pad:, pad:], _codes/_linear.py:281-282) and the inverse,
+// m(x) = c(x) / g(x) (divmod_jit in _convert_codeword_to_message, _codes/_cyclic.py:129-138).  One codeword per wave.
+// ------------------------------------------------------------------------------------------------
+template <bool BIN>
+__global__ __launch_bounds__(1024) void rs_polymul_kernel(RsTables t, RsParams rp, const uint8_t *__restrict__ gdesc,
+                                                          const uint8_t *__restrict__ msg, int ks,
+                                                          uint8_t *__restrict__ out, i64 batch)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    Arith8<BIN> ar;
+    uint8_t *free_l = stage_tables<BIN>(lds_raw, t, ar, rp.qm1, blockDim.x);
+    const int nk = rp.n - rp.k, ns = ks + nk;
+    uint8_t *g_l = free_l; // generator polynomial, highest degree first, nk + 1 coefficients
+    for (int i = threadIdx.x; i <= nk; i += blockDim.x) g_l[i] = gdesc[i];
+    free_l += ((nk + 1 + 15) / 16) * 16;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    uint8_t *m_l = free_l + (size_t)wave * 256;
+    __syncthreads();
+    for (i64 cw = (i64)blockIdx.x * nwaves + wave; cw < batch; cw += (i64)gridDim.x * nwaves) {
+        for (int i = lane; i < ks; i += 64) m_l[i] = msg[cw * ks + i];
+        wave_sync();
+        // descending coefficient order on both sides: out[j] = sum_i m[i] * g[j - i]
+        for (int j = lane; j < ns; j += 64) {
+            const int lo = j - nk > 0 ? j - nk : 0, hi = j < ks - 1 ? j : ks - 1;
+            u32 acc = 0;
+            for (int i = lo; i <= hi; i++) acc = ar.add(acc, ar.mul(m_l[i], g_l[j - i]));
+            out[cw * ns + j] = (uint8_t)acc;
+        }
+        wave_sync();
+    }
+}
+
+template <bool BIN>
+__global__ __launch_bounds__(1024) void rs_polydiv_kernel(RsTables t, RsParams rp, const uint8_t *__restrict__ gdesc,
+                                                          const uint8_t *__restrict__ cw_g, int ns,
+                                                          uint8_t *__restrict__ out, i64 batch)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    Arith8<BIN> ar;
+    uint8_t *free_l = stage_tables<BIN>(lds_raw, t, ar, rp.qm1, blockDim.x);
+    const int nk = rp.n - rp.k, ks = ns - nk;
+    uint8_t *g_l = free_l;
+    for (int i = threadIdx.x; i <= nk; i += blockDim.x) g_l[i] = gdesc[i];
+    free_l += ((nk + 1 + 15) / 16) * 16;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    uint8_t *r_l = free_l + (size_t)wave * 256;
+    __syncthreads();
+    for (i64 cw = (i64)blockIdx.x * nwaves + wave; cw < batch; cw += (i64)gridDim.x * nwaves) {
+        for (int i = lane; i < ns; i += 64) r_l[i] = cw_g[cw * ns + i];
+        wave_sync();
+        // synthetic division by the monic g(x): quotient digit q_t = r[t]; r[t+1+j] -= q_t * g[1+j]
+        for (int tt = 0; tt < ks; tt++) {
+            const u32 q = r_l[tt];
+            if (q != 0) {
+                for (int j = lane; j < nk; j += 64) r_l[tt + 1 + j] = (uint8_t)ar.sub(r_l[tt + 1 + j], ar.mul(q, g_l[1 + j]));
+            }
+            wave_sync();
+        }
+        for (int i = lane; i < ks; i += 64) out[cw * ks + i] = r_l[i];
+        wave_sync();
+    }
+}
+
 int rs_check_device_path(const gfa_rs *code, int dtype, const char *what)
 {
     if (!code->field->has_tab8 || dtype != GFA_U8) {
         set_error(std::string(what) + ": the device path covers codes over fields of order <= 256 stored as uint8");
-        return GFA_ERR_UNSUPPORTED;
-    }
-    if (!code->systematic) {
-        set_error(std::string(what) + ": non-systematic codes have no device path");
         return GFA_ERR_UNSUPPORTED;
     }
     return GFA_OK;
@@ -941,6 +1002,37 @@ int cu_count()
     hipDeviceProp_t prop;
     if (hipGetDevice(&d) != hipSuccess || hipGetDeviceProperties(&prop, d) != hipSuccess) return 256;
     return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+}
+
+
+template <bool DIV>
+int launch_poly(gfa_rs *code, const void *in, int len_in, void *out, i64 batch, hipStream_t st)
+{ // DIV = false: polymul (len_in = ks); DIV = true: polydiv (len_in = ns)
+    int rc;
+    FieldDeviceState *ds;
+    gfa_rs::Dev *cd;
+    if ((rc = code->field->ensure_device(nullptr, &ds))) return rc;
+    if ((rc = code->ensure_device(nullptr, &cd))) return rc;
+    const RsParams rp = make_params(code);
+    const bool bin = rp.p == 2;
+    const int nk = rp.n - rp.k;
+    const int nwaves = bin ? 16 : 8;
+    const size_t lds = (bin ? 65536 : 131072) + 1280 + ((nk + 1 + 15) / 16) * 16 + (size_t)nwaves * 256;
+    const int grid = (int)std::max<i64>(1, std::min<i64>((batch + nwaves - 1) / nwaves, (i64)cu_count()));
+    static bool a[2] = {false, false};
+    if (bin) {
+        auto k = DIV ? rs_polydiv_kernel<true> : rs_polymul_kernel<true>;
+        if ((rc = set_lds_limit(k, &a[0]))) return rc;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(nwaves * 64), lds, st, make_tables(*ds), rp, cd->g8, (const uint8_t *)in, len_in,
+                           (uint8_t *)out, batch);
+    } else {
+        auto k = DIV ? rs_polydiv_kernel<false> : rs_polymul_kernel<false>;
+        if ((rc = set_lds_limit(k, &a[1]))) return rc;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(nwaves * 64), lds, st, make_tables(*ds), rp, cd->g8, (const uint8_t *)in, len_in,
+                           (uint8_t *)out, batch);
+    }
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
 }
 
 
@@ -998,6 +1090,12 @@ int gfa_rs::ensure_device(int *device_out, Dev **out)
         GFA_HIP(hipMalloc((void **)&st.roots8, std::max<size_t>(r8.size(), 16)));
         if (!P8.empty()) GFA_HIP(hipMemcpy(st.P8, P8.data(), P8.size(), hipMemcpyHostToDevice));
         if (!r8.empty()) GFA_HIP(hipMemcpy(st.roots8, r8.data(), r8.size(), hipMemcpyHostToDevice));
+        {
+            std::vector<uint8_t> g8(gpoly.size());
+            for (size_t i = 0; i < g8.size(); i++) g8[i] = (uint8_t)gpoly[i];
+            GFA_HIP(hipMalloc((void **)&st.g8, std::max<size_t>(g8.size(), 16)));
+            GFA_HIP(hipMemcpy(st.g8, g8.data(), g8.size(), hipMemcpyHostToDevice));
+        }
         if (field->has_tab8 && field->calc.p == 2 && nk >= 4 && nk <= 64 && nk % 4 == 0) {
             // LFSR rows: word d of row f packs f * gpoly[1 + 4d .. 4d + 3] (coefficients of x^(nk-1-4d) ..), first in the top byte
             std::vector<uint32_t> rows(256 * (nk / 4));
@@ -1072,7 +1170,7 @@ void gfa_rs_destroy(gfa_rs_t *code)
 {
     if (!code) return;
     for (auto &st : code->dev)
-        if (st.ready) { (void)hipFree(st.P8); (void)hipFree(st.roots8); (void)hipFree(st.lfsr); (void)hipFree(st.rem); }
+        if (st.ready) { (void)hipFree(st.P8); (void)hipFree(st.roots8); (void)hipFree(st.lfsr); (void)hipFree(st.rem); (void)hipFree(st.g8); }
     delete code;
 }
 
@@ -1096,6 +1194,14 @@ int gfa_rs_encode(gfa_rs_t *code, const void *msg, int64_t ks, void *out, int64_
     gfa_rs::Dev *cd;
     if ((rc = code->field->ensure_device(nullptr, &ds))) return rc;
     if ((rc = code->ensure_device(nullptr, &cd))) return rc;
+    if (!code->systematic) {
+        if (parity_only) { set_error("gfa_rs_encode: parity output exists only for systematic codes"); return GFA_ERR_INVALID; }
+        if (code->n == code->k) {
+            GFA_HIP(hipMemcpyAsync(out, msg, (size_t)(batch * ks), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            return GFA_OK;
+        }
+        return launch_poly<false>(code, msg, (int)ks, out, batch, (hipStream_t)stream);
+    }
     const RsParams rp = make_params(code);
     const bool bin = rp.p == 2;
     const int nk = rp.n - rp.k;
@@ -1242,6 +1348,25 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
         }
     }
     return launch_decode(code, recv, erasures, ns, out_codeword, out_n_errors, nullptr, batch, false, (hipStream_t)stream);
+}
+
+int gfa_rs_extract_message(gfa_rs_t *code, const void *cw, int64_t ns, void *out_msg, int64_t batch, int dtype,
+                           gfa_stream_t stream)
+{
+    if (!code || !cw || !out_msg || batch < 0 || ns < code->n - code->k + 1 || ns > code->n) {
+        set_error("gfa_rs_extract_message: bad arguments");
+        return GFA_ERR_INVALID;
+    }
+    int rc = rs_check_device_path(code, dtype, "gfa_rs_extract_message");
+    if (rc) return rc;
+    if (batch == 0) return GFA_OK;
+    const int64_t ks = code->k - (code->n - ns);
+    if (code->systematic || code->n == code->k) {
+        GFA_HIP(hipMemcpy2DAsync(out_msg, (size_t)ks, cw, (size_t)ns, (size_t)ks, (size_t)batch, hipMemcpyDeviceToDevice,
+                                 (hipStream_t)stream));
+        return GFA_OK;
+    }
+    return launch_poly<true>(code, cw, (int)ns, out_msg, batch, (hipStream_t)stream);
 }
 
 int gfa_time_rs_encode(gfa_rs_t *code, const void *msg, int64_t ks, void *out, int64_t batch, int dtype,

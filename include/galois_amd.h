@@ -137,9 +137,14 @@ void gfa_rs_destroy(gfa_rs_t *code);
 int gfa_rs_describe(const gfa_rs_t *code, uint64_t *roots, uint64_t *generator_poly, uint64_t *parity_matrix);
 /* _LinearCode._encode_message -> matmul_jit (_codes/_linear.py:270-284, _domains/_linalg.py:286-308).
  * msg: (batch, ks) row-major, ks <= k (shortened codes pass fewer symbols).  out: (batch, ks + n - k) codewords, or
- * (batch, n - k) parity symbols when parity_only != 0.  Systematic codes only on the device. */
+ * (batch, n - k) parity symbols when parity_only != 0 (systematic codes).  Non-systematic codes: codeword = m(x) g(x),
+ * i.e. message @ G[pad:, pad:]. */
 int gfa_rs_encode(gfa_rs_t *code, const void *msg, int64_t ks, void *out, int64_t batch, int parity_only, int dtype,
                   gfa_stream_t stream);
+/* _CyclicCode._convert_codeword_to_message (_codes/_cyclic.py:129-138): the first ks symbols of a systematic codeword,
+ * or the quotient codeword(x) / g(x) (divmod_jit) for a non-systematic code.  cw: (batch, ns); out_msg: (batch, ks). */
+int gfa_rs_extract_message(gfa_rs_t *code, const void *cw, int64_t ns, void *out_msg, int64_t batch, int dtype,
+                           gfa_stream_t stream);
 /* _LinearCode._detect_errors (_codes/_linear.py:286-298): detected[i] = any(syndrome_i != 0). cw: (batch, ns). */
 int gfa_rs_detect(gfa_rs_t *code, const void *cw, int64_t ns, uint8_t *detected, int64_t batch, int dtype,
                   gfa_stream_t stream);

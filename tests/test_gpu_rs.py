@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_sage_encode_fixtures():
-    """tests/codes/test_reed_solomon.py:98-133 (systematic codes; non-systematic codes have no device path yet)."""
+    """tests/codes/test_reed_solomon.py:98-133: all 56 Sage fixtures, systematic and non-systematic."""
     names, d = H.sage_rs()
     n_checked = 0
     for key in names:
@@ -20,15 +20,15 @@ def test_sage_encode_fixtures():
         rs = ga.ReedSolomon(meta["n"], meta["k"], field=ga.GF(meta["q"]), alpha=meta["alpha"], c=meta["c"],
                             systematic=meta["is_systematic"])
         msgs = d[f"{key}/messages"].astype(np.int64)
-        if not meta["is_systematic"]:
-            with pytest.raises(NotImplementedError):
-                rs.encode(msgs)
-            continue
         cw = rs.encode(msgs)
         assert type(cw) is rs.field
         H.assert_equal_ints(cw.numpy(), d[f"{key}/codewords"], key)
         H.assert_equal_ints(rs.encode(msgs[0]).numpy(), d[f"{key}/codewords"][0], key + " 1-D")
-        H.assert_equal_ints(rs.encode(msgs, output="parity").numpy(), d[f"{key}/codewords"][:, meta["k"]:], key + " parity")
+        if meta["is_systematic"]:
+            H.assert_equal_ints(rs.encode(msgs, output="parity").numpy(), d[f"{key}/codewords"][:, meta["k"]:], key + " parity")
+        else:
+            with pytest.raises(ValueError):
+                rs.encode(msgs, output="parity")
         H.assert_equal_ints(rs.encode(msgs.tolist()).numpy(), d[f"{key}/codewords"], key + " list input")
         if f"{key}/short_messages" in d:
             H.assert_equal_ints(rs.encode(d[f"{key}/short_messages"].astype(np.int64)).numpy(), d[f"{key}/short_codewords"], key + " shortened")
@@ -44,7 +44,7 @@ def test_sage_encode_fixtures():
         H.assert_equal_ints(dec.numpy(), msgs, key + " decode")
         assert np.array_equal(nerr, ne)
         n_checked += 1
-    assert n_checked >= 20
+    assert n_checked == 56
 
 
 def test_reference_generated_cases():
