@@ -634,6 +634,23 @@ class FieldArray(metaclass=FieldArrayMeta):
             out = out.unsqueeze(axis if axis is not None else 0) if axis is not None else out.reshape((1,) * t.dim())
         return cls._wrap(out, self._np_dtype)
 
+    def _accumulate(self, op: int, axis: int) -> "FieldArray":
+        cls = type(self)
+        t = self._t
+        if t.dim() == 0:
+            raise TypeError("cannot accumulate on a scalar")
+        axis = axis % t.dim()
+        t2 = t.movedim(axis, -1).contiguous()
+        shape = t2.shape
+        t2 = t2.reshape(-1, shape[-1])
+        out = torch.empty_like(t2)
+        err = torch.zeros(1, dtype=torch.int32, device=t.device) if op == L.OP_DIV else None
+        L.check(L.lib().gfa_accumulate(cls._handle, op, _ptr(t2), _ptr(out), t2.shape[0], t2.shape[1], self._gfa_dtype(),
+                                       _stream(), _ptr(err) if err is not None else None), "gfa_accumulate")
+        if err is not None:
+            self._check_err(err)
+        return cls._wrap(out.reshape(shape).movedim(-1, axis).contiguous(), self._np_dtype)
+
     # ---- NumPy ufunc protocol (UFuncMixin.__array_ufunc__, _domains/_ufunc.py:660-713) ----------------------
     _UNARY_ONLY = (np.negative, np.reciprocal, np.square)
 
@@ -670,6 +687,9 @@ class FieldArray(metaclass=FieldArrayMeta):
             if method == "reduce":
                 same_field()
                 return inputs[0]._reduce(op, kwargs.get("axis", 0), bool(kwargs.get("keepdims", False)))
+            if method == "accumulate":
+                same_field()
+                return inputs[0]._accumulate(op, kwargs.get("axis", 0))
             if method == "outer":
                 same_field()
                 a, b = inputs

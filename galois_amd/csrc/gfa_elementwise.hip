@@ -581,6 +581,80 @@ int dispatch_convolve(const FieldDev &fd, int dtype, const void *a, i64 na, cons
     GFA_DISPATCH_FT(launch_convolve_ft, fd, dtype, fd, a, na, b, nb, out, st);
 }
 
+
+// ufunc.accumulate over the last axis: one workgroup per row, 256-element chunks scanned in LDS with a running carry.
+// mode 0: inclusive scan with the op; 1: out[i] = a0 - (a1 + ... + ai); 2: out[i] = a0 / (a1 * ... * ai)
+template <class F, typename T, bool IS_MUL>
+__global__ __launch_bounds__(256) void accumulate_kernel(FieldDev fd, const T *__restrict__ in, T *__restrict__ out, i64 n_inner,
+                                                         int mode, int32_t *err)
+{
+    typedef typename F::elem E;
+    __shared__ u64 sh[256];
+    const T *x = in + (i64)blockIdx.x * n_inner;
+    T *y = out + (i64)blockIdx.x * n_inner;
+    const E ident = IS_MUL ? F::one(fd) : (E)0;
+    const E a0 = (E)x[0];
+    E carry = ident;
+    bool bad = false;
+    const i64 start = mode ? 1 : 0;
+    if (mode && threadIdx.x == 0) y[0] = (T)a0;
+    for (i64 base = start; base < n_inner; base += 256) {
+        const i64 i = base + threadIdx.x;
+        E v = i < n_inner ? (E)x[i] : ident;
+        sh[threadIdx.x] = (u64)v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            E o = ident;
+            if ((int)threadIdx.x >= off) o = (E)sh[threadIdx.x - off];
+            __syncthreads();
+            if ((int)threadIdx.x >= off) {
+                v = IS_MUL ? F::mul(fd, o, v) : F::add(fd, o, v);
+                sh[threadIdx.x] = (u64)v;
+            }
+            __syncthreads();
+        }
+        E r = IS_MUL ? F::mul(fd, carry, v) : F::add(fd, carry, v);
+        const E total = IS_MUL ? F::mul(fd, carry, (E)sh[255]) : F::add(fd, carry, (E)sh[255]);
+        if (i < n_inner) {
+            E o = r;
+            if (mode == 1) o = F::sub(fd, a0, r);
+            if (mode == 2) {
+                if (r == 0) { bad = true; o = 0; }
+                else if (a0 == 0) o = 0;
+                else {
+                    if constexpr (std::is_same<F, Lut>::value) o = Lut::div_nz(fd, a0, r);
+                    else o = F::mul(fd, a0, F::inv(fd, r));
+                }
+            }
+            y[i] = (T)o;
+        }
+        carry = total;
+        __syncthreads();
+    }
+    flag_error(err, bad);
+}
+
+template <class F, typename T>
+int launch_accumulate_ft(const FieldDev &fd, int op, const void *a, void *out, i64 n_outer, i64 n_inner, hipStream_t st,
+                         int32_t *err)
+{
+    const int mode = op == GFA_OP_SUB ? 1 : op == GFA_OP_DIV ? 2 : 0;
+    if (op == GFA_OP_MUL || op == GFA_OP_DIV)
+        hipLaunchKernelGGL((accumulate_kernel<F, T, true>), dim3((unsigned)n_outer), dim3(256), 0, st, fd, (const T *)a, (T *)out,
+                           n_inner, mode, err);
+    else
+        hipLaunchKernelGGL((accumulate_kernel<F, T, false>), dim3((unsigned)n_outer), dim3(256), 0, st, fd, (const T *)a, (T *)out,
+                           n_inner, mode, err);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+int dispatch_accumulate(const FieldDev &fd, int dtype, int op, const void *a, void *out, i64 n_outer, i64 n_inner,
+                        hipStream_t st, int32_t *err)
+{
+    GFA_DISPATCH_FT(launch_accumulate_ft, fd, dtype, fd, op, a, out, n_outer, n_inner, st, err);
+}
+
 bool dtype_holds(int dtype, u64 q)
 {
     switch (dtype) {
@@ -764,6 +838,23 @@ int gfa_reduce(gfa_field_t *f, int op, const void *a, void *out, int64_t n_outer
     if (rc) return rc;
     if (f->use_lookup()) return dispatch_reduce(f->lut_desc(*ds), dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
     return dispatch_reduce(f->calc, dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
+}
+
+int gfa_accumulate(gfa_field_t *f, int op, const void *a, void *out, int64_t n_outer, int64_t n_inner, int dtype,
+                   gfa_stream_t stream, int32_t *dev_err)
+{
+    if (!f || n_outer < 0 || n_inner < 0 || op < GFA_OP_ADD || op > GFA_OP_DIV) {
+        set_error("gfa_accumulate: bad arguments");
+        return GFA_ERR_INVALID;
+    }
+    if (n_outer == 0 || n_inner == 0) return GFA_OK;
+    if (!a || !out) { set_error("gfa_accumulate: bad arguments"); return GFA_ERR_INVALID; }
+    if (!dtype_holds(dtype, f->calc.q)) { set_error("dtype cannot hold the field's elements"); return GFA_ERR_INVALID; }
+    FieldDeviceState *ds;
+    int rc = f->ensure_device(nullptr, &ds);
+    if (rc) return rc;
+    if (f->use_lookup()) return dispatch_accumulate(f->lut_desc(*ds), dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
+    return dispatch_accumulate(f->calc, dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
 }
 
 int gfa_convolve(gfa_field_t *f, const void *a, int64_t na, const void *b, int64_t nb, void *out, int dtype,

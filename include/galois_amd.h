@@ -104,6 +104,9 @@ int gfa_scalar_multiply(gfa_field_t *f, const void *a, int64_t a_stride, const i
 int gfa_reduce(gfa_field_t *f, int op, const void *a, void *out, int64_t n_outer, int64_t n_inner, int dtype,
                gfa_stream_t stream, int32_t *dev_err);
 
+/* ufunc.accumulate over the last axis of an (n_outer, n_inner) array, same ops and fold conventions as gfa_reduce. */
+int gfa_accumulate(gfa_field_t *f, int op, const void *a, void *out, int64_t n_outer, int64_t n_inner, int dtype,
+                   gfa_stream_t stream, int32_t *dev_err);
 /* np.convolve(a, b), mode "full": out[k] = sum_i a[i] * b[k-i], na + nb - 1 outputs -- convolve_jit
  * (_domains/_function.py:111-167).  Direct O(na*nb) form for any field; the host routes long prime-field products
  * through gfa_ntt instead (three transforms + one gfa_binary multiply). */

@@ -194,6 +194,16 @@ def test_reductions_and_outer():
             for v in acc:
                 tot = F.add([tot], [v])[0]
             assert int(np.add.reduce(big).numpy()) == int(tot)
+            for ufunc, fold in [(np.add, F.add), (np.multiply, F.mul), (np.subtract, F.sub), (np.true_divide, F.div)]:
+                sub = a[:5, :700]
+                want = np.empty(sub.shape, dtype=np.uint64)
+                want[:, 0] = sub[:, 0]
+                for j in range(1, sub.shape[1]):
+                    want[:, j] = fold(want[:, j - 1], sub[:, j].astype(np.uint64))
+                got = ufunc.accumulate(GF(sub), axis=1)
+                H.assert_equal_ints(got.numpy().astype(np.uint64), want, f"{order} {ufunc.__name__} accumulate")
+                got0 = ufunc.accumulate(GF(np.ascontiguousarray(sub.T)), axis=0)
+                H.assert_equal_ints(got0.numpy().astype(np.uint64), want.T, f"{order} {ufunc.__name__} accumulate axis 0")
             out = np.multiply.outer(GF(a[0, :50]), GF(a[1, :60]))
             assert out.shape == (50, 60)
             H.assert_equal_ints(out.numpy().astype(np.uint64), F.mul(a[0, :50, None].astype(np.uint64), a[1, None, :60].astype(np.uint64)))
@@ -202,6 +212,8 @@ def test_reductions_and_outer():
             np.negative.reduce(g)
         with pytest.raises(ValueError):
             np.power.reduce(g)
+        with pytest.raises(ValueError):
+            np.reciprocal.accumulate(g)
 
 
 def test_api_semantics_and_errors():
