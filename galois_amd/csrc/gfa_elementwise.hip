@@ -62,6 +62,39 @@ __device__ __forceinline__ typename F::elem apply_unary(const FieldDev &fd, type
     }
 }
 
+
+// Simultaneous inversion (Montgomery's trick) of the V elements one lane holds: one field inversion + 3(V-1)
+// multiplications instead of V inversions.  Used where an inversion is an exponentiation (prime fields: a^(p-2)).
+// Zero entries are flagged and yield 0; they are replaced by 1 inside the product chain.
+template <class F>
+struct BatchInv {
+    static constexpr bool value = std::is_same<F, Prime32>::value || std::is_same<F, Prime64>::value ||
+                                  std::is_same<F, Goldilocks>::value;
+};
+
+template <class F, int V>
+__device__ __forceinline__ void batch_inverse(const FieldDev &fd, typename F::elem (&x)[V], bool &bad)
+{
+    typedef typename F::elem E;
+    E pre[V]; // pre[j] = x'[0] * ... * x'[j]
+    E acc = F::one(fd);
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+        const E xj = x[j] == 0 ? F::one(fd) : x[j];
+        bad |= x[j] == 0;
+        acc = j == 0 ? xj : F::mul(fd, acc, xj);
+        pre[j] = acc;
+    }
+    E inv = F::inv(fd, acc);
+#pragma unroll
+    for (int j = V - 1; j >= 0; j--) {
+        const E xj = x[j] == 0 ? F::one(fd) : x[j];
+        const E r = j == 0 ? inv : F::mul(fd, inv, pre[j - 1]);
+        inv = F::mul(fd, inv, xj);
+        x[j] = x[j] == 0 ? (E)0 : r;
+    }
+}
+
 template <class F, typename T, int OP, bool VEC>
 __global__ __launch_bounds__(256) void ew_binary_kernel(FieldDev fd, const T *__restrict__ a, int sa,
                                                         const T *__restrict__ b, int sb, T *__restrict__ out, i64 n,
@@ -80,11 +113,20 @@ __global__ __launch_bounds__(256) void ew_binary_kernel(FieldDev fd, const T *__
             Vec16<T> av, bv, ov;
             if (sa) av = reinterpret_cast<const Vec16<T> *>(a)[i];
             if (sb) bv = reinterpret_cast<const Vec16<T> *>(b)[i];
+            if constexpr (OP == GFA_OP_DIV && BatchInv<F>::value) {
+                E yv[V];
 #pragma unroll
-            for (int j = 0; j < V; j++) {
-                E x = sa ? (E)av.v[j] : a0;
-                E y = sb ? (E)bv.v[j] : b0;
-                ov.v[j] = (T)apply_binary<F, OP>(fd, x, y, bad);
+                for (int j = 0; j < V; j++) yv[j] = sb ? (E)bv.v[j] : b0;
+                batch_inverse<F, V>(fd, yv, bad);
+#pragma unroll
+                for (int j = 0; j < V; j++) ov.v[j] = (T)F::mul(fd, sa ? (E)av.v[j] : a0, yv[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < V; j++) {
+                    E x = sa ? (E)av.v[j] : a0;
+                    E y = sb ? (E)bv.v[j] : b0;
+                    ov.v[j] = (T)apply_binary<F, OP>(fd, x, y, bad);
+                }
             }
             reinterpret_cast<Vec16<T> *>(out)[i] = ov;
         }
@@ -110,8 +152,17 @@ __global__ __launch_bounds__(256) void ew_unary_kernel(FieldDev fd, const T *__r
         const i64 nvec = n / V;
         for (i64 i = tid; i < nvec; i += nth) {
             Vec16<T> av = reinterpret_cast<const Vec16<T> *>(a)[i], ov;
+            if constexpr (OP == GFA_OP_RECIP && BatchInv<F>::value) {
+                E xv[V];
 #pragma unroll
-            for (int j = 0; j < V; j++) ov.v[j] = (T)apply_unary<F, OP>(fd, (E)av.v[j], bad);
+                for (int j = 0; j < V; j++) xv[j] = (E)av.v[j];
+                batch_inverse<F, V>(fd, xv, bad);
+#pragma unroll
+                for (int j = 0; j < V; j++) ov.v[j] = (T)xv[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < V; j++) ov.v[j] = (T)apply_unary<F, OP>(fd, (E)av.v[j], bad);
+            }
             reinterpret_cast<Vec16<T> *>(out)[i] = ov;
         }
         for (i64 i = nvec * V + tid; i < n; i += nth) out[i] = (T)apply_unary<F, OP>(fd, (E)a[i], bad);

@@ -109,9 +109,14 @@ bool gfa_field::use_lookup() const
 {
     if (mode == GFA_MODE_LOOKUP) return has_lut;
     if (mode == GFA_MODE_CALCULATE) return false;
-    // AUTO: explicit arithmetic is cheaper than table gathers for prime fields on this hardware; extension fields
-    // use tables while they stay cache-resident (q <= 2^16), explicit arithmetic beyond.
-    return has_lut && calc.m > 1 && calc.q <= (1u << 16);
+    // AUTO, from tools/ew_bench.py on MI355X:
+    //  * order <= 256 (any field, uint8): the LDS full-table kernels run at the streaming ceiling (mul/div/reciprocal
+    //    66-76 % of HBM peak vs 48 % / 5 % for explicit GF(31) arithmetic) -> lookup;
+    //  * odd-characteristic extension fields up to 2^20: digit-vector arithmetic is far slower than table gathers -> lookup;
+    //  * GF(2^m), 8 < m <= 20 and all larger prime fields: explicit arithmetic beats EXP/LOG gathers from L2 -> calculate.
+    if (!has_lut) return false;
+    if (calc.q <= 256) return true;
+    return calc.m > 1 && calc.p != 2;
 }
 
 gfa::FieldDev gfa_field::lut_desc(const gfa::FieldDeviceState &st) const

@@ -76,7 +76,8 @@ def test_dtypes_follow_the_reference_rules():
     assert names(ga.GF(2**64 - 2**32 + 1)) == ["object"]
     assert names(ga.GF(2**32)) == ["uint32", "int64"]
     assert names(ga.GF(2147483647)) == ["uint32", "int32", "int64"]
-    assert ga.GF(31).ufunc_mode == "jit-calculate" and ga.GF(3**5).ufunc_mode == "jit-lookup"
+    assert ga.GF(31).ufunc_mode == "jit-lookup" and ga.GF(3**5).ufunc_mode == "jit-lookup"  # the reference defaults too
+    assert ga.GF(65537).ufunc_mode == "jit-calculate" and ga.GF(2**16).ufunc_mode == "jit-calculate"
 
 
 @pytest.mark.parametrize("order", [2**8, 31, 3**5, 5**3, 2**4, 65537])

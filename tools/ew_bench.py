@@ -1,0 +1,40 @@
+"""Element-wise throughput across field kinds / dtypes / modes (Gop/s and fraction of the 8 TB/s HBM peak)."""
+import ctypes, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import galois_amd as ga
+from galois_amd import _lib as L
+lib = L.lib()
+st = torch.cuda.current_stream().cuda_stream
+ms = ctypes.c_float()
+rows = []
+cases = [(31, np.uint8, "auto"), (31, np.uint8, "jit-lookup"), (2**8, np.uint8, "jit-calculate"), (2**8, np.int64, "jit-lookup"),
+         (65537, np.uint32, "auto"), (7340033, np.uint32, "auto"), (2147483647, np.uint32, "auto"),
+         (2**64 - 2**32 + 1, None, "auto"), (2**16, np.uint16, "auto"), (2**16, np.uint16, "jit-calculate"), (2**32, np.uint32, "auto"),
+         (3**5, np.uint8, "auto"), (3**5, np.uint8, "jit-calculate"), (251**3, np.uint32, "auto")]
+n = 50_000_000
+for order, dt, mode in cases:
+    GF = ga.GF(order)
+    GF.compile(mode)
+    esize = 8 if dt is None else np.dtype(dt).itemsize
+    rng = np.random.default_rng(1)
+    if order > 2**63:
+        a = torch.from_numpy((rng.integers(0, 2**63, n, dtype=np.uint64) % np.uint64(order)).view(np.int64)).cuda()
+        b = torch.from_numpy(((rng.integers(0, 2**63, n, dtype=np.uint64) % np.uint64(order - 1)) + np.uint64(1)).view(np.int64)).cuda()
+    else:
+        sd = {1: np.uint8, 2: np.int16, 4: np.int32, 8: np.int64}[esize]
+        a = torch.from_numpy(rng.integers(0, order, n, dtype=np.uint64).astype(dt).view(sd)).cuda()
+        b = torch.from_numpy(rng.integers(1, order, n, dtype=np.uint64).astype(dt).view(sd)).cuda()
+    o = torch.empty_like(a)
+    code = {1: L.U8, 2: L.U16, 4: L.U32, 8: L.U64}[esize]
+    r = {"field": GF.name, "dtype": "u%d" % (8 * esize), "mode": GF.ufunc_mode}
+    for name, op in (("add", L.OP_ADD), ("mul", L.OP_MUL), ("div", L.OP_DIV)):
+        L.check(lib.gfa_time_binary(GF._handle, op, a.data_ptr(), b.data_ptr(), o.data_ptr(), n, code, st, 5, ctypes.byref(ms)))
+        r[name] = f"{n / ms.value / 1e6:.0f} Gop/s ({3 * esize * n / ms.value / 1e6 / 8000:.2f})"
+    L.check(lib.gfa_time_unary(GF._handle, L.OP_RECIP, b.data_ptr(), o.data_ptr(), n, code, st, 5, ctypes.byref(ms)))
+    r["recip"] = f"{n / ms.value / 1e6:.0f} Gop/s ({2 * esize * n / ms.value / 1e6 / 8000:.2f})"
+    GF.compile("auto")
+    rows.append(r)
+    print(json.dumps(r), flush=True)
+    del a, b, o
