@@ -212,70 +212,55 @@ __device__ __forceinline__ u32 lookup4(const uint8_t *lds, u32 aw, u32 bw)
     return r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
 }
 
-// out = TABLE[a][b].  `zero_b_is_error`: division flags b == 0.
-template <int UNROLL, bool CHECK_ZERO_B, bool NT>
+// out = TABLE[a][b].  CHECK_ZERO_B: division flags b == 0.
+// Software-pipelined: the first operand vectors are requested BEFORE the table is staged (the 64 KiB L2->LDS copy then
+// overlaps the first HBM round trip), and each lane re-arms its load for the next vector before it does the 16 LDS
+// lookups of the current one.  Measured (tools/ubench/stream3.hip, 1e8 elements): 46.9 us against 49.6 us for the
+// load-all / lookup-all / store-all loop; the plain a^b stream in the same launch shape takes 46.5 us.
+template <bool CHECK_ZERO_B>
 __global__ __launch_bounds__(TAB8_THREADS) void tab8_binary_kernel(const uint8_t *__restrict__ table,
                                                                     const uint8_t *__restrict__ a,
                                                                     const uint8_t *__restrict__ b,
                                                                     uint8_t *__restrict__ out, i64 n, int32_t *err)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(table);
-        uint4 *dst = reinterpret_cast<uint4 *>(lds);
-        for (int i = threadIdx.x; i < 65536 / 16; i += TAB8_THREADS) dst[i] = src[i];
-    }
-    __syncthreads();
-    bool bad = false;
     const i64 nvec = n >> 4;
     const u32x4 *av = reinterpret_cast<const u32x4 *>(a);
     const u32x4 *bv = reinterpret_cast<const u32x4 *>(b);
     u32x4 *ov = reinterpret_cast<u32x4 *>(out);
     const i64 stride = (i64)gridDim.x * TAB8_THREADS;
     i64 i = (i64)blockIdx.x * TAB8_THREADS + threadIdx.x;
-    // main loop: UNROLL independent 16-byte loads per operand in flight per lane
-    for (; i + (UNROLL - 1) * stride < nvec; i += UNROLL * stride) {
-        u32x4 x[UNROLL], y[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            x[u] = NT ? __builtin_nontemporal_load(av + i + u * stride) : av[i + u * stride];
-            y[u] = NT ? __builtin_nontemporal_load(bv + i + u * stride) : bv[i + u * stride];
-        }
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            u32x4 r;
-            r.x = lookup4(lds, x[u].x, y[u].x);
-            r.y = lookup4(lds, x[u].y, y[u].y);
-            r.z = lookup4(lds, x[u].z, y[u].z);
-            r.w = lookup4(lds, x[u].w, y[u].w);
-            if constexpr (CHECK_ZERO_B) {
-                // a byte of y is zero  <=>  (v - 0x01010101) & ~v & 0x80808080 != 0
-                u32 z = ((y[u].x - 0x01010101u) & ~y[u].x) | ((y[u].y - 0x01010101u) & ~y[u].y) |
-                        ((y[u].z - 0x01010101u) & ~y[u].z) | ((y[u].w - 0x01010101u) & ~y[u].w);
-                bad |= (z & 0x80808080u) != 0;
-            }
-            if (NT) __builtin_nontemporal_store(r, ov + i + u * stride);
-            else ov[i + u * stride] = r;
-        }
+    u32x4 x = {0, 0, 0, 0}, y = {0, 0, 0, 0};
+    if (i < nvec) { x = av[i]; y = bv[i]; }
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(table);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds);
+        for (int t = threadIdx.x; t < 65536 / 16; t += TAB8_THREADS) dst[t] = src[t];
     }
+    __syncthreads();
+    bool bad = false;
     for (; i < nvec; i += stride) {
-        u32x4 x = av[i], y = bv[i], r;
-        r.x = lookup4(lds, x.x, y.x);
-        r.y = lookup4(lds, x.y, y.y);
-        r.z = lookup4(lds, x.z, y.z);
-        r.w = lookup4(lds, x.w, y.w);
+        const u32x4 cx = x, cy = y;
+        const i64 nxt = i + stride;
+        if (nxt < nvec) { x = av[nxt]; y = bv[nxt]; }
+        u32x4 r;
+        r.x = lookup4(lds, cx.x, cy.x);
+        r.y = lookup4(lds, cx.y, cy.y);
+        r.z = lookup4(lds, cx.z, cy.z);
+        r.w = lookup4(lds, cx.w, cy.w);
         if constexpr (CHECK_ZERO_B) {
-            u32 z = ((y.x - 0x01010101u) & ~y.x) | ((y.y - 0x01010101u) & ~y.y) | ((y.z - 0x01010101u) & ~y.z) |
-                    ((y.w - 0x01010101u) & ~y.w);
+            // a byte of y is zero  <=>  (v - 0x01010101) & ~v & 0x80808080 != 0
+            u32 z = ((cy.x - 0x01010101u) & ~cy.x) | ((cy.y - 0x01010101u) & ~cy.y) | ((cy.z - 0x01010101u) & ~cy.z) |
+                    ((cy.w - 0x01010101u) & ~cy.w);
             bad |= (z & 0x80808080u) != 0;
         }
         ov[i] = r;
     }
     // tail (< 16 elements)
     for (i64 j = (nvec << 4) + (i64)blockIdx.x * TAB8_THREADS + threadIdx.x; j < n; j += stride) {
-        uint8_t y = b[j];
-        if (CHECK_ZERO_B && y == 0) bad = true;
-        out[j] = lds[((u32)a[j] << 8) | y];
+        uint8_t yb = b[j];
+        if (CHECK_ZERO_B && yb == 0) bad = true;
+        out[j] = lds[((u32)a[j] << 8) | yb];
     }
     if constexpr (CHECK_ZERO_B) flag_error(err, bad);
 }
@@ -283,49 +268,42 @@ __global__ __launch_bounds__(TAB8_THREADS) void tab8_binary_kernel(const uint8_t
 // Unary / scalar-operand form: out = TABLE256[a].  The 256-entry table is replicated 32x in LDS as dwords,
 // entry v of copy c at dword v*32 + c, and lane l reads copy l%32 => every lane of a 32-lane LDS group hits its
 // own bank, no conflicts for any data.
-template <int UNROLL, bool CHECK_ZERO>
+template <bool CHECK_ZERO>
 __global__ __launch_bounds__(TAB8_THREADS) void tab8_unary_kernel(const uint8_t *__restrict__ table256,
                                                                    const uint8_t *__restrict__ a,
                                                                    uint8_t *__restrict__ out, i64 n, int32_t *err)
 {
     __shared__ u32 rep[256 * 32];
-    for (int i = threadIdx.x; i < 256 * 32; i += TAB8_THREADS) rep[i] = table256[i >> 5];
-    __syncthreads();
-    const u32 *my = rep + (threadIdx.x & 31);
-    bool bad = false;
     const i64 nvec = n >> 4;
     const u32x4 *av = reinterpret_cast<const u32x4 *>(a);
     u32x4 *ov = reinterpret_cast<u32x4 *>(out);
     const i64 stride = (i64)gridDim.x * TAB8_THREADS;
+    i64 i = (i64)blockIdx.x * TAB8_THREADS + threadIdx.x;
+    u32x4 x = {0, 0, 0, 0};
+    if (i < nvec) x = av[i];   // in flight while the table is replicated (same pipelining as the binary kernel)
+    for (int t = threadIdx.x; t < 256 * 32; t += TAB8_THREADS) rep[t] = table256[t >> 5];
+    __syncthreads();
+    const u32 *my = rep + (threadIdx.x & 31);
+    bool bad = false;
     auto map4 = [&](u32 w) -> u32 {
         u32 r0 = my[(w & 0xff) << 5], r1 = my[((w >> 8) & 0xff) << 5], r2 = my[((w >> 16) & 0xff) << 5],
             r3 = my[(w >> 24) << 5];
         return r0 | (r1 << 8) | (r2 << 16) | (r3 << 24);
     };
     auto haszero = [](u32 v) -> u32 { return (v - 0x01010101u) & ~v & 0x80808080u; };
-    i64 i = (i64)blockIdx.x * TAB8_THREADS + threadIdx.x;
-    for (; i + (UNROLL - 1) * stride < nvec; i += UNROLL * stride) {
-        u32x4 x[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) x[u] = __builtin_nontemporal_load(av + i + u * stride);
-#pragma unroll
-        for (int u = 0; u < UNROLL; u++) {
-            u32x4 r;
-            r.x = map4(x[u].x); r.y = map4(x[u].y); r.z = map4(x[u].z); r.w = map4(x[u].w);
-            if constexpr (CHECK_ZERO) bad |= (haszero(x[u].x) | haszero(x[u].y) | haszero(x[u].z) | haszero(x[u].w)) != 0;
-            __builtin_nontemporal_store(r, ov + i + u * stride);
-        }
-    }
     for (; i < nvec; i += stride) {
-        u32x4 x = av[i], r;
-        r.x = map4(x.x); r.y = map4(x.y); r.z = map4(x.z); r.w = map4(x.w);
-        if constexpr (CHECK_ZERO) bad |= (haszero(x.x) | haszero(x.y) | haszero(x.z) | haszero(x.w)) != 0;
+        const u32x4 cx = x;
+        const i64 nxt = i + stride;
+        if (nxt < nvec) x = av[nxt];
+        u32x4 r;
+        r.x = map4(cx.x); r.y = map4(cx.y); r.z = map4(cx.z); r.w = map4(cx.w);
+        if constexpr (CHECK_ZERO) bad |= (haszero(cx.x) | haszero(cx.y) | haszero(cx.z) | haszero(cx.w)) != 0;
         ov[i] = r;
     }
     for (i64 j = (nvec << 4) + (i64)blockIdx.x * TAB8_THREADS + threadIdx.x; j < n; j += stride) {
-        uint8_t x = a[j];
-        if (CHECK_ZERO && x == 0) bad = true;
-        out[j] = (uint8_t)my[(u32)x << 5];
+        uint8_t xb = a[j];
+        if (CHECK_ZERO && xb == 0) bad = true;
+        out[j] = (uint8_t)my[(u32)xb << 5];
     }
     if constexpr (CHECK_ZERO) flag_error(err, bad);
 }
@@ -717,7 +695,6 @@ bool dtype_holds(int dtype, u64 q)
     }
 }
 
-constexpr int TAB8_UNROLL = 2;
 
 int tab8_grid(i64 n)
 {
@@ -730,40 +707,19 @@ int tab8_grid(i64 n)
 int launch_tab8_binary(const uint8_t *table, bool check_zero_b, const void *a, const void *b, void *out, i64 n,
                        hipStream_t st, int32_t *err)
 {
-    // tuning knob (tools/gf256_tune.py): GFA_TAB8_VARIANT = <unroll 1|2|4><n|t>, default "2t" (plain loads/stores, unroll 2:
-    // measured 6.0-6.15 TB/s vs 5.9-5.96 TB/s for the nontemporal forms; the plain XOR stream reaches the same 6.0-6.25)
-    static int variant = -1;
-    if (variant < 0) {
-        const char *v = getenv("GFA_TAB8_VARIANT");
-        int u = 2, nt = 0;
-        if (v && v[0]) { u = v[0] - '0'; nt = v[1] == 't' ? 0 : 1; }
-        variant = (u == 1 ? 0 : u == 4 ? 2 : 1) * 2 + nt;
-    }
     const int grid = tab8_grid(n);
-#define GFA_TAB8(U, NTV)                                                                                                   \
-    do {                                                                                                                   \
-        static bool attr[2] = {false, false};                                                                              \
-        if (check_zero_b) {                                                                                                \
-            auto k = tab8_binary_kernel<U, true, NTV>;                                                                     \
-            if (!attr[1]) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr[1] = true; } \
-            hipLaunchKernelGGL(k, dim3(grid), dim3(TAB8_THREADS), 65536, st, table, (const uint8_t *)a, (const uint8_t *)b, \
-                               (uint8_t *)out, n, err);                                                                    \
-        } else {                                                                                                           \
-            auto k = tab8_binary_kernel<U, false, NTV>;                                                                    \
-            if (!attr[0]) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr[0] = true; } \
-            hipLaunchKernelGGL(k, dim3(grid), dim3(TAB8_THREADS), 65536, st, table, (const uint8_t *)a, (const uint8_t *)b, \
-                               (uint8_t *)out, n, err);                                                                    \
-        }                                                                                                                  \
-    } while (0)
-    switch (variant) {
-    case 0: GFA_TAB8(1, false); break;
-    case 1: GFA_TAB8(1, true); break;
-    case 2: GFA_TAB8(2, false); break;
-    case 3: GFA_TAB8(2, true); break;
-    case 4: GFA_TAB8(4, false); break;
-    default: GFA_TAB8(4, true); break;
+    static bool attr[2] = {false, false};
+    if (check_zero_b) {
+        auto k = tab8_binary_kernel<true>;
+        if (!attr[1]) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr[1] = true; }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(TAB8_THREADS), 65536, st, table, (const uint8_t *)a, (const uint8_t *)b,
+                           (uint8_t *)out, n, err);
+    } else {
+        auto k = tab8_binary_kernel<false>;
+        if (!attr[0]) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr[0] = true; }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(TAB8_THREADS), 65536, st, table, (const uint8_t *)a, (const uint8_t *)b,
+                           (uint8_t *)out, n, err);
     }
-#undef GFA_TAB8
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }
@@ -776,10 +732,10 @@ int launch_tab8_unary(const uint8_t *table256, bool check_zero, const void *a, v
     if (blocks < 1) blocks = 1;
     const int grid = (int)(blocks < cap ? blocks : cap);
     if (check_zero)
-        hipLaunchKernelGGL((tab8_unary_kernel<TAB8_UNROLL, true>), dim3(grid), dim3(TAB8_THREADS), 0, st, table256,
+        hipLaunchKernelGGL((tab8_unary_kernel<true>), dim3(grid), dim3(TAB8_THREADS), 0, st, table256,
                            (const uint8_t *)a, (uint8_t *)out, n, err);
     else
-        hipLaunchKernelGGL((tab8_unary_kernel<TAB8_UNROLL, false>), dim3(grid), dim3(TAB8_THREADS), 0, st, table256,
+        hipLaunchKernelGGL((tab8_unary_kernel<false>), dim3(grid), dim3(TAB8_THREADS), 0, st, table256,
                            (const uint8_t *)a, (uint8_t *)out, n, err);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
