@@ -158,6 +158,26 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extras:
         result["extra"] = extras(ga, L, lib, stream, world == 1 and not args.no_cpu_baseline)
+        if not args.no_cpu_baseline:
+            # the same port over every host core (ctypes releases the GIL): what an OpenMP'd reference loop could reach
+            from concurrent.futures import ThreadPoolExecutor
+
+            cores = os.cpu_count() or 1
+            cuts = np.linspace(0, n, cores + 1).astype(np.int64)
+            outs = np.empty(n, dtype=np.uint8)
+
+            def work(i):
+                outs[cuts[i]:cuts[i + 1]] = F.ufunc_u8(O.MUL, x_h[cuts[i]:cuts[i + 1]], y_h[cuts[i]:cuts[i + 1]])
+
+            with ThreadPoolExecutor(cores) as pool:
+                list(pool.map(work, range(cores)))
+                t1, reps = time.perf_counter(), 0
+                while time.perf_counter() - t1 < 5.0:
+                    list(pool.map(work, range(cores)))
+                    reps += 1
+                dt = time.perf_counter() - t1
+            result["extra"]["cpu_baseline_all_cores"] = {"value": round(n * reps / dt / 1e9, 3), "unit": "Gop/s", "cores": cores,
+                                                         "kind": "port", "sample": f"{reps} x 1e8 elements, one slice per thread"}
 
     if rank == 0:
         print(json.dumps(result), flush=True)
@@ -172,9 +192,39 @@ def extras(ga, L, lib, stream, with_cpu):
 
     ex = {}
     ms = ctypes.c_float()
-    # ---- reciprocal, 2 B/element ----
     GF = ga.GF(2**8)
     n = N_ELEMENTS
+    # ---- measured device-to-device copy (1 read + 1 write of 1e8 bytes): the practical HBM ceiling on this box ----
+    src = torch.empty(n, dtype=torch.uint8, device="cuda").random_(0, 256)
+    dst = torch.empty_like(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(5):
+        dst.copy_(src)
+    e0.record()
+    for _ in range(50):
+        dst.copy_(src)
+    e1.record()
+    e1.synchronize()
+    copy_gbs = 2.0 * n / (e0.elapsed_time(e1) / 50 * 1e-3) / 1e9
+    ex["device_copy"] = {"GB/s": round(copy_gbs, 1), "frac_of_peak": round(copy_gbs / HBM_PEAK_GBS, 4),
+                         "note": "torch Tensor.copy_ of 1e8 bytes; roofline fractions elsewhere are against the 8 TB/s spec peak"}
+    del src, dst
+    # ---- the headline op at the reference docs' dtype=int (int64 storage, 24 B/element), same field and kernel family ----
+    n64 = 25_000_000
+    a64 = torch.from_numpy(np.random.default_rng(1).integers(0, 256, n64, dtype=np.int64)).cuda()
+    b64 = torch.from_numpy(np.random.default_rng(2).integers(0, 256, n64, dtype=np.int64)).cuda()
+    o64 = torch.empty_like(a64)
+    L.check(lib.gfa_time_binary(GF._handle, L.OP_MUL, a64.data_ptr(), b64.data_ptr(), o64.data_ptr(), n64, L.U64, stream, 20,
+                                ctypes.byref(ms)))
+    F8 = O.OracleField(2, 8, 285, 2, lookup=True)
+    chk = slice(0, 100_000)
+    assert np.array_equal(o64[chk].cpu().numpy().astype(np.uint8),
+                          F8.ufunc_u8(O.MUL, a64[chk].cpu().numpy().astype(np.uint8), b64[chk].cpu().numpy().astype(np.uint8)))
+    gbs = 24.0 * n64 / (ms.value * 1e-3) / 1e9
+    ex["gf256_mul_int64"] = {"Gop/s": round(n64 / (ms.value * 1e-3) / 1e9, 2), "elements": n64, "kernel_ms": round(ms.value, 5),
+                             "algorithmic_GB/s": round(gbs, 1), "roofline_frac": round(gbs / HBM_PEAK_GBS, 4)}
+    del a64, b64, o64
+    # ---- reciprocal, 2 B/element ----
     a = torch.from_numpy(np.random.default_rng(2).integers(1, 256, n, dtype=np.uint8)).cuda()
     o = torch.empty_like(a)
     L.check(lib.gfa_time_unary(GF._handle, L.OP_RECIP, a.data_ptr(), o.data_ptr(), n, L.U8, stream, 50, ctypes.byref(ms)))
@@ -253,6 +303,20 @@ def extras(ga, L, lib, stream, with_cpu):
         "decode_roofline_frac": round(486.0 * B / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
         "note": "decode is LDS-gather bound, not HBM bound (SURVEY.md section 7)",
     }
+    # the two extremes benchmarks/test_fec.py uses: no errors, and t = 16 errors in every codeword
+    Rd.copy_(Cd)
+    L.check(lib.gfa_time_rs_decode(rs._handle, Rd.data_ptr(), 255, Dd.data_ptr(), Ed.data_ptr(), B, L.U8, stream, 5,
+                                   ctypes.byref(ms)))
+    ex["rs_255_223"]["decode_GB/s_no_errors"] = round(255.0 * B / (ms.value * 1e-3) / 1e9, 2)
+    R16 = C.copy()
+    cols = np.argsort(rng5.random((B, 255)), axis=1)[:, :16]
+    rows = np.arange(B)[:, None]
+    R16[rows, cols] ^= rng5.integers(1, 256, (B, 16), dtype=np.uint8)
+    Rd.copy_(torch.from_numpy(R16))
+    L.check(lib.gfa_time_rs_decode(rs._handle, Rd.data_ptr(), 255, Dd.data_ptr(), Ed.data_ptr(), B, L.U8, stream, 5,
+                                   ctypes.byref(ms)))
+    assert np.array_equal(Dd.cpu().numpy(), C) and bool((Ed == 16).all()), "RS t=16 round trip failed"
+    ex["rs_255_223"]["decode_GB/s_16_errors"] = round(255.0 * B / (ms.value * 1e-3) / 1e9, 2)
     if with_cpu:
         t1 = time.perf_counter()
         OR.encode_u8(M[:2048])
@@ -262,6 +326,36 @@ def extras(ga, L, lib, stream, with_cpu):
         td = time.perf_counter() - t1
         ex["rs_255_223"]["cpu_baseline"] = {"encode_GB/s": round(255.0 * 2048 / te / 1e9, 5), "decode_GB/s": round(255.0 * 2048 / td / 1e9, 5),
                                             "cores": 1, "kind": "port", "sample": "2048 codewords, oracle/gf_oracle.c"}
+    # ---- binary BCH(255, 223), t = 4: same entry points, symbols in GF(2), syndromes in GF(2^8) ----
+    bch = ga.BCH(255, 223)
+    Mb = rng.integers(0, 2, (B, 223), dtype=np.uint8)
+    Mbd = torch.from_numpy(Mb).cuda()
+    L.check(lib.gfa_time_rs_encode(bch._handle, Mbd.data_ptr(), 223, Cd.data_ptr(), B, L.U8, stream, 5, ctypes.byref(ms)))
+    benc_ms = ms.value
+    Cb = Cd.cpu().numpy()
+    Rb = Cb.copy()
+    neb = rng5.integers(0, 5, B)
+    colsb = np.argsort(rng5.random((B, 255)), axis=1)[:, :4]
+    flip = np.arange(4)[None, :] < neb[:, None]
+    Rb[np.repeat(np.arange(B)[:, None], 4, axis=1)[flip], colsb[flip]] ^= 1
+    Rd.copy_(torch.from_numpy(Rb))
+    L.check(lib.gfa_time_rs_decode(bch._handle, Rd.data_ptr(), 255, Dd.data_ptr(), Ed.data_ptr(), B, L.U8, stream, 5,
+                                   ctypes.byref(ms)))
+    assert np.array_equal(Dd.cpu().numpy(), Cb) and np.array_equal(Ed.cpu().numpy(), neb), "BCH round trip failed"
+    ex["bch_255_223"] = {"codewords": B, "errors_per_codeword": "uniform 0..4",
+                         "encode_GB/s": round(255.0 * B / (benc_ms * 1e-3) / 1e9, 2),
+                         "decode_GB/s": round(255.0 * B / (ms.value * 1e-3) / 1e9, 2),
+                         "encode_ms": round(benc_ms, 4), "decode_ms": round(ms.value, 4)}
+    if with_cpu:
+        FB = O.OracleField(2, 8, 285, 2, lookup=True)
+        OB = O.OracleBCH(FB, 255, 223)
+        assert np.array_equal(OB.encode(Mb[:64]), Cb[:64]), "BCH encode differs from the oracle"
+        t1 = time.perf_counter()
+        od, on = OB.decode(Rb[:2048])
+        td = time.perf_counter() - t1
+        assert np.array_equal(od, Cb[:2048]) and np.array_equal(on, neb[:2048])
+        ex["bch_255_223"]["cpu_baseline"] = {"decode_GB/s": round(255.0 * 2048 / td / 1e9, 5), "cores": 1, "kind": "port",
+                                             "sample": "2048 codewords, oracle/gf_oracle.c"}
     return ex
 
 

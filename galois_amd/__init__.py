@@ -12,7 +12,7 @@ _lib_module.lib()  # fail loudly if the HIP extension has not been built
 from ._array import FieldArray  # noqa: E402
 from ._factory import GF, Field  # noqa: E402
 from ._ntt import ntt, intt  # noqa: E402
-from ._codes import ReedSolomon  # noqa: E402
+from ._codes import BCH, ReedSolomon  # noqa: E402
 from ._numtheory import (  # noqa: E402
     is_prime, factors, primitive_root, is_primitive_root, matlab_primitive_poly, conway_poly, primitive_poly,
 )
@@ -21,7 +21,7 @@ from . import _dist as dist  # noqa: E402
 GF2 = GF(2)
 
 __all__ = [
-    "FieldArray", "GF", "GF2", "Field", "ntt", "intt", "ReedSolomon", "is_prime", "factors", "primitive_root",
+    "FieldArray", "GF", "GF2", "Field", "ntt", "intt", "ReedSolomon", "BCH", "is_prime", "factors", "primitive_root",
     "is_primitive_root", "matlab_primitive_poly", "conway_poly", "primitive_poly", "dist",
 ]
 __version__ = "0.1.0"

@@ -50,6 +50,7 @@ SIGNATURES = {
     "gfa_ntt": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_u64, c_int, c_int, c_void_p]),
     "gfa_ntt_columns": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_u64, c_int, c_void_p]),
     "gfa_rs_create": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_u64, c_int, ctypes.POINTER(c_void_p)]),
+    "gfa_bch_create": (c_int, [c_void_p, c_u64, c_i64, c_i64, c_i64, c_i64, c_u64, _u64p, c_int, ctypes.POINTER(c_void_p)]),
     "gfa_rs_destroy": (None, [c_void_p]),
     "gfa_rs_describe": (c_int, [c_void_p, _u64p, _u64p, _u64p]),
     "gfa_rs_encode": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_int, c_void_p]),

@@ -74,7 +74,9 @@ struct gfa_rs {
     int64_t n = 0, k = 0, c = 1;
     uint64_t alpha = 0;
     bool systematic = true;
-    std::vector<uint64_t> roots, gpoly, P; // P: k x (n-k) row-major
+    int64_t base_p = 0; // 0: symbols live in `field` (Reed-Solomon).  p: BCH code over the prime subfield GF(p); the roots,
+                        // syndromes and locators are in `field` = GF(p^m) while corrections use GF(p) subtraction
+    std::vector<uint64_t> roots, gpoly, P; // roots: d-1 entries; gpoly: n-k+1, highest degree first; P: k x (n-k) row-major
     struct Dev {
         bool ready = false;
         uint8_t *P8 = nullptr;     // k x (n-k)

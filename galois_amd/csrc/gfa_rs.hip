@@ -41,6 +41,7 @@ struct RsParams {
     int p;        // characteristic
     int qm1;      // q - 1
     int log_alpha; // LOG[alpha]
+    int base_p;    // 0 = Reed-Solomon; p = BCH over GF(p): corrections use SUBTRACT_BASE (_bch.py:1310, 1573)
 };
 
 template <bool BIN>
@@ -415,7 +416,15 @@ __global__ __launch_bounds__(1024) void rs_decode_kernel(RsTables t, RsParams rp
                             E = ar.mul(E, ar.pow_nz(x, rp.c - 1));
                             E = ar.neg(E);
                             const int pos = ws.errpos[kk];
-                            ws.recv[pos] = (uint8_t)ar.sub(ws.recv[pos], E);
+                            if (rp.base_p == 0 || BIN) {
+                                ws.recv[pos] = (uint8_t)ar.sub(ws.recv[pos], E);
+                            } else {
+                                // SUBTRACT_BASE: the prime subfield's modular subtract on the integer representations
+                                // (_calculate.py:235-251); E lies in GF(p) whenever the word was correctable, and for a
+                                // miscorrection the reference's integer result is reproduced, wrapped to the storage dtype
+                                const int a = ws.recv[pos], b = (int)E;
+                                ws.recv[pos] = (uint8_t)(a >= b ? a - b : rp.base_p + a - b);
+                            }
                         }
                         wave_sync();
                         status = 0;
@@ -973,7 +982,8 @@ int rs_check_device_path(const gfa_rs *code, int dtype, const char *what)
 RsParams make_params(const gfa_rs *code)
 {
     RsParams rp;
-    rp.n = (int)code->n; rp.k = (int)code->k; rp.nroots = (int)(code->n - code->k); rp.c = (int)code->c;
+    rp.n = (int)code->n; rp.k = (int)code->k; rp.nroots = (int)code->roots.size(); rp.c = (int)code->c;
+    rp.base_p = (int)code->base_p;
     rp.p = (int)code->field->calc.p; rp.qm1 = (int)(code->field->calc.q - 1);
     rp.log_alpha = (int)code->field->h_log[code->alpha];
     return rp;
@@ -1083,9 +1093,9 @@ int gfa_rs::ensure_device(int *device_out, Dev **out)
     Dev &st = dev[d];
     if (!st.ready) {
         const size_t nk = (size_t)(n - k);
-        std::vector<uint8_t> P8((size_t)k * nk), r8(nk);
+        std::vector<uint8_t> P8((size_t)k * nk), r8(roots.size());
         for (size_t i = 0; i < P8.size(); i++) P8[i] = (uint8_t)P[i];
-        for (size_t i = 0; i < nk; i++) r8[i] = (uint8_t)roots[i];
+        for (size_t i = 0; i < r8.size(); i++) r8[i] = (uint8_t)roots[i];
         GFA_HIP(hipMalloc((void **)&st.P8, std::max<size_t>(P8.size(), 16)));
         GFA_HIP(hipMalloc((void **)&st.roots8, std::max<size_t>(r8.size(), 16)));
         if (!P8.empty()) GFA_HIP(hipMemcpy(st.P8, P8.data(), P8.size(), hipMemcpyHostToDevice));
@@ -1120,6 +1130,28 @@ int gfa_rs::ensure_device(int *device_out, Dev **out)
 
 extern "C" {
 
+// systematic parity matrix from g(x): row i = -(x^(n-1-i) mod g(x)), built downward from row 0 by dividing by x
+// (same matrix as _poly_to_generator_matrix, _cyclic.py:198-226)
+static void build_parity_matrix(gfa_rs *code)
+{
+    const FieldDev &d = code->field->calc;
+    const int64_t n = code->n, k = code->k, nk = n - k;
+    code->P.assign((size_t)k * nk, 0);
+    if (nk <= 0) return;
+    u64 g0inv;
+    HostArith::inv(d, code->gpoly[nk], &g0inv);
+    for (int64_t j = 0; j < nk; j++) code->P[j] = HostArith::mul(d, code->gpoly[j], g0inv);
+    for (int64_t i = 1; i < k; i++) {
+        u64 *row = &code->P[(size_t)i * nk];
+        const u64 *prev = &code->P[(size_t)(i - 1) * nk];
+        const u64 last = prev[nk - 1];
+        row[0] = 0;
+        for (int64_t j = 1; j < nk; j++) row[j] = prev[j - 1];
+        if (last)
+            for (int64_t j = 0; j < nk; j++) row[j] = HostArith::sub(d, row[j], HostArith::mul(d, last, code->P[j]));
+    }
+}
+
 int gfa_rs_create(gfa_field_t *f, int64_t n, int64_t k, int64_t c, uint64_t alpha, int systematic, gfa_rs_t **out)
 {
     if (!f || !out || n < 1 || k < 1 || k > n || c < 0) { set_error("gfa_rs_create: bad arguments"); return GFA_ERR_INVALID; }
@@ -1145,23 +1177,41 @@ int gfa_rs_create(gfa_field_t *f, int64_t n, int64_t k, int64_t c, uint64_t alph
         g.swap(ng);
     }
     code->gpoly.assign(g.rbegin(), g.rend()); // highest degree first
-    // systematic parity matrix: row i = -(x^(n-1-i) mod g(x)), built downward from row 0 by dividing by x
-    // (same matrix as _poly_to_generator_matrix, _cyclic.py:198-226)
-    code->P.assign((size_t)k * nk, 0);
-    if (nk > 0) {
-        u64 g0inv;
-        HostArith::inv(d, code->gpoly[nk], &g0inv);
-        for (int64_t j = 0; j < nk; j++) code->P[j] = HostArith::mul(d, code->gpoly[j], g0inv);
-        for (int64_t i = 1; i < k; i++) {
-            u64 *row = &code->P[(size_t)i * nk];
-            const u64 *prev = &code->P[(size_t)(i - 1) * nk];
-            const u64 last = prev[nk - 1];
-            row[0] = 0;
-            for (int64_t j = 1; j < nk; j++) row[j] = prev[j - 1];
-            if (last)
-                for (int64_t j = 0; j < nk; j++) row[j] = HostArith::sub(d, row[j], HostArith::mul(d, last, code->P[j]));
-        }
+    build_parity_matrix(code);
+    *out = code;
+    return GFA_OK;
+}
+
+int gfa_bch_create(gfa_field_t *ext, uint64_t base_p, int64_t n, int64_t k, int64_t d_design, int64_t c, uint64_t alpha,
+                   const uint64_t *generator_poly, int systematic, gfa_rs_t **out)
+{
+    if (!ext || !out || !generator_poly || n < 1 || k < 1 || k > n || c < 0 || d_design < 1) {
+        set_error("gfa_bch_create: bad arguments");
+        return GFA_ERR_INVALID;
     }
+    const FieldDev &d = ext->calc;
+    if (base_p != d.p) { set_error("gfa_bch_create: the symbol field must be the prime subfield of the extension field"); return GFA_ERR_INVALID; }
+    if ((u64)n >= d.q || (d.q - 1) % (u64)n != 0) { set_error("gfa_bch_create: n must divide q^m - 1"); return GFA_ERR_INVALID; }
+    if (alpha == 0 || alpha >= d.q) { set_error("gfa_bch_create: alpha out of range"); return GFA_ERR_INVALID; }
+    const int64_t nk = n - k;
+    if (generator_poly[0] != 1) { set_error("gfa_bch_create: the generator polynomial must be monic of degree n - k"); return GFA_ERR_INVALID; }
+    for (int64_t i = 0; i <= nk; i++)
+        if (generator_poly[i] >= base_p) { set_error("gfa_bch_create: generator polynomial coefficient outside GF(p)"); return GFA_ERR_INVALID; }
+    gfa_rs *code = new gfa_rs();
+    code->field = ext; code->n = n; code->k = k; code->c = c; code->alpha = alpha; code->systematic = systematic != 0;
+    code->base_p = (int64_t)base_p;
+    // roots alpha^c .. alpha^(c+d-2) (_bch.py:1178-1197); every one must be a root of g(x)
+    code->roots.resize(d_design - 1);
+    for (int64_t i = 0; i < d_design - 1; i++) {
+        u64 r;
+        HostArith::pow(d, alpha, (i64)(c + i), &r);
+        code->roots[i] = r;
+        u64 acc = 0;
+        for (int64_t j = 0; j <= nk; j++) acc = HostArith::add(d, HostArith::mul(d, acc, r), generator_poly[j]);
+        if (acc != 0) { delete code; set_error("gfa_bch_create: alpha^(c+i) is not a root of the generator polynomial"); return GFA_ERR_INVALID; }
+    }
+    code->gpoly.assign(generator_poly, generator_poly + nk + 1);
+    build_parity_matrix(code);
     *out = code;
     return GFA_OK;
 }
@@ -1177,7 +1227,7 @@ void gfa_rs_destroy(gfa_rs_t *code)
 int gfa_rs_describe(const gfa_rs_t *code, uint64_t *roots, uint64_t *generator_poly, uint64_t *parity_matrix)
 {
     if (!code) return GFA_ERR_INVALID;
-    if (roots) std::copy(code->roots.begin(), code->roots.end(), roots);
+    if (roots) std::copy(code->roots.begin(), code->roots.end(), roots); // d - 1 entries
     if (generator_poly) std::copy(code->gpoly.begin(), code->gpoly.end(), generator_poly);
     if (parity_matrix) std::copy(code->P.begin(), code->P.end(), parity_matrix);
     return GFA_OK;
@@ -1314,7 +1364,7 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
         GFA_HIP(hipMemsetAsync(out_n_errors, 0, sizeof(int64_t) * (size_t)batch, (hipStream_t)stream));
         return GFA_OK;
     }
-    if (lfsr_eligible(code) && code->n - code->k <= 60) {
+    if (lfsr_eligible(code) && code->n - code->k <= 60 && code->base_p == 0) {
         FieldDeviceState *ds;
         gfa_rs::Dev *cd;
         if ((rc = code->field->ensure_device(nullptr, &ds))) return rc;

@@ -135,8 +135,17 @@ int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64
  * gfa_rs_create replaces the arithmetic part of ReedSolomon.__init__ (_codes/_reed_solomon.py:111-218) and
  * _poly_to_generator_matrix (_codes/_cyclic.py:198-226): roots alpha^(c..c+d-2), g(x), systematic parity matrix. */
 int gfa_rs_create(gfa_field_t *f, int64_t n, int64_t k, int64_t c, uint64_t alpha, int systematic, gfa_rs_t **out);
+/* BCH(n, k) code over the prime field GF(p) with syndrome arithmetic in `ext` = GF(p^m): replaces the arithmetic part of
+ * BCH.__init__ after the generator polynomial is known (_codes/_bch.py:106-240) -- roots alpha^c .. alpha^(c+d-2) in
+ * GF(p^m), systematic parity matrix of g(x) (_codes/_cyclic.py:198-226).  `generator_poly`: n-k+1 coefficients in
+ * GF(p), highest degree first, monic (the host computes it as the product of the distinct minimal polynomials of the
+ * roots, _bch.py:1178-1197); every alpha^(c+i) is verified to be one of its roots.  The handle is used with the same
+ * gfa_rs_encode / gfa_rs_detect / gfa_rs_decode / gfa_rs_extract_message entry points; decoding is the reference's
+ * bch_decode_jit with SUBTRACT_BASE = GF(p) subtraction (_bch.py:1310, 1573). */
+int gfa_bch_create(gfa_field_t *ext, uint64_t base_p, int64_t n, int64_t k, int64_t d, int64_t c, uint64_t alpha,
+                   const uint64_t *generator_poly, int systematic, gfa_rs_t **out);
 void gfa_rs_destroy(gfa_rs_t *code);
-/* Host copies: roots (n-k), generator polynomial (n-k+1, highest degree first), parity matrix P (k x (n-k)). */
+/* Host copies: roots (d-1; = n-k for Reed-Solomon), generator polynomial (n-k+1, highest degree first), parity matrix P (k x (n-k)). */
 int gfa_rs_describe(const gfa_rs_t *code, uint64_t *roots, uint64_t *generator_poly, uint64_t *parity_matrix);
 /* _LinearCode._encode_message -> matmul_jit (_codes/_linear.py:270-284, _domains/_linalg.py:286-308).
  * msg: (batch, ks) row-major, ks <= k (shortened codes pass fewer symbols).  out: (batch, ks + n - k) codewords, or

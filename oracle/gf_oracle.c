@@ -618,8 +618,8 @@ void gfo_berlekamp_massey(const gfo_field *f, const u64 *S, i64 n, u64 *C, i64 *
  * (reed_solomon_decode_jit, _codes/_reed_solomon.py:1105-1113).
  * codewords: (N, n) row-major, index 0 = highest degree.  erasures: (N, n) bytes (0/1) or NULL.
  * dec_codewords: (N, n) out.  n_errors: (N) out. */
-int gfo_rs_decode(const gfo_field *f, const u64 *codewords, const uint8_t *erasures, i64 N, i64 n, i64 design_n,
-                  u64 alpha, i64 c, const u64 *roots, i64 n_roots, u64 *dec_codewords, i64 *n_errors)
+static int decode_impl(const gfo_field *f, u64 base_p, const u64 *codewords, const uint8_t *erasures, i64 N, i64 n,
+                       i64 design_n, u64 alpha, i64 c, const u64 *roots, i64 n_roots, u64 *dec_codewords, i64 *n_errors)
 {
     i64 d = n_roots + 1;
     if (n > 512 || d > 256) return GFO_BAD_ARG;
@@ -729,12 +729,34 @@ int gfo_rs_decode(const gfo_field *f, const u64 *codewords, const uint8_t *erasu
         memcpy(codeword, received, sizeof(u64) * (size_t)n);
         for (i64 k = 0; k < v_total; k++) {
             i64 pos = error_positions[k];
-            codeword[pos] = f_sub(f, codeword[pos], error_values[k]);
+            if (base_p == 0) {
+                codeword[pos] = f_sub(f, codeword[pos], error_values[k]);
+            } else if (base_p == 2) {
+                codeword[pos] ^= error_values[k]; /* GF(2) subtract = np.bitwise_xor (_fields/_gf2.py) */
+            } else {
+                /* SUBTRACT_BASE = subtract_modular of the prime base field on int64 (_calculate.py:235-251) */
+                i64 a = (i64)codeword[pos], b = (i64)error_values[k];
+                codeword[pos] = (u64)(a >= b ? a - b : (i64)base_p + a - b);
+            }
         }
         for (i64 i = 0; i < n; i++) dec_codewords[ni * n + i] = codeword[n - 1 - i];
         n_errors[ni] = v;
     }
     return GFO_OK;
+}
+
+int gfo_rs_decode(const gfo_field *f, const u64 *codewords, const uint8_t *erasures, i64 N, i64 n, i64 design_n,
+                  u64 alpha, i64 c, const u64 *roots, i64 n_roots, u64 *dec_codewords, i64 *n_errors)
+{
+    return decode_impl(f, 0, codewords, erasures, N, n, design_n, alpha, c, roots, n_roots, dec_codewords, n_errors);
+}
+
+/* bch_decode_jit with base field GF(p) != extension field `f` = GF(p^m) (_codes/_bch.py:1255-1578): identical steps,
+ * corrections through SUBTRACT_BASE (:1310, :1573). */
+int gfo_bch_decode(const gfo_field *f, u64 base_p, const u64 *codewords, const uint8_t *erasures, i64 N, i64 n,
+                   i64 design_n, u64 alpha, i64 c, const u64 *roots, i64 n_roots, u64 *dec_codewords, i64 *n_errors)
+{
+    return decode_impl(f, base_p, codewords, erasures, N, n, design_n, alpha, c, roots, n_roots, dec_codewords, n_errors);
 }
 
 /* Poly.Roots + _poly_to_generator_matrix (systematic) _codes/_cyclic.py:198-226 and

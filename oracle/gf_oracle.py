@@ -60,6 +60,8 @@ def lib():
         L.gfo_berlekamp_massey.restype = None
         L.gfo_rs_decode.argtypes = [ctypes.c_void_p, _u64p, _u8p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                     ctypes.c_uint64, ctypes.c_int64, _u64p, ctypes.c_int64, _u64p, _i64p]
+        L.gfo_bch_decode.argtypes = [ctypes.c_void_p, ctypes.c_uint64, _u64p, _u8p, ctypes.c_int64, ctypes.c_int64,
+                                     ctypes.c_int64, ctypes.c_uint64, ctypes.c_int64, _u64p, ctypes.c_int64, _u64p, _i64p]
         L.gfo_rs_construct.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_uint64, ctypes.c_int64,
                                        _u64p, _u64p, _u64p]
         L.gfo_rs_construct.restype = None
@@ -329,3 +331,206 @@ class OracleRS:
         if rc:
             raise ValueError(f"oracle decode error {rc}")
         return dec, nerr
+
+
+# ---- polynomials over the prime field GF(p), coefficients highest degree first, plain Python ints ----------------
+def _pp_trim(a):
+    a = list(a)
+    while len(a) > 1 and a[0] == 0:
+        a.pop(0)
+    return a
+
+
+def _pp_mul(a, b, p):
+    out = [0] * (len(a) + len(b) - 1)
+    for i, x in enumerate(a):
+        for j, y in enumerate(b):
+            out[i + j] = (out[i + j] + x * y) % p
+    return _pp_trim(out)
+
+
+def _pp_divmod(a, b, p):
+    a, b = _pp_trim(a), _pp_trim(b)
+    if len(a) < len(b):
+        return [0], a
+    inv = pow(b[0], -1, p)
+    a = list(a)
+    q = []
+    for i in range(len(a) - len(b) + 1):
+        c = a[i] * inv % p
+        q.append(c)
+        for j, y in enumerate(b):
+            a[i + j] = (a[i + j] - c * y) % p
+    return _pp_trim(q), _pp_trim(a[len(a) - len(b) + 1:] or [0])
+
+
+class OracleBCH:
+    """BCH(n, k) over the prime field GF(p) with syndromes in `ext` = GF(p^m)  (BCH.__init__ _codes/_bch.py:106-240,
+    _generator_poly_from_d / _from_k :1178-1252, _CyclicCode.__init__ _codes/_cyclic.py:26-54)."""
+
+    def __init__(self, ext: OracleField, n: int, k: int | None = None, d: int | None = None, alpha: int | None = None,
+                 c: int = 1, systematic: bool = True):
+        self.ext, self.p, self.n, self.c, self.systematic = ext, ext.p, n, c, systematic
+        self.alpha = ext.root_of_unity(n) if alpha is None else int(alpha)
+        if d is not None:
+            g, roots = self._gen_from_d(d)
+            kk = n - (len(g) - 1)
+            if k not in (None, kk):
+                raise ValueError(f"The requested [{n}, {k}, {d}] code is not consistent.")
+            k = kk
+        else:
+            g, roots = self._gen_from_k(k)
+            d = len(roots) + 1
+        self.k, self.d = k, d
+        self.generator_poly = g
+        self.roots = np.array(roots, dtype=np.uint64)
+        xn1 = [1] + [0] * (n - 1) + [self.p - 1]
+        h, rem = _pp_divmod(xn1, g, self.p)
+        assert rem == [0]
+        self.parity_check_poly = h
+        self.G = self._poly_to_generator_matrix(g, systematic)
+        self.H = self._poly_to_generator_matrix(h[::-1], False)
+        self._base = OracleField(self.p, 1, None, _smallest_primitive_root(self.p))
+
+    # minimal polynomial over GF(p) of an element of GF(p^m): product over its distinct Frobenius conjugates
+    # (FieldArray.minimal_poly, _fields/_array.py:1979-2050)
+    def _minimal_poly(self, beta: int):
+        E = self.ext
+        conj, x = [], int(beta)
+        while x not in conj:
+            conj.append(x)
+            x = int(E.pow(np.array([x], dtype=np.uint64), np.array([self.p]))[0])
+        poly = [1]
+        for r in conj:  # poly *= (x - r) in GF(p^m)
+            nr = int(E.ufunc(SUB, np.array([0], dtype=np.uint64), np.array([r], dtype=np.uint64))[0])
+            nxt = poly + [0]
+            for i, cfe in enumerate(poly):
+                t = int(E.mul(np.array([cfe], dtype=np.uint64), np.array([nr], dtype=np.uint64))[0])
+                nxt[i + 1] = int(E.ufunc(ADD, np.array([nxt[i + 1]], dtype=np.uint64), np.array([t], dtype=np.uint64))[0])
+            poly = nxt
+        assert all(cf < self.p for cf in poly)
+        return poly
+
+    def _gen_from_d(self, d: int):
+        E = self.ext
+        roots = [int(E.pow(np.array([self.alpha], dtype=np.uint64), np.array([self.c + i]))[0]) for i in range(d - 1)]
+        g, seen = [1], []
+        for r in roots:
+            mi = self._minimal_poly(r)
+            if mi not in seen:
+                g = _pp_mul(g, mi, self.p)
+                seen.append(mi)
+        return g, roots
+
+    def _gen_from_k(self, k: int):
+        n, m = self.n, self.ext.m
+        possible_d = list(range((n - k) // m + 1, (n - k) + 2))
+        found = False
+        while possible_d:
+            idx = len(possible_d) // 2
+            d = possible_d[idx]
+            g, roots = self._gen_from_d(d)
+            if len(g) - 1 < n - k:
+                possible_d = possible_d[idx + 1:]
+            elif len(g) - 1 == n - k:
+                found = True
+                break
+            else:
+                possible_d = possible_d[:idx]
+        if not found:
+            raise ValueError(f"The BCH({n}, {k}) code does not exist.")
+        best = (g, roots)
+        while True:
+            d += 1
+            g, roots = self._gen_from_d(d)
+            if len(g) - 1 == n - k:
+                best = (g, roots)
+            elif len(g) - 1 > n - k:
+                break
+        return best
+
+    def _poly_to_generator_matrix(self, g, systematic: bool):
+        """_codes/_cyclic.py:198-226 over GF(p)."""
+        p, n = self.p, self.n
+        deg = len(g) - 1
+        k = n - deg
+        if systematic:
+            P = np.zeros((k, n - k), dtype=np.int64)
+            if n - k > 0:
+                inv = pow(g[-1], -1, p)
+                P[0, :] = [(cf * inv) % p for cf in g[:-1]]
+                for i in range(1, k):
+                    P[i, 0] = 0
+                    P[i, 1:] = P[i - 1, :-1]
+                    if P[i - 1, -1] > 0:
+                        P[i, :] = (P[i, :] - P[i - 1, -1] * P[0, :]) % p
+            return np.hstack([np.eye(k, dtype=np.int64), P]).astype(np.uint64)
+        G = np.zeros((k, n), dtype=np.int64)
+        for i in range(k):
+            G[i, i:i + deg + 1] = g
+        return G.astype(np.uint64)
+
+    def encode(self, message):
+        """_LinearCode._encode_message _codes/_linear.py:270-284."""
+        m = np.atleast_2d(_as_u64(message))
+        pad = self.k - m.shape[1]
+        if self.systematic:
+            parity = self._base.matmul(m, np.ascontiguousarray(self.G[pad:, self.k:])) if self.n > self.k else m[:, :0]
+            return np.hstack([m, parity])
+        return self._base.matmul(m, np.ascontiguousarray(self.G[pad:, pad:]))
+
+    def detect(self, codeword):
+        cw = np.atleast_2d(_as_u64(codeword))
+        ns = cw.shape[1]
+        if self.n == self.k:
+            return np.zeros(cw.shape[0], dtype=bool)
+        syn = self._base.matmul(cw, np.ascontiguousarray(self.H[:, self.n - ns:].T))
+        return ~np.all(syn == 0, axis=1)
+
+    def decode(self, codeword, erasures=None):
+        """bch_decode_jit (_codes/_bch.py:1337-1578).  Returns (dec_codeword (N, ns) int64, n_errors (N,) int64)."""
+        cw = np.ascontiguousarray(np.atleast_2d(_as_u64(codeword)))
+        N, ns = cw.shape
+        er = None
+        if erasures is not None:
+            er = np.ascontiguousarray(np.atleast_2d(np.asarray(erasures)).astype(np.uint8))
+        dec = np.empty_like(cw)
+        nerr = np.empty(N, dtype=np.int64)
+        roots = np.ascontiguousarray(self.roots) if self.roots.size else np.zeros(1, dtype=np.uint64)
+        rc = lib().gfo_bch_decode(self.ext._h, self.p, _p(cw, _u64p), _p(er, _u8p) if er is not None else None, N, ns, self.n,
+                                  self.alpha, self.c, _p(roots, _u64p), self.roots.size, _p(dec, _u64p), _p(nerr, _i64p))
+        if rc:
+            raise ValueError(f"oracle decode error {rc}")
+        return dec.view(np.int64), nerr
+
+    def message_of(self, dec_codeword):
+        """_CyclicCode._convert_codeword_to_message (_codes/_cyclic.py:129-138)."""
+        cw = np.atleast_2d(np.asarray(dec_codeword))
+        ns = cw.shape[1]
+        ks = self.k - (self.n - ns)
+        if self.systematic:
+            return cw[:, :ks]
+        out = np.zeros((cw.shape[0], ks), dtype=np.int64)
+        for i, row in enumerate(cw):
+            q, _ = _pp_divmod([int(v) for v in row], self.generator_poly, self.p)
+            q = [0] * (ks - len(q)) + q
+            out[i] = q
+        return out
+
+
+def _smallest_primitive_root(p: int) -> int:
+    if p == 2:
+        return 1
+    phi, fac, x, f = p - 1, [], p - 1, 2
+    while f * f <= x:
+        if x % f == 0:
+            fac.append(f)
+            while x % f == 0:
+                x //= f
+        f += 1
+    if x > 1:
+        fac.append(x)
+    for g in range(2, p):
+        if all(pow(g, phi // q, p) != 1 for q in fac):
+            return g
+    raise ValueError(p)

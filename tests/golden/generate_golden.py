@@ -208,8 +208,123 @@ def reference_outputs():
     np.savez_compressed(os.path.join(HERE, "reference_outputs.npz"), **out)
 
 
+def pack_sage_bch():
+    """tests/codes/data/bch/*.pkl (204 Sage fixtures; loader tests/codes/conftest.py:47-63)."""
+    out = {}
+    names = []
+    for f in sorted(glob.glob(os.path.join(REF_TESTS, "codes", "data", "bch", "*.pkl"))):
+        d = pickle.load(open(f, "rb"))
+        key = os.path.basename(f)[:-4]
+        names.append(key)
+        meta = {k: d[k] for k in ("q", "m", "n", "k", "d", "d_min", "alpha", "c", "is_systematic", "is_primitive",
+                                  "is_narrow_sense", "generator_poly", "parity_check_poly")}
+        out[f"{key}/meta"] = np.array(json.dumps(meta))
+        out[f"{key}/G"] = small(d["G"])
+        out[f"{key}/H"] = small(d["H"])
+        out[f"{key}/messages"] = small(d["encode"]["messages"])
+        out[f"{key}/codewords"] = small(d["encode"]["codewords"])
+        if d["encode_shortened"]:
+            out[f"{key}/short_messages"] = small(d["encode_shortened"]["messages"])
+            out[f"{key}/short_codewords"] = small(d["encode_shortened"]["codewords"])
+    out["names"] = np.array(json.dumps(names))
+    np.savez_compressed(os.path.join(HERE, "sage_bch.npz"), **out)
+    print("packed", len(names), "BCH fixtures")
+
+
+def reference_bch_outputs():
+    """BCH encode / detect / decode outputs of the reference itself (incl. erasures, > t errors and miscorrections)."""
+    import load_reference
+
+    galois = load_reference.load()
+    rng = np.random.default_rng(20260926)
+    out = {}
+
+    def case(tag, n, k=None, d=None, p=2, c=1, systematic=True, N=14, shorten=0, ext_kw=None):
+        GFp = load_reference.ref_field(p)
+        # the default extension field (_bch.py:207-211), built explicitly so that it is in python-calculate mode (the
+        # numba stand-in cannot freeze per-field globals for "jit" Function objects)
+        m = galois.ilog(n, p) + 1
+        ext = load_reference.ref_field(p**m, irreducible_poly=galois.matlab_primitive_poly(p, m))
+        bch = galois.BCH(n, k, d, field=GFp, extension_field=ext, c=c, systematic=systematic)
+        k, dd = bch.k, bch.d
+        ks, ns = k - shorten, n - shorten
+        t = (dd - 1) // 2
+        M = rng.integers(0, p, (N, ks))
+        C = np.asarray(bch.encode(GFp(M))).astype(np.int64)
+        R = C.copy()
+        E = np.zeros((N, ns), dtype=bool)
+        plan = [(0, 0), (t, 0), (t + 1, 0), (t // 2, 0), (1, 0), (t + 2, 0), (0, 2), (max(t - 1, 0), 2), (0, dd - 1), (0, dd),
+                (t // 2, (dd - 1) - 2 * (t // 2)), (1, dd - 1), (t + 3, 0), (2 * t + 1, 0)]
+        for i in range(N):
+            ne, nu = plan[i % len(plan)]
+            ne, nu = min(ne, ns), min(nu, ns)
+            pos = rng.choice(ns, ne, replace=False)
+            R[i, pos] = (R[i, pos] + rng.integers(1, p, ne)) % p
+            if nu:
+                rest = np.setdiff1d(np.arange(ns), pos)
+                epos = rng.choice(rest, min(nu, rest.size), replace=False)
+                E[i, epos] = True
+                R[i, epos] = rng.integers(0, p, epos.size)
+        # row by row: a miscorrection whose error values fall outside GF(p) makes the reference raise ValueError when it
+        # views the decoded int64 array as the base field (_bch.py:1300 -> _fields/_array.py:177); recorded in `raises`
+        dec = np.zeros((N, ns), dtype=np.int64)
+        msg = np.zeros((N, ks), dtype=np.int64)
+        nerr = np.zeros(N, dtype=np.int64)
+        raises = np.zeros(N, dtype=bool)
+        for i in range(N):
+            try:
+                d_i, n_i = bch.decode(GFp(R[i]), erasures=E[i], output="codeword", errors=True)
+                dec[i], nerr[i] = np.asarray(d_i), n_i
+                msg[i] = np.asarray(bch.decode(GFp(R[i]), erasures=E[i], output="message"))
+            except (ValueError, OverflowError):
+                # OverflowError: in python-calculate mode the decoder works on the uint8 array directly and NumPy 2
+                # refuses the negative SUBTRACT_BASE result; the jit path computes it in int64, wraps on astype and
+                # then fails the same field-membership check (ValueError).  Either way: an exception.
+                raises[i] = True
+        ext = bch.extension_field
+        out[f"bch/{tag}/meta"] = np.array(json.dumps({
+            "p": p, "n": n, "k": int(k), "d": int(dd), "c": c, "alpha": int(bch.alpha), "systematic": systematic,
+            "ext_order": int(ext.order), "ext_m": int(ext.degree), "ext_irr": int(ext.irreducible_poly),
+            "ext_alpha": int(ext.primitive_element), "shorten": shorten}))
+        out[f"bch/{tag}/generator_poly"] = small(bch.generator_poly.coeffs)
+        out[f"bch/{tag}/roots"] = small(bch.roots)
+        out[f"bch/{tag}/messages"] = small(M)
+        out[f"bch/{tag}/codewords"] = small(C)
+        out[f"bch/{tag}/received"] = small(R)
+        out[f"bch/{tag}/erasures"] = E
+        out[f"bch/{tag}/decoded"] = np.asarray(dec).astype(np.int64)
+        out[f"bch/{tag}/decoded_message"] = np.asarray(msg).astype(np.int64)
+        out[f"bch/{tag}/n_errors"] = np.asarray(nerr, dtype=np.int64)
+        out[f"bch/{tag}/raises"] = raises
+        out[f"bch/{tag}/detected"] = np.asarray(bch.detect(GFp(R)))
+        print("bch", tag, (n, int(k), int(dd)), list(nerr), "raises", list(np.nonzero(raises)[0]))
+
+    case("bch15_7", 15, 7)
+    case("bch15_5_c3", 15, d=7, c=3)
+    case("bch31_16", 31, 16)
+    case("bch63_45", 63, 45)
+    case("bch63_36_short", 63, 36, shorten=20)
+    case("bch255_223", 255, 223, N=8)
+    case("bch127_99_nonsys", 127, 99, systematic=False, N=8)
+    case("bch13_4_gf3", 13, 4, p=3)
+    case("bch26_14_gf3", 26, 14, p=3)
+    case("bch26_8_gf3_c3", 26, d=9, p=3, c=3)
+    case("bch80_60_gf3", 80, d=9, p=3, N=10)
+    case("bch24_gf5", 24, d=5, p=5)
+    case("bch26_14_gf3_nonsys_short", 26, 14, p=3, systematic=False, shorten=5)
+    np.savez_compressed(os.path.join(HERE, "reference_bch_outputs.npz"), **out)
+
+
 if __name__ == "__main__":
-    pack_sage_fields()
-    pack_sage_rs()
-    reference_outputs()
+    what = sys.argv[1:] or ["fields", "rs", "reference", "bch", "reference_bch"]
+    if "fields" in what:
+        pack_sage_fields()
+    if "rs" in what:
+        pack_sage_rs()
+    if "reference" in what:
+        reference_outputs()
+    if "bch" in what:
+        pack_sage_bch()
+    if "reference_bch" in what:
+        reference_bch_outputs()
     print("done")

@@ -52,3 +52,31 @@ def assert_equal_ints(actual, expected, msg=""):
         assert as_int_list(a) == as_int_list(e), msg
     else:
         assert np.array_equal(a, e), msg
+
+
+def sage_bch():
+    d = np.load(os.path.join(GOLDEN, "sage_bch.npz"))
+    names = json.loads(str(d["names"]))
+    return names, d
+
+
+def reference_bch_outputs():
+    return np.load(os.path.join(GOLDEN, "reference_bch_outputs.npz"))
+
+
+def parse_sage_poly(text, p):
+    """'x^18 + 2*x^14 + x + 2' -> coefficients, highest degree first (Sage's str() of a polynomial over GF(p))."""
+    terms = {}
+    for term in text.replace(" ", "").replace("-", "+-").split("+"):
+        if not term:
+            continue
+        if "x" in term:
+            coef, _, rest = term.partition("x")
+            coef = coef.rstrip("*")
+            c = 1 if coef == "" else (-1 if coef == "-" else int(coef))
+            deg = int(rest[1:]) if rest.startswith("^") else 1
+        else:
+            c, deg = int(term), 0
+        terms[deg] = (terms.get(deg, 0) + c) % p
+    n = max(terms)
+    return [terms.get(i, 0) for i in range(n, -1, -1)]

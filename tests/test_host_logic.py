@@ -197,3 +197,42 @@ def test_shard_range_partitions():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- BCH construction (host logic; the library call gfa_bch_create is host-only) ----------------------------------
+def test_bch_properties_against_sage_fixtures():
+    """tests/codes/test_bch.py:61-95 over the 204 Sage fixtures: k, d, g(x), h(x), G, H, flags."""
+    import json
+
+    from tests import helpers as H
+
+    names, d = H.sage_bch()
+    for key in names:
+        meta = json.loads(str(d[f"{key}/meta"]))
+        b = ga.BCH(meta["n"], meta["k"], d=meta["d"], field=ga.GF(meta["q"]), alpha=meta["alpha"], c=meta["c"],
+                   systematic=meta["is_systematic"])
+        assert (b.n, b.k, b.d, b.t) == (meta["n"], meta["k"], meta["d"], (meta["d"] - 1) // 2)
+        assert [int(v) for v in b.generator_poly.coeffs] == H.parse_sage_poly(meta["generator_poly"], meta["q"]), key
+        assert [int(v) for v in b.parity_check_poly.coeffs] == H.parse_sage_poly(meta["parity_check_poly"], meta["q"]), key
+        assert np.array_equal(b.G, d[f"{key}/G"]) and np.array_equal(b.H, d[f"{key}/H"]), key
+        assert (b.is_primitive, b.is_narrow_sense, b.is_systematic) == (meta["is_primitive"], meta["is_narrow_sense"],
+                                                                         meta["is_systematic"])
+        assert b.extension_field.order == meta["q"] ** meta["m"]
+
+
+def test_bch_valid_binary_codes():
+    """(n, k, t) rows of the classical table of primitive binary BCH codes (tests/codes/test_bch.py:172-226 checks the
+    same table from Lin & Costello): a sample per length, through the k-only constructor (binary search for d)."""
+    for n, k, t in [(7, 4, 1), (15, 11, 1), (15, 7, 2), (15, 5, 3), (31, 26, 1), (31, 21, 2), (31, 16, 3), (31, 11, 5),
+                    (31, 6, 7), (63, 57, 1), (63, 45, 3), (63, 36, 5), (63, 30, 6), (63, 18, 10), (63, 7, 15),
+                    (127, 120, 1), (127, 99, 4), (127, 64, 10), (255, 247, 1), (255, 223, 4), (255, 131, 18)]:
+        b = ga.BCH(n, k)
+        assert (b.n, b.k, b.t) == (n, k, t)
+    assert repr(ga.BCH(15, 7)) == "<BCH Code: [15, 7, 5] over GF(2)>"
+    assert repr(ga.BCH(26, 14, field=ga.GF(3))) == "<BCH Code: [26, 14, 7] over GF(3)>"
+    with pytest.raises(ValueError):
+        ga.BCH(15, 8)
+    with pytest.raises(ValueError):
+        ga.BCH(15, 7, field=ga.GF(4))
+    big = ga.BCH(511, d=11)  # syndrome field GF(2^9): properties only, no device path
+    assert (big.k, big.extension_field.order) == (466, 512)

@@ -131,3 +131,66 @@ def test_reference_reed_solomon_outputs():
     R = O.OracleRS(F, 255, 223)
     H.assert_equal_ints(R.encode(np.arange(223))[223:], d["rs/kat_arange_parity"], "arange parity KAT")
     H.assert_equal_ints(R.encode_u8(np.arange(223, dtype=np.uint8))[0, 223:], d["rs/kat_arange_parity"])
+
+
+# ---- BCH codes: same decoder kernel, base field != extension field -----------------
+_MATLAB_EXT = {(2, 4): 19, (3, 3): 34}  # matlab_primitive_poly(q, m) as integers: x^4+x+1, x^3+2x+1
+
+
+def test_sage_bch_fixtures():
+    """All 204 Sage fixtures of tests/codes/data/bch: k, d, g(x), h(x), G, H, encode and shortened encode."""
+    names, d = H.sage_bch()
+    assert len(names) == 204
+    fields = {}
+    for key in names:
+        meta = json.loads(str(d[f"{key}/meta"]))
+        p, m = meta["q"], meta["m"]
+        if (p, m) not in fields:
+            fields[(p, m)] = O.OracleField(p, m, _MATLAB_EXT[(p, m)], p, lookup=True)
+        B = O.OracleBCH(fields[(p, m)], meta["n"], meta["k"], d=meta["d"], alpha=meta["alpha"], c=meta["c"],
+                        systematic=meta["is_systematic"])
+        assert (B.k, B.d) == (meta["k"], meta["d"]), key
+        assert B.generator_poly == H.parse_sage_poly(meta["generator_poly"], p), key + " g(x)"
+        assert B.parity_check_poly == H.parse_sage_poly(meta["parity_check_poly"], p), key + " h(x)"
+        H.assert_equal_ints(B.G, d[f"{key}/G"], key + " G")
+        H.assert_equal_ints(B.H, d[f"{key}/H"], key + " H")
+        H.assert_equal_ints(B.encode(d[f"{key}/messages"]), d[f"{key}/codewords"], key + " encode")
+        assert not B.detect(d[f"{key}/codewords"]).any(), key
+        if f"{key}/short_messages" in d:
+            H.assert_equal_ints(B.encode(d[f"{key}/short_messages"]), d[f"{key}/short_codewords"], key + " shortened")
+
+
+_BCH_CASES = ["bch15_7", "bch15_5_c3", "bch31_16", "bch63_45", "bch63_36_short", "bch255_223", "bch127_99_nonsys",
+              "bch13_4_gf3", "bch26_14_gf3", "bch26_8_gf3_c3", "bch80_60_gf3", "bch24_gf5", "bch26_14_gf3_nonsys_short"]
+
+
+_BCH_FROM_K = {"bch15_7", "bch31_16", "bch63_45", "bch63_36_short", "bch255_223", "bch127_99_nonsys", "bch13_4_gf3",
+               "bch26_14_gf3", "bch26_14_gf3_nonsys_short"}
+
+
+@pytest.mark.parametrize("tag", _BCH_CASES)
+def test_reference_bch_outputs(tag):
+    """Encode / detect / decode (errors, erasures, beyond-capacity words) against outputs of the reference itself."""
+    d = H.reference_bch_outputs()
+    meta = json.loads(str(d[f"bch/{tag}/meta"]))
+    p = meta["p"]
+    ext = O.OracleField(p, meta["ext_m"], meta["ext_irr"], meta["ext_alpha"], lookup=True)
+    B = O.OracleBCH(ext, meta["n"], meta["k"], d=meta["d"], alpha=meta["alpha"], c=meta["c"], systematic=meta["systematic"])
+    assert B.d == meta["d"]
+    if tag in _BCH_FROM_K:  # the search for the largest design distance of that size (_bch.py:1200-1252)
+        Bk = O.OracleBCH(ext, meta["n"], meta["k"], alpha=meta["alpha"], c=meta["c"], systematic=meta["systematic"])
+        assert (Bk.d, Bk.generator_poly) == (B.d, B.generator_poly)
+    H.assert_equal_ints(B.generator_poly, d[f"bch/{tag}/generator_poly"])
+    H.assert_equal_ints(B.roots, d[f"bch/{tag}/roots"])
+    H.assert_equal_ints(B.encode(d[f"bch/{tag}/messages"]), d[f"bch/{tag}/codewords"])
+    R, E = d[f"bch/{tag}/received"], d[f"bch/{tag}/erasures"]
+    assert np.array_equal(B.detect(R), d[f"bch/{tag}/detected"])
+    dec, nerr = B.decode(R, E)
+    raises = d[f"bch/{tag}/raises"]
+    # rows on which the reference raises: the decoded word holds symbols outside GF(p)
+    bad = ((dec < 0) | (dec >= p)).any(axis=1)
+    assert np.array_equal(bad, raises)
+    ok = ~raises
+    assert np.array_equal(nerr[ok], d[f"bch/{tag}/n_errors"][ok])
+    assert np.array_equal(dec[ok], d[f"bch/{tag}/decoded"][ok])
+    assert np.array_equal(B.message_of(dec[ok]), d[f"bch/{tag}/decoded_message"][ok])
