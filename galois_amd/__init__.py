@@ -17,11 +17,12 @@ from ._numtheory import (  # noqa: E402
     is_prime, factors, primitive_root, is_primitive_root, matlab_primitive_poly, conway_poly, primitive_poly,
 )
 from . import _dist as dist  # noqa: E402
+from . import _linalg as linalg  # noqa: E402
 
 GF2 = GF(2)
 
 __all__ = [
     "FieldArray", "GF", "GF2", "Field", "ntt", "intt", "ReedSolomon", "BCH", "is_prime", "factors", "primitive_root",
-    "is_primitive_root", "matlab_primitive_poly", "conway_poly", "primitive_poly", "dist",
+    "is_primitive_root", "matlab_primitive_poly", "conway_poly", "primitive_poly", "dist", "linalg",
 ]
 __version__ = "0.1.0"

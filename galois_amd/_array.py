@@ -34,6 +34,17 @@ _NP_SIGNED = {1: np.uint8, 2: np.int16, 4: np.int32, 8: np.int64}
 _GFA_DTYPE = {1: L.U8, 2: L.U16, 4: L.U32, 8: L.U64}
 
 
+def _to_storage(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Field-element tensor -> another storage width.  uint16 / uint32 arrays live in same-width signed torch storage, so
+    widening must undo the sign extension (elements are never negative)."""
+    if t.dtype == dtype:
+        return t
+    wide = t.to(torch.int64)
+    if t.dtype in (torch.int16, torch.int32):
+        wide = wide & ((1 << (8 * t.element_size())) - 1)
+    return wide.to(dtype)
+
+
 def _device() -> torch.device:
     if not torch.cuda.is_available():
         raise RuntimeError(
@@ -49,6 +60,11 @@ def _stream() -> int:
 
 def _ptr(t: torch.Tensor) -> int:
     return t.data_ptr()
+
+
+# np functions overridden with field arithmetic (LinalgFunctionMixin._OVERRIDDEN_FUNCTIONS, _domains/_linalg.py:562-576)
+_LINALG_FUNCTIONS = {np.dot: "dot", np.vdot: "vdot", np.inner: "inner", np.outer: "outer", np.linalg.det: "det",
+                     np.linalg.matrix_rank: "matrix_rank", np.linalg.solve: "solve", np.linalg.inv: "inv"}
 
 
 class FieldArrayMeta(type):
@@ -478,7 +494,7 @@ class FieldArray(metaclass=FieldArrayMeta):
         size = cls._itemsize(np_dtype)
         if size == self._t.element_size():
             return cls._wrap(self._t.clone(), np_dtype)
-        return cls._wrap(self._t.to(torch.int64).to(_TORCH_STORAGE[size]), np_dtype)
+        return cls._wrap(_to_storage(self._t, _TORCH_STORAGE[size]), np_dtype)
 
     def __getitem__(self, key) -> "FieldArray":
         key = self._convert_key(key)
@@ -516,7 +532,7 @@ class FieldArray(metaclass=FieldArrayMeta):
         if isinstance(other, FieldArray):
             if type(other) is not cls:
                 return NotImplemented
-            o = other._t if other._t.dtype == self._t.dtype else other._t.to(torch.int64).to(self._t.dtype)
+            o = _to_storage(other._t, self._t.dtype)
             return (self._t == o).cpu().numpy()
         return self.numpy() == np.asarray(other)
 
@@ -536,7 +552,7 @@ class FieldArray(metaclass=FieldArrayMeta):
         """Other operand's tensor in this array's storage width (the result keeps `self.dtype`, _ufunc.py:675)."""
         if other._t.element_size() == self._t.element_size():
             return other._t
-        return other._t.to(torch.int64).to(self._t.dtype)
+        return _to_storage(other._t, self._t.dtype)
 
     @staticmethod
     def _broadcast(a: torch.Tensor, b: torch.Tensor):
@@ -731,6 +747,12 @@ class FieldArray(metaclass=FieldArrayMeta):
             same_field()
             shape = torch.broadcast_shapes(inputs[0].shape, inputs[1].shape)
             return cls.Zeros(tuple(shape), dtype=self._np_dtype if self._np_dtype != np.dtype(object) else None)
+        if ufunc is np.matmul:
+            if method != "__call__":
+                raise ValueError(f"Ufunc method {method!r} is not supported on 'matmul'.")
+            same_field()
+            from . import _linalg
+            return _linalg.matmul(inputs[0], inputs[1])
         if ufunc in (np.equal, np.not_equal) and method == "__call__":
             r = inputs[0].__eq__(inputs[1]) if isinstance(inputs[0], cls) else inputs[1].__eq__(inputs[0])
             return r if ufunc is np.equal else ~r
@@ -749,6 +771,12 @@ class FieldArray(metaclass=FieldArrayMeta):
             from ._ntt import _field_convolve
 
             return _field_convolve(*args, **kwargs)
+        if func in _LINALG_FUNCTIONS:
+            from . import _linalg
+
+            if kwargs.get("out") is not None:
+                raise NotImplementedError("The `out=` keyword is not supported for device-resident field arrays.")
+            return getattr(_linalg, _LINALG_FUNCTIONS[func])(*args)
         # anything else: plain NumPy on host copies (returns ndarrays, not field arrays)
         def host(v):
             if isinstance(v, FieldArray):
@@ -783,8 +811,34 @@ class FieldArray(metaclass=FieldArrayMeta):
     def __pos__(self): return np.positive(self)
     def __pow__(self, o): return np.power(self, o)  # _ufunc.py:715-719
 
-    def __matmul__(self, o):
-        raise NotImplementedError(
-            "General field matrix multiplication is outside this engine's hot path (SURVEY.md section 8(f) item 2); "
-            "Reed-Solomon encoding uses its own kernel (galois_amd.ReedSolomon.encode)."
-        )
+    def __matmul__(self, o): return np.matmul(self, o)
+    def __rmatmul__(self, o): return np.matmul(o, self)
+
+    # ---- linear algebra methods (_fields/_array.py:1412-1760) -------------------------------------------------------
+    def row_reduce(self, ncols=None, eye: str = "left"):
+        from . import _linalg
+        return _linalg.row_reduce(self, ncols=ncols, eye=eye)
+
+    def lu_decompose(self):
+        from . import _linalg
+        return _linalg.lu_decompose(self)
+
+    def plu_decompose(self):
+        from . import _linalg
+        return _linalg.plu_decompose(self)
+
+    def row_space(self):
+        from . import _linalg
+        return _linalg.row_space(self)
+
+    def column_space(self):
+        from . import _linalg
+        return _linalg.column_space(self)
+
+    def left_null_space(self):
+        from . import _linalg
+        return _linalg.left_null_space(self)
+
+    def null_space(self):
+        from . import _linalg
+        return _linalg.null_space(self)

@@ -22,6 +22,7 @@ U8, U16, U32, U64 = 0, 1, 2, 3
 OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_RECIP, OP_POW = range(7)
 MODE_AUTO, MODE_LOOKUP, MODE_CALCULATE = 0, 1, 2
 DEVERR_ZERO_DIVISION = 1
+DEVERR_NO_LU = 2
 
 c_void_p, c_int, c_i64, c_u64, c_u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint32
 _u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -49,6 +50,12 @@ SIGNATURES = {
     "gfa_convolve": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p]),
     "gfa_ntt": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_u64, c_int, c_int, c_void_p]),
     "gfa_ntt_columns": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_u64, c_int, c_void_p]),
+    "gfa_matmul": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),
+    "gfa_row_reduce": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_void_p, c_int, c_void_p]),
+    "gfa_plu_decompose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p,
+                                  c_int, c_void_p, c_void_p]),
+    "gfa_time_matmul": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p, c_int,
+                                ctypes.POINTER(ctypes.c_float)]),
     "gfa_rs_create": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_u64, c_int, ctypes.POINTER(c_void_p)]),
     "gfa_bch_create": (c_int, [c_void_p, c_u64, c_i64, c_i64, c_i64, c_i64, c_u64, _u64p, c_int, ctypes.POINTER(c_void_p)]),
     "gfa_rs_destroy": (None, [c_void_p]),

@@ -396,52 +396,6 @@ int launch_intarg_ft(const FieldDev &fd, bool is_pow, const void *a, i64 sa, con
     return GFA_OK;
 }
 
-// dispatch on (arithmetic kind, storage dtype)
-#define GFA_DISPATCH_FT(FUNC, fd, dtype, ...)                                                              \
-    do {                                                                                                   \
-        switch ((fd).kind) {                                                                               \
-        case KIND_PRIME32:                                                                                 \
-            switch (dtype) {                                                                               \
-            case GFA_U8: return FUNC<Prime32, uint8_t>(__VA_ARGS__);                                       \
-            case GFA_U16: return FUNC<Prime32, uint16_t>(__VA_ARGS__);                                     \
-            case GFA_U32: return FUNC<Prime32, uint32_t>(__VA_ARGS__);                                     \
-            case GFA_U64: return FUNC<Prime32, uint64_t>(__VA_ARGS__);                                     \
-            }                                                                                              \
-            break;                                                                                         \
-        case KIND_LUT:                                                                                     \
-            switch (dtype) {                                                                               \
-            case GFA_U8: return FUNC<Lut, uint8_t>(__VA_ARGS__);                                           \
-            case GFA_U16: return FUNC<Lut, uint16_t>(__VA_ARGS__);                                         \
-            case GFA_U32: return FUNC<Lut, uint32_t>(__VA_ARGS__);                                         \
-            case GFA_U64: return FUNC<Lut, uint64_t>(__VA_ARGS__);                                         \
-            }                                                                                              \
-            break;                                                                                         \
-        case KIND_BIN:                                                                                     \
-            switch (dtype) {                                                                               \
-            case GFA_U8: return FUNC<Bin, uint8_t>(__VA_ARGS__);                                           \
-            case GFA_U16: return FUNC<Bin, uint16_t>(__VA_ARGS__);                                         \
-            case GFA_U32: return FUNC<Bin, uint32_t>(__VA_ARGS__);                                         \
-            case GFA_U64: return FUNC<Bin, uint64_t>(__VA_ARGS__);                                         \
-            }                                                                                              \
-            break;                                                                                         \
-        case KIND_EXT:                                                                                     \
-            switch (dtype) {                                                                               \
-            case GFA_U8: return FUNC<Ext, uint8_t>(__VA_ARGS__);                                           \
-            case GFA_U16: return FUNC<Ext, uint16_t>(__VA_ARGS__);                                         \
-            case GFA_U32: return FUNC<Ext, uint32_t>(__VA_ARGS__);                                         \
-            case GFA_U64: return FUNC<Ext, uint64_t>(__VA_ARGS__);                                         \
-            }                                                                                              \
-            break;                                                                                         \
-        case KIND_PRIME64:                                                                                 \
-            if (dtype == GFA_U64) return FUNC<Prime64, uint64_t>(__VA_ARGS__);                             \
-            break;                                                                                         \
-        case KIND_GOLDILOCKS:                                                                              \
-            if (dtype == GFA_U64) return FUNC<Goldilocks, uint64_t>(__VA_ARGS__);                          \
-            break;                                                                                         \
-        }                                                                                                  \
-        set_error("unsupported (field kind, dtype) combination");                                          \
-        return GFA_ERR_UNSUPPORTED;                                                                        \
-    } while (0)
 
 int dispatch_binary(const FieldDev &fd, int dtype, int op, const void *a, i64 sa, const void *b, i64 sb, void *out,
                     i64 n, hipStream_t st, int32_t *err)
@@ -684,16 +638,6 @@ int dispatch_accumulate(const FieldDev &fd, int dtype, int op, const void *a, vo
     GFA_DISPATCH_FT(launch_accumulate_ft, fd, dtype, fd, op, a, out, n_outer, n_inner, st, err);
 }
 
-bool dtype_holds(int dtype, u64 q)
-{
-    switch (dtype) {
-    case GFA_U8: return q - 1 <= 0xffull;
-    case GFA_U16: return q - 1 <= 0xffffull;
-    case GFA_U32: return q - 1 <= 0xffffffffull;
-    case GFA_U64: return true;
-    default: return false;
-    }
-}
 
 
 int tab8_grid(i64 n)

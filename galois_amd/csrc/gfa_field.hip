@@ -33,8 +33,8 @@ int time_loop(hipStream_t st, int iters, float *ms_out, const std::function<int(
     float ms = 0;
     GFA_HIP(hipEventElapsedTime(&ms, e0, e1));
     *ms_out = ms / (iters > 0 ? iters : 1);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return GFA_OK;
 }
 
@@ -309,9 +309,9 @@ void gfa_field_destroy(gfa_field_t *f)
     gfa::ntt_forget_field(f);
     for (auto &st : f->dev) {
         if (!st.ready) continue;
-        hipFree(st.exp_tab); hipFree(st.log_tab); hipFree(st.zech_tab);
-        hipFree(st.mul8); hipFree(st.add8); hipFree(st.sub8); hipFree(st.div8);
-        hipFree(st.inv8); hipFree(st.neg8); hipFree(st.exp8); hipFree(st.log8);
+        (void)hipFree(st.exp_tab); (void)hipFree(st.log_tab); (void)hipFree(st.zech_tab);
+        (void)hipFree(st.mul8); (void)hipFree(st.add8); (void)hipFree(st.sub8); (void)hipFree(st.div8);
+        (void)hipFree(st.inv8); (void)hipFree(st.neg8); (void)hipFree(st.exp8); (void)hipFree(st.log8);
     }
     delete f;
 }

@@ -47,7 +47,66 @@ struct FieldDeviceState {
     uint8_t *exp8 = nullptr, *log8 = nullptr; // byte EXP (512) / LOG (256) for the RS kernels
 };
 
+// can the storage dtype hold every element of a field of order q?
+inline bool dtype_holds(int dtype, u64 q)
+{
+    switch (dtype) {
+    case GFA_U8: return q - 1 <= 0xffull;
+    case GFA_U16: return q - 1 <= 0xffffull;
+    case GFA_U32: return q - 1 <= 0xffffffffull;
+    case GFA_U64: return true;
+    default: return false;
+    }
+}
+
 } // namespace gfa
+
+// dispatch on (arithmetic kind, storage dtype)
+#define GFA_DISPATCH_FT(FUNC, fd, dtype, ...)                                                              \
+    do {                                                                                                   \
+        switch ((fd).kind) {                                                                               \
+        case KIND_PRIME32:                                                                                 \
+            switch (dtype) {                                                                               \
+            case GFA_U8: return FUNC<Prime32, uint8_t>(__VA_ARGS__);                                       \
+            case GFA_U16: return FUNC<Prime32, uint16_t>(__VA_ARGS__);                                     \
+            case GFA_U32: return FUNC<Prime32, uint32_t>(__VA_ARGS__);                                     \
+            case GFA_U64: return FUNC<Prime32, uint64_t>(__VA_ARGS__);                                     \
+            }                                                                                              \
+            break;                                                                                         \
+        case KIND_LUT:                                                                                     \
+            switch (dtype) {                                                                               \
+            case GFA_U8: return FUNC<Lut, uint8_t>(__VA_ARGS__);                                           \
+            case GFA_U16: return FUNC<Lut, uint16_t>(__VA_ARGS__);                                         \
+            case GFA_U32: return FUNC<Lut, uint32_t>(__VA_ARGS__);                                         \
+            case GFA_U64: return FUNC<Lut, uint64_t>(__VA_ARGS__);                                         \
+            }                                                                                              \
+            break;                                                                                         \
+        case KIND_BIN:                                                                                     \
+            switch (dtype) {                                                                               \
+            case GFA_U8: return FUNC<Bin, uint8_t>(__VA_ARGS__);                                           \
+            case GFA_U16: return FUNC<Bin, uint16_t>(__VA_ARGS__);                                         \
+            case GFA_U32: return FUNC<Bin, uint32_t>(__VA_ARGS__);                                         \
+            case GFA_U64: return FUNC<Bin, uint64_t>(__VA_ARGS__);                                         \
+            }                                                                                              \
+            break;                                                                                         \
+        case KIND_EXT:                                                                                     \
+            switch (dtype) {                                                                               \
+            case GFA_U8: return FUNC<Ext, uint8_t>(__VA_ARGS__);                                           \
+            case GFA_U16: return FUNC<Ext, uint16_t>(__VA_ARGS__);                                         \
+            case GFA_U32: return FUNC<Ext, uint32_t>(__VA_ARGS__);                                         \
+            case GFA_U64: return FUNC<Ext, uint64_t>(__VA_ARGS__);                                         \
+            }                                                                                              \
+            break;                                                                                         \
+        case KIND_PRIME64:                                                                                 \
+            if (dtype == GFA_U64) return FUNC<Prime64, uint64_t>(__VA_ARGS__);                             \
+            break;                                                                                         \
+        case KIND_GOLDILOCKS:                                                                              \
+            if (dtype == GFA_U64) return FUNC<Goldilocks, uint64_t>(__VA_ARGS__);                          \
+            break;                                                                                         \
+        }                                                                                                  \
+        set_error("unsupported (field kind, dtype) combination");                                          \
+        return GFA_ERR_UNSUPPORTED;                                                                        \
+    } while (0)
 
 struct gfa_field {
     gfa::FieldDev calc;   // descriptor for explicit calculation (kind = PRIME32/PRIME64/GOLDILOCKS/BIN/EXT)

@@ -60,6 +60,7 @@ typedef enum {
 typedef enum { GFA_MODE_AUTO = 0, GFA_MODE_LOOKUP = 1, GFA_MODE_CALCULATE = 2 } gfa_mode;
 
 #define GFA_DEVERR_ZERO_DIVISION 1 /* reciprocal(0), x/0, 0**negative (_lookup.py:194-195, _calculate.py:403-404,536-537) */
+#define GFA_DEVERR_NO_LU 2         /* lu_decompose needs a row exchange ("The LU decomposition of 'A' does not exist", _linalg.py:374) */
 
 /* ---- library -------------------------------------------------------------------------------------- */
 int gfa_abi_version(void);
@@ -131,6 +132,27 @@ int gfa_ntt(gfa_field_t *f, const void *in, void *out, int64_t n, int64_t batch,
 int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64_t cols, int64_t col0, int64_t n_total,
                     uint64_t omega, int dtype, gfa_stream_t stream);
 
+/* ---- Field linear algebra ------------------------------------------------------- *
+ * gfa_matmul replaces matmul_jit.implementation `int64[:,:,:](int64[:,:,:], int64[:,:,:])` (_domains/_linalg.py:283-308)
+ * and the BLAS-then-mod-p shortcut of prime fields (_lapack_linalg, :21-75): out[b] = a[b] @ b[b] for `batch` row-major
+ * matrices, a: (M x K), b: (K x N), out: (M x N) contiguous.  a_batch_stride / b_batch_stride are in elements; 0
+ * broadcasts one matrix over the batch (np.matmul broadcasting, _linalg.py:232-246). */
+int gfa_matmul(gfa_field_t *f, const void *a, const void *b, void *out, int64_t batch, int64_t M, int64_t K, int64_t N,
+               int64_t a_batch_stride, int64_t b_batch_stride, int dtype, gfa_stream_t stream);
+/* row_reduce_jit.__call__ (_linalg.py:315-351): Gauss-Jordan elimination IN PLACE on `batch` contiguous (m x n)
+ * matrices over the first `ncols` columns; pivot = first non-zero entry at or below the pivot row.  rank_out[b] =
+ * number of pivots.  inv_jit / solve_jit / matrix_rank_jit and the row/column/null spaces are host compositions of
+ * this call (:480-548, _fields/_array.py:1541-1760).  At most 4096 rows. */
+int gfa_row_reduce(gfa_field_t *f, void *a, int64_t batch, int64_t m, int64_t n, int64_t ncols, int64_t *rank_out, int dtype,
+                   gfa_stream_t stream);
+/* lu_decompose_jit (pivoting == 0, _linalg.py:354-384) / plu_decompose_jit (pivoting != 0, :387-424) on `batch`
+ * (m x n) matrices: `a` is overwritten with U; l_out (m x m) and p_out (m x m, the ROW permutation matrix -- the
+ * reference returns its transpose) may be NULL.  n_permutations_out (may be NULL): row exchanges per matrix.
+ * det_out (may be NULL): (-1)^exchanges * prod(diag U), the value det_jit computes (:447-477).  Without pivoting a
+ * zero pivot above a non-zero entry ORs GFA_DEVERR_NO_LU into *dev_err. */
+int gfa_plu_decompose(gfa_field_t *f, void *a, void *l_out, void *p_out, int64_t batch, int64_t m, int64_t n, int pivoting,
+                      int64_t *n_permutations_out, void *det_out, int dtype, gfa_stream_t stream, int32_t *dev_err);
+
 /* ---- Reed-Solomon -------------------------------------------------------------------------------- *
  * gfa_rs_create replaces the arithmetic part of ReedSolomon.__init__ (_codes/_reed_solomon.py:111-218) and
  * _poly_to_generator_matrix (_codes/_cyclic.py:198-226): roots alpha^(c..c+d-2), g(x), systematic parity matrix. */
@@ -170,6 +192,8 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
 /* ---- measurement support (bench.py) --------------------------------------------------------------- *
  * Times `iters` back-to-back launches of the named hot kernel on `stream` with HIP events recorded on that same
  * stream and returns the average milliseconds per launch in *ms_out. */
+int gfa_time_matmul(gfa_field_t *f, const void *a, const void *b, void *out, int64_t batch, int64_t M, int64_t K, int64_t N,
+                    int dtype, gfa_stream_t stream, int iters, float *ms_out);
 int gfa_time_binary(gfa_field_t *f, int op, const void *a, const void *b, void *out, int64_t n, int dtype,
                     gfa_stream_t stream, int iters, float *ms_out);
 int gfa_time_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int dtype, gfa_stream_t stream,

@@ -219,6 +219,137 @@ class OracleField:
         lib().gfo_matmul(self._h, _p(A, _u64p), _p(B, _u64p), _p(C, _u64p), M, K, N)
         return C
 
+    # matrix routines of _domains/_linalg.py, restated with the same pivot rules on uint64 host arrays
+    def _outer_sub(self, A, rows, col_factors, pivot_row):
+        """A[rows, :] -= outer(col_factors, pivot_row)."""
+        if len(rows) == 0:
+            return
+        prod = self.mul(np.repeat(col_factors[:, None], pivot_row.size, axis=1), np.tile(pivot_row, (len(rows), 1)))
+        A[rows, :] = self.sub(A[rows, :], prod)
+
+    def row_reduce(self, A, ncols=None):
+        """row_reduce_jit.__call__ _linalg.py:315-351.  Returns (A_rre, p)."""
+        A = _as_u64(A).copy()
+        m, n = A.shape
+        ncols = n if ncols is None else ncols
+        p = 0
+        if m == 0:
+            return A, 0
+        for j in range(ncols):
+            idxs = np.nonzero(A[p:, j])[0]
+            if idxs.size == 0:
+                continue
+            i = p + int(idxs[0])
+            A[[p, i], :] = A[[i, p], :]
+            A[p, :] = self.div(A[p, :], np.full(n, A[p, j], dtype=np.uint64))
+            idxs = [int(r) for r in np.nonzero(A[:, j])[0] if r != p]
+            self._outer_sub(A, idxs, A[idxs, j].copy(), A[p, :].copy())
+            p += 1
+            if p == m:
+                break
+        return A, p
+
+    def lu_decompose(self, A):
+        """lu_decompose_jit.__call__ _linalg.py:354-384.  Returns (L, U); ValueError if a row exchange is needed."""
+        Ai = _as_u64(A).copy()
+        m = Ai.shape[0]
+        L = np.eye(m, dtype=np.uint64)
+        for i in range(0, m - 1):
+            if Ai[i, i] == 0:
+                idxs = np.nonzero(Ai[i:, i])[0]
+                if idxs.size == 0:
+                    L[i, i] = 1
+                    continue
+                raise ValueError("The LU decomposition of 'A' does not exist. Use the PLU decomposition instead.")
+            l = self.div(Ai[i + 1:, i], np.full(m - i - 1, Ai[i, i], dtype=np.uint64))
+            self._outer_sub(Ai, list(range(i + 1, m)), l, Ai[i, :].copy())
+            L[i + 1:, i] = l
+        return L, Ai
+
+    def plu_decompose(self, A):
+        """plu_decompose_jit.__call__ _linalg.py:387-424.  Returns (P (column permutation = P_row.T), L, U, N_perm)."""
+        Ai = _as_u64(A).copy()
+        m, n = Ai.shape
+        L = np.zeros((m, m), dtype=np.uint64)
+        P = np.eye(m, dtype=np.uint64)
+        nperm = 0
+        for i in range(0, min(m, n)):
+            if Ai[i, i] == 0:
+                idxs = np.nonzero(Ai[i:, i])[0]
+                if idxs.size == 0:
+                    L[i, i] = 1
+                    continue
+                j = i + int(idxs[0])
+                P[[i, j], :] = P[[j, i], :]
+                Ai[[i, j], :] = Ai[[j, i], :]
+                L[[i, j], :] = L[[j, i], :]
+                nperm += 1
+            l = self.div(Ai[i + 1:, i], np.full(m - i - 1, Ai[i, i], dtype=np.uint64)) if i + 1 < m else np.zeros(0, np.uint64)
+            self._outer_sub(Ai, list(range(i + 1, m)), l, Ai[i, :].copy())
+            L[i, i] = 1
+            L[i + 1:, i] = l
+        L[-1, -1] = 1
+        return P.T.copy(), L, Ai, nperm
+
+    def det(self, A):
+        """det_jit.__call__ _linalg.py:447-477 (the 2x2 / 3x3 closed forms give the same field element)."""
+        A = _as_u64(A)
+        assert A.ndim == 2 and A.shape[0] == A.shape[1]
+        _, L, U, nperm = self.plu_decompose(A)
+        d = 1
+        for i in range(A.shape[0]):
+            d = int(self.mul([d], [int(L[i, i])])[0])
+            d = int(self.mul([d], [int(U[i, i])])[0])
+        if nperm % 2:
+            d = int(self.neg([d])[0])
+        return d
+
+    def matrix_rank(self, A):
+        A_rre, _ = self.row_reduce(A)
+        return int(np.sum(~np.all(A_rre == 0, axis=1)))
+
+    def inv(self, A):
+        """inv_jit.__call__ _linalg.py:495-520."""
+        A = _as_u64(A)
+        n = A.shape[0]
+        assert A.ndim == 2 and A.shape[1] == n
+        AI = np.concatenate([A, np.eye(n, dtype=np.uint64)], axis=-1)
+        AI_rre, _ = self.row_reduce(AI, ncols=n)
+        rank = int(np.sum(~np.all(AI_rre[:, 0:n] == 0, axis=1)))
+        if rank != n:
+            raise np.linalg.LinAlgError(f"Argument 'A' is singular and not invertible because it does not have full rank of {n}, but rank of {rank}.")
+        return AI_rre[:, -n:].copy()
+
+    def solve(self, A, b):
+        """solve_jit.__call__ _linalg.py:523-548."""
+        b = _as_u64(b)
+        Ainv = self.inv(A)
+        if b.ndim == 1:
+            return self.matmul(Ainv, b.reshape(-1, 1)).reshape(-1)
+        return self.matmul(Ainv, b)
+
+    def row_space(self, A):
+        """FieldArray.row_space _fields/_array.py:1541-1590."""
+        A_rre, _ = self.row_reduce(A)
+        rank = int(np.sum(~np.all(A_rre == 0, axis=1)))
+        return A_rre[0:rank, :]
+
+    def column_space(self, A):
+        return self.row_space(_as_u64(A).T)
+
+    def left_null_space(self, A):
+        """FieldArray.left_null_space _fields/_array.py:1639-1703."""
+        A = _as_u64(A)
+        m, n = A.shape
+        AI = np.concatenate([A, np.eye(m, dtype=np.uint64)], axis=-1)
+        AI_rre, p = self.row_reduce(AI, ncols=n)
+        LN = AI_rre[p:, n:]
+        LN, _ = self.row_reduce(LN)
+        return LN
+
+    def null_space(self, A):
+        return self.left_null_space(_as_u64(A).T)
+
     def poly_eval(self, coeffs_desc, values):
         c = _as_u64(coeffs_desc); v = _as_u64(values)
         y = np.empty(v.size, dtype=np.uint64)

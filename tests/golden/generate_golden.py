@@ -67,6 +67,28 @@ def pack_sage_fields():
         print("packed", folder)
 
 
+def pack_sage_linalg():
+    """tests/fields/data/*/{matrix_multiply,row_reduce,lu_decompose,plu_decompose,matrix_inverse,matrix_determinant,
+    matrix_solve,row_space,column_space,left_null_space,null_space}.pkl (loaders tests/fields/conftest.py:296-420)."""
+    ops = ["matrix_multiply", "row_reduce", "lu_decompose", "plu_decompose", "matrix_inverse", "matrix_determinant",
+           "matrix_solve", "row_space", "column_space", "left_null_space", "null_space"]
+    for folder in sorted(os.listdir(os.path.join(REF_TESTS, "fields", "data"))):
+        path = os.path.join(REF_TESTS, "fields", "data", folder)
+        props = json.load(open(os.path.join(path, "properties.json")))
+        if props["order"] >= 2**64:
+            continue
+        out = {"properties": np.array(json.dumps(props))}
+        for op in ops:
+            d = pickle.load(open(os.path.join(path, op + ".pkl"), "rb"))
+            out[f"{op}_count"] = np.array(len(d["X"]))
+            for k, vals in d.items():
+                for i, v in enumerate(vals):
+                    out[f"{op}{i}_{k}"] = small(np.asarray(v if not np.isscalar(v) else int(v)))
+        name = folder.replace("(", "_").replace(")", "").replace("^", "e").replace(", ", "_")
+        np.savez_compressed(os.path.join(HERE, f"sage_linalg_{name}.npz"), **out)
+        print("packed linalg", folder)
+
+
 def pack_sage_rs():
     out = {}
     names = []
@@ -316,13 +338,15 @@ def reference_bch_outputs():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["fields", "rs", "reference", "bch", "reference_bch"]
+    what = sys.argv[1:] or ["fields", "rs", "reference", "bch", "reference_bch", "linalg"]
     if "fields" in what:
         pack_sage_fields()
     if "rs" in what:
         pack_sage_rs()
     if "reference" in what:
         reference_outputs()
+    if "linalg" in what:
+        pack_sage_linalg()
     if "bch" in what:
         pack_sage_bch()
     if "reference_bch" in what:

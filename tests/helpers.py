@@ -80,3 +80,18 @@ def parse_sage_poly(text, p):
         terms[deg] = (terms.get(deg, 0) + c) % p
     n = max(terms)
     return [terms.get(i, 0) for i in range(n, -1, -1)]
+
+
+SAGE_LINALG = sorted(f[len("sage_linalg_"):-4] for f in os.listdir(GOLDEN) if f.startswith("sage_linalg_"))
+
+
+def load_sage_linalg(tag):
+    d = np.load(os.path.join(GOLDEN, f"sage_linalg_{tag}.npz"))
+    props = json.loads(str(d["properties"]))
+    return props, d
+
+
+def linalg_cases(d, op, keys):
+    """Yields tuples of arrays (one per key) for every stored case of `op`."""
+    for i in range(int(d[f"{op}_count"])):
+        yield tuple(d[f"{op}{i}_{k}"] for k in keys)

@@ -268,3 +268,17 @@ def test_api_semantics_and_errors():
     assert v.torch().data_ptr() == t.data_ptr()
     with pytest.raises(ValueError):
         ga.GF(31)(t)
+
+
+def test_mixed_storage_widths_keep_large_unsigned_values():
+    """uint32 / uint16 arrays sit in same-width signed torch storage: widening to int64 must not sign-extend."""
+    GF = ga.GF(2**32)
+    a = np.array([2**31, 2**32 - 1, 5, 2**31 + 12345], dtype=np.uint32)
+    x32, x64 = GF(a, dtype=np.uint32), GF(a.astype(np.int64), dtype=np.int64)
+    assert np.array_equal(x32.astype(np.int64).numpy(), a.astype(np.int64))
+    assert np.array_equal((x64 + x32).numpy(), np.zeros(4, dtype=np.int64))
+    assert np.array_equal((x64 * x32).numpy(), (x64 * x64).numpy())
+    assert np.array_equal(x64 == x32, np.ones(4, dtype=bool))
+    G16 = ga.GF(2**16)
+    b = np.array([2**15, 2**16 - 1, 7], dtype=np.uint16)
+    assert np.array_equal((G16(b.astype(np.int32), dtype=np.int32) * G16(b)).numpy(), (G16(b) * G16(b)).numpy().astype(np.int32))

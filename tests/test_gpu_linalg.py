@@ -1,0 +1,208 @@
+"""Parity of the field linear-algebra kernels against the reference's Sage fixtures
+(tests/fields/test_linalg.py) and the oracle.  Bit-exact, including the pivot order of L, U and P."""
+import numpy as np
+import pytest
+
+import galois_amd as ga
+from oracle import gf_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _field(props):
+    p, m = props["characteristic"], props["degree"]
+    if m == 1:
+        return ga.GF(p, primitive_element=int(props["primitive_element"]))
+    return ga.GF(p, m, irreducible_poly=H.poly_coeffs_to_int(props["irreducible_poly"], p),
+                 primitive_element=int(props["primitive_element"]))
+
+
+@pytest.mark.parametrize("tag", H.SAGE_LINALG)
+def test_sage_linalg_fixtures(tag):
+    props, d = H.load_sage_linalg(tag)
+    GF = _field(props)
+    rng = np.random.default_rng(5)
+
+    def arr(x):
+        dt = GF.dtypes[int(rng.integers(0, len(GF.dtypes)))]  # the reference tests draw a random legal dtype too
+        return GF(x.astype(np.uint64).astype(dt) if x.dtype != object else x, dtype=dt)
+
+    for X, Y, Z in H.linalg_cases(d, "matrix_multiply", "XYZ"):
+        z = arr(X) @ arr(Y)
+        assert type(z) is GF
+        H.assert_equal_ints(z.numpy(), Z, "matmul")
+    for X, Z in H.linalg_cases(d, "row_reduce", "XZ"):
+        H.assert_equal_ints(arr(X).row_reduce().numpy(), Z, "row_reduce")
+    for X, Lt, Ut in H.linalg_cases(d, "lu_decompose", "XLU"):
+        l, u = arr(X).lu_decompose()
+        H.assert_equal_ints(l.numpy(), Lt, "lu L")
+        H.assert_equal_ints(u.numpy(), Ut, "lu U")
+    for X, Pt, Lt, Ut in H.linalg_cases(d, "plu_decompose", "XPLU"):
+        p, l, u = arr(X).plu_decompose()
+        H.assert_equal_ints(p.numpy(), Pt, "plu P")
+        H.assert_equal_ints(l.numpy(), Lt, "plu L")
+        H.assert_equal_ints(u.numpy(), Ut, "plu U")
+        H.assert_equal_ints((p @ l @ u).numpy(), X, "P L U = A")
+    for X, Z in H.linalg_cases(d, "matrix_inverse", "XZ"):
+        H.assert_equal_ints(np.linalg.inv(arr(X)).numpy(), Z, "inv")
+    for X, Z in H.linalg_cases(d, "matrix_determinant", "XZ"):
+        assert int(np.linalg.det(arr(X))) == int(Z), "det"
+    for X, Y, Z in H.linalg_cases(d, "matrix_solve", "XYZ"):
+        H.assert_equal_ints(np.linalg.solve(arr(X), arr(Y)).numpy(), Z, "solve")
+    for op in ("row_space", "column_space", "left_null_space", "null_space"):
+        for X, Z in H.linalg_cases(d, op, "XZ"):
+            got = getattr(arr(X), op)().numpy()
+            if Z.size == 0:
+                assert got.size == 0, op
+            else:
+                H.assert_equal_ints(got, Z.reshape(got.shape), op)
+
+
+_FIELDS = [("gf256", 2, 8, 285, 2), ("gf2", 2, 1, None, 1), ("gf31", 31, 1, None, 3), ("gf65537", 65537, 1, None, 3),
+           ("gf2147483647", 2147483647, 1, None, 7), ("gf3e5", 3, 5, None, None), ("gf2e16", 2, 16, None, None),
+           ("goldilocks", H.GOLDILOCKS, 1, None, 7), ("gf251e3", 251, 3, None, None), ("gf2e32", 2, 32, None, None)]
+
+
+def _pair(tag):
+    name, p, m, irr, alpha = next(f for f in _FIELDS if f[0] == tag)
+    if m == 1:
+        GF = ga.GF(p)
+        return GF, O.OracleField(p, 1, None, int(GF.primitive_element))
+    GF = ga.GF(p, m) if irr is None else ga.GF(p, m, irreducible_poly=irr)
+    return GF, O.OracleField(p, m, int(GF.irreducible_poly), int(GF.primitive_element), lookup=GF.order <= 2**16)
+
+
+def _rand(rng, q, shape):
+    if q > 2**63:
+        return (rng.integers(0, 2**63, shape, dtype=np.uint64) * 2 + rng.integers(0, 2, shape, dtype=np.uint64)) % np.uint64(q)
+    return rng.integers(0, q, shape, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("tag", [f[0] for f in _FIELDS])
+def test_matmul_against_oracle(tag):
+    """Ragged sizes around the 64 x 64 x 16 tile, batch broadcasting, vectors (tests/fields/test_linalg.py:181-268)."""
+    GF, F = _pair(tag)
+    rng = np.random.default_rng(17)
+    for M, K, N in [(1, 1, 1), (3, 5, 2), (64, 16, 64), (65, 17, 63), (130, 100, 70), (7, 257, 9)]:
+        A, B = _rand(rng, GF.order, (M, K)), _rand(rng, GF.order, (K, N))
+        H.assert_equal_ints((GF(A) @ GF(B)).numpy(), F.matmul(A, B), f"{tag} {M}x{K}x{N}")
+    # stacks and broadcasting: (3, 1, M, K) @ (2, K, N) -> (3, 2, M, N); (K,) @ (K, N); (M, K) @ (K,)
+    A, B = _rand(rng, GF.order, (3, 1, 5, 7)), _rand(rng, GF.order, (2, 7, 4))
+    C = (GF(A) @ GF(B)).numpy()
+    assert C.shape == (3, 2, 5, 4)
+    for i in range(3):
+        for j in range(2):
+            H.assert_equal_ints(C[i, j], F.matmul(A[i, 0], B[j]))
+    v, w = _rand(rng, GF.order, 7), _rand(rng, GF.order, 5)
+    H.assert_equal_ints((GF(v) @ GF(B[0])).numpy(), F.matmul(v.reshape(1, 7), B[0])[0])
+    H.assert_equal_ints((GF(A[0, 0]) @ GF(v)).numpy(), F.matmul(A[0, 0], v.reshape(7, 1))[:, 0])
+    assert int(GF(v) @ GF(v)) == int(F.matmul(v.reshape(1, 7), v.reshape(7, 1))[0, 0])
+    H.assert_equal_ints(np.dot(GF(A[0, 0]), GF(B[0])).numpy(), F.matmul(A[0, 0], B[0]))
+    assert int(np.vdot(GF(v), GF(v))) == int(F.matmul(v.reshape(1, 7), v.reshape(7, 1))[0, 0])
+    assert int(np.inner(GF(v), GF(v))) == int(F.matmul(v.reshape(1, 7), v.reshape(7, 1))[0, 0])
+    H.assert_equal_ints(np.outer(GF(v), GF(w)).numpy(), F.matmul(v.reshape(7, 1), w.reshape(1, 5)))
+    with pytest.raises(ValueError):
+        GF(A[0, 0]) @ GF(w)
+
+
+@pytest.mark.parametrize("tag", [f[0] for f in _FIELDS])
+def test_elimination_against_oracle(tag):
+    """row_reduce / PLU / LU / det / inv / solve / rank / subspaces on random, rank-deficient and rectangular matrices."""
+    GF, F = _pair(tag)
+    rng = np.random.default_rng(23)
+    q = GF.order
+    mats = [_rand(rng, q, (n, n)) for n in (1, 2, 3, 4, 9, 33)] + [_rand(rng, q, s) for s in ((3, 7), (8, 5), (20, 31))]
+    low = _rand(rng, q, (12, 4))
+    mats.append(np.asarray(F.matmul(low, _rand(rng, q, (4, 12)))))          # rank <= 4
+    z = _rand(rng, q, (6, 6)); z[:, 0] = 0; z[2, :] = 0; mats.append(z)      # zero column and row: pivot skips
+    sw = _rand(rng, q, (5, 5)); sw[0, 0] = 0; sw[1, 1] = 0; mats.append(sw)  # forces row exchanges
+    for A in mats:
+        gA = GF(A)
+        rre, rank = F.row_reduce(A)
+        H.assert_equal_ints(gA.row_reduce().numpy(), rre, "row_reduce")
+        assert np.linalg.matrix_rank(gA) == F.matrix_rank(A)
+        p, l, u = gA.plu_decompose()
+        P, Lm, U, _ = F.plu_decompose(A)
+        H.assert_equal_ints(p.numpy(), P); H.assert_equal_ints(l.numpy(), Lm); H.assert_equal_ints(u.numpy(), U)
+        H.assert_equal_ints((p @ l @ u).numpy(), A, "PLU product")
+        for op in ("row_space", "column_space", "left_null_space", "null_space"):
+            want = getattr(F, op)(A)
+            got = getattr(gA, op)().numpy()
+            assert got.shape == want.shape or (got.size == 0 and want.size == 0), op
+            if want.size:
+                H.assert_equal_ints(got, want, op)
+        if A.shape[0] == A.shape[1]:
+            assert int(np.linalg.det(gA)) == F.det(A)
+            try:
+                want = F.inv(A)
+            except np.linalg.LinAlgError:
+                with pytest.raises(np.linalg.LinAlgError):
+                    np.linalg.inv(gA)
+            else:
+                H.assert_equal_ints(np.linalg.inv(gA).numpy(), want, "inv")
+                b = _rand(rng, q, (A.shape[0], 3))
+                H.assert_equal_ints(np.linalg.solve(gA, GF(b)).numpy(), F.solve(A, b), "solve")
+                H.assert_equal_ints(np.linalg.solve(gA, GF(b[:, 0])).numpy(), F.solve(A, b[:, 0]), "solve 1-D")
+            if A.shape[0] - 1 <= A.shape[1]:
+                try:
+                    Lw, Uw = F.lu_decompose(A)
+                except ValueError:
+                    with pytest.raises(ValueError):
+                        gA.lu_decompose()
+                else:
+                    lg, ug = gA.lu_decompose()
+                    H.assert_equal_ints(lg.numpy(), Lw); H.assert_equal_ints(ug.numpy(), Uw)
+    H.assert_equal_ints(GF(mats[3]).row_reduce(eye="right").numpy(), F.row_reduce(mats[3][::-1, ::-1])[0][::-1, ::-1])
+    H.assert_equal_ints(GF(mats[7]).row_reduce(ncols=3).numpy(), F.row_reduce(mats[7], ncols=3)[0])
+
+
+def test_batched_extensions_and_sizes():
+    """A stack of 4096 GF(2^8) 16 x 16 systems (inverse, determinant, RREF in one launch each) and one 512 x 512 inverse."""
+    GF, F = _pair("gf256")
+    rng = np.random.default_rng(29)
+    S = rng.integers(0, 256, (4096, 16, 16), dtype=np.uint8)
+    gS = GF(S)
+    dets = ga.linalg.det_batched(gS).numpy()
+    rre, ranks = ga.linalg.row_reduce_batched(gS)
+    for i in range(0, 4096, 257):
+        assert int(dets[i]) == F.det(S[i])
+        H.assert_equal_ints(rre.numpy()[i], F.row_reduce(S[i])[0])
+    full = ranks == 16
+    assert np.array_equal(dets != 0, full)
+    inv = ga.linalg.inv_batched(GF(S[full]))
+    prod = (GF(S[full]) @ inv).numpy()
+    assert np.array_equal(prod, np.broadcast_to(np.eye(16, dtype=np.uint8), prod.shape))
+    with pytest.raises(np.linalg.LinAlgError):
+        ga.linalg.inv_batched(GF(np.zeros((2, 3, 3), dtype=np.uint8)))
+    P = ga.GF(65537)
+    A = rng.integers(0, 65537, (512, 512), dtype=np.uint32)
+    gA = P(A)
+    Ai = np.linalg.inv(gA)
+    assert np.array_equal((gA @ Ai).numpy(), np.eye(512, dtype=np.uint32))
+
+
+def test_exceptions():
+    """tests/fields/test_linalg.py:15-36, 86-92, 123-132, 291-299, 321-329, 345-353, 394-420."""
+    GF = ga.GF(2**8)
+    rng = np.random.default_rng(1)
+    a1, a3 = GF(rng.integers(0, 256, 5)), GF(rng.integers(0, 256, (2, 2, 2)))
+    for fn in (lambda x: x.row_reduce(), lambda x: x.lu_decompose(), lambda x: x.plu_decompose()):
+        with pytest.raises(ValueError):
+            fn(a1)
+        with pytest.raises(ValueError):
+            fn(a3)
+    for fn in (np.linalg.inv, np.linalg.det):
+        with pytest.raises(np.linalg.LinAlgError):
+            fn(a1)
+        with pytest.raises(np.linalg.LinAlgError):
+            fn(a3)
+    with pytest.raises(np.linalg.LinAlgError):
+        np.linalg.solve(GF(rng.integers(0, 256, (2, 3))), GF(rng.integers(0, 256, 3)))
+    with pytest.raises(TypeError):
+        np.dot(a1, ga.GF(31)(np.arange(5)))
+    with pytest.raises(ValueError):
+        np.inner(a1, GF(rng.integers(0, 256, 4)))
+    H2 = ga.GF(2)([[1, 0, 1, 0, 1, 0, 1, 0], [0, 1, 1, 0, 0, 1, 1, 0], [0, 0, 0, 1, 1, 1, 1, 0], [1, 1, 1, 1, 1, 1, 1, 1]])
+    assert np.array_equal(H2.row_reduce(eye="right").numpy(), [[0, 1, 1, 1, 1, 0, 0, 0], [1, 0, 1, 1, 0, 1, 0, 0],
+                                                              [1, 1, 0, 1, 0, 0, 1, 0], [1, 1, 1, 0, 0, 0, 0, 1]])

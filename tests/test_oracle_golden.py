@@ -194,3 +194,36 @@ def test_reference_bch_outputs(tag):
     assert np.array_equal(nerr[ok], d[f"bch/{tag}/n_errors"][ok])
     assert np.array_equal(dec[ok], d[f"bch/{tag}/decoded"][ok])
     assert np.array_equal(B.message_of(dec[ok]), d[f"bch/{tag}/decoded_message"][ok])
+
+
+# ---- field linear algebra against the Sage fixtures of tests/fields/test_linalg.py -----
+@pytest.mark.parametrize("tag", H.SAGE_LINALG)
+def test_sage_linalg_fixtures(tag):
+    props, d = H.load_sage_linalg(tag)
+    F = H.oracle_field_from_props(props, lookup=props["order"] <= 2**16)
+    for X, Y, Z in H.linalg_cases(d, "matrix_multiply", "XYZ"):
+        H.assert_equal_ints(F.matmul(X, Y), Z, "matmul")
+    for X, Z in H.linalg_cases(d, "row_reduce", "XZ"):
+        H.assert_equal_ints(F.row_reduce(X)[0], Z, "row_reduce")
+    for X, L, U in H.linalg_cases(d, "lu_decompose", "XLU"):
+        l, u = F.lu_decompose(X)
+        H.assert_equal_ints(l, L, "lu L")
+        H.assert_equal_ints(u, U, "lu U")
+    for X, P, L, U in H.linalg_cases(d, "plu_decompose", "XPLU"):
+        p, l, u, _ = F.plu_decompose(X)
+        H.assert_equal_ints(p, P, "plu P")
+        H.assert_equal_ints(l, L, "plu L")
+        H.assert_equal_ints(u, U, "plu U")
+    for X, Z in H.linalg_cases(d, "matrix_inverse", "XZ"):
+        H.assert_equal_ints(F.inv(X), Z, "inv")
+    for X, Z in H.linalg_cases(d, "matrix_determinant", "XZ"):
+        assert F.det(X) == int(Z), "det"
+    for X, Y, Z in H.linalg_cases(d, "matrix_solve", "XYZ"):
+        H.assert_equal_ints(F.solve(X, Y), Z, "solve")
+    for op in ("row_space", "column_space", "left_null_space", "null_space"):
+        for X, Z in H.linalg_cases(d, op, "XZ"):
+            got = getattr(F, op)(X)
+            if Z.size == 0:
+                assert got.size == 0, op
+            else:
+                H.assert_equal_ints(got, Z.reshape(got.shape), op)
