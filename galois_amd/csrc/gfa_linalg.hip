@@ -23,9 +23,9 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 constexpr int MM_BM = 64, MM_BN = 64, MM_BK = 16, MM_THREADS = 256;
 
-// multiply-accumulate policy.  Default: acc = acc + a*b in the field.  Prime fields below 2^30 accumulate the raw
-// 64-bit products of one K-slab (16 * (p-1)^2 + p < 2^64) and reduce once per slab.
-template <class F, bool LAZY>
+// multiply-accumulate policy.  Default (FOLD = 0): acc = acc + a*b in the field.  Prime fields accumulate raw 64-bit
+// products and reduce every FOLD steps of k: FOLD = 16 for p < 2^30 (16 (p-1)^2 + p < 2^64), FOLD = 4 for p < 2^31.
+template <class F, int FOLD>
 struct Mac {
     typedef typename F::elem acc_t;
     static __device__ __forceinline__ void mac(const FieldDev &fd, acc_t &acc, typename F::elem a, typename F::elem b)
@@ -35,21 +35,23 @@ struct Mac {
     static __device__ __forceinline__ void fold(const FieldDev &, acc_t &) {}
     static __device__ __forceinline__ typename F::elem result(const FieldDev &, acc_t acc) { return acc; }
 };
-template <>
-struct Mac<Prime32, true> {
+template <int FOLD>
+struct MacLazy32 {
     typedef u64 acc_t;
     static __device__ __forceinline__ void mac(const FieldDev &, acc_t &acc, u32 a, u32 b) { acc += (u64)a * b; }
     static __device__ __forceinline__ void fold(const FieldDev &fd, acc_t &acc) { acc = Prime32::reduce64(fd, acc); }
     static __device__ __forceinline__ u32 result(const FieldDev &, acc_t acc) { return (u32)acc; }
 };
+template <> struct Mac<Prime32, 16> : MacLazy32<16> {};
+template <> struct Mac<Prime32, 4> : MacLazy32<4> {};
 
-template <class F, typename T, bool LAZY>
+template <class F, typename T, int FOLD>
 __global__ __launch_bounds__(MM_THREADS) void matmul_kernel(FieldDev fd, const T *__restrict__ A, const T *__restrict__ B,
                                                             T *__restrict__ C, int M, int K, int N, i64 a_bstride,
                                                             i64 b_bstride)
 {
     typedef typename F::elem E;
-    typedef Mac<F, LAZY> MAC;
+    typedef Mac<F, FOLD> MAC;
     __shared__ E As[MM_BK][MM_BM + 1]; // As[k][m]
     __shared__ E Bs[MM_BK][MM_BN + 1]; // Bs[k][n]
     const int batch = blockIdx.z;
@@ -88,11 +90,13 @@ __global__ __launch_bounds__(MM_THREADS) void matmul_kernel(FieldDev fd, const T
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) MAC::mac(fd, acc[i][j], av[i], bv[j]);
+            if (FOLD > 0 && (kk + 1) % (FOLD > 0 ? FOLD : 1) == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) MAC::fold(fd, acc[i][j]);
+            }
         }
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) MAC::fold(fd, acc[i][j]);
         __syncthreads();
     }
 #pragma unroll
@@ -175,13 +179,19 @@ int launch_matmul_ft(const FieldDev &fd, const void *a, const void *b, void *out
     const dim3 grid((unsigned)((N + MM_BN - 1) / MM_BN), (unsigned)((M + MM_BM - 1) / MM_BM), (unsigned)batch);
     if constexpr (std::is_same<F, Prime32>::value) {
         if (fd.p < (1ull << 30)) {
-            hipLaunchKernelGGL((matmul_kernel<F, T, true>), grid, dim3(MM_THREADS), 0, st, fd, (const T *)a, (const T *)b,
+            hipLaunchKernelGGL((matmul_kernel<F, T, 16>), grid, dim3(MM_THREADS), 0, st, fd, (const T *)a, (const T *)b,
+                               (T *)out, (int)M, (int)K, (int)N, a_bstride, b_bstride);
+            GFA_HIP(hipGetLastError());
+            return GFA_OK;
+        }
+        if (fd.p < (1ull << 31)) {
+            hipLaunchKernelGGL((matmul_kernel<F, T, 4>), grid, dim3(MM_THREADS), 0, st, fd, (const T *)a, (const T *)b,
                                (T *)out, (int)M, (int)K, (int)N, a_bstride, b_bstride);
             GFA_HIP(hipGetLastError());
             return GFA_OK;
         }
     }
-    hipLaunchKernelGGL((matmul_kernel<F, T, false>), grid, dim3(MM_THREADS), 0, st, fd, (const T *)a, (const T *)b,
+    hipLaunchKernelGGL((matmul_kernel<F, T, 0>), grid, dim3(MM_THREADS), 0, st, fd, (const T *)a, (const T *)b,
                        (T *)out, (int)M, (int)K, (int)N, a_bstride, b_bstride);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
@@ -237,17 +247,121 @@ __global__ __launch_bounds__(GJ_THREADS) void row_reduce_kernel(FieldDev fd, T *
         __syncthreads();
         for (int i = threadIdx.x; i < m; i += GJ_THREADS) factor[i] = i == p ? (E)0 : (E)A[(i64)i * n + j];
         __syncthreads();
-        // A[i, :] -= factor[i] * A[p, :] for every other row with a non-zero entry in column j
-        const i64 total = (i64)m * n;
-        for (i64 e = threadIdx.x; e < total; e += GJ_THREADS) {
-            const int i = (int)(e / n), c = (int)(e - (i64)i * n);
-            const E f = factor[i];
-            if (f != 0) A[e] = (T)F::sub(fd, (E)A[e], F::mul(fd, f, (E)A[(i64)p * n + c]));
+        // A[i, j:] -= factor[i] * A[p, j:] for every other row with a non-zero entry in column j (the pivot row is zero
+        // to the left of column j).  Threads tile (rows x columns) with a power-of-two column count: no integer division.
+        {
+            const int width = n - j;
+            int tcols = GJ_THREADS;
+            while (tcols > 1 && (tcols >> 1) >= width) tcols >>= 1;
+            const int lc = threadIdx.x & (tcols - 1), r0 = threadIdx.x / tcols, rstep = GJ_THREADS / tcols;
+            for (int c = j + lc; c < n; c += tcols) {
+                const E pv = (E)A[(i64)p * n + c];
+                if (pv == 0) continue;
+                for (int i = r0; i < m; i += rstep) {
+                    const E f = factor[i];
+                    if (f != 0) A[(i64)i * n + c] = (T)F::sub(fd, (E)A[(i64)i * n + c], F::mul(fd, f, pv));
+                }
+            }
         }
         __syncthreads();
         p++;
     }
     if (threadIdx.x == 0) rank_out[blockIdx.x] = p;
+}
+
+// ---- large matrices: the same elimination as two kernels per column, the update spread over the whole chip -----------
+struct GjState { int p, cur, has, pad; };
+
+template <class F, typename T>
+__global__ __launch_bounds__(1024) void gj_pivot_kernel(FieldDev fd, T *__restrict__ Aall, int m, int n, int j,
+                                                        GjState *__restrict__ state, u64 *__restrict__ factor_all)
+{
+    typedef typename F::elem E;
+    __shared__ int piv_row;
+    __shared__ E piv_inv;
+    T *A = Aall + (i64)blockIdx.x * m * n;
+    GjState *st = state + blockIdx.x;
+    u64 *factor = factor_all + (i64)blockIdx.x * m;
+    const int p = st->p;
+    if (threadIdx.x == 0) piv_row = m;
+    __syncthreads();
+    if (p < m)
+        for (int i = p + threadIdx.x; i < m; i += 1024)
+            if (A[(i64)i * n + j] != 0) { atomicMin(&piv_row, i); break; }
+    __syncthreads();
+    const int pr = piv_row;
+    if (pr >= m) {
+        if (threadIdx.x == 0) st->has = 0;
+        return;
+    }
+    if (threadIdx.x == 0) piv_inv = field_inv<F>(fd, (E)A[(i64)pr * n + j]);
+    __syncthreads();
+    const E inv = piv_inv;
+    // rows p and pr are zero left of column j (earlier pivot columns were cleared, earlier pivot-free columns were
+    // already zero from row p down), so the exchange and the scaling only touch columns >= j
+    for (int c = j + threadIdx.x; c < n; c += 1024) {
+        const E top = (E)A[(i64)p * n + c];
+        const E piv = F::mul(fd, (E)A[(i64)pr * n + c], inv);
+        if (pr != p) A[(i64)pr * n + c] = (T)top;
+        A[(i64)p * n + c] = (T)piv;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += 1024) factor[i] = i == p ? 0 : (u64)A[(i64)i * n + j];
+    if (threadIdx.x == 0) { st->cur = p; st->p = p + 1; st->has = 1; }
+}
+
+// grid: (column tiles of 64 starting at column j, row tiles of 32, batch)
+template <class F, typename T>
+__global__ __launch_bounds__(256) void gj_eliminate_kernel(FieldDev fd, T *__restrict__ Aall, int m, int n, int j,
+                                                           const GjState *__restrict__ state,
+                                                           const u64 *__restrict__ factor_all)
+{
+    typedef typename F::elem E;
+    const GjState st = state[blockIdx.z];
+    if (!st.has) return;
+    T *A = Aall + (i64)blockIdx.z * m * n;
+    const u64 *factor = factor_all + (i64)blockIdx.z * m;
+    const int c = j + blockIdx.x * 64 + (threadIdx.x & 63);
+    if (c >= n) return;
+    const E pv = (E)A[(i64)st.cur * n + c];
+    if (pv == 0) return;
+    const int r_end = min(m, (int)(blockIdx.y + 1) * 32);
+    for (int i = blockIdx.y * 32 + (threadIdx.x >> 6); i < r_end; i += 4) {
+        const E f = (E)factor[i];
+        if (f != 0) A[(i64)i * n + c] = (T)F::sub(fd, (E)A[(i64)i * n + c], F::mul(fd, f, pv));
+    }
+}
+
+__global__ void gj_finish_kernel(const GjState *__restrict__ state, i64 *__restrict__ rank_out, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch) rank_out[b] = state[b].p;
+}
+
+template <class F, typename T>
+int launch_row_reduce_wide_ft(const FieldDev &fd, void *a, i64 batch, i64 m, i64 n, i64 ncols, i64 *rank_out, hipStream_t st)
+{
+    GjState *state = nullptr;
+    u64 *factor = nullptr;
+    GFA_HIP(hipMallocAsync((void **)&state, sizeof(GjState) * (size_t)batch, st));
+    GFA_HIP(hipMallocAsync((void **)&factor, sizeof(u64) * (size_t)(batch * m), st));
+    GFA_HIP(hipMemsetAsync(state, 0, sizeof(GjState) * (size_t)batch, st));
+    for (i64 j = 0; j < ncols; j++) {
+        hipLaunchKernelGGL((gj_pivot_kernel<F, T>), dim3((unsigned)batch), dim3(1024), 0, st, fd, (T *)a, (int)m, (int)n, (int)j,
+                           state, factor);
+        const dim3 grid((unsigned)((n - j + 63) / 64), (unsigned)((m + 31) / 32), (unsigned)batch);
+        hipLaunchKernelGGL((gj_eliminate_kernel<F, T>), grid, dim3(256), 0, st, fd, (T *)a, (int)m, (int)n, (int)j, state, factor);
+    }
+    hipLaunchKernelGGL(gj_finish_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, state, rank_out, (int)batch);
+    GFA_HIP(hipGetLastError());
+    GFA_HIP(hipFreeAsync(state, st));
+    GFA_HIP(hipFreeAsync(factor, st));
+    return GFA_OK;
+}
+int dispatch_row_reduce_wide(const FieldDev &fd, int dtype, void *a, i64 batch, i64 m, i64 n, i64 ncols, i64 *rank_out,
+                             hipStream_t st)
+{
+    GFA_DISPATCH_FT(launch_row_reduce_wide_ft, fd, dtype, fd, a, batch, m, n, ncols, rank_out, st);
 }
 
 // lu_decompose_jit / plu_decompose_jit (_linalg.py:354-424) and det_jit (:447-477).
@@ -410,7 +524,7 @@ int gfa_matmul(gfa_field_t *f, const void *a, const void *b, void *out, int64_t 
             hipLaunchKernelGGL(matmul_tab8_kernel, grid, dim3(MM_THREADS), lds, (hipStream_t)stream, ds->mul8, (const uint8_t *)pa,
                                (const uint8_t *)pb, (uint8_t *)po, (int)M, (int)K, (int)N, (i64)a_batch_stride, (i64)b_batch_stride);
             GFA_HIP(hipGetLastError());
-        } else if (f->use_lookup()) {
+        } else if (f->use_lookup() && f->calc.m > 1) { // prime fields: integer products + lazy reduction, not log/exp gathers
             rc = dispatch_matmul(f->lut_desc(*ds), dtype, pa, pb, po, nb, M, K, N, a_batch_stride, b_batch_stride, (hipStream_t)stream);
         } else {
             rc = dispatch_matmul(f->calc, dtype, pa, pb, po, nb, M, K, N, a_batch_stride, b_batch_stride, (hipStream_t)stream);
@@ -427,7 +541,10 @@ int gfa_row_reduce(gfa_field_t *f, void *a, int64_t batch, int64_t m, int64_t n,
     if (!dtype_holds(dtype, f->calc.q)) { set_error("dtype cannot hold the field's elements"); return GFA_ERR_INVALID; }
     if (batch == 0) return GFA_OK;
     if (!rank_out || ((m > 0 && n > 0) && !a)) { set_error("gfa_row_reduce: bad arguments"); return GFA_ERR_INVALID; }
-    if (m > GJ_MAX_ROWS || n > (1 << 24)) { set_error("gfa_row_reduce: matrix too large (at most 4096 rows)"); return GFA_ERR_UNSUPPORTED; }
+    if ((m > GJ_MAX_ROWS && !(m * n >= 131072 && batch <= 32)) || n > (1 << 24) || m > (1 << 24)) {
+        set_error("gfa_row_reduce: stacks of matrices are limited to 4096 rows each");
+        return GFA_ERR_UNSUPPORTED;
+    }
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
@@ -435,8 +552,11 @@ int gfa_row_reduce(gfa_field_t *f, void *a, int64_t batch, int64_t m, int64_t n,
         GFA_HIP(hipMemsetAsync(rank_out, 0, sizeof(int64_t) * (size_t)batch, (hipStream_t)stream));
         return GFA_OK;
     }
-    if (f->use_lookup()) return dispatch_row_reduce(f->lut_desc(*ds), dtype, a, batch, m, n, ncols, (i64 *)rank_out, (hipStream_t)stream);
-    return dispatch_row_reduce(f->calc, dtype, a, batch, m, n, ncols, (i64 *)rank_out, (hipStream_t)stream);
+    const FieldDev fd = f->use_lookup() ? f->lut_desc(*ds) : f->calc;
+    // few large matrices: two kernels per column with the update spread over all CUs; otherwise one workgroup per matrix
+    if (m * n >= 131072 && batch <= 32 && batch <= 65535)
+        return dispatch_row_reduce_wide(fd, dtype, a, batch, m, n, ncols, (i64 *)rank_out, (hipStream_t)stream);
+    return dispatch_row_reduce(fd, dtype, a, batch, m, n, ncols, (i64 *)rank_out, (hipStream_t)stream);
 }
 
 int gfa_plu_decompose(gfa_field_t *f, void *a, void *l_out, void *p_out, int64_t batch, int64_t m, int64_t n, int pivoting,

@@ -182,6 +182,30 @@ def test_batched_extensions_and_sizes():
     assert np.array_equal((gA @ Ai).numpy(), np.eye(512, dtype=np.uint32))
 
 
+@pytest.mark.parametrize("tag,n", [("gf256", 384), ("gf65537", 400), ("gf2147483647", 370), ("gf3e5", 365)])
+def test_wide_elimination_path(tag, n):
+    """Matrices large enough for the two-kernels-per-column path: RREF, rank and inverse against the oracle, including a
+    rank-deficient matrix and a rectangular one with ncols < n."""
+    GF, F = _pair(tag)
+    rng = np.random.default_rng(31)
+    q = GF.order
+    A = _rand(rng, q, (n, n))
+    gA = GF(A)
+    Ai = np.linalg.inv(gA)
+    H.assert_equal_ints(Ai.numpy(), F.inv(A), "inv")
+    assert np.array_equal((gA @ Ai).numpy().astype(np.uint64), np.eye(n, dtype=np.uint64))
+    low = np.asarray(F.matmul(_rand(rng, q, (n, 7)), _rand(rng, q, (7, n + 40))))
+    low[5] = 0
+    rre, rank = F.row_reduce(low)
+    H.assert_equal_ints(GF(low).row_reduce().numpy(), rre, "rank-deficient RREF")
+    assert np.linalg.matrix_rank(GF(low)) == rank == 7
+    R = _rand(rng, q, (300, 500))
+    H.assert_equal_ints(GF(R).row_reduce(ncols=123).numpy(), F.row_reduce(R, ncols=123)[0], "ncols")
+    stack = GF(np.stack([A, A[::-1].copy()]))
+    rs, ranks = ga.linalg.row_reduce_batched(stack)
+    assert list(ranks) == [n, n] and np.array_equal(rs.numpy()[0].astype(np.uint64), np.eye(n, dtype=np.uint64))
+
+
 def test_exceptions():
     """tests/fields/test_linalg.py:15-36, 86-92, 123-132, 291-299, 321-329, 345-353, 394-420."""
     GF = ga.GF(2**8)
