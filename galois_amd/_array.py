@@ -45,6 +45,14 @@ def _to_storage(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     return wide.to(dtype)
 
 
+def _unsigned_less(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a < b on unsigned bit patterns held in signed torch storage (uint8 storage compares natively)."""
+    if a.dtype == torch.uint8:
+        return a < b
+    bias = torch.iinfo(a.dtype).min
+    return (a ^ bias) < (b ^ bias)
+
+
 def _device() -> torch.device:
     if not torch.cuda.is_available():
         raise RuntimeError(
@@ -672,8 +680,18 @@ class FieldArray(metaclass=FieldArrayMeta):
 
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
         cls = type(self)
-        if kwargs.get("out") is not None:
-            raise NotImplementedError("The `out=` keyword is not supported for device-resident field arrays.")
+        out = kwargs.pop("out", None)
+        if out is not None:
+            # the kernel result is written into the caller's array (_ufunc.py:309-319); same field and shape required
+            target = out[0] if isinstance(out, tuple) else out
+            if not (isinstance(out, tuple) and len(out) == 1 or isinstance(out, FieldArray)) or not isinstance(target, cls):
+                raise TypeError(f"Argument 'out' must be a {cls.name} array (or a 1-tuple holding one), not {type(target)}.")
+            result = self.__array_ufunc__(ufunc, method, *inputs, **kwargs)
+            if not isinstance(result, cls) or tuple(result.shape) != tuple(target.shape):
+                raise ValueError(f"Argument 'out' has shape {tuple(target.shape)} but the result has shape "
+                                 f"{tuple(getattr(result, 'shape', ()))}.")
+            target._t.copy_(_to_storage(result._t, target._t.dtype))
+            return target
         operands = list(range(len(inputs)))
         field_ops = [i for i in operands if isinstance(inputs[i], cls)]
         non_field = [i for i in operands if not isinstance(inputs[i], cls)]
@@ -736,9 +754,23 @@ class FieldArray(metaclass=FieldArrayMeta):
                 raise TypeError(f"Operation 'power' requires the first operand to be a {cls!r} array, not {type(inputs[0])}.")
             if isinstance(inputs[1], FieldArray):
                 raise TypeError(f"Operation 'power' requires the second operand to be an integer array, not {type(inputs[1])}.")
+            if method == "outer":
+                # np.power.outer(x, ints): shape x.shape + ints.shape (used by Vandermonde, _fields/_array.py:371-373)
+                base = inputs[0]
+                tk = base._int_operand(np.asarray(inputs[1]) if not isinstance(inputs[1], torch.Tensor) else inputs[1], "The exponent")
+                tb = base._t.reshape(tuple(base.shape) + (1,) * tk.dim())
+                return cls._wrap(tb, base._np_dtype)._with_int(tk.reshape((1,) * base.ndim + tuple(tk.shape)), is_pow=True)
             if method != "__call__":
                 raise NotImplementedError(f"Ufunc method {method!r} of 'power' is not implemented on the device.")
             return inputs[0]._with_int(inputs[1], is_pow=True)
+        if ufunc is np.log:
+            if method != "__call__":
+                raise ValueError(f"Ufunc method {method!r} is not supported on 'log'.")
+            return inputs[0].log()
+        if ufunc is np.sqrt:
+            if method != "__call__":
+                raise ValueError(f"Ufunc method {method!r} is not supported on 'sqrt'.")
+            return inputs[0]._sqrt()
         if ufunc is np.divmod and method == "__call__":
             same_field()
             q = self._binary(L.OP_DIV, inputs[0], inputs[1])
@@ -813,6 +845,103 @@ class FieldArray(metaclass=FieldArrayMeta):
 
     def __matmul__(self, o): return np.matmul(self, o)
     def __rmatmul__(self, o): return np.matmul(o, self)
+
+    # ---- discrete logarithm, squares and square roots --------------------------------------------------------------
+    def log(self, base=None):
+        """FieldArray.log (_fields/_array.py:2127-2200): integer array i with base**i == self; base defaults to the
+        field's primitive element.  Returns a host int64 array (a Python int for 0-D input), like the reference."""
+        cls = type(self)
+        if base is None:
+            t, sa, tb, sb, out_shape = self._t.contiguous(), 1, None, 0, tuple(self._t.shape)
+        else:
+            b = base if isinstance(base, cls) else cls(base)
+            t, sa, tb, sb, out_shape = self._broadcast(self._t, self._same_storage(b))
+        out = torch.empty(out_shape, dtype=torch.int64, device=t.device)
+        err = torch.zeros(1, dtype=torch.int32, device=t.device)
+        L.check(L.lib().gfa_log(cls._handle, _ptr(t), sa, _ptr(tb) if tb is not None else None, sb, _ptr(out), out.numel(),
+                                self._gfa_dtype(), _stream(), _ptr(err)), "gfa_log")
+        e = int(err.item())
+        if e & L.DEVERR_LOG_ZERO:
+            raise ArithmeticError("Cannot compute the discrete logarithm of 0 in a Galois field.")
+        if e & L.DEVERR_LOG_BASE:
+            raise ArithmeticError("The specified logarithm base is not a primitive element of the Galois field.")
+        res = out.cpu().numpy()
+        return int(res) if res.ndim == 0 else res
+
+    def is_square(self):
+        """FieldArray.is_square (_fields/_array.py:1340-1410): x is a square iff x == 0 or x^((q-1)/2) == 1; every
+        element of a characteristic-2 field is a square.  Returns a host bool array."""
+        cls = type(self)
+        if cls._characteristic == 2:
+            r = np.ones(tuple(self.shape), dtype=bool)
+        else:
+            w = self._with_int((cls._order - 1) // 2, is_pow=True)
+            r = ((w._t == 1) | (self._t == 0)).cpu().numpy()
+        return bool(r) if r.ndim == 0 else r
+
+    def _sqrt(self) -> "FieldArray":
+        """np.sqrt (sqrt_binary / sqrt, _domains/_calculate.py:758-832): the smaller of the two roots, as an integer."""
+        cls = type(self)
+        p, q = cls._characteristic, cls._order
+        if p == 2:
+            return self._with_int(2 ** (cls._degree - 1), is_pow=True)
+        sq = self.is_square()
+        if not np.all(sq):
+            bad = self.numpy()[~np.asarray(sq)] if self.ndim else self.numpy()
+            raise ArithmeticError(f"Input array has elements that are non-squares in {cls.name}.\n{bad}")
+        if q % 4 == 3:
+            roots = self._with_int((q + 1) // 4, is_pow=True)
+        elif q % 8 == 5:
+            d = self._with_int((q - 1) // 4, is_pow=True)
+            r1 = self._with_int((q + 3) // 8, is_pow=True)
+            four_a = self._with_int(4, is_pow=False)
+            r2 = self._with_int(2, is_pow=False) * four_a._with_int((q - 5) // 8, is_pow=True)
+            t = torch.where(d._t == 1, r1._t, torch.where(d._t == p - 1, r2._t, torch.zeros_like(r1._t)))
+            roots = cls._wrap(t, self._np_dtype)
+        else:
+            # Tonelli-Shanks with a fixed non-square b (any non-square gives the same final min(root, -root))
+            b = 2
+            while cls(b).is_square():
+                b += 1
+            n, s_ = q - 1, 0
+            while n % 2 == 0:
+                n >>= 1
+                s_ += 1
+            tt = n
+            minus_one = p - 1  # -1 is the constant p - 1 of the prime subfield (`d == p - 1`, _calculate.py:826)
+            nz = self._t != 0
+            safe = cls._wrap(torch.where(nz, self._t, torch.ones_like(self._t)), self._np_dtype)
+            a_inv = np.reciprocal(safe)
+            c = cls._scalar(L.OP_POW, b, tt)
+            r = safe._with_int((tt + 1) // 2, is_pow=True)
+            for i in range(1, s_):
+                dd = (r * r * a_inv)._with_int(2 ** (s_ - i - 1), is_pow=True)
+                rc = r * cls(c)
+                r = cls._wrap(torch.where(dd._t == minus_one, rc._t, r._t), self._np_dtype)
+                c = cls._scalar(L.OP_MUL, c, c)
+            roots = cls._wrap(torch.where(nz, r._t, torch.zeros_like(r._t)), self._np_dtype)
+        neg = np.negative(roots)
+        # np.minimum(roots, -roots) on the integer representations (field elements are non-negative)
+        small = torch.where(_unsigned_less(neg._t, roots._t), neg._t, roots._t)
+        return cls._wrap(small, self._np_dtype)
+
+    @classmethod
+    def Vandermonde(cls, element, rows: int, cols: int, dtype=None) -> "FieldArray":
+        """FieldArray.Vandermonde (_fields/_array.py:334-374): V[i, j] = (element**i)**j."""
+        if not isinstance(element, (int, np.integer, cls)):
+            raise TypeError(f"Argument 'element' must be an instance of (int, np.integer, {cls.name}), not {type(element)}.")
+        for name, v in (("rows", rows), ("cols", cols)):
+            if not isinstance(v, (int, np.integer)):
+                raise TypeError(f"Argument {name!r} must be an instance of int, not {type(v)}.")
+        if not rows > 0:
+            raise ValueError(f"Argument 'rows' must be non-negative, not {rows}.")
+        if not cols > 0:
+            raise ValueError(f"Argument 'cols' must be non-negative, not {cols}.")
+        element = element if isinstance(element, cls) else cls(int(element), dtype=dtype)
+        if not element.ndim == 0:
+            raise ValueError(f"Argument 'element' must be element scalar, not {element.ndim}-D.")
+        v = element ** np.arange(0, rows)
+        return np.power.outer(v, np.arange(0, cols))
 
     # ---- linear algebra methods (_fields/_array.py:1412-1760) -------------------------------------------------------
     def row_reduce(self, ncols=None, eye: str = "left"):

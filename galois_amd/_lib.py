@@ -23,6 +23,8 @@ OP_ADD, OP_SUB, OP_MUL, OP_DIV, OP_NEG, OP_RECIP, OP_POW = range(7)
 MODE_AUTO, MODE_LOOKUP, MODE_CALCULATE = 0, 1, 2
 DEVERR_ZERO_DIVISION = 1
 DEVERR_NO_LU = 2
+DEVERR_LOG_ZERO = 4
+DEVERR_LOG_BASE = 8
 
 c_void_p, c_int, c_i64, c_u64, c_u32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_uint64, ctypes.c_uint32
 _u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -50,6 +52,8 @@ SIGNATURES = {
     "gfa_convolve": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p]),
     "gfa_ntt": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_u64, c_int, c_int, c_void_p]),
     "gfa_ntt_columns": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_u64, c_int, c_void_p]),
+    "gfa_poly_evaluate": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    "gfa_log": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "gfa_matmul": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),
     "gfa_row_reduce": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_void_p, c_int, c_void_p]),
     "gfa_plu_decompose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p,

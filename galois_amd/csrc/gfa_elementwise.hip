@@ -565,6 +565,68 @@ int dispatch_convolve(const FieldDev &fd, int dtype, const void *a, i64 na, cons
 }
 
 
+// evaluate_elementwise_jit (_polys/_dense.py:432-440): y[i] = Horner(coeffs, x[i]), coefficients highest degree first.
+// The coefficient index is uniform across the wave, so the compiler keeps the coefficient stream in scalar loads.
+template <class F, typename T>
+__global__ __launch_bounds__(256) void poly_eval_kernel(FieldDev fd, const T *__restrict__ coeffs, i64 ncoef,
+                                                        const T *__restrict__ x, T *__restrict__ out, i64 n)
+{
+    typedef typename F::elem E;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        const E xv = (E)x[i];
+        E acc = (E)coeffs[0];
+        for (i64 j = 1; j < ncoef; j++) acc = F::add(fd, F::mul(fd, acc, xv), (E)coeffs[j]);
+        out[i] = (T)acc;
+    }
+}
+
+template <class F, typename T>
+int launch_poly_eval_ft(const FieldDev &fd, const void *coeffs, i64 ncoef, const void *x, void *out, i64 n, hipStream_t st)
+{
+    const int grid = grid_for(n, 256, 8);
+    hipLaunchKernelGGL((poly_eval_kernel<F, T>), dim3(grid), dim3(256), 0, st, fd, (const T *)coeffs, ncoef, (const T *)x, (T *)out, n);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+int dispatch_poly_eval(const FieldDev &fd, int dtype, const void *coeffs, i64 ncoef, const void *x, void *out, i64 n, hipStream_t st)
+{
+    GFA_DISPATCH_FT(launch_poly_eval_ft, fd, dtype, fd, coeffs, ncoef, x, out, n, st);
+}
+
+// log_ufunc.lookup (_domains/_lookup.py:273-294): out[i] = LOG[a[i]] for base alpha.  For another primitive element
+// beta (stride-0 scalar or an array): log_beta(a) = LOG[a] * LOG[beta]^-1 mod (q - 1); a base that is not primitive has
+// no inverse exponent and is flagged (the reference's search raises ArithmeticError for it, _calculate.py:617).
+template <typename T>
+__global__ __launch_bounds__(256) void log_lut_kernel(FieldDev fd, const T *__restrict__ a, int sa, const T *__restrict__ base,
+                                                      int sb, i64 *__restrict__ out, i64 n, int32_t *err)
+{
+    int bad = 0;
+    const i64 qm1 = (i64)fd.qm1;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        const u32 av = (u32)a[sa ? i : 0];
+        if (av == 0) { bad |= GFA_DEVERR_LOG_ZERO; out[i] = 0; continue; }
+        i64 la = fd.log_tab[av];
+        if (base) {
+            const u32 bv = (u32)base[sb ? i : 0];
+            if (bv == 0) { bad |= GFA_DEVERR_LOG_BASE; out[i] = 0; continue; }
+            const i64 lb = fd.log_tab[bv];
+            // inverse of lb modulo q - 1 by the extended Euclidean algorithm
+            i64 r0 = qm1, r1 = lb % qm1, t0 = 0, t1 = 1;
+            while (r1 != 0) {
+                const i64 qq = r0 / r1;
+                i64 tmp = r0 - qq * r1; r0 = r1; r1 = tmp;
+                tmp = t0 - qq * t1; t0 = t1; t1 = tmp;
+            }
+            if (r0 != 1 && qm1 != 1) { bad |= GFA_DEVERR_LOG_BASE; out[i] = 0; continue; }
+            if (t0 < 0) t0 += qm1;
+            la = qm1 == 1 ? 0 : (i64)(((unsigned __int128)(u64)la * (u64)t0) % (u64)qm1);
+        }
+        out[i] = la;
+    }
+    if (bad && err) atomicOr((int *)err, bad);
+}
+
 // ufunc.accumulate over the last axis: one workgroup per row, 256-element chunks scanned in LDS with a running carry.
 // mode 0: inclusive scan with the op; 1: out[i] = a0 - (a1 + ... + ai); 2: out[i] = a0 / (a1 * ... * ai)
 template <class F, typename T, bool IS_MUL>
@@ -818,6 +880,51 @@ int gfa_convolve(gfa_field_t *f, const void *a, int64_t na, const void *b, int64
     if (rc) return rc;
     if (f->use_lookup()) return dispatch_convolve(f->lut_desc(*ds), dtype, a, na, b, nb, out, (hipStream_t)stream);
     return dispatch_convolve(f->calc, dtype, a, na, b, nb, out, (hipStream_t)stream);
+}
+
+int gfa_poly_evaluate(gfa_field_t *f, const void *coeffs, int64_t ncoef, const void *x, void *out, int64_t n, int dtype,
+                      gfa_stream_t stream)
+{
+    if (!f || !coeffs || ncoef < 1 || n < 0) { set_error("gfa_poly_evaluate: bad arguments"); return GFA_ERR_INVALID; }
+    if (!dtype_holds(dtype, f->calc.q)) { set_error("dtype cannot hold the field's elements"); return GFA_ERR_INVALID; }
+    if (n == 0) return GFA_OK;
+    if (!x || !out) { set_error("gfa_poly_evaluate: bad arguments"); return GFA_ERR_INVALID; }
+    FieldDeviceState *ds;
+    int rc = f->ensure_device(nullptr, &ds);
+    if (rc) return rc;
+    if (f->use_lookup()) return dispatch_poly_eval(f->lut_desc(*ds), dtype, coeffs, ncoef, x, out, n, (hipStream_t)stream);
+    return dispatch_poly_eval(f->calc, dtype, coeffs, ncoef, x, out, n, (hipStream_t)stream);
+}
+
+int gfa_log(gfa_field_t *f, const void *a, int64_t a_stride, const void *base, int64_t base_stride, int64_t *out, int64_t n,
+            int dtype, gfa_stream_t stream, int32_t *dev_err)
+{
+    if (!f || n < 0 || (a_stride != 0 && a_stride != 1) || (base_stride != 0 && base_stride != 1)) {
+        set_error("gfa_log: bad arguments");
+        return GFA_ERR_INVALID;
+    }
+    if (!dtype_holds(dtype, f->calc.q)) { set_error("dtype cannot hold the field's elements"); return GFA_ERR_INVALID; }
+    if (!f->has_lut) {
+        set_error("gfa_log: discrete logarithms are implemented for fields with EXP/LOG tables (order <= 2^20)");
+        return GFA_ERR_UNSUPPORTED;
+    }
+    if (n == 0) return GFA_OK;
+    if (!a || !out) { set_error("gfa_log: bad arguments"); return GFA_ERR_INVALID; }
+    FieldDeviceState *ds;
+    int rc = f->ensure_device(nullptr, &ds);
+    if (rc) return rc;
+    const FieldDev fd = f->lut_desc(*ds);
+    const int grid = grid_for(n, 256, 8);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+    case GFA_U8: hipLaunchKernelGGL(log_lut_kernel<uint8_t>, dim3(grid), dim3(256), 0, st, fd, (const uint8_t *)a, (int)a_stride, (const uint8_t *)base, (int)base_stride, (i64 *)out, n, dev_err); break;
+    case GFA_U16: hipLaunchKernelGGL(log_lut_kernel<uint16_t>, dim3(grid), dim3(256), 0, st, fd, (const uint16_t *)a, (int)a_stride, (const uint16_t *)base, (int)base_stride, (i64 *)out, n, dev_err); break;
+    case GFA_U32: hipLaunchKernelGGL(log_lut_kernel<uint32_t>, dim3(grid), dim3(256), 0, st, fd, (const uint32_t *)a, (int)a_stride, (const uint32_t *)base, (int)base_stride, (i64 *)out, n, dev_err); break;
+    case GFA_U64: hipLaunchKernelGGL(log_lut_kernel<uint64_t>, dim3(grid), dim3(256), 0, st, fd, (const uint64_t *)a, (int)a_stride, (const uint64_t *)base, (int)base_stride, (i64 *)out, n, dev_err); break;
+    default: set_error("gfa_log: bad dtype"); return GFA_ERR_INVALID;
+    }
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
 }
 
 int gfa_time_binary(gfa_field_t *f, int op, const void *a, const void *b, void *out, int64_t n, int dtype,

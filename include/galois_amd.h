@@ -60,6 +60,8 @@ typedef enum {
 typedef enum { GFA_MODE_AUTO = 0, GFA_MODE_LOOKUP = 1, GFA_MODE_CALCULATE = 2 } gfa_mode;
 
 #define GFA_DEVERR_ZERO_DIVISION 1 /* reciprocal(0), x/0, 0**negative (_lookup.py:194-195, _calculate.py:403-404,536-537) */
+#define GFA_DEVERR_LOG_ZERO 4      /* log(0): ArithmeticError (_lookup.py:291-292, _calculate.py:613-614) */
+#define GFA_DEVERR_LOG_BASE 8      /* log base that is not a primitive element (_calculate.py:621) */
 #define GFA_DEVERR_NO_LU 2         /* lu_decompose needs a row exchange ("The LU decomposition of 'A' does not exist", _linalg.py:374) */
 
 /* ---- library -------------------------------------------------------------------------------------- */
@@ -113,6 +115,17 @@ int gfa_accumulate(gfa_field_t *f, int op, const void *a, void *out, int64_t n_o
  * through gfa_ntt instead (three transforms + one gfa_binary multiply). */
 int gfa_convolve(gfa_field_t *f, const void *a, int64_t na, const void *b, int64_t nb, void *out, int dtype,
                  gfa_stream_t stream);
+
+/* evaluate_elementwise_jit `int64[:](int64[:] coeffs_desc, int64[:] x)` (_polys/_dense.py:404-440): out[i] =
+ * poly(x[i]) by Horner's rule; `coeffs` holds ncoef coefficients, highest degree first, in device memory. */
+int gfa_poly_evaluate(gfa_field_t *f, const void *coeffs, int64_t ncoef, const void *x, void *out, int64_t n, int dtype,
+                      gfa_stream_t stream);
+/* log_ufunc (_domains/_lookup.py:273-294; FieldArray.log _fields/_array.py:2127-2200): out[i] = log_base(a[i]) as
+ * int64.  base == NULL: the field's primitive element.  Strides in {0, 1} as for gfa_binary.  a[i] == 0 ORs
+ * GFA_DEVERR_LOG_ZERO, a non-primitive base GFA_DEVERR_LOG_BASE into *dev_err (both ArithmeticError in the reference).
+ * Fields of order <= 2^20 (those with LOG tables); larger fields return GFA_ERR_UNSUPPORTED. */
+int gfa_log(gfa_field_t *f, const void *a, int64_t a_stride, const void *base, int64_t base_stride, int64_t *out, int64_t n,
+            int dtype, gfa_stream_t stream, int32_t *dev_err);
 
 /* ---- NTT: replaces fft_jit/ifft_jit `self.jit(x.astype(int64), int64(omega), factors)` (_domains/_function.py:201) *
  * Computes out[k] = sum_j in[j] * omega^(j*k) for each of `batch` contiguous length-n rows, natural order in and

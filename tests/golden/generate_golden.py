@@ -89,6 +89,35 @@ def pack_sage_linalg():
         print("packed linalg", folder)
 
 
+def pack_sage_polys():
+    """tests/polys/data/*/{evaluate,evaluate_matrix,add,subtract,multiply,scalar_multiply,derivative}.pkl (loaders
+    tests/polys/conftest.py) and tests/fields/data/*/log.pkl (tests/fields/conftest.py:257-262)."""
+    for folder in sorted(os.listdir(os.path.join(REF_TESTS, "polys", "data"))):
+        path = os.path.join(REF_TESTS, "polys", "data", folder)
+        fpath = os.path.join(REF_TESTS, "fields", "data", folder)
+        props = json.load(open(os.path.join(fpath, "properties.json")))
+        if props["order"] >= 2**64:
+            continue
+        out = {"properties": np.array(json.dumps(props))}
+        for op in ["add", "subtract", "multiply", "scalar_multiply", "derivative", "evaluate_matrix"]:
+            d = pickle.load(open(os.path.join(path, op + ".pkl"), "rb"))
+            out[f"{op}_count"] = np.array(len(d["X"]))
+            for k, vals in d.items():
+                for i, v in enumerate(vals):
+                    out[f"{op}{i}_{k}"] = small(np.asarray(v))
+        d = pickle.load(open(os.path.join(path, "evaluate.pkl"), "rb"))
+        out["evaluate_count"] = np.array(len(d["X"]))
+        out["evaluate_Y"] = small(np.asarray(d["Y"]))
+        for i, v in enumerate(d["X"]):
+            out[f"evaluate{i}_X"] = small(np.asarray(v))
+            out[f"evaluate{i}_Z"] = small(np.asarray(d["Z"][i]))
+        d = pickle.load(open(os.path.join(fpath, "log.pkl"), "rb"))
+        out["log_X"], out["log_Z"] = small(np.asarray(d["X"])), small(np.asarray(d["Z"]))
+        name = folder.replace("(", "_").replace(")", "").replace("^", "e").replace(", ", "_")
+        np.savez_compressed(os.path.join(HERE, f"sage_polys_{name}.npz"), **out)
+        print("packed polys", folder)
+
+
 def pack_sage_rs():
     out = {}
     names = []
@@ -338,13 +367,15 @@ def reference_bch_outputs():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["fields", "rs", "reference", "bch", "reference_bch", "linalg"]
+    what = sys.argv[1:] or ["fields", "rs", "reference", "bch", "reference_bch", "linalg", "polys"]
     if "fields" in what:
         pack_sage_fields()
     if "rs" in what:
         pack_sage_rs()
     if "reference" in what:
         reference_outputs()
+    if "polys" in what:
+        pack_sage_polys()
     if "linalg" in what:
         pack_sage_linalg()
     if "bch" in what:

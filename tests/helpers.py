@@ -95,3 +95,12 @@ def linalg_cases(d, op, keys):
     """Yields tuples of arrays (one per key) for every stored case of `op`."""
     for i in range(int(d[f"{op}_count"])):
         yield tuple(d[f"{op}{i}_{k}"] for k in keys)
+
+
+SAGE_POLYS = sorted(f[len("sage_polys_"):-4] for f in os.listdir(GOLDEN) if f.startswith("sage_polys_"))
+
+
+def load_sage_polys(tag):
+    d = np.load(os.path.join(GOLDEN, f"sage_polys_{tag}.npz"))
+    props = json.loads(str(d["properties"]))
+    return props, d

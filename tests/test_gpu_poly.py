@@ -1,0 +1,140 @@
+"""Parity of polynomial evaluation / arithmetic, discrete logarithms, square roots, Vandermonde matrices and the `out=`
+keyword against the reference's Sage fixtures and the oracle.  Bit-exact."""
+import numpy as np
+import pytest
+
+import galois_amd as ga
+from oracle import gf_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _field(props):
+    p, m = props["characteristic"], props["degree"]
+    if m == 1:
+        return ga.GF(p, primitive_element=int(props["primitive_element"]))
+    return ga.GF(p, m, irreducible_poly=H.poly_coeffs_to_int(props["irreducible_poly"], p),
+                 primitive_element=int(props["primitive_element"]))
+
+
+def _coeffs(p):
+    return [int(v) for v in p.coeffs.numpy()]
+
+
+@pytest.mark.parametrize("tag", H.SAGE_POLYS)
+def test_sage_poly_fixtures(tag):
+    """tests/polys/test_arithmetic.py + test_operations.py: evaluate (element-wise and matrix), +, -, *, scalar *, d/dx."""
+    props, d = H.load_sage_polys(tag)
+    GF = _field(props)
+    Y = GF(d["evaluate_Y"])
+    for i in range(int(d["evaluate_count"])):
+        poly = ga.Poly(d[f"evaluate{i}_X"], field=GF)
+        z = poly(Y)
+        assert type(z) is GF
+        H.assert_equal_ints(z.numpy(), d[f"evaluate{i}_Z"], "evaluate")
+        assert int(poly(Y[-1])) == int(d[f"evaluate{i}_Z"][-1])
+    for X, Ym, Z in H.linalg_cases(d, "evaluate_matrix", "XYZ"):
+        H.assert_equal_ints(ga.Poly(X, field=GF)(GF(Ym), elementwise=False).numpy(), Z, "evaluate_matrix")
+    for op, fn in (("add", lambda a, b: a + b), ("subtract", lambda a, b: a - b), ("multiply", lambda a, b: a * b)):
+        for X, Yp, Z in H.linalg_cases(d, op, "XYZ"):
+            assert _coeffs(fn(ga.Poly(X, field=GF), ga.Poly(Yp, field=GF))) == H.as_int_list(Z), op
+    for X, k, Z in H.linalg_cases(d, "scalar_multiply", "XYZ"):
+        assert _coeffs(ga.Poly(X, field=GF) * int(k)) == H.as_int_list(Z), "scalar_multiply"
+        assert _coeffs(int(k) * ga.Poly(X, field=GF)) == H.as_int_list(Z)
+    for X, k, Z in H.linalg_cases(d, "derivative", "XYZ"):
+        assert _coeffs(ga.Poly(X, field=GF).derivative(int(k))) == H.as_int_list(Z), "derivative"
+
+
+@pytest.mark.parametrize("tag", H.SAGE_POLYS)
+def test_sage_log_fixtures(tag):
+    """tests/fields/test_advanced_arithmetic.py log vectors; fields without LOG tables raise NotImplementedError."""
+    props, d = H.load_sage_polys(tag)
+    GF = _field(props)
+    x = GF(d["log_X"])
+    if GF.order > 2**20:
+        with pytest.raises(NotImplementedError):
+            np.log(x)
+        return
+    z = np.log(x)
+    H.assert_equal_ints(z, d["log_Z"], "log")
+    assert np.array_equal(x.log(), z)
+    assert np.array_equal((GF(GF.primitive_element) ** z).numpy(), x.numpy())
+    with pytest.raises(ArithmeticError):
+        np.log(GF([1, 0]))
+    if GF.order > 4:
+        # another primitive element as base (FieldArray.log docs, _fields/_array.py:2163-2179): beta = alpha^k, gcd(k, q-1) = 1
+        k = next(k for k in range(2, GF.order) if np.gcd(k, GF.order - 1) == 1)
+        beta = GF(GF.primitive_element) ** k
+        zb = x.log(beta)
+        assert np.array_equal((beta ** zb).numpy(), x.numpy())
+        assert 0 <= zb.min() and zb.max() < GF.order - 1
+    if (GF.order - 1) % 2 == 0 and GF.order > 3:
+        with pytest.raises(ArithmeticError):
+            x.log(GF(GF.primitive_element) ** 2)  # a square is not primitive
+
+
+@pytest.mark.parametrize("q", [2, 7, 13, 17, 2**3, 3**3, 5**3, 2**8, 31, 65537, 3**5, 7340033, 2147483647, 2**16, 109**2])
+def test_sqrt(q):
+    """tests/fields/test_sqrt.py: y*y == x and y is the smaller of the two roots; non-squares raise ArithmeticError.
+    The literal vectors of the reference's tests for GF(7), GF(13), GF(17) are included."""
+    GF = ga.GF(q)
+    rng = np.random.default_rng(q)
+    x = GF.Random(2000, seed=int(q)) if q > 2000 else GF(np.arange(q))
+    sq = x.is_square()
+    xs = GF(x.numpy()[sq])
+    y = np.sqrt(xs)
+    assert type(y) is GF
+    assert np.array_equal((y * y).numpy(), xs.numpy())
+    yn, ynn = y.numpy().astype(np.uint64), (-y).numpy().astype(np.uint64)
+    assert np.all(yn <= ynn)
+    if q % 2 and q > 2:
+        assert 0 < sq.sum() < sq.size or q <= 3
+        with pytest.raises(ArithmeticError):
+            np.sqrt(GF(x.numpy()[~sq][:3]))
+    else:
+        assert sq.all()
+    if q == 7:
+        assert np.array_equal(np.sqrt(GF([0, 1, 2, 4])).numpy(), [0, 1, 3, 2])
+    if q == 13:
+        assert np.array_equal(np.sqrt(GF([0, 1, 3, 4, 9, 10, 12])).numpy(), [0, 1, 4, 2, 3, 6, 5])
+    if q == 17:
+        assert np.array_equal(np.sqrt(GF([0, 1, 2, 4, 8, 9, 13, 15, 16])).numpy(), [0, 1, 6, 2, 5, 3, 8, 7, 4])
+
+
+def test_vandermonde_power_outer_and_out():
+    GF = ga.GF(2**8)
+    F = O.OracleField(2, 8, 285, 2, lookup=True)
+    V = GF.Vandermonde(GF.primitive_element, 7, 9)
+    want = np.array([[int(F.pow([int(F.pow([2], [i])[0])], [j])[0]) for j in range(9)] for i in range(7)])
+    assert V.shape == (7, 9) and np.array_equal(V.numpy(), want)
+    x = GF([3, 7, 200])
+    po = np.power.outer(x, np.array([[0, 1], [2, -1]]))
+    assert po.shape == (3, 2, 2)
+    for i, xv in enumerate([3, 7, 200]):
+        assert np.array_equal(po.numpy()[i].ravel(), F.pow([xv] * 4, [0, 1, 2, -1]))
+    with pytest.raises(ValueError):
+        GF.Vandermonde(2, 0, 3)
+    # out= (the result lands in the caller's array, _ufunc.py:309-319)
+    a, b = GF.Random(1000, seed=1), GF.Random(1000, seed=2)
+    out = GF.Zeros(1000)
+    r = np.multiply(a, b, out=out)
+    assert r is out and np.array_equal(out.numpy(), F.ufunc_u8(O.MUL, a.numpy(), b.numpy()))
+    np.add(a, b, out=(out,))
+    assert np.array_equal(out.numpy(), a.numpy() ^ b.numpy())
+    with pytest.raises(ValueError):
+        np.multiply(a, b, out=GF.Zeros(999))
+    with pytest.raises(TypeError):
+        np.multiply(a, b, out=np.zeros(1000, dtype=np.uint8))
+
+
+def test_poly_evaluate_large_against_oracle():
+    """Degree-255 polynomial at 2^20 points over GF(2^8) and GF(65537): Horner kernel vs the oracle's Horner."""
+    rng = np.random.default_rng(41)
+    for q, F in ((2**8, O.OracleField(2, 8, 285, 2, lookup=True)), (65537, O.OracleField(65537, 1, None, 3))):
+        GF = ga.GF(q)
+        c = rng.integers(1, q, 256)
+        x = rng.integers(0, q, 1 << 20)
+        got = ga.Poly(c, field=GF)(GF(x)).numpy()
+        idx = rng.integers(0, 1 << 20, 4096)
+        H.assert_equal_ints(got[idx], F.poly_eval(c, x[idx]))

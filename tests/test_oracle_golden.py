@@ -227,3 +227,21 @@ def test_sage_linalg_fixtures(tag):
                 assert got.size == 0, op
             else:
                 H.assert_equal_ints(got, Z.reshape(got.shape), op)
+
+
+# ---- polynomial evaluation / products and discrete logs ----------------------
+@pytest.mark.parametrize("tag", H.SAGE_POLYS)
+def test_sage_poly_and_log_fixtures(tag):
+    props, d = H.load_sage_polys(tag)
+    F = H.oracle_field_from_props(props, lookup=props["order"] <= 2**16)
+    Y = d["evaluate_Y"]
+    for i in range(int(d["evaluate_count"])):
+        H.assert_equal_ints(F.poly_eval(d[f"evaluate{i}_X"], Y), d[f"evaluate{i}_Z"], "evaluate")
+    for X, Yp, Z in H.linalg_cases(d, "multiply", "XYZ"):
+        got = F.convolve(X, Yp)
+        nz = np.nonzero(got)[0]
+        got = got[nz[0]:] if nz.size else got[-1:]
+        H.assert_equal_ints(got, Z, "multiply")
+    if props["order"] <= 2**20:
+        _, LOG, _, _ = F.tables()
+        H.assert_equal_ints(LOG[d["log_X"].astype(np.int64)], d["log_Z"], "log")
