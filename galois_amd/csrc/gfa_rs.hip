@@ -604,29 +604,33 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
 //   * Berlekamp-Massey with C(x) and x^m B(x) held one coefficient per lane in VGPRs, the discrepancy folded with DPP;
 //   * Chien search and Forney's formula in the log domain: lambda_k * x^k = EXP[LOG lambda_k + k LOG x], all terms
 //     independent, four codeword positions per lane in flight.
+// Per-wave LDS scratch with a compile-time layout: every array is `base + constant`, so the addresses ride in the
+// immediate offset field of the LDS instructions instead of ten live VGPRs (the kernel is register-bound).
+// S = slots per array (>= d - 1 + 4): 40 for n - k <= 36, 64 otherwise.  recv: n <= 256 bytes.
+template <int S>
 struct WaveScratch2 {
-    uint8_t *recv, *synd, *gamma, *sprime, *lam, *ltotal, *omega, *epos, *errpos, *errloc;
-    static __host__ __device__ int bytes(int n, int dd) { return ((n + 11 * (dd + 4) + 15) / 16) * 16; }
-    __device__ void carve(uint8_t *p, int n, int dd)
-    {
-        const int s = dd + 4;
-        recv = p; p += n;
-        synd = p; p += s; gamma = p; p += s; sprime = p; p += s; lam = p; p += s; ltotal = p; p += 2 * s;
-        omega = p; p += s; epos = p; p += s; errpos = p; p += s; errloc = p; p += s;
-    }
+    uint8_t *base;
+    static constexpr int BYTES = 256 + 10 * S;
+    __device__ __forceinline__ uint8_t *recv() const { return base; }
+    __device__ __forceinline__ uint8_t *synd() const { return base + 256; }
+    __device__ __forceinline__ uint8_t *gamma() const { return base + 256 + S; }
+    __device__ __forceinline__ uint8_t *sprime() const { return base + 256 + 2 * S; }
+    __device__ __forceinline__ uint8_t *lam() const { return base + 256 + 3 * S; }
+    __device__ __forceinline__ uint8_t *ltotal() const { return base + 256 + 4 * S; } // 2 S
+    __device__ __forceinline__ uint8_t *epos() const { return base + 256 + 6 * S; }
+    __device__ __forceinline__ uint8_t *errpos() const { return base + 256 + 7 * S; }
+    __device__ __forceinline__ uint8_t *errloc() const { return base + 256 + 8 * S; }
 };
 
-__device__ __forceinline__ int lane_shift_up1(int v, int lane)
-{ // lane i <- lane i-1, lane 0 <- 0
-    int t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); // row_shr:1, zero fill at each row start
-    const int r15 = __builtin_amdgcn_readlane(v, 15), r31 = __builtin_amdgcn_readlane(v, 31), r47 = __builtin_amdgcn_readlane(v, 47);
-    t = lane == 16 ? r15 : t;
-    t = lane == 32 ? r31 : t;
-    t = lane == 48 ? r47 : t;
-    return t;
+__device__ __forceinline__ int lane_shift_up1(int v, int)
+{ // lane i <- lane i-1 across the whole wavefront, lane 0 <- 0: one DPP move (wave_shr:1, GFX9 family incl. gfx950;
+  // checked on hardware by tools/ubench/wave_shr.hip).  The row_shr + 3 readlane + 3 select form it replaces cost 7.
+    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);
 }
 
-__global__ __launch_bounds__(1024, 8) void rs_decode_bin_kernel(RsTables t, RsParams rp, const uint8_t *__restrict__ recv_g,
+// WPS = resident waves per SIMD the register budget is sized for (block = 2 * WPS waves, two blocks per CU)
+template <int S, int WPS>
+__global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables t, RsParams rp, const uint8_t *__restrict__ recv_g,
                                                              const uint8_t *__restrict__ eras_g,
                                                              const uint8_t *__restrict__ rem_g, int n,
                                                              uint8_t *__restrict__ out_g, i64 *__restrict__ nerr_g, i64 batch)
@@ -636,14 +640,12 @@ __global__ __launch_bounds__(1024, 8) void rs_decode_bin_kernel(RsTables t, RsPa
     uint8_t *free_l = stage_tables<true>(lds_raw, t, ar, rp.qm1, blockDim.x);
     const int dd = rp.nroots, qm1 = rp.qm1, la = rp.log_alpha;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
-    WaveScratch2 ws;
-    ws.carve(free_l + (size_t)wave * WaveScratch2::bytes(n, dd), n, dd);
+    WaveScratch2<S> ws;
+    ws.base = free_l + (size_t)wave * WaveScratch2<S>::BYTES;
     __syncthreads();
     const unsigned long long lt_mask = ((unsigned long long)1 << lane) - 1;
     const int cm = rp.c % qm1;
-    const int jl = rp.nroots <= 32 ? (lane & 31) : lane;
-    const int lroot = (la * ((cm + jl) % qm1)) % qm1;   // LOG of root_j = alpha^(c+j), j = lane (mod 32 when n-k <= 32)
-    const int ZIDX = 2 * (qm1 + 1) - 1;                 // EXP[2q-1] == 0
+    const u32 xroot = ar.exp_t[(la * ((cm + lane) % qm1)) % qm1]; // root_j = alpha^(c+j), j = lane
 
     for (i64 cw = (i64)blockIdx.x * nwaves + wave; cw < batch; cw += (i64)gridDim.x * nwaves) {
         const uint8_t *row = recv_g + cw * n;
@@ -664,10 +666,10 @@ __global__ __launch_bounds__(1024, 8) void rs_decode_bin_kernel(RsTables t, RsPa
             if (i < n) {
                 const u32 r = row[n - 1 - i];
                 if (eras_g) er = eras_g[cw * n + (n - 1 - i)] != 0;
-                ws.recv[i] = er ? 0 : (uint8_t)r;
+                ws.recv()[i] = er ? 0 : (uint8_t)r;
             }
             const unsigned long long m = __ballot(er);
-            if (er && u + __popcll(m & lt_mask) < dd + 4) ws.epos[u + __popcll(m & lt_mask)] = (uint8_t)i;
+            if (er && u + __popcll(m & lt_mask) < dd + 4) ws.epos()[u + __popcll(m & lt_mask)] = (uint8_t)i;
             u += __popcll(m);
         }
         int status = 0, v = 0;
@@ -676,51 +678,30 @@ __global__ __launch_bounds__(1024, 8) void rs_decode_bin_kernel(RsTables t, RsPa
         } else if (!any_nz && u == 0) {
             status = 1;
         } else {
-            // ---- 1. syndromes from the remainder: S_j = sum_t rem_t * root_j^t ----
-            // For n-k <= 32 the two wave halves each take half of the terms of the same 32 syndromes (one exchange).
+            // ---- 1. syndromes from the remainder: S_j = rem(root_j) by Horner's rule through the product table ----
+            // (lane j evaluates at root_j; two VALU instructions + one LDS gather per term)
             {
-                const int lrem = remc ? (int)ar.log_t[remc] : -1;
-                u32 acc = 0;
-                if (dd <= 32) {
-                    const bool hi = lane >= 32;
-                    int e = hi ? (16 * lroot) % qm1 : 0;
-#pragma unroll 8
-                    for (int it = 0; it < 16; it++) {
-                        const int l0 = __builtin_amdgcn_readlane(lrem, it), l1 = __builtin_amdgcn_readlane(lrem, it + 16);
-                        const int lt = hi ? l1 : l0; // coefficients beyond n-k are zero (-1)
-                        acc ^= ar.exp_t[lt >= 0 ? lt + e : ZIDX];
-                        e += lroot;
-                        e = e >= qm1 ? e - qm1 : e;
-                    }
-                    acc ^= (u32)__shfl_xor((int)acc, 32);
-                } else {
-                    int e = 0;
-#pragma unroll 8
-                    for (int tt = 0; tt < dd; tt++) {
-                        const int lt = __builtin_amdgcn_readlane(lrem, tt);
-                        acc ^= ar.exp_t[lt >= 0 ? lt + e : ZIDX];
-                        e += lroot;
-                        e = e >= qm1 ? e - qm1 : e;
-                    }
-                }
-                if (lane < dd) ws.synd[lane] = (uint8_t)acc;
+                u32 acc = (u32)__builtin_amdgcn_readlane((int)remc, dd - 1);
+                for (int tt = dd - 2; tt >= 0; tt--)
+                    acc = ar.mul_t[(acc << 8) | xroot] ^ (u32)__builtin_amdgcn_readlane((int)remc, tt);
+                if (lane < dd) ws.synd()[lane] = (uint8_t)acc;
             }
             wave_sync();
             // ---- 2. erasure locator (_bch.py:1389-1393) ----
             int glen = 1;
-            if (lane == 0) ws.gamma[0] = 1;
+            if (lane == 0) ws.gamma()[0] = 1;
             wave_sync();
             for (int k = 0; k < u; k++) {
-                const int e = ws.epos[k];
+                const int e = ws.epos()[k];
                 const u32 Yk = ar.exp_t[(la * e) % qm1];
                 u32 g = 0;
                 if (lane <= glen) {
-                    const u32 gi = lane < glen ? ws.gamma[lane] : 0;
-                    const u32 gm = lane >= 1 ? ws.gamma[lane - 1] : 0;
+                    const u32 gi = lane < glen ? ws.gamma()[lane] : 0;
+                    const u32 gm = lane >= 1 ? ws.gamma()[lane - 1] : 0;
                     g = gi ^ ar.mul(gm, Yk);
                 }
                 wave_sync();
-                if (lane <= glen) ws.gamma[lane] = (uint8_t)g;
+                if (lane <= glen) ws.gamma()[lane] = (uint8_t)g;
                 glen++;
                 wave_sync();
             }
@@ -728,8 +709,8 @@ __global__ __launch_bounds__(1024, 8) void rs_decode_bin_kernel(RsTables t, RsPa
             if (lane < dd) {
                 u32 acc = 0;
                 const int imax = lane < glen - 1 ? lane : glen - 1;
-                for (int i = 0; i <= imax; i++) acc ^= ar.mul(ws.gamma[i], ws.synd[lane - i]);
-                ws.sprime[lane] = (uint8_t)acc;
+                for (int i = 0; i <= imax; i++) acc ^= ar.mul(ws.gamma()[i], ws.synd()[lane - i]);
+                ws.sprime()[lane] = (uint8_t)acc;
             }
             wave_sync();
             // ---- 4. Berlekamp-Massey on S'[u:], coefficients one per lane (_lfsr.py:1647-1702) ----
@@ -737,7 +718,7 @@ __global__ __launch_bounds__(1024, 8) void rs_decode_bin_kernel(RsTables t, RsPa
             const int nsq = dd - u;
             u32 Creg = lane == 0 ? 1u : 0u;
             if (nsq > 0) {
-                const int Sall = lane < nsq ? (int)ws.sprime[u + lane] : 0;
+                const int Sall = lane < nsq ? (int)ws.sprime()[u + lane] : 0;
                 // Bs holds x^m * B(x) / b, so the update C -= (d/b) x^m B is ONE table gather on the critical path
                 u32 Bs = (lane == 1 && nsq > 1) ? 1u : 0u; // m = 1, B = 1, b = 1
                 int Sreg = 0;                               // S[k - lane]
@@ -764,7 +745,7 @@ __global__ __launch_bounds__(1024, 8) void rs_decode_bin_kernel(RsTables t, RsPa
                 const unsigned long long mk = __ballot(lane < clen && Creg != 0);
                 llen = mk ? 64 - __clzll((long long)mk) : 1;
             }
-            if (lane < dd + 4) ws.lam[lane] = lane < llen ? (uint8_t)Creg : 0;
+            if (lane < dd + 4) ws.lam()[lane] = lane < llen ? (uint8_t)Creg : 0;
             v = llen - 1;
             wave_sync();
             if (2 * v + u > dd) {
@@ -777,29 +758,21 @@ __global__ __launch_bounds__(1024, 8) void rs_decode_bin_kernel(RsTables t, RsPa
                     const int ilo = lane - (llen - 1) > 0 ? lane - (llen - 1) : 0;
                     const int ihi = lane < glen - 1 ? lane : glen - 1;
 #pragma unroll 4
-                    for (int i = ilo; i <= ihi; i++) ltk ^= ar.mul(ws.gamma[i], ws.lam[lane - i]);
-                    ws.ltotal[lane] = (uint8_t)ltk;
+                    for (int i = ilo; i <= ihi; i++) ltk ^= ar.mul(ws.gamma()[i], ws.lam()[lane - i]);
+                    ws.ltotal()[lane] = (uint8_t)ltk;
                 }
-                const int ltl = (lane < ltlen && ltk) ? (int)ar.log_t[ltk] : -1; // LOG of coefficient `lane`
-                // ---- 6. Chien search, log domain, positions lane, lane+64, lane+128, lane+192 ----
-                int stepn[4], ee[4];
-                u32 acc[4];
+                // ---- 6. Chien search: Lambda_total(alpha^-i) by Horner's rule, positions lane, lane+64, lane+128, lane+192
+                u32 xinv[4], acc[4];
 #pragma unroll
                 for (int s4 = 0; s4 < 4; s4++) {
                     const int i = lane + 64 * s4;
-                    stepn[s4] = (qm1 - (la * i) % qm1) % qm1; // LOG alpha^(-i)
-                    ee[s4] = 0;
-                    acc[s4] = 0;
+                    xinv[s4] = ar.exp_t[(qm1 - (la * i) % qm1) % qm1]; // alpha^(-i)
+                    acc[s4] = (u32)__builtin_amdgcn_readlane((int)ltk, ltlen - 1);
                 }
-#pragma unroll 2
-                for (int k = 0; k < ltlen; k++) {
-                    const int lk = __builtin_amdgcn_readlane(ltl, k);
+                for (int k = ltlen - 2; k >= 0; k--) {
+                    const u32 lk = (u32)__builtin_amdgcn_readlane((int)ltk, k);
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; s4++) {
-                        acc[s4] ^= ar.exp_t[lk >= 0 ? lk + ee[s4] : ZIDX];
-                        ee[s4] += stepn[s4];
-                        ee[s4] = ee[s4] >= qm1 ? ee[s4] - qm1 : ee[s4];
-                    }
+                    for (int s4 = 0; s4 < 4; s4++) acc[s4] = ar.mul_t[(acc[s4] << 8) | xinv[s4]] ^ lk;
                 }
                 int v_total = 0;
                 bool out_of_range_root = false;
@@ -812,7 +785,7 @@ __global__ __launch_bounds__(1024, 8) void rs_decode_bin_kernel(RsTables t, RsPa
                     const unsigned long long mk = __ballot(rec);
                     if (rec) {
                         const int slot = v_total + __popcll(mk & lt_mask);
-                        if (slot < dd + 4) { ws.errpos[slot] = (uint8_t)i; ws.errloc[slot] = (uint8_t)ar.exp_t[stepn[s4]]; }
+                        if (slot < dd + 4) { ws.errpos()[slot] = (uint8_t)i; ws.errloc()[slot] = (uint8_t)xinv[s4]; }
                     }
                     v_total += __popcll(mk);
                 }
@@ -825,70 +798,29 @@ __global__ __launch_bounds__(1024, 8) void rs_decode_bin_kernel(RsTables t, RsPa
                     if (lane < dd) {
                         const int ihi = lane < llen - 1 ? lane : llen - 1;
 #pragma unroll 4
-                        for (int i = 0; i <= ihi; i++) om ^= ar.mul(ws.lam[i], ws.sprime[lane - i]);
+                        for (int i = 0; i <= ihi; i++) om ^= ar.mul(ws.lam()[i], ws.sprime()[lane - i]);
                     }
-                    const int lom = om ? (int)ar.log_t[om] : -1;
-                    // ---- 8./9./10. Forney in the log domain, one located symbol per lane ----
-                    // (char 2: the formal derivative keeps the odd-degree coefficients of Lambda_total, _bch.py:1512-1515)
+                    // ---- 8./9./10. Forney, one located symbol per lane: numerator Omega'(x) and denominator
+                    // Lambda_total'(x) by Horner's rule at x = X^-1.  Characteristic 2: the formal derivative keeps the
+                    // odd-degree coefficients (_bch.py:1512-1515), i.e. it is a polynomial in x^2.
                     const int L_total = ltlen - 1;
-                    u32 num = 0, den = 0;
-                    int lx = 0;
-                    bool act = lane < v_total;
-                    if (dd <= 32) {
-                        // located symbol e = lane & 31; the wave halves split the terms of both evaluations
-                        const bool hi = lane >= 32;
-                        const int el = lane & 31;
-                        act = el < v_total;
-                        if (act) lx = ar.log_t[ws.errloc[el]];
-                        int e = hi ? (16 * lx) % qm1 : 0;
-#pragma unroll 8
-                        for (int it = 0; it < 16; it++) {
-                            const int l0 = __builtin_amdgcn_readlane(lom, it), l1 = __builtin_amdgcn_readlane(lom, it + 16);
-                            const int lo = hi ? l1 : l0;
-                            num ^= ar.exp_t[lo >= 0 ? lo + e : ZIDX];
-                            e += lx;
-                            e = e >= qm1 ? e - qm1 : e;
-                        }
-                        int lx2 = 2 * lx;
-                        lx2 = lx2 >= qm1 ? lx2 - qm1 : lx2;
-                        int e2 = hi ? (8 * lx2) % qm1 : 0; // odd j = 2*jj + 1, exponent (j-1) = 2*jj; upper half starts at jj = 8
-#pragma unroll 8
-                        for (int it = 0; it < 8; it++) {
-                            const int l0 = __builtin_amdgcn_readlane(ltl, 2 * it + 1), l1 = __builtin_amdgcn_readlane(ltl, 2 * it + 17);
-                            const int lj = hi ? l1 : l0; // lanes >= ltlen hold -1
-                            den ^= ar.exp_t[lj >= 0 ? lj + e2 : ZIDX];
-                            e2 += lx2;
-                            e2 = e2 >= qm1 ? e2 - qm1 : e2;
-                        }
-                        num ^= (u32)__shfl_xor((int)num, 32);
-                        den ^= (u32)__shfl_xor((int)den, 32);
-                        act = act && !hi;
-                    } else {
-                        if (act) lx = ar.log_t[ws.errloc[lane]];
-                        int e = 0;
-#pragma unroll 8
-                        for (int tt = 0; tt < dd; tt++) {
-                            const int lo = __builtin_amdgcn_readlane(lom, tt);
-                            num ^= ar.exp_t[lo >= 0 ? lo + e : ZIDX];
-                            e += lx;
-                            e = e >= qm1 ? e - qm1 : e;
-                        }
-                        int e2 = 0, lx2 = 2 * lx;
-                        lx2 = lx2 >= qm1 ? lx2 - qm1 : lx2;
-#pragma unroll 4
-                        for (int j = 1; j <= L_total; j += 2) {
-                            const int lj = __builtin_amdgcn_readlane(ltl, j);
-                            den ^= ar.exp_t[lj >= 0 ? lj + e2 : ZIDX];
-                            e2 += lx2;
-                            e2 = e2 >= qm1 ? e2 - qm1 : e2;
-                        }
+                    const bool act = lane < v_total;
+                    const u32 x = act ? (u32)ws.errloc()[lane] : 0u;
+                    u32 num = (u32)__builtin_amdgcn_readlane((int)om, dd - 1);
+                    for (int tt = dd - 2; tt >= 0; tt--) num = ar.mul_t[(num << 8) | x] ^ (u32)__builtin_amdgcn_readlane((int)om, tt);
+                    const u32 x2 = ar.mul_t[(x << 8) | x];
+                    const int jtop = (L_total & 1) ? L_total : L_total - 1; // highest odd degree
+                    u32 den = 0;
+                    if (jtop >= 1) {
+                        den = (u32)__builtin_amdgcn_readlane((int)ltk, jtop);
+                        for (int j = jtop - 2; j >= 1; j -= 2) den = ar.mul_t[(den << 8) | x2] ^ (u32)__builtin_amdgcn_readlane((int)ltk, j);
                     }
                     if (act && num != 0 && den != 0) {
-                        int ex = (int)ar.log_t[num] - (int)ar.log_t[den] + ((rp.c - 1) % qm1) * lx;
+                        int ex = (int)ar.log_t[num] - (int)ar.log_t[den] + ((rp.c - 1) % qm1) * (int)ar.log_t[x];
                         ex %= qm1;
                         if (ex < 0) ex += qm1;
-                        const int pos = ws.errpos[lane & 63];
-                        ws.recv[pos] ^= ar.exp_t[ex];
+                        const int pos = ws.errpos()[lane];
+                        ws.recv()[pos] ^= ar.exp_t[ex];
                     }
                     wave_sync();
                     status = 0;
@@ -896,7 +828,7 @@ __global__ __launch_bounds__(1024, 8) void rs_decode_bin_kernel(RsTables t, RsPa
             }
         }
         if (status == 0) {
-            for (int j = lane; j < n; j += 64) orow[j] = ws.recv[n - 1 - j];
+            for (int j = lane; j < n; j += 64) orow[j] = ws.recv()[n - 1 - j];
         } else {
             for (int j = lane; j < n; j += 64) orow[j] = row[j];
         }
@@ -1383,16 +1315,38 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
                 return rc;
             const RsParams rp = make_params(code);
             const size_t fixed = 65536 + 1280;
-            const size_t per_wave = (size_t)WaveScratch2::bytes((int)ns, nk);
-            const int nwaves = 16;
+            const bool small = nk + 4 <= 40;
+            const size_t per_wave = small ? WaveScratch2<40>::BYTES : WaveScratch2<64>::BYTES;
+            static int wps = 0;
+            if (!wps) { const char *e = getenv("GFA_RS_WPS"); wps = e ? atoi(e) : 8; if (wps != 4 && wps != 5 && wps != 6) wps = 8; }
+            const int nwaves = 2 * wps;
             const size_t lds = fixed + nwaves * per_wave;
-            static bool attr = false;
-            if ((rc = set_lds_limit(rs_decode_bin_kernel, &attr))) return rc;
             const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
             const int grid = (int)std::max<i64>(1, std::min<i64>((batch + nwaves - 1) / nwaves, (i64)cu_count() * per_cu));
-            hipLaunchKernelGGL(rs_decode_bin_kernel, dim3(grid), dim3(nwaves * 64), lds, st, make_tables(*ds), rp,
-                               (const uint8_t *)recv, erasures, cd->rem, (int)ns, (uint8_t *)out_codeword, (i64 *)out_n_errors,
-                               batch);
+#define GFA_K2(SV, W, IDX)                                                                                              \
+    do {                                                                                                                \
+        static bool attr = false;                                                                                       \
+        if ((rc = set_lds_limit(rs_decode_bin_kernel<SV, W>, &attr))) return rc;                                        \
+        hipLaunchKernelGGL((rs_decode_bin_kernel<SV, W>), dim3(grid), dim3(nwaves * 64), lds, st, make_tables(*ds), rp, \
+                           (const uint8_t *)recv, erasures, cd->rem, (int)ns, (uint8_t *)out_codeword,                  \
+                           (i64 *)out_n_errors, batch);                                                                 \
+    } while (0)
+            if (small) {
+                switch (wps) {
+                case 4: GFA_K2(40, 4, 0); break;
+                case 5: GFA_K2(40, 5, 1); break;
+                case 6: GFA_K2(40, 6, 2); break;
+                default: GFA_K2(40, 8, 3); break;
+                }
+            } else {
+                switch (wps) {
+                case 4: GFA_K2(64, 4, 4); break;
+                case 5: GFA_K2(64, 5, 5); break;
+                case 6: GFA_K2(64, 6, 6); break;
+                default: GFA_K2(64, 8, 7); break;
+                }
+            }
+#undef GFA_K2
             GFA_HIP(hipGetLastError());
             return GFA_OK;
         }
