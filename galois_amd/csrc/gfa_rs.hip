@@ -718,28 +718,54 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
             const int nsq = dd - u;
             u32 Creg = lane == 0 ? 1u : 0u;
             if (nsq > 0) {
-                const int Sall = lane < nsq ? (int)ws.sprime()[u + lane] : 0;
-                // Bs holds x^m * B(x) / b, so the update C -= (d/b) x^m B is ONE table gather on the critical path
-                u32 Bs = (lane == 1 && nsq > 1) ? 1u : 0u; // m = 1, B = 1, b = 1
-                int Sreg = 0;                               // S[k - lane]
                 int L = 0;
-                for (int k = 0; k < nsq; k++) {
-                    Sreg = lane_shift_up1(Sreg, lane);
-                    const int sk = __builtin_amdgcn_readlane(Sall, k);
-                    if (lane == 0) Sreg = sk;
-                    const u32 term = lane <= L ? ar.mul((u32)Sreg, Creg) : 0u;
-                    const u32 dsc = ar.wave_sum(term);
-                    u32 nextB = Bs;
-                    if (dsc != 0) {
-                        const u32 cnew = Creg ^ ar.mul(dsc, Bs);
-                        if (!(2 * L > k)) {
-                            nextB = ar.mul(ar.inv(dsc), Creg); // new B / new b = C_old / d
-                            L = k + 1 - L;
-                        }
-                        Creg = cnew;
+                if (dd <= 32) {
+                    // Inversionless Berlekamp-Massey without a discrepancy reduction (the RiBM arrangement of Sarwate &
+                    // Shanbhag): lanes 0..31 hold Lambda (X) and B (Y), lanes 32.. hold the coefficients r.. of
+                    // Lambda*S (X) and B*S (Y), so the discrepancy of step r is simply X[32].  One step for every lane:
+                    //     X' = gamma*A - d0*Bv,  Y' = (d0 != 0 && 2L <= r) ? A : Bv
+                    // with (A, Bv) = (X, Y shifted up) in the locator half and (X shifted down, Y) in the product half.
+                    // Lambda comes out multiplied by a non-zero constant; Omega' = Lambda*S' carries the same constant
+                    // and Forney's quotient, the roots and the degree are unchanged.  7 VALU + 2 gathers per step
+                    // instead of ~25 + 2 for the division form with a wave-wide XOR reduction.
+                    u32 X = lane == 0 ? 1u : ((lane >= 32 && lane - 32 < nsq) ? (u32)ws.sprime()[u + lane - 32] : 0u);
+                    u32 Y = X;
+                    u32 gamma = 1;
+                    for (int r = 0; r < nsq; r++) {
+                        const u32 d0 = (u32)__builtin_amdgcn_readlane((int)X, 32);
+                        const u32 A = (u32)__builtin_amdgcn_update_dpp((int)X, (int)X, 0x130, 0xC, 0xf, true);  // wave_shl:1, rows 2-3
+                        const u32 Bv = (u32)__builtin_amdgcn_update_dpp((int)Y, (int)Y, 0x138, 0x3, 0xf, true); // wave_shr:1, rows 0-1
+                        const u32 t1 = ar.mul_t[(gamma << 8) | A];
+                        const u32 t2 = ar.mul_t[(d0 << 8) | Bv];
+                        const bool change = d0 != 0 && 2 * L <= r;
+                        Y = change ? A : Bv;
+                        X = t1 ^ t2;
+                        if (change) { L = r + 1 - L; gamma = d0; }
                     }
-                    const int sh = lane_shift_up1((int)nextB, lane);
-                    Bs = lane < nsq ? (u32)sh : 0u;
+                    Creg = lane < 32 ? X : 0u;
+                } else {
+                    const int Sall = lane < nsq ? (int)ws.sprime()[u + lane] : 0;
+                    // Bs holds x^m * B(x) / b, so the update C -= (d/b) x^m B is ONE table gather on the critical path
+                    u32 Bs = (lane == 1 && nsq > 1) ? 1u : 0u; // m = 1, B = 1, b = 1
+                    int Sreg = 0;                               // S[k - lane]
+                    for (int k = 0; k < nsq; k++) {
+                        Sreg = lane_shift_up1(Sreg, lane);
+                        const int sk = __builtin_amdgcn_readlane(Sall, k);
+                        if (lane == 0) Sreg = sk;
+                        const u32 term = lane <= L ? ar.mul((u32)Sreg, Creg) : 0u;
+                        const u32 dsc = ar.wave_sum(term);
+                        u32 nextB = Bs;
+                        if (dsc != 0) {
+                            const u32 cnew = Creg ^ ar.mul(dsc, Bs);
+                            if (!(2 * L > k)) {
+                                nextB = ar.mul(ar.inv(dsc), Creg); // new B / new b = C_old / d
+                                L = k + 1 - L;
+                            }
+                            Creg = cnew;
+                        }
+                        const int sh = lane_shift_up1((int)nextB, lane);
+                        Bs = lane < nsq ? (u32)sh : 0u;
+                    }
                 }
                 const int clen = L + 1 < nsq ? L + 1 : nsq;
                 const unsigned long long mk = __ballot(lane < clen && Creg != 0);
