@@ -301,7 +301,7 @@ def extras(ga, L, lib, stream, with_cpu):
         "decode_algorithmic_GB/s": round(486.0 * B / (dec_ms * 1e-3) / 1e9, 2),
         "encode_roofline_frac": round(478.0 * B / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
         "decode_roofline_frac": round(486.0 * B / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-        "note": "decode is LDS-gather bound, not HBM bound (SURVEY.md section 7)",
+        "note": "decode is VALU-issue bound (PMC: LDS busy 27 %), not HBM bound; see DESIGN.md section 4.1",
     }
     # the two extremes benchmarks/test_fec.py uses: no errors, and t = 16 errors in every codeword
     Rd.copy_(Cd)

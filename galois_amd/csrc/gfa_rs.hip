@@ -500,7 +500,11 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
                 stage[row * ns_out + ((u32)b - row * (u32)len)] = src[b];
             }
         } else {
-            const bool al = ((reinterpret_cast<uintptr_t>(src) | (eras ? reinterpret_cast<uintptr_t>(eras + cw0 * len) : 0)) & 15) == 0;
+            // decoder pre-pass: `out` (if given and not the input itself) receives a verbatim copy of the received rows, so
+            // that the wave kernel only has to patch the corrected symbols (failed words stay "received row unchanged")
+            uint8_t *cp = (!ENCODE && out && out != in) ? out + cw0 * len : nullptr;
+            const bool al = ((reinterpret_cast<uintptr_t>(src) | (eras ? reinterpret_cast<uintptr_t>(eras + cw0 * len) : 0) |
+                              reinterpret_cast<uintptr_t>(cp)) & 15) == 0;
             int done = 0;
             if (al) {
                 const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
@@ -509,6 +513,7 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
                 const int nv = nbytes >> 4;
                 for (int i = lane; i < nv; i += 64) {
                     uint4 v = s4[i];
+                    if (cp) reinterpret_cast<uint4 *>(cp)[i] = v;
                     if (e4) { // erased symbols are treated as zeros (_bch.py:1355): byte mask from "non-zero"
                         const uint4 e = e4[i];
                         auto mask = [](u32 w) -> u32 { return ((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) >> 7 & 0x01010101u) * 0xffu; };
@@ -520,6 +525,7 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
             }
             for (int i = done + lane; i < nbytes; i += 64) {
                 uint8_t v = src[i];
+                if (cp) cp[i] = v;
                 if (eras && eras[cw0 * len + i]) v = 0;
                 stage[i] = v;
             }
@@ -597,13 +603,15 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
 // ------------------------------------------------------------------------------------------------
 // Fast decoder for characteristic-2 codes with n-k <= 60: second kernel of the two-kernel decode
 // ------------------------------------------------------------------------------------------------
-// rs_lfsr_kernel has already reduced every received word modulo g(x).  Words with a zero remainder and no erasures
-// are copied through.  The rest are decoded ONE CODEWORD PER WAVEFRONT with the same mathematics and failure exits as
-// rs_decode_kernel / bch_decode_jit, arranged so that almost no step is a chain of dependent LDS gathers:
-//   * syndromes S_j = rem(alpha^(c+j)) from the (n-k)-term remainder, in the log domain (independent gathers);
-//   * Berlekamp-Massey with C(x) and x^m B(x) held one coefficient per lane in VGPRs, the discrepancy folded with DPP;
-//   * Chien search and Forney's formula in the log domain: lambda_k * x^k = EXP[LOG lambda_k + k LOG x], all terms
-//     independent, four codeword positions per lane in flight.
+// rs_lfsr_kernel has already reduced every received word modulo g(x) and copied the received rows to the output.  Words
+// with a zero remainder and no erasures need nothing more.  The rest are decoded ONE CODEWORD PER WAVEFRONT with the same
+// mathematics and failure exits as rs_decode_kernel / bch_decode_jit; the kernel is VALU-issue bound (PMC: LDS busy 27 %),
+// so every stage is arranged for the fewest vector instructions:
+//   * syndromes S_j = rem(root_j), Chien search Lambda_total(alpha^-i) (four positions per lane) and Forney's numerator /
+//     denominator are Horner recurrences through the 64 KiB LDS product table: per term one v_lshl_or (index), one byte
+//     gather, one v_xor with the broadcast coefficient;
+//   * Berlekamp-Massey in the inversionless RiBM arrangement: no discrepancy reduction, 7 VALU + 2 gathers per step;
+//   * corrected symbols are patched into the output row in place (erased symbols become E, others r ^ E).
 // Per-wave LDS scratch with a compile-time layout: every array is `base + constant`, so the addresses ride in the
 // immediate offset field of the LDS instructions instead of ten live VGPRs (the kernel is register-bound).
 // S = slots per array (>= d - 1 + 4): 40 for n - k <= 36, 64 otherwise.  recv: n <= 256 bytes.
@@ -639,6 +647,7 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
     Arith8<true> ar;
     uint8_t *free_l = stage_tables<true>(lds_raw, t, ar, rp.qm1, blockDim.x);
     const int dd = rp.nroots, qm1 = rp.qm1, la = rp.log_alpha;
+    const int nk = rp.n - rp.k; // length of the remainder r(x) mod g(x); equals dd for Reed-Solomon, larger for BCH
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
     WaveScratch2<S> ws;
     ws.base = free_l + (size_t)wave * WaveScratch2<S>::BYTES;
@@ -648,29 +657,24 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
     const u32 xroot = ar.exp_t[(la * ((cm + lane) % qm1)) % qm1]; // root_j = alpha^(c+j), j = lane
 
     for (i64 cw = (i64)blockIdx.x * nwaves + wave; cw < batch; cw += (i64)gridDim.x * nwaves) {
-        const uint8_t *row = recv_g + cw * n;
-        uint8_t *orow = out_g + cw * n;
+        uint8_t *orow = out_g + cw * n; // already holds the received row (copied by the pre-pass)
         // remainder coefficient of x^lane (stored highest degree first)
-        const u32 remc = lane < dd ? rem_g[cw * dd + (dd - 1 - lane)] : 0;
+        const u32 remc = lane < nk ? rem_g[cw * nk + (nk - 1 - lane)] : 0;
         const bool any_nz = __any(remc != 0);
         if (!any_nz && !eras_g) { // clean word (_bch.py:1373-1376)
-            for (int j = lane; j < n; j += 64) orow[j] = row[j];
             if (lane == 0) nerr_g[cw] = 0;
             continue;
         }
-        // ---- received word ascending, erased symbols zeroed (_bch.py:1351-1355) ----
+        // ---- erased positions, ascending degree (_bch.py:1351-1355; the pre-pass already treated them as zeros) ----
         int u = 0;
-        for (int base = 0; base < n; base += 64) {
-            const int i = base + lane;
-            bool er = false;
-            if (i < n) {
-                const u32 r = row[n - 1 - i];
-                if (eras_g) er = eras_g[cw * n + (n - 1 - i)] != 0;
-                ws.recv()[i] = er ? 0 : (uint8_t)r;
+        if (eras_g) {
+            for (int base = 0; base < n; base += 64) {
+                const int i = base + lane;
+                const bool er = i < n && eras_g[cw * n + (n - 1 - i)] != 0;
+                const unsigned long long m = __ballot(er);
+                if (er && u + __popcll(m & lt_mask) < dd + 4) ws.epos()[u + __popcll(m & lt_mask)] = (uint8_t)i;
+                u += __popcll(m);
             }
-            const unsigned long long m = __ballot(er);
-            if (er && u + __popcll(m & lt_mask) < dd + 4) ws.epos()[u + __popcll(m & lt_mask)] = (uint8_t)i;
-            u += __popcll(m);
         }
         int status = 0, v = 0;
         if (u > dd) {
@@ -681,8 +685,8 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
             // ---- 1. syndromes from the remainder: S_j = rem(root_j) by Horner's rule through the product table ----
             // (lane j evaluates at root_j; two VALU instructions + one LDS gather per term)
             {
-                u32 acc = (u32)__builtin_amdgcn_readlane((int)remc, dd - 1);
-                for (int tt = dd - 2; tt >= 0; tt--)
+                u32 acc = (u32)__builtin_amdgcn_readlane((int)remc, nk - 1);
+                for (int tt = nk - 2; tt >= 0; tt--)
                     acc = ar.mul_t[(acc << 8) | xroot] ^ (u32)__builtin_amdgcn_readlane((int)remc, tt);
                 if (lane < dd) ws.synd()[lane] = (uint8_t)acc;
             }
@@ -841,22 +845,24 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
                         den = (u32)__builtin_amdgcn_readlane((int)ltk, jtop);
                         for (int j = jtop - 2; j >= 1; j -= 2) den = ar.mul_t[(den << 8) | x2] ^ (u32)__builtin_amdgcn_readlane((int)ltk, j);
                     }
-                    if (act && num != 0 && den != 0) {
-                        int ex = (int)ar.log_t[num] - (int)ar.log_t[den] + ((rp.c - 1) % qm1) * (int)ar.log_t[x];
-                        ex %= qm1;
-                        if (ex < 0) ex += qm1;
-                        const int pos = ws.errpos()[lane];
-                        ws.recv()[pos] ^= ar.exp_t[ex];
+                    if (act) {
+                        // corrected = received - E; an erased symbol was taken as zero, so it becomes E itself
+                        u32 E = 0;
+                        if (num != 0 && den != 0) {
+                            int ex = (int)ar.log_t[num] - (int)ar.log_t[den] + ((rp.c - 1) % qm1) * (int)ar.log_t[x];
+                            ex %= qm1;
+                            if (ex < 0) ex += qm1;
+                            E = ar.exp_t[ex];
+                        }
+                        uint8_t *o = orow + (n - 1 - (int)ws.errpos()[lane]);
+                        const bool erased = eras_g && eras_g[cw * n + (n - 1 - (int)ws.errpos()[lane])] != 0;
+                        if (erased) *o = (uint8_t)E;
+                        else if (E) *o = (uint8_t)(*o ^ E);
                     }
                     wave_sync();
                     status = 0;
                 }
             }
-        }
-        if (status == 0) {
-            for (int j = lane; j < n; j += 64) orow[j] = ws.recv()[n - 1 - j];
-        } else {
-            for (int j = lane; j < n; j += 64) orow[j] = row[j];
         }
         if (lane == 0) nerr_g[cw] = status < 0 ? -1 : (status == 1 ? 0 : v);
         wave_sync();
@@ -1322,7 +1328,7 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
         GFA_HIP(hipMemsetAsync(out_n_errors, 0, sizeof(int64_t) * (size_t)batch, (hipStream_t)stream));
         return GFA_OK;
     }
-    if (lfsr_eligible(code) && code->n - code->k <= 60 && code->base_p == 0) {
+    if (lfsr_eligible(code) && code->n - code->k <= 60 && (code->base_p == 0 || code->base_p == 2) && code->roots.size() >= 1) {
         FieldDeviceState *ds;
         gfa_rs::Dev *cd;
         if ((rc = code->field->ensure_device(nullptr, &ds))) return rc;
@@ -1337,11 +1343,12 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
                 GFA_HIP(hipMalloc((void **)&cd->rem, need));
                 cd->rem_bytes = need;
             }
-            if ((rc = launch_lfsr<false>(code, cd, (const uint8_t *)recv, erasures, (int)ns, nullptr, 0, cd->rem, nullptr, batch, st)))
+            if ((rc = launch_lfsr<false>(code, cd, (const uint8_t *)recv, erasures, (int)ns, (uint8_t *)out_codeword, 0, cd->rem, nullptr,
+                                         batch, st)))
                 return rc;
             const RsParams rp = make_params(code);
             const size_t fixed = 65536 + 1280;
-            const bool small = nk + 4 <= 40;
+            const bool small = (int)code->roots.size() + 4 <= 40;
             const size_t per_wave = small ? WaveScratch2<40>::BYTES : WaveScratch2<64>::BYTES;
             static int wps = 0;
             if (!wps) { const char *e = getenv("GFA_RS_WPS"); wps = e ? atoi(e) : 8; if (wps != 4 && wps != 5 && wps != 6) wps = 8; }

@@ -165,3 +165,31 @@ def test_front_end_errors():
         rs.decode(np.zeros(15, dtype=int), erasures=np.zeros(14, dtype=bool))
     m, n = rs.decode(np.zeros(15, dtype=int), errors=True)
     assert n == 0 and m.shape == (9,)
+
+
+def test_c_abi_decode_in_place():
+    """gfa_rs_decode with out_codeword == recv (the pre-pass then skips its copy and the wave kernel patches in place)."""
+    import ctypes
+
+    import torch
+
+    from galois_amd import _lib as L
+
+    rs = ga.ReedSolomon(255, 223)
+    rng = np.random.default_rng(77)
+    N = 4096
+    M = rng.integers(0, 256, (N, 223), dtype=np.uint8)
+    C = rs.encode(M).numpy()
+    R = C.copy()
+    ne = rng.integers(0, 20, N)
+    for i in range(N):
+        pos = rng.choice(255, ne[i], replace=False)
+        R[i, pos] ^= rng.integers(1, 256, ne[i], dtype=np.uint8)
+    F = O.OracleField(2, 8, 285, 2, lookup=True)
+    want, wn = O.OracleRS(F, 255, 223).decode_u8(R)
+    buf = torch.from_numpy(R).cuda()
+    nerr = torch.empty(N, dtype=torch.int64, device="cuda")
+    L.check(L.lib().gfa_rs_decode(rs._handle, buf.data_ptr(), None, 255, buf.data_ptr(), nerr.data_ptr(), N, L.U8,
+                                  torch.cuda.current_stream().cuda_stream), "gfa_rs_decode")
+    assert np.array_equal(nerr.cpu().numpy(), wn)
+    assert np.array_equal(buf.cpu().numpy(), want)
