@@ -721,8 +721,8 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
             int llen = 1;
             const int nsq = dd - u;
             u32 Creg = lane == 0 ? 1u : 0u;
+            int L = 0; // LFSR length found by Berlekamp-Massey
             if (nsq > 0) {
-                int L = 0;
                 if (dd <= 32) {
                     // Inversionless Berlekamp-Massey without a discrepancy reduction (the RiBM arrangement of Sarwate &
                     // Shanbhag): lanes 0..31 hold Lambda (X) and B (Y), lanes 32.. hold the coefficients r.. of
@@ -824,8 +824,11 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
                     status = -1; // _bch.py:1469-1485
                 } else {
                     // ---- 7. Omega' = Lambda * S' mod x^(d-1) ----
+                    // Berlekamp-Massey guarantees sum_i Lambda_i S'_(k-i) = 0 for u + L <= k < d - 1, so the coefficients
+                    // from u + L upward are exactly zero: neither computed nor fed to Horner's rule below.
+                    const int oplen = u + L < dd ? (u + L > 0 ? u + L : 1) : dd;
                     u32 om = 0;
-                    if (lane < dd) {
+                    if (lane < oplen) {
                         const int ihi = lane < llen - 1 ? lane : llen - 1;
 #pragma unroll 4
                         for (int i = 0; i <= ihi; i++) om ^= ar.mul(ws.lam()[i], ws.sprime()[lane - i]);
@@ -836,8 +839,8 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
                     const int L_total = ltlen - 1;
                     const bool act = lane < v_total;
                     const u32 x = act ? (u32)ws.errloc()[lane] : 0u;
-                    u32 num = (u32)__builtin_amdgcn_readlane((int)om, dd - 1);
-                    for (int tt = dd - 2; tt >= 0; tt--) num = ar.mul_t[(num << 8) | x] ^ (u32)__builtin_amdgcn_readlane((int)om, tt);
+                    u32 num = (u32)__builtin_amdgcn_readlane((int)om, oplen - 1);
+                    for (int tt = oplen - 2; tt >= 0; tt--) num = ar.mul_t[(num << 8) | x] ^ (u32)__builtin_amdgcn_readlane((int)om, tt);
                     const u32 x2 = ar.mul_t[(x << 8) | x];
                     const int jtop = (L_total & 1) ? L_total : L_total - 1; // highest odd degree
                     u32 den = 0;
