@@ -95,3 +95,17 @@ def test_layout_helpers_roundtrip():
     blocks = [np.array([[X[k1 + n1 * k2] for k2 in range(n2)] for k1 in range(g * n1 // world, (g + 1) * n1 // world)])
               for g in range(world)]
     assert np.array_equal(gdist.local_to_natural(blocks, n1, n2), X)
+
+
+def test_choose_split():
+    from galois_amd import _dist as D
+
+    assert D.choose_split(1 << 26, 8) == (1 << 10, 1 << 16)
+    assert D.choose_split(1 << 20, 2) == (1 << 10, 1 << 10)
+    assert D.choose_split(1 << 8, 2) == (1 << 7, 2)
+    assert D.choose_split(1 << 32, 8) == (1 << 12, 1 << 20)
+    for n, w in ((1 << 26, 8), (1 << 16, 4), (1 << 12, 2)):
+        n1, n2 = D.choose_split(n, w)
+        assert n1 * n2 == n and n1 % w == 0 and n2 % w == 0
+    with pytest.raises(ValueError):
+        D.choose_split(1000, 8)
