@@ -468,6 +468,10 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
     u32 *T = reinterpret_cast<u32 *>(lds_raw); // 256 rows x NKW words
     for (int i = threadIdx.x; i < 256 * NKW; i += blockDim.x) T[i] = rowtab[i];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    // Lane l divides row rowi = 4*(l % 16) + l/16 of the wave's 64 staged rows.  With the natural pitch of n = 255 bytes,
+    // rows r and r+1 start 63.75 dwords apart, so four CONSECUTIVE rows share an LDS bank; the interleave leaves at most
+    // two lanes of a 32-lane group on one bank for the per-symbol byte read.
+    const int rowi = ((lane & 15) << 2) | (lane >> 4);
     uint8_t *stage = lds_raw + 256 * NK + (size_t)wave * stage_bytes;
     __syncthreads();
     const int ns_out = len + NK;
@@ -535,8 +539,8 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
         u32 st[NKW];
 #pragma unroll
         for (int d = 0; d < NKW; d++) st[d] = 0;
-        if (lane < count) {
-            const uint8_t *row = stage + lane * ((ENCODE && !parity_only) ? ns_out : len);
+        if (rowi < count) {
+            const uint8_t *row = stage + rowi * ((ENCODE && !parity_only) ? ns_out : len);
             for (int i = 0; i < len; i++) {
                 const u32 sym = row[i];
                 const u32 top = st[0] >> 24;
@@ -544,17 +548,26 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
 #pragma unroll
                 for (int d = 0; d + 1 < NKW; d++) st[d] = __builtin_amdgcn_alignbit(st[d], st[d + 1], 24);
                 st[NKW - 1] = (st[NKW - 1] << 8) | (ENCODE ? 0u : sym);
-                const u32 *r = T + f * NKW;
+                // table rows are stored in 16-byte chunks, chunk c of row f at T[c*1024 + f*4 ..]: a ds_read_b128 then
+                // spreads over 16 bank classes instead of 8 (the 32-byte row pitch made 75 % of the LDS cycles conflicts)
 #pragma unroll
-                for (int d = 0; d < NKW; d++) st[d] ^= r[d];
+                for (int c4 = 0; c4 < NKW / 4; c4++) {
+                    const uint4 rv = *reinterpret_cast<const uint4 *>(T + c4 * 1024 + f * 4);
+                    st[4 * c4 + 0] ^= rv.x; st[4 * c4 + 1] ^= rv.y; st[4 * c4 + 2] ^= rv.z; st[4 * c4 + 3] ^= rv.w;
+                }
+                if constexpr (NKW % 4 != 0) {
+                    const u32 *r = T + (NKW / 4) * 1024 + f * (NKW % 4);
+#pragma unroll
+                    for (int d = 0; d < NKW % 4; d++) st[(NKW / 4) * 4 + d] ^= r[d];
+                }
             }
         }
         wave_sync();
         if (ENCODE) {
             if (parity_only) {
                 // parity bytes (highest degree first) -> LDS -> global, flat
-                u32 *ps = reinterpret_cast<u32 *>(stage) + lane * NKW;
-                if (lane < count) {
+                u32 *ps = reinterpret_cast<u32 *>(stage) + rowi * NKW;
+                if (rowi < count) {
 #pragma unroll
                     for (int d = 0; d < NKW; d++) ps[d] = __builtin_bswap32(st[d]);
                 }
@@ -567,8 +580,8 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
                     for (int i = lane; i < count * NK; i += 64) out[cw0 * NK + i] = stage[i];
                 }
             } else {
-                if (lane < count) {
-                    uint8_t *pp = stage + lane * ns_out + len;
+                if (rowi < count) {
+                    uint8_t *pp = stage + rowi * ns_out + len;
 #pragma unroll
                     for (int d = 0; d < NKW; d++) {
                         pp[4 * d + 0] = (uint8_t)(st[d] >> 24); pp[4 * d + 1] = (uint8_t)(st[d] >> 16);
@@ -586,13 +599,13 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
             u32 nzw = 0;
 #pragma unroll
             for (int d = 0; d < NKW; d++) nzw |= st[d];
-            if (lane < count) {
+            if (rowi < count) {
                 if (rem_out) {
-                    u32 *dst = reinterpret_cast<u32 *>(rem_out) + (cw0 + lane) * NKW; // rem_out is 16-byte aligned scratch
+                    u32 *dst = reinterpret_cast<u32 *>(rem_out) + (cw0 + rowi) * NKW; // rem_out is 16-byte aligned scratch
 #pragma unroll
                     for (int d = 0; d < NKW; d++) dst[d] = __builtin_bswap32(st[d]);
                 }
-                if (flag_out) flag_out[cw0 + lane] = nzw != 0;
+                if (flag_out) flag_out[cw0 + rowi] = nzw != 0;
             }
         }
         wave_sync();
@@ -1075,15 +1088,20 @@ int gfa_rs::ensure_device(int *device_out, Dev **out)
         }
         if (field->has_tab8 && field->calc.p == 2 && nk >= 4 && nk <= 64 && nk % 4 == 0) {
             // LFSR rows: word d of row f packs f * gpoly[1 + 4d .. 4d + 3] (coefficients of x^(nk-1-4d) ..), first in the top byte
-            std::vector<uint32_t> rows(256 * (nk / 4));
+            // chunked layout (see rs_lfsr_kernel): full 4-word chunks first, chunk c of row f at c*1024 + f*4; the
+            // remaining nkw % 4 words of row f at (nkw/4)*1024 + f*(nkw % 4)
+            const size_t nkw = nk / 4, full = nkw / 4, tail = nkw % 4;
+            std::vector<uint32_t> rows(256 * nkw);
             for (uint32_t fb = 0; fb < 256; fb++)
-                for (size_t d = 0; d < nk / 4; d++) {
+                for (size_t d = 0; d < nkw; d++) {
                     uint32_t w = 0;
                     for (int b = 0; b < 4; b++) {
                         const uint64_t gc = gpoly[1 + 4 * d + b];
                         w = (w << 8) | (fb < field->calc.q && gc < field->calc.q ? field->h_mul8[(fb << 8) | gc] : 0);
                     }
-                    rows[fb * (nk / 4) + d] = w;
+                    const size_t c4 = d / 4;
+                    const size_t idx = c4 < full ? c4 * 1024 + fb * 4 + (d % 4) : full * 1024 + fb * tail + (d - full * 4);
+                    rows[idx] = w;
                 }
             GFA_HIP(hipMalloc((void **)&st.lfsr, rows.size() * sizeof(uint32_t)));
             GFA_HIP(hipMemcpy(st.lfsr, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
