@@ -27,6 +27,11 @@ int time_loop(hipStream_t st, int iters, float *ms_out, const std::function<int(
 
 void ntt_forget_field(const struct ::gfa_field *f); // drops cached NTT plans of a field being destroyed
 
+// matrix-core path of gfa_matmul for prime fields with p <= 256 (gfa_matmul_mfma.hip)
+bool matmul_mfma_eligible(const FieldDev &fd, i64 M, i64 K, i64 N);
+int matmul_mfma(const FieldDev &fd, int dtype, const void *a, const void *b, void *out, i64 batch, i64 M, i64 K, i64 N,
+                i64 a_bstride, i64 b_bstride, hipStream_t st);
+
 // Host scalar arithmetic on a field, dispatched on FieldDev::kind with the same formulas the kernels use.
 struct HostArith {
     static u64 add(const FieldDev &f, u64 a, u64 b);

@@ -1,0 +1,197 @@
+// gfa_matmul_mfma.hip -- matrix products over small prime fields GF(p), p <= 256, on the matrix cores.
+//
+// The one place in this engine where the work IS a GEMM (SURVEY.md section 8(f) item 2 asks for exactly this evaluation;
+// the reference itself multiplies prime-field matrices with an integer BLAS call and reduces afterwards,
+// _domains/_linalg.py:21-75).  Elements are moved to the centred residue system a' = a - p*(a > p/2) in [-127, 127], so a
+// product fits int8 x int8 and K <= 131072 products fit the int32 accumulator of v_mfma_i32_32x32x32_i8 exactly; one
+// integer reduction mod p per output element recovers the field element.  Exact arithmetic throughout: bit-identical to the
+// scalar kernels.
+//
+//   1. centre_kernel: A (M x K, any storage width) -> int8 A' (Mp x Kp, zero padded), B (K x N) -> int8 Bt' (Np x Kp), i.e.
+//      transposed so that both operands are K-contiguous, which is what the MFMA operand layout wants (16 consecutive k
+//      per lane).  Costs one pass over A and B; the product does M*N*K / (M*K + K*N) times more work.
+//   2. gemm_i8_nt_kernel: 128 x 128 block tile, 4 waves in 2 x 2, each wave 2 x 2 MFMA tiles of 32 x 32, K step 64,
+//      register-prefetched global loads, LDS rows padded to 80 bytes (conflict-free ds_read_b128), epilogue acc mod p.
+#include "gfa_internal.h"
+
+using namespace gfa;
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 64, PITCH = 80, GEMM_THREADS = 256;
+
+__device__ __forceinline__ int8_t centre(u32 a, u32 p, u32 half) { return (int8_t)(a > half ? (int)a - (int)p : (int)a); }
+
+// dst[r][c] = centre(src[r][c]) for r < rows, c < cols; zero elsewhere in the (rows_p x cols_p) padded array
+template <typename T>
+__global__ __launch_bounds__(256) void centre_rows_kernel(const T *__restrict__ src, int8_t *__restrict__ dst, i64 rows, i64 cols,
+                                                          i64 rows_p, i64 cols_p, u32 p, i64 src_bstride, i64 dst_bstride)
+{
+    const T *s = src + (i64)blockIdx.z * src_bstride;
+    int8_t *d = dst + (i64)blockIdx.z * dst_bstride;
+    const u32 half = p >> 1;
+    const i64 total = rows_p * cols_p;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (i64)gridDim.x * blockDim.x) {
+        const i64 r = e / cols_p, c = e - r * cols_p;
+        d[e] = (r < rows && c < cols) ? centre((u32)s[r * cols + c], p, half) : (int8_t)0;
+    }
+}
+
+// dst[c][r] = centre(src[r][c]) (transpose), 32 x 32 tiles through LDS; dst is (cols_p x rows_p), zero padded
+template <typename T>
+__global__ __launch_bounds__(256) void centre_transpose_kernel(const T *__restrict__ src, int8_t *__restrict__ dst, i64 rows, i64 cols,
+                                                               i64 rows_p, i64 cols_p, u32 p, i64 src_bstride, i64 dst_bstride)
+{
+    __shared__ int8_t tile[32][33];
+    const T *s = src + (i64)blockIdx.z * src_bstride;
+    int8_t *d = dst + (i64)blockIdx.z * dst_bstride;
+    const u32 half = p >> 1;
+    const i64 r0 = (i64)blockIdx.y * 32, c0 = (i64)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const i64 r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < rows && c < cols) ? centre((u32)s[r * cols + c], p, half) : (int8_t)0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const i64 c = c0 + j, r = r0 + tx; // dst row = source column
+        if (c < cols_p && r < rows_p) d[c * rows_p + r] = tile[tx][j];
+    }
+}
+
+// C[m][n] = (sum_k A'[m][k] * Bt'[n][k]) mod p.  A': (Mp x Kp), Bt': (Np x Kp), both padded to the tile sizes.
+template <typename T>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_i8_nt_kernel(const int8_t *__restrict__ A, const int8_t *__restrict__ Bt,
+                                                                  T *__restrict__ C, int M, int N, int Kp, i64 a_bstride,
+                                                                  i64 b_bstride, int p)
+{
+    __shared__ __attribute__((aligned(16))) int8_t As[2][BM * PITCH];
+    __shared__ __attribute__((aligned(16))) int8_t Bs[2][BN * PITCH];
+    const int8_t *Ab = A + (i64)blockIdx.z * a_bstride + (i64)blockIdx.y * BM * Kp;
+    const int8_t *Bb = Bt + (i64)blockIdx.z * b_bstride + (i64)blockIdx.x * BN * Kp;
+    T *Cb = C + (i64)blockIdx.z * M * N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1; // 2 x 2 waves, 64 x 64 each
+    // staging: thread t moves rows t/4 and t/4 + 64, 16-byte chunk t%4 of the 64-byte K slab
+    const int srow = tid >> 2, schunk = (tid & 3) * 16;
+    v4i ga[2], gb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            ga[j] = *reinterpret_cast<const v4i *>(Ab + (i64)(srow + 64 * j) * Kp + k0 + schunk);
+            gb[j] = *reinterpret_cast<const v4i *>(Bb + (i64)(srow + 64 * j) * Kp + k0 + schunk);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            *reinterpret_cast<v4i *>(&As[buf][(srow + 64 * j) * PITCH + schunk]) = ga[j];
+            *reinterpret_cast<v4i *>(&Bs[buf][(srow + 64 * j) * PITCH + schunk]) = gb[j];
+        }
+    };
+    v16i acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int nsteps = Kp / BK;
+    const int frow = lane & 31, fk = (lane >> 5) * 16; // MFMA operand: row/column `frow`, 16 consecutive k from `fk`
+    for (int s = 0; s < nsteps; s++) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) gload((s + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 32) {
+            v4i a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                a[t] = *reinterpret_cast<const v4i *>(&As[buf][(wm * 64 + t * 32 + frow) * PITCH + kk + fk]);
+                b[t] = *reinterpret_cast<const v4i *>(&Bs[buf][(wn * 64 + t * 32 + frow) * PITCH + kk + fk]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < nsteps) {
+            lstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // epilogue: D[row][col], col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int m_base = blockIdx.y * BM + wm * 64, n_base = blockIdx.x * BN + wn * 64;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = n_base + j * 32 + (lane & 31);
+                if (row < M && col < N) {
+                    int v = acc[i][j][r] % p;
+                    if (v < 0) v += p;
+                    Cb[(i64)row * N + col] = (T)v;
+                }
+            }
+}
+
+template <typename T>
+int run_mfma(const FieldDev &fd, const void *a, const void *b, void *out, i64 batch, i64 M, i64 K, i64 N, i64 a_bstride,
+             i64 b_bstride, hipStream_t st)
+{
+    const i64 Mp = (M + BM - 1) / BM * BM, Np = (N + BN - 1) / BN * BN, Kp = (K + BK - 1) / BK * BK;
+    const i64 nA = a_bstride ? batch : 1, nB = b_bstride ? batch : 1;
+    int8_t *Ac = nullptr, *Bc = nullptr;
+    GFA_HIP(hipMallocAsync((void **)&Ac, (size_t)(nA * Mp * Kp), st));
+    GFA_HIP(hipMallocAsync((void **)&Bc, (size_t)(nB * Np * Kp), st));
+    const u32 p = (u32)fd.p;
+    {
+        const i64 total = Mp * Kp;
+        const unsigned gx = (unsigned)std::min<i64>((total + 255) / 256, 65535);
+        hipLaunchKernelGGL(centre_rows_kernel<T>, dim3(gx, 1, (unsigned)nA), dim3(256), 0, st, (const T *)a, Ac, M, K, Mp, Kp, p,
+                           a_bstride, Mp * Kp);
+        hipLaunchKernelGGL(centre_transpose_kernel<T>, dim3((unsigned)(Np / 32), (unsigned)(Kp / 32), (unsigned)nB), dim3(256), 0, st,
+                           (const T *)b, Bc, K, N, Kp, Np, p, b_bstride, Np * Kp);
+    }
+    const dim3 grid((unsigned)(Np / BN), (unsigned)(Mp / BM), (unsigned)batch);
+    hipLaunchKernelGGL(gemm_i8_nt_kernel<T>, grid, dim3(GEMM_THREADS), 0, st, Ac, Bc, (T *)out, (int)M, (int)N, (int)Kp,
+                       a_bstride ? Mp * Kp : 0, b_bstride ? Np * Kp : 0, (int)p);
+    GFA_HIP(hipGetLastError());
+    GFA_HIP(hipFreeAsync(Ac, st));
+    GFA_HIP(hipFreeAsync(Bc, st));
+    return GFA_OK;
+}
+
+} // namespace
+
+namespace gfa {
+
+// true if the matrix-core path applies: prime field with p <= 256, K small enough for exact int32 accumulation, and a
+// product large enough to amortise the centring pass.  Batches ride on gridDim.z (<= 65535 per call, sliced by the caller).
+bool matmul_mfma_eligible(const FieldDev &fd, i64 M, i64 K, i64 N)
+{
+    return fd.m == 1 && fd.p <= 256 && K <= 131072 && M * N * K >= ((i64)1 << 21) && M <= (1 << 24) && N <= (1 << 24);
+}
+
+int matmul_mfma(const FieldDev &fd, int dtype, const void *a, const void *b, void *out, i64 batch, i64 M, i64 K, i64 N, i64 a_bstride,
+                i64 b_bstride, hipStream_t st)
+{
+    switch (dtype) {
+    case GFA_U8: return run_mfma<uint8_t>(fd, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
+    case GFA_U16: return run_mfma<uint16_t>(fd, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
+    case GFA_U32: return run_mfma<uint32_t>(fd, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
+    case GFA_U64: return run_mfma<uint64_t>(fd, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
+    default: set_error("gfa_matmul: bad dtype"); return GFA_ERR_INVALID;
+    }
+}
+
+} // namespace gfa

@@ -206,6 +206,28 @@ def test_wide_elimination_path(tag, n):
     assert list(ranks) == [n, n] and np.array_equal(rs.numpy()[0].astype(np.uint64), np.eye(n, dtype=np.uint64))
 
 
+@pytest.mark.parametrize("p", [2, 3, 31, 127, 251])
+def test_prime_field_matmul_on_matrix_cores(p):
+    """Products large enough for the int8 MFMA path (centred residues, exact int32 accumulation): ragged sizes around the
+    128 x 128 x 64 tiles, every storage dtype, stacks with a broadcast operand -- against the oracle's scalar loop."""
+    GF = ga.GF(p)
+    F = O.OracleField(p, 1, None, int(GF.primitive_element))
+    rng = np.random.default_rng(p)
+    for M, K, N in [(300, 500, 260), (128, 64, 128), (129, 65, 127), (1, 4096, 600), (513, 1000, 5)]:
+        A, B = rng.integers(0, p, (M, K)), rng.integers(0, p, (K, N))
+        want = F.matmul(A, B)
+        for dt in GF.dtypes[:1] + GF.dtypes[-1:]:
+            got = (GF(A.astype(dt), dtype=dt) @ GF(B.astype(dt), dtype=dt)).numpy()
+            H.assert_equal_ints(got, want, f"GF({p}) {M}x{K}x{N} {np.dtype(dt).name}")
+    A3, B1 = rng.integers(0, p, (3, 200, 300)), rng.integers(0, p, (300, 150))
+    C = (GF(A3) @ GF(B1)).numpy()
+    for i in range(3):
+        H.assert_equal_ints(C[i], F.matmul(A3[i], B1))
+    # extremes: all entries p - 1 (largest centred magnitude) over a long K
+    A, B = np.full((130, 20000), p - 1), np.full((20000, 140), p - 1)
+    assert np.all((GF(A) @ GF(B)).numpy() == (20000 * (p - 1) * (p - 1)) % p)
+
+
 def test_exceptions():
     """tests/fields/test_linalg.py:15-36, 86-92, 123-132, 291-299, 321-329, 345-353, 394-420."""
     GF = ga.GF(2**8)

@@ -43,7 +43,10 @@ mm("GF(2^8) u8 small stack", G8, np.uint8, L.U8, 16384, 16, 16, 16)
 mm("GF(2^8) u8 RS-encode shape", G8, np.uint8, L.U8, 1, 131072, 223, 32)
 mm("GF(65537) u32 (lazy u64 acc)", ga.GF(65537), np.uint32, L.U32, 1, 4096, 4096, 4096, 3)
 mm("GF(2^31-1) u32 (reduce every 4)", ga.GF(2147483647), np.uint32, L.U32, 1, 2048, 2048, 2048, 3)
-mm("GF(31) u8 (lazy)", ga.GF(31), np.uint8, L.U8, 1, 4096, 4096, 4096, 3)
+mm("GF(31) u8", ga.GF(31), np.uint8, L.U8, 1, 4096, 4096, 4096, 3)
+mm("GF(251) u8", ga.GF(251), np.uint8, L.U8, 1, 8192, 8192, 8192, 3)
+mm("GF(2) u8", ga.GF(2), np.uint8, L.U8, 1, 8192, 8192, 8192, 3)
+mm("GF(31) u8 stack", ga.GF(31), np.uint8, L.U8, 64, 512, 512, 512, 3)
 mm("Goldilocks u64", ga.GF(2**64 - 2**32 + 1), np.uint64, L.U64, 1, 1024, 1024, 1024, 3)
 mm("GF(3^5) u8 (Zech tables)", ga.GF(3**5), np.uint8, L.U8, 1, 1024, 1024, 1024, 3)
 mm("GF(2^32) u32 (shift-xor)", ga.GF(2**32), np.uint32, L.U32, 1, 1024, 1024, 1024, 3)
