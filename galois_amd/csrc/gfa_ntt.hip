@@ -132,6 +132,50 @@ struct TwShoupLazy {
     }
 };
 
+// p < 2^24: the register DFTs run WITHOUT reducing sums and differences.  Inside one radix-32 network values grow to at
+// most 2^5 * 2p < 2^30; the difference path adds a stage-dependent multiple of p (>= any operand of that stage) instead of
+// correcting, and every Shoup product brings its result back to [0, 2p) whatever the size of its input.  A butterfly is then
+// add | sub, add | mulhi, mul, mul, sub = 7 instructions instead of 9, a twiddle-free one 3 instead of 6.
+// The values that meet no multiplication on their way out of a network (line 0 of the exchange, the untwiddled last
+// pass) are normalised explicitly with a Shoup product by one.
+struct TwShoupWide : TwShoupLazy {
+    static constexpr bool WIDE = true;
+    struct Ctx { u32 p, p2, one_q; };
+    static __device__ __forceinline__ Ctx make_ctx(const FieldDev &fd)
+    {
+        u32 pv = (u32)fd.p;
+        asm volatile("" : "+v"(pv));
+        return Ctx{pv, 2 * pv, (u32)(0xffffffffull / fd.p)}; // floor((2^32 - 1) / p) = floor(2^32 / p) for odd p
+    }
+    static __device__ __forceinline__ W make_w(Ctx, u32 w, u32 wq) { return W{w, wq}; }
+    static __device__ __forceinline__ u32 mul(Ctx c, u32 x, W t)
+    {
+        const u32 q = __umulhi(t.wq, x);
+        return t.w * x - q * c.p;
+    }
+    static __device__ __forceinline__ u32 add(Ctx, u32 a, u32 b) { return a + b; }
+    // stage t of a network whose inputs are below 2p: operands are below 2^t * 2p = p << (t + 1), so adding that constant
+    // keeps the difference non-negative and below twice the bound -- sums and twiddle-free differences then grow by the
+    // same factor 2 per stage, to 64p after five stages (v_lshl_add_u32 + v_sub_u32)
+    static __device__ __forceinline__ u32 sub(Ctx c, u32 a, u32 b, int t) { return a + (c.p << (t + 1)) - b; }
+    static __device__ __forceinline__ u32 submul(Ctx c, u32 a, u32 b, W w, int t) { return mul(c, a + (c.p << (t + 1)) - b, w); }
+    static __device__ __forceinline__ u32 norm(Ctx c, u32 a) { return a - __umulhi(c.one_q, a) * c.p; } // any u32 -> [0, 2p)
+    static __device__ __forceinline__ u32 canon(Ctx c, u32 a) { return min(a, a - c.p); }
+    static __device__ __forceinline__ u32 redc(Ctx c, u32 x, u32 y, u32 pinv)
+    { // x < 64p, y < 2p, p < 2^24  =>  x*y < p * 2^32
+        const u32 hi = __umulhi(x, y), lo = x * y;
+        const u32 m = lo * pinv;
+        return hi - __umulhi(m, c.p) + c.p;
+    }
+};
+
+template <class TW, class = void>
+struct WideTrait { static constexpr bool value = false; };
+template <class TW>
+struct WideTrait<TW, std::enable_if_t<TW::WIDE>> { static constexpr bool value = true; };
+template <class TW>
+constexpr bool is_wide() { return WideTrait<TW>::value; }
+
 __device__ __forceinline__ u32 bitrev(u32 x, int bits) { return __brev(x) >> (32 - bits); }
 
 // ------------------------------------------------------------------------------------------------
@@ -309,11 +353,23 @@ __device__ __forceinline__ void reg_dif(typename TW::Ctx fd, typename F::elem (&
                 const E u = v[b + j], x = v[b + j + half];
                 v[b + j] = TW::add(fd, u, x);
                 const int tj = j << (LOGR - 1 - s);
-                if (tj != 0) v[b + j + half] = TW::submul(fd, u, x, TW::load(w, wq, (u32)(tj * wstride)));
-                else v[b + j + half] = TW::sub(fd, u, x);
+                if constexpr (is_wide<TW>()) {
+                    if (tj != 0) v[b + j + half] = TW::submul(fd, u, x, TW::load(w, wq, (u32)(tj * wstride)), LOGR - 1 - s);
+                    else v[b + j + half] = TW::sub(fd, u, x, LOGR - 1 - s);
+                } else {
+                    if (tj != 0) v[b + j + half] = TW::submul(fd, u, x, TW::load(w, wq, (u32)(tj * wstride)));
+                    else v[b + j + half] = TW::sub(fd, u, x);
+                }
             }
         }
     }
+}
+
+inline bool ntt_wide_enabled()
+{ // GFA_NTT_UNREDUCED=0 selects the always-reduced lazy butterflies for p < 2^24 as well (A/B measurements)
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("GFA_NTT_UNREDUCED"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
 }
 
 template <class TW, class = void>
@@ -393,7 +449,8 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fdk, const ty
         __syncthreads(); // middle-twiddle table staged
         if (active_a) {
             E *dst = data + ca * PC + ra_;
-            dst[0] = v[0];
+            if constexpr (is_wide<TW>()) dst[0] = TW::norm(fd, v[0]);
+            else dst[0] = v[0];
             u32 idx = 0;
 #pragma unroll
             for (int ka = 1; ka < R1; ka++) {
@@ -450,6 +507,12 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fdk, const ty
             const typename TW::W sw = TW::make_w(fd, (E)ra.scale, (E)ra.scale_q);
 #pragma unroll
             for (int kr = 0; kr < R2; kr++) v[kr] = TW::mul(fd, v[kr], sw);
+        }
+        if constexpr (is_wide<TW>()) {
+            if (!ra.post_twiddle && !ra.do_scale) {
+#pragma unroll
+                for (int kr = 0; kr < R2; kr++) v[kr] = TW::norm(fd, v[kr]);
+            }
         }
         if constexpr (is_lazy<TW>()) {
 #pragma unroll
@@ -984,7 +1047,8 @@ int run_typed(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *
         while (((i64)1 << lg) < n) lg++;
         if (lg >= 2 && lg <= 2 * REG_MAX_LOG) {
             if constexpr (std::is_same<F, Prime32>::value) {
-                if (fd.p < (1ull << 30)) rc = run_pow2_reg<F, TwShoupLazy>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+                if (fd.p < (1ull << 24) && ntt_wide_enabled()) rc = run_pow2_reg<F, TwShoupWide>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+                else if (fd.p < (1ull << 30)) rc = run_pow2_reg<F, TwShoupLazy>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
                 else if (fd.p < (1ull << 31)) rc = run_pow2_reg<F, TwShoup32>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
                 else rc = run_pow2_reg<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
             } else {
@@ -1143,7 +1207,7 @@ int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64
         ta.in_stride_c = 1; ta.in_stride_t = cols; ta.out_stride_c = 1; ta.out_stride_t = cols;
         ta.post_twiddle = 1; ta.lo_bits = pl->lo_bits; ta.n_mask = (u64)n_total - 1; ta.line_offset = col0;
         ta.tw_in_lds = lg1 <= 12;
-        if constexpr (std::is_same<TW, TwShoupLazy>::value) {
+        if constexpr (std::is_same<TW, TwShoupLazy>::value || std::is_same<TW, TwShoupWide>::value) {
             set_error("gfa_ntt_columns: internal: lazy twiddles are only used by the register kernel");
             return GFA_ERR_UNSUPPORTED;
         } else {
@@ -1152,6 +1216,7 @@ int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64
     };
     switch (c.kind) {
     case KIND_PRIME32:
+        if (c.p < (1ull << 24) && n1 <= ((i64)1 << REG_MAX_LOG) && ntt_wide_enabled()) return run(Prime32{}, TwShoupWide{});
         if (c.p < (1ull << 30) && n1 <= ((i64)1 << REG_MAX_LOG)) return run(Prime32{}, TwShoupLazy{});
         if (c.p < (1ull << 31)) return run(Prime32{}, TwShoup32{});
         return run(Prime32{}, Tw<Prime32>{});

@@ -182,3 +182,29 @@ def test_distributed_column_pass_emulated_on_one_gpu():
         gx = GF(np.array([int(t) for t in xs], dtype=object)) if order > 2**63 else GF(xs.astype(np.int64))
         want = np.fft.fft(gx).numpy()
         H.assert_equal_ints(full.astype(np.uint64), np.array([int(t) for t in want], dtype=np.uint64), f"dist {order}")
+
+
+@pytest.mark.parametrize("logn", [5, 10, 15, 20])
+def test_unreduced_butterflies_at_the_magnitude_limit(logn):
+    """p just below 2^24 (13 * 2^20 + 1) takes the unreduced register butterflies, whose intermediate values reach 96 p:
+    worst-case inputs (all p - 1, alternating 0 / p - 1, an impulse) and random data against the oracle."""
+    p = 13 * 2**20 + 1
+    assert ga.is_prime(p) and p < 2**24
+    GF = ga.GF(p)
+    F = O.OracleField(p, 1, None, int(GF.primitive_element))
+    n = 1 << logn
+    omega = GF._root_of_unity_int(n)
+    rng = np.random.default_rng(logn)
+    rows = [np.full(n, p - 1, dtype=np.uint32), np.tile(np.array([0, p - 1], dtype=np.uint32), n // 2),
+            np.concatenate([[p - 1], np.zeros(n - 1, dtype=np.uint32)]).astype(np.uint32),
+            rng.integers(0, p, n, dtype=np.uint32), (p - 1 - rng.integers(0, 3, n)).astype(np.uint32)]
+    X = ga.fft_batched(GF(np.stack(rows))) if hasattr(ga, "fft_batched") else None
+    if X is None:
+        from galois_amd._ntt import fft_batched
+        X = fft_batched(GF(np.stack(rows)))
+    got = X.numpy()
+    for i, r in enumerate(rows):
+        assert np.array_equal(got[i], F.ntt_u32_pow2(r, omega)), f"row {i}"
+    from galois_amd._ntt import fft_batched
+    back = fft_batched(X, inverse=True).numpy()
+    assert np.array_equal(back, np.stack(rows))
