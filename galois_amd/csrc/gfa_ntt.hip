@@ -823,7 +823,7 @@ int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64
 {
     typedef typename F::elem E;
     constexpr int R1 = 1 << LOGR1, R2 = 1 << LOGR2, L = R1 * R2, C = THREADS / R1;
-    constexpr size_t lds = sizeof(E) * ((size_t)C * (R1 * (R2 + 1) + 1) + 2 * L);
+    constexpr size_t lds = sizeof(E) * ((size_t)C * (R1 * (R2 + 1) + 1) + (TW::HAS_SHOUP ? 2 : 1) * L); // quotient table only with Shoup twiddles
     ra.tiles_per_batch = (int)((ra.total_lines + C - 1) / C);
     const unsigned grid = (unsigned)(batch * ra.tiles_per_batch);
     static const int xcd = env_int("GFA_NTT_XCD", 1);
@@ -857,6 +857,12 @@ int launch_reg_t(const FieldDev &fd, const void *in, void *out, const RegArgs &r
         static const int wide = env_int("GFA_NTT_WIDE", 0);
         if (wide) return launch_reg_tt<F, TW, LOGR1, LOGR2, 1024>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
         return launch_reg_tt<F, TW, LOGR1, LOGR2, 512>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
+    } else if constexpr (sizeof(E) == 8 && LOGR1 == 5 && !TW::HAS_SHOUP) {
+        // 64-bit elements: 16 lines per tile (128-byte global segments) in one 512-thread workgroup per CU, or 8 lines in
+        // 256-thread workgroups, two per CU now that the unused quotient table is no longer reserved (GFA_NTT_T64=256)
+        static const int t64 = env_int("GFA_NTT_T64", 256);
+        if (t64 == 512) return launch_reg_tt<F, TW, LOGR1, LOGR2, 512>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
+        return launch_reg_tt<F, TW, LOGR1, LOGR2, 256>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
     } else {
         return launch_reg_tt<F, TW, LOGR1, LOGR2, 256>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
     }

@@ -167,6 +167,20 @@ __global__ __launch_bounds__(THREADS) void k_flat(const u32x4 *a, const u32x4 *b
     if (i < nvec) o[i] = a[i] ^ b[i];
 }
 
+// persistent, but the workgroup -> chunk assignment rotates every iteration (breaks any fixed XCD <-> HBM-channel affinity)
+template <int THREADS, int ROT>
+__global__ __launch_bounds__(THREADS) void k_rotate(const u32x4 *a, const u32x4 *b, u32x4 *o, i64 nvec)
+{
+    const int G = gridDim.x;
+    int slot = blockIdx.x;
+    for (i64 base = 0; base < nvec; base += (i64)G * THREADS) {
+        const i64 i = base + (i64)slot * THREADS + threadIdx.x;
+        if (i < nvec) o[i] = a[i] ^ b[i];
+        slot += ROT;
+        if (slot >= G) slot -= G;
+    }
+}
+
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void k_copy(const u32x4 *a, u32x4 *o, i64 nvec)
 {
@@ -257,6 +271,10 @@ int main()
     RUN("dyn 256thr 8/CU chunk 4K", 3e8, hipLaunchKernelGGL((k_dyn<256, 1>), dim3(cus * 8), dim3(256), 0, 0, a, b, o, nvec, ctr))
     RUN("dyn 256thr 8/CU chunk 8K", 3e8, hipLaunchKernelGGL((k_dyn<256, 2>), dim3(cus * 8), dim3(256), 0, 0, a, b, o, nvec, ctr))
     RUN("dyn 512thr 4/CU chunk 8K", 3e8, hipLaunchKernelGGL((k_dyn<512, 1>), dim3(cus * 4), dim3(512), 0, 0, a, b, o, nvec, ctr))
+    RUN("rotate+1  1024thr 2/CU", 3e8, hipLaunchKernelGGL((k_rotate<1024, 1>), dim3(cus * 2), dim3(1024), 0, 0, a, b, o, nvec))
+    RUN("rotate+3  1024thr 2/CU", 3e8, hipLaunchKernelGGL((k_rotate<1024, 3>), dim3(cus * 2), dim3(1024), 0, 0, a, b, o, nvec))
+    RUN("rotate+37 1024thr 2/CU", 3e8, hipLaunchKernelGGL((k_rotate<1024, 37>), dim3(cus * 2), dim3(1024), 0, 0, a, b, o, nvec))
+    RUN("rotate+1  256thr 8/CU", 3e8, hipLaunchKernelGGL((k_rotate<256, 1>), dim3(cus * 8), dim3(256), 0, 0, a, b, o, nvec))
     RUN("flat 256thr one vector per thread", 3e8, hipLaunchKernelGGL((k_flat<256>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, a, b, o, nvec))
     RUN("flat 1024thr one vector per thread", 3e8, hipLaunchKernelGGL((k_flat<1024>), dim3((unsigned)((nvec + 1023) / 1024)), dim3(1024), 0, 0, a, b, o, nvec))
     RUN("copy gridstride 256thr 8/CU", 2e8, hipLaunchKernelGGL((k_copy<256>), dim3(cus * 8), dim3(256), 0, 0, a, o, nvec))
