@@ -846,6 +846,36 @@ class FieldArray(metaclass=FieldArrayMeta):
     def __matmul__(self, o): return np.matmul(self, o)
     def __rmatmul__(self, o): return np.matmul(o, self)
 
+    # ---- vector-space view over the prime subfield (_fields/_array.py:383-491) ----------------------------------------
+    def vector(self, dtype=None) -> "FieldArray":
+        """FieldArray.vector: shape (...,) over GF(p^m) -> shape (..., m) over GF(p), degree m-1 first."""
+        cls = type(self)
+        sub = cls.prime_subfield
+        np_dtype = sub._get_dtype(dtype)
+        m = cls._degree
+        t = self._t.contiguous()
+        out = torch.empty(tuple(t.shape) + (m,), dtype=_TORCH_STORAGE[sub._itemsize(np_dtype)], device=t.device)
+        L.check(L.lib().gfa_vector(cls._handle, 1, _ptr(t), self._gfa_dtype(), _ptr(out), _GFA_DTYPE[out.element_size()], t.numel(),
+                                   _stream()), "gfa_vector")
+        return sub._wrap(out, np_dtype)
+
+    @classmethod
+    def Vector(cls, array, dtype=None) -> "FieldArray":
+        """FieldArray.Vector: length-m vectors over GF(p) (last axis, degree m-1 first) -> elements of GF(p^m)."""
+        np_dtype = cls._get_dtype(dtype)
+        sub = cls.prime_subfield
+        x = array if isinstance(array, FieldArray) and type(array) is sub else sub(array)
+        if x.ndim == 0 or not x.shape[-1] == cls._degree:
+            raise ValueError(
+                f"Argument 'array' must have last dimension equal to the field extension dimension {cls._degree}, "
+                f"not {x.shape[-1] if x.ndim else ()}."
+            )
+        t = x._t.contiguous()
+        out = torch.empty(tuple(t.shape[:-1]), dtype=_TORCH_STORAGE[cls._itemsize(np_dtype)], device=t.device)
+        L.check(L.lib().gfa_vector(cls._handle, 0, _ptr(t), _GFA_DTYPE[t.element_size()], _ptr(out), _GFA_DTYPE[out.element_size()],
+                                   out.numel(), _stream()), "gfa_vector")
+        return cls._wrap(out, np_dtype)
+
     # ---- discrete logarithm, squares and square roots --------------------------------------------------------------
     def log(self, base=None):
         """FieldArray.log (_fields/_array.py:2127-2200): integer array i with base**i == self; base defaults to the

@@ -627,6 +627,58 @@ __global__ __launch_bounds__(256) void log_lut_kernel(FieldDev fd, const T *__re
     if (bad && err) atomicOr((int *)err, bad);
 }
 
+// FieldArray.vector / FieldArray.Vector (_fields/_array.py:383-491): base-p digits of the integer representation, most
+// significant digit (degree m-1) first.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void to_digits_kernel(u64 p, int m, const TI *__restrict__ in, TO *__restrict__ out, i64 n)
+{
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        u64 x = (u64)in[i];
+        for (int j = m - 1; j >= 0; j--) {
+            const u64 q = x / p;
+            out[i * m + j] = (TO)(x - q * p);
+            x = q;
+        }
+    }
+}
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void from_digits_kernel(u64 p, int m, const TI *__restrict__ in, TO *__restrict__ out, i64 n)
+{
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        u64 x = 0;
+        for (int j = 0; j < m; j++) x = x * p + (u64)in[i * m + j];
+        out[i] = (TO)x;
+    }
+}
+
+template <bool TO_DIGITS>
+int launch_digits(u64 p, int m, const void *in, int dtype_in, void *out, int dtype_out, i64 n, hipStream_t st)
+{
+    const int grid = grid_for(n, 256, 8);
+#define GFA_DG(TI, TO)                                                                                                    \
+    do {                                                                                                                  \
+        if (TO_DIGITS) hipLaunchKernelGGL((to_digits_kernel<TI, TO>), dim3(grid), dim3(256), 0, st, p, m, (const TI *)in, (TO *)out, n);   \
+        else hipLaunchKernelGGL((from_digits_kernel<TI, TO>), dim3(grid), dim3(256), 0, st, p, m, (const TI *)in, (TO *)out, n);           \
+    } while (0)
+#define GFA_DG_OUT(TI)                                                                                                    \
+    switch (dtype_out) {                                                                                                  \
+    case GFA_U8: GFA_DG(TI, uint8_t); break;                                                                              \
+    case GFA_U16: GFA_DG(TI, uint16_t); break;                                                                            \
+    case GFA_U32: GFA_DG(TI, uint32_t); break;                                                                            \
+    default: GFA_DG(TI, uint64_t); break;                                                                                 \
+    }
+    switch (dtype_in) {
+    case GFA_U8: GFA_DG_OUT(uint8_t) break;
+    case GFA_U16: GFA_DG_OUT(uint16_t) break;
+    case GFA_U32: GFA_DG_OUT(uint32_t) break;
+    default: GFA_DG_OUT(uint64_t) break;
+    }
+#undef GFA_DG_OUT
+#undef GFA_DG
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
 // ufunc.accumulate over the last axis: one workgroup per row, 256-element chunks scanned in LDS with a running carry.
 // mode 0: inclusive scan with the op; 1: out[i] = a0 - (a1 + ... + ai); 2: out[i] = a0 / (a1 * ... * ai)
 template <class F, typename T, bool IS_MUL>
@@ -880,6 +932,22 @@ int gfa_convolve(gfa_field_t *f, const void *a, int64_t na, const void *b, int64
     if (rc) return rc;
     if (f->use_lookup()) return dispatch_convolve(f->lut_desc(*ds), dtype, a, na, b, nb, out, (hipStream_t)stream);
     return dispatch_convolve(f->calc, dtype, a, na, b, nb, out, (hipStream_t)stream);
+}
+
+int gfa_vector(gfa_field_t *f, int to_digits, const void *in, int dtype_in, void *out, int dtype_out, int64_t n, gfa_stream_t stream)
+{
+    if (!f || n < 0 || dtype_in < GFA_U8 || dtype_in > GFA_U64 || dtype_out < GFA_U8 || dtype_out > GFA_U64) {
+        set_error("gfa_vector: bad arguments");
+        return GFA_ERR_INVALID;
+    }
+    if (!dtype_holds(to_digits ? dtype_in : dtype_out, f->calc.q) || !dtype_holds(to_digits ? dtype_out : dtype_in, f->calc.p)) {
+        set_error("gfa_vector: dtype cannot hold the elements");
+        return GFA_ERR_INVALID;
+    }
+    if (n == 0) return GFA_OK;
+    if (!in || !out) { set_error("gfa_vector: bad arguments"); return GFA_ERR_INVALID; }
+    if (to_digits) return launch_digits<true>(f->calc.p, (int)f->calc.m, in, dtype_in, out, dtype_out, n, (hipStream_t)stream);
+    return launch_digits<false>(f->calc.p, (int)f->calc.m, in, dtype_in, out, dtype_out, n, (hipStream_t)stream);
 }
 
 int gfa_poly_evaluate(gfa_field_t *f, const void *coeffs, int64_t ncoef, const void *x, void *out, int64_t n, int dtype,

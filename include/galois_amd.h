@@ -116,6 +116,10 @@ int gfa_accumulate(gfa_field_t *f, int op, const void *a, void *out, int64_t n_o
 int gfa_convolve(gfa_field_t *f, const void *a, int64_t na, const void *b, int64_t nb, void *out, int dtype,
                  gfa_stream_t stream);
 
+/* FieldArray.vector (to_digits != 0: n field elements -> n*m digits of GF(p), degree m-1 first) and FieldArray.Vector
+ * (to_digits == 0: n*m digits -> n elements) of _fields/_array.py:383-491; element and digit arrays may use different
+ * storage widths. */
+int gfa_vector(gfa_field_t *f, int to_digits, const void *in, int dtype_in, void *out, int dtype_out, int64_t n, gfa_stream_t stream);
 /* evaluate_elementwise_jit `int64[:](int64[:] coeffs_desc, int64[:] x)` (_polys/_dense.py:404-440): out[i] =
  * poly(x[i]) by Horner's rule; `coeffs` holds ncoef coefficients, highest degree first, in device memory. */
 int gfa_poly_evaluate(gfa_field_t *f, const void *coeffs, int64_t ncoef, const void *x, void *out, int64_t n, int dtype,

@@ -282,3 +282,29 @@ def test_mixed_storage_widths_keep_large_unsigned_values():
     G16 = ga.GF(2**16)
     b = np.array([2**15, 2**16 - 1, 7], dtype=np.uint16)
     assert np.array_equal((G16(b.astype(np.int32), dtype=np.int32) * G16(b)).numpy(), (G16(b) * G16(b)).numpy().astype(np.int32))
+
+
+@pytest.mark.parametrize("order", [3**5, 2**8, 7**3, 251**3, 2**32, 31, 2**16])
+def test_vector_and_Vector(order):
+    """FieldArray.vector / FieldArray.Vector (_fields/_array.py:383-491): base-p digits, degree m-1 first, and back."""
+    GF = ga.GF(order)
+    p, m = GF.characteristic, GF.degree
+    rng = np.random.default_rng(order % 1000)
+    x = rng.integers(0, order, (5, 7), dtype=np.uint64)
+    x[0, :3] = [0, order - 1, p % order]
+    v = GF([[int(e) for e in r] for r in x]).vector()
+    assert type(v) is GF.prime_subfield and v.shape == (5, 7, m)
+    want = np.zeros((5, 7, m), dtype=np.uint64)
+    y = x.copy()
+    for i in range(m - 1, -1, -1):  # the reference's own loop (_fields/_array.py:485-489)
+        want[..., i] = y % p
+        y //= p
+    assert np.array_equal(v.numpy().astype(np.uint64), want)
+    back = GF.Vector(v)
+    assert type(back) is GF and np.array_equal(back.numpy().astype(np.uint64), x)
+    assert np.array_equal(GF.Vector(want.astype(np.int64).tolist()).numpy().astype(np.uint64), x)
+    with pytest.raises(ValueError):
+        GF.Vector(np.zeros((2, m + 1), dtype=np.int64))
+    # addition in GF(p^m) is digit-wise addition in GF(p)
+    a, b = GF.Random(100, seed=1), GF.Random(100, seed=2)
+    assert np.array_equal((a + b).vector().numpy(), (a.vector() + b.vector()).numpy())
