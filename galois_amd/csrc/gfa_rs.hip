@@ -1344,8 +1344,9 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
     int rc = rs_check_device_path(code, dtype, "gfa_rs_decode");
     if (rc) return rc;
     if (batch == 0) return GFA_OK;
-    if (code->n == code->k) {
-        GFA_HIP(hipMemcpyAsync(out_codeword, recv, (size_t)(batch * ns), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (code->n == code->k && !erasures) { // identity code: nothing to correct (with erasures every erased word fails, below)
+        if (out_codeword != recv)
+            GFA_HIP(hipMemcpyAsync(out_codeword, recv, (size_t)(batch * ns), hipMemcpyDeviceToDevice, (hipStream_t)stream));
         GFA_HIP(hipMemsetAsync(out_n_errors, 0, sizeof(int64_t) * (size_t)batch, (hipStream_t)stream));
         return GFA_OK;
     }

@@ -193,3 +193,16 @@ def test_c_abi_decode_in_place():
                                   torch.cuda.current_stream().cuda_stream), "gfa_rs_decode")
     assert np.array_equal(nerr.cpu().numpy(), wn)
     assert np.array_equal(buf.cpu().numpy(), want)
+
+
+def test_identity_code_with_erasures():
+    """n == k (d = 1): any erased word fails (u > d - 1, _bch.py:1357-1360), the others pass through (found by tools/fuzz_codes.py)."""
+    GF = ga.GF(2**3)
+    rs = ga.ReedSolomon(7, 7, field=GF)
+    R = np.arange(21).reshape(3, 7) % 8
+    E = np.zeros((3, 7), dtype=bool)
+    E[1, 2] = True
+    dec, nerr = rs.decode(R, erasures=E, output="codeword", errors=True)
+    assert list(nerr) == [0, -1, 0] and np.array_equal(dec.numpy(), R)
+    dec, nerr = rs.decode(R, errors=True)
+    assert list(nerr) == [0, 0, 0] and np.array_equal(dec.numpy(), R)
