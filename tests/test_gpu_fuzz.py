@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tool,seed", [("fuzz_codes.py", 7), ("fuzz_fields.py", 11)])
+@pytest.mark.parametrize("tool,seed", [("fuzz_codes.py", 7), ("fuzz_fields.py", 11), ("fuzz_ntt_linalg.py", 13)])
 def test_fuzz(tool, seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "8", str(seed)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
