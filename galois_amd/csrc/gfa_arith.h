@@ -338,10 +338,33 @@ struct Lut {
 struct Ext {
     typedef u64 elem;
     static GFA_HD void to_vec(const FieldDev &f, u64 a, u32 *v)
-    { // most significant digit first, like int_to_vector (_calculate.py:22-33)
-        for (int i = (int)f.m - 1; i >= 0; i--) {
-            v[i] = (u32)(a % f.p);
-            a /= f.p;
+    { // most significant digit first, like int_to_vector (_calculate.py:22-33).  Division by p is a multiplication by
+      // mu = floor(2^64 / p) with at most two corrections (hardware 64-bit div/mod costs ~100 instructions each and
+      // used to dominate every GF(p^m) operation); 32-bit arithmetic when the whole element fits 32 bits.
+        if (f.q <= 0xffffffffull) {
+            u32 x = (u32)a;
+            const u32 p32 = (u32)f.p, mu32 = (u32)(f.mu >> 32); // floor(2^32 / p)
+            for (int i = (int)f.m - 1; i >= 0; i--) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                u32 qd = __umulhi(x, mu32);
+#else
+                u32 qd = (u32)(((u64)x * mu32) >> 32);
+#endif
+                u32 r = x - qd * p32;
+                if (r >= p32) { r -= p32; qd++; }
+                if (r >= p32) { r -= p32; qd++; }
+                v[i] = r;
+                x = qd;
+            }
+        } else {
+            for (int i = (int)f.m - 1; i >= 0; i--) {
+                u64 qd = mulhi64(a, f.mu);
+                u64 r = a - qd * f.p;
+                if (r >= f.p) { r -= f.p; qd++; }
+                if (r >= f.p) { r -= f.p; qd++; }
+                v[i] = (u32)r;
+                a = qd;
+            }
         }
     }
     static GFA_HD u64 from_vec(const FieldDev &f, const u32 *v)

@@ -24,11 +24,16 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int BM = 128, BN = 128, BK = 64, PITCH = 80, GEMM_THREADS = 256;
 
 __device__ __forceinline__ int8_t centre(u32 a, u32 p, u32 half) { return (int8_t)(a > half ? (int)a - (int)p : (int)a); }
+// operand byte: the centred residue (shift < 0, p <= 256) or the 7-bit limb of the element at bit `shift` (larger primes)
+__device__ __forceinline__ int8_t operand(u64 a, u32 p, u32 half, int shift)
+{
+    return shift < 0 ? centre((u32)a, p, half) : (int8_t)((a >> shift) & 127u);
+}
 
 // dst[r][c] = centre(src[r][c]) for r < rows, c < cols; zero elsewhere in the (rows_p x cols_p) padded array
 template <typename T>
 __global__ __launch_bounds__(256) void centre_rows_kernel(const T *__restrict__ src, int8_t *__restrict__ dst, i64 rows, i64 cols,
-                                                          i64 rows_p, i64 cols_p, u32 p, i64 src_bstride, i64 dst_bstride)
+                                                          i64 rows_p, i64 cols_p, u32 p, i64 src_bstride, i64 dst_bstride, int shift)
 {
     const T *s = src + (i64)blockIdx.z * src_bstride;
     int8_t *d = dst + (i64)blockIdx.z * dst_bstride;
@@ -36,14 +41,14 @@ __global__ __launch_bounds__(256) void centre_rows_kernel(const T *__restrict__ 
     const i64 total = rows_p * cols_p;
     for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (i64)gridDim.x * blockDim.x) {
         const i64 r = e / cols_p, c = e - r * cols_p;
-        d[e] = (r < rows && c < cols) ? centre((u32)s[r * cols + c], p, half) : (int8_t)0;
+        d[e] = (r < rows && c < cols) ? operand((u64)s[r * cols + c], p, half, shift) : (int8_t)0;
     }
 }
 
 // dst[c][r] = centre(src[r][c]) (transpose), 32 x 32 tiles through LDS; dst is (cols_p x rows_p), zero padded
 template <typename T>
 __global__ __launch_bounds__(256) void centre_transpose_kernel(const T *__restrict__ src, int8_t *__restrict__ dst, i64 rows, i64 cols,
-                                                               i64 rows_p, i64 cols_p, u32 p, i64 src_bstride, i64 dst_bstride)
+                                                               i64 rows_p, i64 cols_p, u32 p, i64 src_bstride, i64 dst_bstride, int shift)
 {
     __shared__ int8_t tile[32][33];
     const T *s = src + (i64)blockIdx.z * src_bstride;
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(256) void centre_transpose_kernel(const T *__restri
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
     for (int j = ty; j < 32; j += 8) {
         const i64 r = r0 + j, c = c0 + tx;
-        tile[j][tx] = (r < rows && c < cols) ? centre((u32)s[r * cols + c], p, half) : (int8_t)0;
+        tile[j][tx] = (r < rows && c < cols) ? operand((u64)s[r * cols + c], p, half, shift) : (int8_t)0;
     }
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
@@ -63,7 +68,8 @@ __global__ __launch_bounds__(256) void centre_transpose_kernel(const T *__restri
 }
 
 // C[m][n] = (sum_k A'[m][k] * Bt'[n][k]) mod p.  A': (Mp x Kp), Bt': (Np x Kp), both padded to the tile sizes.
-template <typename T>
+// RAW: C is an int32 array and the exact integer sums are ADDED to it (limb products of one diagonal share a buffer)
+template <typename T, bool RAW>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_i8_nt_kernel(const int8_t *__restrict__ A, const int8_t *__restrict__ Bt,
                                                                   T *__restrict__ C, int M, int N, int Kp, i64 a_bstride,
                                                                   i64 b_bstride, int p)
@@ -137,9 +143,13 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_i8_nt_kernel(const int8_t *
                 const int row = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int col = n_base + j * 32 + (lane & 31);
                 if (row < M && col < N) {
-                    int v = acc[i][j][r] % p;
-                    if (v < 0) v += p;
-                    Cb[(i64)row * N + col] = (T)v;
+                    if constexpr (RAW) {
+                        Cb[(i64)row * N + col] += (T)acc[i][j][r];
+                    } else {
+                        int v = acc[i][j][r] % p;
+                        if (v < 0) v += p;
+                        Cb[(i64)row * N + col] = (T)v;
+                    }
                 }
             }
 }
@@ -158,17 +168,89 @@ int run_mfma(const FieldDev &fd, const void *a, const void *b, void *out, i64 ba
         const i64 total = Mp * Kp;
         const unsigned gx = (unsigned)std::min<i64>((total + 255) / 256, 65535);
         hipLaunchKernelGGL(centre_rows_kernel<T>, dim3(gx, 1, (unsigned)nA), dim3(256), 0, st, (const T *)a, Ac, M, K, Mp, Kp, p,
-                           a_bstride, Mp * Kp);
+                           a_bstride, Mp * Kp, -1);
         hipLaunchKernelGGL(centre_transpose_kernel<T>, dim3((unsigned)(Np / 32), (unsigned)(Kp / 32), (unsigned)nB), dim3(256), 0, st,
-                           (const T *)b, Bc, K, N, Kp, Np, p, b_bstride, Np * Kp);
+                           (const T *)b, Bc, K, N, Kp, Np, p, b_bstride, Np * Kp, -1);
     }
     const dim3 grid((unsigned)(Np / BN), (unsigned)(Mp / BM), (unsigned)batch);
-    hipLaunchKernelGGL(gemm_i8_nt_kernel<T>, grid, dim3(GEMM_THREADS), 0, st, Ac, Bc, (T *)out, (int)M, (int)N, (int)Kp,
+    hipLaunchKernelGGL((gemm_i8_nt_kernel<T, false>), grid, dim3(GEMM_THREADS), 0, st, Ac, Bc, (T *)out, (int)M, (int)N, (int)Kp,
                        a_bstride ? Mp * Kp : 0, b_bstride ? Np * Kp : 0, (int)p);
     GFA_HIP(hipGetLastError());
     GFA_HIP(hipFreeAsync(Ac, st));
     GFA_HIP(hipFreeAsync(Bc, st));
     return GFA_OK;
+}
+
+// ---- primes up to 2^31: 7-bit limbs ------------------------------------------------------------------------------
+// a = sum_l a_l 2^(7l), 0 <= a_l < 128, NL = ceil(bits(p) / 7) limbs (3 for p < 2^21, 5 for p < 2^35).  Every limb pair
+// (i, j) is one exact int8 GEMM whose int32 sums are added to the buffer of its diagonal s = i + j (at most NL products
+// of K * 127^2 each: K is limited so that the buffer cannot overflow); a last pass folds the 2NL-1 diagonals,
+// out = sum_s (D_s mod p) * (2^(7s) mod p) mod p.  NL^2 matrix-core GEMMs instead of M*N*K Barrett products.
+template <typename T>
+__global__ __launch_bounds__(256) void fold_diagonals_kernel(const int *__restrict__ D, int ndiag, i64 plane, T *__restrict__ out,
+                                                             i64 count, u64 p, u64 mu)
+{
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (i64)gridDim.x * blockDim.x) {
+        u64 acc = 0, w = 1; // w = 2^(7s) mod p
+        for (int sdg = 0; sdg < ndiag; sdg++) {
+            const u64 v = (u64)(u32)D[(i64)sdg * plane + e] % p; // sums are non-negative (unsigned limbs)
+            acc = (acc + (unsigned __int128)v * w % p) % p;
+            w = (w << 7) % p;
+        }
+        out[e] = (T)acc;
+    }
+    (void)mu;
+}
+
+template <typename T>
+int run_mfma_limbs(const FieldDev &fd, int nl, const void *a, const void *b, void *out, i64 batch, i64 M, i64 K, i64 N, i64 a_bstride,
+                   i64 b_bstride, hipStream_t st)
+{
+    const i64 Mp = (M + BM - 1) / BM * BM, Np = (N + BN - 1) / BN * BN, Kp = (K + BK - 1) / BK * BK;
+    const int ndiag = 2 * nl - 1;
+    const i64 plane = M * N;
+    int8_t *Ac = nullptr, *Bc = nullptr;
+    int *D = nullptr;
+    GFA_HIP(hipMallocAsync((void **)&Ac, (size_t)(nl * Mp * Kp), st));
+    GFA_HIP(hipMallocAsync((void **)&Bc, (size_t)(nl * Np * Kp), st));
+    GFA_HIP(hipMallocAsync((void **)&D, sizeof(int) * (size_t)(ndiag * plane), st));
+    const u32 p32 = (u32)(fd.p & 0xffffffffu);
+    static const int itemsize[4] = {1, 2, 4, 8};
+    (void)itemsize;
+    for (i64 bi = 0; bi < batch; bi++) { // one matrix pair at a time: the diagonal buffers are the large scratch
+        const T *pa = (const T *)a + bi * a_bstride;
+        const T *pb = (const T *)b + bi * b_bstride;
+        if (bi == 0 || a_bstride)
+            for (int l = 0; l < nl; l++) {
+                const unsigned gx = (unsigned)std::min<i64>((Mp * Kp + 255) / 256, 65535);
+                hipLaunchKernelGGL(centre_rows_kernel<T>, dim3(gx, 1, 1), dim3(256), 0, st, pa, Ac + (i64)l * Mp * Kp, M, K, Mp, Kp, p32,
+                                   (i64)0, (i64)0, 7 * l);
+            }
+        if (bi == 0 || b_bstride)
+            for (int l = 0; l < nl; l++)
+                hipLaunchKernelGGL(centre_transpose_kernel<T>, dim3((unsigned)(Np / 32), (unsigned)(Kp / 32), 1), dim3(256), 0, st, pb,
+                                   Bc + (i64)l * Np * Kp, K, N, Kp, Np, p32, (i64)0, (i64)0, 7 * l);
+        GFA_HIP(hipMemsetAsync(D, 0, sizeof(int) * (size_t)(ndiag * plane), st));
+        const dim3 grid((unsigned)(Np / BN), (unsigned)(Mp / BM), 1);
+        for (int i = 0; i < nl; i++)
+            for (int j = 0; j < nl; j++)
+                hipLaunchKernelGGL((gemm_i8_nt_kernel<int, true>), grid, dim3(GEMM_THREADS), 0, st, Ac + (i64)i * Mp * Kp,
+                                   Bc + (i64)j * Np * Kp, D + (i64)(i + j) * plane, (int)M, (int)N, (int)Kp, (i64)0, (i64)0, 0);
+        const unsigned gf = (unsigned)std::min<i64>((plane + 255) / 256, 65535);
+        hipLaunchKernelGGL(fold_diagonals_kernel<T>, dim3(gf), dim3(256), 0, st, D, ndiag, plane, (T *)out + bi * plane, plane, fd.p, fd.mu);
+    }
+    GFA_HIP(hipGetLastError());
+    GFA_HIP(hipFreeAsync(Ac, st));
+    GFA_HIP(hipFreeAsync(Bc, st));
+    GFA_HIP(hipFreeAsync(D, st));
+    return GFA_OK;
+}
+
+int limbs_for(u64 p)
+{
+    int bits = 0;
+    while (bits < 64 && (p >> bits)) bits++;
+    return (bits + 6) / 7;
 }
 
 } // namespace
@@ -179,12 +261,27 @@ namespace gfa {
 // product large enough to amortise the centring pass.  Batches ride on gridDim.z (<= 65535 per call, sliced by the caller).
 bool matmul_mfma_eligible(const FieldDev &fd, i64 M, i64 K, i64 N)
 {
-    return fd.m == 1 && fd.p <= 256 && K <= 131072 && M * N * K >= ((i64)1 << 21) && M <= (1 << 24) && N <= (1 << 24);
+    if (fd.m != 1 || M > (1 << 24) || N > (1 << 24)) return false;
+    if (fd.p <= 256) return K <= 131072 && M * N * K >= ((i64)1 << 21);
+    if (fd.kind != KIND_PRIME32) return false;
+    // 7-bit limbs: NL^2 GEMMs + NL staging passes + a fold; worth it for large products only, and NL * K * 127^2 < 2^31
+    const int nl = limbs_for(fd.p);
+    return nl <= 5 && (i64)nl * K * 16129 < ((i64)1 << 31) && M * N * K >= ((i64)1 << 27) && M >= 64 && N >= 64 &&
+           M * N <= ((i64)1 << 27);
 }
 
 int matmul_mfma(const FieldDev &fd, int dtype, const void *a, const void *b, void *out, i64 batch, i64 M, i64 K, i64 N, i64 a_bstride,
                 i64 b_bstride, hipStream_t st)
 {
+    if (fd.p > 256) {
+        const int nl = limbs_for(fd.p);
+        switch (dtype) {
+        case GFA_U32: return run_mfma_limbs<uint32_t>(fd, nl, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
+        case GFA_U64: return run_mfma_limbs<uint64_t>(fd, nl, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
+        case GFA_U16: return run_mfma_limbs<uint16_t>(fd, nl, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
+        default: set_error("gfa_matmul: bad dtype"); return GFA_ERR_INVALID;
+        }
+    }
     switch (dtype) {
     case GFA_U8: return run_mfma<uint8_t>(fd, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
     case GFA_U16: return run_mfma<uint16_t>(fd, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);

@@ -228,6 +228,23 @@ def test_prime_field_matmul_on_matrix_cores(p):
     assert np.all((GF(A) @ GF(B)).numpy() == (20000 * (p - 1) * (p - 1)) % p)
 
 
+@pytest.mark.parametrize("p", [65537, 7340033, 2147483647, 257])
+def test_large_prime_matmul_on_matrix_cores(p):
+    """Primes above 256 split into 7-bit limbs (3 limbs below 2^21, 5 below 2^35): NL^2 exact int8 GEMMs whose int32 sums
+    are folded mod p.  Sizes above the 2^27-MAC threshold, ragged edges, all-(p-1) operands, both storage dtypes."""
+    GF = ga.GF(p)
+    F = O.OracleField(p, 1, None, int(GF.primitive_element))
+    rng = np.random.default_rng(p % 1000)
+    for M, K, N in [(512, 512, 512), (515, 700, 381)]:
+        A, B = rng.integers(0, p, (M, K)), rng.integers(0, p, (K, N))
+        want = F.matmul(A, B)
+        for dt in (GF.dtypes[0], np.int64):
+            got = (GF(A.astype(dt), dtype=dt) @ GF(B.astype(dt), dtype=dt)).numpy()
+            H.assert_equal_ints(got, want, f"GF({p}) {M}x{K}x{N} {np.dtype(dt).name}")
+    A, B = np.full((600, 900), p - 1, dtype=np.int64), np.full((900, 600), p - 1, dtype=np.int64)
+    assert np.all((GF(A) @ GF(B)).numpy().astype(np.int64) == (900 * pow(p - 1, 2, p)) % p)
+
+
 def test_exceptions():
     """tests/fields/test_linalg.py:15-36, 86-92, 123-132, 291-299, 321-329, 345-353, 394-420."""
     GF = ga.GF(2**8)

@@ -41,8 +41,9 @@ t = time.perf_counter(); ref = F8.matmul(a[0, :256, :256], b[0, :256, :256]); dt
 print(f"  oracle C port, 1 thread: 256^3 in {dt * 1e3:.1f} ms = {256**3 / dt / 1e9:.3f} GMAC/s")
 mm("GF(2^8) u8 small stack", G8, np.uint8, L.U8, 16384, 16, 16, 16)
 mm("GF(2^8) u8 RS-encode shape", G8, np.uint8, L.U8, 1, 131072, 223, 32)
-mm("GF(65537) u32 (lazy u64 acc)", ga.GF(65537), np.uint32, L.U32, 1, 4096, 4096, 4096, 3)
-mm("GF(2^31-1) u32 (reduce every 4)", ga.GF(2147483647), np.uint32, L.U32, 1, 2048, 2048, 2048, 3)
+mm("GF(65537) u32 (3 limbs, MFMA)", ga.GF(65537), np.uint32, L.U32, 1, 4096, 4096, 4096, 3)
+mm("GF(2^31-1) u32 (5 limbs, MFMA)", ga.GF(2147483647), np.uint32, L.U32, 1, 4096, 4096, 4096, 3)
+mm("GF(65537) u32 (VALU, below thresh)", ga.GF(65537), np.uint32, L.U32, 1, 400, 400, 400, 3)
 mm("GF(31) u8", ga.GF(31), np.uint8, L.U8, 1, 4096, 4096, 4096, 3)
 mm("GF(251) u8", ga.GF(251), np.uint8, L.U8, 1, 8192, 8192, 8192, 3)
 mm("GF(2) u8", ga.GF(2), np.uint8, L.U8, 1, 8192, 8192, 8192, 3)
