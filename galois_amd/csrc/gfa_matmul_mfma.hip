@@ -10,8 +10,9 @@
 //   1. centre_kernel: A (M x K, any storage width) -> int8 A' (Mp x Kp, zero padded), B (K x N) -> int8 Bt' (Np x Kp), i.e.
 //      transposed so that both operands are K-contiguous, which is what the MFMA operand layout wants (16 consecutive k
 //      per lane).  Costs one pass over A and B; the product does M*N*K / (M*K + K*N) times more work.
-//   2. gemm_i8_nt_kernel: 128 x 128 block tile, 4 waves in 2 x 2, each wave 2 x 2 MFMA tiles of 32 x 32, K step 64,
-//      register-prefetched global loads, LDS rows padded to 80 bytes (conflict-free ds_read_b128), epilogue acc mod p.
+//   2. gemm_i8_nt_kernel: 256 x 256 (16 waves) or 128 x 128 (4 waves) block tile, each wave 2 x 2 MFMA tiles of 32 x 32,
+//      K step 64, register-prefetched global loads, LDS rows padded to 80 bytes (conflict-free ds_read_b128), epilogue
+//      acc mod p.
 #include "gfa_internal.h"
 
 using namespace gfa;
@@ -21,7 +22,7 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 64, PITCH = 80, GEMM_THREADS = 256;
+constexpr int BK = 64, PITCH = 80;
 
 __device__ __forceinline__ int8_t centre(u32 a, u32 p, u32 half) { return (int8_t)(a > half ? (int)a - (int)p : (int)a); }
 // operand byte: the centred residue (shift < 0, p <= 256) or the 7-bit limb of the element at bit `shift` (larger primes)
@@ -67,36 +68,39 @@ __global__ __launch_bounds__(256) void centre_transpose_kernel(const T *__restri
     }
 }
 
-// C[m][n] = (sum_k A'[m][k] * Bt'[n][k]) mod p.  A': (Mp x Kp), Bt': (Np x Kp), both padded to the tile sizes.
-// RAW: C is an int32 array and the exact integer sums are ADDED to it (limb products of one diagonal share a buffer)
-template <typename T, bool RAW>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_i8_nt_kernel(const int8_t *__restrict__ A, const int8_t *__restrict__ Bt,
-                                                                  T *__restrict__ C, int M, int N, int Kp, i64 a_bstride,
-                                                                  i64 b_bstride, int p)
+// C[m][n] = (sum_k A'[m][k] * Bt'[n][k]) mod p.  A': (Mp x Kp), Bt': (Np x Kp), both padded to 256.
+// RAW: C is an int32 array and the exact integer sums are ADDED to it (limb products of one diagonal share a buffer).
+// Block tile (64 WM) x (64 WN) with WM x WN waves of 64 x 64 each.  The kernel is bound by the L2 -> LDS operand stream
+// (every block re-reads its A and B panels): 128 x 128 tiles moved 8 TB/s from L2 at 512 TMAC/s, so large products use
+// 256 x 256 tiles (16 waves, one workgroup per CU) and halve that traffic.
+template <typename T, bool RAW, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_i8_nt_kernel(const int8_t *__restrict__ A, const int8_t *__restrict__ Bt,
+                                                                   T *__restrict__ C, int M, int N, int Kp, i64 a_bstride,
+                                                                   i64 b_bstride, int p)
 {
-    __shared__ __attribute__((aligned(16))) int8_t As[2][BM * PITCH];
-    __shared__ __attribute__((aligned(16))) int8_t Bs[2][BN * PITCH];
-    const int8_t *Ab = A + (i64)blockIdx.z * a_bstride + (i64)blockIdx.y * BM * Kp;
-    const int8_t *Bb = Bt + (i64)blockIdx.z * b_bstride + (i64)blockIdx.x * BN * Kp;
+    constexpr int TBM = 64 * WM, TBN = 64 * WN, THREADS = 64 * WM * WN;
+    constexpr int ACH = TBM * 4 / THREADS, BCH = TBN * 4 / THREADS; // 16-byte chunks per thread per K slab
+    static_assert(ACH >= 1 && BCH >= 1 && (TBM * 4) % THREADS == 0 && (TBN * 4) % THREADS == 0, "tile / thread mismatch");
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    int8_t *As0 = smem, *Bs0 = smem + 2 * TBM * PITCH; // As[2][TBM*PITCH], Bs[2][TBN*PITCH]
+    const int8_t *Ab = A + (i64)blockIdx.z * a_bstride + (i64)blockIdx.y * TBM * Kp;
+    const int8_t *Bb = Bt + (i64)blockIdx.z * b_bstride + (i64)blockIdx.x * TBN * Kp;
     T *Cb = C + (i64)blockIdx.z * M * N;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1; // 2 x 2 waves, 64 x 64 each
-    // staging: thread t moves rows t/4 and t/4 + 64, 16-byte chunk t%4 of the 64-byte K slab
-    const int srow = tid >> 2, schunk = (tid & 3) * 16;
-    v4i ga[2], gb[2];
+    const int wm = wave / WN, wn = wave % WN;
+    const int srow = tid >> 2, schunk = (tid & 3) * 16; // thread moves rows srow + j * THREADS/4, 16-byte chunk tid % 4
+    v4i ga[ACH], gb[BCH];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            ga[j] = *reinterpret_cast<const v4i *>(Ab + (i64)(srow + 64 * j) * Kp + k0 + schunk);
-            gb[j] = *reinterpret_cast<const v4i *>(Bb + (i64)(srow + 64 * j) * Kp + k0 + schunk);
-        }
+        for (int j = 0; j < ACH; j++) ga[j] = *reinterpret_cast<const v4i *>(Ab + (i64)(srow + (THREADS / 4) * j) * Kp + k0 + schunk);
+#pragma unroll
+        for (int j = 0; j < BCH; j++) gb[j] = *reinterpret_cast<const v4i *>(Bb + (i64)(srow + (THREADS / 4) * j) * Kp + k0 + schunk);
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            *reinterpret_cast<v4i *>(&As[buf][(srow + 64 * j) * PITCH + schunk]) = ga[j];
-            *reinterpret_cast<v4i *>(&Bs[buf][(srow + 64 * j) * PITCH + schunk]) = gb[j];
-        }
+        for (int j = 0; j < ACH; j++) *reinterpret_cast<v4i *>(As0 + buf * TBM * PITCH + (srow + (THREADS / 4) * j) * PITCH + schunk) = ga[j];
+#pragma unroll
+        for (int j = 0; j < BCH; j++) *reinterpret_cast<v4i *>(Bs0 + buf * TBN * PITCH + (srow + (THREADS / 4) * j) * PITCH + schunk) = gb[j];
     };
     v16i acc[2][2];
 #pragma unroll
@@ -114,13 +118,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_i8_nt_kernel(const int8_t *
     for (int s = 0; s < nsteps; s++) {
         const int buf = s & 1;
         if (s + 1 < nsteps) gload((s + 1) * BK);
+        const int8_t *Asb = As0 + buf * TBM * PITCH, *Bsb = Bs0 + buf * TBN * PITCH;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 32) {
             v4i a[2], b[2];
 #pragma unroll
             for (int t = 0; t < 2; t++) {
-                a[t] = *reinterpret_cast<const v4i *>(&As[buf][(wm * 64 + t * 32 + frow) * PITCH + kk + fk]);
-                b[t] = *reinterpret_cast<const v4i *>(&Bs[buf][(wn * 64 + t * 32 + frow) * PITCH + kk + fk]);
+                a[t] = *reinterpret_cast<const v4i *>(Asb + (wm * 64 + t * 32 + frow) * PITCH + kk + fk);
+                b[t] = *reinterpret_cast<const v4i *>(Bsb + (wn * 64 + t * 32 + frow) * PITCH + kk + fk);
             }
 #pragma unroll
             for (int i = 0; i < 2; i++)
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_i8_nt_kernel(const int8_t *
         }
     }
     // epilogue: D[row][col], col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int m_base = blockIdx.y * BM + wm * 64, n_base = blockIdx.x * BN + wn * 64;
+    const int m_base = blockIdx.y * TBM + wm * 64, n_base = blockIdx.x * TBN + wn * 64;
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -154,11 +159,35 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_i8_nt_kernel(const int8_t *
             }
 }
 
+// launches the tile configuration that suits the product: 256 x 256 for large M, N, else 128 x 128
+template <typename T, bool RAW>
+int launch_gemm(const int8_t *A, const int8_t *Bt, T *C, i64 M, i64 N, i64 Mp, i64 Np, i64 Kp, i64 a_bstride, i64 b_bstride, i64 batch,
+                int p, hipStream_t st)
+{
+    static int big_env = -1; // GFA_MFMA_TILE=128 forces the small tiles (A/B measurements)
+    if (big_env < 0) { const char *e = getenv("GFA_MFMA_TILE"); big_env = (e && atoi(e) == 128) ? 0 : 1; }
+    if (big_env && M >= 1024 && N >= 1024) {
+        auto k = gemm_i8_nt_kernel<T, RAW, 4, 4>;
+        constexpr size_t lds = 2 * (256 + 256) * PITCH;
+        static bool attr = false;
+        if (!attr) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+        hipLaunchKernelGGL(k, dim3((unsigned)(Np / 256), (unsigned)(Mp / 256), (unsigned)batch), dim3(1024), lds, st, A, Bt, C, (int)M, (int)N,
+                           (int)Kp, a_bstride, b_bstride, p);
+    } else {
+        auto k = gemm_i8_nt_kernel<T, RAW, 2, 2>;
+        constexpr size_t lds = 2 * (128 + 128) * PITCH;
+        hipLaunchKernelGGL(k, dim3((unsigned)(Np / 128), (unsigned)(Mp / 128), (unsigned)batch), dim3(256), lds, st, A, Bt, C, (int)M, (int)N,
+                           (int)Kp, a_bstride, b_bstride, p);
+    }
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
 template <typename T>
 int run_mfma(const FieldDev &fd, const void *a, const void *b, void *out, i64 batch, i64 M, i64 K, i64 N, i64 a_bstride,
              i64 b_bstride, hipStream_t st)
 {
-    const i64 Mp = (M + BM - 1) / BM * BM, Np = (N + BN - 1) / BN * BN, Kp = (K + BK - 1) / BK * BK;
+    const i64 Mp = (M + 255) / 256 * 256, Np = (N + 255) / 256 * 256, Kp = (K + BK - 1) / BK * BK;
     const i64 nA = a_bstride ? batch : 1, nB = b_bstride ? batch : 1;
     int8_t *Ac = nullptr, *Bc = nullptr;
     GFA_HIP(hipMallocAsync((void **)&Ac, (size_t)(nA * Mp * Kp), st));
@@ -172,10 +201,8 @@ int run_mfma(const FieldDev &fd, const void *a, const void *b, void *out, i64 ba
         hipLaunchKernelGGL(centre_transpose_kernel<T>, dim3((unsigned)(Np / 32), (unsigned)(Kp / 32), (unsigned)nB), dim3(256), 0, st,
                            (const T *)b, Bc, K, N, Kp, Np, p, b_bstride, Np * Kp, -1);
     }
-    const dim3 grid((unsigned)(Np / BN), (unsigned)(Mp / BM), (unsigned)batch);
-    hipLaunchKernelGGL((gemm_i8_nt_kernel<T, false>), grid, dim3(GEMM_THREADS), 0, st, Ac, Bc, (T *)out, (int)M, (int)N, (int)Kp,
-                       a_bstride ? Mp * Kp : 0, b_bstride ? Np * Kp : 0, (int)p);
-    GFA_HIP(hipGetLastError());
+    int rcg = launch_gemm<T, false>(Ac, Bc, (T *)out, M, N, Mp, Np, Kp, a_bstride ? Mp * Kp : 0, b_bstride ? Np * Kp : 0, batch, (int)p, st);
+    if (rcg) return rcg;
     GFA_HIP(hipFreeAsync(Ac, st));
     GFA_HIP(hipFreeAsync(Bc, st));
     return GFA_OK;
@@ -206,7 +233,7 @@ template <typename T>
 int run_mfma_limbs(const FieldDev &fd, int nl, const void *a, const void *b, void *out, i64 batch, i64 M, i64 K, i64 N, i64 a_bstride,
                    i64 b_bstride, hipStream_t st)
 {
-    const i64 Mp = (M + BM - 1) / BM * BM, Np = (N + BN - 1) / BN * BN, Kp = (K + BK - 1) / BK * BK;
+    const i64 Mp = (M + 255) / 256 * 256, Np = (N + 255) / 256 * 256, Kp = (K + BK - 1) / BK * BK;
     const int ndiag = 2 * nl - 1;
     const i64 plane = M * N;
     int8_t *Ac = nullptr, *Bc = nullptr;
@@ -231,11 +258,11 @@ int run_mfma_limbs(const FieldDev &fd, int nl, const void *a, const void *b, voi
                 hipLaunchKernelGGL(centre_transpose_kernel<T>, dim3((unsigned)(Np / 32), (unsigned)(Kp / 32), 1), dim3(256), 0, st, pb,
                                    Bc + (i64)l * Np * Kp, K, N, Kp, Np, p32, (i64)0, (i64)0, 7 * l);
         GFA_HIP(hipMemsetAsync(D, 0, sizeof(int) * (size_t)(ndiag * plane), st));
-        const dim3 grid((unsigned)(Np / BN), (unsigned)(Mp / BM), 1);
         for (int i = 0; i < nl; i++)
-            for (int j = 0; j < nl; j++)
-                hipLaunchKernelGGL((gemm_i8_nt_kernel<int, true>), grid, dim3(GEMM_THREADS), 0, st, Ac + (i64)i * Mp * Kp,
-                                   Bc + (i64)j * Np * Kp, D + (i64)(i + j) * plane, (int)M, (int)N, (int)Kp, (i64)0, (i64)0, 0);
+            for (int j = 0; j < nl; j++) {
+                int rcg = launch_gemm<int, true>(Ac + (i64)i * Mp * Kp, Bc + (i64)j * Np * Kp, D + (i64)(i + j) * plane, M, N, Mp, Np, Kp, 0, 0, 1, 0, st);
+                if (rcg) return rcg;
+            }
         const unsigned gf = (unsigned)std::min<i64>((plane + 255) / 256, 65535);
         hipLaunchKernelGGL(fold_diagonals_kernel<T>, dim3(gf), dim3(256), 0, st, D, ndiag, plane, (T *)out + bi * plane, plane, fd.p, fd.mu);
     }
