@@ -386,7 +386,10 @@ constexpr int brev_c(int x, int bits)
     return r;
 }
 
-template <class F, class TW, int LOGR1, int LOGR2, int THREADS>
+// SPLIT: the LDS exchange runs in two rounds of R1/2 rows each (half the buffer: three 512-thread workgroups per CU
+// instead of two for 1024-point lines of 32-bit elements; the kernel is occupancy sensitive -- 8 instead of 16 waves per
+// CU cost 40 %).
+template <class F, class TW, int LOGR1, int LOGR2, int THREADS, bool SPLIT = false>
 __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fdk, const typename F::elem *__restrict__ in,
                                                           typename F::elem *__restrict__ out, RegArgs ra,
                                                           const typename F::elem *__restrict__ wL,
@@ -402,7 +405,8 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fdk, const ty
     constexpr int C = THREADS / R1;           // lines per tile
     constexpr int LOGC = __builtin_ctz(C);
     constexpr int ROW = R2 + 1;               // padded row of R2 values
-    constexpr int PC = R1 * ROW + 1;          // padded line pitch
+    constexpr int RROWS = SPLIT ? R1 / 2 : R1; // rows of a line resident in LDS at a time
+    constexpr int PC = RROWS * ROW + 1;       // padded line pitch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     E *data = reinterpret_cast<E *>(smem_raw);      // C * PC
     E *twl = data + C * PC;                          // L middle twiddles w_L^e
@@ -434,8 +438,12 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fdk, const ty
     int ca, ra_;
     if (ra.load_along_line) { ca = tid >> LOGR2; ra_ = tid & (R2 - 1); }
     else { ra_ = tid >> LOGC; ca = tid & (C - 1); }
+    int c, ka; // step B: line and output row of this thread
+    if (ra.store_along_line) { c = tid >> LOGR1; ka = tid & (R1 - 1); }
+    else { ka = tid >> LOGC; c = tid & (C - 1); }
+    E v[R2];
     {
-        E v[R1];
+        E va[R1];
         if (active_a) {
             // lines beyond the end of the batch are clamped to the last line (they compute garbage that is never stored)
             const i64 last = ra.total_lines - 1 - line0;
@@ -443,32 +451,39 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fdk, const ty
             const u32 off = cl * isc + (u32)ra_ * ist;
             const u32 step = (u32)R2 * ist;
 #pragma unroll
-            for (int a = 0; a < R1; a++) v[a] = *reinterpret_cast<const E *>(ginb + (off + (u32)a * step));
-            reg_dif<F, TW, LOGR1>(fd, v, wL, wLq, R2); // w_R1 = w_L^R2
+            for (int a = 0; a < R1; a++) va[a] = *reinterpret_cast<const E *>(ginb + (off + (u32)a * step));
+            reg_dif<F, TW, LOGR1>(fd, va, wL, wLq, R2); // w_R1 = w_L^R2
         }
         __syncthreads(); // middle-twiddle table staged
-        if (active_a) {
-            E *dst = data + ca * PC + ra_;
-            if constexpr (is_wide<TW>()) dst[0] = TW::norm(fd, v[0]);
-            else dst[0] = v[0];
-            u32 idx = 0;
 #pragma unroll
-            for (int ka = 1; ka < R1; ka++) {
-                idx += (u32)ra_; // r * ka
-                dst[ka * ROW] = TW::mul(fd, v[brev_c(ka, LOGR1)], TW::load(twl, twql, idx));
+        for (int h = 0; h < (SPLIT ? 2 : 1); h++) {
+            if (active_a) {
+                E *dst = data + ca * PC + ra_;
+                u32 idx = (u32)ra_ * (u32)(h * RROWS); // r * ka
+#pragma unroll
+                for (int kl = 0; kl < RROWS; kl++) {
+                    const int kaa = h * RROWS + kl;
+                    if (kaa == 0) {
+                        if constexpr (is_wide<TW>()) dst[0] = TW::norm(fd, va[0]);
+                        else dst[0] = va[0];
+                    } else {
+                        dst[kl * ROW] = TW::mul(fd, va[brev_c(kaa, LOGR1)], TW::load(twl, twql, idx));
+                    }
+                    idx += (u32)ra_;
+                }
             }
+            __syncthreads();
+            // ---- step B reads its row once the round that carries it has landed ----
+            if (!SPLIT || (ka / RROWS) == h) {
+                const E *srcl = data + c * PC + (ka - h * RROWS) * ROW;
+#pragma unroll
+                for (int r = 0; r < R2; r++) v[r] = srcl[r];
+            }
+            if (SPLIT && h == 0) __syncthreads();
         }
     }
-    __syncthreads();
     // ---- step B ----
     {
-        int c, ka;
-        if (ra.store_along_line) { c = tid >> LOGR1; ka = tid & (R1 - 1); }
-        else { ka = tid >> LOGC; c = tid & (C - 1); }
-        E v[R2];
-        const E *srcl = data + c * PC + ka * ROW;
-#pragma unroll
-        for (int r = 0; r < R2; r++) v[r] = srcl[r];
         reg_dif<F, TW, LOGR2>(fd, v, wL, wLq, R1); // w_R2 = w_L^R1
         if (ra.post_twiddle) {
             const u32 line = (u32)(ra.line_offset + line0 + c);
@@ -817,13 +832,13 @@ int env_int(const char *name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
-template <class F, class TW, int LOGR1, int LOGR2, int THREADS>
+template <class F, class TW, int LOGR1, int LOGR2, int THREADS, bool SPLIT = false>
 int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64 batch, const void *wl, const void *wlq,
                   const void *pa, const void *paq, const void *pb, const void *pbq, const void *pam, hipStream_t st)
 {
     typedef typename F::elem E;
     constexpr int R1 = 1 << LOGR1, R2 = 1 << LOGR2, L = R1 * R2, C = THREADS / R1;
-    constexpr size_t lds = sizeof(E) * ((size_t)C * (R1 * (R2 + 1) + 1) + (TW::HAS_SHOUP ? 2 : 1) * L); // quotient table only with Shoup twiddles
+    constexpr size_t lds = sizeof(E) * ((size_t)C * ((SPLIT ? R1 / 2 : R1) * (R2 + 1) + 1) + (TW::HAS_SHOUP ? 2 : 1) * L); // quotient table only with Shoup twiddles
     ra.tiles_per_batch = (int)((ra.total_lines + C - 1) / C);
     const unsigned grid = (unsigned)(batch * ra.tiles_per_batch);
     static const int xcd = env_int("GFA_NTT_XCD", 1);
@@ -835,13 +850,14 @@ int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64
             return GFA_ERR_UNSUPPORTED;
         }
     }
-    auto kern = ntt_reg_kernel<F, TW, LOGR1, LOGR2, THREADS>;
+    auto kern = ntt_reg_kernel<F, TW, LOGR1, LOGR2, THREADS, SPLIT>;
     static bool attr = false;
     if (!attr) {
         GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, fd, (const E *)in, (E *)out, ra, (const E *)wl,
+    static const int lds_pad = env_int("GFA_NTT_LDS_PAD", 0); // occupancy experiments only
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds + (size_t)lds_pad, st, fd, (const E *)in, (E *)out, ra, (const E *)wl,
                        (const E *)wlq, (const E *)pa, (const E *)paq, (const E *)pb, (const E *)pbq, (const E *)pam);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
@@ -856,6 +872,8 @@ int launch_reg_t(const FieldDev &fd, const void *in, void *out, const RegArgs &r
         // 32 lines per tile (128-byte global segments, one 1024-thread workgroup per CU) or 16 lines (two 512-thread ones)
         static const int wide = env_int("GFA_NTT_WIDE", 0);
         if (wide) return launch_reg_tt<F, TW, LOGR1, LOGR2, 1024>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
+        static const int split = env_int("GFA_NTT_SPLIT", 1); // two-round LDS exchange: 3 workgroups per CU instead of 2
+        if (split) return launch_reg_tt<F, TW, LOGR1, LOGR2, 512, true>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
         return launch_reg_tt<F, TW, LOGR1, LOGR2, 512>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
     } else if constexpr (sizeof(E) == 8 && LOGR1 == 5 && !TW::HAS_SHOUP) {
         // 64-bit elements: 16 lines per tile (128-byte global segments) in one 512-thread workgroup per CU, or 8 lines in
