@@ -627,20 +627,18 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
 //   * corrected symbols are patched into the output row in place (erased symbols become E, others r ^ E).
 // Per-wave LDS scratch with a compile-time layout: every array is `base + constant`, so the addresses ride in the
 // immediate offset field of the LDS instructions instead of ten live VGPRs (the kernel is register-bound).
-// S = slots per array (>= d - 1 + 4): 40 for n - k <= 36, 64 otherwise.  recv: n <= 256 bytes.
+// S = slots per array (>= d - 1 + 4): 40 for d - 1 <= 36, 64 otherwise.
 template <int S>
 struct WaveScratch2 {
     uint8_t *base;
-    static constexpr int BYTES = 256 + 10 * S;
-    __device__ __forceinline__ uint8_t *recv() const { return base; }
-    __device__ __forceinline__ uint8_t *synd() const { return base + 256; }
-    __device__ __forceinline__ uint8_t *gamma() const { return base + 256 + S; }
-    __device__ __forceinline__ uint8_t *sprime() const { return base + 256 + 2 * S; }
-    __device__ __forceinline__ uint8_t *lam() const { return base + 256 + 3 * S; }
-    __device__ __forceinline__ uint8_t *ltotal() const { return base + 256 + 4 * S; } // 2 S
-    __device__ __forceinline__ uint8_t *epos() const { return base + 256 + 6 * S; }
-    __device__ __forceinline__ uint8_t *errpos() const { return base + 256 + 7 * S; }
-    __device__ __forceinline__ uint8_t *errloc() const { return base + 256 + 8 * S; }
+    static constexpr int BYTES = 7 * S;
+    __device__ __forceinline__ uint8_t *synd() const { return base; }
+    __device__ __forceinline__ uint8_t *gamma() const { return base + S; }
+    __device__ __forceinline__ uint8_t *sprime() const { return base + 2 * S; }
+    __device__ __forceinline__ uint8_t *lam() const { return base + 3 * S; }
+    __device__ __forceinline__ uint8_t *epos() const { return base + 4 * S; }
+    __device__ __forceinline__ uint8_t *errpos() const { return base + 5 * S; }
+    __device__ __forceinline__ uint8_t *errloc() const { return base + 6 * S; }
 };
 
 __device__ __forceinline__ int lane_shift_up1(int v, int)
@@ -651,8 +649,7 @@ __device__ __forceinline__ int lane_shift_up1(int v, int)
 
 // WPS = resident waves per SIMD the register budget is sized for (block = 2 * WPS waves, two blocks per CU)
 template <int S, int WPS>
-__global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables t, RsParams rp, const uint8_t *__restrict__ recv_g,
-                                                             const uint8_t *__restrict__ eras_g,
+__global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables t, RsParams rp, const uint8_t *__restrict__ eras_g,
                                                              const uint8_t *__restrict__ rem_g, int n,
                                                              uint8_t *__restrict__ out_g, i64 *__restrict__ nerr_g, i64 batch)
 {
@@ -802,7 +799,6 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
                     const int ihi = lane < glen - 1 ? lane : glen - 1;
 #pragma unroll 4
                     for (int i = ilo; i <= ihi; i++) ltk ^= ar.mul(ws.gamma()[i], ws.lam()[lane - i]);
-                    ws.ltotal()[lane] = (uint8_t)ltk;
                 }
                 // ---- 6. Chien search: Lambda_total(alpha^-i) by Horner's rule, positions lane, lane+64, lane+128, lane+192
                 u32 xinv[4], acc[4];
@@ -1383,8 +1379,7 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
         static bool attr = false;                                                                                       \
         if ((rc = set_lds_limit(rs_decode_bin_kernel<SV, W>, &attr))) return rc;                                        \
         hipLaunchKernelGGL((rs_decode_bin_kernel<SV, W>), dim3(grid), dim3(nwaves * 64), lds, st, make_tables(*ds), rp, \
-                           (const uint8_t *)recv, erasures, cd->rem, (int)ns, (uint8_t *)out_codeword,                  \
-                           (i64 *)out_n_errors, batch);                                                                 \
+                           erasures, cd->rem, (int)ns, (uint8_t *)out_codeword, (i64 *)out_n_errors, batch);            \
     } while (0)
             if (small) {
                 switch (wps) {
