@@ -209,6 +209,27 @@ def extras(ga, L, lib, stream, with_cpu):
     ex["device_copy"] = {"GB/s": round(copy_gbs, 1), "frac_of_peak": round(copy_gbs / HBM_PEAK_GBS, 4),
                          "note": "torch Tensor.copy_ of 1e8 bytes; roofline fractions elsewhere are against the 8 TB/s spec peak"}
     del src, dst
+    # ---- the headline kernel on arrays far larger than the 256 MiB Infinity Cache (the 1e8-element BASELINE config has a
+    # 300 MB working set and is partly served by it): the HBM-only rate ----
+    nbig = 1_000_000_000
+    xb = torch.empty(nbig, dtype=torch.uint8, device="cuda").random_(0, 256)
+    yb = torch.empty(nbig, dtype=torch.uint8, device="cuda").random_(0, 256)
+    ob = torch.empty_like(xb)
+    L.check(lib.gfa_time_binary(GF._handle, L.OP_MUL, xb.data_ptr(), yb.data_ptr(), ob.data_ptr(), nbig, L.U8, stream, 10, ctypes.byref(ms)))
+    F8b = O.OracleField(2, 8, 285, 2, lookup=True)
+    sl = slice(nbig - 100_000, nbig)
+    assert np.array_equal(ob[sl].cpu().numpy(), F8b.ufunc_u8(O.MUL, xb[sl].cpu().numpy(), yb[sl].cpu().numpy()))
+    e0.record()
+    for _ in range(10):
+        ob.copy_(xb)
+    e1.record()
+    e1.synchronize()
+    ex["gf256_mul_1e9_elements"] = {"Gop/s": round(nbig / (ms.value * 1e-3) / 1e9, 1), "kernel_ms": round(ms.value, 4),
+                                    "algorithmic_GB/s": round(3.0 * nbig / (ms.value * 1e-3) / 1e9, 1),
+                                    "roofline_frac": round(3.0 * nbig / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "device_copy_GB/s_same_size": round(2.0 * nbig / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e9, 1),
+                                    "note": "3 GB working set, no Infinity Cache reuse between launches"}
+    del xb, yb, ob
     # ---- the headline op at the reference docs' dtype=int (int64 storage, 24 B/element), same field and kernel family ----
     n64 = 25_000_000
     a64 = torch.from_numpy(np.random.default_rng(1).integers(0, 256, n64, dtype=np.int64)).cuda()
