@@ -265,6 +265,80 @@ __global__ __launch_bounds__(TAB8_THREADS) void tab8_binary_kernel(const uint8_t
     if constexpr (CHECK_ZERO_B) flag_error(err, bad);
 }
 
+// Large arrays (beyond the Infinity Cache): same table kernel, but the persistent workgroups CLAIM their next 32 KiB block
+// from a global counter instead of striding statically.  Statically assigned workgroups drift apart, the set of DRAM pages
+// in use spreads, and the stream falls to ~5.0 TB/s; claiming in completion order keeps the active window compact, like a
+// flat launch (measured on 1e9-byte operands, tools/ubench/stream3.hip: static 5.0, claimed 5.97, flat 6.0 TB/s).  The claim
+// for the block after next is taken while the current one is looked up, and its loads are issued before the current
+// results are stored.  For small arrays the atomic costs more than the drift (51 vs 47 us at 1e8 elements).
+template <bool CHECK_ZERO_B>
+__global__ __launch_bounds__(TAB8_THREADS) void tab8_binary_claim_kernel(const uint8_t *__restrict__ table,
+                                                                          const uint8_t *__restrict__ a,
+                                                                          const uint8_t *__restrict__ b,
+                                                                          uint8_t *__restrict__ out, i64 n, int32_t *err,
+                                                                          unsigned int *__restrict__ counter)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ unsigned int s_next;
+    constexpr int U = 2; // vectors per thread per block: 2 * 1024 * 16 B = 32 KiB per operand
+    const i64 nvec = n >> 4;
+    const i64 nblk = (nvec + U * TAB8_THREADS - 1) / (U * TAB8_THREADS);
+    const u32x4 *av = reinterpret_cast<const u32x4 *>(a);
+    const u32x4 *bv = reinterpret_cast<const u32x4 *>(b);
+    u32x4 *ov = reinterpret_cast<u32x4 *>(out);
+    i64 blk = blockIdx.x; // the first block of every workgroup is static
+    u32x4 x[U], y[U];
+    auto issue = [&](i64 bk) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const i64 i = (bk * U + u) * TAB8_THREADS + threadIdx.x;
+            if (i < nvec) { x[u] = __builtin_nontemporal_load(av + i); y[u] = __builtin_nontemporal_load(bv + i); }
+        }
+    };
+    if (blk < nblk) issue(blk);
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(table);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds);
+        for (int t = threadIdx.x; t < 65536 / 16; t += TAB8_THREADS) dst[t] = src[t];
+    }
+    __syncthreads();
+    bool bad = false;
+    while (blk < nblk) {
+        if (threadIdx.x == 0) s_next = atomicAdd(counter, 1u) + gridDim.x;
+        u32x4 r[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            r[u].x = lookup4(lds, x[u].x, y[u].x);
+            r[u].y = lookup4(lds, x[u].y, y[u].y);
+            r[u].z = lookup4(lds, x[u].z, y[u].z);
+            r[u].w = lookup4(lds, x[u].w, y[u].w);
+            if constexpr (CHECK_ZERO_B) {
+                u32 z = ((y[u].x - 0x01010101u) & ~y[u].x) | ((y[u].y - 0x01010101u) & ~y[u].y) | ((y[u].z - 0x01010101u) & ~y[u].z) |
+                        ((y[u].w - 0x01010101u) & ~y[u].w);
+                bad |= (z & 0x80808080u) != 0;
+            }
+        }
+        __syncthreads();
+        const i64 cur = blk;
+        blk = s_next;
+        __syncthreads();
+        if (blk < nblk) issue(blk);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const i64 i = (cur * U + u) * TAB8_THREADS + threadIdx.x;
+            if (i < nvec) __builtin_nontemporal_store(r[u], ov + i);
+        }
+    }
+    // tail (< 16 elements): first workgroup
+    if (blockIdx.x == 0)
+        for (i64 j = (nvec << 4) + threadIdx.x; j < n; j += TAB8_THREADS) {
+            uint8_t yb = b[j];
+            if (CHECK_ZERO_B && yb == 0) bad = true;
+            out[j] = lds[((u32)a[j] << 8) | yb];
+        }
+    if constexpr (CHECK_ZERO_B) flag_error(err, bad);
+}
+
 // Unary / scalar-operand form: out = TABLE256[a].  The 256-entry table is replicated 32x in LDS as dwords,
 // entry v of copy c at dword v*32 + c, and lane l reads copy l%32 => every lane of a 32-lane LDS group hits its
 // own bank, no conflicts for any data.
@@ -334,6 +408,16 @@ inline int grid_for(i64 work_items, int threads, int blocks_per_cu)
     return (int)(blocks < cap ? blocks : cap);
 }
 
+// Streaming kernels without per-workgroup set-up are launched FLAT (one 16-byte vector per thread).  With a persistent
+// grid-stride launch the workgroups drift apart, the active address window spreads and HBM efficiency drops once the
+// arrays exceed the Infinity Cache: 5.0 vs 6.0-6.6 TB/s on 1e9-byte operands (tools/ubench/stream_big.hip).
+inline int grid_flat(i64 work_items, int threads)
+{
+    i64 blocks = (work_items + threads - 1) / threads;
+    if (blocks < 1) blocks = 1;
+    return (int)(blocks < 0x7fffffff ? blocks : 0x7fffffff);
+}
+
 template <class F, typename T>
 int launch_binary_ft(const FieldDev &fd, int op, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n,
                      hipStream_t st, int32_t *err)
@@ -342,7 +426,7 @@ int launch_binary_ft(const FieldDev &fd, int op, const void *a, i64 sa, const vo
     T *po = (T *)out;
     const bool vec = aligned16(out) && (sa == 0 || aligned16(a)) && (sb == 0 || aligned16(b));
     constexpr int V = Vec16<T>::N;
-    const int grid = grid_for(vec ? (n + V - 1) / V : n, 256, 8);
+    const int grid = grid_flat(vec ? (n + V - 1) / V : n, 256);
 #define GFA_LAUNCH_B(OPC)                                                                                              \
     if (vec) hipLaunchKernelGGL((ew_binary_kernel<F, T, OPC, true>), dim3(grid), dim3(256), 0, st, fd, pa, (int)sa, pb, \
                                 (int)sb, po, n, err);                                                                  \
@@ -367,7 +451,7 @@ int launch_unary_ft(const FieldDev &fd, int op, const void *a, void *out, i64 n,
     T *po = (T *)out;
     const bool vec = aligned16(out) && aligned16(a);
     constexpr int V = Vec16<T>::N;
-    const int grid = grid_for(vec ? (n + V - 1) / V : n, 256, 8);
+    const int grid = grid_flat(vec ? (n + V - 1) / V : n, 256);
 #define GFA_LAUNCH_U(OPC)                                                                                             \
     if (vec) hipLaunchKernelGGL((ew_unary_kernel<F, T, OPC, true>), dim3(grid), dim3(256), 0, st, fd, pa, po, n, err); \
     else hipLaunchKernelGGL((ew_unary_kernel<F, T, OPC, false>), dim3(grid), dim3(256), 0, st, fd, pa, po, n, err);
@@ -766,7 +850,26 @@ int launch_tab8_binary(const uint8_t *table, bool check_zero_b, const void *a, c
                        hipStream_t st, int32_t *err)
 {
     const int grid = tab8_grid(n);
-    static bool attr[2] = {false, false};
+    static bool attr[4] = {false, false, false, false};
+    if (n >= ((i64)1 << 28)) { // operands beyond the Infinity Cache: claimed blocks (see tab8_binary_claim_kernel)
+        unsigned int *counter = nullptr;
+        GFA_HIP(hipMallocAsync((void **)&counter, sizeof(unsigned int), st));
+        GFA_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned int), st));
+        if (check_zero_b) {
+            auto k = tab8_binary_claim_kernel<true>;
+            if (!attr[3]) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr[3] = true; }
+            hipLaunchKernelGGL(k, dim3(grid), dim3(TAB8_THREADS), 65536, st, table, (const uint8_t *)a, (const uint8_t *)b,
+                               (uint8_t *)out, n, err, counter);
+        } else {
+            auto k = tab8_binary_claim_kernel<false>;
+            if (!attr[2]) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr[2] = true; }
+            hipLaunchKernelGGL(k, dim3(grid), dim3(TAB8_THREADS), 65536, st, table, (const uint8_t *)a, (const uint8_t *)b,
+                               (uint8_t *)out, n, err, counter);
+        }
+        GFA_HIP(hipGetLastError());
+        GFA_HIP(hipFreeAsync(counter, st));
+        return GFA_OK;
+    }
     if (check_zero_b) {
         auto k = tab8_binary_kernel<true>;
         if (!attr[1]) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr[1] = true; }

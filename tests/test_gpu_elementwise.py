@@ -308,3 +308,21 @@ def test_vector_and_Vector(order):
     # addition in GF(p^m) is digit-wise addition in GF(p)
     a, b = GF.Random(100, seed=1), GF.Random(100, seed=2)
     assert np.array_equal((a + b).vector().numpy(), (a.vector() + b.vector()).numpy())
+
+
+def test_gf256_arrays_beyond_the_infinity_cache():
+    """2^28 + 12345 elements: the table kernel switches to claimed blocks (and the generic kernels to flat launches); the
+    whole result is compared with the oracle, and a zero divisor anywhere still raises."""
+    GF = ga.GF(2**8)
+    F = O.OracleField(2, 8, 285, 2, lookup=True)
+    n = (1 << 28) + 12345
+    rng = np.random.default_rng(123)
+    a = rng.integers(0, 256, n, dtype=np.uint8)
+    b = rng.integers(1, 256, n, dtype=np.uint8)
+    ga_, gb_ = GF(a), GF(b)
+    assert np.array_equal((ga_ * gb_).numpy(), F.ufunc_u8(O.MUL, a, b))
+    assert np.array_equal((ga_ / gb_).numpy(), F.ufunc_u8(O.DIV, a, b))
+    assert np.array_equal((ga_ + gb_).numpy(), a ^ b)
+    b[n - 7] = 0
+    with pytest.raises(ZeroDivisionError):
+        ga_ / GF(b)

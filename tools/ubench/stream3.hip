@@ -1,6 +1,7 @@
 // Micro-benchmark: which launch structure streams 2 reads + 1 write (out = a ^ b, uint8, 1e8 elements) fastest on gfx950.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef long long i64;
 
@@ -204,15 +205,15 @@ float timeit(F f)
     return best;
 }
 
-int main()
+int main(int argc, char **argv)
 {
-    const i64 n = 100000000, nvec = n / 16;
+    const i64 n = argc > 1 ? atoll(argv[1]) : 100000000, nvec = n / 16;
     u32x4 *a, *b, *o;
     hipMalloc(&a, n); hipMalloc(&b, n); hipMalloc(&o, n);
     hipMemset(a, 1, n); hipMemset(b, 2, n);
     const int cus = 256;
     unsigned *ctr; hipMalloc(&ctr, 8); hipMemset(ctr, 0, 8);
-#define RUN(name, bytes, ...) { float ms = timeit([&]() { __VA_ARGS__; }); printf("%-46s %7.2f us  %6.3f TB/s\n", name, ms * 1e3, bytes / ms / 1e9); }
+#define RUN(name, bytes, ...) { float ms = timeit([&]() { __VA_ARGS__; }); printf("%-46s %7.2f us  %6.3f TB/s\n", name, ms * 1e3, (bytes) * (double)n / 1e8 / ms / 1e9); }
     // GF(2^8)/0x11d product table and random operands
     unsigned char *htab = (unsigned char *)malloc(65536), *dtab;
     for (int x = 0; x < 256; x++) for (int y = 0; y < 256; y++) {
