@@ -886,6 +886,15 @@ class FieldArray(metaclass=FieldArrayMeta):
         else:
             b = base if isinstance(base, cls) else cls(base)
             t, sa, tb, sb, out_shape = self._broadcast(self._t, self._same_storage(b))
+        if cls._order > 2**20 and not getattr(cls, "_log_prepared", False):
+            # no LOG table: the device runs Pohlig-Hellman and needs the factorisation of q - 1 (host number theory, once)
+            from . import _numtheory as nt
+
+            primes, mults = nt.factors(cls._order - 1)
+            pa = (ctypes.c_uint64 * len(primes))(*primes)
+            ma = (ctypes.c_uint32 * len(primes))(*mults)
+            L.check(L.lib().gfa_log_prepare(cls._handle, pa, ma, len(primes)), "gfa_log_prepare")
+            cls._log_prepared = True
         out = torch.empty(out_shape, dtype=torch.int64, device=t.device)
         err = torch.zeros(1, dtype=torch.int32, device=t.device)
         L.check(L.lib().gfa_log(cls._handle, _ptr(t), sa, _ptr(tb) if tb is not None else None, sb, _ptr(out), out.numel(),
@@ -896,6 +905,10 @@ class FieldArray(metaclass=FieldArrayMeta):
         if e & L.DEVERR_LOG_BASE:
             raise ArithmeticError("The specified logarithm base is not a primitive element of the Galois field.")
         res = out.cpu().numpy()
+        if cls._order > 2**63:  # logarithms up to q - 2 do not fit int64: Python integers, like the reference's object arrays
+            u = res.view(np.uint64)
+            obj = np.array([int(v) for v in u.ravel()], dtype=object).reshape(u.shape)
+            return int(obj) if obj.ndim == 0 else obj
         return int(res) if res.ndim == 0 else res
 
     def is_square(self):

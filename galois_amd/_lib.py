@@ -54,6 +54,7 @@ SIGNATURES = {
     "gfa_ntt_columns": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_u64, c_int, c_void_p]),
     "gfa_vector": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_i64, c_void_p]),
     "gfa_poly_evaluate": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    "gfa_log_prepare": (c_int, [c_void_p, _u64p, ctypes.POINTER(c_u32), c_int]),
     "gfa_log": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "gfa_matmul": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),
     "gfa_row_reduce": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_void_p, c_int, c_void_p]),

@@ -1075,12 +1075,10 @@ int gfa_log(gfa_field_t *f, const void *a, int64_t a_stride, const void *base, i
         return GFA_ERR_INVALID;
     }
     if (!dtype_holds(dtype, f->calc.q)) { set_error("dtype cannot hold the field's elements"); return GFA_ERR_INVALID; }
-    if (!f->has_lut) {
-        set_error("gfa_log: discrete logarithms are implemented for fields with EXP/LOG tables (order <= 2^20)");
-        return GFA_ERR_UNSUPPORTED;
-    }
     if (n == 0) return GFA_OK;
     if (!a || !out) { set_error("gfa_log: bad arguments"); return GFA_ERR_INVALID; }
+    if (!f->has_lut) // no LOG table: Pohlig-Hellman with baby-step / giant-step digits (gfa_dlog.hip)
+        return dlog_run(f, a, a_stride, base, base_stride, out, n, dtype, (hipStream_t)stream, dev_err);
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;

@@ -307,6 +307,7 @@ void gfa_field_destroy(gfa_field_t *f)
 {
     if (!f) return;
     gfa::ntt_forget_field(f);
+    gfa::dlog_forget_field(f);
     for (auto &st : f->dev) {
         if (!st.ready) continue;
         (void)hipFree(st.exp_tab); (void)hipFree(st.log_tab); (void)hipFree(st.zech_tab);

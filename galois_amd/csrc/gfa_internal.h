@@ -27,6 +27,11 @@ int time_loop(hipStream_t st, int iters, float *ms_out, const std::function<int(
 
 void ntt_forget_field(const struct ::gfa_field *f); // drops cached NTT plans of a field being destroyed
 
+// discrete logarithms without tables (gfa_dlog.hip)
+void dlog_forget_field(const struct ::gfa_field *f);
+int dlog_run(struct ::gfa_field *f, const void *a, i64 sa, const void *base, i64 sb, int64_t *out, i64 n, int dtype, hipStream_t st,
+             int32_t *err);
+
 // matrix-core path of gfa_matmul for prime fields with p <= 256 (gfa_matmul_mfma.hip)
 bool matmul_mfma_eligible(const FieldDev &fd, i64 M, i64 K, i64 N);
 int matmul_mfma(const FieldDev &fd, int dtype, const void *a, const void *b, void *out, i64 batch, i64 M, i64 K, i64 N,

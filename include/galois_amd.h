@@ -127,7 +127,10 @@ int gfa_poly_evaluate(gfa_field_t *f, const void *coeffs, int64_t ncoef, const v
 /* log_ufunc (_domains/_lookup.py:273-294; FieldArray.log _fields/_array.py:2127-2200): out[i] = log_base(a[i]) as
  * int64.  base == NULL: the field's primitive element.  Strides in {0, 1} as for gfa_binary.  a[i] == 0 ORs
  * GFA_DEVERR_LOG_ZERO, a non-primitive base GFA_DEVERR_LOG_BASE into *dev_err (both ArithmeticError in the reference).
- * Fields of order <= 2^20 (those with LOG tables); larger fields return GFA_ERR_UNSUPPORTED. */
+ * Fields of order <= 2^20 read their LOG table.  Larger fields (the reference: log_pollard_rho / log_pohlig_hellman,
+ * _calculate.py:630-755) run Pohlig-Hellman on the device and need gfa_log_prepare once: the prime factorisation of q - 1
+ * (primes ascending, multiplicities; every prime at most 2^40).  Results of fields with q > 2^63 are uint64 bit patterns. */
+int gfa_log_prepare(gfa_field_t *f, const uint64_t *primes, const uint32_t *multiplicities, int count);
 int gfa_log(gfa_field_t *f, const void *a, int64_t a_stride, const void *base, int64_t base_stride, int64_t *out, int64_t n,
             int dtype, gfa_stream_t stream, int32_t *dev_err);
 
