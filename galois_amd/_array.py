@@ -658,6 +658,76 @@ class FieldArray(metaclass=FieldArrayMeta):
             out = out.unsqueeze(axis if axis is not None else 0) if axis is not None else out.reshape((1,) * t.dim())
         return cls._wrap(out, self._np_dtype)
 
+    def _reduceat(self, op: int, indices, axis: int) -> "FieldArray":
+        """ufunc.reduceat: folds of a[indices[i] : indices[i+1]] along `axis` (the last one runs to the end; an empty or
+        reversed slice yields a[indices[i]])."""
+        cls = type(self)
+        idx = np.asarray(indices)
+        if idx.ndim != 1 or not np.issubdtype(idx.dtype, np.integer):
+            raise TypeError("Argument 'indices' of reduceat must be a 1-D integer array.")
+        t = self._t
+        if t.dim() == 0:
+            raise TypeError("cannot reduceat on a scalar")
+        axis = axis % t.dim()
+        n = t.shape[axis]
+        if idx.size and (idx.min() < 0 or idx.max() >= n):
+            raise IndexError(f"index {int(idx.max() if idx.max() >= n else idx.min())} out-of-bounds in reduceat [0, {n})")
+        t2 = t.movedim(axis, -1).contiguous()
+        lead = tuple(t2.shape[:-1])
+        rows = int(np.prod(lead)) if lead else 1
+        starts = np.asarray(idx, dtype=np.int64)
+        ends = np.concatenate([starts[1:], [n]]).astype(np.int64)
+        base = (np.arange(rows, dtype=np.int64) * n)[:, None]
+        st = torch.from_numpy(np.ascontiguousarray((base + starts[None, :]).ravel())).to(t.device)
+        en = torch.from_numpy(np.ascontiguousarray((base + ends[None, :]).ravel())).to(t.device)
+        out = torch.empty(rows * idx.size, dtype=t.dtype, device=t.device)
+        err = torch.zeros(1, dtype=torch.int32, device=t.device)
+        L.check(L.lib().gfa_reduceat(cls._handle, op, _ptr(t2), _ptr(st), _ptr(en), st.numel(), _ptr(out), self._gfa_dtype(), _stream(),
+                                     _ptr(err)), "gfa_reduceat")
+        self._check_err(err)
+        return cls._wrap(out.reshape(lead + (idx.size,)).movedim(-1, axis).contiguous(), self._np_dtype)
+
+    def _at(self, ufunc, indices, values):
+        """ufunc.at: unbuffered in-place a[indices] = op(a[indices], values); repeated indices are applied one after the other,
+        as NumPy does: round r updates the r-th occurrence of every index (all distinct within a round)."""
+        cls = type(self)
+        idx = np.asarray(indices)
+        if idx.dtype == bool or not np.issubdtype(idx.dtype, np.integer):
+            raise TypeError("Argument 'indices' of ufunc.at must be an integer array (flat indices of a 1-D array or the first axis).")
+        if self._t.dim() != 1:
+            raise NotImplementedError("ufunc.at is implemented for 1-D field arrays.")
+        n = self._t.shape[0]
+        flat = idx.ravel().astype(np.int64)
+        flat = np.where(flat < 0, flat + n, flat)
+        if flat.size and (flat.min() < 0 or flat.max() >= n):
+            raise IndexError(f"index out of bounds for axis 0 with size {n}")
+        vals = None
+        if values is not None:
+            if ufunc is np.power or (ufunc is np.multiply and not isinstance(values, FieldArray)):
+                vals = np.broadcast_to(np.asarray(values), idx.shape).ravel()
+            else:
+                v = values if isinstance(values, cls) else cls(values)
+                vals = cls._wrap(torch.broadcast_to(self._same_storage(v), idx.shape).reshape(-1).contiguous(), self._np_dtype)
+        # occurrence number of every entry within its index group (stable order)
+        order = np.argsort(flat, kind="stable")
+        sorted_idx = flat[order]
+        group_start = np.r_[0, np.nonzero(np.diff(sorted_idx))[0] + 1] if flat.size else np.zeros(0, dtype=np.int64)
+        occ_sorted = np.arange(flat.size) - np.repeat(group_start, np.diff(np.r_[group_start, flat.size]))
+        occ = np.empty(flat.size, dtype=np.int64)
+        occ[order] = occ_sorted
+        for r in range(int(occ.max()) + 1 if flat.size else 0):
+            sel = np.nonzero(occ == r)[0]
+            ti = torch.from_numpy(flat[sel]).to(self._t.device)
+            cur = cls._wrap(self._t[ti], self._np_dtype)
+            if values is None:
+                new = ufunc(cur)
+            elif isinstance(vals, FieldArray):
+                new = ufunc(cur, vals[torch.from_numpy(sel).to(self._t.device)])
+            else:
+                new = ufunc(cur, vals[sel])
+            self._t[ti] = new._t
+        return None
+
     def _accumulate(self, op: int, axis: int) -> "FieldArray":
         cls = type(self)
         t = self._t
@@ -724,6 +794,14 @@ class FieldArray(metaclass=FieldArrayMeta):
             if method == "accumulate":
                 same_field()
                 return inputs[0]._accumulate(op, kwargs.get("axis", 0))
+            if method == "reduceat":
+                if not isinstance(inputs[0], cls):
+                    raise TypeError(f"Operation {ufunc.__name__!r} requires a {cls!r} array, not {type(inputs[0])}.")
+                return inputs[0]._reduceat(op, inputs[1], kwargs.get("axis", 0))
+            if method == "at":
+                if not isinstance(inputs[0], cls):
+                    raise TypeError(f"Operation {ufunc.__name__!r} requires a {cls!r} array, not {type(inputs[0])}.")
+                return inputs[0]._at(ufunc, inputs[1], inputs[2] if len(inputs) > 2 else None)
             if method == "outer":
                 same_field()
                 a, b = inputs
@@ -731,6 +809,10 @@ class FieldArray(metaclass=FieldArrayMeta):
                 tb = b._t.reshape((1,) * a.ndim + tuple(b.shape))
                 return self._binary(op, cls._wrap(ta, a._np_dtype), cls._wrap(tb, b._np_dtype))
             raise NotImplementedError(f"Ufunc method {method!r} of {ufunc.__name__!r} is not implemented on the device.")
+        if ufunc in (np.negative, np.reciprocal) and method == "at":
+            return inputs[0]._at(ufunc, inputs[1], None)
+        if ufunc is np.power and method == "at":
+            return inputs[0]._at(ufunc, inputs[1], inputs[2])
         if ufunc in (np.negative, np.reciprocal):
             if method != "__call__":
                 raise ValueError(

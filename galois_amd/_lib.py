@@ -48,6 +48,7 @@ SIGNATURES = {
     "gfa_power": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "gfa_scalar_multiply": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p]),
     "gfa_reduce": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p]),
+    "gfa_reduceat": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_int, c_void_p, c_void_p]),
     "gfa_accumulate": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "gfa_convolve": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p]),
     "gfa_ntt": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_u64, c_int, c_int, c_void_p]),

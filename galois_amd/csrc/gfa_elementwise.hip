@@ -560,6 +560,71 @@ __global__ void reduce_finalize_kernel(FieldDev fd, const T *__restrict__ in, i6
     flag_error(err, bad);
 }
 
+// ufunc.reduceat: out[s] = fold(a[starts[s] : ends[s]]) with NumPy's convention that an empty or reversed slice yields
+// a[starts[s]].  One 64-lane workgroup per segment; subtract / divide are left folds a0 - sum(rest), a0 / prod(rest).
+template <class F, typename T, bool IS_MUL>
+__global__ __launch_bounds__(64) void reduce_ragged_kernel(FieldDev fd, const T *__restrict__ in, const i64 *__restrict__ starts,
+                                                           const i64 *__restrict__ ends, T *__restrict__ out, int mode, int32_t *err)
+{
+    typedef typename F::elem E;
+    __shared__ u64 sh[64];
+    const i64 lo = starts[blockIdx.x];
+    i64 hi = ends[blockIdx.x];
+    if (hi <= lo) hi = lo + 1;
+    const i64 first = mode ? lo + 1 : lo;
+    E acc = IS_MUL ? F::one(fd) : (E)0;
+    for (i64 i = first + threadIdx.x; i < hi; i += 64) {
+        const E v = (E)in[i];
+        acc = IS_MUL ? F::mul(fd, acc, v) : F::add(fd, acc, v);
+    }
+    sh[threadIdx.x] = (u64)acc;
+    __syncthreads();
+    for (int off = 32; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const E x = (E)sh[threadIdx.x], y = (E)sh[threadIdx.x + off];
+            sh[threadIdx.x] = (u64)(IS_MUL ? F::mul(fd, x, y) : F::add(fd, x, y));
+        }
+        __syncthreads();
+    }
+    bool bad = false;
+    if (threadIdx.x == 0) {
+        E r = (E)sh[0];
+        if (mode == 1) r = F::sub(fd, (E)in[lo], r);
+        if (mode == 2) {
+            const E a0 = (E)in[lo];
+            if (r == 0) { bad = true; r = 0; }
+            else if (a0 == 0) r = 0;
+            else {
+                if constexpr (std::is_same<F, Lut>::value) r = Lut::div_nz(fd, a0, r);
+                else r = F::mul(fd, a0, F::inv(fd, r));
+            }
+        }
+        out[blockIdx.x] = (T)r;
+    }
+    flag_error(err, bad);
+}
+
+template <class F, typename T>
+int launch_reduceat_ft(const FieldDev &fd, int op, const void *a, const i64 *starts, const i64 *ends, i64 nseg, void *out,
+                       hipStream_t st, int32_t *err)
+{
+    const bool is_mul = op == GFA_OP_MUL || op == GFA_OP_DIV;
+    const int mode = op == GFA_OP_SUB ? 1 : op == GFA_OP_DIV ? 2 : 0;
+    if (is_mul)
+        hipLaunchKernelGGL((reduce_ragged_kernel<F, T, true>), dim3((unsigned)nseg), dim3(64), 0, st, fd, (const T *)a, starts, ends,
+                           (T *)out, mode, err);
+    else
+        hipLaunchKernelGGL((reduce_ragged_kernel<F, T, false>), dim3((unsigned)nseg), dim3(64), 0, st, fd, (const T *)a, starts, ends,
+                           (T *)out, mode, err);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+int dispatch_reduceat(const FieldDev &fd, int dtype, int op, const void *a, const i64 *starts, const i64 *ends, i64 nseg, void *out,
+                      hipStream_t st, int32_t *err)
+{
+    GFA_DISPATCH_FT(launch_reduceat_ft, fd, dtype, fd, op, a, starts, ends, nseg, out, st, err);
+}
+
 struct ReduceScratch {
     u64 *p = nullptr;
     size_t n = 0;
@@ -1006,6 +1071,21 @@ int gfa_reduce(gfa_field_t *f, int op, const void *a, void *out, int64_t n_outer
     if (rc) return rc;
     if (f->use_lookup()) return dispatch_reduce(f->lut_desc(*ds), dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
     return dispatch_reduce(f->calc, dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
+}
+
+int gfa_reduceat(gfa_field_t *f, int op, const void *a, const int64_t *starts, const int64_t *ends, int64_t nseg, void *out, int dtype,
+                 gfa_stream_t stream, int32_t *dev_err)
+{
+    if (!f || nseg < 0 || op < GFA_OP_ADD || op > GFA_OP_DIV) { set_error("gfa_reduceat: bad arguments"); return GFA_ERR_INVALID; }
+    if (!dtype_holds(dtype, f->calc.q)) { set_error("dtype cannot hold the field's elements"); return GFA_ERR_INVALID; }
+    if (nseg == 0) return GFA_OK;
+    if (!a || !starts || !ends || !out || nseg > 0x7fffffff) { set_error("gfa_reduceat: bad arguments"); return GFA_ERR_INVALID; }
+    FieldDeviceState *ds;
+    int rc = f->ensure_device(nullptr, &ds);
+    if (rc) return rc;
+    if (f->use_lookup())
+        return dispatch_reduceat(f->lut_desc(*ds), dtype, op, a, (const i64 *)starts, (const i64 *)ends, nseg, out, (hipStream_t)stream, dev_err);
+    return dispatch_reduceat(f->calc, dtype, op, a, (const i64 *)starts, (const i64 *)ends, nseg, out, (hipStream_t)stream, dev_err);
 }
 
 int gfa_accumulate(gfa_field_t *f, int op, const void *a, void *out, int64_t n_outer, int64_t n_inner, int dtype,

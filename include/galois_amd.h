@@ -108,6 +108,10 @@ int gfa_reduce(gfa_field_t *f, int op, const void *a, void *out, int64_t n_outer
                gfa_stream_t stream, int32_t *dev_err);
 
 /* ufunc.accumulate over the last axis of an (n_outer, n_inner) array, same ops and fold conventions as gfa_reduce. */
+/* ufunc.reduceat (dispatched like reduce, _domains/_ufunc.py:689): out[s] = fold of a[starts[s] : ends[s]] with the op; an
+ * empty or reversed slice yields a[starts[s]] (NumPy's convention).  starts / ends: device int64 arrays of nseg entries. */
+int gfa_reduceat(gfa_field_t *f, int op, const void *a, const int64_t *starts, const int64_t *ends, int64_t nseg, void *out, int dtype,
+                 gfa_stream_t stream, int32_t *dev_err);
 int gfa_accumulate(gfa_field_t *f, int op, const void *a, void *out, int64_t n_outer, int64_t n_inner, int dtype,
                    gfa_stream_t stream, int32_t *dev_err);
 /* np.convolve(a, b), mode "full": out[k] = sum_i a[i] * b[k-i], na + nb - 1 outputs -- convolve_jit

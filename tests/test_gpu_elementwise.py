@@ -326,3 +326,54 @@ def test_gf256_arrays_beyond_the_infinity_cache():
     b[n - 7] = 0
     with pytest.raises(ZeroDivisionError):
         ga_ / GF(b)
+
+
+@pytest.mark.parametrize("order", [2**8, 31, 65537, 3**5, 2**32])
+def test_reduceat_and_at(order):
+    """ufunc.reduceat / ufunc.at (tests/fields/test_numpy_ufuncs.py TestReduceAt / TestAt) against sequential oracle folds."""
+    GF = ga.GF(order)
+    F = O.OracleField(GF.characteristic, GF.degree, int(GF.irreducible_poly) if GF.degree > 1 else None, int(GF.primitive_element))
+    rng = np.random.default_rng(order % 97)
+    a = rng.integers(1, order, 50, dtype=np.uint64)
+    idx = np.array([0, 7, 7, 20, 3, 49, 10])  # increasing, repeated and decreasing entries
+    ends = list(idx[1:]) + [50]
+    for ufn, op in ((np.add, F.add), (np.subtract, F.sub), (np.multiply, F.mul), (np.true_divide, F.div)):
+        got = ufn.reduceat(GF(a), idx).numpy().astype(np.uint64)
+        want = []
+        for s0, e0 in zip(idx, ends):
+            seg = a[s0:e0] if e0 > s0 else a[s0:s0 + 1]
+            acc = seg[0]
+            for v in seg[1:]:
+                acc = op([acc], [v])[0]
+            want.append(acc)
+        assert np.array_equal(got, np.array(want, dtype=np.uint64)), ufn.__name__
+    m2 = rng.integers(0, order, (4, 50), dtype=np.uint64)
+    got = np.add.reduceat(GF(m2), [0, 10, 25], axis=1).numpy().astype(np.uint64)
+    for r in range(4):
+        for j, (s0, e0) in enumerate(((0, 10), (10, 25), (25, 50))):
+            acc = m2[r, s0]
+            for v in m2[r, s0 + 1:e0]:
+                acc = F.add([acc], [v])[0]
+            assert got[r, j] == acc
+    # at: repeated indices accumulate in order
+    x = GF(a.copy())
+    ii = np.array([3, 3, 5, 3, 49, 0, 5])
+    vv = rng.integers(1, order, ii.size, dtype=np.uint64)
+    np.add.at(x, ii, GF(vv))
+    want = a.copy()
+    for i, v in zip(ii, vv):
+        want[i] = F.add([want[i]], [v])[0]
+    assert np.array_equal(x.numpy().astype(np.uint64), want)
+    np.multiply.at(x, ii, GF(vv))
+    for i, v in zip(ii, vv):
+        want[i] = F.mul([want[i]], [v])[0]
+    assert np.array_equal(x.numpy().astype(np.uint64), want)
+    np.negative.at(x, [1, 1, 2])
+    want[2] = F.neg([want[2]])[0]
+    assert np.array_equal(x.numpy().astype(np.uint64), want)
+    np.power.at(x, [4, 4], 3)
+    want[4] = F.pow([want[4]], [9])[0]
+    assert np.array_equal(x.numpy().astype(np.uint64), want)
+    np.subtract.at(x, [6], GF(vv[:1]))
+    want[6] = F.sub([want[6]], [vv[0]])[0]
+    assert np.array_equal(x.numpy().astype(np.uint64), want)
