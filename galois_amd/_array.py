@@ -928,6 +928,64 @@ class FieldArray(metaclass=FieldArrayMeta):
     def __matmul__(self, o): return np.matmul(self, o)
     def __rmatmul__(self, o): return np.matmul(o, self)
 
+    # ---- orders, trace and norm (_fields/_array.py:1233-1360, 1759-1880) --------------------------------------------------
+    def additive_order(self):
+        """1 for the zero element, the characteristic otherwise."""
+        cls = type(self)
+        r = torch.where(self._t == 0, 1, cls._characteristic).cpu().numpy().astype(np.int64)
+        return int(r) if r.ndim == 0 else r
+
+    def multiplicative_order(self):
+        """Smallest a > 0 with x**a == 1.  For every prime r | q - 1 the factor r is stripped from the candidate order while
+        x**(order / r) == 1 -- element-wise masks on the device, the same value as the reference's divisor search / log formula."""
+        cls = type(self)
+        if bool((self._t == 0).any()):
+            raise ArithmeticError("The multiplicative order of 0 is not defined.")
+        from . import _numtheory as nt
+
+        n = cls._order - 1
+        order = np.full(tuple(self.shape), n, dtype=object)
+        if n > 1:
+            primes, mults = nt.factors(n)
+            for r, e in zip(primes, mults):
+                for _ in range(e):
+                    # candidates still divisible by r: test x**(order / r) == 1 group by group of equal exponents
+                    flat = order.ravel()
+                    for val in sorted(set(int(v) for v in flat if int(v) % r == 0)):
+                        ex = val // r
+                        if ex >= 2**63:
+                            continue
+                        w = self._with_int(ex, is_pow=True)
+                        hit = ((w._t == 1).cpu().numpy().ravel()) & np.array([int(v) == val for v in flat])
+                        for i in np.nonzero(hit)[0]:
+                            flat[i] = ex
+                    order = flat.reshape(order.shape)
+        if cls._order <= 2**63:
+            order = order.astype(np.int64)
+        return int(order) if order.ndim == 0 else order
+
+    def field_trace(self) -> "FieldArray":
+        """Tr(x) = sum of x**(p**i), i < m, an element of the prime subfield."""
+        cls = type(self)
+        sub = cls.prime_subfield
+        if cls._degree == 1:
+            return self.copy()
+        acc = self
+        conj = self
+        for _ in range(1, cls._degree):
+            conj = conj._with_int(cls._characteristic, is_pow=True)
+            acc = acc + conj
+        return sub._wrap(_to_storage(acc._t, _TORCH_STORAGE[sub._itemsize(sub._get_dtype(None))]), sub._get_dtype(None))
+
+    def field_norm(self) -> "FieldArray":
+        """N(x) = x**((q - 1) / (p - 1)), an element of the prime subfield."""
+        cls = type(self)
+        sub = cls.prime_subfield
+        if cls._degree == 1:
+            return self.copy()
+        w = self._with_int((cls._order - 1) // (cls._characteristic - 1), is_pow=True)
+        return sub._wrap(_to_storage(w._t, _TORCH_STORAGE[sub._itemsize(sub._get_dtype(None))]), sub._get_dtype(None))
+
     # ---- vector-space view over the prime subfield (_fields/_array.py:383-491) ----------------------------------------
     def vector(self, dtype=None) -> "FieldArray":
         """FieldArray.vector: shape (...,) over GF(p^m) -> shape (..., m) over GF(p), degree m-1 first."""

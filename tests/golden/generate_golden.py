@@ -113,6 +113,9 @@ def pack_sage_polys():
             out[f"evaluate{i}_Z"] = small(np.asarray(d["Z"][i]))
         d = pickle.load(open(os.path.join(fpath, "log.pkl"), "rb"))
         out["log_X"], out["log_Z"] = small(np.asarray(d["X"])), small(np.asarray(d["Z"]))
+        for op in ("field_trace", "field_norm", "additive_order", "multiplicative_order"):
+            d = pickle.load(open(os.path.join(fpath, op + ".pkl"), "rb"))
+            out[f"{op}_X"], out[f"{op}_Z"] = small(np.asarray(d["X"])), small(np.asarray(d["Z"]))
         name = folder.replace("(", "_").replace(")", "").replace("^", "e").replace(", ", "_")
         np.savez_compressed(os.path.join(HERE, f"sage_polys_{name}.npz"), **out)
         print("packed polys", folder)

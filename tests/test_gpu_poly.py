@@ -174,3 +174,20 @@ def test_discrete_log_without_tables(q):
             b = int(F.mul([b], [b])[0])
             ee >>= 1
         assert r == int(v)
+
+
+@pytest.mark.parametrize("tag", H.SAGE_POLYS)
+def test_sage_orders_trace_norm(tag):
+    """tests/fields/test_arithmetic_methods.py: additive / multiplicative order, field trace and norm vs the Sage vectors."""
+    props, d = H.load_sage_polys(tag)
+    GF = _field(props)
+    H.assert_equal_ints(GF(d["additive_order_X"]).additive_order(), d["additive_order_Z"])
+    H.assert_equal_ints(GF(d["multiplicative_order_X"]).multiplicative_order(), d["multiplicative_order_Z"])
+    tr = GF(d["field_trace_X"]).field_trace()
+    assert type(tr) is GF.prime_subfield
+    H.assert_equal_ints(tr.numpy(), d["field_trace_Z"])
+    nm = GF(d["field_norm_X"]).field_norm()
+    assert type(nm) is GF.prime_subfield
+    H.assert_equal_ints(nm.numpy(), d["field_norm_Z"])
+    with pytest.raises(ArithmeticError):
+        GF([1, 0]).multiplicative_order()
