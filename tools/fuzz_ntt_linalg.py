@@ -56,6 +56,18 @@ while time.time() < t_end:
     else:
         q = int(LA_FIELDS[rng.integers(0, len(LA_FIELDS))])
         GF, F = pair(q)
+        if q in (2, 3, 31, 251) and rng.random() < 0.3:  # large enough for the matrix-core path (centred int8 residues)
+            m, k, n = (int(v) for v in rng.integers(100, 420, 3))
+            A, B = rnd(q, (m, k)), rnd(q, (k, n))
+            assert np.array_equal(u64((GF(A) @ GF(B)).numpy()), F.matmul(A, B)), ("matmul mfma", q, m, k, n)
+            n_la += 1
+            continue
+        if q in (65537, 2**31 - 1) and rng.random() < 0.05:  # 7-bit limb path (>= 2^27 multiply-adds)
+            m, k, n = 512 + int(rng.integers(0, 40)), 512 + int(rng.integers(0, 40)), 512 + int(rng.integers(0, 40))
+            A, B = rnd(q, (m, k)), rnd(q, (k, n))
+            assert np.array_equal(u64((GF(A) @ GF(B)).numpy()), F.matmul(A, B)), ("matmul limbs", q, m, k, n)
+            n_la += 1
+            continue
         m, n, k = (int(v) for v in rng.integers(1, 40, 3))
         A, B = rnd(q, (m, k)), rnd(q, (k, n))
         mk = (lambda a: GF([[int(v) for v in r] for r in a])) if q > 2**63 else (lambda a: GF(a))
