@@ -99,3 +99,104 @@ def test_reed_solomon_against_reference(order, n, k, c, shorten):
     dmine, nmine = R.decode(Rx, erasures=E)
     assert np.array_equal(nref, nmine) and _eq(dref, dmine)
     assert np.array_equal(rs.detect(GF(Rx)), R.detect(Rx))
+
+
+# ---- the "next" rows: BCH decoding, linear algebra, polynomial evaluation and logarithms, live against the reference ----
+@pytest.mark.parametrize("p,n,k,d,c,shorten", [(2, 15, 7, None, 1, 0), (2, 31, None, 7, 1, 5), (2, 63, 45, None, 1, 0), (3, 26, 14, None, 1, 0),
+                                                (3, 13, None, 5, 3, 2), (2, 15, None, 7, 3, 0)])
+def test_bch_against_reference(p, n, k, d, c, shorten):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        galois = load_reference.load()
+        GFp = load_reference.ref_field(p)
+        m = galois.ilog(n, p) + 1
+        ext = load_reference.ref_field(p**m, irreducible_poly=galois.matlab_primitive_poly(p, m))
+        bch = galois.BCH(n, k, d, field=GFp, extension_field=ext, c=c)
+    Fe = O.OracleField(p, m, int(ext.irreducible_poly), int(ext.primitive_element), lookup=True)
+    B = O.OracleBCH(Fe, n, k, d=d, alpha=int(bch.alpha), c=c)
+    assert (B.k, B.d) == (bch.k, bch.d)
+    assert B.generator_poly == [int(v) for v in bch.generator_poly.coeffs]
+    assert _eq(B.G, bch.G) and _eq(B.H, bch.H)
+    rng = np.random.default_rng(n * 7 + c)
+    ks, ns, t = bch.k - shorten, n - shorten, bch.t
+    for trial in range(8):
+        msg = rng.integers(0, p, ks)
+        cw = np.asarray(bch.encode(GFp(msg))).astype(np.int64)
+        assert _eq(B.encode(msg)[0], cw)
+        r = cw.copy()
+        ne = int(rng.integers(0, t + 2))
+        pos = rng.choice(ns, min(ne, ns), replace=False)
+        r[pos] = (r[pos] + rng.integers(1, p, pos.size)) % p
+        er = np.zeros(ns, dtype=bool)
+        if trial % 3 == 2:
+            er[rng.choice(ns, int(rng.integers(0, bch.d)), replace=False)] = True
+        odec, onerr = B.decode(r, er if er.any() else None)
+        try:
+            dec, nerr = bch.decode(GFp(r), erasures=er if er.any() else None, output="codeword", errors=True)
+        except (ValueError, OverflowError):
+            assert ((odec < 0) | (odec >= p)).any()  # the reference rejects symbols outside GF(p)
+            continue
+        assert int(nerr) == int(onerr[0]) and _eq(dec, odec[0])
+        assert bool(bch.detect(GFp(r))) == bool(B.detect(r)[0])
+
+
+@pytest.mark.parametrize("order", [2, 5, 31, 2**8, 3**3, 65537, 2147483647, 2**64 - 2**32 + 1])
+def test_linear_algebra_against_reference(order):
+    GF, F = _pair(order)
+    rng = np.random.default_rng(order % 1009)
+
+    def rnd(shape):
+        return np.array([int(rng.integers(0, 2**62)) % order for _ in range(int(np.prod(shape)))], dtype=object).reshape(shape)
+
+    for m, n in [(1, 1), (3, 3), (4, 6), (6, 4), (5, 5)]:
+        A = rnd((m, n))
+        if m == 5:
+            A[2] = A[0]  # rank-deficient
+            A[:, 1] = 0
+        gA = GF(A)
+        assert _eq(F.row_reduce(A)[0], gA.row_reduce())
+        P, Lm, U, _ = F.plu_decompose(A)
+        rp, rl, ru = gA.plu_decompose()
+        assert _eq(P, rp) and _eq(Lm, rl) and _eq(U, ru)
+        B = rnd((n, 3))
+        assert _eq(F.matmul(A, B), gA @ GF(B))
+        assert F.matrix_rank(A) == np.linalg.matrix_rank(gA)
+        for op in ("row_space", "column_space", "left_null_space", "null_space"):
+            want = getattr(gA, op)()
+            got = getattr(F, op)(A)
+            assert want.size == got.size and _eq(got, want), op
+        if m == n:
+            assert F.det(A) == int(np.linalg.det(gA))
+            try:
+                inv = np.linalg.inv(gA)
+            except np.linalg.LinAlgError:
+                with pytest.raises(np.linalg.LinAlgError):
+                    F.inv(A)
+            else:
+                assert _eq(F.inv(A), inv)
+                b = rnd((n,))
+                assert _eq(F.solve(A, b), np.linalg.solve(gA, GF(b)))
+            try:
+                rl2, ru2 = gA.lu_decompose()
+            except ValueError:
+                with pytest.raises(ValueError):
+                    F.lu_decompose(A)
+            else:
+                l2, u2 = F.lu_decompose(A)
+                assert _eq(l2, rl2) and _eq(u2, ru2)
+
+
+@pytest.mark.parametrize("order", [31, 2**8, 3**4, 65537])
+def test_poly_evaluate_and_log_against_reference(order):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        galois = load_reference.load()
+    GF, F = _pair(order, lookup=True)
+    rng = np.random.default_rng(order)
+    coeffs = rng.integers(0, order, 9)
+    coeffs[0] = 1
+    x = rng.integers(0, order, 40)
+    assert _eq(F.poly_eval(coeffs, x), galois.Poly(coeffs, field=GF)(GF(x)))
+    xs = rng.integers(1, order, 40)
+    _, LOG, _, _ = F.tables()
+    assert _eq(LOG[xs], np.log(GF(xs)))
