@@ -13,7 +13,7 @@ from ._array import FieldArray  # noqa: E402
 from ._factory import GF, Field  # noqa: E402
 from ._ntt import ntt, intt  # noqa: E402
 from ._codes import BCH, ReedSolomon  # noqa: E402
-from ._poly import Poly  # noqa: E402
+from ._poly import Poly, berlekamp_massey  # noqa: E402
 from ._numtheory import (  # noqa: E402
     is_prime, factors, primitive_root, is_primitive_root, matlab_primitive_poly, conway_poly, primitive_poly,
 )
@@ -23,7 +23,7 @@ from . import _linalg as linalg  # noqa: E402
 GF2 = GF(2)
 
 __all__ = [
-    "FieldArray", "GF", "GF2", "Field", "ntt", "intt", "ReedSolomon", "BCH", "Poly", "is_prime", "factors", "primitive_root",
+    "FieldArray", "GF", "GF2", "Field", "ntt", "intt", "ReedSolomon", "BCH", "Poly", "berlekamp_massey", "is_prime", "factors", "primitive_root",
     "is_primitive_root", "matlab_primitive_poly", "conway_poly", "primitive_poly", "dist", "linalg",
 ]
 __version__ = "0.1.0"

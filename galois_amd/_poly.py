@@ -142,3 +142,30 @@ class Poly:
             mult = np.arange(p.degree, 0, -1)
             p = Poly(c * mult)
         return p
+
+
+def berlekamp_massey(sequence, output: str = "minimal") -> Poly:
+    """galois.berlekamp_massey (_lfsr.py:1560-1625): the minimal (characteristic) polynomial c(x) of a linear recurrent
+    sequence, or its connection polynomial C(x) = reverse of c(x).  The LFSR-object outputs of the reference ("fibonacci",
+    "galois") are out of scope."""
+    if not isinstance(sequence, FieldArray):
+        raise TypeError(f"Argument 'sequence' must be a FieldArray, not {type(sequence)}.")
+    if not isinstance(output, str):
+        raise TypeError(f"Argument 'output' must be a string, not {type(output)}.")
+    if not sequence.ndim == 1:
+        raise ValueError(f"Argument 'sequence' must be 1-D, not {sequence.ndim}-D.")
+    if output not in ["minimal", "connection", "fibonacci", "galois"]:
+        raise ValueError(f"Argument 'output' must be in ['minimal', 'connection', 'fibonacci', 'galois'], not {output!r}.")
+    if output in ["fibonacci", "galois"]:
+        raise NotImplementedError("LFSR objects are outside this engine; use output='minimal' or 'connection'.")
+    F = type(sequence)
+    t = sequence._t.contiguous()
+    n = t.numel()
+    out = torch.empty_like(t)
+    ln = torch.empty(1, dtype=torch.int64, device=t.device)
+    L.check(L.lib().gfa_berlekamp_massey(F._handle, _ptr(t), n, 1, _ptr(out), _ptr(ln), sequence._gfa_dtype(), _stream()),
+            "gfa_berlekamp_massey")
+    asc = out[: int(ln.item())]
+    if output == "connection":
+        return Poly(F._wrap(torch.flip(asc, dims=(0,)).contiguous(), sequence._np_dtype))  # degree-descending C(x)
+    return Poly(F._wrap(asc.contiguous(), sequence._np_dtype))  # c(x) = x^L C(1/x): the ascending C read as descending

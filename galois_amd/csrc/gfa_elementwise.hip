@@ -828,6 +828,78 @@ int launch_digits(u64 p, int m, const void *in, int dtype_in, void *out, int dty
     return GFA_OK;
 }
 
+// berlekamp_massey_jit.implementation (_lfsr.py:1647-1702): shortest LFSR (connection polynomial C, ascending) of each of
+// `batch` sequences of length n.  One 64-lane workgroup per sequence, C / B / T in LDS; the discrepancy is a strided
+// partial sum folded in LDS.  out_c: (batch, n) ascending coefficients, zero padded; out_len: trimmed length (>= 1).
+template <class F, typename T>
+__global__ __launch_bounds__(64) void berlekamp_massey_kernel(FieldDev fd, const T *__restrict__ seq, i64 n, T *__restrict__ out_c,
+                                                              i64 *__restrict__ out_len)
+{
+    typedef typename F::elem E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char bm_raw[];
+    E *C = reinterpret_cast<E *>(bm_raw), *B = C + n, *Tm = B + n;
+    __shared__ u64 part[64];
+    const T *S = seq + (i64)blockIdx.x * n;
+    const int tid = threadIdx.x;
+    for (i64 i = tid; i < n; i += 64) { C[i] = i == 0 ? F::one(fd) : (E)0; B[i] = C[i]; }
+    __syncthreads();
+    i64 L = 0, m = 1;
+    E b = F::one(fd);
+    for (i64 k = 0; k < n; k++) {
+        E acc = 0;
+        for (i64 i = tid; i <= L; i += 64) acc = F::add(fd, acc, F::mul(fd, (E)S[k - i], C[i]));
+        part[tid] = (u64)acc;
+        __syncthreads();
+        for (int off = 32; off >= 1; off >>= 1) {
+            if (tid < off) part[tid] = (u64)F::add(fd, (E)part[tid], (E)part[tid + off]);
+            __syncthreads();
+        }
+        const E d = (E)part[0];
+        __syncthreads();
+        if (d == 0) { m++; continue; }
+        E coef;
+        if constexpr (std::is_same<F, Lut>::value) coef = Lut::div_nz(fd, d, b);
+        else coef = F::mul(fd, d, F::inv(fd, b));
+        const bool grow = !(2 * L > k);
+        if (grow) for (i64 i = tid; i < n; i += 64) Tm[i] = C[i];
+        __syncthreads();
+        for (i64 i = m + tid; i < n; i += 64) C[i] = F::sub(fd, C[i], F::mul(fd, coef, B[i - m]));
+        __syncthreads();
+        if (grow) {
+            for (i64 i = tid; i < n; i += 64) B[i] = Tm[i];
+            L = k + 1 - L; b = d; m = 1;
+        } else {
+            m++;
+        }
+        __syncthreads();
+    }
+    // C[: L + 1], trailing zeros trimmed (at least one coefficient)
+    const i64 clen = L + 1 < n ? L + 1 : n;
+    if (tid == 0) {
+        i64 last = 0;
+        for (i64 i = 0; i < clen; i++) if (C[i] != 0) last = i;
+        out_len[blockIdx.x] = last + 1;
+    }
+    for (i64 i = tid; i < n; i += 64) out_c[(i64)blockIdx.x * n + i] = i < clen ? (T)C[i] : (T)0;
+}
+
+template <class F, typename T>
+int launch_bm_ft(const FieldDev &fd, const void *seq, i64 n, i64 batch, void *out_c, i64 *out_len, hipStream_t st)
+{
+    typedef typename F::elem E;
+    const size_t lds = 3 * (size_t)n * sizeof(E);
+    auto k = berlekamp_massey_kernel<F, T>;
+    static bool attr = false;
+    if (!attr) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
+    hipLaunchKernelGGL(k, dim3((unsigned)batch), dim3(64), lds, st, fd, (const T *)seq, n, (T *)out_c, out_len);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+int dispatch_bm(const FieldDev &fd, int dtype, const void *seq, i64 n, i64 batch, void *out_c, i64 *out_len, hipStream_t st)
+{
+    GFA_DISPATCH_FT(launch_bm_ft, fd, dtype, fd, seq, n, batch, out_c, out_len, st);
+}
+
 // ufunc.accumulate over the last axis: one workgroup per row, 256-element chunks scanned in LDS with a running carry.
 // mode 0: inclusive scan with the op; 1: out[i] = a0 - (a1 + ... + ai); 2: out[i] = a0 / (a1 * ... * ai)
 template <class F, typename T, bool IS_MUL>
@@ -1115,6 +1187,21 @@ int gfa_convolve(gfa_field_t *f, const void *a, int64_t na, const void *b, int64
     if (rc) return rc;
     if (f->use_lookup()) return dispatch_convolve(f->lut_desc(*ds), dtype, a, na, b, nb, out, (hipStream_t)stream);
     return dispatch_convolve(f->calc, dtype, a, na, b, nb, out, (hipStream_t)stream);
+}
+
+int gfa_berlekamp_massey(gfa_field_t *f, const void *seq, int64_t n, int64_t batch, void *out_coeffs, int64_t *out_len, int dtype,
+                          gfa_stream_t stream)
+{
+    if (!f || n < 1 || batch < 0) { set_error("gfa_berlekamp_massey: bad arguments"); return GFA_ERR_INVALID; }
+    if (!dtype_holds(dtype, f->calc.q)) { set_error("dtype cannot hold the field's elements"); return GFA_ERR_INVALID; }
+    if (batch == 0) return GFA_OK;
+    if (!seq || !out_coeffs || !out_len) { set_error("gfa_berlekamp_massey: bad arguments"); return GFA_ERR_INVALID; }
+    if (n > 6000 || batch > 0x7fffffff) { set_error("gfa_berlekamp_massey: sequences are limited to 6000 terms"); return GFA_ERR_UNSUPPORTED; }
+    FieldDeviceState *ds;
+    int rc = f->ensure_device(nullptr, &ds);
+    if (rc) return rc;
+    if (f->use_lookup()) return dispatch_bm(f->lut_desc(*ds), dtype, seq, n, batch, out_coeffs, (i64 *)out_len, (hipStream_t)stream);
+    return dispatch_bm(f->calc, dtype, seq, n, batch, out_coeffs, (i64 *)out_len, (hipStream_t)stream);
 }
 
 int gfa_vector(gfa_field_t *f, int to_digits, const void *in, int dtype_in, void *out, int dtype_out, int64_t n, gfa_stream_t stream)

@@ -120,6 +120,11 @@ int gfa_accumulate(gfa_field_t *f, int op, const void *a, void *out, int64_t n_o
 int gfa_convolve(gfa_field_t *f, const void *a, int64_t na, const void *b, int64_t nb, void *out, int dtype,
                  gfa_stream_t stream);
 
+/* berlekamp_massey_jit `int64[:](int64[:])` (_lfsr.py:1627-1702): connection polynomial of the shortest LFSR generating each of
+ * `batch` contiguous sequences of n terms.  out_coeffs: (batch, n) coefficients C_0 = 1, C_1, ... in ASCENDING degree, zero
+ * padded; out_len[b]: number of coefficients after trimming (the reference returns them degree-descending). */
+int gfa_berlekamp_massey(gfa_field_t *f, const void *seq, int64_t n, int64_t batch, void *out_coeffs, int64_t *out_len, int dtype,
+                          gfa_stream_t stream);
 /* FieldArray.vector (to_digits != 0: n field elements -> n*m digits of GF(p), degree m-1 first) and FieldArray.Vector
  * (to_digits == 0: n*m digits -> n elements) of _fields/_array.py:383-491; element and digit arrays may use different
  * storage widths. */

@@ -191,3 +191,47 @@ def test_sage_orders_trace_norm(tag):
     H.assert_equal_ints(nm.numpy(), d["field_norm_Z"])
     with pytest.raises(ArithmeticError):
         GF([1, 0]).multiplicative_order()
+
+
+def test_berlekamp_massey():
+    """tests/test_berlekamp_massey.py: the Sage known answers (GF(2), GF(3), GF(2^3), GF(3^3) primitive LFSRs and a random
+    GF(2) sequence), exceptions, and random / LFSR-generated sequences over larger fields against the oracle."""
+    y = [0, 0, 1, 0, 0, 1, 1, 0, 1, 0, 1, 1, 1, 1, 0, 0, 0, 1, 0, 0, 1, 1, 0, 1, 0, 1, 1, 1, 1, 0, 0, 0, 1, 0, 0, 1, 1, 0, 1, 0, 1, 1, 1, 1, 0, 0, 0, 1, 0, 0]
+    assert _coeffs(ga.berlekamp_massey(ga.GF(2)(y))) == [1, 0, 0, 1, 1]  # x^4 + x + 1
+    y = [1, 1, 1, 1, 0, 0, 0, 1, 0, 0, 2, 1, 0, 1, 1, 1, 2, 0, 0, 2, 2, 0, 1, 0, 2, 2, 1, 1, 0, 1, 0, 1, 2, 1, 2, 2, 1, 2, 0, 1, 2, 2, 2, 2, 0, 0, 0, 2, 0, 0]
+    assert _coeffs(ga.berlekamp_massey(ga.GF(3)(y))) == [1, 0, 0, 1, 2]  # x^4 + x + 2
+    y = [1, 1, 1, 1, 2, 2, 2, 1, 4, 4, 7, 7, 3, 0, 5, 1, 5, 5, 5, 6, 1, 1, 2, 0, 2, 1, 6, 2, 7, 5, 3, 1, 7, 7, 4, 4, 5, 6, 3, 2, 2, 2, 7, 4, 4, 1, 6, 3, 6, 5]
+    assert _coeffs(ga.berlekamp_massey(ga.GF(2**3)(y))) == [1, 0, 0, 1, 3]  # x^4 + x + 3
+    y = [1, 1, 1, 1, 19, 19, 19, 1, 25, 25, 16, 4, 24, 6, 6, 6, 26, 2, 2, 9, 4, 11, 1, 11, 13, 21, 9, 9, 12, 10, 3, 0, 6, 2, 4, 3, 6, 15, 18, 7, 20, 20, 20, 8, 17, 17, 2, 1, 13, 19]
+    assert _coeffs(ga.berlekamp_massey(ga.GF(3**3)(y))) == [1, 0, 0, 1, 10]  # x^4 + x + 10
+    y = [0, 1, 0, 0, 1, 1, 0, 0, 0, 0, 1, 1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 1, 1, 1, 0, 1, 0, 1, 1, 1, 1, 0, 0, 1, 0, 0, 1, 1, 1, 0, 0, 1, 1, 0, 0, 0, 0, 1, 0, 1]
+    want = [0] * 25
+    for dgr in (24, 21, 19, 18, 17, 15, 14, 13, 12, 11, 9, 8, 7, 6, 5, 4, 2, 1, 0):
+        want[24 - dgr] = 1
+    assert _coeffs(ga.berlekamp_massey(ga.GF(2)(y))) == want
+    with pytest.raises(TypeError):
+        ga.berlekamp_massey(np.array(y))
+    with pytest.raises(ValueError):
+        ga.berlekamp_massey(ga.GF(2)([y, y]))
+    with pytest.raises(ValueError):
+        ga.berlekamp_massey(ga.GF(2)(y), output="invalid-argument")
+    rng = np.random.default_rng(5)
+    for q in (2**8, 65537, 3**5, 2**64 - 2**32 + 1, 2**32):
+        GF = ga.GF(q)
+        F = O.OracleField(GF.characteristic, GF.degree, int(GF.irreducible_poly) if GF.degree > 1 else None, int(GF.primitive_element))
+        for n in (1, 7, 64, 300):
+            s = np.array([int(rng.integers(0, 2**62)) % q for _ in range(n)], dtype=np.uint64)
+            if n == 64:  # a genuine LFSR sequence of order 9
+                taps = [int(rng.integers(1, 2**62)) % q for _ in range(9)]
+                seq = [int(v) for v in s[:9]]
+                for _ in range(n - 9):
+                    acc = 0
+                    for tp, v in zip(taps, seq[-9:]):
+                        acc = int(F.add([acc], [int(F.mul([tp], [v])[0])])[0])
+                    seq.append(acc)
+                s = np.array(seq, dtype=np.uint64)
+            gs = GF([int(v) for v in s]) if q > 2**63 else GF(s)
+            got = _coeffs(ga.berlekamp_massey(gs, output="connection"))
+            assert got == [int(v) for v in F.berlekamp_massey(s)], (q, n)
+            minimal = _coeffs(ga.berlekamp_massey(gs))
+            assert minimal[0] == 1 and minimal == (got[::-1] if got[-1] == 1 else minimal)
