@@ -93,6 +93,15 @@ struct TwShoup32 {
         const u32 r = t.w * x - q * c.p;
         return min(r, r - c.p);
     }
+    static constexpr bool REDC = true;
+    static __device__ __forceinline__ u32 canon(Ctx c, u32 a) { return min(a, a - c.p); } // [0, 2p) -> [0, p)
+    // Montgomery product x * y * 2^-32 mod p for x*y < p * 2^32 (x < 2p, y < p, p < 2^31); result in (0, 2p)
+    static __device__ __forceinline__ u32 redc(Ctx c, u32 x, u32 y, u32 pinv)
+    {
+        const u32 hi = __umulhi(x, y), lo = x * y;
+        const u32 m = lo * pinv;
+        return hi - __umulhi(m, c.p) + c.p;
+    }
 };
 
 // GF(p), p < 2^30, register kernel only: Harvey-style lazy butterflies.  Values live in [0, 2p); a Shoup product
@@ -104,6 +113,7 @@ struct TwShoupLazy {
     static constexpr bool HAS_SHOUP = true;
     static constexpr int QBITS = 32;
     static constexpr bool LAZY = true;
+    static constexpr bool REDC = true;
     struct W { u32 w, wq; };
     struct Ctx { u32 p, p2; };
     static __device__ __forceinline__ W load(const u32 *tab, const u32 *tabq, u32 i) { return W{tab[i], tabq[i]}; }
@@ -379,6 +389,13 @@ struct LazyTrait<TW, std::enable_if_t<TW::LAZY>> { static constexpr bool value =
 template <class TW>
 constexpr bool is_lazy() { return LazyTrait<TW>::value; }
 
+template <class TW, class = void>
+struct RedcTrait { static constexpr bool value = false; };
+template <class TW>
+struct RedcTrait<TW, std::enable_if_t<TW::REDC>> { static constexpr bool value = true; };
+template <class TW>
+constexpr bool has_redc() { return RedcTrait<TW>::value; } // 32-bit Montgomery products for the post-twiddle progression
+
 constexpr int brev_c(int x, int bits)
 {
     int r = 0;
@@ -488,33 +505,30 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fdk, const ty
         if (ra.post_twiddle) {
             const u32 line = (u32)(ra.line_offset + line0 + c);
             const u32 nmask = (u32)ra.n_mask, lo_mask = (1u << ra.lo_bits) - 1;
-            if constexpr (is_lazy<TW>()) {
-                // * w_N^(line * (ka + R1*kr)) for kr = 0..R2-1 is a geometric progression per thread: t_0 = w^(line*ka),
-                // ratio w^(line*R1).  Both are fetched ONCE per thread from the two-level power table (A kept in
-                // Montgomery form, A*2^32 mod p) and every later factor comes from a Montgomery product in registers.
-                // (The first version gathered two table entries per element from global memory; those fully
-                // divergent 4-byte gathers cost more than the whole transform -- pass 1 ran 2x slower than pass 2.)
-                const u32 e0 = (line * (u32)ka) & nmask, es = (line * (u32)R1) & nmask;
+            // * w_N^(line * (ka + R1*kr)) for kr = 0..R2-1 is a geometric progression per thread: t_0 = w^(line*ka),
+            // ratio w^(line*R1).  Both are fetched ONCE per thread from the two-level power table and every later factor
+            // comes from a product in registers.  (The first version gathered two table entries per element from global
+            // memory; those fully divergent gathers cost more than the whole transform -- pass 1 ran 2x slower than pass 2.)
+            const u32 e0 = (line * (u32)ka) & nmask, es = (line * (u32)R1) & nmask;
+            if constexpr (has_redc<TW>()) {
+                // 32-bit classes: A kept in Montgomery form (A * 2^32 mod p), Montgomery products from then on
                 u32 tm = TW::mul(fd, powAm[e0 >> ra.lo_bits], TW::load(powB, powBq, e0 & lo_mask));               // t_0 * R, [0,2p)
                 const u32 sm = TW::canon(fd, TW::mul(fd, powAm[es >> ra.lo_bits], TW::load(powB, powBq, es & lo_mask))); // ratio * R, [0,p)
                 const u32 pinv = (u32)ra.pinv;
 #pragma unroll
                 for (int kr = 0; kr < R2; kr++) {
-                    v[brev_c(kr, LOGR2)] = TW::redc(fd, v[brev_c(kr, LOGR2)], tm, pinv); // x * t_kr, lazy
-                    if (kr + 1 < R2) tm = TW::redc(fd, tm, sm, pinv);                    // t_{kr+1} * R
+                    u32 x = TW::redc(fd, v[brev_c(kr, LOGR2)], tm, pinv); // x * t_kr, in (0, 2p)
+                    if constexpr (!is_lazy<TW>()) x = TW::canon(fd, x);
+                    v[brev_c(kr, LOGR2)] = x;
+                    if (kr + 1 < R2) tm = TW::redc(fd, tm, sm, pinv);      // t_{kr+1} * R
                 }
             } else {
-                // two-level table A[e >> lo] * B[e & mask], exponent by repeated addition
-                u32 e = line * (u32)ka;
-                const u32 de = line * (u32)R1;
+                E t = F::mul(fdk, powA[e0 >> ra.lo_bits], powB[e0 & lo_mask]);
+                const E sr = F::mul(fdk, powA[es >> ra.lo_bits], powB[es & lo_mask]);
 #pragma unroll
                 for (int kr = 0; kr < R2; kr++) {
-                    const u32 em = e & nmask;
-                    E x = v[brev_c(kr, LOGR2)];
-                    x = TW::mul(fd, x, TW::load(powA, powAq, em >> ra.lo_bits));
-                    x = TW::mul(fd, x, TW::load(powB, powBq, em & lo_mask));
-                    v[brev_c(kr, LOGR2)] = x;
-                    e += de;
+                    v[brev_c(kr, LOGR2)] = F::mul(fdk, v[brev_c(kr, LOGR2)], t);
+                    if (kr + 1 < R2) t = F::mul(fdk, t, sr);
                 }
             }
         }
@@ -624,6 +638,11 @@ struct Plan {
     // register-blocked path: full w_L^e tables (L entries) per pass, with Shoup quotients
     void *wl1 = nullptr, *wl1q = nullptr, *wl2 = nullptr, *wl2q = nullptr;
     bool reg_ready = false;
+    // three-pass register path (2^21 .. 2^29 points): outer lines of 2^log0, then the two-pass transform of 2^(log1+log2)
+    int log0 = 0, lo_bits2 = 0;
+    void *wl0 = nullptr, *wl0q = nullptr;
+    void *powA2 = nullptr, *powB2 = nullptr, *powA2q = nullptr, *powB2q = nullptr, *powA2m = nullptr; // w_M^e, M = n >> log0
+    bool reg3_ready = false;
     // generic path
     void *wpow = nullptr; // n entries
     std::vector<i64> factors;
@@ -832,6 +851,12 @@ int env_int(const char *name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
+inline int env_int_now(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 template <class F, class TW, int LOGR1, int LOGR2, int THREADS, bool SPLIT = false>
 int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64 batch, const void *wl, const void *wlq,
                   const void *pa, const void *paq, const void *pb, const void *pbq, const void *pam, hipStream_t st)
@@ -918,28 +943,38 @@ int build_line_tables(const FieldDev &fd, u64 omega, i64 n_total, int logL, void
     return GFA_OK;
 }
 
+// Two-level table of w^e, e < domain, w = omega^mult: w^e = A[e >> lo_bits] * B[e & mask]
 template <class F, class TW>
-int build_post_tables(const FieldDev &fd, u64 omega, i64 n_total, Plan *pl, hipStream_t st)
+int build_post_tables_at(const FieldDev &fd, u64 omega, i64 domain, u64 mult, void **A, void **B, void **Aq, void **Bq, void **Am,
+                         int *lo_bits_out, hipStream_t st)
 {
     int logn = 0;
-    while (((i64)1 << logn) < n_total) logn++;
-    pl->lo_bits = (logn + 1) / 2;
-    const i64 nb = (i64)1 << pl->lo_bits, na = n_total >> pl->lo_bits;
+    while (((i64)1 << logn) < domain) logn++;
+    const int lo_bits = (logn + 1) / 2;
+    *lo_bits_out = lo_bits;
+    const i64 nb = (i64)1 << lo_bits, na = domain >> lo_bits;
     int rc;
-    if ((rc = build_pow_table<F>(fd, omega, (u64)nb, na, &pl->powA, st))) return rc;
-    if ((rc = build_pow_table<F>(fd, omega, 1, nb, &pl->powB, st))) return rc;
+    if ((rc = build_pow_table<F>(fd, omega, mult * (u64)nb, na, A, st))) return rc;
+    if ((rc = build_pow_table<F>(fd, omega, mult, nb, B, st))) return rc;
     if (TW::HAS_SHOUP) {
-        if ((rc = build_shoup(fd, pl->powA, na, &pl->powAq, st, qbits_of<TW>()))) return rc;
-        if ((rc = build_shoup(fd, pl->powB, nb, &pl->powBq, st, qbits_of<TW>()))) return rc;
+        if ((rc = build_shoup(fd, *A, na, Aq, st, qbits_of<TW>()))) return rc;
+        if ((rc = build_shoup(fd, *B, nb, Bq, st, qbits_of<TW>()))) return rc;
     }
-    if constexpr (is_lazy<TW>()) {
+    if constexpr (has_redc<TW>()) {
         // (w << 32) mod p == floor-free Montgomery form; reuse the quotient kernel's arithmetic: w*2^32 - floor(w*2^32/p)*p
-        GFA_HIP(hipMalloc(&pl->powAm, sizeof(u32) * (size_t)na));
+        GFA_HIP(hipMalloc(Am, sizeof(u32) * (size_t)na));
         hipLaunchKernelGGL(mont_table_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, st, (u32)fd.p,
-                           (const u32 *)pl->powA, (u32 *)pl->powAm, na);
+                           (const u32 *)*A, (u32 *)*Am, na);
         GFA_HIP(hipGetLastError());
     }
     return GFA_OK;
+}
+
+template <class F, class TW>
+int build_post_tables(const FieldDev &fd, u64 omega, i64 n_total, Plan *pl, hipStream_t st)
+{
+    return build_post_tables_at<F, TW>(fd, omega, n_total, 1, &pl->powA, &pl->powB, &pl->powAq, &pl->powBq, &pl->powAm,
+                                       &pl->lo_bits, st);
 }
 
 // power-of-two n, 4 <= n <= 2^20, on the register-blocked kernel: one pass up to 2^10, else four-step in two passes
@@ -1003,6 +1038,88 @@ int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n,
             ra.do_scale = do_scale; ra.scale = scale; ra.scale_q = shoup_quotient<TW>(fd, scale);
             if ((rc = launch_reg<F, TW>(fd, pl->log2, pl->ws0.p, dst, ra, nb, pl->wl2, pl->wl2q, nullptr, nullptr, nullptr,
                                         nullptr, nullptr, st)))
+                return rc;
+        }
+    }
+    return GFA_OK;
+}
+
+// power-of-two n, 2^21 <= n <= 2^29, in THREE passes of the register-blocked kernel (each pass reads and writes every
+// point once): n = L0 * M, M = L1 * L2.
+//   A : the M columns of length L0 (stride M), * w_n^(jr*k1)                   -> ws[k1*M + jr]
+//   B1: per row k1, the L2 columns of length L1 (stride L2), * w_M^(j3*k2)     -> ws[k1*M + k2*L2 + j3]   (in place)
+//   B2: per (k2, k1) the contiguous row of length L2                           -> X[k1 + L0*(k2 + L1*k3)]
+// B2 takes k2 as the "batch" index and k1 as the line index, so that the C lines of a tile are adjacent in the output.
+// Returns GFA_ERR_UNSUPPORTED (before touching anything) when a tile would leave the kernel's 32-bit offset range.
+template <class F, class TW>
+int run_pow2_reg3(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n, i64 batch, u64 omega, int do_scale,
+                  u64 scale, hipStream_t st)
+{
+    typedef typename F::elem E;
+    int rc;
+    int logn = 0;
+    while (((i64)1 << logn) < n) logn++;
+    // measured on 2^22 .. 2^26 points (tools/ntt3_tune.py): longest lines in the widest-strided pass, shortest in the last
+    int log0 = (logn + 2) / 3, log1 = (logn - log0 + 1) / 2;
+    if (!pl->reg3_ready) { // GFA_NTT3_LOG0 / GFA_NTT3_LOG1: tuning overrides, read when the plan is built
+        const int e0 = env_int_now("GFA_NTT3_LOG0", 0), e1 = env_int_now("GFA_NTT3_LOG1", 0);
+        if (e0 >= 2 && e0 <= REG_MAX_LOG) { log0 = e0; log1 = (logn - log0 + 1) / 2; }
+        if (e1 >= 2 && e1 <= REG_MAX_LOG && logn - log0 - e1 >= 2) log1 = e1;
+    } else {
+        log0 = pl->log0; log1 = pl->log1;
+    }
+    const int log2 = logn - log0 - log1;
+    const i64 L0 = (i64)1 << log0, L1 = (i64)1 << log1, L2 = (i64)1 << log2, M = L1 * L2;
+    {
+        const i64 lim = ((i64)1 << 31) / (i64)sizeof(E), cmax = 32;
+        if (log2 > REG_MAX_LOG || log2 < 2 || log1 > REG_MAX_LOG || log0 < 2 || cmax + (L0 - 1) * M >= lim || cmax + (L2 - 1) * L0 * L1 >= lim ||
+            cmax * M + L2 >= lim)
+            return GFA_ERR_UNSUPPORTED;
+    }
+    if (!pl->reg3_ready) {
+        pl->logn = logn; pl->log0 = log0; pl->log1 = log1; pl->log2 = log2;
+        if ((rc = build_line_tables<F, TW>(fd, omega, n, log0, &pl->wl0, &pl->wl0q, st))) return rc;
+        if ((rc = build_line_tables<F, TW>(fd, omega, n, log1, &pl->wl1, &pl->wl1q, st))) return rc;
+        if ((rc = build_line_tables<F, TW>(fd, omega, n, log2, &pl->wl2, &pl->wl2q, st))) return rc;
+        if ((rc = build_post_tables<F, TW>(fd, omega, n, pl, st))) return rc;
+        if ((rc = build_post_tables_at<F, TW>(fd, omega, M, (u64)L0, &pl->powA2, &pl->powB2, &pl->powA2q, &pl->powB2q,
+                                              &pl->powA2m, &pl->lo_bits2, st)))
+            return rc;
+        pl->reg3_ready = true;
+    }
+    if ((rc = pl->ws0.ensure(sizeof(E) * (size_t)n))) return rc;
+    E *ws = (E *)pl->ws0.p;
+    for (i64 b = 0; b < batch; b++) {
+        const E *src = (const E *)in + b * n;
+        E *dst = (E *)out + b * n;
+        {
+            RegArgs ra{};
+            ra.in_stride_c = 1; ra.in_stride_t = M; ra.out_stride_c = 1; ra.out_stride_t = M;
+            ra.total_lines = M;
+            ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits; ra.n_mask = (u64)n - 1; ra.pinv = inverse_mod_2_32(fd.p);
+            if ((rc = launch_reg<F, TW>(fd, log0, src, ws, ra, 1, pl->wl0, pl->wl0q, pl->powA, pl->powAq, pl->powB, pl->powBq,
+                                        pl->powAm, st)))
+                return rc;
+        }
+        {
+            RegArgs ra{};
+            ra.in_stride_c = 1; ra.in_stride_t = L2; ra.out_stride_c = 1; ra.out_stride_t = L2;
+            ra.in_batch_stride = M; ra.out_batch_stride = M;
+            ra.total_lines = L2;
+            ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits2; ra.n_mask = (u64)M - 1; ra.pinv = inverse_mod_2_32(fd.p);
+            if ((rc = launch_reg<F, TW>(fd, log1, ws, ws, ra, L0, pl->wl1, pl->wl1q, pl->powA2, pl->powA2q, pl->powB2,
+                                        pl->powB2q, pl->powA2m, st)))
+                return rc;
+        }
+        {
+            RegArgs ra{};
+            ra.in_batch_stride = L2; ra.out_batch_stride = L0;
+            ra.in_stride_c = M; ra.in_stride_t = 1; ra.out_stride_c = 1; ra.out_stride_t = L0 * L1;
+            ra.total_lines = L0;
+            ra.load_along_line = 1; ra.store_along_line = 0;
+            ra.do_scale = do_scale; ra.scale = scale; ra.scale_q = shoup_quotient<TW>(fd, scale);
+            if ((rc = launch_reg<F, TW>(fd, log2, ws, dst, ra, L1, pl->wl2, pl->wl2q, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                        st)))
                 return rc;
         }
     }
@@ -1080,7 +1197,19 @@ int run_typed(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *
             }
             if (rc) return rc;
             done = true;
-        } else if (lg <= 24) {
+        } else if (lg <= 29) {
+            if constexpr (std::is_same<F, Prime32>::value) {
+                // (no prime below 2^24 has 2^21 | p - 1, so the unreduced 24-bit butterflies never apply here)
+                if (fd.p < (1ull << 30)) rc = run_pow2_reg3<F, TwShoupLazy>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+                else if (fd.p < (1ull << 31)) rc = run_pow2_reg3<F, TwShoup32>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+                else rc = run_pow2_reg3<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+            } else {
+                rc = run_pow2_reg3<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+            }
+            if (rc && rc != GFA_ERR_UNSUPPORTED) return rc;
+            done = rc == GFA_OK;
+        }
+        if (!done && lg > 2 * REG_MAX_LOG && lg <= 24) {
             if constexpr (std::is_same<F, Prime32>::value) {
                 if (fd.p < (1ull << 31)) rc = run_pow2<F, TwShoup32>(f, fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
                 else rc = run_pow2<F, Tw<F>>(f, fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
@@ -1110,7 +1239,8 @@ void ntt_forget_field(const gfa_field *f)
         if (it->first.f == f) {
             Plan *pl = it->second;
             for (void *p : {pl->w1, pl->w1q, pl->w2, pl->w2q, pl->powA, pl->powB, pl->powAq, pl->powBq, pl->powAm, pl->wl1, pl->wl1q, pl->wl2,
-                            pl->wl2q, pl->wpow, pl->ws0.p, pl->ws1.p, pl->cvt.p})
+                            pl->wl2q, pl->wpow, pl->ws0.p, pl->ws1.p, pl->cvt.p, pl->wl0, pl->wl0q, pl->powA2, pl->powB2, pl->powA2q,
+                            pl->powB2q, pl->powA2m})
                 if (p) (void)hipFree(p);
             delete pl;
             it = g_plans.erase(it);

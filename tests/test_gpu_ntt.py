@@ -208,3 +208,46 @@ def test_unreduced_butterflies_at_the_magnitude_limit(logn):
     from galois_amd._ntt import fft_batched
     back = fft_batched(X, inverse=True).numpy()
     assert np.array_equal(back, np.stack(rows))
+
+
+@pytest.mark.parametrize("order,logn", [(469762049, 21), (469762049, 22), (469762049, 23), (2013265921, 21), (2013265921, 24),
+                                        (3221225473, 22), (2**64 - 2**32 + 1, 21), (2**64 - 2**32 + 1, 23)])
+def test_three_pass_sizes_against_oracle(order, logn):
+    """2^21 .. 2^29 points run as three passes of the register kernel (n = L0 * L1 * L2); every output compared."""
+    n = 1 << logn
+    GF = ga.GF(order)
+    F = O.OracleField(order, 1, None, GF._primitive_element_int)
+    rng = np.random.default_rng(logn)
+    x = rng.integers(0, 2**63, n, dtype=np.uint64) % np.uint64(order)
+    gx = GF(x.astype(np.int64)) if order < 2**63 else GF._wrap(__import__("torch").from_numpy(x.view(np.int64)).cuda(), np.object_)
+    omega = GF._root_of_unity_int(n)
+    want = F.ntt_u32_pow2(x.astype(np.uint32), omega).astype(np.uint64) if order < 2**31 else F.ntt(x, omega=omega)
+    X = np.fft.fft(gx)
+    got = X._t.cpu().numpy().view(np.uint64) if order > 2**63 else X.numpy().astype(np.uint64)
+    assert np.array_equal(got, want)
+    back = np.fft.ifft(X)
+    gb = back._t.cpu().numpy().view(np.uint64) if order > 2**63 else back.numpy().astype(np.uint64)
+    assert np.array_equal(gb, x)
+
+
+def test_three_pass_batched_and_2_26():
+    GF = ga.GF(469762049)
+    F = O.OracleField(469762049, 1, None, GF._primitive_element_int)
+    n = 1 << 21
+    x = np.random.default_rng(5).integers(0, 469762049, (3, n), dtype=np.uint32)
+    X = fft_batched(GF(x))
+    for i in range(3):
+        assert np.array_equal(X.numpy()[i].astype(np.uint32), F.ntt_u32_pow2(x[i], GF._root_of_unity_int(n)))
+    # 2^26 points: inverse round trip, X[0] = sum, and a few outputs recomputed as sum_j x_j w^(jk) with the (separately
+    # pinned) power, multiply and reduce kernels
+    n = 1 << 26
+    a = GF(np.random.default_rng(1).integers(0, 469762049, n, dtype=np.uint32))
+    A = np.fft.fft(a)
+    assert np.array_equal(np.fft.ifft(A).numpy(), a.numpy())
+    assert int(A[0]) == int(np.add.reduce(a))
+    omega = GF._root_of_unity_int(n)
+    j = np.arange(n, dtype=np.int64)
+    for k in (1, 2, 12345, (1 << 25) + 17, n - 1):
+        wk = GF(omega) ** int(k)
+        col = GF(np.full(n, int(wk), dtype=np.int64)) ** j
+        assert int(A[k]) == int(np.add.reduce(a * col)), k
