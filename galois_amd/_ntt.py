@@ -70,7 +70,9 @@ def _field_convolve(a: FieldArray, b: FieldArray, mode: str = "full") -> FieldAr
 
     Short products run in one direct kernel (gfa_convolve).  Long products over a prime field whose multiplicative
     group has enough 2-adicity run as three NTTs and a pointwise product -- the direct consumer of the fast transform
-    (SURVEY.md section 8(f) item 1); the result is the same exact polynomial product either way."""
+    (SURVEY.md section 8(f) item 1).  Long products over any other prime field below 2^32 are taken inside gfa_convolve
+    through three auxiliary NTT primes and the Chinese remainder theorem (gfa_conv_crt.hip); the result is the same exact
+    polynomial product every way."""
     if not isinstance(a, FieldArray) or not isinstance(b, FieldArray) or type(a) is not type(b):
         raise TypeError(f"Arguments of 'convolve' must be arrays over the same field, not {type(a)} and {type(b)}.")
     if not mode == "full":
@@ -81,7 +83,7 @@ def _field_convolve(a: FieldArray, b: FieldArray, mode: str = "full") -> FieldAr
     na, nb = a.size, b.size
     n_out = na + nb - 1
     n_fft = 1 << (n_out - 1).bit_length()
-    if cls.is_prime_field and min(na, nb) >= 64 and n_out >= 2048 and (cls.order - 1) % n_fft == 0 and n_fft <= 2**24:
+    if cls.is_prime_field and min(na, nb) >= 64 and n_out >= 2048 and (cls.order - 1) % n_fft == 0 and n_fft <= 2**28:
         both = cls.Zeros((2, n_fft), dtype=a.dtype if a.dtype != np.dtype(object) else None)
         both._t[0, :na] = a._t
         both._t[1, :nb] = a._same_storage(b)

@@ -1185,6 +1185,7 @@ int gfa_convolve(gfa_field_t *f, const void *a, int64_t na, const void *b, int64
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
+    if (convolve_crt_eligible(f->calc, na, nb)) return convolve_crt(f, dtype, a, na, b, nb, out, (hipStream_t)stream);
     if (f->use_lookup()) return dispatch_convolve(f->lut_desc(*ds), dtype, a, na, b, nb, out, (hipStream_t)stream);
     return dispatch_convolve(f->calc, dtype, a, na, b, nb, out, (hipStream_t)stream);
 }

@@ -37,6 +37,10 @@ bool matmul_mfma_eligible(const FieldDev &fd, i64 M, i64 K, i64 N);
 int matmul_mfma(const FieldDev &fd, int dtype, const void *a, const void *b, void *out, i64 batch, i64 M, i64 K, i64 N,
                 i64 a_bstride, i64 b_bstride, hipStream_t st);
 
+// long prime-field products through three NTT primes + CRT (gfa_conv_crt.hip)
+bool convolve_crt_eligible(const FieldDev &fd, i64 na, i64 nb);
+int convolve_crt(struct ::gfa_field *f, int dtype, const void *a, i64 na, const void *b, i64 nb, void *out, hipStream_t st);
+
 // Host scalar arithmetic on a field, dispatched on FieldDev::kind with the same formulas the kernels use.
 struct HostArith {
     static u64 add(const FieldDev &f, u64 a, u64 b);

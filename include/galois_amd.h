@@ -115,8 +115,11 @@ int gfa_reduceat(gfa_field_t *f, int op, const void *a, const int64_t *starts, c
 int gfa_accumulate(gfa_field_t *f, int op, const void *a, void *out, int64_t n_outer, int64_t n_inner, int dtype,
                    gfa_stream_t stream, int32_t *dev_err);
 /* np.convolve(a, b), mode "full": out[k] = sum_i a[i] * b[k-i], na + nb - 1 outputs -- convolve_jit
- * (_domains/_function.py:111-167).  Direct O(na*nb) form for any field; the host routes long prime-field products
- * through gfa_ntt instead (three transforms + one gfa_binary multiply). */
+ * (_domains/_function.py:111-167).  Direct O(na*nb) kernel for any field.  Prime fields below 2^32 with na*nb >= 2^22
+ * (and at most 2^26 outputs) instead take the integer route the reference itself uses for prime fields
+ * (`np.convolve(a, b) % p`, _function.py:141-150): residues modulo three 31-bit NTT primes, nine gfa_ntt transforms, CRT,
+ * then mod p -- the same exact product.  (The host additionally routes fields that have the needed root of unity
+ * themselves through three gfa_ntt calls + one gfa_binary multiply.) */
 int gfa_convolve(gfa_field_t *f, const void *a, int64_t na, const void *b, int64_t nb, void *out, int dtype,
                  gfa_stream_t stream);
 

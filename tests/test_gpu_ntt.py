@@ -251,3 +251,38 @@ def test_three_pass_batched_and_2_26():
         wk = GF(omega) ** int(k)
         col = GF(np.full(n, int(wk), dtype=np.int64)) ** j
         assert int(A[k]) == int(np.add.reduce(a * col)), k
+
+
+@pytest.mark.parametrize("order,na,nb", [(2**31 - 1, 8192, 8192), (4294967291, 8192, 8200), (65521, 70000, 1000), (31, 9000, 9000),
+                                         (3, 8192, 8192), (251, 20000, 4000)])
+def test_convolve_crt_route_against_oracle(order, na, nb):
+    """Long products over prime fields WITHOUT a power-of-two root of unity: gfa_convolve goes through three auxiliary NTT
+    primes + CRT (gfa_conv_crt.hip).  Every coefficient against the oracle's O(na*nb) product."""
+    GF = ga.GF(order)
+    F = O.OracleField(order, 1, None, GF._primitive_element_int)
+    rng = np.random.default_rng(na + nb)
+    a = rng.integers(0, order, na, dtype=np.uint64)
+    b = rng.integers(0, order, nb, dtype=np.uint64)
+    # worst case for the CRT bound in one corner: all-(p-1) runs
+    a[: na // 4] = order - 1
+    b[: nb // 4] = order - 1
+    for dt in GF.dtypes[:2]:
+        z = np.convolve(GF(a.astype(np.int64), dtype=dt), GF(b.astype(np.int64), dtype=dt))
+        assert z.dtype == dt
+        H.assert_equal_ints(z.numpy().astype(np.uint64), F.convolve(a, b), f"crt convolve {order} {dt}")
+
+
+def test_convolve_crt_large_by_evaluation():
+    """2^20 x 2^20 terms over GF(2^31 - 1): c(x) = a(x) b(x) at random points (Horner kernel), plus the end coefficients."""
+    GF = ga.GF(2**31 - 1)
+    rng = np.random.default_rng(11)
+    n = 1 << 20
+    a = GF(rng.integers(0, 2**31 - 1, n, dtype=np.int64))
+    b = GF(rng.integers(0, 2**31 - 1, n - 3, dtype=np.int64))
+    c = np.convolve(a, b)
+    assert c.size == 2 * n - 4
+    assert int(c[0]) == int(a[0] * b[0]) and int(c[-1]) == int(a[-1] * b[-1])
+    pts = GF(rng.integers(1, 2**31 - 1, 8, dtype=np.int64))
+    # np.convolve's index 0 is the highest-degree coefficient of a Poly (degree-descending), as in Poly.__mul__
+    pa, pb, pc = ga.Poly(a), ga.Poly(b), ga.Poly(c)
+    assert np.array_equal(pc(pts).numpy(), (pa(pts) * pb(pts)).numpy())
