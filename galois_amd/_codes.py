@@ -22,7 +22,7 @@ import torch
 
 from . import _lib as L
 from . import _numtheory as nt
-from ._array import FieldArray, _ptr, _stream
+from ._array import FieldArray, _GFA_DTYPE, _TORCH_STORAGE, _ptr, _stream, _to_storage
 from ._factory import GF
 
 
@@ -103,21 +103,27 @@ class _CyclicCode:
 
     # ---- helpers ----------------------------------------------------------------------------------------------
     def _to_u8_device(self, x, what: str):
-        """array-like / FieldArray -> (uint8 device tensor, original FieldArray for dtype bookkeeping)."""
+        """array-like / FieldArray -> (device tensor in the code's symbol storage, original FieldArray for dtype bookkeeping).
+
+        Codes whose syndrome field has at most 256 elements run on the byte kernels (uint8 symbols).  Larger codes --
+        RS(1023, k) over GF(2^10), BCH(1023, k) over GF(2), ... -- keep the narrowest storage that holds a symbol
+        (uint8 / uint16 / uint32) and run on the table-driven kernels of gfa_rs_wide.hip (syndrome fields up to 2^20)."""
         arr = x if isinstance(x, FieldArray) and type(x) is self.field else self.field(x)
-        if self._ext_order > 256:
-            raise NotImplementedError(f"{what}: the device path covers codes whose syndrome field has order <= 256.")
-        if arr._t.element_size() != 1:
-            return arr._t.to(torch.uint8), arr
+        if self._ext_order > 2**20:
+            raise NotImplementedError(f"{what}: the device path covers codes whose syndrome field has order <= 2^20.")
+        width = 1 if (self._ext_order <= 256 or self.field.order <= 256) else (2 if self.field.order <= 65536 else 4)
+        want = _TORCH_STORAGE[width]
+        if arr._t.dtype != want:
+            return _to_storage(arr._t, want), arr
         return arr._t, arr
 
     def _verify_decoded(self, out: torch.Tensor):
         """Hook for BCH: the reference views the decoder's integer output as the symbol field (_bch.py:1300)."""
 
-    def _wrap(self, t_u8: torch.Tensor, like: FieldArray) -> FieldArray:
-        if like._t.element_size() != 1:
-            return self.field._wrap(t_u8.to(like._t.dtype), like._np_dtype)
-        return self.field._wrap(t_u8, like._np_dtype)
+    def _wrap(self, t_sym: torch.Tensor, like: FieldArray) -> FieldArray:
+        if like._t.dtype != t_sym.dtype:
+            return self.field._wrap(_to_storage(t_sym, like._t.dtype), like._np_dtype)
+        return self.field._wrap(t_sym, like._np_dtype)
 
     # ---- encode (_linear.py:58-93) -----------------------------------------------------------------------------
     def encode(self, message, output: str = "codeword") -> FieldArray:
@@ -139,10 +145,10 @@ class _CyclicCode:
         N, ks = m2.shape
         nk = self.n - self.k
         parity_only = output == "parity"
-        out = torch.empty((N, nk if parity_only else ks + nk), dtype=torch.uint8, device=m2.device)
+        out = torch.empty((N, nk if parity_only else ks + nk), dtype=m2.dtype, device=m2.device)
         if out.numel():  # the identity code (n == k) has no parity symbols
-            L.check(L.lib().gfa_rs_encode(self._handle, _ptr(m2), ks, _ptr(out), N, 1 if parity_only else 0, L.U8,
-                                          _stream()), "gfa_rs_encode")
+            L.check(L.lib().gfa_rs_encode(self._handle, _ptr(m2), ks, _ptr(out), N, 1 if parity_only else 0,
+                                          _GFA_DTYPE[m2.element_size()], _stream()), "gfa_rs_encode")
         if is_1d:
             out = out[0]
         return self._wrap(out, like)
@@ -153,7 +159,8 @@ class _CyclicCode:
         t2, is_1d = self._check_codeword(t)
         N, ns = t2.shape
         det = torch.empty(N, dtype=torch.uint8, device=t2.device)
-        L.check(L.lib().gfa_rs_detect(self._handle, _ptr(t2), ns, _ptr(det), N, L.U8, _stream()), "gfa_rs_detect")
+        L.check(L.lib().gfa_rs_detect(self._handle, _ptr(t2), ns, _ptr(det), N, _GFA_DTYPE[t2.element_size()], _stream()),
+                "gfa_rs_detect")
         detected = det.cpu().numpy().astype(bool)
         return bool(detected[0]) if is_1d else detected
 
@@ -185,13 +192,13 @@ class _CyclicCode:
         out = torch.empty_like(t2)
         nerr = torch.empty(N, dtype=torch.int64, device=t2.device)
         L.check(L.lib().gfa_rs_decode(self._handle, _ptr(t2), _ptr(er_t) if er_t is not None else None, ns, _ptr(out),
-                                      _ptr(nerr), N, L.U8, _stream()), "gfa_rs_decode")
+                                      _ptr(nerr), N, _GFA_DTYPE[t2.element_size()], _stream()), "gfa_rs_decode")
         self._verify_decoded(out)
         if output == "message":
             ks = self.k - (self.n - ns)
-            dec = torch.empty((N, ks), dtype=torch.uint8, device=out.device)  # _cyclic.py:129-138
-            L.check(L.lib().gfa_rs_extract_message(self._handle, _ptr(out), ns, _ptr(dec), N, L.U8, _stream()),
-                    "gfa_rs_extract_message")
+            dec = torch.empty((N, ks), dtype=out.dtype, device=out.device)  # _cyclic.py:129-138
+            L.check(L.lib().gfa_rs_extract_message(self._handle, _ptr(out), ns, _ptr(dec), N, _GFA_DTYPE[out.element_size()],
+                                                   _stream()), "gfa_rs_extract_message")
         else:
             dec = out
         n_errors = nerr.cpu().numpy()

@@ -41,6 +41,14 @@ int matmul_mfma(const FieldDev &fd, int dtype, const void *a, const void *b, voi
 bool convolve_crt_eligible(const FieldDev &fd, i64 na, i64 nb);
 int convolve_crt(struct ::gfa_field *f, int dtype, const void *a, i64 na, const void *b, i64 nb, void *out, hipStream_t st);
 
+// Reed-Solomon / BCH codes whose (syndrome) field has 256 < q <= 2^20 elements (gfa_rs_wide.hip)
+bool rs_wide_code(const struct ::gfa_rs *code);
+int rs_wide_check(const struct ::gfa_rs *code, int dtype, const char *what);
+int rs_wide_encode(struct ::gfa_rs *code, const void *msg, i64 ks, void *out, i64 batch, int parity_only, int dtype, hipStream_t st);
+int rs_wide_decode(struct ::gfa_rs *code, const void *recv, const uint8_t *eras, i64 ns, void *out, i64 *nerr, uint8_t *detected,
+                   i64 batch, bool detect_only, int dtype, hipStream_t st);
+int rs_wide_polydiv(struct ::gfa_rs *code, const void *cw, i64 ns, void *out, i64 batch, int dtype, hipStream_t st);
+
 // Host scalar arithmetic on a field, dispatched on FieldDev::kind with the same formulas the kernels use.
 struct HostArith {
     static u64 add(const FieldDev &f, u64 a, u64 b);
@@ -158,6 +166,8 @@ struct gfa_rs {
         uint32_t *lfsr = nullptr;  // 256 x (n-k)/4 words: rows f * (g_{nk-1} .. g_0) of the byte-wide LFSR (binary fields)
         uint8_t *rem = nullptr;    // scratch: r(x) mod g(x) per codeword for the two-kernel decoder
         size_t rem_bytes = 0;
+        // codes over fields above 256 elements (gfa_rs_wide.hip): 32-bit copies instead of the byte arrays
+        uint32_t *Pw = nullptr, *rootsw = nullptr, *gw = nullptr;
     };
     std::mutex mu;
     std::vector<Dev> dev;

@@ -1,4 +1,5 @@
-// gfa_rs.hip -- Reed-Solomon encode / detect / decode on gfx950 for codes over fields of order <= 256 (uint8).
+// gfa_rs.hip -- Reed-Solomon encode / detect / decode on gfx950 for codes over fields of order <= 256 (uint8); codes over
+// larger fields are routed to gfa_rs_wide.hip from the entry points at the bottom of this file.
 //
 // Replaces, for ReedSolomon codes (reference paths relative to src/galois):
 //   * encode : _LinearCode._encode_message -> matmul_jit            (_codes/_linear.py:270-284, _domains/_linalg.py:286-308)
@@ -946,6 +947,8 @@ __global__ __launch_bounds__(1024) void rs_polydiv_kernel(RsTables t, RsParams r
     }
 }
 
+size_t elem_bytes(int dtype) { return dtype == GFA_U8 ? 1 : dtype == GFA_U16 ? 2 : dtype == GFA_U32 ? 4 : 8; }
+
 int rs_check_device_path(const gfa_rs *code, int dtype, const char *what)
 {
     if (!code->field->has_tab8 || dtype != GFA_U8) {
@@ -1067,6 +1070,19 @@ int gfa_rs::ensure_device(int *device_out, Dev **out)
     std::lock_guard<std::mutex> lock(mu);
     if ((size_t)d >= dev.size()) dev.resize(d + 1);
     Dev &st = dev[d];
+    if (!st.ready && !field->has_tab8) {
+        // wide codes: 32-bit copies of P, the roots and g(x) for gfa_rs_wide.hip
+        auto upload = [](const std::vector<uint64_t> &src, uint32_t **dst) -> int {
+            std::vector<uint32_t> w(src.size());
+            for (size_t i = 0; i < w.size(); i++) w[i] = (uint32_t)src[i];
+            GFA_HIP(hipMalloc((void **)dst, std::max<size_t>(w.size() * sizeof(uint32_t), 16)));
+            if (!w.empty()) GFA_HIP(hipMemcpy(*dst, w.data(), w.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            return GFA_OK;
+        };
+        int rc;
+        if ((rc = upload(P, &st.Pw)) || (rc = upload(roots, &st.rootsw)) || (rc = upload(gpoly, &st.gw))) return rc;
+        st.ready = true;
+    }
     if (!st.ready) {
         const size_t nk = (size_t)(n - k);
         std::vector<uint8_t> P8((size_t)k * nk), r8(roots.size());
@@ -1201,7 +1217,7 @@ void gfa_rs_destroy(gfa_rs_t *code)
 {
     if (!code) return;
     for (auto &st : code->dev)
-        if (st.ready) { (void)hipFree(st.P8); (void)hipFree(st.roots8); (void)hipFree(st.lfsr); (void)hipFree(st.rem); (void)hipFree(st.g8); }
+        if (st.ready) { (void)hipFree(st.P8); (void)hipFree(st.roots8); (void)hipFree(st.lfsr); (void)hipFree(st.rem); (void)hipFree(st.g8); (void)hipFree(st.Pw); (void)hipFree(st.rootsw); (void)hipFree(st.gw); }
     delete code;
 }
 
@@ -1218,6 +1234,17 @@ int gfa_rs_encode(gfa_rs_t *code, const void *msg, int64_t ks, void *out, int64_
                   gfa_stream_t stream)
 {
     if (!code || !msg || !out || batch < 0 || ks < 1 || ks > code->k) { set_error("gfa_rs_encode: bad arguments"); return GFA_ERR_INVALID; }
+    if (rs_wide_code(code)) {
+        int rcw = rs_wide_check(code, dtype, "gfa_rs_encode");
+        if (rcw) return rcw;
+        if (!code->systematic && parity_only) { set_error("gfa_rs_encode: parity output exists only for systematic codes"); return GFA_ERR_INVALID; }
+        if (batch == 0) return GFA_OK;
+        if (code->n == code->k) {
+            if (!parity_only) GFA_HIP(hipMemcpyAsync(out, msg, elem_bytes(dtype) * (size_t)(batch * ks), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            return GFA_OK;
+        }
+        return rs_wide_encode(code, msg, ks, out, batch, parity_only, dtype, (hipStream_t)stream);
+    }
     int rc = rs_check_device_path(code, dtype, "gfa_rs_encode");
     if (rc) return rc;
     if (batch == 0) return GFA_OK;
@@ -1311,13 +1338,14 @@ int gfa_rs_detect(gfa_rs_t *code, const void *cw, int64_t ns, uint8_t *detected,
         set_error("gfa_rs_detect: bad arguments");
         return GFA_ERR_INVALID;
     }
-    int rc = rs_check_device_path(code, dtype, "gfa_rs_detect");
+    int rc = rs_wide_code(code) ? rs_wide_check(code, dtype, "gfa_rs_detect") : rs_check_device_path(code, dtype, "gfa_rs_detect");
     if (rc) return rc;
     if (batch == 0) return GFA_OK;
     if (code->n == code->k) {
         GFA_HIP(hipMemsetAsync(detected, 0, (size_t)batch, (hipStream_t)stream));
         return GFA_OK;
     }
+    if (rs_wide_code(code)) return rs_wide_decode(code, cw, nullptr, ns, nullptr, nullptr, detected, batch, true, dtype, (hipStream_t)stream);
     if (lfsr_eligible(code)) {
         FieldDeviceState *ds;
         gfa_rs::Dev *cd;
@@ -1337,15 +1365,17 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
         set_error("gfa_rs_decode: bad arguments");
         return GFA_ERR_INVALID;
     }
-    int rc = rs_check_device_path(code, dtype, "gfa_rs_decode");
+    int rc = rs_wide_code(code) ? rs_wide_check(code, dtype, "gfa_rs_decode") : rs_check_device_path(code, dtype, "gfa_rs_decode");
     if (rc) return rc;
     if (batch == 0) return GFA_OK;
     if (code->n == code->k && !erasures) { // identity code: nothing to correct (with erasures every erased word fails, below)
         if (out_codeword != recv)
-            GFA_HIP(hipMemcpyAsync(out_codeword, recv, (size_t)(batch * ns), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            GFA_HIP(hipMemcpyAsync(out_codeword, recv, elem_bytes(dtype) * (size_t)(batch * ns), hipMemcpyDeviceToDevice, (hipStream_t)stream));
         GFA_HIP(hipMemsetAsync(out_n_errors, 0, sizeof(int64_t) * (size_t)batch, (hipStream_t)stream));
         return GFA_OK;
     }
+    if (rs_wide_code(code))
+        return rs_wide_decode(code, recv, erasures, ns, out_codeword, (i64 *)out_n_errors, nullptr, batch, false, dtype, (hipStream_t)stream);
     if (lfsr_eligible(code) && code->n - code->k <= 60 && (code->base_p == 0 || code->base_p == 2) && code->roots.size() >= 1) {
         FieldDeviceState *ds;
         gfa_rs::Dev *cd;
@@ -1411,15 +1441,17 @@ int gfa_rs_extract_message(gfa_rs_t *code, const void *cw, int64_t ns, void *out
         set_error("gfa_rs_extract_message: bad arguments");
         return GFA_ERR_INVALID;
     }
-    int rc = rs_check_device_path(code, dtype, "gfa_rs_extract_message");
+    int rc = rs_wide_code(code) ? rs_wide_check(code, dtype, "gfa_rs_extract_message") : rs_check_device_path(code, dtype, "gfa_rs_extract_message");
     if (rc) return rc;
     if (batch == 0) return GFA_OK;
     const int64_t ks = code->k - (code->n - ns);
     if (code->systematic || code->n == code->k) {
-        GFA_HIP(hipMemcpy2DAsync(out_msg, (size_t)ks, cw, (size_t)ns, (size_t)ks, (size_t)batch, hipMemcpyDeviceToDevice,
+        const size_t eb = elem_bytes(dtype);
+        GFA_HIP(hipMemcpy2DAsync(out_msg, eb * (size_t)ks, cw, eb * (size_t)ns, eb * (size_t)ks, (size_t)batch, hipMemcpyDeviceToDevice,
                                  (hipStream_t)stream));
         return GFA_OK;
     }
+    if (rs_wide_code(code)) return rs_wide_polydiv(code, cw, ns, out_msg, batch, dtype, (hipStream_t)stream);
     return launch_poly<true>(code, cw, (int)ns, out_msg, batch, (hipStream_t)stream);
 }
 

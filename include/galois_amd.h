@@ -187,7 +187,12 @@ int gfa_plu_decompose(gfa_field_t *f, void *a, void *l_out, void *p_out, int64_t
 
 /* ---- Reed-Solomon -------------------------------------------------------------------------------- *
  * gfa_rs_create replaces the arithmetic part of ReedSolomon.__init__ (_codes/_reed_solomon.py:111-218) and
- * _poly_to_generator_matrix (_codes/_cyclic.py:198-226): roots alpha^(c..c+d-2), g(x), systematic parity matrix. */
+ * _poly_to_generator_matrix (_codes/_cyclic.py:198-226): roots alpha^(c..c+d-2), g(x), systematic parity matrix.
+ *
+ * Symbol storage (`dtype` of the encode / detect / decode / extract calls below): codes whose (syndrome) field has at most 256
+ * elements take GFA_U8 symbols and run on the byte kernels.  Codes over larger fields with EXP/LOG tables (q <= 2^20:
+ * RS(1023, k) over GF(2^10), BCH(1023, k) over GF(2), RS over GF(3^6), ...) take GFA_U8 / GFA_U16 / GFA_U32 symbols, whichever
+ * holds a symbol of the code's symbol field, and run on the table-driven kernels (same algorithm; d - 1 <= 254 roots). */
 int gfa_rs_create(gfa_field_t *f, int64_t n, int64_t k, int64_t c, uint64_t alpha, int systematic, gfa_rs_t **out);
 /* BCH(n, k) code over the prime field GF(p) with syndrome arithmetic in `ext` = GF(p^m): replaces the arithmetic part of
  * BCH.__init__ after the generator polynomial is known (_codes/_bch.py:106-240) -- roots alpha^c .. alpha^(c+d-2) in

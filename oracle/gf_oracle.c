@@ -622,10 +622,15 @@ static int decode_impl(const gfo_field *f, u64 base_p, const u64 *codewords, con
                        i64 design_n, u64 alpha, i64 c, const u64 *roots, i64 n_roots, u64 *dec_codewords, i64 *n_errors)
 {
     i64 d = n_roots + 1;
-    if (n > 512 || d > 256) return GFO_BAD_ARG;
-    u64 received[512], tmp[512], syndrome[256], gamma[512], gtmp[512], sprime[1024], lambda_[512], ltotal[1024];
-    u64 omega_p[1024], ltp[1024], codeword[512];
-    i64 epos[512], error_positions[512];
+    if (n < 1 || d > 256) return GFO_BAD_ARG;
+    /* per-codeword buffers sized by the codeword length (codes over fields above 256 elements: n up to 2^20 - 1) */
+    const size_t cap = (size_t)(n > 1024 ? n : 1024);
+    u64 *received = malloc(sizeof(u64) * cap), *tmp = malloc(sizeof(u64) * cap), *codeword = malloc(sizeof(u64) * cap);
+    i64 *epos = malloc(sizeof(i64) * cap);
+    if (!received || !tmp || !codeword || !epos) { free(received); free(tmp); free(codeword); free(epos); return GFO_BAD_ARG; }
+    u64 syndrome[256], gamma[512], gtmp[512], sprime[1024], lambda_[512], ltotal[1024];
+    u64 omega_p[1024], ltp[1024];
+    i64 error_positions[512];
     u64 error_locators_inv[512], error_values[512];
 
     memcpy(dec_codewords, codewords, sizeof(u64) * (size_t)(N * n));
@@ -742,6 +747,7 @@ static int decode_impl(const gfo_field *f, u64 base_p, const u64 *codewords, con
         for (i64 i = 0; i < n; i++) dec_codewords[ni * n + i] = codeword[n - 1 - i];
         n_errors[ni] = v;
     }
+    free(received); free(tmp); free(codeword); free(epos);
     return GFO_OK;
 }
 

@@ -143,6 +143,119 @@ def pack_sage_rs():
     print("packed", len(names), "RS fixtures")
 
 
+def _rs_case(out, rng, galois, GFref, tag, order, n, k, c=1, N=12, field_kw=None, shorten=0):
+    GF = GFref(order, **(field_kw or {}))
+    rs = galois.ReedSolomon(n, k, field=GF, c=c)
+    ks, ns = k - shorten, n - shorten
+    t = (n - k) // 2
+    M = rng.integers(0, order, (N, ks))
+    C = np.asarray(rs.encode(GF(M))).astype(np.int64)
+    R = C.copy()
+    E = np.zeros((N, ns), dtype=bool)
+    plan = [(0, 0), (t, 0), (t + 1, 0), (t // 2, 0), (1, 0), (t + 3, 0), (0, 2), (t - 1, 2), (0, n - k), (0, n - k + 1),
+            (t // 2, (n - k) - 2 * (t // 2)), (1, n - k)]
+    for i in range(N):
+        ne, nu = plan[i % len(plan)]
+        ne, nu = min(ne, ns), min(nu, ns)
+        pos = rng.choice(ns, ne, replace=False)
+        R[i, pos] = (R[i, pos] + rng.integers(1, order, ne)) % order
+        if nu:
+            rest = np.setdiff1d(np.arange(ns), pos)
+            epos = rng.choice(rest, min(nu, rest.size), replace=False)
+            E[i, epos] = True
+            R[i, epos] = rng.integers(0, order, epos.size)
+    dec, nerr = rs.decode(GF(R), erasures=E, output="codeword", errors=True)
+    out[f"rs/{tag}/meta"] = np.array(json.dumps({"q": order, "n": n, "k": k, "c": c, "alpha": int(rs.alpha),
+                                                 "irr": int(GF.irreducible_poly), "p": int(GF.characteristic),
+                                                 "m": int(GF.degree), "field_alpha": int(GF.primitive_element)}))
+    out[f"rs/{tag}/generator_poly"] = small(rs.generator_poly.coeffs)
+    out[f"rs/{tag}/messages"] = small(M)
+    out[f"rs/{tag}/codewords"] = small(C)
+    out[f"rs/{tag}/received"] = small(R)
+    out[f"rs/{tag}/erasures"] = E
+    out[f"rs/{tag}/decoded"] = small(dec)
+    out[f"rs/{tag}/n_errors"] = np.asarray(nerr, dtype=np.int64)
+    out[f"rs/{tag}/detected"] = np.asarray(rs.detect(GF(R)))
+    print("rs", tag, list(nerr))
+
+
+def _bch_case(out, rng, galois, load_reference, tag, n, k=None, d=None, p=2, c=1, systematic=True, N=14, shorten=0, ext_kw=None):
+    GFp = load_reference.ref_field(p)
+    # the default extension field (_bch.py:207-211), built explicitly so that it is in python-calculate mode (the
+    # numba stand-in cannot freeze per-field globals for "jit" Function objects)
+    m = galois.ilog(n, p) + 1
+    ext = load_reference.ref_field(p**m, irreducible_poly=galois.matlab_primitive_poly(p, m))
+    bch = galois.BCH(n, k, d, field=GFp, extension_field=ext, c=c, systematic=systematic)
+    k, dd = bch.k, bch.d
+    ks, ns = k - shorten, n - shorten
+    t = (dd - 1) // 2
+    M = rng.integers(0, p, (N, ks))
+    C = np.asarray(bch.encode(GFp(M))).astype(np.int64)
+    R = C.copy()
+    E = np.zeros((N, ns), dtype=bool)
+    plan = [(0, 0), (t, 0), (t + 1, 0), (t // 2, 0), (1, 0), (t + 2, 0), (0, 2), (max(t - 1, 0), 2), (0, dd - 1), (0, dd),
+            (t // 2, (dd - 1) - 2 * (t // 2)), (1, dd - 1), (t + 3, 0), (2 * t + 1, 0)]
+    for i in range(N):
+        ne, nu = plan[i % len(plan)]
+        ne, nu = min(ne, ns), min(nu, ns)
+        pos = rng.choice(ns, ne, replace=False)
+        R[i, pos] = (R[i, pos] + rng.integers(1, p, ne)) % p
+        if nu:
+            rest = np.setdiff1d(np.arange(ns), pos)
+            epos = rng.choice(rest, min(nu, rest.size), replace=False)
+            E[i, epos] = True
+            R[i, epos] = rng.integers(0, p, epos.size)
+    # row by row: a miscorrection whose error values fall outside GF(p) makes the reference raise ValueError when it
+    # views the decoded int64 array as the base field (_bch.py:1300 -> _fields/_array.py:177); recorded in `raises`
+    dec = np.zeros((N, ns), dtype=np.int64)
+    msg = np.zeros((N, ks), dtype=np.int64)
+    nerr = np.zeros(N, dtype=np.int64)
+    raises = np.zeros(N, dtype=bool)
+    for i in range(N):
+        try:
+            if p**m > 256:
+                # Syndrome fields above 256 elements: BCH.decode casts the codeword to the base field's uint8 before the
+                # stand-in runs the kernel body in place of the compiled function, and extension-field values do not
+                # fit.  Call the decoder the way the compiled branch does (bch_decode_jit.__call__, _bch.py:1280-1288:
+                # int64 arrays), then apply the same post-processing (_bch.py:1299-1300, _cyclic.py:129-138).
+                from galois._codes._bch import bch_decode_jit
+
+                func = bch_decode_jit(bch.field, bch.extension_field)
+                d2, n2 = func.python(R[i:i + 1].astype(np.int64), E[i:i + 1].astype(bool), bch.n, int(bch.alpha), bch.c,
+                                     np.asarray(bch.roots).astype(np.int64))
+                d8 = np.asarray(d2).astype(np.uint8)
+                if (d8 >= p).any():
+                    raise ValueError("decoded symbols outside the base field")
+                dec[i], nerr[i] = d8[0], int(n2[0])
+                msg[i] = np.asarray(bch._convert_codeword_to_message(GFp(d8)))[0]
+                continue
+            d_i, n_i = bch.decode(GFp(R[i]), erasures=E[i], output="codeword", errors=True)
+            dec[i], nerr[i] = np.asarray(d_i), n_i
+            msg[i] = np.asarray(bch.decode(GFp(R[i]), erasures=E[i], output="message"))
+        except (ValueError, OverflowError):
+            # OverflowError: in python-calculate mode the decoder works on the uint8 array directly and NumPy 2
+            # refuses the negative SUBTRACT_BASE result; the jit path computes it in int64, wraps on astype and
+            # then fails the same field-membership check (ValueError).  Either way: an exception.
+            raises[i] = True
+    ext = bch.extension_field
+    out[f"bch/{tag}/meta"] = np.array(json.dumps({
+        "p": p, "n": n, "k": int(k), "d": int(dd), "c": c, "alpha": int(bch.alpha), "systematic": systematic,
+        "ext_order": int(ext.order), "ext_m": int(ext.degree), "ext_irr": int(ext.irreducible_poly),
+        "ext_alpha": int(ext.primitive_element), "shorten": shorten}))
+    out[f"bch/{tag}/generator_poly"] = small(bch.generator_poly.coeffs)
+    out[f"bch/{tag}/roots"] = small(bch.roots)
+    out[f"bch/{tag}/messages"] = small(M)
+    out[f"bch/{tag}/codewords"] = small(C)
+    out[f"bch/{tag}/received"] = small(R)
+    out[f"bch/{tag}/erasures"] = E
+    out[f"bch/{tag}/decoded"] = np.asarray(dec).astype(np.int64)
+    out[f"bch/{tag}/decoded_message"] = np.asarray(msg).astype(np.int64)
+    out[f"bch/{tag}/n_errors"] = np.asarray(nerr, dtype=np.int64)
+    out[f"bch/{tag}/raises"] = raises
+    out[f"bch/{tag}/detected"] = np.asarray(bch.detect(GFp(R)))
+    print("bch", tag, (n, int(k), int(dd)), list(nerr), "raises", list(np.nonzero(raises)[0]))
+
+
 def reference_outputs():
     import load_reference
 
@@ -212,39 +325,7 @@ def reference_outputs():
 
     # ---- Reed-Solomon: RS(255,223) (no upstream fixture) and small codes with erasures ----
     def rs_case(tag, order, n, k, c=1, N=12, field_kw=None, shorten=0):
-        GF = GFref(order, **(field_kw or {}))
-        rs = galois.ReedSolomon(n, k, field=GF, c=c)
-        ks, ns = k - shorten, n - shorten
-        t = (n - k) // 2
-        M = rng.integers(0, order, (N, ks))
-        C = np.asarray(rs.encode(GF(M))).astype(np.int64)
-        R = C.copy()
-        E = np.zeros((N, ns), dtype=bool)
-        plan = [(0, 0), (t, 0), (t + 1, 0), (t // 2, 0), (1, 0), (t + 3, 0), (0, 2), (t - 1, 2), (0, n - k), (0, n - k + 1),
-                (t // 2, (n - k) - 2 * (t // 2)), (1, n - k)]
-        for i in range(N):
-            ne, nu = plan[i % len(plan)]
-            ne, nu = min(ne, ns), min(nu, ns)
-            pos = rng.choice(ns, ne, replace=False)
-            R[i, pos] = (R[i, pos] + rng.integers(1, order, ne)) % order
-            if nu:
-                rest = np.setdiff1d(np.arange(ns), pos)
-                epos = rng.choice(rest, min(nu, rest.size), replace=False)
-                E[i, epos] = True
-                R[i, epos] = rng.integers(0, order, epos.size)
-        dec, nerr = rs.decode(GF(R), erasures=E, output="codeword", errors=True)
-        out[f"rs/{tag}/meta"] = np.array(json.dumps({"q": order, "n": n, "k": k, "c": c, "alpha": int(rs.alpha),
-                                                     "irr": int(GF.irreducible_poly), "p": int(GF.characteristic),
-                                                     "m": int(GF.degree), "field_alpha": int(GF.primitive_element)}))
-        out[f"rs/{tag}/generator_poly"] = small(rs.generator_poly.coeffs)
-        out[f"rs/{tag}/messages"] = small(M)
-        out[f"rs/{tag}/codewords"] = small(C)
-        out[f"rs/{tag}/received"] = small(R)
-        out[f"rs/{tag}/erasures"] = E
-        out[f"rs/{tag}/decoded"] = small(dec)
-        out[f"rs/{tag}/n_errors"] = np.asarray(nerr, dtype=np.int64)
-        out[f"rs/{tag}/detected"] = np.asarray(rs.detect(GF(R)))
-        print("rs", tag, list(nerr))
+        _rs_case(out, rng, galois, GFref, tag, order, n, k, c, N, field_kw, shorten)
 
     matlab = galois.matlab_primitive_poly(2, 8)
     rs_case("rs255_223", 2**8, 255, 223, field_kw=dict(irreducible_poly=matlab))
@@ -294,64 +375,7 @@ def reference_bch_outputs():
     out = {}
 
     def case(tag, n, k=None, d=None, p=2, c=1, systematic=True, N=14, shorten=0, ext_kw=None):
-        GFp = load_reference.ref_field(p)
-        # the default extension field (_bch.py:207-211), built explicitly so that it is in python-calculate mode (the
-        # numba stand-in cannot freeze per-field globals for "jit" Function objects)
-        m = galois.ilog(n, p) + 1
-        ext = load_reference.ref_field(p**m, irreducible_poly=galois.matlab_primitive_poly(p, m))
-        bch = galois.BCH(n, k, d, field=GFp, extension_field=ext, c=c, systematic=systematic)
-        k, dd = bch.k, bch.d
-        ks, ns = k - shorten, n - shorten
-        t = (dd - 1) // 2
-        M = rng.integers(0, p, (N, ks))
-        C = np.asarray(bch.encode(GFp(M))).astype(np.int64)
-        R = C.copy()
-        E = np.zeros((N, ns), dtype=bool)
-        plan = [(0, 0), (t, 0), (t + 1, 0), (t // 2, 0), (1, 0), (t + 2, 0), (0, 2), (max(t - 1, 0), 2), (0, dd - 1), (0, dd),
-                (t // 2, (dd - 1) - 2 * (t // 2)), (1, dd - 1), (t + 3, 0), (2 * t + 1, 0)]
-        for i in range(N):
-            ne, nu = plan[i % len(plan)]
-            ne, nu = min(ne, ns), min(nu, ns)
-            pos = rng.choice(ns, ne, replace=False)
-            R[i, pos] = (R[i, pos] + rng.integers(1, p, ne)) % p
-            if nu:
-                rest = np.setdiff1d(np.arange(ns), pos)
-                epos = rng.choice(rest, min(nu, rest.size), replace=False)
-                E[i, epos] = True
-                R[i, epos] = rng.integers(0, p, epos.size)
-        # row by row: a miscorrection whose error values fall outside GF(p) makes the reference raise ValueError when it
-        # views the decoded int64 array as the base field (_bch.py:1300 -> _fields/_array.py:177); recorded in `raises`
-        dec = np.zeros((N, ns), dtype=np.int64)
-        msg = np.zeros((N, ks), dtype=np.int64)
-        nerr = np.zeros(N, dtype=np.int64)
-        raises = np.zeros(N, dtype=bool)
-        for i in range(N):
-            try:
-                d_i, n_i = bch.decode(GFp(R[i]), erasures=E[i], output="codeword", errors=True)
-                dec[i], nerr[i] = np.asarray(d_i), n_i
-                msg[i] = np.asarray(bch.decode(GFp(R[i]), erasures=E[i], output="message"))
-            except (ValueError, OverflowError):
-                # OverflowError: in python-calculate mode the decoder works on the uint8 array directly and NumPy 2
-                # refuses the negative SUBTRACT_BASE result; the jit path computes it in int64, wraps on astype and
-                # then fails the same field-membership check (ValueError).  Either way: an exception.
-                raises[i] = True
-        ext = bch.extension_field
-        out[f"bch/{tag}/meta"] = np.array(json.dumps({
-            "p": p, "n": n, "k": int(k), "d": int(dd), "c": c, "alpha": int(bch.alpha), "systematic": systematic,
-            "ext_order": int(ext.order), "ext_m": int(ext.degree), "ext_irr": int(ext.irreducible_poly),
-            "ext_alpha": int(ext.primitive_element), "shorten": shorten}))
-        out[f"bch/{tag}/generator_poly"] = small(bch.generator_poly.coeffs)
-        out[f"bch/{tag}/roots"] = small(bch.roots)
-        out[f"bch/{tag}/messages"] = small(M)
-        out[f"bch/{tag}/codewords"] = small(C)
-        out[f"bch/{tag}/received"] = small(R)
-        out[f"bch/{tag}/erasures"] = E
-        out[f"bch/{tag}/decoded"] = np.asarray(dec).astype(np.int64)
-        out[f"bch/{tag}/decoded_message"] = np.asarray(msg).astype(np.int64)
-        out[f"bch/{tag}/n_errors"] = np.asarray(nerr, dtype=np.int64)
-        out[f"bch/{tag}/raises"] = raises
-        out[f"bch/{tag}/detected"] = np.asarray(bch.detect(GFp(R)))
-        print("bch", tag, (n, int(k), int(dd)), list(nerr), "raises", list(np.nonzero(raises)[0]))
+        _bch_case(out, rng, galois, load_reference, tag, n, k, d, p, c, systematic, N, shorten, ext_kw)
 
     case("bch15_7", 15, 7)
     case("bch15_5_c3", 15, d=7, c=3)
@@ -369,8 +393,31 @@ def reference_bch_outputs():
     np.savez_compressed(os.path.join(HERE, "reference_bch_outputs.npz"), **out)
 
 
+def reference_wide_codes():
+    """Codes whose syndrome field has more than 256 elements (gfa_rs_wide.hip): outputs of the reference itself."""
+    import load_reference
+
+    galois = load_reference.load()
+    rng = np.random.default_rng(20260927)
+    out = {}
+
+    def GFref(order, **kw):
+        return load_reference.ref_field(order, **kw)
+
+    _rs_case(out, rng, galois, GFref, "rs1023_1003", 2**10, 1023, 1003, N=8)
+    _rs_case(out, rng, galois, GFref, "rs1023_1011_short_c0", 2**10, 1023, 1011, c=0, N=8, shorten=600)
+    _rs_case(out, rng, galois, GFref, "rs728_712_gf729", 3**6, 728, 712, N=8)
+    _rs_case(out, rng, galois, GFref, "rs511_501", 2**9, 511, 501, c=2, N=6)
+    _bch_case(out, rng, galois, load_reference, "bch511_493", 511, 493, N=8)
+    _bch_case(out, rng, galois, load_reference, "bch1023_1003", 1023, 1003, N=8)
+    _bch_case(out, rng, galois, load_reference, "bch1023_973_short", 1023, 973, N=6, shorten=500)
+    _bch_case(out, rng, galois, load_reference, "bch728_gf3", 728, d=7, p=3, N=8)
+    _bch_case(out, rng, galois, load_reference, "bch511_484_nonsys", 511, 484, systematic=False, N=6)
+    np.savez_compressed(os.path.join(HERE, "reference_wide_codes.npz"), **out)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["fields", "rs", "reference", "bch", "reference_bch", "linalg", "polys"]
+    what = sys.argv[1:] or ["fields", "rs", "reference", "bch", "reference_bch", "reference_wide", "linalg", "polys"]
     if "fields" in what:
         pack_sage_fields()
     if "rs" in what:
@@ -385,4 +432,6 @@ if __name__ == "__main__":
         pack_sage_bch()
     if "reference_bch" in what:
         reference_bch_outputs()
+    if "reference_wide" in what:
+        reference_wide_codes()
     print("done")

@@ -64,6 +64,15 @@ def reference_bch_outputs():
     return np.load(os.path.join(GOLDEN, "reference_bch_outputs.npz"))
 
 
+def reference_wide_codes():
+    """RS / BCH codes whose syndrome field has more than 256 elements (generate_golden.py reference_wide)."""
+    return np.load(os.path.join(GOLDEN, "reference_wide_codes.npz"))
+
+
+WIDE_RS_CASES = ["rs1023_1003", "rs1023_1011_short_c0", "rs728_712_gf729", "rs511_501"]
+WIDE_BCH_CASES = ["bch511_493", "bch1023_1003", "bch1023_973_short", "bch728_gf3", "bch511_484_nonsys"]
+
+
 def parse_sage_poly(text, p):
     """'x^18 + 2*x^14 + x + 2' -> coefficients, highest degree first (Sage's str() of a polynomial over GF(p))."""
     terms = {}

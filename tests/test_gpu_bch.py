@@ -53,12 +53,7 @@ def test_sage_bch_fixtures():
             assert np.array_equal(bch.detect(R), ne > 0), key
 
 
-@pytest.mark.parametrize("tag", ["bch15_7", "bch15_5_c3", "bch31_16", "bch63_45", "bch63_36_short", "bch255_223",
-                                 "bch127_99_nonsys", "bch13_4_gf3", "bch26_14_gf3", "bch26_8_gf3_c3", "bch80_60_gf3",
-                                 "bch24_gf5", "bch26_14_gf3_nonsys_short"])
-def test_reference_generated_cases(tag):
-    """Errors, erasures, beyond-capacity words and the rows on which the reference raises (symbols outside GF(p))."""
-    d = H.reference_bch_outputs()
+def _check_device_bch(d, tag):
     meta = json.loads(str(d[f"bch/{tag}/meta"]))
     p = meta["p"]
     ext = ga.GF(p, meta["ext_m"], irreducible_poly=meta["ext_irr"], primitive_element=meta["ext_alpha"])
@@ -84,9 +79,26 @@ def test_reference_generated_cases(tag):
             bch.decode(R, erasures=E)
 
 
+@pytest.mark.parametrize("tag", ["bch15_7", "bch15_5_c3", "bch31_16", "bch63_45", "bch63_36_short", "bch255_223",
+                                 "bch127_99_nonsys", "bch13_4_gf3", "bch26_14_gf3", "bch26_8_gf3_c3", "bch80_60_gf3",
+                                 "bch24_gf5", "bch26_14_gf3_nonsys_short"])
+def test_reference_generated_cases(tag):
+    """Errors, erasures, beyond-capacity words and the rows on which the reference raises (symbols outside GF(p))."""
+    _check_device_bch(H.reference_bch_outputs(), tag)
+
+
+@pytest.mark.parametrize("tag", H.WIDE_BCH_CASES)
+def test_wide_reference_generated_cases(tag):
+    """BCH codes of length 511, 728 (GF(3)) and 1023 -- syndrome fields GF(2^9), GF(3^6), GF(2^10) -- against outputs of the
+    reference itself (gfa_rs_wide.hip)."""
+    _check_device_bch(H.reference_wide_codes(), tag)
+
+
 @pytest.mark.parametrize("p,n,d,c,systematic", [(2, 255, 9, 1, True), (2, 255, 37, 1, True), (2, 127, 21, 0, True),
                                                 (2, 63, 13, 1, False), (3, 80, 9, 1, True), (3, 242, 11, 2, True),
-                                                (5, 124, 9, 1, True), (7, 48, 7, 1, False)])
+                                                (5, 124, 9, 1, True), (7, 48, 7, 1, False),
+                                                (2, 1023, 21, 1, True), (2, 511, 9, 0, False), (3, 728, 9, 1, True),
+                                                (2, 4095, 7, 1, True), (2, 2047, 9, 1, True), (5, 624, 7, 2, True)])
 def test_random_batches_against_oracle(p, n, d, c, systematic):
     """Larger batches with 0 .. t+2 errors and random erasures: decoded rows, n_errors and the out-of-field rows match
     the oracle row by row (the batch call raises iff any row leaves GF(p))."""

@@ -47,28 +47,32 @@ def test_sage_encode_fixtures():
     assert n_checked == 56
 
 
+def _check_device_rs(d, tag):
+    meta = json.loads(str(d[f"rs/{tag}/meta"]))
+    GF = ga.GF(meta["p"], meta["m"], irreducible_poly=meta["irr"], primitive_element=meta["field_alpha"]) if meta["m"] > 1 \
+        else ga.GF(meta["p"], primitive_element=meta["field_alpha"])
+    rs = ga.ReedSolomon(meta["n"], meta["k"], field=GF, c=meta["c"], alpha=meta["alpha"])
+    H.assert_equal_ints(rs.generator_poly.coeffs, d[f"rs/{tag}/generator_poly"])
+    M = d[f"rs/{tag}/messages"].astype(np.int64)
+    H.assert_equal_ints(rs.encode(M).numpy(), d[f"rs/{tag}/codewords"], tag + " encode")
+    R, E = d[f"rs/{tag}/received"].astype(np.int64), d[f"rs/{tag}/erasures"]
+    dec, nerr = rs.decode(R, erasures=E, output="codeword", errors=True)
+    assert np.array_equal(nerr, d[f"rs/{tag}/n_errors"]), (tag, nerr, d[f"rs/{tag}/n_errors"])
+    H.assert_equal_ints(dec.numpy(), d[f"rs/{tag}/decoded"], tag + " decoded")
+    assert np.array_equal(rs.detect(R), d[f"rs/{tag}/detected"]), tag + " detect"
+    # 1-D forms
+    d1, n1 = rs.decode(R[1], erasures=E[1], output="codeword", errors=True)
+    assert isinstance(n1, int) and n1 == int(d[f"rs/{tag}/n_errors"][1])
+    H.assert_equal_ints(d1.numpy(), d[f"rs/{tag}/decoded"][1])
+    ks = M.shape[1]
+    H.assert_equal_ints(rs.decode(R[:2], erasures=E[:2]).numpy(), d[f"rs/{tag}/decoded"][:2, :ks])
+
+
 def test_reference_generated_cases():
     d = H.reference_outputs()
     tags = sorted({k.split("/")[1] for k in d.files if k.startswith("rs/") and k.endswith("/meta")})
     for tag in tags:
-        meta = json.loads(str(d[f"rs/{tag}/meta"]))
-        GF = ga.GF(meta["p"], meta["m"], irreducible_poly=meta["irr"], primitive_element=meta["field_alpha"]) if meta["m"] > 1 \
-            else ga.GF(meta["p"], primitive_element=meta["field_alpha"])
-        rs = ga.ReedSolomon(meta["n"], meta["k"], field=GF, c=meta["c"], alpha=meta["alpha"])
-        H.assert_equal_ints(rs.generator_poly.coeffs, d[f"rs/{tag}/generator_poly"])
-        M = d[f"rs/{tag}/messages"].astype(np.int64)
-        H.assert_equal_ints(rs.encode(M).numpy(), d[f"rs/{tag}/codewords"], tag + " encode")
-        R, E = d[f"rs/{tag}/received"].astype(np.int64), d[f"rs/{tag}/erasures"]
-        dec, nerr = rs.decode(R, erasures=E, output="codeword", errors=True)
-        assert np.array_equal(nerr, d[f"rs/{tag}/n_errors"]), (tag, nerr, d[f"rs/{tag}/n_errors"])
-        H.assert_equal_ints(dec.numpy(), d[f"rs/{tag}/decoded"], tag + " decoded")
-        assert np.array_equal(rs.detect(R), d[f"rs/{tag}/detected"]), tag + " detect"
-        # 1-D forms
-        d1, n1 = rs.decode(R[1], erasures=E[1], output="codeword", errors=True)
-        assert isinstance(n1, int) and n1 == int(d[f"rs/{tag}/n_errors"][1])
-        H.assert_equal_ints(d1.numpy(), d[f"rs/{tag}/decoded"][1])
-        ks = M.shape[1]
-        H.assert_equal_ints(rs.decode(R[:2], erasures=E[:2]).numpy(), d[f"rs/{tag}/decoded"][:2, :ks])
+        _check_device_rs(d, tag)
     rs = ga.ReedSolomon(255, 223)
     H.assert_equal_ints(rs.encode(np.arange(223), output="parity").numpy(), d["rs/kat_arange_parity"])
 
@@ -206,3 +210,69 @@ def test_identity_code_with_erasures():
     assert list(nerr) == [0, -1, 0] and np.array_equal(dec.numpy(), R)
     dec, nerr = rs.decode(R, errors=True)
     assert list(nerr) == [0, 0, 0] and np.array_equal(dec.numpy(), R)
+
+
+# ---- codes over fields above 256 elements (gfa_rs_wide.hip) ------------------------------------------------------------
+@pytest.mark.parametrize("tag", H.WIDE_RS_CASES)
+def test_wide_reference_generated_cases(tag):
+    """RS over GF(2^10), GF(2^9), GF(3^6) against outputs of the reference itself (errors, erasures, failures, shortened)."""
+    _check_device_rs(H.reference_wide_codes(), tag)
+
+
+@pytest.mark.parametrize("q,n,k,c,N", [(2**10, 1023, 1003, 1, 300), (2**10, 1023, 901, 0, 60), (3**6, 728, 712, 1, 200),
+                                       (2**9, 511, 479, 2, 200), (2**12, 4095, 4063, 1, 40), (2**16, 65535, 65519, 1, 6),
+                                       (7**4, 2400, 2380, 1, 40), (2**10, 341, 321, 1, 100)])
+def test_wide_random_batches_against_oracle(q, n, k, c, N):
+    GF = ga.GF(q)
+    rs = ga.ReedSolomon(n, k, field=GF, c=c)
+    p, m = GF.characteristic, GF.degree
+    F = O.OracleField(p, m, int(GF.irreducible_poly), GF._primitive_element_int, lookup=True)
+    R_ = O.OracleRS(F, n, k, alpha=rs.alpha, c=c)
+    rng = np.random.default_rng(n * 7 + k)
+    t = (n - k) // 2
+    for shorten in (0, min(n // 3, k - 1)):
+        ks, ns = k - shorten, n - shorten
+        M = rng.integers(0, q, (N, ks))
+        C = rs.encode(M).numpy().astype(np.int64)
+        assert np.array_equal(C, R_.encode(M).astype(np.int64))
+        assert np.array_equal(rs.encode(M, output="parity").numpy(), C[:, ks:])
+        R = C.copy()
+        E = np.zeros((N, ns), dtype=bool)
+        for i in range(N):
+            ne = int(rng.integers(0, t + 3))
+            nu = int(rng.integers(0, n - k + 2)) if i % 3 == 0 else 0
+            pos = rng.choice(ns, min(ne, ns), replace=False)
+            R[i, pos] = (R[i, pos] + rng.integers(1, q, pos.size)) % q
+            if nu:
+                epos = rng.choice(ns, min(nu, ns), replace=False)
+                E[i, epos] = True
+                R[i, epos] = rng.integers(0, q, epos.size)
+        dec, nerr = rs.decode(R, erasures=E, output="codeword", errors=True)
+        odec, onerr = R_.decode(R, E)
+        assert np.array_equal(nerr, onerr), np.nonzero(nerr != onerr)[0][:10]
+        assert np.array_equal(dec.numpy().astype(np.int64), odec.astype(np.int64))
+        assert dec.dtype == GF.dtypes[0]
+        dec2, nerr2 = rs.decode(R, errors=True)
+        odec2, onerr2 = R_.decode(R)
+        assert np.array_equal(nerr2, onerr2) and np.array_equal(dec2.numpy().astype(np.int64), odec2[:, :ks].astype(np.int64))
+        assert np.array_equal(rs.detect(R), R_.detect(R))
+    # other storage widths of the same field, and a non-systematic code of the same parameters
+    wide = rs.decode(GF(R, dtype=GF.dtypes[-1]), output="codeword")
+    assert wide.dtype == GF.dtypes[-1] and np.array_equal(wide.numpy().astype(np.int64), odec2.astype(np.int64))
+    if n <= 4095:
+        ns_rs = ga.ReedSolomon(n, k, field=GF, c=c, systematic=False)
+        M = rng.integers(0, q, (8, k))
+        Cn = ns_rs.encode(M)
+        assert not ns_rs.detect(Cn).any()
+        Rn = Cn.numpy().astype(np.int64)
+        Rn[:, 3] = (Rn[:, 3] + 1) % q
+        back, ne = ns_rs.decode(Rn, errors=True)
+        assert np.array_equal(back.numpy().astype(np.int64), M) and (ne == 1).all()
+
+
+def test_wide_limits():
+    GF = ga.GF(2**10)
+    with pytest.raises((NotImplementedError, ValueError)):
+        ga.ReedSolomon(1023, 523, field=GF).encode(np.zeros(523, dtype=np.int64))  # d - 1 = 500 roots: beyond the device path
+    with pytest.raises((NotImplementedError, ValueError)):
+        ga.ReedSolomon(2**21 - 1, 2**21 - 9, field=ga.GF(2**21)).encode(np.zeros(2**21 - 9, dtype=np.int64))

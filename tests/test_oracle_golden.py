@@ -113,20 +113,24 @@ def test_reference_ntt_outputs():
         H.assert_equal_ints(F.ntt(x, inverse=True), d[f"ntt/{tag}/ifft"], tag + " inverse")
 
 
+def _check_oracle_rs(d, tag):
+    meta = json.loads(str(d[f"rs/{tag}/meta"]))
+    F = O.OracleField(meta["p"], meta["m"], meta["irr"] if meta["m"] > 1 else None, meta["field_alpha"], lookup=True)
+    R = O.OracleRS(F, meta["n"], meta["k"], alpha=meta["alpha"], c=meta["c"])
+    H.assert_equal_ints(R.generator_poly, d[f"rs/{tag}/generator_poly"], tag)
+    H.assert_equal_ints(R.encode(d[f"rs/{tag}/messages"]), d[f"rs/{tag}/codewords"], tag + " encode")
+    dec, nerr = R.decode(d[f"rs/{tag}/received"], d[f"rs/{tag}/erasures"])
+    H.assert_equal_ints(nerr, d[f"rs/{tag}/n_errors"], tag + " n_errors")
+    H.assert_equal_ints(dec, d[f"rs/{tag}/decoded"], tag + " decoded")
+    H.assert_equal_ints(R.detect(d[f"rs/{tag}/received"]), d[f"rs/{tag}/detected"], tag + " detect")
+
+
 def test_reference_reed_solomon_outputs():
     d = H.reference_outputs()
     tags = sorted({k.split("/")[1] for k in d.files if k.startswith("rs/") and k.endswith("/meta")})
     assert "rs255_223" in tags
     for tag in tags:
-        meta = json.loads(str(d[f"rs/{tag}/meta"]))
-        F = O.OracleField(meta["p"], meta["m"], meta["irr"] if meta["m"] > 1 else None, meta["field_alpha"], lookup=True)
-        R = O.OracleRS(F, meta["n"], meta["k"], alpha=meta["alpha"], c=meta["c"])
-        H.assert_equal_ints(R.generator_poly, d[f"rs/{tag}/generator_poly"], tag)
-        H.assert_equal_ints(R.encode(d[f"rs/{tag}/messages"]), d[f"rs/{tag}/codewords"], tag + " encode")
-        dec, nerr = R.decode(d[f"rs/{tag}/received"], d[f"rs/{tag}/erasures"])
-        H.assert_equal_ints(nerr, d[f"rs/{tag}/n_errors"], tag + " n_errors")
-        H.assert_equal_ints(dec, d[f"rs/{tag}/decoded"], tag + " decoded")
-        H.assert_equal_ints(R.detect(d[f"rs/{tag}/received"]), d[f"rs/{tag}/detected"], tag + " detect")
+        _check_oracle_rs(d, tag)
     F = O.OracleField(2, 8, 285, 2, lookup=True)
     R = O.OracleRS(F, 255, 223)
     H.assert_equal_ints(R.encode(np.arange(223))[223:], d["rs/kat_arange_parity"], "arange parity KAT")
@@ -168,16 +172,13 @@ _BCH_FROM_K = {"bch15_7", "bch31_16", "bch63_45", "bch63_36_short", "bch255_223"
                "bch26_14_gf3", "bch26_14_gf3_nonsys_short"}
 
 
-@pytest.mark.parametrize("tag", _BCH_CASES)
-def test_reference_bch_outputs(tag):
-    """Encode / detect / decode (errors, erasures, beyond-capacity words) against outputs of the reference itself."""
-    d = H.reference_bch_outputs()
+def _check_oracle_bch(d, tag, from_k):
     meta = json.loads(str(d[f"bch/{tag}/meta"]))
     p = meta["p"]
     ext = O.OracleField(p, meta["ext_m"], meta["ext_irr"], meta["ext_alpha"], lookup=True)
     B = O.OracleBCH(ext, meta["n"], meta["k"], d=meta["d"], alpha=meta["alpha"], c=meta["c"], systematic=meta["systematic"])
     assert B.d == meta["d"]
-    if tag in _BCH_FROM_K:  # the search for the largest design distance of that size (_bch.py:1200-1252)
+    if from_k:  # the search for the largest design distance of that size (_bch.py:1200-1252)
         Bk = O.OracleBCH(ext, meta["n"], meta["k"], alpha=meta["alpha"], c=meta["c"], systematic=meta["systematic"])
         assert (Bk.d, Bk.generator_poly) == (B.d, B.generator_poly)
     H.assert_equal_ints(B.generator_poly, d[f"bch/{tag}/generator_poly"])
@@ -194,6 +195,23 @@ def test_reference_bch_outputs(tag):
     assert np.array_equal(nerr[ok], d[f"bch/{tag}/n_errors"][ok])
     assert np.array_equal(dec[ok], d[f"bch/{tag}/decoded"][ok])
     assert np.array_equal(B.message_of(dec[ok]), d[f"bch/{tag}/decoded_message"][ok])
+
+
+@pytest.mark.parametrize("tag", _BCH_CASES)
+def test_reference_bch_outputs(tag):
+    """Encode / detect / decode (errors, erasures, beyond-capacity words) against outputs of the reference itself."""
+    _check_oracle_bch(H.reference_bch_outputs(), tag, tag in _BCH_FROM_K)
+
+
+@pytest.mark.parametrize("tag", H.WIDE_RS_CASES + H.WIDE_BCH_CASES)
+def test_reference_wide_code_outputs(tag):
+    """Codes whose syndrome field has more than 256 elements (RS over GF(2^10), GF(2^9), GF(3^6); BCH of length 511, 728,
+    1023): the oracle against outputs of the reference itself."""
+    d = H.reference_wide_codes()
+    if tag.startswith("rs"):
+        _check_oracle_rs(d, tag)
+    else:
+        _check_oracle_bch(d, tag, "_gf3" not in tag)
 
 
 # ---- field linear algebra (SURVEY.md section 8(f) item 2) against the Sage fixtures of tests/fields/test_linalg.py -----
