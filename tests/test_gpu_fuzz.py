@@ -1,4 +1,4 @@
-"""Short seeded runs of the differential fuzzers (tools/fuzz_codes.py, tools/fuzz_fields.py): random codes / fields / shapes
+"""Short seeded runs of the differential fuzzers (tools/fuzz_codes.py [wide], tools/fuzz_fields.py, tools/fuzz_ntt_linalg.py, tools/fuzz_conv_ntt3.py): random codes / fields / shapes
 against the oracle.  Longer campaigns: `python tools/fuzz_codes.py 600 <seed>`."""
 import os
 import subprocess
@@ -10,8 +10,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tool,seed", [("fuzz_codes.py", 7), ("fuzz_fields.py", 11), ("fuzz_ntt_linalg.py", 13)])
-def test_fuzz(tool, seed):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "8", str(seed)], capture_output=True, text=True, timeout=600)
+@pytest.mark.parametrize("tool,seed,extra", [("fuzz_codes.py", 7, []), ("fuzz_fields.py", 11, []), ("fuzz_ntt_linalg.py", 13, []),
+                                             ("fuzz_codes.py", 17, ["wide"]), ("fuzz_conv_ntt3.py", 19, [])])
+def test_fuzz(tool, seed, extra):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "8", str(seed)] + extra, capture_output=True, text=True,
+                       timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "identical to the oracle" in r.stdout

@@ -1,7 +1,7 @@
 """Differential fuzzing of the Reed-Solomon / BCH device paths against the oracle: random codes (field, n, k or d, c,
 systematic or not), random shortening, 0 .. t+3 errors and 0 .. d erasures per word.  Every decoded word, error count,
 detect flag and encoder output must match bit for bit (rows on which the reference would raise are checked to raise).
-Usage: python tools/fuzz_codes.py [seconds] [seed]"""
+Usage: python tools/fuzz_codes.py [seconds] [seed] [wide]   (wide: codes whose syndrome field has 512 .. 4096 elements)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,6 +11,7 @@ from oracle import gf_oracle as O
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+WIDE = len(sys.argv) > 3 and sys.argv[3] == "wide"
 rng = np.random.default_rng(seed)
 t_end = time.time() + budget
 n_codes = n_words = 0
@@ -28,12 +29,15 @@ def field(q):
 while time.time() < t_end:
     kind = rng.choice(["rs", "rs", "bch"])
     if kind == "rs":
-        q = int(rng.choice([8, 16, 32, 64, 128, 256, 256, 256, 27, 81, 125, 31, 251]))
+        q = int(rng.choice([512, 1024, 1024, 2048, 4096, 729, 343, 625, 2401, 257, 1009]) if WIDE else
+                rng.choice([8, 16, 32, 64, 128, 256, 256, 256, 27, 81, 125, 31, 251]))
         GF, F = field(q)
         divs = [d for d in range(3, q) if (q - 1) % d == 0]
         n = int(rng.choice(divs + [q - 1] * 3))
         k = int(rng.integers(1, n + 1))
-        if rng.random() < 0.5 and n > 8:  # favour parity lengths that take the LFSR / wave-kernel fast path
+        if WIDE:
+            k = n - int(rng.integers(0, min(n - 1, 120) + 1))
+        elif rng.random() < 0.5 and n > 8:  # favour parity lengths that take the LFSR / wave-kernel fast path
             nk = int(rng.choice([x for x in range(4, min(n - 1, 60) + 1, 4)] or [n - k]))
             k = n - nk
         c = int(rng.choice([0, 1, 1, 2, 5]))
@@ -44,8 +48,8 @@ while time.time() < t_end:
         base_p = 0
     else:
         p = int(rng.choice([2, 2, 2, 3, 5]))
-        m = int(rng.integers(2, {2: 9, 3: 6, 5: 4}[p]))
-        if p**m > 256:
+        m = int(rng.integers({2: 9, 3: 6, 5: 4}[p], {2: 13, 3: 8, 5: 6}[p])) if WIDE else int(rng.integers(2, {2: 9, 3: 6, 5: 4}[p]))
+        if (p**m > 256) != WIDE:
             continue
         n = p**m - 1
         dsg = int(rng.integers(2, min(n, 40)))
@@ -64,7 +68,7 @@ while time.time() < t_end:
     t = (d - 1) // 2
     shorten = int(rng.integers(0, k)) if rng.random() < 0.4 else 0
     ks, ns = k - shorten, n - shorten
-    N = int(rng.integers(1, 300))
+    N = int(rng.integers(1, 40 if WIDE else 300))
     M = rng.integers(0, p, (N, ks))
     C = code.encode(M).numpy().astype(np.int64)
     if oc is not None:
