@@ -286,6 +286,33 @@ def extras(ga, L, lib, stream, with_cpu):
                                      "sample": f"{reps} transforms of 2^{logn} points, oracle/gf_oracle.c"}
         ex[tag] = entry
         del xd, od
+    # ---- ONE long transform (three passes of the register kernel) and a long polynomial product that needs the CRT route ----
+    for tag, p, logn, dt, tdt in (("ntt_single_2^26_gf469762049", 469762049, 26, L.U32, torch.int32),
+                                  ("ntt_single_2^26_goldilocks", 2**64 - 2**32 + 1, 26, L.U64, torch.int64)):
+        P = ga.GF(p)
+        N = 1 << logn
+        xd = torch.empty(N, dtype=tdt, device="cuda").random_(0, min(p, 2**62))
+        od = torch.empty_like(xd)
+        L.check(lib.gfa_time_ntt(P._handle, xd.data_ptr(), od.data_ptr(), N, 1, P._root_of_unity_int(N), dt, stream, 5, ctypes.byref(ms)))
+        width = 4 if dt == L.U32 else 8
+        gbs = 2.0 * width * N / (ms.value * 1e-3) / 1e9
+        ex[tag] = {"ms": round(ms.value, 4), "points_per_s": round(N / (ms.value * 1e-3), 0), "algorithmic_GB/s": round(gbs, 1),
+                   "roofline_frac": round(gbs / HBM_PEAK_GBS, 4), "passes": 3}
+        del xd, od
+    M31 = ga.GF(2**31 - 1)
+    ca = M31(np.random.default_rng(8).integers(0, 2**31 - 1, 1 << 20, dtype=np.int64))
+    cb = M31(np.random.default_rng(9).integers(0, 2**31 - 1, 1 << 20, dtype=np.int64))
+    cc = np.convolve(ca, cb)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        cc = np.convolve(ca, cb)
+    torch.cuda.synchronize()
+    conv_ms = (time.perf_counter() - t1) / 5 * 1e3
+    assert int(cc[0]) == int(ca[0] * cb[0]) and int(cc[-1]) == int(ca[-1] * cb[-1])
+    ex["convolve_2^20x2^20_gf2147483647"] = {"ms": round(conv_ms, 3), "multiply_adds_equivalent_per_s": round(2.0**40 / (conv_ms * 1e-3), 0),
+                                            "route": "three 31-bit NTT primes + CRT inside gfa_convolve (no 2^21-th root of unity in the field)"}
+    del ca, cb, cc
     # ---- RS(255,223): 2^17 codewords per GPU (= 2^20 over 8 GPUs), e ~ U{0..16} errors per codeword ----
     rs = ga.ReedSolomon(255, 223)
     B = 1 << 17
@@ -322,7 +349,7 @@ def extras(ga, L, lib, stream, with_cpu):
         "decode_algorithmic_GB/s": round(486.0 * B / (dec_ms * 1e-3) / 1e9, 2),
         "encode_roofline_frac": round(478.0 * B / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
         "decode_roofline_frac": round(486.0 * B / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-        "note": "decode is VALU-issue bound (PMC: LDS busy 27 %), not HBM bound; see DESIGN.md section 4.1",
+        "note": "decode is LDS / VALU bound (PMC: LDS array 72 % busy after the Horner rewrite), not HBM bound; see DESIGN.md section 4.1",
     }
     # the two extremes benchmarks/test_fec.py uses: no errors, and t = 16 errors in every codeword
     Rd.copy_(Cd)
