@@ -236,3 +236,35 @@ def test_bch_valid_binary_codes():
         ga.BCH(15, 7, field=ga.GF(4))
     big = ga.BCH(511, d=11)  # syndrome field GF(2^9): properties only, no device path
     assert (big.k, big.extension_field.order) == (466, 512)
+
+
+def _build_c_host(tmp_path):
+    """gcc -std=c99 on examples/c_host_rs.c against include/galois_amd.h and the in-tree library: the boundary is usable
+    from a plain C host (no C++, no Python)."""
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("gcc / ROCm headers not available")
+    exe = str(tmp_path / "c_host_rs")
+    lib_dir = os.path.join(root, "galois_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(root, "include"), "-I/opt/rocm/include",
+           os.path.join(root, "examples", "c_host_rs.c"), "-L" + lib_dir, "-lgalois_amd", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_c_host_example_compiles_and_links(tmp_path):
+    assert os.path.exists(_build_c_host(tmp_path))
+
+
+@pytest.mark.gpu
+def test_c_host_example_runs(tmp_path):
+    import subprocess
+
+    r = subprocess.run([_build_c_host(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "round trip of 4096 codewords (16 errors each) OK" in r.stdout
