@@ -286,3 +286,37 @@ def test_convolve_crt_large_by_evaluation():
     # np.convolve's index 0 is the highest-degree coefficient of a Poly (degree-descending), as in Poly.__mul__
     pa, pb, pc = ga.Poly(a), ga.Poly(b), ga.Poly(c)
     assert np.array_equal(pc(pts).numpy(), (pa(pts) * pb(pts)).numpy())
+
+
+@pytest.mark.parametrize("order,logn", [(3221225473, 28), (2**64 - 2**32 + 1, 28), (3221225473, 29)])
+def test_three_pass_largest_sizes(order, logn):
+    """The largest single transforms of the three-pass path (tile offsets close to the kernel's 32-bit limit): inverse round
+    trip, X[0] = sum, and two outputs recomputed chunk by chunk with the power / multiply / reduce kernels."""
+    import torch
+
+    n = 1 << logn
+    GF = ga.GF(order)
+    g = torch.Generator(device="cuda").manual_seed(logn)
+    if order < 2**32:
+        t = torch.randint(0, 2**31, (n,), dtype=torch.int64, device="cuda", generator=g).to(torch.int32)  # < 2^31 < p
+        a = GF._wrap(t, np.uint32)
+    else:
+        a = GF._wrap(torch.randint(0, 2**62, (n,), dtype=torch.int64, device="cuda", generator=g), np.object_)
+    A = np.fft.fft(a)
+    back = np.fft.ifft(A)
+    assert bool(torch.equal(back._t, a._t))
+    del back
+    assert int(A[0]) == int(np.add.reduce(a))
+    omega = GF._root_of_unity_int(n)
+    chunk = 1 << 24
+    j = np.arange(chunk, dtype=np.int64)
+    for k in (1, n - 3):
+        wk = GF(omega) ** int(k)
+        col = GF(np.full(chunk, int(wk), dtype=np.int64 if order < 2**63 else object)) ** j
+        step = wk ** chunk
+        acc, scale = GF(0), GF(1)
+        for c in range(n // chunk):
+            part = np.add.reduce(a[c * chunk:(c + 1) * chunk] * col)
+            acc = acc + part * scale
+            scale = scale * step
+        assert int(A[k]) == int(acc), (order, logn, k)
