@@ -1,0 +1,19 @@
+"""The README's example, executed (kept in sync by hand)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, galois_amd as galois
+GF = galois.GF(2**8)
+x, y = GF.Random(10**8, seed=1), GF.Random(10**8, seed=2)
+z = x * y
+rs = galois.ReedSolomon(255, 223)
+c = rs.encode(GF.Random((1 << 17, 223)))
+m, n_err = rs.decode(c, errors=True)
+assert (n_err == 0).all()
+X = np.fft.fft(galois.GF(7340033).Random(1 << 20))
+Y = np.fft.fft(galois.GF(2**64 - 2**32 + 1).Random(1 << 26))
+P = galois.GF(2**31 - 1)
+c = np.convolve(P.Random(1 << 20), P.Random(1 << 20))
+bch = galois.BCH(1023, d=21)
+assert (bch.n, bch.k, bch.t) == (1023, 923, 10)
+A = galois.GF(251).Random((4096, 4096)); B = A @ np.linalg.inv(A)
+print("readme example OK", z.shape, X.shape, Y.shape, c.shape, bool((B == galois.GF(251).Identity(4096)).all()))
