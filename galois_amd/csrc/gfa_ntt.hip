@@ -904,6 +904,8 @@ int launch_reg_t(const FieldDev &fd, const void *in, void *out, const RegArgs &r
         // 64-bit elements: 16 lines per tile (128-byte global segments) in one 512-thread workgroup per CU, or 8 lines in
         // 256-thread workgroups, two per CU now that the unused quotient table is no longer reserved (GFA_NTT_T64=256)
         static const int t64 = env_int("GFA_NTT_T64", 256);
+        static const int split64 = env_int("GFA_NTT_SPLIT64", 1); // two-round exchange: half the LDS buffer, three workgroups per CU (Goldilocks 2^20 x 16: 0.283 -> 0.251 ms)
+        if (split64) return launch_reg_tt<F, TW, LOGR1, LOGR2, 256, true>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
         if (t64 == 512) return launch_reg_tt<F, TW, LOGR1, LOGR2, 512>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
         return launch_reg_tt<F, TW, LOGR1, LOGR2, 256>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
     } else {
