@@ -646,6 +646,12 @@ struct Plan {
     // generic path
     void *wpow = nullptr; // n entries
     std::vector<i64> factors;
+    struct Scratch *sc = nullptr; // work buffers of the (device, stream) this call runs on; set at lookup
+};
+
+// Work buffers (inter-pass intermediates, dtype conversion) are shared by every plan used on one (device, stream): they are
+// grow-only, so their size is the largest transform seen on that stream rather than the sum over all cached plans.
+struct Scratch {
     DevBuf ws0, ws1, cvt;
 };
 
@@ -660,6 +666,19 @@ struct PlanKey {
 
 std::mutex g_plan_mu;
 std::map<PlanKey, Plan *> g_plans;
+std::map<std::pair<int, hipStream_t>, Scratch *> g_scratch;
+
+// under g_plan_mu
+Plan *lookup_plan(const PlanKey &key, hipStream_t st)
+{
+    auto it = g_plans.find(key);
+    if (it == g_plans.end()) it = g_plans.emplace(key, new Plan()).first;
+    auto sk = std::make_pair(key.device, st);
+    auto is = g_scratch.find(sk);
+    if (is == g_scratch.end()) is = g_scratch.emplace(sk, new Scratch()).first;
+    it->second->sc = is->second;
+    return it->second;
+}
 
 template <class F>
 int build_pow_table(const FieldDev &fd, u64 base, u64 exp_stride, i64 count, void **out, hipStream_t st)
@@ -814,7 +833,7 @@ int run_pow2(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *o
     }
     const i64 n1 = (i64)1 << pl->log1, n2 = (i64)1 << pl->log2;
     int rc;
-    if ((rc = pl->ws0.ensure(sizeof(E) * (size_t)(n * batch)))) return rc;
+    if ((rc = pl->sc->ws0.ensure(sizeof(E) * (size_t)(n * batch)))) return rc;
     // pass 1: columns j2 (lines), position j1 with stride n2; output A[k1*n2 + j2] * w^(j2*k1)
     {
         TileArgs ta{};
@@ -825,7 +844,7 @@ int run_pow2(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *o
         ta.in_batch_stride = n; ta.out_batch_stride = n;
         ta.post_twiddle = 1; ta.lo_bits = pl->lo_bits; ta.n_mask = (u64)n - 1;
         ta.tw_in_lds = pl->log1 <= 12;
-        if ((rc = launch_tile<F, TW>(fd, false, false, in, pl->ws0.p, ta, batch, pl->w1, pl->w1q, pl->powA, pl->powB, st)))
+        if ((rc = launch_tile<F, TW>(fd, false, false, in, pl->sc->ws0.p, ta, batch, pl->w1, pl->w1q, pl->powA, pl->powB, st)))
             return rc;
     }
     // pass 2: rows k1 (lines), contiguous along j2; output X[k1 + n1*k2]
@@ -838,7 +857,7 @@ int run_pow2(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *o
         ta.in_batch_stride = n; ta.out_batch_stride = n;
         ta.do_scale = do_scale; ta.scale = scale;
         ta.tw_in_lds = pl->log2 <= 12;
-        if ((rc = launch_tile<F, TW>(fd, true, false, pl->ws0.p, out, ta, batch, pl->w2, pl->w2q, nullptr, nullptr, st)))
+        if ((rc = launch_tile<F, TW>(fd, true, false, pl->sc->ws0.p, out, ta, batch, pl->w2, pl->w2q, nullptr, nullptr, st)))
             return rc;
     }
     return GFA_OK;
@@ -1016,7 +1035,7 @@ int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n,
         if (sub < 1) sub = 1;
         if (sub > batch) sub = batch;
     }
-    if ((rc = pl->ws0.ensure(sizeof(E) * (size_t)(n * sub)))) return rc;
+    if ((rc = pl->sc->ws0.ensure(sizeof(E) * (size_t)(n * sub)))) return rc;
     for (i64 b0 = 0; b0 < batch; b0 += sub) {
         const i64 nb = std::min(sub, batch - b0);
         const E *src = (const E *)in + b0 * n;
@@ -1027,7 +1046,7 @@ int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n,
             ra.in_batch_stride = n; ra.out_batch_stride = n;
             ra.total_lines = n2;
             ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits; ra.n_mask = (u64)n - 1; ra.pinv = inverse_mod_2_32(fd.p);
-            if ((rc = launch_reg<F, TW>(fd, pl->log1, src, pl->ws0.p, ra, nb, pl->wl1, pl->wl1q, pl->powA, pl->powAq, pl->powB,
+            if ((rc = launch_reg<F, TW>(fd, pl->log1, src, pl->sc->ws0.p, ra, nb, pl->wl1, pl->wl1q, pl->powA, pl->powAq, pl->powB,
                                         pl->powBq, pl->powAm, st)))
                 return rc;
         }
@@ -1038,7 +1057,7 @@ int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n,
             ra.total_lines = n1;
             ra.load_along_line = 1; ra.store_along_line = 0;
             ra.do_scale = do_scale; ra.scale = scale; ra.scale_q = shoup_quotient<TW>(fd, scale);
-            if ((rc = launch_reg<F, TW>(fd, pl->log2, pl->ws0.p, dst, ra, nb, pl->wl2, pl->wl2q, nullptr, nullptr, nullptr,
+            if ((rc = launch_reg<F, TW>(fd, pl->log2, pl->sc->ws0.p, dst, ra, nb, pl->wl2, pl->wl2q, nullptr, nullptr, nullptr,
                                         nullptr, nullptr, st)))
                 return rc;
         }
@@ -1089,8 +1108,8 @@ int run_pow2_reg3(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n
             return rc;
         pl->reg3_ready = true;
     }
-    if ((rc = pl->ws0.ensure(sizeof(E) * (size_t)n))) return rc;
-    E *ws = (E *)pl->ws0.p;
+    if ((rc = pl->sc->ws0.ensure(sizeof(E) * (size_t)n))) return rc;
+    E *ws = (E *)pl->sc->ws0.p;
     for (i64 b = 0; b < batch; b++) {
         const E *src = (const E *)in + b * n;
         E *dst = (E *)out + b * n;
@@ -1144,8 +1163,8 @@ int run_generic(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n, 
         if (in != out) GFA_HIP(hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, st));
         return GFA_OK;
     }
-    if ((rc = pl->ws0.ensure(bytes))) return rc;
-    if ((rc = pl->ws1.ensure(bytes))) return rc;
+    if ((rc = pl->sc->ws0.ensure(bytes))) return rc;
+    if ((rc = pl->sc->ws1.ensure(bytes))) return rc;
     const E *src = (const E *)in;
     i64 m = 1;
     const int grid = (int)std::min<i64>((n * batch + 255) / 256, 256 * 16);
@@ -1153,7 +1172,7 @@ int run_generic(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n, 
         const i64 r = pl->factors[S - 1 - s];
         const i64 q = n / (m * r);
         const bool last = s == S - 1;
-        E *dst = last ? ((S == 1 && in == out) ? (E *)pl->ws0.p : (E *)out) : (E *)((s & 1) ? pl->ws1.p : pl->ws0.p);
+        E *dst = last ? ((S == 1 && in == out) ? (E *)pl->sc->ws0.p : (E *)out) : (E *)((s & 1) ? pl->sc->ws1.p : pl->sc->ws0.p);
         hipLaunchKernelGGL((ntt_stage_kernel<F>), dim3(grid), dim3(256), 0, st, fd, src, dst, n, r, m, q,
                            (const E *)pl->wpow, batch, (last && do_scale) ? 1 : 0, (E)scale);
         GFA_HIP(hipGetLastError());
@@ -1176,11 +1195,11 @@ int run_typed(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *
     void *eout = out;
     int rc;
     if (dtype != native) { // widen / narrow through a scratch buffer in the arithmetic's element type
-        if ((rc = pl->cvt.ensure(sizeof(E) * (size_t)(n * batch)))) return rc;
+        if ((rc = pl->sc->cvt.ensure(sizeof(E) * (size_t)(n * batch)))) return rc;
         const int grid = (int)std::min<i64>((n * batch + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL((convert_in_kernel<E>), dim3(grid), dim3(256), 0, st, in, dtype, (E *)pl->cvt.p, n * batch);
+        hipLaunchKernelGGL((convert_in_kernel<E>), dim3(grid), dim3(256), 0, st, in, dtype, (E *)pl->sc->cvt.p, n * batch);
         GFA_HIP(hipGetLastError());
-        ein = pl->cvt.p; eout = pl->cvt.p;
+        ein = pl->sc->cvt.p; eout = pl->sc->cvt.p;
     }
     constexpr bool prime_kind = std::is_same<F, Prime32>::value || std::is_same<F, Prime64>::value ||
                                 std::is_same<F, Goldilocks>::value;
@@ -1225,7 +1244,7 @@ int run_typed(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *
     if (!done && (rc = run_generic<F>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st))) return rc;
     if (dtype != native) {
         const int grid = (int)std::min<i64>((n * batch + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL((convert_out_kernel<E>), dim3(grid), dim3(256), 0, st, (const E *)pl->cvt.p, out, dtype, n * batch);
+        hipLaunchKernelGGL((convert_out_kernel<E>), dim3(grid), dim3(256), 0, st, (const E *)pl->sc->cvt.p, out, dtype, n * batch);
         GFA_HIP(hipGetLastError());
     }
     return GFA_OK;
@@ -1241,7 +1260,7 @@ void ntt_forget_field(const gfa_field *f)
         if (it->first.f == f) {
             Plan *pl = it->second;
             for (void *p : {pl->w1, pl->w1q, pl->w2, pl->w2q, pl->powA, pl->powB, pl->powAq, pl->powBq, pl->powAm, pl->wl1, pl->wl1q, pl->wl2,
-                            pl->wl2q, pl->wpow, pl->ws0.p, pl->ws1.p, pl->cvt.p, pl->wl0, pl->wl0q, pl->powA2, pl->powB2, pl->powA2q,
+                            pl->wl2q, pl->wpow, pl->wl0, pl->wl0q, pl->powA2, pl->powB2, pl->powA2q,
                             pl->powB2q, pl->powA2m})
                 if (p) (void)hipFree(p);
             delete pl;
@@ -1281,10 +1300,7 @@ int gfa_ntt(gfa_field_t *f, const void *in, void *out, int64_t n, int64_t batch,
     Plan *pl;
     {
         std::lock_guard<std::mutex> lock(g_plan_mu);
-        PlanKey key{f, dev, n, omega, lookup ? 1 : 0, 0};
-        auto it = g_plans.find(key);
-        if (it == g_plans.end()) it = g_plans.emplace(key, new Plan()).first;
-        pl = it->second;
+        pl = lookup_plan(PlanKey{f, dev, n, omega, lookup ? 1 : 0, 0}, st);
     }
     if (lookup) return run_typed<Lut>(f, f->lut_desc(*ds), pl, in, out, n, batch, omega, scale_by_n_inverse, scale, dtype, st);
     switch (c.kind) {
@@ -1315,10 +1331,7 @@ int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64
     Plan *pl;
     {
         std::lock_guard<std::mutex> lock(g_plan_mu);
-        PlanKey key{f, dev, n_total, omega, 0, n1};
-        auto it = g_plans.find(key);
-        if (it == g_plans.end()) it = g_plans.emplace(key, new Plan()).first;
-        pl = it->second;
+        pl = lookup_plan(PlanKey{f, dev, n_total, omega, 0, n1}, st);
     }
     auto run = [&](auto Ftag, auto TWtag) -> int {
         typedef decltype(Ftag) F;
