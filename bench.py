@@ -56,6 +56,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    if not os.path.exists(os.path.join(ROOT, "galois_amd", "libgalois_amd.so")):
+        # a checkout without build artefacts: build the product (rank 0 builds, the others wait at the barrier)
+        import subprocess
+
+        if rank == 0:
+            subprocess.run([sys.executable, os.path.join(ROOT, "galois_amd", "build.py")], check=True, stdout=sys.stderr)
+        if dist is not None:
+            dist.barrier()
     import galois_amd as ga
     from galois_amd import _lib as L
 
