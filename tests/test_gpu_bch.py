@@ -182,3 +182,31 @@ def test_front_end_errors():
         bch.decode(np.zeros(16, dtype=int))
     with pytest.raises(ValueError):
         ga.BCH(15, 7, systematic=False).encode(np.zeros(7, dtype=int), output="parity")
+
+
+@pytest.mark.parametrize("p,n,d,c", [(2, 4095, 3, 3), (3, 728, 2, 3), (2, 1023, 5, 1)])
+def test_wide_miscorrections_stay_out_of_field(p, n, d, c):
+    """Beyond-capacity words of codes with a large syndrome field: the Forney values of a miscorrection are arbitrary elements
+    of GF(p^m) (up to 4095 here), so the corrected symbol leaves GF(p) and the reference raises (_bch.py:1300).  The device
+    stores symbols as uint8: the out-of-field value must survive the narrowing (found by tools/fuzz_codes.py ... wide: a plain
+    truncation wrapped 1 in 128 of them back into range)."""
+    bch = ga.BCH(n, d=d, field=ga.GF(p), c=c)
+    ext = bch.extension_field
+    F = O.OracleField(p, ext.degree, int(ext.irreducible_poly), int(ext.primitive_element), lookup=True)
+    B = O.OracleBCH(F, n, d=d, alpha=bch.alpha, c=c)
+    rng = np.random.default_rng(n + d)
+    N = 600
+    C = bch.encode(rng.integers(0, p, (N, bch.k))).numpy().astype(np.int64)
+    R = C.copy()
+    for i in range(N):
+        pos = rng.choice(n, bch.t + 1 + int(rng.integers(0, 3)), replace=False)
+        R[i, pos] = (R[i, pos] + rng.integers(1, p, pos.size)) % p
+    odec, onerr = B.decode(R)
+    bad = ((odec < 0) | (odec >= p)).any(axis=1)
+    assert bad.sum() > 50
+    for i in np.nonzero(bad)[0]:
+        with pytest.raises(ValueError):
+            bch.decode(R[i])
+    ok = ~bad
+    dec, nerr = bch.decode(R[ok], output="codeword", errors=True)
+    assert np.array_equal(nerr, onerr[ok]) and np.array_equal(dec.numpy().astype(np.int64), odec[ok])
