@@ -1233,7 +1233,9 @@ int gfa_rs_describe(const gfa_rs_t *code, uint64_t *roots, uint64_t *generator_p
 int gfa_rs_encode(gfa_rs_t *code, const void *msg, int64_t ks, void *out, int64_t batch, int parity_only, int dtype,
                   gfa_stream_t stream)
 {
-    if (!code || !msg || !out || batch < 0 || ks < 1 || ks > code->k) { set_error("gfa_rs_encode: bad arguments"); return GFA_ERR_INVALID; }
+    if (!code || batch < 0 || ks < 1 || ks > code->k) { set_error("gfa_rs_encode: bad arguments"); return GFA_ERR_INVALID; }
+    if (batch == 0) return GFA_OK; // empty batches carry no buffers
+    if (!msg || !out) { set_error("gfa_rs_encode: bad arguments"); return GFA_ERR_INVALID; }
     if (rs_wide_code(code)) {
         int rcw = rs_wide_check(code, dtype, "gfa_rs_encode");
         if (rcw) return rcw;
@@ -1334,10 +1336,12 @@ static int launch_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasur
 int gfa_rs_detect(gfa_rs_t *code, const void *cw, int64_t ns, uint8_t *detected, int64_t batch, int dtype,
                   gfa_stream_t stream)
 {
-    if (!code || !cw || !detected || batch < 0 || ns < code->n - code->k + 1 || ns > code->n) {
+    if (!code || batch < 0 || ns < code->n - code->k + 1 || ns > code->n) {
         set_error("gfa_rs_detect: bad arguments");
         return GFA_ERR_INVALID;
     }
+    if (batch == 0) return GFA_OK;
+    if (!cw || !detected) { set_error("gfa_rs_detect: bad arguments"); return GFA_ERR_INVALID; }
     int rc = rs_wide_code(code) ? rs_wide_check(code, dtype, "gfa_rs_detect") : rs_check_device_path(code, dtype, "gfa_rs_detect");
     if (rc) return rc;
     if (batch == 0) return GFA_OK;
@@ -1361,10 +1365,12 @@ int gfa_rs_detect(gfa_rs_t *code, const void *cw, int64_t ns, uint8_t *detected,
 int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int64_t ns, void *out_codeword,
                   int64_t *out_n_errors, int64_t batch, int dtype, gfa_stream_t stream)
 {
-    if (!code || !recv || !out_codeword || !out_n_errors || batch < 0 || ns < code->n - code->k + 1 || ns > code->n) {
+    if (!code || batch < 0 || ns < code->n - code->k + 1 || ns > code->n) {
         set_error("gfa_rs_decode: bad arguments");
         return GFA_ERR_INVALID;
     }
+    if (batch == 0) return GFA_OK;
+    if (!recv || !out_codeword || !out_n_errors) { set_error("gfa_rs_decode: bad arguments"); return GFA_ERR_INVALID; }
     int rc = rs_wide_code(code) ? rs_wide_check(code, dtype, "gfa_rs_decode") : rs_check_device_path(code, dtype, "gfa_rs_decode");
     if (rc) return rc;
     if (batch == 0) return GFA_OK;
@@ -1437,10 +1443,12 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
 int gfa_rs_extract_message(gfa_rs_t *code, const void *cw, int64_t ns, void *out_msg, int64_t batch, int dtype,
                            gfa_stream_t stream)
 {
-    if (!code || !cw || !out_msg || batch < 0 || ns < code->n - code->k + 1 || ns > code->n) {
+    if (!code || batch < 0 || ns < code->n - code->k + 1 || ns > code->n) {
         set_error("gfa_rs_extract_message: bad arguments");
         return GFA_ERR_INVALID;
     }
+    if (batch == 0) return GFA_OK;
+    if (!cw || !out_msg) { set_error("gfa_rs_extract_message: bad arguments"); return GFA_ERR_INVALID; }
     int rc = rs_wide_code(code) ? rs_wide_check(code, dtype, "gfa_rs_extract_message") : rs_check_device_path(code, dtype, "gfa_rs_extract_message");
     if (rc) return rc;
     if (batch == 0) return GFA_OK;

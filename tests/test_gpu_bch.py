@@ -184,12 +184,12 @@ def test_front_end_errors():
         ga.BCH(15, 7, systematic=False).encode(np.zeros(7, dtype=int), output="parity")
 
 
-@pytest.mark.parametrize("p,n,d,c", [(2, 4095, 3, 3), (3, 728, 2, 3), (2, 1023, 5, 1)])
-def test_wide_miscorrections_stay_out_of_field(p, n, d, c):
+@pytest.mark.parametrize("p,n,d,c,nu", [(2, 4095, 3, 3, 0), (3, 728, 2, 3, 1), (2, 1023, 5, 1, 2), (2, 511, 3, 1, 2)])
+def test_wide_miscorrections_stay_out_of_field(p, n, d, c, nu):
     """Beyond-capacity words of codes with a large syndrome field: the Forney values of a miscorrection are arbitrary elements
     of GF(p^m) (up to 4095 here), so the corrected symbol leaves GF(p) and the reference raises (_bch.py:1300).  The device
     stores symbols as uint8: the out-of-field value must survive the narrowing (found by tools/fuzz_codes.py ... wide: a plain
-    truncation wrapped 1 in 128 of them back into range)."""
+    truncation wrapped about 1 in 100 of them back into range).  nu erasures per word on top of the errors."""
     bch = ga.BCH(n, d=d, field=ga.GF(p), c=c)
     ext = bch.extension_field
     F = O.OracleField(p, ext.degree, int(ext.irreducible_poly), int(ext.primitive_element), lookup=True)
@@ -198,15 +198,18 @@ def test_wide_miscorrections_stay_out_of_field(p, n, d, c):
     N = 600
     C = bch.encode(rng.integers(0, p, (N, bch.k))).numpy().astype(np.int64)
     R = C.copy()
+    E = np.zeros((N, n), dtype=bool)
     for i in range(N):
-        pos = rng.choice(n, bch.t + 1 + int(rng.integers(0, 3)), replace=False)
-        R[i, pos] = (R[i, pos] + rng.integers(1, p, pos.size)) % p
-    odec, onerr = B.decode(R)
+        pos = rng.choice(n, bch.t + 1 + int(rng.integers(0, 3)) + nu, replace=False)
+        err = pos[nu:]
+        R[i, err] = (R[i, err] + rng.integers(1, p, err.size)) % p
+        E[i, pos[:nu]] = True
+    odec, onerr = B.decode(R, E if nu else None)
     bad = ((odec < 0) | (odec >= p)).any(axis=1)
-    assert bad.sum() > 50
+    assert bad.sum() > 10, bad.sum()
     for i in np.nonzero(bad)[0]:
         with pytest.raises(ValueError):
-            bch.decode(R[i])
+            bch.decode(R[i], erasures=E[i] if nu else None)
     ok = ~bad
-    dec, nerr = bch.decode(R[ok], output="codeword", errors=True)
-    assert np.array_equal(nerr, onerr[ok]) and np.array_equal(dec.numpy().astype(np.int64), odec[ok])
+    dec, nerr = bch.decode(R[ok], erasures=E[ok] if nu else None, output="codeword", errors=True)  # possibly an empty batch
+    assert np.array_equal(nerr, onerr[ok]) and np.array_equal(dec.numpy().astype(np.int64).reshape(-1, n), odec[ok])
