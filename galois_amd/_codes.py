@@ -449,8 +449,9 @@ class BCH(_CyclicCode):
     def _verify_decoded(self, out: torch.Tensor):
         # dec_codeword.view(self.field) -> _verify_array_values (_bch.py:1300, _fields/_array.py:170-177): a miscorrection
         # whose Forney values fall outside GF(p) leaves symbols >= p in the decoder's integer output
-        if self._field.order < 256 and bool((out >= self._field.order).any()):
-            bad = out[out >= self._field.order]
+        wide = out if out.dtype == torch.uint8 else (out.to(torch.int64) & ((1 << (8 * out.element_size())) - 1))
+        if self._field.order < (1 << (8 * out.element_size())) and bool((wide >= self._field.order).any()):
+            bad = wide[wide >= self._field.order]
             raise ValueError(
                 f"{self._field.name} arrays must have elements in `0 <= x < {self._field.order}`, "
                 f"not {bad.cpu().numpy()}."
