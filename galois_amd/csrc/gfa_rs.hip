@@ -986,11 +986,16 @@ int set_lds_limit(K kern, bool *done)
 }
 
 int cu_count()
-{
+{ // cached per device: the property query is far slower than a kernel launch
+    static int cached[64] = {0};
     int d = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&d) != hipSuccess || hipGetDeviceProperties(&prop, d) != hipSuccess) return 256;
-    return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return 256;
+    if (!cached[d]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess) return 256;
+        cached[d] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cached[d];
 }
 
 

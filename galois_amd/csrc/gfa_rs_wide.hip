@@ -434,11 +434,15 @@ WideParams make_wide_params(const gfa_rs *code)
 
 int grid_for_waves(i64 batch, int nwaves, size_t lds_bytes = 0)
 {
-    int d = 0;
-    hipDeviceProp_t prop;
-    int cus = 256;
-    if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0)
-        cus = prop.multiProcessorCount;
+    static int cached[64] = {0};
+    int d = 0, cus = 256;
+    if (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64) {
+        if (!cached[d]) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, d) == hipSuccess && prop.multiProcessorCount > 0) cached[d] = prop.multiProcessorCount;
+        }
+        if (cached[d]) cus = cached[d];
+    }
     // persistent workgroups: as many as fit per CU (each one stages the tables once when they live in LDS)
     const i64 per_cu = lds_bytes > 20 * 1024 ? std::max<i64>(1, (i64)(160 * 1024 / lds_bytes)) : 8;
     return (int)std::max<i64>(1, std::min<i64>((batch + nwaves - 1) / nwaves, (i64)cus * per_cu));
