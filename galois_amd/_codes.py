@@ -183,12 +183,19 @@ class _CyclicCode:
         N, ns = t2.shape
         er_t = None
         if erasures is not None:
-            er = erasures.cpu().numpy() if isinstance(erasures, torch.Tensor) else np.asarray(erasures)
-            if er.dtype != bool:
-                raise TypeError(f"Argument 'erasures' must have dtype bool, not {er.dtype}.")
-            if er.shape != tuple(t.shape):
-                raise ValueError(f"Argument 'erasures' must have shape {tuple(t.shape)}, not {er.shape}.")
-            er_t = torch.from_numpy(np.ascontiguousarray(er.reshape(N, ns)).astype(np.uint8)).to(t2.device)
+            if isinstance(erasures, torch.Tensor):  # a mask that already lives on the device stays there
+                if erasures.dtype != torch.bool:
+                    raise TypeError(f"Argument 'erasures' must have dtype bool, not {erasures.dtype}.")
+                if tuple(erasures.shape) != tuple(t.shape):
+                    raise ValueError(f"Argument 'erasures' must have shape {tuple(t.shape)}, not {tuple(erasures.shape)}.")
+                er_t = erasures.to(t2.device).reshape(N, ns).to(torch.uint8).contiguous()
+            else:
+                er = np.asarray(erasures)
+                if er.dtype != bool:
+                    raise TypeError(f"Argument 'erasures' must have dtype bool, not {er.dtype}.")
+                if er.shape != tuple(t.shape):
+                    raise ValueError(f"Argument 'erasures' must have shape {tuple(t.shape)}, not {er.shape}.")
+                er_t = torch.from_numpy(np.ascontiguousarray(er.reshape(N, ns)).astype(np.uint8)).to(t2.device)
         out = torch.empty_like(t2)
         nerr = torch.empty(N, dtype=torch.int64, device=t2.device)
         L.check(L.lib().gfa_rs_decode(self._handle, _ptr(t2), _ptr(er_t) if er_t is not None else None, ns, _ptr(out),

@@ -276,3 +276,24 @@ def test_wide_limits():
         ga.ReedSolomon(1023, 523, field=GF).encode(np.zeros(523, dtype=np.int64))  # d - 1 = 500 roots: beyond the device path
     with pytest.raises((NotImplementedError, ValueError)):
         ga.ReedSolomon(2**21 - 1, 2**21 - 9, field=ga.GF(2**21)).encode(np.zeros(2**21 - 9, dtype=np.int64))
+
+
+def test_erasure_mask_as_device_tensor():
+    import torch
+
+    rs = ga.ReedSolomon(255, 223)
+    rng = np.random.default_rng(77)
+    C = rs.encode(rng.integers(0, 256, (64, 223))).numpy()
+    R = C.copy()
+    E = np.zeros(C.shape, dtype=bool)
+    for i in range(64):
+        epos = rng.choice(255, 20, replace=False)
+        E[i, epos] = True
+        R[i, epos] = rng.integers(0, 256, 20)
+    want = rs.decode(R, erasures=E, output="codeword")
+    got = rs.decode(R, erasures=torch.from_numpy(E).cuda(), output="codeword")
+    assert np.array_equal(got.numpy(), want.numpy()) and np.array_equal(got.numpy(), C)
+    with pytest.raises(TypeError):
+        rs.decode(R, erasures=torch.from_numpy(E.astype(np.uint8)).cuda())
+    with pytest.raises(ValueError):
+        rs.decode(R, erasures=torch.from_numpy(E[:, :10]).cuda())
