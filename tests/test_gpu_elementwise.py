@@ -377,3 +377,51 @@ def test_reduceat_and_at(order):
     np.subtract.at(x, [6], GF(vv[:1]))
     want[6] = F.sub([want[6]], [vv[0]])[0]
     assert np.array_equal(x.numpy().astype(np.uint64), want)
+
+
+def test_library_calls_are_graph_capturable():
+    """After a warm-up call (plans, tables and scratch exist) the hot-path entry points are plain kernel launches on the
+    caller's stream, so they can be captured into a HIP graph and replayed on new data."""
+    import torch
+
+    GF = ga.GF(2**8)
+    P = ga.GF(7340033)
+    rs = ga.ReedSolomon(255, 223)
+    rng = np.random.default_rng(21)
+    x, y = GF(rng.integers(0, 256, 1 << 20)), GF(rng.integers(1, 256, 1 << 20))
+    v = P(rng.integers(0, 7340033, (4, 1 << 12)))
+    m = GF(rng.integers(0, 256, (2048, 223)))
+    from galois_amd._ntt import fft_batched
+
+    def work():
+        z = x * y
+        w = z + x  # (division would not capture through the Python front end: its ZeroDivisionError check reads the device
+        #             error word back; the C-ABI call itself is capturable)
+        V = fft_batched(v)
+        c = rs.encode(m)
+        return z, w, V, c
+
+    work()  # warm-up: builds plans / uploads tables outside the capture
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        work()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            z, w, V, c = work()
+    # replay on NEW input data written into the captured buffers
+    x2, m2 = rng.integers(0, 256, 1 << 20), rng.integers(0, 256, (2048, 223))
+    v2 = rng.integers(0, 7340033, (4, 1 << 12))
+    x._t.copy_(torch.from_numpy(x2.astype(np.uint8)).cuda())
+    m._t.copy_(torch.from_numpy(m2.astype(np.uint8)).cuda())
+    v._t.copy_(torch.from_numpy(v2.astype(np.int32)).cuda())
+    g.replay()
+    torch.cuda.synchronize()
+    F = O.OracleField(2, 8, 285, 2, lookup=True)
+    assert np.array_equal(z.numpy(), F.ufunc_u8(O.MUL, x2.astype(np.uint8), y.numpy()))
+    assert np.array_equal(w.numpy(), z.numpy() ^ x2.astype(np.uint8))
+    FP = O.OracleField(7340033, 1, None, P._primitive_element_int)
+    assert np.array_equal(V.numpy()[1].astype(np.uint32), FP.ntt_u32_pow2(v2[1].astype(np.uint32), P._root_of_unity_int(1 << 12)))
+    assert np.array_equal(c.numpy(), O.OracleRS(F, 255, 223).encode_u8(m2.astype(np.uint8)))
