@@ -1025,6 +1025,17 @@ int launch_tab8_binary(const uint8_t *table, bool check_zero_b, const void *a, c
 int launch_tab8_unary(const uint8_t *table256, bool check_zero, const void *a, void *out, i64 n, hipStream_t st,
                       int32_t *err)
 {
+    // Arrays far beyond the Infinity Cache: statically strided persistent workgroups drift apart over a long launch and the
+    // DRAM page set spreads (section 4 of DESIGN.md); consecutive launches over 2^26-element slices keep them in step
+    // (reciprocal of 1e9 elements: 5.07 -> 5.27 TB/s, tools/unary_big.py).
+    static const i64 slice = [] { const char *e = getenv("GFA_TAB8_UNARY_SLICE"); return e ? (i64)atoll(e) : ((i64)1 << 26); }();
+    if (slice > 0 && n >= ((i64)1 << 28)) {
+        for (i64 o = 0; o < n; o += slice) {
+            const int rc = launch_tab8_unary(table256, check_zero, (const uint8_t *)a + o, (uint8_t *)out + o, std::min(slice, n - o), st, err);
+            if (rc) return rc;
+        }
+        return GFA_OK;
+    }
     i64 blocks = ((n >> 4) + TAB8_THREADS - 1) / TAB8_THREADS;
     i64 cap = (i64)num_cus() * 2;
     if (blocks < 1) blocks = 1;
