@@ -320,3 +320,31 @@ def test_three_pass_largest_sizes(order, logn):
             acc = acc + part * scale
             scale = scale * step
         assert int(A[k]) == int(acc), (order, logn, k)
+
+
+def test_distributed_transform_over_rccl_world_of_one():
+    """galois_amd.dist.ntt_four_step_distributed itself -- device kernels AND the RCCL all_to_all_single on device tensors --
+    in a process group of one rank (the box has one GPU; the N > 1 exchange layout is covered by the gloo tests)."""
+    import os
+    import torch
+    import torch.distributed as tdist
+    from galois_amd import dist as gdist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    tdist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for order, n1, n2 in [(2**64 - 2**32 + 1, 1 << 10, 1 << 12), (7340033, 1 << 8, 1 << 10)]:
+            GF = ga.GF(order)
+            n = n1 * n2
+            xs = (np.random.default_rng(n2).integers(0, 2**62, n, dtype=np.uint64) * np.uint64(5)) % np.uint64(order)
+            native = np.uint64 if order > 2**32 else np.uint32
+            local = torch.from_numpy(gdist.columns_to_local(xs.astype(native), 0, 1, n1, n2).view(np.int64 if native is np.uint64 else np.int32)).cuda()
+            out = gdist.ntt_four_step_distributed(GF, local, n1, n2)
+            full = gdist.local_to_natural([out.cpu().numpy().view(native)], n1, n2)
+            gx = GF._wrap(torch.from_numpy(xs.view(np.int64)).cuda(), np.object_) if order > 2**63 else GF(xs.astype(np.int64))
+            want = np.fft.fft(gx)
+            wv = want._t.cpu().numpy().view(np.uint64) if order > 2**63 else want.numpy().astype(np.uint64)
+            assert np.array_equal(full.astype(np.uint64), wv), order
+    finally:
+        tdist.destroy_process_group()
