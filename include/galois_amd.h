@@ -221,8 +221,12 @@ int gfa_rs_detect(gfa_rs_t *code, const void *cw, int64_t ns, uint8_t *detected,
                   gfa_stream_t stream);
 /* bch_decode_jit.implementation (_codes/_bch.py:1337-1578) via reed_solomon_decode_jit (_reed_solomon.py:1105-1113).
  * recv: (batch, ns) received words, index 0 = highest degree; erasures: (batch, ns) bytes (non-zero = erased) or NULL;
- * out_codeword: (batch, ns) corrected codewords (the received row unchanged where decoding fails);
- * out_n_errors: (batch) int64, number of corrected errors (not erasures), -1 on failure. */
+ * out_codeword: (batch, ns) corrected codewords (the received row unchanged where decoding fails); may alias recv
+ * (in-place decoding);
+ * out_n_errors: (batch) int64, number of corrected errors (not erasures), -1 on failure.
+ * BCH codes: a MIScorrected word can leave symbols outside GF(p) (the reference then raises on its field-membership check,
+ * _bch.py:1300); such symbols are stored as values >= p (saturated for the narrow storage types) so that the host can detect
+ * them with one comparison.  batch == 0 is accepted by every entry point of this section (no buffers are touched). */
 int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int64_t ns, void *out_codeword,
                   int64_t *out_n_errors, int64_t batch, int dtype, gfa_stream_t stream);
 
