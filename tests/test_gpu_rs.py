@@ -297,3 +297,29 @@ def test_erasure_mask_as_device_tensor():
         rs.decode(R, erasures=torch.from_numpy(E.astype(np.uint8)).cuda())
     with pytest.raises(ValueError):
         rs.decode(R, erasures=torch.from_numpy(E[:, :10]).cuda())
+
+
+def test_c_abi_decode_in_place_wide_field():
+    """The same aliasing contract on the table-driven path (uint16 symbols over GF(2^10)): the library decodes through a copy."""
+    import torch
+
+    from galois_amd import _lib as L
+
+    GF = ga.GF(2**10)
+    rs = ga.ReedSolomon(1023, 1003, field=GF)
+    rng = np.random.default_rng(78)
+    N = 200
+    C = rs.encode(rng.integers(0, 1024, (N, 1003))).numpy().astype(np.int64)
+    R = C.copy()
+    ne = rng.integers(0, 13, N)
+    for i in range(N):
+        pos = rng.choice(1023, ne[i], replace=False)
+        R[i, pos] = (R[i, pos] + rng.integers(1, 1024, ne[i])) % 1024
+    F = O.OracleField(2, 10, int(GF.irreducible_poly), GF._primitive_element_int, lookup=True)
+    want, wn = O.OracleRS(F, 1023, 1003, alpha=rs.alpha).decode(R)
+    buf = torch.from_numpy(R.astype(np.int16)).cuda()
+    nerr = torch.empty(N, dtype=torch.int64, device="cuda")
+    L.check(L.lib().gfa_rs_decode(rs._handle, buf.data_ptr(), None, 1023, buf.data_ptr(), nerr.data_ptr(), N, L.U16,
+                                  torch.cuda.current_stream().cuda_stream), "gfa_rs_decode")
+    assert np.array_equal(nerr.cpu().numpy(), wn)
+    assert np.array_equal(buf.cpu().numpy().astype(np.int64), want.astype(np.int64))
