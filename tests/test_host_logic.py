@@ -234,8 +234,35 @@ def test_bch_valid_binary_codes():
         ga.BCH(15, 8)
     with pytest.raises(ValueError):
         ga.BCH(15, 7, field=ga.GF(4))
-    big = ga.BCH(511, d=11)  # syndrome field GF(2^9): properties only, no device path
+    big = ga.BCH(511, d=11)  # syndrome field GF(2^9): served by the table-driven kernels (gfa_rs_wide.hip)
     assert (big.k, big.extension_field.order) == (466, 512)
+
+
+def test_wide_code_construction_against_the_reference():
+    """Codes whose syndrome field has more than 256 elements: k, d, roots and g(x) as the reference built them
+    (tests/golden/reference_wide_codes.npz), through both BCH constructors."""
+    import json
+
+    from tests import helpers as H
+
+    d = H.reference_wide_codes()
+    for tag in H.WIDE_RS_CASES:
+        meta = json.loads(str(d[f"rs/{tag}/meta"]))
+        GF = ga.GF(meta["p"], meta["m"], irreducible_poly=meta["irr"], primitive_element=meta["field_alpha"])
+        rs = ga.ReedSolomon(meta["n"], meta["k"], field=GF, c=meta["c"], alpha=meta["alpha"])
+        assert [int(v) for v in rs.generator_poly.coeffs] == [int(v) for v in d[f"rs/{tag}/generator_poly"]], tag
+        assert (rs.d, rs.t) == (meta["n"] - meta["k"] + 1, (meta["n"] - meta["k"]) // 2)
+    for tag in H.WIDE_BCH_CASES:
+        meta = json.loads(str(d[f"bch/{tag}/meta"]))
+        p = meta["p"]
+        ext = ga.GF(p, meta["ext_m"], irreducible_poly=meta["ext_irr"], primitive_element=meta["ext_alpha"])
+        kw = dict(field=ga.GF(p), extension_field=ext, alpha=meta["alpha"], c=meta["c"], systematic=meta["systematic"])
+        b = ga.BCH(meta["n"], meta["k"], d=meta["d"], **kw)
+        assert (b.k, b.d) == (meta["k"], meta["d"]), tag
+        assert [int(v) for v in b.generator_poly.coeffs] == [int(v) for v in d[f"bch/{tag}/generator_poly"]], tag
+        assert [int(v) for v in b.roots] == [int(v) for v in d[f"bch/{tag}/roots"]], tag
+        bd = ga.BCH(meta["n"], d=meta["d"], **kw)
+        assert (bd.k, [int(v) for v in bd.generator_poly.coeffs]) == (b.k, [int(v) for v in b.generator_poly.coeffs]), tag
 
 
 def _build_c_host(tmp_path):
