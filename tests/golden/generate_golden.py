@@ -24,6 +24,7 @@ import warnings
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT_DIR = os.environ.get("GOLDEN_OUT", HERE)  # tests regenerate into a scratch directory and compare
 ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
 sys.path.insert(0, os.path.join(ROOT, "oracle", "ref_shim"))
 REF_TESTS = "/root/reference/tests"
@@ -63,7 +64,7 @@ def pack_sage_fields():
             for k in ("X", "Y", "Z"):
                 out[f"convolve{i}_{k}"] = small(d[k][i])
         name = folder.replace("(", "_").replace(")", "").replace("^", "e").replace(", ", "_")
-        np.savez_compressed(os.path.join(HERE, f"sage_fields_{name}.npz"), **out)
+        np.savez_compressed(os.path.join(OUT_DIR, f"sage_fields_{name}.npz"), **out)
         print("packed", folder)
 
 
@@ -85,7 +86,7 @@ def pack_sage_linalg():
                 for i, v in enumerate(vals):
                     out[f"{op}{i}_{k}"] = small(np.asarray(v if not np.isscalar(v) else int(v)))
         name = folder.replace("(", "_").replace(")", "").replace("^", "e").replace(", ", "_")
-        np.savez_compressed(os.path.join(HERE, f"sage_linalg_{name}.npz"), **out)
+        np.savez_compressed(os.path.join(OUT_DIR, f"sage_linalg_{name}.npz"), **out)
         print("packed linalg", folder)
 
 
@@ -117,7 +118,7 @@ def pack_sage_polys():
             d = pickle.load(open(os.path.join(fpath, op + ".pkl"), "rb"))
             out[f"{op}_X"], out[f"{op}_Z"] = small(np.asarray(d["X"])), small(np.asarray(d["Z"]))
         name = folder.replace("(", "_").replace(")", "").replace("^", "e").replace(", ", "_")
-        np.savez_compressed(os.path.join(HERE, f"sage_polys_{name}.npz"), **out)
+        np.savez_compressed(os.path.join(OUT_DIR, f"sage_polys_{name}.npz"), **out)
         print("packed polys", folder)
 
 
@@ -139,7 +140,7 @@ def pack_sage_rs():
             out[f"{key}/short_messages"] = small(d["encode_shortened"]["messages"])
             out[f"{key}/short_codewords"] = small(d["encode_shortened"]["codewords"])
     out["names"] = np.array(json.dumps(names))
-    np.savez_compressed(os.path.join(HERE, "sage_rs.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "sage_rs.npz"), **out)
     print("packed", len(names), "RS fixtures")
 
 
@@ -340,7 +341,7 @@ def reference_outputs():
     GF = GFref(2**8, irreducible_poly=matlab)
     rs = galois.ReedSolomon(255, 223, field=GF)
     out["rs/kat_arange_parity"] = small(rs.encode(GF(np.arange(223)), output="parity"))
-    np.savez_compressed(os.path.join(HERE, "reference_outputs.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "reference_outputs.npz"), **out)
 
 
 def pack_sage_bch():
@@ -362,7 +363,7 @@ def pack_sage_bch():
             out[f"{key}/short_messages"] = small(d["encode_shortened"]["messages"])
             out[f"{key}/short_codewords"] = small(d["encode_shortened"]["codewords"])
     out["names"] = np.array(json.dumps(names))
-    np.savez_compressed(os.path.join(HERE, "sage_bch.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "sage_bch.npz"), **out)
     print("packed", len(names), "BCH fixtures")
 
 
@@ -390,7 +391,7 @@ def reference_bch_outputs():
     case("bch80_60_gf3", 80, d=9, p=3, N=10)
     case("bch24_gf5", 24, d=5, p=5)
     case("bch26_14_gf3_nonsys_short", 26, 14, p=3, systematic=False, shorten=5)
-    np.savez_compressed(os.path.join(HERE, "reference_bch_outputs.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "reference_bch_outputs.npz"), **out)
 
 
 def reference_wide_codes():
@@ -413,7 +414,7 @@ def reference_wide_codes():
     _bch_case(out, rng, galois, load_reference, "bch1023_973_short", 1023, 973, N=6, shorten=500)
     _bch_case(out, rng, galois, load_reference, "bch728_gf3", 728, d=7, p=3, N=8)
     _bch_case(out, rng, galois, load_reference, "bch511_484_nonsys", 511, 484, systematic=False, N=6)
-    np.savez_compressed(os.path.join(HERE, "reference_wide_codes.npz"), **out)
+    np.savez_compressed(os.path.join(OUT_DIR, "reference_wide_codes.npz"), **out)
 
 
 if __name__ == "__main__":
