@@ -27,6 +27,10 @@ int time_loop(hipStream_t st, int iters, float *ms_out, const std::function<int(
 
 void ntt_forget_field(const struct ::gfa_field *f); // drops cached NTT plans of a field being destroyed
 
+// 2^16-point transforms over GF(65537) in one pass over HBM (gfa_ntt_fermat.hip)
+bool ntt_fermat16_eligible(const FieldDev &fd, i64 n, i64 batch);
+int ntt_fermat16(const void *in, void *out, i64 batch, u64 omega, int negate, hipStream_t st);
+
 // discrete logarithms without tables (gfa_dlog.hip)
 void dlog_forget_field(const struct ::gfa_field *f);
 int dlog_run(struct ::gfa_field *f, const void *a, i64 sa, const void *base, i64 sb, int64_t *out, i64 n, int dtype, hipStream_t st,

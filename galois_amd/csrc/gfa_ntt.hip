@@ -1207,7 +1207,16 @@ int run_typed(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *
     if constexpr (prime_kind) if (is_pow2(n) && n >= 2) {
         int lg = 0;
         while (((i64)1 << lg) < n) lg++;
-        if (lg >= 2 && lg <= 2 * REG_MAX_LOG) {
+        if constexpr (std::is_same<F, Prime32>::value) {
+            // GF(65537), 2^16 points: whole transform in one workgroup's registers, shift twiddles (gfa_ntt_fermat.hip)
+            if (ntt_fermat16_eligible(fd, n, batch) && (!do_scale || scale == fd.p - 1)) {
+                rc = ntt_fermat16(ein, eout, batch, omega, do_scale ? 1 : 0, st);
+                if (rc && rc != GFA_ERR_UNSUPPORTED) return rc;
+                done = rc == GFA_OK;
+            }
+        }
+        if (done) {
+        } else if (lg >= 2 && lg <= 2 * REG_MAX_LOG) {
             if constexpr (std::is_same<F, Prime32>::value) {
                 if (fd.p < (1ull << 24) && ntt_wide_enabled()) rc = run_pow2_reg<F, TwShoupWide>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
                 else if (fd.p < (1ull << 30)) rc = run_pow2_reg<F, TwShoupLazy>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);

@@ -348,3 +348,47 @@ def test_distributed_transform_over_rccl_world_of_one():
             assert np.array_equal(full.astype(np.uint64), wv), order
     finally:
         tdist.destroy_process_group()
+
+
+def test_fermat_single_pass_kernel_gf65537():
+    """2^16-point transforms over GF(65537) in batches >= 64 run on the one-pass register kernel (gfa_ntt_fermat.hip):
+    random and worst-case inputs, several roots of unity (every odd power of w is another primitive root, which
+    exercises the input-order permutation), forward and scaled inverse, against the oracle and the two-pass kernel."""
+    import torch
+    from galois_amd import _lib as L
+
+    lib = L.lib()
+    GF = ga.GF(65537)
+    F = O.OracleField(65537, 1, None, 3)
+    n, batch = 65536, 64
+    rng = np.random.default_rng(16)
+    x = rng.integers(0, 65537, (batch, n), dtype=np.uint32)
+    x[0] = 65536                      # every element -1
+    x[1] = 0
+    x[2, ::2] = 65536; x[2, 1::2] = 0
+    x[3, ::2] = 0; x[3, 1::2] = 65536
+    x[4] = rng.choice(np.array([0, 1, 65535, 65536], dtype=np.uint32), n)
+    x[5, : n // 2] = 65536; x[5, n // 2:] = 1
+    xt = torch.from_numpy(x.view(np.int32)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    w = GF._root_of_unity_int(n)
+    for j in (1, 3, 65535, 12345, 40961):
+        wj = pow(w, j, 65537)
+        out = torch.empty_like(xt)
+        L.check(lib.gfa_ntt(GF._handle, xt.data_ptr(), out.data_ptr(), n, batch, wj, 0, L.U32, st))
+        got = out.cpu().numpy().view(np.uint32)
+        for i in (0, 1, 2, 3, 4, 5, 17, 63):
+            H.assert_equal_ints(got[i], F.ntt_u32_pow2(x[i], wj), f"root w^{j}, row {i}")
+        # every row against the two-pass kernel (batches below 64 take that path)
+        ref = torch.empty_like(xt)
+        for b0 in range(0, batch, 32):
+            L.check(lib.gfa_ntt(GF._handle, xt[b0:b0 + 32].data_ptr(), ref[b0:b0 + 32].data_ptr(), n, 32, wj, 0, L.U32, st))
+        assert torch.equal(out, ref), f"root w^{j}"
+        # scaled inverse with the inverse root, in place
+        winv = pow(wj, 65537 - 2, 65537)
+        L.check(lib.gfa_ntt(GF._handle, out.data_ptr(), out.data_ptr(), n, batch, winv, 1, L.U32, st))
+        assert torch.equal(out, xt), f"inverse, root w^{j}"
+    # through the array front end
+    X = fft_batched(GF(x))
+    H.assert_equal_ints(X.numpy()[9], F.ntt_u32_pow2(x[9], w))
+    assert np.array_equal(fft_batched(X, inverse=True).numpy(), x)
