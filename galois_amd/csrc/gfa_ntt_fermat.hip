@@ -17,6 +17,7 @@
 //   * the networks use the canonical roots (sqrt(2), 2).  A transform with root of unity w has w^(N/64) = sqrt(2)^u for
 //     one odd u; feeding network inputs in the order a' = u*a mod R turns the canonical network into the wanted one, and
 //     that permutation is folded into the global load addresses and the LDS write positions (no instructions).
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -71,86 +72,177 @@ struct FermatArgs {
     const int *tw1; // [64][1024]: balanced w^(m * k0)
     const int *tw2; // [32][32]:   balanced w^(64 * r * k1), index k1 * 32 + r
     int u, uinv;    // w^(N/64) == sqrt(2)^u, uinv = u^-1 mod 64
-    int negate;     // inverse transform of length 2^16: the scale 1/N == -1
+    int batch;
+    int stagger;    // first-round start offset between the four workgroup groups, in units of 4096 clocks (0: none)
+    unsigned long long *dbg; // optional phase timestamps (100 MHz), 8 per (workgroup, round); nullptr in production
 };
+#define FM_STAMP(i)                                     \
+    do {                                                \
+        if (DBG) ts[i] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 
+// final reduction of a network output |c| < 2^29 to the canonical [0, 65536] (NEGATE: of -c, the 1/N of the inverse):
+// adding a multiple of p first makes the value non-negative, the first fold then ends in [-2^14, 65535] and the second
+// in [0, 65536] -- no conditional step
+constexpr int FM_OFFSET = 65537 * 8192; // == 0 mod p, >= 2^29
+template <bool NEGATE>
+__device__ __forceinline__ u32 fm_canon(int c)
+{
+    c = NEGATE ? fm_sub(FM_OFFSET, c) : fm_add(c, FM_OFFSET);
+    return (u32)fm_fold(fm_fold(c));
+}
+
+// Workgroup barrier for LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL access (vmcnt(0)), which
+// would stall each exchange on the twiddle loads in flight, on the stores of the finished half and on the early loads of
+// the next transform.  LDS operations of a wave complete in order, so lgkmcnt(0) + s_barrier is all the exchange needs.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int AUX_NT = 2; // streaming (non-temporal) hint on the data loads / stores: keep the shared twiddle table in L2
+
+template <bool NEGATE, bool DBG>
 __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
 {
     extern __shared__ int lds[];
     int *ex = lds;
     int *tw2l = lds + EX_WORDS;
-    const int tid = threadIdx.x;
-    const u32 *x = a.in + (size_t)blockIdx.x * 65536u;
-    u32 *y = a.out + (size_t)blockIdx.x * 65536u;
+    const unsigned tid = threadIdx.x;
+    const int voff = (int)(tid * 4u);
+    const int g = (int)(tid >> 5), r = (int)(tid & 31);   // exchange 1 / network 1 coordinates
+    const int l = (int)(tid & 63), wv = (int)(tid >> 6);  // exchange 2 / network 2 coordinates
+    const int wpos1 = (((a.u * g) & 31) << 5) + r;        // exchange 1 write slot b' = u * b mod 32
+    const int wpos2 = ((a.u * r) & 31);                   // exchange 2 write slot r' = u * r mod 32
+    int *const e1w = ex + wpos1;
+    const int *const e1r = ex + g * 1024 + r;
+    int *const e2w = ex + g * E2_PITCH + wpos2;
+    const int *const e2r = ex + wv * (64 * E2_PITCH) + l * E2_PITCH;
+    const __amdgpu_buffer_rsrc_t tr = __builtin_amdgcn_make_buffer_rsrc((void *)a.tw1, 0, 65536 * 4, 0x00020000);
     tw2l[tid] = a.tw2[tid];
-
-    // ---- network 0: radix 64 over a (stride 1024); thread m = tid ----
+    // Workgroups are persistent (one per CU) and all run the same program, so without help every CU would read, compute
+    // and write at the same moments and HBM would idle while the chip computes.  The first round is staggered in four
+    // groups (each XCD holds all four): group j starts j * stagger later, and the offset persists from round to round.
+    if (a.stagger > 0) {
+        const int grp = (int)((blockIdx.x >> 3) & 3u);
+        for (int i = 0; i < grp * a.stagger; i++) __builtin_amdgcn_s_sleep(64);
+    }
+    // every global access is `buffer_* v, v_off, s[rsrc], s_off offen`: lane offset tid*4 in one VGPR, row offset in an
+    // SGPR, descriptors from kernel arguments and the (wave-uniform) transform index -- no vector address arithmetic
+    auto in_rsrc = [&](unsigned t) { return __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (size_t)t * 65536u), 0, 65536 * 4, 0x00020000); };
     int v[64];
-#pragma unroll
-    for (int ap = 0; ap < 64; ap++) v[ap] = (int)x[(((a.uinv * ap) & 63) << 10) + tid];
-    fermat_net64_canon(v);
     {
-        const int *t1 = a.tw1 + tid;
+        const __amdgpu_buffer_rsrc_t xr = in_rsrc(blockIdx.x);
 #pragma unroll
-        for (int k0 = 0; k0 < 64; k0++) {
-            int &r = v[brev_c(k0, 6)];
-            r = (k0 == 0) ? fm_fold(r) : fm_mul_tw(r, t1[k0 * 1024]);
-        }
+        for (int ap = 0; ap < 64; ap++) v[ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xr, voff, (int)((((unsigned)a.uinv * ap) & 63u) << 12), AUX_NT);
     }
-    // ---- exchange 1 + network 1: thread (g, r) takes k0 = g and g + 32, radix 32 over b (m = 32 b + r) ----
-    const int g = tid >> 5, r = tid & 31;
-    const int wpos1 = (((a.u * g) & 31) << 5) + r; // slot b' = u * b mod 32
-    int w[2][32];
+    for (unsigned tr_i = blockIdx.x; tr_i < (unsigned)a.batch; tr_i += gridDim.x) {
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (size_t)tr_i * 65536u), 0, 65536 * 4, 0x00020000);
+        const unsigned tr_next = tr_i + gridDim.x;
+        const bool has_next = tr_next < (unsigned)a.batch;
+        const __amdgpu_buffer_rsrc_t xn = in_rsrc(has_next ? tr_next : tr_i);
+        unsigned uinv = (unsigned)a.uinv;
+        asm volatile("" : "+s"(uinv)); // keep the 64 row offsets out of loop-invariant SGPRs (they are 3 scalar ops each)
+        unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // phase timestamps: scalar registers, written out once at the end
+        FM_STAMP(0);
+        // ---- network 0: radix 64 over a (stride 1024); thread m = tid.  Twiddles w^(m * k0), k0 = 1..63, come from the
+        // shared 256 KiB table (L2 resident): a rolling window of TWW values is requested ahead of its use so that the L2
+        // latency hides behind the network and the products themselves
+        constexpr int TWW = 32;
+        int tw[TWW];
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        if (h) __syncthreads();
+        for (int i = 0; i < TWW; i++) tw[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(tr, voff, (i + 1) * 4096, 0);
+        fermat_net64_canon(v);
+        FM_STAMP(1);
+        v[0] = fm_fold(v[0]);
+        auto tw1_range = [&](int lo, int hi) {
 #pragma unroll
-        for (int kl = 0; kl < 32; kl++) ex[kl * 1024 + wpos1] = v[brev_c(kl + 32 * h, 6)];
-        __syncthreads();
+            for (int k0 = lo; k0 < hi; k0++) {
+                int &q = v[brev_c(k0, 6)];
+                q = fm_mul_tw(q, tw[(k0 - 1) % TWW]);
+                if (k0 + TWW < 64) tw[(k0 - 1) % TWW] = (int)__builtin_amdgcn_raw_buffer_load_b32(tr, voff, (k0 + TWW) * 4096, 0);
+            }
+        };
+        tw1_range(1, 32);
+        FM_STAMP(2);
+        // ---- exchange 1 + network 1: thread (g, r) takes k0 = g and g + 32, radix 32 over b (m = 32 b + r).  Each LDS
+        // write burst is followed by arithmetic that does not depend on it, so the LDS pipe and the VALU overlap ----
+        int w[2][32];
+        lds_barrier(); // the previous transform's exchange-2 reads (first round: the staging of tw2l) are complete
 #pragma unroll
-        for (int bp = 0; bp < 32; bp++) w[h][bp] = ex[g * 1024 + bp * 32 + r];
-    }
+        for (int kl = 0; kl < 32; kl++) e1w[kl * 1024] = v[brev_c(kl, 6)];
+        tw1_range(32, 64);
+        lds_barrier();
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        fermat_net32_fold(w[h]);
+        for (int bp = 0; bp < 32; bp++) w[0][bp] = e1r[bp * 32];
+        lds_barrier();
 #pragma unroll
-        for (int k1 = 0; k1 < 32; k1++) {
-            int &q = w[h][brev_c(k1, 5)];
-            q = (k1 == 0) ? fm_fold(q) : fm_mul_tw(q, tw2l[k1 * 32 + r]);
-        }
-    }
-    // ---- exchange 2 + network 2: thread (lane l = k0, wave wv) takes k1 = wv and wv + 16, radix 32 over r ----
-    const int l = tid & 63, wv = tid >> 6;
-    const int wpos2 = ((a.u * r) & 31); // slot r' = u * r mod 32
-    int z[2][32];
+        for (int kl = 0; kl < 32; kl++) e1w[kl * 1024] = v[brev_c(kl + 32, 6)];
+        FM_STAMP(3);
+        auto net1 = [&](int h) {
+            fermat_net32_fold(w[h]);
+            w[h][0] = fm_fold(w[h][0]);
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        __syncthreads();
+            for (int k1 = 1; k1 < 32; k1++) {
+                int &q = w[h][brev_c(k1, 5)];
+                q = fm_mul_tw(q, tw2l[k1 * 32 + r]);
+            }
+        };
+        net1(0);
+        lds_barrier();
+#pragma unroll
+        for (int bp = 0; bp < 32; bp++) w[1][bp] = e1r[bp * 32];
+        net1(1);
+        FM_STAMP(4);
+        // ---- exchange 2 + network 2: thread (lane l = k0, wave wv) takes k1 = wv and wv + 16, radix 32 over r ----
+        int z[2][32];
+        lds_barrier();
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int kl = 0; kl < 16; kl++) ex[kl * (64 * E2_PITCH) + (g + 32 * i) * E2_PITCH + wpos2] = w[i][brev_c(kl + 16 * h, 5)];
-        __syncthreads();
+            for (int kl = 0; kl < 16; kl++) e2w[kl * (64 * E2_PITCH) + 32 * i * E2_PITCH] = w[i][brev_c(kl, 5)];
+        lds_barrier();
 #pragma unroll
-        for (int rp = 0; rp < 32; rp++) z[h][rp] = ex[wv * (64 * E2_PITCH) + l * E2_PITCH + rp];
-    }
+        for (int rp = 0; rp < 32; rp++) z[0][rp] = e2r[rp];
+        lds_barrier();
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        fermat_net32_fold(z[h]);
-        u32 *yo = y + l + 64 * (wv + 16 * h);
+        for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int k2 = 0; k2 < 32; k2++) {
-            int c = z[h][brev_c(k2, 5)];
-            if (a.negate) c = fm_sub(0, c);
-            c = fm_fold(fm_fold(c));                 // [-1, 65536]
-            yo[2048 * k2] = min((u32)c, 65536u);     // -1 == 65536
+            for (int kl = 0; kl < 16; kl++) e2w[kl * (64 * E2_PITCH) + 32 * i * E2_PITCH] = w[i][brev_c(kl + 16, 5)];
+        FM_STAMP(5);
+        auto net2 = [&](int h) {
+            fermat_net32_fold(z[h]);
+            // X[k0 + 64 * (k1 + 32 * k2)], k1 = wv + 16 h: lane offset tid
+#pragma unroll
+            for (int k2 = 0; k2 < 32; k2++)
+                __builtin_amdgcn_raw_buffer_store_b32(fm_canon<NEGATE>(z[h][brev_c(k2, 5)]), yr, voff, (2048 * k2 + 1024 * h) * 4, AUX_NT);
+        };
+        net2(0);
+        FM_STAMP(6);
+        // the next transform's first half is requested as soon as registers are free
+        if (has_next) {
+#pragma unroll
+            for (int ap = 0; ap < 32; ap++) v[ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xn, voff, (int)(((uinv * ap) & 63u) << 12), AUX_NT);
+        }
+        lds_barrier();
+#pragma unroll
+        for (int rp = 0; rp < 32; rp++) z[1][rp] = e2r[rp];
+        net2(1);
+        if (has_next) {
+#pragma unroll
+            for (int ap = 32; ap < 64; ap++) v[ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xn, voff, (int)(((uinv * ap) & 63u) << 12), AUX_NT);
+        }
+        FM_STAMP(7);
+        if (DBG && tid == 0) {
+            unsigned long long *d = a.dbg + ((size_t)(tr_i / gridDim.x) * gridDim.x + blockIdx.x) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) d[i] = ts[i];
         }
     }
 }
 
+unsigned long long *g_fermat_dbg = nullptr;
+
 struct FermatPlan {
     int *tw1 = nullptr, *tw2 = nullptr;
-    int u = 0, uinv = 0;
+    int u = 0, uinv = 0, cus = 256;
     bool ok = false;
 };
 std::mutex g_mu;
@@ -207,15 +299,28 @@ int ntt_fermat16(const void *in, void *out, i64 batch, u64 omega, int negate, hi
             GFA_HIP(hipMalloc((void **)&p.tw2, t2.size() * sizeof(int)));
             GFA_HIP(hipMemcpy(p.tw1, t1.data(), t1.size() * sizeof(int), hipMemcpyHostToDevice));
             GFA_HIP(hipMemcpy(p.tw2, t2.data(), t2.size() * sizeof(int), hipMemcpyHostToDevice));
-            p.u = u; p.uinv = uinv; p.ok = true;
-            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipDeviceProp_t prop;
+            GFA_HIP(hipGetDeviceProperties(&prop, dev));
+            p.u = u; p.uinv = uinv; p.cus = prop.multiProcessorCount; p.ok = true;
+            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         }
         pl = p;
     }
-    FermatArgs a{(const u32 *)in, (u32 *)out, pl.tw1, pl.tw2, pl.u, pl.uinv, negate};
-    hipLaunchKernelGGL(ntt_fermat16_kernel, dim3((unsigned)batch), dim3(1024), FERMAT_LDS_BYTES, st, a);
+    static const int stagger_env = [] { const char *e = getenv("GFA_NTT_FERMAT_STAGGER"); return e ? atoi(e) : 2; }();
+    static const int grid_env = [] { const char *e = getenv("GFA_NTT_FERMAT_GRID"); return e ? atoi(e) : 0; }();
+    const i64 grid = std::min<i64>(batch, grid_env > 0 ? grid_env : pl.cus);
+    // the stagger only pays when every group has later rounds to keep busy
+    FermatArgs a{(const u32 *)in, (u32 *)out, pl.tw1, pl.tw2, pl.u, pl.uinv, (int)batch, batch >= 2 * grid ? stagger_env : 0, g_fermat_dbg};
+    if (a.dbg && !negate) hipLaunchKernelGGL((ntt_fermat16_kernel<false, true>), dim3((unsigned)grid), dim3(1024), FERMAT_LDS_BYTES, st, a);
+    else if (negate) hipLaunchKernelGGL((ntt_fermat16_kernel<true, false>), dim3((unsigned)grid), dim3(1024), FERMAT_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((ntt_fermat16_kernel<false, false>), dim3((unsigned)grid), dim3(1024), FERMAT_LDS_BYTES, st, a);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }
+
+// tuning aid (tools/fermat_phases.py): device buffer of 8 timestamps per (round, workgroup), or nullptr to switch off
+extern "C" void gfa_debug_fermat_stamps(unsigned long long *buf) { g_fermat_dbg = buf; }
 
 } // namespace gfa
