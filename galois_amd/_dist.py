@@ -72,6 +72,16 @@ def _device_row_pass(field, rows: torch.Tensor, n2: int, omega_n2: int) -> torch
     return out
 
 
+def _device_column_pass_inv(field, local: torch.Tensor, n1: int, cols: int, col0: int, n_total: int, omega_inv: int,
+                            scaled: bool) -> torch.Tensor:
+    from ._array import _GFA_DTYPE, _ptr, _stream
+
+    out = torch.empty_like(local)
+    L.check(L.lib().gfa_ntt_columns_inv(field._handle, _ptr(local), _ptr(out), n1, cols, col0, n_total, omega_inv, 1 if scaled else 0,
+                                        _GFA_DTYPE[local.element_size()], _stream()), "gfa_ntt_columns_inv")
+    return out
+
+
 def choose_split(n_total: int, world: int) -> tuple[int, int]:
     """(n1, n2) with n1 * n2 == n_total for ntt_four_step_distributed.  The column pass runs strided transforms of length
     n1 and is fastest when n1 fits the register-blocked kernel (n1 <= 2^10); n2 = n_total / n1 may then be up to 2^20 (the
@@ -122,3 +132,44 @@ def ntt_four_step_distributed(field, local_cols: torch.Tensor, n1: int, n2: int,
     # (3) rows: X[k1 + n1*k2] = sum_j2 A[k1][j2] * w_n2^(j2*k2),  w_n2 = w^n1
     omega_n2 = field._scalar(L.OP_POW, omega, n1)
     return row_pass(field, mine, n2, omega_n2)
+
+
+def intt_four_step_distributed(field, local_rows: torch.Tensor, n1: int, n2: int, omega: int | None = None, group=None,
+                               scaled: bool = True, row_pass: Callable | None = None,
+                               column_pass_inv: Callable | None = None) -> torch.Tensor:
+    """
+    Inverse of `ntt_four_step_distributed` (ifft_jit semantics, reference _domains/_function.py:387-392): consumes the
+    (n1/G, n2) row-block layout that the forward transform produces (rank g holds X[k1 + n1*k2] at [k1 - g*n1/G][k2]) and
+    returns the (n1, n2/G) column-block layout it consumes -- so intt(ntt(x)) costs two exchanges in total and no
+    re-layout in between.  `omega` is the FORWARD root of unity (default: the field's); `scaled` divides by n1*n2.
+
+    Steps (the forward ones backwards, with w' = w^-1):
+      (1) local length-n2 transforms of the owned rows, root w'^n1                              [gfa_ntt, batched]
+      (2) ONE all-to-all that turns row blocks into column blocks                                [RCCL over xGMI]
+      (3) multiply (k1, c) by w'^(k1 * (col0 + c)), length-n1 transforms of the owned columns,
+          scale by 1/(n1*n2)                                                                     [gfa_ntt_columns_inv]
+    """
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_total = n1 * n2
+    cols = n2 // world
+    rows = n1 // world
+    if n2 % world or n1 % world:
+        raise ValueError("n1 and n2 must be divisible by the number of ranks")
+    if tuple(local_rows.shape) != (rows, n2):
+        raise ValueError(f"local_rows must have shape {(rows, n2)}, not {tuple(local_rows.shape)}")
+    if omega is None:
+        omega = field._root_of_unity_int(n_total)
+    omega_inv = field._scalar(L.OP_RECIP, omega, 0)
+    row_pass = row_pass or _device_row_pass
+    column_pass_inv = column_pass_inv or _device_column_pass_inv
+    # (1) rows: B[k1][o] = sum_k2 Y[k1][k2] * (w'^n1)^(k2*o)
+    b = row_pass(field, local_rows.contiguous(), n2, field._scalar(L.OP_POW, omega_inv, n1))
+    # (2) the one exchange: rank s receives columns [s*cols, (s+1)*cols) of every rank's row block
+    send = b.view(rows, world, cols).permute(1, 0, 2).contiguous()
+    recv = torch.empty((world, rows, cols), dtype=b.dtype, device=b.device)
+    dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)
+    # recv[s][k1_local][c] is row s*rows + k1_local of this rank's column block: already (n1, cols) row-major
+    return column_pass_inv(field, recv.view(n1, cols), n1, cols, rank * cols, n_total, omega_inv, scaled)

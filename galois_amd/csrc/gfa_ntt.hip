@@ -336,6 +336,7 @@ struct RegArgs {
     int tiles_per_batch;
     int load_along_line, store_along_line; // which index is contiguous in memory (runs fastest across lanes)
     int post_twiddle; // multiply output (line, k) by w_N^((line_offset + line) * k) = A[e >> lo_bits] * B[e & mask]
+    int pre_twiddle;  // multiply INPUT (line, t) by w_N^((line_offset + line) * t) before the transform (inverse four-step)
     int lo_bits;
     u64 n_mask;
     i64 line_offset;
@@ -469,6 +470,32 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fdk, const ty
             const u32 step = (u32)R2 * ist;
 #pragma unroll
             for (int a = 0; a < R1; a++) va[a] = *reinterpret_cast<const E *>(ginb + (off + (u32)a * step));
+            if (ra.pre_twiddle) {
+                // * w_N^(line * (r + R2*a)), a = 0..R1-1: the same per-thread geometric progression as the post-twiddle below
+                const u32 line = (u32)(ra.line_offset + line0 + cl);
+                const u32 nmask = (u32)ra.n_mask, lo_mask = (1u << ra.lo_bits) - 1;
+                const u32 e0 = (line * (u32)ra_) & nmask, es = (line * (u32)R2) & nmask;
+                if constexpr (has_redc<TW>()) {
+                    u32 tm = TW::mul(fd, powAm[e0 >> ra.lo_bits], TW::load(powB, powBq, e0 & lo_mask));
+                    const u32 sm = TW::canon(fd, TW::mul(fd, powAm[es >> ra.lo_bits], TW::load(powB, powBq, es & lo_mask)));
+                    const u32 pinv = (u32)ra.pinv;
+#pragma unroll
+                    for (int a = 0; a < R1; a++) {
+                        u32 x = TW::redc(fd, va[a], tm, pinv); // canonical input * t_a, in (0, 2p)
+                        if constexpr (!is_lazy<TW>()) x = TW::canon(fd, x);
+                        va[a] = x;
+                        if (a + 1 < R1) tm = TW::redc(fd, tm, sm, pinv);
+                    }
+                } else {
+                    E t = F::mul(fdk, powA[e0 >> ra.lo_bits], powB[e0 & lo_mask]);
+                    const E sr = F::mul(fdk, powA[es >> ra.lo_bits], powB[es & lo_mask]);
+#pragma unroll
+                    for (int a = 0; a < R1; a++) {
+                        va[a] = F::mul(fdk, va[a], t);
+                        if (a + 1 < R1) t = F::mul(fdk, t, sr);
+                    }
+                }
+            }
             reg_dif<F, TW, LOGR1>(fd, va, wL, wLq, R2); // w_R1 = w_L^R2
         }
         __syncthreads(); // middle-twiddle table staged
@@ -1322,8 +1349,8 @@ int gfa_ntt(gfa_field_t *f, const void *in, void *out, int64_t n, int64_t batch,
     }
 }
 
-int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64_t cols, int64_t col0, int64_t n_total,
-                    uint64_t omega, int dtype, gfa_stream_t stream)
+static int ntt_columns_impl(gfa_field_t *f, const void *in, void *out, int64_t n1, int64_t cols, int64_t col0, int64_t n_total,
+                            uint64_t omega, int dtype, gfa_stream_t stream, bool inverse_form, int scale_by_n_total_inverse)
 {
     if (!f || !in || !out || n1 < 2 || cols < 1 || col0 < 0 || n_total < n1 || (n_total % n1) != 0 || !is_pow2(n1) ||
         !is_pow2(n_total) || !is_pow2(cols)) {
@@ -1365,10 +1392,17 @@ int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64
             RegArgs ra{};
             ra.in_stride_c = 1; ra.in_stride_t = cols; ra.out_stride_c = 1; ra.out_stride_t = cols;
             ra.total_lines = cols;
-            ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits; ra.n_mask = (u64)n_total - 1; ra.line_offset = col0;
+            ra.post_twiddle = inverse_form ? 0 : 1; ra.pre_twiddle = inverse_form ? 1 : 0;
+            ra.lo_bits = pl->lo_bits; ra.n_mask = (u64)n_total - 1; ra.line_offset = col0;
             ra.pinv = inverse_mod_2_32(c.p);
+            if (scale_by_n_total_inverse) {
+                u64 sc = 1;
+                if (!HostArith::inv(c, (u64)n_total % c.p, &sc)) { set_error("gfa_ntt_columns_inv: n_total is not invertible in the field"); return GFA_ERR_INVALID; }
+                ra.do_scale = 1; ra.scale = sc; ra.scale_q = shoup_quotient<TW>(c, sc);
+            }
             return launch_reg<F, TW>(c, lg1, in, out, ra, 1, pl->wl1, pl->wl1q, pl->powA, pl->powAq, pl->powB, pl->powBq, pl->powAm, st);
         }
+        if (inverse_form) { set_error("gfa_ntt_columns_inv: n1 must be at most 2^10"); return GFA_ERR_UNSUPPORTED; }
         if (!pl->w1) {
             pl->log1 = lg1; pl->logn = lgn;
             if ((rc2 = build_pow_table<F>(c, omega, (u64)(n_total / n1), n1 / 2, &pl->w1, st))) return rc2;
@@ -1402,6 +1436,18 @@ int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64
     case KIND_GOLDILOCKS: return run(Goldilocks{}, Tw<Goldilocks>{});
     default: set_error("gfa_ntt_columns: prime fields only"); return GFA_ERR_UNSUPPORTED;
     }
+}
+
+int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64_t cols, int64_t col0, int64_t n_total,
+                    uint64_t omega, int dtype, gfa_stream_t stream)
+{
+    return ntt_columns_impl(f, in, out, n1, cols, col0, n_total, omega, dtype, stream, false, 0);
+}
+
+int gfa_ntt_columns_inv(gfa_field_t *f, const void *in, void *out, int64_t n1, int64_t cols, int64_t col0, int64_t n_total,
+                        uint64_t omega, int scale_by_n_total_inverse, int dtype, gfa_stream_t stream)
+{
+    return ntt_columns_impl(f, in, out, n1, cols, col0, n_total, omega, dtype, stream, true, scale_by_n_total_inverse);
 }
 
 int gfa_time_ntt(gfa_field_t *f, const void *in, void *out, int64_t n, int64_t batch, uint64_t omega, int dtype,

@@ -163,6 +163,15 @@ int gfa_ntt(gfa_field_t *f, const void *in, void *out, int64_t n, int64_t batch,
  * dtype must be the field's native device width (GFA_U32 for p < 2^32, GFA_U64 otherwise). */
 int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64_t cols, int64_t col0, int64_t n_total,
                     uint64_t omega, int dtype, gfa_stream_t stream);
+/* Per-rank LAST kernel of the distributed INVERSE transform (ifft_jit semantics, _domains/_function.py:387-392, spread
+ * over G GPUs).  The inverse runs the forward steps backwards: a plain batched gfa_ntt of length n2 (root omega^n1) on the
+ * rank's row block, the one all-to-all back to column blocks, then THIS call on the local (n1 x cols) array: element
+ * (k1, c) is first multiplied by omega^(k1 * (col0 + c)), then every column is transformed (length n1, root
+ * omega^(n_total/n1)), optionally scaled by (n_total mod p)^-1.  `omega` is the root of the inverse transform (w^-1 of
+ * the forward one).  Output: x[j1*n2 + col0 + c] at (j1, c) -- the column-block layout gfa_ntt_columns consumes.
+ * n1 <= 2^10; dtype as for gfa_ntt_columns. */
+int gfa_ntt_columns_inv(gfa_field_t *f, const void *in, void *out, int64_t n1, int64_t cols, int64_t col0, int64_t n_total,
+                        uint64_t omega, int scale_by_n_total_inverse, int dtype, gfa_stream_t stream);
 
 /* ---- Field linear algebra ------------------------------------------------------- *
  * gfa_matmul replaces matmul_jit.implementation `int64[:,:,:](int64[:,:,:], int64[:,:,:])` (_domains/_linalg.py:283-308)

@@ -55,14 +55,30 @@ def _worker(rank, world, port, order, n1, n2, q):
             out = np.stack([F.ntt(r.copy(), omega=om2) for r in a])
             return torch.from_numpy(out.view(np.int64))
 
+        def column_pass_inv(field, local, n1_, cols, col0, n_total, om_inv, scaled):
+            a = local.numpy().view(np.uint64).reshape(n1_, cols)
+            w_n1 = int(F.pow([om_inv], [n_total // n1_])[0])
+            ninv = pow(n_total % order, order - 2, order)
+            out = np.empty_like(a)
+            for c in range(cols):
+                tw = F.pow(np.full(n1_, om_inv, dtype=np.uint64), ((col0 + c) * np.arange(n1_)) % n_total)
+                col = F.ntt(F.mul(a[:, c].copy(), tw), omega=w_n1)
+                out[:, c] = F.mul(col, np.full(n1_, ninv, dtype=np.uint64)) if scaled else col
+            return torch.from_numpy(out.view(np.int64))
+
         local = torch.from_numpy(gdist.columns_to_local(x, rank, world, n1, n2).view(np.int64))
         mine = gdist.ntt_four_step_distributed(GF, local, n1, n2, omega=omega, column_pass=column_pass, row_pass=row_pass)
+        # the inverse consumes the row-block layout directly and returns the column-block layout: two exchanges in total
+        back = gdist.intt_four_step_distributed(GF, mine, n1, n2, omega=omega, row_pass=row_pass, column_pass_inv=column_pass_inv)
+        round_trip_ok = bool(torch.equal(back, local))
+        flags = [None] * world
+        dist.all_gather_object(flags, round_trip_ok)
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
         if rank == 0:
             full = gdist.local_to_natural([g.numpy().view(np.uint64) for g in gathered], n1, n2)
             want = F.ntt(x, omega=omega)
-            q.put(bool(np.array_equal(full, want)))
+            q.put(bool(np.array_equal(full, want)) and all(flags))
     finally:
         dist.destroy_process_group()
 

@@ -392,3 +392,96 @@ def test_fermat_single_pass_kernel_gf65537():
     X = fft_batched(GF(x))
     H.assert_equal_ints(X.numpy()[9], F.ntt_u32_pow2(x[9], w))
     assert np.array_equal(fft_batched(X, inverse=True).numpy(), x)
+
+
+def _emulate_forward(GF, xs_dev_cols, n1, n2, G, omega):
+    """G ranks' work of galois_amd.dist.ntt_four_step_distributed on one GPU (the all-to-all is a re-slicing)."""
+    from galois_amd import dist as gdist
+    from galois_amd import _lib as L
+    import torch
+
+    cols, rows = n2 // G, n1 // G
+    a_parts = [gdist._device_column_pass(GF, xs_dev_cols[g], n1, cols, g * cols, n1 * n2, omega) for g in range(G)]
+    omega_n2 = GF._scalar(L.OP_POW, omega, n1)
+    outs = []
+    for r in range(G):
+        mine = torch.cat([a_parts[s][r * rows:(r + 1) * rows, :] for s in range(G)], dim=1).contiguous()
+        outs.append(gdist._device_row_pass(GF, mine, n2, omega_n2))
+    return outs
+
+
+def _emulate_inverse(GF, row_blocks, n1, n2, G, omega):
+    """G ranks' work of galois_amd.dist.intt_four_step_distributed on one GPU."""
+    from galois_amd import dist as gdist
+    from galois_amd import _lib as L
+    import torch
+
+    cols, rows = n2 // G, n1 // G
+    omega_inv = GF._scalar(L.OP_RECIP, omega, 0)
+    w_rows = GF._scalar(L.OP_POW, omega_inv, n1)
+    b_parts = [gdist._device_row_pass(GF, row_blocks[g], n2, w_rows) for g in range(G)]
+    outs = []
+    for s in range(G):
+        mine = torch.cat([b_parts[g][:, s * cols:(s + 1) * cols] for g in range(G)], dim=0).contiguous()
+        outs.append(gdist._device_column_pass_inv(GF, mine, n1, cols, s * cols, n1 * n2, omega_inv, True))
+    return outs
+
+
+def test_distributed_inverse_emulated_on_one_gpu():
+    """intt_four_step_distributed's kernels (batched gfa_ntt + gfa_ntt_columns_inv) consume the forward transform's row-block
+    layout and return its column-block input bit for bit, for 32-bit (lazy / unreduced Shoup) and 64-bit fields."""
+    import torch
+    from galois_amd import dist as gdist
+
+    for order, n1, n2, G in [(7340033, 1 << 10, 1 << 8, 4), (2**64 - 2**32 + 1, 1 << 10, 1 << 6, 8), (65537, 1 << 6, 1 << 10, 2),
+                             (469762049, 1 << 9, 1 << 11, 2), (3221225473, 1 << 8, 1 << 6, 4)]:
+        GF = ga.GF(order)
+        n = n1 * n2
+        rng = np.random.default_rng(n2)
+        xs = (rng.integers(0, 2**62, n, dtype=np.uint64) * np.uint64(3)) % np.uint64(order)
+        xs[:4] = order - 1
+        native = np.uint64 if order > 2**32 else np.uint32
+        tview = np.int64 if native is np.uint64 else np.int32
+        omega = GF._root_of_unity_int(n)
+        locals_ = [torch.from_numpy(gdist.columns_to_local(xs.astype(native), g, G, n1, n2).view(tview)).cuda() for g in range(G)]
+        fwd = _emulate_forward(GF, locals_, n1, n2, G, omega)
+        back = _emulate_inverse(GF, fwd, n1, n2, G, omega)
+        for g in range(G):
+            assert torch.equal(back[g], locals_[g]), f"order {order}, rank {g}"
+
+
+def test_c5_full_size_emulated_on_one_gpu():
+    """BASELINE config C5 at its real size: 2^26 Goldilocks points split 1024 x 65536 over G = 8 ranks, every rank's kernels
+    run on this GPU with the exchange emulated, compared with the single-GPU three-pass transform (itself pinned by the
+    oracle at 2^21 / 2^23 and by the properties below), then inverted back through the distributed inverse."""
+    import torch
+    from galois_amd import dist as gdist
+
+    order = 2**64 - 2**32 + 1
+    GF = ga.GF(order)
+    n1, n2, G = 1 << 10, 1 << 16, 8
+    assert gdist.choose_split(1 << 26, G) == (n1, n2)
+    n = n1 * n2
+    x = torch.empty(n, dtype=torch.int64, device="cuda").random_(0, 2**62) * 3
+    # reduce into the field on the device: (x mod p) via the field's own add of zero is not needed -- values < 2^64 - 2^32 + 1
+    x = torch.where(x < 0, x + (2**32 - 1), x)  # bit patterns >= 2^63 are valid uint64 values; keep them below p
+    xu = x.cpu().numpy().view(np.uint64)
+    xu %= np.uint64(order)
+    x = torch.from_numpy(xu.view(np.int64)).cuda()
+    omega = GF._root_of_unity_int(n)
+    gx = GF._wrap(x, np.object_)
+    want = np.fft.fft(gx)._t  # single-GPU path
+    cols = n2 // G
+    xm = x.view(n1, n2)
+    locals_ = [xm[:, g * cols:(g + 1) * cols].contiguous() for g in range(G)]
+    fwd = _emulate_forward(GF, locals_, n1, n2, G, omega)
+    rows = n1 // G
+    wv = want.view(n2, n1)  # X[k1 + n1*k2] -> [k2][k1]
+    for g in range(G):
+        assert torch.equal(fwd[g], wv[:, g * rows:(g + 1) * rows].t().contiguous()), f"rank {g}"
+    # size-independent properties of the single-GPU reference itself: X[0] = sum x, X[N/2] = alternating sum
+    s = sum(int(v) for v in np.add.reduce(xu.reshape(-1, 1 << 10).astype(object), axis=1)) % order
+    assert int(want.cpu().numpy().view(np.uint64)[0]) == s
+    back = _emulate_inverse(GF, fwd, n1, n2, G, omega)
+    for g in range(G):
+        assert torch.equal(back[g], locals_[g]), f"inverse, rank {g}"
