@@ -41,6 +41,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-extras", action="store_true", help="skip the NTT / Reed-Solomon side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-extras", action="store_true",
+                    help="run the multi-GPU side measurements (sharded RS / NTT, distributed C5 transform) even at world size 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -48,13 +50,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("GFA_BENCH_SINGLE_DEVICE"):  # plumbing runs only: every rank on the one visible GPU
+        local_rank = int(os.environ["GFA_BENCH_SINGLE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.dist_extras:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29513")
+        backend = os.environ.get("GFA_BENCH_BACKEND", "nccl")  # "gloo": plumbing runs with several ranks on one GPU
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     if not os.path.exists(os.path.join(ROOT, "galois_amd", "libgalois_amd.so")):
         # a checkout without build artefacts: build the product (rank 0 builds, the others wait at the barrier)
@@ -187,11 +196,121 @@ def main():
             result["extra"]["cpu_baseline_all_cores"] = {"value": round(n * reps / dt / 1e9, 3), "unit": "Gop/s", "cores": cores,
                                                          "kind": "port", "sample": f"{reps} x 1e8 elements, one slice per thread"}
 
+    if dist is not None and not args.no_extras and (world > 1 or args.dist_extras):
+        # the other parts of the composite metric at N GPUs: every rank takes part, rank 0 reports
+        ex = extras_distributed(ga, L, lib, stream, dist, rank, world)
+        if rank == 0:
+            result.setdefault("extra", {}).update(ex)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extras_distributed(ga, L, lib, stream, dist, rank, world):
+    """BASELINE.json configs[3] and [4] and the batched NTTs at N GPUs: codewords and whole
+    transforms shard across ranks with no data-path collective; the single 2^26-point Goldilocks transform uses the
+    four-step split with ONE all-to-all.  Every figure is whole-job: units of all ranks / MAX over ranks of the time."""
+    from galois_amd import dist as gdist
+
+    ms = ctypes.c_float()
+
+    def job_ms(local_ms):
+        t = torch.tensor([local_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    ex = {}
+    # ---- RS(255,223): 2^20 codewords batch-sharded over the ranks, e ~ U{0..16} errors per codeword ----
+    rs = ga.ReedSolomon(255, 223)
+    total = 1 << 20
+    lo, hi = gdist.shard_range(total, rank, world)
+    B = hi - lo
+    rng = np.random.default_rng(4 + 1000 * rank)
+    M = rng.integers(0, 256, (B, 223), dtype=np.uint8)
+    Md = torch.from_numpy(M).cuda()
+    Cd = torch.empty((B, 255), dtype=torch.uint8, device="cuda")
+    dist.barrier()
+    L.check(lib.gfa_time_rs_encode(rs._handle, Md.data_ptr(), 223, Cd.data_ptr(), B, L.U8, stream, 5, ctypes.byref(ms)))
+    enc_ms = job_ms(ms.value)
+    # errors are planted on the device: ne[i] positions per codeword, distinct, non-zero values
+    g = torch.Generator(device="cuda").manual_seed(5 + rank)
+    ne = torch.randint(0, 17, (B,), device="cuda", generator=g)
+    order = torch.rand((B, 255), device="cuda", generator=g).argsort(dim=1)[:, :16]
+    vals = torch.randint(1, 256, (B, 16), device="cuda", generator=g, dtype=torch.int64).to(torch.uint8)
+    mask = torch.arange(16, device="cuda")[None, :] < ne[:, None]
+    Rd = Cd.clone()
+    rowsel = torch.arange(B, device="cuda")[:, None].expand(B, 16)
+    Rd[rowsel[mask], order[mask]] ^= vals[mask]
+    Dd = torch.empty_like(Rd)
+    Ed = torch.empty(B, dtype=torch.int64, device="cuda")
+    dist.barrier()
+    L.check(lib.gfa_time_rs_decode(rs._handle, Rd.data_ptr(), 255, Dd.data_ptr(), Ed.data_ptr(), B, L.U8, stream, 5, ctypes.byref(ms)))
+    dec_ms = job_ms(ms.value)
+    assert torch.equal(Dd, Cd) and torch.equal(Ed, ne), "RS round trip failed"
+    ex["rs_255_223_sharded"] = {
+        "codewords_total": total, "codewords_per_rank": B, "errors_per_codeword": "uniform 0..16",
+        "encode_GB/s": round(255.0 * total / (enc_ms * 1e-3) / 1e9, 2), "decode_GB/s": round(255.0 * total / (dec_ms * 1e-3) / 1e9, 2),
+        "encode+decode_GB/s": round(255.0 * total / ((enc_ms + dec_ms) * 1e-3) / 1e9, 2),
+        "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4), "collectives": "none (timing only)"}
+    del Md, Cd, Rd, Dd, Ed, order, vals, mask, rowsel
+    # ---- batched NTTs: whole transforms per rank ----
+    for tag, p, logn, batch in (("ntt_2^20_gf7340033_sharded", 7340033, 20, 64), ("ntt_16x2^16_gf65537_sharded", 65537, 16, 1024)):
+        P = ga.GF(p)
+        N = 1 << logn
+        xd = torch.from_numpy(np.random.default_rng(3 + rank).integers(0, p, (batch, N), dtype=np.uint32).view(np.int32)).cuda()
+        od = torch.empty_like(xd)
+        dist.barrier()
+        L.check(lib.gfa_time_ntt(P._handle, xd.data_ptr(), od.data_ptr(), N, batch, P._root_of_unity_int(N), L.U32, stream, 10, ctypes.byref(ms)))
+        t = job_ms(ms.value)
+        ex[tag] = {"transforms_per_s": round(world * batch / (t * 1e-3), 1), "batch_per_rank": batch, "ms_per_launch": round(t, 4),
+                   "2^20_points_per_s_equiv": round(world * batch * N / (1 << 20) / (t * 1e-3), 1),
+                   "roofline_frac_per_gpu": round(8.0 * batch * N / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "collectives": "none (timing only)"}
+        del xd, od
+    # ---- C5: ONE 2^26-point Goldilocks transform over all ranks: column pass, one all-to-all, row pass ----
+    p = 2**64 - 2**32 + 1
+    P = ga.GF(p)
+    N = 1 << 26
+    if world >= 2 and (world & (world - 1)) == 0 or world == 1:
+        n1, n2 = gdist.choose_split(N, world) if world > 1 else (1 << 10, 1 << 16)
+        cols = n2 // world
+        xl = torch.empty((n1, cols), dtype=torch.int64, device="cuda").random_(0, 2**62)  # < p: valid field elements
+        omega = P._root_of_unity_int(N)
+        fw, bw = {}, {}
+        X = gdist.ntt_four_step_distributed(P, xl, n1, n2, omega=omega)  # warm-up: plans, RCCL channels
+        back = gdist.intt_four_step_distributed(P, X, n1, n2, omega=omega)
+        assert torch.equal(back, xl), "distributed inverse(forward(x)) != x"
+        # X[0] = sum of all inputs: the one output that is cheap to recompute independently
+        part = int(np.add.reduce(P._wrap(xl.reshape(-1), np.object_)))
+        parts = [None] * world
+        dist.all_gather_object(parts, part)
+        if rank == 0:
+            assert int(X[0, 0].item()) % 2**64 == sum(parts) % p, "X[0] differs from the sum of the inputs"
+        for _ in range(5):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            X = gdist.ntt_four_step_distributed(P, xl, n1, n2, omega=omega, timings=fw)
+            torch.cuda.synchronize()
+            fw.setdefault("wall_ms", []).append((time.perf_counter() - t0) * 1e3)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gdist.intt_four_step_distributed(P, X, n1, n2, omega=omega, timings=bw)
+            torch.cuda.synchronize()
+            bw.setdefault("wall_ms", []).append((time.perf_counter() - t0) * 1e3)
+        entry = {"points": N, "split": f"{n1} x {n2}", "ranks": world, "bytes_per_peer_pair": 8 * (n1 // world) * cols}
+        for name, tm in (("forward", fw), ("inverse", bw)):
+            stages = {k: round(job_ms(float(np.median(v))), 4) for k, v in sorted(tm.items())}
+            kern = stages.get("column_pass_ms", 0) + stages.get("row_pass_ms", 0) + stages.get("relayout_ms", 0)
+            stages["kernels_ms"] = round(kern, 4)
+            stages["points_per_s"] = round(N / (stages["wall_ms"] * 1e-3), 0)
+            entry[name] = stages
+        entry["note"] = ("stage times are GPU events on the launch stream, max over ranks of the per-rank median; all_to_all_ms is the "
+                         "RCCL exchange over xGMI (at one rank: a device copy); wall_ms includes the Python launch overhead")
+        ex["c5_goldilocks_2^26_distributed"] = entry
+    return ex
 
 
 def extras(ga, L, lib, stream, with_cpu):

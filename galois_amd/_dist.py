@@ -98,8 +98,43 @@ def choose_split(n_total: int, world: int) -> tuple[int, int]:
     return n1, n2
 
 
+def _all_to_all(recv: torch.Tensor, send: torch.Tensor, group=None) -> None:
+    """The one collective of the path.  RCCL ("nccl" backend) moves device buffers directly over xGMI.  Under the gloo
+    backend (CPU test rigs, or several ranks sharing ONE GPU for plumbing runs -- RCCL refuses duplicate devices) device
+    tensors are staged through host memory; that route is for testing the N > 1 control flow, never for measurements."""
+    import torch.distributed as dist
+
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        r = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(r.view(-1), send.reshape(-1).cpu(), group=group)
+        recv.copy_(r)
+    else:
+        dist.all_to_all_single(recv.view(-1), send.reshape(-1), group=group)
+
+
+class _Stamps:
+    """Optional per-stage GPU timing (torch events on the current stream) for bench.py: stages in issue order."""
+
+    def __init__(self, sink: dict | None):
+        self.sink = sink
+        self.events = []
+
+    def mark(self, name: str):
+        if self.sink is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.events.append((name, e))
+
+    def finish(self):
+        if self.sink is not None and len(self.events) > 1:
+            self.events[-1][1].synchronize()
+            for (_, e0), (name, e1) in zip(self.events[:-1], self.events[1:]):
+                self.sink.setdefault(name, []).append(e0.elapsed_time(e1))
+
+
 def ntt_four_step_distributed(field, local_cols: torch.Tensor, n1: int, n2: int, omega: int | None = None, group=None,
-                              column_pass: Callable | None = None, row_pass: Callable | None = None) -> torch.Tensor:
+                              column_pass: Callable | None = None, row_pass: Callable | None = None,
+                              timings: dict | None = None) -> torch.Tensor:
     """
     One rank's part of a single length-(n1*n2) NTT over `field` spread over the ranks of `group`.
 
@@ -122,21 +157,29 @@ def ntt_four_step_distributed(field, local_cols: torch.Tensor, n1: int, n2: int,
         omega = field._root_of_unity_int(n_total)
     column_pass = column_pass or _device_column_pass
     row_pass = row_pass or _device_row_pass
+    st = _Stamps(timings)
+    st.mark("start")
     # (1) columns: A[k1][c] = w^((col0+c)*k1) * sum_j1 x[j1][c] * w_n1^(j1*k1)
     a = column_pass(field, local_cols.contiguous(), n1, cols, rank * cols, n_total, omega)
+    st.mark("column_pass_ms")
     # (2) the one exchange: rank r receives, from every rank s, rows [r*rows, (r+1)*rows) of s's column block
     recv = torch.empty((world, rows, cols), dtype=a.dtype, device=a.device)
-    dist.all_to_all_single(recv.view(-1), a.reshape(-1), group=group)
+    _all_to_all(recv, a, group)
+    st.mark("all_to_all_ms")
     # recv[s][k1_local][c] is column s*cols + c of row k1_local -> (rows, n2) row-major
     mine = recv.permute(1, 0, 2).reshape(rows, n2).contiguous()
+    st.mark("relayout_ms")
     # (3) rows: X[k1 + n1*k2] = sum_j2 A[k1][j2] * w_n2^(j2*k2),  w_n2 = w^n1
     omega_n2 = field._scalar(L.OP_POW, omega, n1)
-    return row_pass(field, mine, n2, omega_n2)
+    out = row_pass(field, mine, n2, omega_n2)
+    st.mark("row_pass_ms")
+    st.finish()
+    return out
 
 
 def intt_four_step_distributed(field, local_rows: torch.Tensor, n1: int, n2: int, omega: int | None = None, group=None,
                                scaled: bool = True, row_pass: Callable | None = None,
-                               column_pass_inv: Callable | None = None) -> torch.Tensor:
+                               column_pass_inv: Callable | None = None, timings: dict | None = None) -> torch.Tensor:
     """
     Inverse of `ntt_four_step_distributed` (ifft_jit semantics, reference _domains/_function.py:387-392): consumes the
     (n1/G, n2) row-block layout that the forward transform produces (rank g holds X[k1 + n1*k2] at [k1 - g*n1/G][k2]) and
@@ -165,11 +208,19 @@ def intt_four_step_distributed(field, local_rows: torch.Tensor, n1: int, n2: int
     omega_inv = field._scalar(L.OP_RECIP, omega, 0)
     row_pass = row_pass or _device_row_pass
     column_pass_inv = column_pass_inv or _device_column_pass_inv
+    st = _Stamps(timings)
+    st.mark("start")
     # (1) rows: B[k1][o] = sum_k2 Y[k1][k2] * (w'^n1)^(k2*o)
     b = row_pass(field, local_rows.contiguous(), n2, field._scalar(L.OP_POW, omega_inv, n1))
+    st.mark("row_pass_ms")
     # (2) the one exchange: rank s receives columns [s*cols, (s+1)*cols) of every rank's row block
     send = b.view(rows, world, cols).permute(1, 0, 2).contiguous()
+    st.mark("relayout_ms")
     recv = torch.empty((world, rows, cols), dtype=b.dtype, device=b.device)
-    dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)
+    _all_to_all(recv, send, group)
+    st.mark("all_to_all_ms")
     # recv[s][k1_local][c] is row s*rows + k1_local of this rank's column block: already (n1, cols) row-major
-    return column_pass_inv(field, recv.view(n1, cols), n1, cols, rank * cols, n_total, omega_inv, scaled)
+    out = column_pass_inv(field, recv.view(n1, cols), n1, cols, rank * cols, n_total, omega_inv, scaled)
+    st.mark("column_pass_ms")
+    st.finish()
+    return out
