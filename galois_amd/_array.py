@@ -285,10 +285,33 @@ class FieldArray(metaclass=FieldArrayMeta):
             else:
                 raise TypeError(f"{cls.name} arrays only support dtypes {[np.dtype(d).name for d in cls._dtypes]}, not {x.dtype}.")
         size = cls._itemsize(np_dtype)
-        if x.element_size() == size:
+        # Range check FIRST, on the tensor as given and in its own signedness (narrowing would wrap out-of-range values
+        # into the field, and comparing same-width signed storage with `order` wraps the scalar): work on the bit pattern
+        # viewed as the same-width signed type.
+        s_in = x.element_size()
+        unsigned_in = x.dtype in (torch.uint8, torch.uint16, torch.uint32, torch.uint64)
+        bits = x if x.dtype == torch.uint8 else x.view({1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[s_in])
+        if x.numel():
+            order, top, full = cls._order, 1 << (8 * s_in - 1), 1 << (8 * s_in)
+            if x.dtype == torch.uint8:
+                ok = True if order >= 256 else bool((bits < order).all().item())
+            elif not unsigned_in:
+                ok = bool((bits >= 0).all().item()) if order >= top else bool(((bits >= 0) & (bits < order)).all().item())
+            elif order >= full:
+                ok = True
+            elif order <= top:
+                ok = bool(((bits >= 0) & (bits < order)).all().item()) if order < top else bool((bits >= 0).all().item())
+            else:  # top < order < full: patterns with the high bit set are valid up to order - 1
+                ok = bool(((bits >= 0) | (bits < order - full)).all().item())
+            if not ok:
+                raise ValueError(f"{cls.name} arrays must have elements in `0 <= x < {cls._order}`.")
+        if s_in == size:
             t = x.view(_TORCH_STORAGE[size]) if x.dtype != _TORCH_STORAGE[size] else x
         else:
-            t = x.to(torch.int64).to(_TORCH_STORAGE[size])
+            wide = bits.to(torch.int64)
+            if unsigned_in and s_in < 8:
+                wide = wide & ((1 << (8 * s_in)) - 1)  # undo the sign extension of the same-width signed view
+            t = wide.to(_TORCH_STORAGE[size])
             copy = False
         if t.device.type != "cuda":
             t = t.to(_device())
@@ -297,19 +320,6 @@ class FieldArray(metaclass=FieldArrayMeta):
             t = t.clone()
         if not t.is_contiguous():
             t = t.contiguous()
-        if t.numel():
-            if size == 8 and cls._order > 2**63:
-                ok = True  # full uint64 range check below
-                u = t
-                hi = cls._order
-                # unsigned compare via bias
-                bias = torch.tensor(-(2**63), dtype=torch.int64, device=t.device)
-                ok = bool(((u + bias) < (hi - 2**63)).all().item()) if hi < 2**64 else True
-            else:
-                tt = t if t.dtype != torch.uint8 else t.to(torch.int16)
-                ok = bool(((tt >= 0) & (tt < cls._order)).all().item()) if cls._order <= 2**63 - 1 else bool((tt >= 0).all().item())
-            if not ok:
-                raise ValueError(f"{cls.name} arrays must have elements in `0 <= x < {cls._order}`.")
         return t, np.dtype(np_dtype)
 
     # ---- alternate constructors (_domains/_array.py:159-316) -----------------------------------------------
@@ -578,11 +588,21 @@ class FieldArray(metaclass=FieldArrayMeta):
         if int(err.item()) & L.DEVERR_ZERO_DIVISION:
             raise ZeroDivisionError("Cannot compute the multiplicative inverse of 0 in a Galois field.")
 
+    _out_target = None  # set by __array_ufunc__ while an element-wise call with `out=` runs
+
+    def _alloc_out(self, shape) -> torch.Tensor:
+        """Result buffer of an element-wise kernel: the caller's `out=` tensor when it fits, else a fresh one."""
+        tgt = FieldArray._out_target
+        if tgt is not None and tuple(tgt.shape) == tuple(shape) and tgt.dtype == self._t.dtype and tgt.device == self._t.device:
+            FieldArray._out_target = None
+            return tgt
+        return torch.empty(shape, dtype=self._t.dtype, device=self._t.device)
+
     def _binary(self, op: int, a: "FieldArray", b: "FieldArray") -> "FieldArray":
         cls = type(self)
         ta, tb = (a._t if a is self else self._same_storage(a)), (b._t if b is self else self._same_storage(b))
         ta, sa, tb, sb, shape = self._broadcast(ta, tb)
-        out = torch.empty(shape, dtype=self._t.dtype, device=self._t.device)
+        out = self._alloc_out(shape)
         n = out.numel()
         err = torch.zeros(1, dtype=torch.int32, device=self._t.device) if op == L.OP_DIV else None
         L.check(L.lib().gfa_binary(cls._handle, op, _ptr(ta), sa, _ptr(tb), sb, _ptr(out), n, self._gfa_dtype(), _stream(),
@@ -594,7 +614,7 @@ class FieldArray(metaclass=FieldArrayMeta):
     def _unary(self, op: int) -> "FieldArray":
         cls = type(self)
         t = self._t.contiguous()
-        out = torch.empty_like(t)
+        out = self._alloc_out(t.shape)
         err = torch.zeros(1, dtype=torch.int32, device=t.device) if op == L.OP_RECIP else None
         L.check(L.lib().gfa_unary(cls._handle, op, _ptr(t), _ptr(out), t.numel(), self._gfa_dtype(), _stream(),
                                   _ptr(err) if err is not None else None), "gfa_unary")
@@ -622,7 +642,7 @@ class FieldArray(metaclass=FieldArrayMeta):
         cls = type(self)
         tk = self._int_operand(k, "The exponent" if is_pow else "The integer multiplicand")
         ta, sa, tk, sk, shape = self._broadcast(self._t, tk)
-        out = torch.empty(shape, dtype=self._t.dtype, device=self._t.device)
+        out = self._alloc_out(shape)
         if is_pow:
             err = torch.zeros(1, dtype=torch.int32, device=self._t.device)
             L.check(L.lib().gfa_power(cls._handle, _ptr(ta), sa, _ptr(tk), sk, _ptr(out), out.numel(), self._gfa_dtype(),
@@ -756,12 +776,29 @@ class FieldArray(metaclass=FieldArrayMeta):
             target = out[0] if isinstance(out, tuple) else out
             if not (isinstance(out, tuple) and len(out) == 1 or isinstance(out, FieldArray)) or not isinstance(target, cls):
                 raise TypeError(f"Argument 'out' must be a {cls.name} array (or a 1-tuple holding one), not {type(target)}.")
-            result = self.__array_ufunc__(ufunc, method, *inputs, **kwargs)
+            # element-wise calls write straight into the caller's buffer (also when it aliases an input: out[i] depends on
+            # element i only); other methods, or a target of another width / layout, are computed and then stored
+            FieldArray._out_target = target._t if method == "__call__" and target._t.is_contiguous() else None
+            try:
+                result = self.__array_ufunc__(ufunc, method, *inputs, **kwargs)
+            finally:
+                FieldArray._out_target = None
             if not isinstance(result, cls) or tuple(result.shape) != tuple(target.shape):
                 raise ValueError(f"Argument 'out' has shape {tuple(target.shape)} but the result has shape "
                                  f"{tuple(getattr(result, 'shape', ()))}.")
-            target._t.copy_(_to_storage(result._t, target._t.dtype))
+            if result._t.data_ptr() != target._t.data_ptr():
+                target._t.copy_(_to_storage(result._t, target._t.dtype))
             return target
+        # keywords: `casting` is overridden by the reference itself ("unsafe", _ufunc.py:678-680) and `dtype` only names the
+        # intermediate type of a result that is cast back to the array's dtype (:686-687, :322-330) -- neither changes a
+        # value here.  `where` masks and reduction seeds are not implemented on the device: refuse rather than ignore.
+        for key in ("where", "initial"):
+            v = kwargs.get(key, None)
+            if v is not None and v is not True and v is not np._NoValue:
+                raise NotImplementedError(f"The {key!r} keyword of ufuncs is not supported on device-resident {cls.name} arrays.")
+        unknown = set(kwargs) - {"where", "initial", "casting", "dtype", "order", "subok", "axis", "keepdims", "signature"}
+        if unknown:
+            raise TypeError(f"Unsupported keyword argument(s) {sorted(unknown)} for ufunc {ufunc.__name__!r} on {cls.name} arrays.")
         operands = list(range(len(inputs)))
         field_ops = [i for i in operands if isinstance(inputs[i], cls)]
         non_field = [i for i in operands if not isinstance(inputs[i], cls)]
@@ -891,14 +928,151 @@ class FieldArray(metaclass=FieldArrayMeta):
             if kwargs.get("out") is not None:
                 raise NotImplementedError("The `out=` keyword is not supported for device-resident field arrays.")
             return getattr(_linalg, _LINALG_FUNCTIONS[func])(*args)
-        # anything else: plain NumPy on host copies (returns ndarrays, not field arrays)
-        def host(v):
+        # Reductions that NumPy implements through ufunc methods on the subclass (the reference reaches its field
+        # kernels through ndarray.__array_function__ -> add.reduce / multiply.reduce ..., _domains/_function.py:476)
+        x = args[0] if args else None
+        cls = type(self)
+
+        def kw(name, pos, default):
+            return args[pos] if len(args) > pos else kwargs.get(name, default)
+
+        def no_extra(*allowed):
+            bad = [k for k, v in kwargs.items() if k not in allowed and v is not None and v is not np._NoValue]
+            if bad:
+                raise NotImplementedError(f"Keyword(s) {bad} of np.{func.__name__} are not supported on device-resident {cls.name} arrays.")
+
+        if func in (np.sum, np.prod) and isinstance(x, cls):
+            no_extra("axis", "keepdims", "a")
+            op = L.OP_ADD if func is np.sum else L.OP_MUL
+            axis = kw("axis", 1, None)
+            keep = bool(kwargs.get("keepdims", False)) if kwargs.get("keepdims", False) is not np._NoValue else False
+            if axis is None:
+                r = x.reshape(-1)._reduce(op, 0, False)
+                return r.reshape((1,) * x.ndim) if keep else r
+            return x._reduce(op, axis, keep)
+        if func in (np.cumsum, np.cumprod) and isinstance(x, cls):
+            no_extra("axis", "a")
+            axis = kw("axis", 1, None)
+            op = L.OP_ADD if func is np.cumsum else L.OP_MUL
+            return x.reshape(-1)._accumulate(op, 0) if axis is None else x._accumulate(op, axis)
+        if func is np.trace and isinstance(x, cls):
+            no_extra("offset", "axis1", "axis2", "a")
+            d = torch.diagonal(x._t, offset=kw("offset", 1, 0), dim1=kw("axis1", 2, 0), dim2=kw("axis2", 3, 1))
+            return cls._wrap(d.contiguous(), x._np_dtype)._reduce(L.OP_ADD, -1, False)
+        if func is np.diff and isinstance(x, cls):
+            no_extra("n", "axis", "a")
+            n, axis = kw("n", 1, 1), kw("axis", 2, -1)
+            r = x
+            for _ in range(int(n)):
+                hi = cls._wrap(r._t.narrow(axis, 1, r._t.shape[axis] - 1).contiguous(), r._np_dtype)
+                lo = cls._wrap(r._t.narrow(axis, 0, r._t.shape[axis] - 1).contiguous(), r._np_dtype)
+                r = hi - lo
+            return r
+        # Pure data movement: done on the device tensors, result re-viewed as the field (the reference's
+        # _FUNCTIONS_REQUIRING_VIEW and the subclass-preserving ndarray functions)
+        def tens(v):
+            if isinstance(v, cls):
+                return v._t
             if isinstance(v, FieldArray):
-                return v.numpy()
-            if isinstance(v, (list, tuple)):
-                return type(v)(host(e) for e in v)
-            return v
-        return func(*[host(a) for a in args], **{k: host(v) for k, v in kwargs.items()})
+                raise TypeError(f"np.{func.__name__} cannot combine arrays over {type(v).name} and {cls.name}.")
+            return cls(v, dtype=self._np_dtype if self._np_dtype != np.dtype(object) else None)._t
+
+        def seq(v):
+            ts = [tens(e) for e in v]
+            dt = max((t.dtype for t in ts), key=lambda d: torch.empty((), dtype=d).element_size())
+            return [_to_storage(t, dt) for t in ts], dt
+
+        def wrap(t, like=None):
+            size = t.element_size()
+            cands = [np.dtype(object)] if cls._object_dtype else [np.dtype(d) for d in cls._dtypes]
+            np_dtype = self._np_dtype if cls._itemsize(self._np_dtype) == size else next(d for d in cands if cls._itemsize(d) == size)
+            return cls._wrap(t.contiguous(), np_dtype)
+
+        if func in (np.concatenate, np.stack, np.vstack, np.hstack, np.dstack, np.column_stack):
+            if kwargs.get("out") is not None:
+                raise NotImplementedError("The `out=` keyword is not supported for device-resident field arrays.")
+            ts, _ = seq(args[0])
+            if func is np.concatenate:
+                axis = kw("axis", 1, 0)
+                return wrap(torch.cat([t.reshape(-1) for t in ts]) if axis is None else torch.cat(ts, dim=axis))
+            if func is np.stack:
+                return wrap(torch.stack(ts, dim=kw("axis", 1, 0)))
+            f = {np.vstack: torch.vstack, np.hstack: torch.hstack, np.dstack: torch.dstack, np.column_stack: torch.column_stack}[func]
+            return wrap(f(ts))
+        if isinstance(x, cls):
+            t = x._t
+            if func is np.broadcast_to:
+                return wrap(t.broadcast_to(tuple(np.atleast_1d(kw("shape", 1, None)).tolist())))
+            if func is np.reshape:
+                return x.reshape(kw("shape", 1, None) if "newshape" not in kwargs else kwargs["newshape"])
+            if func is np.ravel:
+                return x.reshape(-1)
+            if func is np.transpose:
+                axes = kw("axes", 1, None)
+                return wrap(t.permute(*(reversed(range(t.dim())) if axes is None else axes)))
+            if func is np.swapaxes:
+                return wrap(t.transpose(args[1], args[2]))
+            if func is np.moveaxis:
+                return wrap(torch.movedim(t, args[1], args[2]))
+            if func is np.squeeze:
+                axis = kw("axis", 1, None)
+                return wrap(t.squeeze() if axis is None else t.squeeze(axis))
+            if func is np.expand_dims:
+                axis = kw("axis", 1, None)
+                for ax in sorted(np.atleast_1d(axis).tolist()):
+                    t = t.unsqueeze(ax)
+                return wrap(t)
+            if func is np.flip:
+                axis = kw("axis", 1, None)
+                return wrap(torch.flip(t, dims=list(range(t.dim())) if axis is None else np.atleast_1d(axis).tolist()))
+            if func is np.roll:
+                shift, axis = kw("shift", 1, None), kw("axis", 2, None)
+                return wrap(torch.roll(t.reshape(-1), int(shift)).reshape(t.shape) if axis is None
+                            else torch.roll(t, shifts=tuple(np.atleast_1d(shift).tolist()), dims=tuple(np.atleast_1d(axis).tolist())))
+            if func is np.tile:
+                reps = tuple(np.atleast_1d(kw("reps", 1, None)).tolist())
+                return wrap(t.reshape((1,) * (len(reps) - t.dim()) + tuple(t.shape)).repeat(*((1,) * (t.dim() - len(reps)) + reps)))
+            if func is np.repeat:
+                axis = kw("axis", 2, None)
+                return wrap(torch.repeat_interleave(t.reshape(-1) if axis is None else t, int(kw("repeats", 1, None)), dim=0 if axis is None else axis))
+            if func is np.copy:
+                return x.copy()
+            if func in (np.diag, np.diagonal):
+                k = kw("k", 1, 0) if func is np.diag else kw("offset", 1, 0)
+                if func is np.diag and t.dim() == 1:
+                    return wrap(torch.diag(t, k))
+                return wrap(torch.diagonal(t, offset=k, dim1=kw("axis1", 2, 0) if func is np.diagonal else 0,
+                                           dim2=kw("axis2", 3, 1) if func is np.diagonal else 1))
+            if func in (np.tril, np.triu):
+                return wrap((torch.tril if func is np.tril else torch.triu)(t, kw("k", 1, 0)))
+            if func is np.take:
+                idx = torch.as_tensor(np.asarray(kw("indices", 1, None)), device=t.device)
+                axis = kw("axis", 2, None)
+                return wrap(t.reshape(-1)[idx] if axis is None else torch.index_select(t, axis, idx.reshape(-1)).reshape(
+                    tuple(t.shape[:axis]) + tuple(idx.shape) + tuple(t.shape[axis + 1:])))
+            if func is np.array_equal:
+                o = args[1]
+                return bool(isinstance(o, cls) and tuple(o.shape) == tuple(x.shape) and (x == o).all()) if isinstance(o, FieldArray) \
+                    else bool(np.array_equal(x.numpy(), np.asarray(o)))
+            if func in (np.count_nonzero, np.any, np.all, np.nonzero, np.argwhere, np.flatnonzero):
+                return func(x.numpy() != 0, *args[1:], **kwargs)  # predicates on "element is zero": no field arithmetic involved
+            if func is np.shape:
+                return tuple(x.shape)
+            if func is np.ndim:
+                return x.ndim
+            if func is np.size:
+                return x.size if len(args) < 2 else x.shape[args[1]]
+        if func is np.where and len(args) == 3:
+            ts, _ = seq(args[1:])
+            cond = args[0].numpy() != 0 if isinstance(args[0], FieldArray) else np.asarray(args[0])
+            return wrap(torch.where(torch.as_tensor(cond, device=ts[0].device), ts[0], ts[1]))
+        # No silent host fallback: integer NumPy arithmetic on the elements would be WRONG in the field (the reference raises
+        # for its _UNSUPPORTED_FUNCTIONS, _domains/_function.py:405-461; everything it supports beyond the list above goes
+        # through ufuncs, which __array_ufunc__ serves)
+        raise NotImplementedError(
+            f"The NumPy function {func.__name__!r} is not supported on device-resident {cls.name} arrays. "
+            "If you'd like to perform this operation on the data, call `array.numpy()` first and then call the function."
+        )
 
     # ---- Python operators ---------------------------------------------------------------------------------
     def __add__(self, o): return np.add(self, o)

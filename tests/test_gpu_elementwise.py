@@ -431,3 +431,91 @@ def test_library_calls_are_graph_capturable():
     FP = O.OracleField(7340033, 1, None, P._primitive_element_int)
     assert np.array_equal(V.numpy()[1].astype(np.uint32), FP.ntt_u32_pow2(v2[1].astype(np.uint32), P._root_of_unity_int(1 << 12)))
     assert np.array_equal(c.numpy(), O.OracleRS(F, 255, 223).encode_u8(m2.astype(np.uint8)))
+
+
+def test_torch_adoption_range_checks_in_every_storage_width():
+    """Range checks happen on the tensor as given (its own width and signedness), before any narrowing: fields whose
+    2- or 4-byte storage needs the top bit, and out-of-field values that would wrap into the field."""
+    import torch
+
+    G16, G65521, G32, G8, G7 = ga.GF(2**16), ga.GF(65521), ga.GF(2**32), ga.GF(2**8), ga.GF(7)
+    a = G16(torch.tensor([5, 7, 65535, 32768], dtype=torch.uint16))
+    assert [int(v) for v in a.numpy()] == [5, 7, 65535, 32768]
+    assert [int(v) for v in (a * a).numpy()] == [int(v) for v in (G16([5, 7, 65535, 32768]) * G16([5, 7, 65535, 32768])).numpy()]
+    b = G65521(torch.tensor([5, 65520, 40000], dtype=torch.uint16))
+    assert [int(v) for v in (b + b).numpy()] == [10, 65519, 80000 - 65521]
+    with pytest.raises(ValueError):
+        G65521(torch.tensor([65521], dtype=torch.uint16))
+    c = G32(torch.tensor([5, 2**32 - 1, 2**31], dtype=torch.uint32))
+    assert [int(v) for v in c.numpy()] == [5, 2**32 - 1, 2**31]
+    with pytest.raises(ValueError):
+        G8(torch.tensor([261, 300]), dtype=np.uint8)  # would wrap to [5, 44]
+    with pytest.raises(ValueError):
+        G7(torch.tensor([6, -1], dtype=torch.int8))
+    with pytest.raises(ValueError):
+        G16(torch.tensor([65536], dtype=torch.int32))
+    assert int(G16(torch.tensor([65535], dtype=torch.int32))[0]) == 65535
+
+
+def test_out_keyword_writes_in_place_and_unsupported_keywords_raise():
+    GF = ga.GF(2**8)
+    x = GF.Random(1000, seed=1); y = GF.Random(1000, low=1, seed=2)
+    want = (x * y).numpy()
+    out = GF.Zeros(1000)
+    ptr = out.torch().data_ptr()
+    r = np.multiply(x, y, out=out)
+    assert r is out and out.torch().data_ptr() == ptr and np.array_equal(out.numpy(), want)
+    # aliasing an input (x *= y style) and the other element-wise kernels
+    x2 = x.copy(); p2 = x2.torch().data_ptr()
+    np.multiply(x2, y, out=x2)
+    assert x2.torch().data_ptr() == p2 and np.array_equal(x2.numpy(), want)
+    o2 = GF.Zeros(1000)
+    np.reciprocal(y, out=o2); assert np.array_equal(o2.numpy(), (y ** -1).numpy())
+    np.power(x, 3, out=o2); assert np.array_equal(o2.numpy(), (x * x * x).numpy())
+    np.divide(x, y, out=(o2,)); assert np.array_equal(o2.numpy(), (x / y).numpy())
+    # a wider target: computed, then stored
+    wide = GF.Zeros(1000, dtype=np.int32)
+    np.add(x, y, out=wide); assert wide.dtype == np.int32 and np.array_equal(wide.numpy(), (x + y).numpy())
+    with pytest.raises(ValueError):
+        np.add(x, y, out=GF.Zeros(999))
+    with pytest.raises(TypeError):
+        np.add(x, y, out=np.zeros(1000, dtype=np.uint8))
+    with pytest.raises(NotImplementedError):
+        np.add(x, y, where=np.arange(1000) % 2 == 0)
+    with pytest.raises(NotImplementedError):
+        np.add.reduce(x, initial=GF(3))
+    # casting= is overridden by the reference too, dtype= only names an intermediate type: accepted, no effect on values
+    assert np.array_equal(np.add(x, y, casting="safe").numpy(), (x + y).numpy())
+    assert np.array_equal(np.add(x, y, dtype=np.int64).numpy(), (x + y).numpy())
+
+
+def test_numpy_functions_stay_in_the_field_or_raise():
+    """np.sum / prod / cumsum / cumprod / trace / diff reach the device reductions (the reference gets there through
+    ndarray.__array_function__ -> ufunc methods); data-movement functions return field arrays; the rest raises."""
+    GF = ga.GF(7)
+    a = GF([3, 5, 6, 1])
+    assert int(np.sum(a)) == (3 + 5 + 6 + 1) % 7 and type(np.sum(a)) is GF
+    assert int(np.prod(a)) == (3 * 5 * 6 * 1) % 7
+    assert np.array_equal(np.cumsum(a).numpy(), np.cumsum([3, 5, 6, 1]) % 7)
+    assert np.array_equal(np.cumprod(a).numpy(), np.cumprod([3, 5, 6, 1]) % 7)
+    assert np.array_equal(np.diff(a).numpy(), np.diff([3, 5, 6, 1]) % 7)
+    m = GF(np.arange(12).reshape(3, 4) % 7)
+    assert np.array_equal(np.sum(m, axis=0).numpy(), (np.arange(12).reshape(3, 4) % 7).sum(axis=0) % 7)
+    assert np.array_equal(np.sum(m, axis=1, keepdims=True).numpy(), (np.arange(12).reshape(3, 4) % 7).sum(axis=1, keepdims=True) % 7)
+    sq = GF(np.arange(9).reshape(3, 3) % 7)
+    assert int(np.trace(sq)) == int(np.trace(np.arange(9).reshape(3, 3) % 7)) % 7
+    c = np.concatenate([a, a])
+    assert type(c) is GF and np.array_equal(c.numpy(), [3, 5, 6, 1, 3, 5, 6, 1])
+    assert type(np.stack([a, a])) is GF and np.stack([a, a]).shape == (2, 4)
+    assert type(np.broadcast_to(a, (2, 4))) is GF
+    assert np.array_equal(np.flip(a).numpy(), [1, 6, 5, 3]) and np.array_equal(np.roll(a, 1).numpy(), [1, 3, 5, 6])
+    assert np.array_equal(np.transpose(m).numpy(), (np.arange(12).reshape(3, 4) % 7).T)
+    assert type(np.reshape(m, (4, 3))) is GF and np.array_equal(np.tile(a, 2).numpy(), np.tile([3, 5, 6, 1], 2))
+    assert np.array_equal(np.where(np.array([True, False, True, False]), a, GF([0, 0, 0, 0])).numpy(), [3, 0, 6, 0])
+    assert np.array_equal(np.diag(sq).numpy(), np.diag(np.arange(9).reshape(3, 3) % 7))
+    assert np.count_nonzero(GF([0, 1, 0, 2])) == 2 and np.array_equal(a, GF([3, 5, 6, 1]))
+    with pytest.raises(TypeError):
+        np.concatenate([a, ga.GF(5)([1, 2])])
+    for f in (np.around, np.gradient, np.cross, np.median, np.mean, np.sort):
+        with pytest.raises(NotImplementedError):
+            f(a) if f is not np.cross else f(a, a)
