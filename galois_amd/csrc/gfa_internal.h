@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <deque>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -146,7 +147,7 @@ struct gfa_field {
     uint32_t zech_e = 0;
     std::vector<uint8_t> h_mul8, h_add8, h_sub8, h_div8, h_inv8, h_neg8, h_exp8, h_log8;
     std::mutex mu;
-    std::vector<gfa::FieldDeviceState> dev; // indexed by HIP device ordinal
+    std::deque<gfa::FieldDeviceState> dev; // indexed by HIP device ordinal; a deque: growing it keeps handed-out pointers valid
 
     // true if the lookup path is the one to launch for this field in its current mode
     bool use_lookup() const;
@@ -168,12 +169,10 @@ struct gfa_rs {
         uint8_t *roots8 = nullptr; // n-k
         uint8_t *g8 = nullptr;     // generator polynomial, highest degree first, n-k+1 coefficients
         uint32_t *lfsr = nullptr;  // 256 x (n-k)/4 words: rows f * (g_{nk-1} .. g_0) of the byte-wide LFSR (binary fields)
-        uint8_t *rem = nullptr;    // scratch: r(x) mod g(x) per codeword for the two-kernel decoder
-        size_t rem_bytes = 0;
         // codes over fields above 256 elements (gfa_rs_wide.hip): 32-bit copies instead of the byte arrays
         uint32_t *Pw = nullptr, *rootsw = nullptr, *gw = nullptr;
     };
     std::mutex mu;
-    std::vector<Dev> dev;
+    std::deque<Dev> dev; // a deque: growing it keeps handed-out pointers valid
     int ensure_device(int *device_out, Dev **out);
 };

@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "gfa_internal.h"
+#include "gfa_goldilocks.h"
 
 using namespace gfa;
 
@@ -383,6 +384,13 @@ inline bool ntt_wide_enabled()
     return v != 0;
 }
 
+inline bool ntt_goldi_enabled()
+{ // GFA_NTT_GL=0 selects the plain 64-bit modular arithmetic for Goldilocks (A/B measurements)
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("GFA_NTT_GL"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
+
 template <class TW, class = void>
 struct LazyTrait { static constexpr bool value = false; };
 template <class TW>
@@ -579,6 +587,155 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fdk, const ty
             const u32 step = (u32)R1 * ost;
 #pragma unroll
             for (int kr = 0; kr < R2; kr++) *reinterpret_cast<E *>(goutb + (off + (u32)kr * step)) = v[brev_c(kr, LOGR2)];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the same line transform for GF(2^64 - 2^32 + 1) on lazy 96-bit registers (gfa_goldilocks.h)
+// ------------------------------------------------------------------------------------------------
+// Identical data movement to ntt_reg_kernel (same RegArgs, tiles, LDS exchange); the arithmetic keeps every value as a
+// three-limb two's-complement integer: butterflies are 3 + 3 carry-chained instructions with no reduction, a twiddle
+// product is 4 v_mad_u64_u32 plus folds, and only what goes to LDS / memory is brought back to 64 bits.  The compiler's
+// lowering of the plain 64-bit modular add / sub / mul (Tw<Goldilocks>) spends 287 instructions per point and pass on
+// compare / select chains; this formulation needs about 130.
+struct TwGoldi : Tw<Goldilocks> {};
+#ifndef GFA_GL_WAVES
+#define GFA_GL_WAVES 3 // waves per SIMD the register allocation of the Goldilocks kernel is held to (168 VGPRs)
+#endif
+
+template <int LOGR>
+__device__ __forceinline__ void reg_dif_gl(gl::G3 (&v)[1 << LOGR], const u64 *__restrict__ w, int wstride)
+{ // v[bitrev(k)] <- sum_a v[a] * w_R^(a*k), w[j * wstride] = w_R^j (wave-uniform: scalar loads)
+    constexpr int R = 1 << LOGR;
+#pragma unroll
+    for (int s = LOGR - 1; s >= 0; s--) {
+        const int half = 1 << s;
+#pragma unroll
+        for (int b = 0; b < R; b += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; j++) {
+                const gl::G3 u = v[b + j], x = v[b + j + half];
+                v[b + j] = gl::add(u, x);
+                const int tj = j << (LOGR - 1 - s);
+                if (tj != 0) v[b + j + half] = gl::mul(gl::sub(u, x), w[tj * wstride]);
+                else v[b + j + half] = gl::sub(u, x);
+            }
+        }
+    }
+}
+
+template <int LOGR1, int LOGR2, int THREADS, bool SPLIT>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_GL_WAVES, GFA_GL_WAVES))) void ntt_reg_kernel_gl(FieldDev fdk, const u64 *__restrict__ in, u64 *__restrict__ out, RegArgs ra,
+                                                             const u64 *__restrict__ wL, const u64 *__restrict__ powA,
+                                                             const u64 *__restrict__ powB)
+{
+    typedef u64 E;
+    using gl::G3;
+    constexpr int R1 = 1 << LOGR1, R2 = 1 << LOGR2, L = R1 * R2;
+    constexpr int C = THREADS / R1;
+    constexpr int LOGC = __builtin_ctz(C);
+    constexpr int ROW = R2 + 1;
+    constexpr int RROWS = SPLIT ? R1 / 2 : R1;
+    constexpr int PC = RROWS * ROW + 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    E *data = reinterpret_cast<E *>(smem_raw); // C * PC
+    E *twl = data + C * PC;                     // L middle twiddles w_L^e
+    (void)fdk;
+    const int tid = threadIdx.x;
+    u32 vb = blockIdx.x;
+    if (ra.xcd_remap) vb = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const i64 batch = vb / ra.tiles_per_batch;
+    const i64 line0 = (i64)(vb % ra.tiles_per_batch) * C;
+    const E *gin = in + batch * ra.in_batch_stride + line0 * ra.in_stride_c;
+    E *gout = out + batch * ra.out_batch_stride + line0 * ra.out_stride_c;
+    const u32 isc = (u32)ra.in_stride_c * 8u, ist = (u32)ra.in_stride_t * 8u;
+    const u32 osc = (u32)ra.out_stride_c * 8u, ost = (u32)ra.out_stride_t * 8u;
+    const char *ginb = reinterpret_cast<const char *>(gin);
+    char *goutb = reinterpret_cast<char *>(gout);
+    for (int i = tid; i < L; i += THREADS) twl[i] = wL[i];
+    const bool active_a = tid < C * R2;
+    int ca, ra_;
+    if (ra.load_along_line) { ca = tid >> LOGR2; ra_ = tid & (R2 - 1); }
+    else { ra_ = tid >> LOGC; ca = tid & (C - 1); }
+    int c, ka;
+    if (ra.store_along_line) { c = tid >> LOGR1; ka = tid & (R1 - 1); }
+    else { ka = tid >> LOGC; c = tid & (C - 1); }
+    const u32 nmask = (u32)ra.n_mask, lo_mask = (1u << ra.lo_bits) - 1;
+    G3 v[R2];
+    {
+        G3 va[R1];
+        if (active_a) {
+            const i64 last = ra.total_lines - 1 - line0;
+            const u32 cl = (u32)((i64)ca <= last ? ca : last);
+            const u32 off = cl * isc + (u32)ra_ * ist;
+            const u32 step = (u32)R2 * ist;
+#pragma unroll
+            for (int a = 0; a < R1; a++) va[a] = gl::from_u64(*reinterpret_cast<const E *>(ginb + (off + (u32)a * step)));
+            if (ra.pre_twiddle) {
+                // * w_N^(line * (r + R2*a)): per-thread geometric progression, one table fetch for its start and its ratio
+                const u32 line = (u32)(ra.line_offset + line0 + cl);
+                const u32 e0 = (line * (u32)ra_) & nmask, es = (line * (u32)R2) & nmask;
+                u64 t = gl::to_u64(gl::mul_u64(powA[e0 >> ra.lo_bits], powB[e0 & lo_mask]));
+                const u64 sr = gl::to_u64(gl::mul_u64(powA[es >> ra.lo_bits], powB[es & lo_mask]));
+#pragma unroll
+                for (int a = 0; a < R1; a++) {
+                    va[a] = gl::from_u64(gl::to_u64(gl::mul_u64(gl::to_u64(va[a]), t))); // back to [0, 2^64): the network's input range
+                    if (a + 1 < R1) t = gl::to_u64(gl::mul_u64(t, sr));
+                }
+            }
+            reg_dif_gl<LOGR1>(va, wL, R2); // w_R1 = w_L^R2
+        }
+        __syncthreads(); // middle-twiddle table staged
+#pragma unroll
+        for (int h = 0; h < (SPLIT ? 2 : 1); h++) {
+            if (active_a) {
+                E *dst = data + ca * PC + ra_;
+                u32 idx = (u32)ra_ * (u32)(h * RROWS); // r * ka
+#pragma unroll
+                for (int kl = 0; kl < RROWS; kl++) {
+                    const int kaa = h * RROWS + kl;
+                    if (kaa == 0) dst[0] = gl::to_u64(va[0]);
+                    else dst[kl * ROW] = gl::to_u64(gl::mul(va[brev_c(kaa, LOGR1)], twl[idx]));
+                    idx += (u32)ra_;
+                }
+            }
+            __syncthreads();
+            if (!SPLIT || (ka / RROWS) == h) {
+                const E *srcl = data + c * PC + (ka - h * RROWS) * ROW;
+#pragma unroll
+                for (int r = 0; r < R2; r++) v[r] = gl::from_u64(srcl[r]);
+            }
+            if (SPLIT && h == 0) __syncthreads();
+        }
+    }
+    reg_dif_gl<LOGR2>(v, wL, R1); // w_R2 = w_L^R1
+    // results are reduced to the canonical [0, p) and stored one by one, so that the registers of v[] free up as they go
+    const bool live = line0 + c < ra.total_lines;
+    char *const obase = goutb + ((u32)c * osc + (u32)ka * ost);
+    const u32 ostep = (u32)R1 * ost;
+    if (ra.post_twiddle) {
+        const u32 line = (u32)(ra.line_offset + line0 + c);
+        const u32 e0 = (line * (u32)ka) & nmask, es = (line * (u32)R1) & nmask;
+        u64 t = gl::to_u64(gl::mul_u64(powA[e0 >> ra.lo_bits], powB[e0 & lo_mask]));
+        const u64 sr = gl::to_u64(gl::mul_u64(powA[es >> ra.lo_bits], powB[es & lo_mask]));
+#pragma unroll
+        for (int kr = 0; kr < R2; kr++) {
+            const u64 y = gl::canon(gl::mul(v[brev_c(kr, LOGR2)], t));
+            if (live) *reinterpret_cast<E *>(obase + (u32)kr * ostep) = y;
+            if (kr + 1 < R2) t = gl::to_u64(gl::mul_u64(t, sr));
+        }
+    } else if (ra.do_scale) {
+#pragma unroll
+        for (int kr = 0; kr < R2; kr++) {
+            const u64 y = gl::canon(gl::mul(v[brev_c(kr, LOGR2)], ra.scale));
+            if (live) *reinterpret_cast<E *>(obase + (u32)kr * ostep) = y;
+        }
+    } else {
+#pragma unroll
+        for (int kr = 0; kr < R2; kr++) {
+            const u64 y = gl::canon(v[brev_c(kr, LOGR2)]);
+            if (live) *reinterpret_cast<E *>(obase + (u32)kr * ostep) = y;
         }
     }
 }
@@ -921,15 +1078,26 @@ int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64
             return GFA_ERR_UNSUPPORTED;
         }
     }
-    auto kern = ntt_reg_kernel<F, TW, LOGR1, LOGR2, THREADS, SPLIT>;
-    static bool attr = false;
-    if (!attr) {
-        GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
     static const int lds_pad = env_int("GFA_NTT_LDS_PAD", 0); // occupancy experiments only
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds + (size_t)lds_pad, st, fd, (const E *)in, (E *)out, ra, (const E *)wl,
-                       (const E *)wlq, (const E *)pa, (const E *)paq, (const E *)pb, (const E *)pbq, (const E *)pam);
+    if constexpr (std::is_same<TW, TwGoldi>::value) {
+        auto kern = ntt_reg_kernel_gl<LOGR1, LOGR2, THREADS, SPLIT>;
+        static bool attr = false;
+        if (!attr) {
+            GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds + (size_t)lds_pad, st, fd, (const u64 *)in, (u64 *)out, ra, (const u64 *)wl,
+                           (const u64 *)pa, (const u64 *)pb);
+    } else {
+        auto kern = ntt_reg_kernel<F, TW, LOGR1, LOGR2, THREADS, SPLIT>;
+        static bool attr = false;
+        if (!attr) {
+            GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds + (size_t)lds_pad, st, fd, (const E *)in, (E *)out, ra, (const E *)wl,
+                           (const E *)wlq, (const E *)pa, (const E *)paq, (const E *)pb, (const E *)pbq, (const E *)pam);
+    }
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }
@@ -1249,6 +1417,9 @@ int run_typed(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *
                 else if (fd.p < (1ull << 30)) rc = run_pow2_reg<F, TwShoupLazy>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
                 else if (fd.p < (1ull << 31)) rc = run_pow2_reg<F, TwShoup32>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
                 else rc = run_pow2_reg<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+            } else if constexpr (std::is_same<F, Goldilocks>::value) {
+                if (ntt_goldi_enabled()) rc = run_pow2_reg<F, TwGoldi>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+                else rc = run_pow2_reg<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
             } else {
                 rc = run_pow2_reg<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
             }
@@ -1259,6 +1430,9 @@ int run_typed(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *
                 // (no prime below 2^24 has 2^21 | p - 1, so the unreduced 24-bit butterflies never apply here)
                 if (fd.p < (1ull << 30)) rc = run_pow2_reg3<F, TwShoupLazy>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
                 else if (fd.p < (1ull << 31)) rc = run_pow2_reg3<F, TwShoup32>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+                else rc = run_pow2_reg3<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+            } else if constexpr (std::is_same<F, Goldilocks>::value) {
+                if (ntt_goldi_enabled()) rc = run_pow2_reg3<F, TwGoldi>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
                 else rc = run_pow2_reg3<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
             } else {
                 rc = run_pow2_reg3<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
@@ -1433,7 +1607,9 @@ static int ntt_columns_impl(gfa_field_t *f, const void *in, void *out, int64_t n
         if (c.p < (1ull << 31)) return run(Prime32{}, TwShoup32{});
         return run(Prime32{}, Tw<Prime32>{});
     case KIND_PRIME64: return run(Prime64{}, Tw<Prime64>{});
-    case KIND_GOLDILOCKS: return run(Goldilocks{}, Tw<Goldilocks>{});
+    case KIND_GOLDILOCKS:
+        if (ntt_goldi_enabled() && n1 <= ((i64)1 << REG_MAX_LOG)) return run(Goldilocks{}, TwGoldi{});
+        return run(Goldilocks{}, Tw<Goldilocks>{});
     default: set_error("gfa_ntt_columns: prime fields only"); return GFA_ERR_UNSUPPORTED;
     }
 }

@@ -1222,7 +1222,7 @@ void gfa_rs_destroy(gfa_rs_t *code)
 {
     if (!code) return;
     for (auto &st : code->dev)
-        if (st.ready) { (void)hipFree(st.P8); (void)hipFree(st.roots8); (void)hipFree(st.lfsr); (void)hipFree(st.rem); (void)hipFree(st.g8); (void)hipFree(st.Pw); (void)hipFree(st.rootsw); (void)hipFree(st.gw); }
+        if (st.ready) { (void)hipFree(st.P8); (void)hipFree(st.roots8); (void)hipFree(st.lfsr); (void)hipFree(st.g8); (void)hipFree(st.Pw); (void)hipFree(st.rootsw); (void)hipFree(st.gw); }
     delete code;
 }
 
@@ -1396,15 +1396,15 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
             hipStream_t st = (hipStream_t)stream;
             const int nk = (int)(code->n - code->k);
             const size_t need = (size_t)batch * nk;
-            if (cd->rem_bytes < need) {
-                if (cd->rem) GFA_HIP(hipFree(cd->rem));
-                cd->rem = nullptr; cd->rem_bytes = 0;
-                GFA_HIP(hipMalloc((void **)&cd->rem, need));
-                cd->rem_bytes = need;
-            }
-            if ((rc = launch_lfsr<false>(code, cd, (const uint8_t *)recv, erasures, (int)ns, (uint8_t *)out_codeword, 0, cd->rem, nullptr,
-                                         batch, st)))
+            // remainder scratch of THIS call, stream-ordered (two decodes of one code on different streams, or from
+            // different host threads, must not share it; no device synchronisation, so the call stays graph-capturable)
+            uint8_t *rem = nullptr;
+            GFA_HIP(hipMallocAsync((void **)&rem, need, st));
+            if ((rc = launch_lfsr<false>(code, cd, (const uint8_t *)recv, erasures, (int)ns, (uint8_t *)out_codeword, 0, rem, nullptr,
+                                         batch, st))) {
+                (void)hipFreeAsync(rem, st);
                 return rc;
+            }
             const RsParams rp = make_params(code);
             const size_t fixed = 65536 + 1280;
             const bool small = (int)code->roots.size() + 4 <= 40;
@@ -1420,7 +1420,7 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
         static bool attr = false;                                                                                       \
         if ((rc = set_lds_limit(rs_decode_bin_kernel<SV, W>, &attr))) return rc;                                        \
         hipLaunchKernelGGL((rs_decode_bin_kernel<SV, W>), dim3(grid), dim3(nwaves * 64), lds, st, make_tables(*ds), rp, \
-                           erasures, cd->rem, (int)ns, (uint8_t *)out_codeword, (i64 *)out_n_errors, batch);            \
+                           erasures, rem, (int)ns, (uint8_t *)out_codeword, (i64 *)out_n_errors, batch);                \
     } while (0)
             if (small) {
                 switch (wps) {
@@ -1438,7 +1438,9 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
                 }
             }
 #undef GFA_K2
-            GFA_HIP(hipGetLastError());
+            const hipError_t launch_err = hipGetLastError();
+            GFA_HIP(hipFreeAsync(rem, st));
+            GFA_HIP(launch_err);
             return GFA_OK;
         }
     }

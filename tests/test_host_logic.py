@@ -295,3 +295,15 @@ def test_c_host_example_runs(tmp_path):
     r = subprocess.run([_build_c_host(tmp_path)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "round trip of 4096 codewords (16 errors each) OK" in r.stdout
+
+
+def test_lazy_goldilocks_arithmetic_header_on_the_host(tmp_path, repo_root):
+    """galois_amd/csrc/gfa_goldilocks.h compiles for the host too: its 96-bit lazy add / sub / fold / multiply formulas are
+    checked against __int128 arithmetic on a million random and edge-case operands (tests/csrc/goldilocks_host_test.cpp)."""
+    import subprocess
+
+    exe = str(tmp_path / "gl_test")
+    subprocess.run(["g++", "-O2", "-I", os.path.join(repo_root, "galois_amd", "csrc"), os.path.join(repo_root, "tests", "csrc", "goldilocks_host_test.cpp"),
+                    "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "fails 0" in r.stdout, r.stdout + r.stderr
