@@ -72,6 +72,36 @@ def _device_row_pass(field, rows: torch.Tensor, n2: int, omega_n2: int) -> torch
     return out
 
 
+def _device_row_pass_from_chunks(field, recv: torch.Tensor, n2: int, omega_n2: int) -> torch.Tensor | None:
+    """Row pass reading the all-to-all receive buffer recv[s][k1_local][c] in place (row k1_local, element s*cols + c): the
+    kernel addresses the per-peer chunks itself, so the (rows, n2) re-layout copy disappears.  None if unsupported."""
+    from ._array import _GFA_DTYPE, _ptr, _stream
+
+    world, rows, cols = recv.shape
+    out = torch.empty((rows, n2), dtype=recv.dtype, device=recv.device)
+    rc = L.lib().gfa_ntt_chunked(field._handle, _ptr(recv), _ptr(out), n2, rows, omega_n2, 0, cols, rows * cols, cols, 0, 0, 0,
+                                 _GFA_DTYPE[recv.element_size()], _stream())
+    if rc == L.ERR_UNSUPPORTED:
+        return None
+    L.check(rc, "gfa_ntt_chunked")
+    return out
+
+
+def _device_row_pass_to_chunks(field, rows_in: torch.Tensor, n2: int, omega_n2: int, world: int) -> torch.Tensor | None:
+    """Row pass of the inverse writing straight into the all-to-all SEND buffer send[s][k1_local][c]."""
+    from ._array import _GFA_DTYPE, _ptr, _stream
+
+    rows = rows_in.shape[0]
+    cols = n2 // world
+    send = torch.empty((world, rows, cols), dtype=rows_in.dtype, device=rows_in.device)
+    rc = L.lib().gfa_ntt_chunked(field._handle, _ptr(rows_in), _ptr(send), n2, rows, omega_n2, 0, 0, 0, 0, cols, rows * cols, cols,
+                                 _GFA_DTYPE[rows_in.element_size()], _stream())
+    if rc == L.ERR_UNSUPPORTED:
+        return None
+    L.check(rc, "gfa_ntt_chunked")
+    return send
+
+
 def _device_column_pass_inv(field, local: torch.Tensor, n1: int, cols: int, col0: int, n_total: int, omega_inv: int,
                             scaled: bool) -> torch.Tensor:
     from ._array import _GFA_DTYPE, _ptr, _stream
@@ -166,12 +196,15 @@ def ntt_four_step_distributed(field, local_cols: torch.Tensor, n1: int, n2: int,
     recv = torch.empty((world, rows, cols), dtype=a.dtype, device=a.device)
     _all_to_all(recv, a, group)
     st.mark("all_to_all_ms")
-    # recv[s][k1_local][c] is column s*cols + c of row k1_local -> (rows, n2) row-major
-    mine = recv.permute(1, 0, 2).reshape(rows, n2).contiguous()
-    st.mark("relayout_ms")
-    # (3) rows: X[k1 + n1*k2] = sum_j2 A[k1][j2] * w_n2^(j2*k2),  w_n2 = w^n1
+    # (3) rows: X[k1 + n1*k2] = sum_j2 A[k1][j2] * w_n2^(j2*k2),  w_n2 = w^n1.  recv[s][k1_local][c] is column s*cols + c of
+    # row k1_local: the device row pass reads those per-peer chunks in place; stand-ins (and chunk sizes the kernel does not
+    # take) get the (rows, n2) row-major copy
     omega_n2 = field._scalar(L.OP_POW, omega, n1)
-    out = row_pass(field, mine, n2, omega_n2)
+    out = _device_row_pass_from_chunks(field, recv, n2, omega_n2) if row_pass is _device_row_pass and recv.is_cuda else None
+    if out is None:
+        mine = recv.permute(1, 0, 2).reshape(rows, n2).contiguous()
+        st.mark("relayout_ms")
+        out = row_pass(field, mine, n2, omega_n2)
     st.mark("row_pass_ms")
     st.finish()
     return out
@@ -210,13 +243,19 @@ def intt_four_step_distributed(field, local_rows: torch.Tensor, n1: int, n2: int
     column_pass_inv = column_pass_inv or _device_column_pass_inv
     st = _Stamps(timings)
     st.mark("start")
-    # (1) rows: B[k1][o] = sum_k2 Y[k1][k2] * (w'^n1)^(k2*o)
-    b = row_pass(field, local_rows.contiguous(), n2, field._scalar(L.OP_POW, omega_inv, n1))
-    st.mark("row_pass_ms")
-    # (2) the one exchange: rank s receives columns [s*cols, (s+1)*cols) of every rank's row block
-    send = b.view(rows, world, cols).permute(1, 0, 2).contiguous()
-    st.mark("relayout_ms")
-    recv = torch.empty((world, rows, cols), dtype=b.dtype, device=b.device)
+    # (1) rows: B[k1][o] = sum_k2 Y[k1][k2] * (w'^n1)^(k2*o), written straight into the send buffer send[s][k1_local][c]
+    # (rank s receives columns [s*cols, (s+1)*cols) of every rank's row block) when the device kernel takes that layout
+    w_rows = field._scalar(L.OP_POW, omega_inv, n1)
+    send = _device_row_pass_to_chunks(field, local_rows.contiguous(), n2, w_rows, world) if row_pass is _device_row_pass and local_rows.is_cuda else None
+    if send is None:
+        b = row_pass(field, local_rows.contiguous(), n2, w_rows)
+        st.mark("row_pass_ms")
+        send = b.view(rows, world, cols).permute(1, 0, 2).contiguous()
+        st.mark("relayout_ms")
+    else:
+        st.mark("row_pass_ms")
+    # (2) the one exchange
+    recv = torch.empty((world, rows, cols), dtype=send.dtype, device=send.device)
     _all_to_all(recv, send, group)
     st.mark("all_to_all_ms")
     # recv[s][k1_local][c] is row s*rows + k1_local of this rank's column block: already (n1, cols) row-major

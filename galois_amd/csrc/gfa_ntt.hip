@@ -346,7 +346,18 @@ struct RegArgs {
     u64 scale_q; // Shoup quotient of `scale` for the twiddle class in use
     int xcd_remap;
     u64 pinv;    // p^-1 mod 2^32 (lazy 32-bit path)
+    // Two-level position strides (the distributed transform's exchange buffers, which are laid out in per-peer chunks):
+    // position t of a line lives at (t & (2^split - 1)) * stride_t + (t >> split) * chunk_stride.  split = 31: one level.
+    // The kernel needs 2^in_split >= R2 and 2^out_split >= R1 (the per-lane part of a position never crosses a chunk).
+    int in_split = 31, out_split = 31;
+    i64 in_chunk_stride = 0, out_chunk_stride = 0; // elements
 };
+
+// byte offset of position t0 (a multiple of the lane-owned low part; wave-uniform => scalar arithmetic)
+__device__ __forceinline__ u32 pos_offset(u32 t0, int split, u32 stride_bytes, u32 chunk_bytes)
+{
+    return (t0 & ((1u << split) - 1u)) * stride_bytes + (t0 >> split) * chunk_bytes;
+}
 
 template <class F, class TW, int LOGR>
 __device__ __forceinline__ void reg_dif(typename TW::Ctx fd, typename F::elem (&v)[1 << LOGR],
@@ -475,9 +486,9 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fdk, const ty
             const i64 last = ra.total_lines - 1 - line0;
             const u32 cl = (u32)((i64)ca <= last ? ca : last);
             const u32 off = cl * isc + (u32)ra_ * ist;
-            const u32 step = (u32)R2 * ist;
+            const u32 icb = (u32)ra.in_chunk_stride * (u32)sizeof(E);
 #pragma unroll
-            for (int a = 0; a < R1; a++) va[a] = *reinterpret_cast<const E *>(ginb + (off + (u32)a * step));
+            for (int a = 0; a < R1; a++) va[a] = *reinterpret_cast<const E *>(ginb + (off + pos_offset((u32)(a * R2), ra.in_split, ist, icb)));
             if (ra.pre_twiddle) {
                 // * w_N^(line * (r + R2*a)), a = 0..R1-1: the same per-thread geometric progression as the post-twiddle below
                 const u32 line = (u32)(ra.line_offset + line0 + cl);
@@ -584,9 +595,10 @@ __global__ __launch_bounds__(THREADS) void ntt_reg_kernel(FieldDev fdk, const ty
         }
         if (line0 + c < ra.total_lines) {
             const u32 off = (u32)c * osc + (u32)ka * ost;
-            const u32 step = (u32)R1 * ost;
+            const u32 ocb = (u32)ra.out_chunk_stride * (u32)sizeof(E);
 #pragma unroll
-            for (int kr = 0; kr < R2; kr++) *reinterpret_cast<E *>(goutb + (off + (u32)kr * step)) = v[brev_c(kr, LOGR2)];
+            for (int kr = 0; kr < R2; kr++)
+                *reinterpret_cast<E *>(goutb + (off + pos_offset((u32)(kr * R1), ra.out_split, ost, ocb))) = v[brev_c(kr, LOGR2)];
         }
     }
 }
@@ -669,9 +681,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_GL_
             const i64 last = ra.total_lines - 1 - line0;
             const u32 cl = (u32)((i64)ca <= last ? ca : last);
             const u32 off = cl * isc + (u32)ra_ * ist;
-            const u32 step = (u32)R2 * ist;
+            const u32 icb = (u32)ra.in_chunk_stride * 8u;
 #pragma unroll
-            for (int a = 0; a < R1; a++) va[a] = gl::from_u64(*reinterpret_cast<const E *>(ginb + (off + (u32)a * step)));
+            for (int a = 0; a < R1; a++)
+                va[a] = gl::from_u64(*reinterpret_cast<const E *>(ginb + (off + pos_offset((u32)(a * R2), ra.in_split, ist, icb))));
             if (ra.pre_twiddle) {
                 // * w_N^(line * (r + R2*a)): per-thread geometric progression, one table fetch for its start and its ratio
                 const u32 line = (u32)(ra.line_offset + line0 + cl);
@@ -713,7 +726,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_GL_
     // results are reduced to the canonical [0, p) and stored one by one, so that the registers of v[] free up as they go
     const bool live = line0 + c < ra.total_lines;
     char *const obase = goutb + ((u32)c * osc + (u32)ka * ost);
-    const u32 ostep = (u32)R1 * ost;
+    const u32 ocb = (u32)ra.out_chunk_stride * 8u;
     if (ra.post_twiddle) {
         const u32 line = (u32)(ra.line_offset + line0 + c);
         const u32 e0 = (line * (u32)ka) & nmask, es = (line * (u32)R1) & nmask;
@@ -722,20 +735,20 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_GL_
 #pragma unroll
         for (int kr = 0; kr < R2; kr++) {
             const u64 y = gl::canon(gl::mul(v[brev_c(kr, LOGR2)], t));
-            if (live) *reinterpret_cast<E *>(obase + (u32)kr * ostep) = y;
+            if (live) *reinterpret_cast<E *>(obase + pos_offset((u32)(kr * R1), ra.out_split, ost, ocb)) = y;
             if (kr + 1 < R2) t = gl::to_u64(gl::mul_u64(t, sr));
         }
     } else if (ra.do_scale) {
 #pragma unroll
         for (int kr = 0; kr < R2; kr++) {
             const u64 y = gl::canon(gl::mul(v[brev_c(kr, LOGR2)], ra.scale));
-            if (live) *reinterpret_cast<E *>(obase + (u32)kr * ostep) = y;
+            if (live) *reinterpret_cast<E *>(obase + pos_offset((u32)(kr * R1), ra.out_split, ost, ocb)) = y;
         }
     } else {
 #pragma unroll
         for (int kr = 0; kr < R2; kr++) {
             const u64 y = gl::canon(v[brev_c(kr, LOGR2)]);
-            if (live) *reinterpret_cast<E *>(obase + (u32)kr * ostep) = y;
+            if (live) *reinterpret_cast<E *>(obase + pos_offset((u32)(kr * R1), ra.out_split, ost, ocb)) = y;
         }
     }
 }
@@ -1073,7 +1086,9 @@ int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64
     ra.xcd_remap = (xcd && (grid % 8) == 0 && grid >= 16) ? 1 : 0;
     {
         const i64 lim = ((i64)1 << 31) / (i64)sizeof(E);
-        if ((C - 1) * ra.in_stride_c + (L - 1) * ra.in_stride_t >= lim || (C - 1) * ra.out_stride_c + (L - 1) * ra.out_stride_t >= lim) {
+        const i64 in_chunks = ra.in_split < 31 ? ((i64)L >> ra.in_split) : 0, out_chunks = ra.out_split < 31 ? ((i64)L >> ra.out_split) : 0;
+        if ((C - 1) * ra.in_stride_c + (L - 1) * ra.in_stride_t + in_chunks * ra.in_chunk_stride >= lim ||
+            (C - 1) * ra.out_stride_c + (L - 1) * ra.out_stride_t + out_chunks * ra.out_chunk_stride >= lim) {
             set_error("register NTT: tile extent exceeds the 32-bit offset range");
             return GFA_ERR_UNSUPPORTED;
         }
@@ -1193,6 +1208,20 @@ int build_post_tables(const FieldDev &fd, u64 omega, i64 n_total, Plan *pl, hipS
                                        &pl->lo_bits, st);
 }
 
+// Where the rows of a batched transform live.  Contiguous (chunk_len == 0): row b at b * n.  Chunked (the exchange buffers of
+// the distributed transform): element j of row b at (j / chunk_len) * chunk_stride + b * row_stride + (j % chunk_len).
+struct RowLayout {
+    i64 chunk_len = 0, chunk_stride = 0, row_stride = 0;
+};
+thread_local RowLayout g_layout_in, g_layout_out; // set by gfa_ntt_chunked around its call into the plain transform
+
+inline int log2_exact(i64 v)
+{
+    int l = 0;
+    while (((i64)1 << l) < v) l++;
+    return ((i64)1 << l) == v ? l : -1;
+}
+
 // power-of-two n, 4 <= n <= 2^20, on the register-blocked kernel: one pass up to 2^10, else four-step in two passes
 template <class F, class TW>
 int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n, i64 batch, u64 omega, int do_scale,
@@ -1200,6 +1229,7 @@ int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n,
 {
     typedef typename F::elem E;
     int rc;
+    const RowLayout li = g_layout_in, lo = g_layout_out;
     if (!pl->reg_ready) {
         pl->logn = 0;
         while (((i64)1 << pl->logn) < n) pl->logn++;
@@ -1212,15 +1242,40 @@ int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n,
         }
         pl->reg_ready = true;
     }
+    // chunked rows: the lane-owned low part of a position (R2 values on the load side, R1 on the store side) must not
+    // cross a chunk boundary, and in the two-pass form a chunk must hold whole sub-lines
+    auto bad_layout = []() { set_error("gfa_ntt_chunked: chunk length not supported for this transform length"); return GFA_ERR_UNSUPPORTED; };
     if (pl->log2 == 0) {
         RegArgs ra{};
         ra.in_stride_c = n; ra.in_stride_t = 1; ra.out_stride_c = n; ra.out_stride_t = 1;
+        if (li.chunk_len) {
+            const int sp = log2_exact(li.chunk_len);
+            if (sp < pl->log1 / 2) return bad_layout();
+            ra.in_stride_c = li.row_stride; ra.in_split = sp; ra.in_chunk_stride = li.chunk_stride;
+        }
+        if (lo.chunk_len) {
+            const int sp = log2_exact(lo.chunk_len);
+            if (sp < (pl->log1 + 1) / 2) return bad_layout();
+            ra.out_stride_c = lo.row_stride; ra.out_split = sp; ra.out_chunk_stride = lo.chunk_stride;
+        }
         ra.total_lines = batch;
         ra.load_along_line = 1; ra.store_along_line = 1;
         ra.do_scale = do_scale; ra.scale = scale; ra.scale_q = shoup_quotient<TW>(fd, scale);
         return launch_reg<F, TW>(fd, pl->log1, in, out, ra, 1, pl->wl1, pl->wl1q, nullptr, nullptr, nullptr, nullptr, nullptr, st);
     }
     const i64 n1 = (i64)1 << pl->log1, n2 = (i64)1 << pl->log2;
+    int in_split = 31, out_split = 31;
+    if (li.chunk_len) { // pass 1 reads position t of column c at element t * n2 + c
+        const int sp = log2_exact(li.chunk_len);
+        if (sp < pl->log2 || sp - pl->log2 < pl->log1 / 2) return bad_layout();
+        in_split = sp - pl->log2;
+    }
+    if (lo.chunk_len) { // pass 2 stores position t of column k1 at element k1 + n1 * t
+        const int sp = log2_exact(lo.chunk_len);
+        if (sp < pl->log1 || sp - pl->log1 < (pl->log2 + 1) / 2) return bad_layout();
+        out_split = sp - pl->log1;
+    }
+    const i64 in_row = li.chunk_len ? li.row_stride : n, out_row = lo.chunk_len ? lo.row_stride : n;
     // Sub-batches keep the pass-1 -> pass-2 intermediate small enough to stay in the 256 MiB Infinity Cache instead of
     // making a round trip through HBM.
     static const int sub_mb = env_int("GFA_NTT_SUBBATCH_MB", 0);
@@ -1233,12 +1288,13 @@ int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n,
     if ((rc = pl->sc->ws0.ensure(sizeof(E) * (size_t)(n * sub)))) return rc;
     for (i64 b0 = 0; b0 < batch; b0 += sub) {
         const i64 nb = std::min(sub, batch - b0);
-        const E *src = (const E *)in + b0 * n;
-        E *dst = (E *)out + b0 * n;
+        const E *src = (const E *)in + b0 * in_row;
+        E *dst = (E *)out + b0 * out_row;
         { // pass 1: the n2 columns (length n1, stride n2), then * w^(j2*k1); same layout out
             RegArgs ra{};
             ra.in_stride_c = 1; ra.in_stride_t = n2; ra.out_stride_c = 1; ra.out_stride_t = n2;
-            ra.in_batch_stride = n; ra.out_batch_stride = n;
+            ra.in_batch_stride = in_row; ra.out_batch_stride = n;
+            ra.in_split = in_split; ra.in_chunk_stride = li.chunk_stride;
             ra.total_lines = n2;
             ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits; ra.n_mask = (u64)n - 1; ra.pinv = inverse_mod_2_32(fd.p);
             if ((rc = launch_reg<F, TW>(fd, pl->log1, src, pl->sc->ws0.p, ra, nb, pl->wl1, pl->wl1q, pl->powA, pl->powAq, pl->powB,
@@ -1248,7 +1304,8 @@ int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n,
         { // pass 2: the n1 rows (contiguous), stored transposed: X[k1 + n1*k2]
             RegArgs ra{};
             ra.in_stride_c = n2; ra.in_stride_t = 1; ra.out_stride_c = 1; ra.out_stride_t = n1;
-            ra.in_batch_stride = n; ra.out_batch_stride = n;
+            ra.in_batch_stride = n; ra.out_batch_stride = out_row;
+            ra.out_split = out_split; ra.out_chunk_stride = lo.chunk_stride;
             ra.total_lines = n1;
             ra.load_along_line = 1; ra.store_along_line = 0;
             ra.do_scale = do_scale; ra.scale = scale; ra.scale_q = shoup_quotient<TW>(fd, scale);
@@ -1404,7 +1461,7 @@ int run_typed(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *
         while (((i64)1 << lg) < n) lg++;
         if constexpr (std::is_same<F, Prime32>::value) {
             // GF(65537), 2^16 points: whole transform in one workgroup's registers, shift twiddles (gfa_ntt_fermat.hip)
-            if (ntt_fermat16_eligible(fd, n, batch) && (!do_scale || scale == fd.p - 1)) {
+            if (ntt_fermat16_eligible(fd, n, batch) && (!do_scale || scale == fd.p - 1) && !g_layout_in.chunk_len && !g_layout_out.chunk_len) {
                 rc = ntt_fermat16(ein, eout, batch, omega, do_scale ? 1 : 0, st);
                 if (rc && rc != GFA_ERR_UNSUPPORTED) return rc;
                 done = rc == GFA_OK;
@@ -1612,6 +1669,32 @@ static int ntt_columns_impl(gfa_field_t *f, const void *in, void *out, int64_t n
         return run(Goldilocks{}, Tw<Goldilocks>{});
     default: set_error("gfa_ntt_columns: prime fields only"); return GFA_ERR_UNSUPPORTED;
     }
+}
+
+int gfa_ntt_chunked(gfa_field_t *f, const void *in, void *out, int64_t n, int64_t batch, uint64_t omega, int scale_by_n_inverse,
+                    int64_t in_chunk_len, int64_t in_chunk_stride, int64_t in_row_stride, int64_t out_chunk_len,
+                    int64_t out_chunk_stride, int64_t out_row_stride, int dtype, gfa_stream_t stream)
+{
+    if (!f || n < 4 || (n & (n - 1)) || n > ((int64_t)1 << (2 * REG_MAX_LOG)) || in == out) {
+        set_error("gfa_ntt_chunked: power-of-two 4 <= n <= 2^20 and distinct buffers required");
+        return GFA_ERR_UNSUPPORTED;
+    }
+    const FieldDev &c = f->calc;
+    const bool prime = c.kind == KIND_PRIME32 || c.kind == KIND_PRIME64 || c.kind == KIND_GOLDILOCKS;
+    if (!prime || f->use_lookup() || dtype != (c.kind == KIND_PRIME32 ? GFA_U32 : GFA_U64)) {
+        set_error("gfa_ntt_chunked: prime fields in calculate mode, native device width only");
+        return GFA_ERR_UNSUPPORTED;
+    }
+    if ((in_chunk_len && (in_chunk_len & (in_chunk_len - 1))) || (out_chunk_len && (out_chunk_len & (out_chunk_len - 1)))) {
+        set_error("gfa_ntt_chunked: chunk lengths must be powers of two");
+        return GFA_ERR_INVALID;
+    }
+    g_layout_in = RowLayout{in_chunk_len, in_chunk_stride, in_row_stride};
+    g_layout_out = RowLayout{out_chunk_len, out_chunk_stride, out_row_stride};
+    const int rc = gfa_ntt(f, in, out, n, batch, omega, scale_by_n_inverse, dtype, stream);
+    g_layout_in = RowLayout{};
+    g_layout_out = RowLayout{};
+    return rc;
 }
 
 int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64_t cols, int64_t col0, int64_t n_total,

@@ -153,6 +153,14 @@ int gfa_log(gfa_field_t *f, const void *a, int64_t a_stride, const void *base, i
  * in == out is allowed.  Any n with n | q-1 is accepted; powers of two take the LDS radix path. */
 int gfa_ntt(gfa_field_t *f, const void *in, void *out, int64_t n, int64_t batch, uint64_t omega, int scale_by_n_inverse,
             int dtype, gfa_stream_t stream);
+/* gfa_ntt on rows that live in per-peer chunks -- the send / receive buffers of the distributed transform's all-to-all, so
+ * that no re-layout pass is needed on either side of the exchange (new design).  Element j of row b
+ * is at (j / chunk_len) * chunk_stride + b * row_stride + (j % chunk_len) (elements); chunk_len == 0 selects the plain
+ * contiguous layout (row b at b * n) for that side.  Power-of-two 4 <= n <= 2^20 over a prime field, native device width,
+ * in != out.  Returns GFA_ERR_UNSUPPORTED (nothing launched) when a chunk is shorter than the kernel's access granule. */
+int gfa_ntt_chunked(gfa_field_t *f, const void *in, void *out, int64_t n, int64_t batch, uint64_t omega, int scale_by_n_inverse,
+                    int64_t in_chunk_len, int64_t in_chunk_stride, int64_t in_row_stride, int64_t out_chunk_len,
+                    int64_t out_chunk_stride, int64_t out_row_stride, int dtype, gfa_stream_t stream);
 /* Per-rank kernel of the distributed four-step transform of ONE length-n_total sequence over G GPUs (n_total =
  * n1 * n2, all powers of two; new design -- the reference has no distributed path).
  * The rank holds `cols` adjacent columns [col0, col0+cols) of the (n1 x n2) row-major view x[j1*n2 + j2] as a local

@@ -405,8 +405,14 @@ def _emulate_forward(GF, xs_dev_cols, n1, n2, G, omega):
     omega_n2 = GF._scalar(L.OP_POW, omega, n1)
     outs = []
     for r in range(G):
-        mine = torch.cat([a_parts[s][r * rows:(r + 1) * rows, :] for s in range(G)], dim=1).contiguous()
-        outs.append(gdist._device_row_pass(GF, mine, n2, omega_n2))
+        # what the all-to-all delivers to rank r: recv[s][k1_local][c]; the row pass reads those per-peer chunks in place
+        recv = torch.stack([a_parts[s][r * rows:(r + 1) * rows, :] for s in range(G)]).contiguous()
+        got = gdist._device_row_pass_from_chunks(GF, recv, n2, omega_n2)
+        mine = recv.permute(1, 0, 2).reshape(rows, n2).contiguous()
+        ref = gdist._device_row_pass(GF, mine, n2, omega_n2)
+        if got is not None:
+            assert torch.equal(got, ref), "chunked row pass differs from the row pass on the re-laid-out copy"
+        outs.append(ref)
     return outs
 
 
@@ -420,6 +426,11 @@ def _emulate_inverse(GF, row_blocks, n1, n2, G, omega):
     omega_inv = GF._scalar(L.OP_RECIP, omega, 0)
     w_rows = GF._scalar(L.OP_POW, omega_inv, n1)
     b_parts = [gdist._device_row_pass(GF, row_blocks[g], n2, w_rows) for g in range(G)]
+    for g in range(G):
+        # the row pass that writes the send buffer send[s][k1_local][c] directly
+        send = gdist._device_row_pass_to_chunks(GF, row_blocks[g], n2, w_rows, G)
+        if send is not None:
+            assert torch.equal(send, b_parts[g].view(rows, G, cols).permute(1, 0, 2).contiguous()), "chunked send buffer differs"
     outs = []
     for s in range(G):
         mine = torch.cat([b_parts[g][:, s * cols:(s + 1) * cols] for g in range(G)], dim=0).contiguous()
@@ -448,6 +459,12 @@ def test_distributed_inverse_emulated_on_one_gpu():
         back = _emulate_inverse(GF, fwd, n1, n2, G, omega)
         for g in range(G):
             assert torch.equal(back[g], locals_[g]), f"order {order}, rank {g}"
+    # the chunked layouts are really taken by the kernel at the C5 shape (not silently refused)
+    GL = ga.GF(2**64 - 2**32 + 1)
+    recv = torch.zeros((8, 2, 1 << 13), dtype=torch.int64, device="cuda")
+    assert gdist._device_row_pass_from_chunks(GL, recv, 1 << 16, GL._root_of_unity_int(1 << 16)) is not None
+    assert gdist._device_row_pass_to_chunks(GL, torch.zeros((2, 1 << 16), dtype=torch.int64, device="cuda"), 1 << 16,
+                                            GL._root_of_unity_int(1 << 16), 8) is not None
 
 
 def test_c5_full_size_emulated_on_one_gpu():
