@@ -181,6 +181,19 @@ int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64
 int gfa_ntt_columns_inv(gfa_field_t *f, const void *in, void *out, int64_t n1, int64_t cols, int64_t col0, int64_t n_total,
                         uint64_t omega, int scale_by_n_total_inverse, int dtype, gfa_stream_t stream);
 
+/* The whole distributed transform, collective included (SURVEY.md section 8(b) `gf_ntt_dist(comm, ...)`; semantics of
+ * fft_jit / ifft_jit, _domains/_function.py:246-392, for ONE sequence of n1 * n2 points spread over `world` GPUs, one
+ * process per GPU).  `nccl_comm` is the caller's ncclComm_t (RCCL; bound with dlsym at first use, so the library has no
+ * link-time dependency on it).  Forward: local_cols = the rank's (n1 x n2/world) column block of the row-major (n1 x n2)
+ * view, out_rows = its (n1/world x n2) block of the result, X[k1 + n1*k2] at [k1 - rank*n1/world][k2]; steps:
+ * gfa_ntt_columns, ONE ncclAllToAll over xGMI, gfa_ntt_chunked on the receive buffer.  The inverse consumes that row-block
+ * layout and returns the column-block layout (`omega` is the FORWARD root in both calls).  n1 <= 2^10 for the inverse,
+ * n2 <= 2^20; dtype = the field's native device width; input and output buffers must differ. */
+int gfa_ntt_dist(gfa_field_t *f, void *nccl_comm, int rank, int world, const void *local_cols, void *out_rows, int64_t n1, int64_t n2,
+                 uint64_t omega, int dtype, gfa_stream_t stream);
+int gfa_intt_dist(gfa_field_t *f, void *nccl_comm, int rank, int world, const void *local_rows, void *out_cols, int64_t n1, int64_t n2,
+                  uint64_t omega, int scale_by_n_inverse, int dtype, gfa_stream_t stream);
+
 /* ---- Field linear algebra ------------------------------------------------------- *
  * gfa_matmul replaces matmul_jit.implementation `int64[:,:,:](int64[:,:,:], int64[:,:,:])` (_domains/_linalg.py:283-308)
  * and the BLAS-then-mod-p shortcut of prime fields (_lapack_linalg, :21-75): out[b] = a[b] @ b[b] for `batch` row-major

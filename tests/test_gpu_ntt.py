@@ -502,3 +502,45 @@ def test_c5_full_size_emulated_on_one_gpu():
     back = _emulate_inverse(GF, fwd, n1, n2, G, omega)
     for g in range(G):
         assert torch.equal(back[g], locals_[g]), f"inverse, rank {g}"
+
+
+def test_c_abi_distributed_transform_owns_its_rccl_exchange():
+    """gfa_ntt_dist / gfa_intt_dist (the collective lives inside the library: columns, ONE ncclAllToAll, chunked rows) driven
+    with a communicator created directly through RCCL, as a non-Python host would; one rank here (the exchange is then a
+    device copy inside RCCL), compared with the single-GPU transform and inverted back."""
+    import ctypes
+    import os
+    import torch
+    from galois_amd import _lib as L
+
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    rccl = ctypes.CDLL(path if os.path.exists(path) else "librccl.so", mode=ctypes.RTLD_GLOBAL)
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        lib = L.lib()
+        st = torch.cuda.current_stream().cuda_stream
+        for order, n1, n2, dt, tdt in [(2**64 - 2**32 + 1, 1 << 10, 1 << 12, L.U64, torch.int64), (7340033, 1 << 8, 1 << 10, L.U32, torch.int32),
+                                       (469762049, 1 << 10, 1 << 16, L.U32, torch.int32)]:
+            GF = ga.GF(order)
+            n = n1 * n2
+            x = torch.empty(n, dtype=torch.int64, device="cuda").random_(0, min(order, 2**62)).to(tdt)
+            omega = GF._root_of_unity_int(n)
+            out = torch.empty_like(x)
+            L.check(lib.gfa_ntt_dist(GF._handle, comm, 0, 1, x.data_ptr(), out.data_ptr(), n1, n2, omega, dt, st), "gfa_ntt_dist")
+            want = torch.empty_like(x)
+            L.check(lib.gfa_ntt(GF._handle, x.data_ptr(), want.data_ptr(), n, 1, omega, 0, dt, st))
+            assert torch.equal(out.view(n1, n2), want.view(n2, n1).t()), f"forward, order {order}"
+            back = torch.empty_like(x)
+            L.check(lib.gfa_intt_dist(GF._handle, comm, 0, 1, out.data_ptr(), back.data_ptr(), n1, n2, omega, 1, dt, st), "gfa_intt_dist")
+            assert torch.equal(back, x), f"inverse, order {order}"
+        torch.cuda.synchronize()
+    finally:
+        rccl.ncclCommDestroy(comm)
