@@ -215,8 +215,27 @@ struct Bin {
     static GFA_HD u64 add(const FieldDev &, u64 a, u64 b) { return a ^ b; }
     static GFA_HD u64 sub(const FieldDev &, u64 a, u64 b) { return a ^ b; }
     static GFA_HD u64 neg(const FieldDev &, u64 a) { return a; }
+    // m <= 32 on the device: the same shift-and-xor product with a fixed m steps, no data-dependent branch and 32-bit
+    // registers -- per step one sign-extended bit extract of b, and / xor into the result, and a masked reduction
+    // (7 vector instructions; the 64-bit data-dependent loop below diverges inside a wavefront)
+    static GFA_HD u32 mul32(const FieldDev &f, u32 a, u32 b)
+    {
+        const int m = (int)f.m;
+        const u32 red = (u32)f.irr; // m < 32: includes bit m, which cancels the bit shifted out of the field; m = 32: low word
+        u32 c = 0;
+        for (int i = 0; i < m; i++) {
+            const u32 bm = (u32)(((int32_t)(b << (31 - i))) >> 31); // all-ones iff bit i of b
+            c ^= a & bm;
+            const u32 hm = (u32)(((int32_t)(a << (32 - m))) >> 31); // all-ones iff bit m-1 of a
+            a = (a << 1) ^ (red & hm);
+        }
+        return c;
+    }
     static GFA_HD u64 mul(const FieldDev &f, u64 a, u64 b)
     { // shift-and-xor with reduction by the irreducible polynomial (value-identical to _calculate.py:308-324)
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (f.m <= 32) return mul32(f, (u32)a, (u32)b);
+#endif
         u64 c = 0;
         const u64 top = (u64)1 << (f.m - 1);
         const u64 red = f.irr ^ ((u64)1 << f.m); // low m bits of the irreducible polynomial
@@ -373,6 +392,96 @@ struct Ext {
         for (u32 i = 0; i < f.m; i++) a = a * f.p + v[i];
         return a;
     }
+    // ---- degree known at compile time (2 <= M <= 8): every digit array lives in registers and the loops unroll; the
+    // run-time-m versions below index their arrays dynamically, which puts them in scratch memory ----
+    template <int M>
+    static GFA_HD void to_vec_m(const FieldDev &f, u64 a, u32 (&v)[M])
+    {
+        if (f.q <= 0xffffffffull) {
+            u32 x = (u32)a;
+            const u32 p32 = (u32)f.p, mu32 = (u32)(f.mu >> 32);
+#pragma unroll
+            for (int i = M - 1; i >= 0; i--) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                u32 qd = __umulhi(x, mu32);
+#else
+                u32 qd = (u32)(((u64)x * mu32) >> 32);
+#endif
+                u32 r = x - qd * p32;
+                if (r >= p32) { r -= p32; qd++; }
+                if (r >= p32) { r -= p32; qd++; }
+                v[i] = r;
+                x = qd;
+            }
+        } else {
+#pragma unroll
+            for (int i = M - 1; i >= 0; i--) {
+                u64 qd = mulhi64(a, f.mu);
+                u64 r = a - qd * f.p;
+                if (r >= f.p) { r -= f.p; qd++; }
+                if (r >= f.p) { r -= f.p; qd++; }
+                v[i] = (u32)r;
+                a = qd;
+            }
+        }
+    }
+    template <int M>
+    static GFA_HD u64 from_vec_m(const FieldDev &f, const u32 (&v)[M])
+    {
+        u64 a = 0;
+#pragma unroll
+        for (int i = 0; i < M; i++) a = a * f.p + v[i];
+        return a;
+    }
+    static GFA_HD u32 red64(const FieldDev &f, u64 x)
+    { // x mod p, any 64-bit x (mu = floor(2^64 / p): the estimate is short by at most 2)
+        u64 r = x - mulhi64(x, f.mu) * f.p;
+        if (r >= f.p) r -= f.p;
+        if (r >= f.p) r -= f.p;
+        return (u32)r;
+    }
+    // OP: 0 add, 1 sub, 2 neg (b unused)
+    template <int M, int OP>
+    static GFA_HD u64 lin_m(const FieldDev &f, u64 a, u64 b)
+    {
+        u32 av[M], bv[M];
+        to_vec_m<M>(f, a, av);
+        if (OP != 2) to_vec_m<M>(f, b, bv);
+#pragma unroll
+        for (int i = 0; i < M; i++) av[i] = OP == 0 ? Prime32::add(f, av[i], bv[i]) : OP == 1 ? Prime32::sub(f, av[i], bv[i]) : Prime32::neg(f, av[i]);
+        return from_vec_m<M>(f, av);
+    }
+    // schoolbook product with the coefficients left unreduced in 64 bits ((2M - 1) p^2 < 2^64: always for M >= 3, and for
+    // M = 2 when p < 2^31), the top M - 1 coefficients folded back through x^M = -(irr), one reduction per coefficient
+    template <int M>
+    static GFA_HD u64 mul_m(const FieldDev &f, u64 a, u64 b)
+    {
+        u32 av[M], bv[M];
+        to_vec_m<M>(f, a, av);
+        to_vec_m<M>(f, b, bv);
+        u64 c[2 * M - 1];
+#pragma unroll
+        for (int k = 0; k < 2 * M - 1; k++) c[k] = 0;
+#pragma unroll
+        for (int i = 0; i < M; i++)
+#pragma unroll
+            for (int j = 0; j < M; j++) c[i + j] += (u64)av[i] * bv[j]; // index k <-> degree 2M - 2 - k
+        u32 nir[M]; // x^M == sum_j nir[j] x^(M-1-j)
+#pragma unroll
+        for (int j = 0; j < M; j++) nir[j] = f.ext_irr[j] ? (u32)f.p - f.ext_irr[j] : 0u;
+#pragma unroll
+        for (int k = 0; k + 1 < M; k++) {
+            const u32 t = red64(f, c[k]);
+#pragma unroll
+            for (int j = 0; j < M; j++) c[k + 1 + j] += (u64)t * nir[j];
+        }
+        u32 out[M];
+#pragma unroll
+        for (int i = 0; i < M; i++) out[i] = red64(f, c[M - 1 + i]);
+        return from_vec_m<M>(f, out);
+    }
+    // degrees the element-wise kernels are instantiated for (ExtM below)
+    static GFA_HD bool fixed_degree(const FieldDev &f) { return f.m >= 2 && f.m <= 6 && f.p < (1ull << 31); }
     static GFA_HD u64 add(const FieldDev &f, u64 a, u64 b)
     {
         u32 av[GFA_MAX_EXT_DEGREE], bv[GFA_MAX_EXT_DEGREE];
@@ -439,6 +548,37 @@ struct Ext {
         if (r < 0) r += (i64)f.p;
         return (u64)r;
     }
+};
+
+// GF(p^M) with the degree fixed at compile time: the element-wise kernels are instantiated per degree (the host picks the
+// instance), so every digit array stays in registers.  Same values as Ext for every operation.
+template <int M>
+struct ExtM {
+    typedef u64 elem;
+    static GFA_HD u64 add(const FieldDev &f, u64 a, u64 b) { return Ext::lin_m<M, 0>(f, a, b); }
+    static GFA_HD u64 sub(const FieldDev &f, u64 a, u64 b) { return Ext::lin_m<M, 1>(f, a, b); }
+    static GFA_HD u64 neg(const FieldDev &f, u64 a) { return Ext::lin_m<M, 2>(f, a, a); }
+    static GFA_HD u64 mul(const FieldDev &f, u64 a, u64 b) { return Ext::mul_m<M>(f, a, b); }
+    static GFA_HD u64 one(const FieldDev &) { return 1; }
+    static GFA_HD u64 pow_u(const FieldDev &f, u64 a, u64 e)
+    {
+        u64 r = 1;
+        while (e) {
+            if (e & 1) r = mul(f, r, a);
+            a = mul(f, a, a);
+            e >>= 1;
+        }
+        return r;
+    }
+    static GFA_HD u64 inv(const FieldDev &f, u64 a)
+    { // Itoh-Tsujii as Ext::inv
+        const u64 r = (f.q - 1) / (f.p - 1);
+        const u64 a_r1 = pow_u(f, a, r - 1);
+        const u64 a_r = mul(f, a_r1, a);
+        const u32 norm_inv = Prime32::inv(f, (u32)a_r);
+        return mul(f, (u64)norm_inv, a_r1);
+    }
+    static GFA_HD u64 from_int(const FieldDev &f, i64 k) { return Ext::from_int(f, k); }
 };
 
 // a^e for signed e on the explicit-calculation kinds (power_square_and_multiply.calculate, _calculate.py:579-592).

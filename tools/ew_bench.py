@@ -12,7 +12,8 @@ rows = []
 cases = [(31, np.uint8, "auto"), (31, np.uint8, "jit-lookup"), (2**8, np.uint8, "jit-calculate"), (2**8, np.int64, "jit-lookup"),
          (65537, np.uint32, "auto"), (7340033, np.uint32, "auto"), (2147483647, np.uint32, "auto"),
          (2**64 - 2**32 + 1, None, "auto"), (2**16, np.uint16, "auto"), (2**16, np.uint16, "jit-calculate"), (2**32, np.uint32, "auto"),
-         (3**5, np.uint8, "auto"), (3**5, np.uint8, "jit-calculate"), (251**3, np.uint32, "auto")]
+         (3**5, np.uint8, "auto"), (3**5, np.uint8, "jit-calculate"), (251**3, np.uint32, "auto"),
+         (2**10, np.uint16, "auto"), (2**10, np.uint16, "jit-calculate"), (2**12, np.uint16, "jit-calculate"), (3**7, np.uint16, "auto"), (3**7, np.uint16, "jit-calculate")]
 n = 50_000_000
 for order, dt, mode in cases:
     GF = ga.GF(order)
@@ -34,6 +35,19 @@ for order, dt, mode in cases:
         r[name] = f"{n / ms.value / 1e6:.0f} Gop/s ({3 * esize * n / ms.value / 1e6 / 8000:.2f})"
     L.check(lib.gfa_time_unary(GF._handle, L.OP_RECIP, b.data_ptr(), o.data_ptr(), n, code, st, 5, ctypes.byref(ms)))
     r["recip"] = f"{n / ms.value / 1e6:.0f} Gop/s ({2 * esize * n / ms.value / 1e6 / 8000:.2f})"
+    # np.power (north_star names it): a scalar exponent and one exponent per element (int64 array, 8 more bytes per element)
+    ek = torch.tensor([12345], dtype=torch.int64, device="cuda")
+    ev = torch.from_numpy(rng.integers(-50, 1000, n, dtype=np.int64)).cuda()
+    for name, e, se, extra in (("pow_scalar", ek, 0, 0), ("pow_array", ev, 1, 8)):
+        ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+        err = torch.zeros(1, dtype=torch.int32, device="cuda")
+        L.check(lib.gfa_power(GF._handle, b.data_ptr(), 1, e.data_ptr(), se, o.data_ptr(), n, code, st, err.data_ptr()))
+        ev0.record()
+        for _ in range(3):
+            L.check(lib.gfa_power(GF._handle, b.data_ptr(), 1, e.data_ptr(), se, o.data_ptr(), n, code, st, err.data_ptr()))
+        ev1.record(); ev1.synchronize()
+        t = ev0.elapsed_time(ev1) / 3
+        r[name] = f"{n / t / 1e6:.0f} Gop/s ({(2 * esize + extra) * n / t / 1e6 / 8000:.2f})"
     GF.compile("auto")
     rows.append(r)
     print(json.dumps(r), flush=True)
