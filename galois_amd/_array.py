@@ -132,6 +132,8 @@ class FieldArrayMeta(type):
 
     @property
     def ufunc_mode(cls) -> str:
+        if cls._handle is None:  # fields of order >= 2^64 (galois_amd/_wide.py): one device mode
+            return cls._default_ufunc_mode
         return "jit-lookup" if L.lib().gfa_field_get_mode(cls._handle) == L.MODE_LOOKUP else "jit-calculate"
 
     @property
@@ -842,9 +844,7 @@ class FieldArray(metaclass=FieldArrayMeta):
             if method == "outer":
                 same_field()
                 a, b = inputs
-                ta = a._t.reshape(tuple(a.shape) + (1,) * b.ndim)
-                tb = b._t.reshape((1,) * a.ndim + tuple(b.shape))
-                return self._binary(op, cls._wrap(ta, a._np_dtype), cls._wrap(tb, b._np_dtype))
+                return self._binary(op, a.reshape(tuple(a.shape) + (1,) * b.ndim), b.reshape((1,) * a.ndim + tuple(b.shape)))
             raise NotImplementedError(f"Ufunc method {method!r} of {ufunc.__name__!r} is not implemented on the device.")
         if ufunc in (np.negative, np.reciprocal) and method == "at":
             return inputs[0]._at(ufunc, inputs[1], None)

@@ -194,11 +194,13 @@ def _default_primitive_element(irr_int: int, p: int, verify_poly: bool) -> int:
 
 def _make_class(p: int, m: int, irr_int: int, alpha: int, is_primitive_poly: bool, prime_subfield) -> type:
     order = p**m
-    if order >= 2**64:
+    if order >= 2**128:
         raise NotImplementedError(
-            f"GF({p}^{m}) has order >= 2^64. The reference represents such fields with dtype=object Python integers; "
-            "there is no device representation for them in galois_amd."
+            f"GF({p}^{m}) has order >= 2^128. The reference represents such fields with dtype=object Python integers; the "
+            "device representation of galois_amd stops at two 64-bit limbs per element."
         )
+    if order >= 2**64:
+        return _make_wide_class(p, m, irr_int, alpha, is_primitive_poly, prime_subfield)
     coeffs = nt.poly_from_int(irr_int, p)
     handle = ctypes.c_void_p()
     arr = (ctypes.c_uint64 * (m + 1))(*coeffs) if m > 1 else None
@@ -227,6 +229,37 @@ def _make_class(p: int, m: int, irr_int: int, alpha: int, is_primitive_poly: boo
     mode = L.lib().gfa_field_get_mode(handle)
     cls._default_ufunc_mode = "jit-lookup" if mode == L.MODE_LOOKUP else "jit-calculate"
     return cls
+
+
+def _make_wide_class(p: int, m: int, irr_int: int, alpha: int, is_primitive_poly: bool, prime_subfield) -> type:
+    """2^64 <= order < 2^128: two 64-bit limbs per element on the device (galois_amd/_wide.py, csrc/gfa_wide.hip)."""
+    from ._wide import WideFieldArray, wide_params
+
+    kind, words = wide_params(p, m, irr_int)
+    handle = ctypes.c_void_p()
+    arr = (ctypes.c_uint64 * 27)(*words)
+    L.check(L.lib().gfa_wfield_create(kind, m, arr, ctypes.byref(handle)), f"GF({p}^{m})")
+    name = f"FieldArray_{p}_{alpha}" if m == 1 else f"FieldArray_{p}_{m}_{alpha}_{irr_int}"
+    ns = {
+        "_characteristic": p,
+        "_degree": m,
+        "_order": p**m,
+        "_irreducible_poly": IrreduciblePoly(irr_int, p),
+        "_primitive_element_int": alpha,
+        "_primitive_element_str": nt.poly_str(nt.poly_from_int(alpha, p)) if m > 1 else str(alpha),
+        "_is_primitive_poly": bool(is_primitive_poly),
+        "_prime_subfield": prime_subfield,
+        "_dtypes": [np.object_],
+        "_object_dtype": True,
+        # the reference runs these fields in "python-calculate"; here the same formulas run in device kernels
+        "_ufunc_modes": ["jit-calculate"],
+        "_default_ufunc_mode": "jit-calculate",
+        "_handle": None,
+        "_wide_handle": handle,
+        "__module__": __name__,
+        "__hash__": None,
+    }
+    return FieldArrayMeta(name, (WideFieldArray,), ns)
 
 
 def Field(*args, **kwargs):

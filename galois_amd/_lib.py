@@ -52,6 +52,11 @@ SIGNATURES = {
     "gfa_accumulate": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "gfa_convolve": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_int, c_void_p]),
     "gfa_ntt": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_u64, c_int, c_int, c_void_p]),
+    "gfa_wfield_create": (c_int, [c_int, c_u32, _u64p, ctypes.POINTER(c_void_p)]),
+    "gfa_wfield_destroy": (None, [c_void_p]),
+    "gfa_wide_binary": (c_int, [c_void_p, c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p]),
+    "gfa_wide_unary": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    "gfa_wide_power": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "gfa_ntt_chunked": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_u64, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),
     "gfa_ntt_dist": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_i64, c_i64, c_u64, c_int, c_void_p]),
     "gfa_intt_dist": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_i64, c_i64, c_u64, c_int, c_int, c_void_p]),

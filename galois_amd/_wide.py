@@ -1,0 +1,321 @@
+"""
+Field arrays over GF(q), 2^64 <= q < 2^128 -- the reference's dtype=object fields (src/galois/_fields/_ufunc.py:36-48,
+_domains/_meta.py:39-41: arrays of Python integers through the pure-Python ufuncs).
+
+Here the elements live on the GPU as two 64-bit limbs (an int64 tensor with a trailing axis of 2); the host sees Python
+integers (`numpy()` returns dtype=object) exactly as with the reference.  The element-wise ufunc surface is covered --
+add, subtract, multiply, divide, negative, reciprocal, power (arbitrary-size integer exponents), field * integer, square,
+divmod / remainder, ==, indexing and reshaping -- through the kernels of csrc/gfa_wide.hip.  Reductions, NTTs, linear algebra
+and codes over these fields are not implemented and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from ._array import FieldArray, _device, _ptr, _stream
+
+_M64 = (1 << 64) - 1
+
+
+def wide_params(p: int, m: int, irr_int: int) -> tuple[int, list[int]]:
+    """(kind, 27 parameter words) for gfa_wfield_create (layout: include/galois_amd.h)."""
+    q = p**m
+    w = [0] * 27
+    if m == 1:
+        kind = 1
+        w[0], w[1] = p & _M64, p >> 64
+        w[2] = (-pow(p, -1, 1 << 64)) & _M64
+        r2 = pow(2, 256, p)
+        w[3], w[4] = r2 & _M64, r2 >> 64
+        w[5], w[6] = (p - 2) & _M64, (p - 2) >> 64
+    elif p == 2:
+        if m > 127:
+            raise NotImplementedError(f"GF(2^{m}): binary fields are supported up to degree 127.")
+        kind = 2
+        w[0] = 2
+        w[5], w[6] = (q - 2) & _M64, (q - 2) >> 64
+        red = irr_int ^ (1 << m)
+        w[7], w[8] = red & _M64, red >> 64
+    else:
+        if p >= 2**32 or m > 16:
+            raise NotImplementedError(f"GF({p}^{m}): extension fields of order >= 2^64 need p < 2^32 and degree <= 16.")
+        kind = 3
+        w[0] = p
+        itr = (q - 1) // (p - 1) - 1
+        w[9], w[10] = itr & _M64, itr >> 64
+        digits = []
+        v = irr_int
+        while v:
+            digits.append(v % p)
+            v //= p
+        digits = digits[::-1]  # degree m .. 0
+        for i, c in enumerate(digits[1:]):
+            w[11 + i] = c
+    return kind, w
+
+
+def _split(values: np.ndarray) -> torch.Tensor:
+    """Object array of Python integers in [0, 2^128) -> int64 tensor (..., 2) of little-endian limbs."""
+    flat = [int(v) for v in values.ravel()]
+    limbs = np.empty((len(flat), 2), dtype=np.uint64)
+    for i, v in enumerate(flat):
+        limbs[i, 0] = v & _M64
+        limbs[i, 1] = v >> 64
+    return torch.from_numpy(limbs.view(np.int64).reshape(tuple(values.shape) + (2,)))
+
+
+class WideFieldArray(FieldArray):
+    _wide_handle = None
+
+    def __init__(self, x, dtype=None, copy: bool = True):
+        cls = type(self)
+        if dtype is not None and np.dtype(dtype) != np.dtype(object):
+            raise TypeError(f"{cls.name} arrays only support dtypes ['object'], not {np.dtype(dtype).name!r}.")
+        self._np_dtype = np.dtype(object)
+        if isinstance(x, FieldArray):
+            if type(x) is not cls:
+                raise TypeError(f"Cannot convert an array over {type(x).name} into an array over {cls.name}.")
+            self._t = x._t.clone() if copy else x._t
+            return
+        if isinstance(x, torch.Tensor):
+            raise TypeError(f"{cls.name} arrays are built from Python integers (two 64-bit limbs per element on the device).")
+        arr = cls._verify_host(x)
+        self._t = _split(np.asarray(arr, dtype=object)).to(_device())
+
+    @classmethod
+    def _verify_host(cls, x) -> np.ndarray:
+        """Element verification of array-likes (_fields/_array.py:129-180): Python integers in [0, order), kept as objects."""
+        if isinstance(x, (int, np.integer)):
+            arr = np.array(int(x), dtype=object)
+        elif isinstance(x, (list, tuple, np.ndarray)):
+            arr = np.array(x, dtype=object) if not isinstance(x, np.ndarray) else x
+            if arr.dtype != object:
+                if not np.issubdtype(arr.dtype, np.integer):
+                    raise TypeError(f"{cls.name} arrays must have integer dtypes, not {arr.dtype}.")
+                arr = arr.astype(object)
+        else:
+            raise TypeError(
+                f"{cls.name} arrays can be created with scalars of type int, not {type(x)}."
+                if np.isscalar(x) else f"{cls.name} arrays cannot be created from {type(x)}."
+            )
+        flat = arr.ravel()
+        for v in flat:
+            if not isinstance(v, (int, np.integer)):
+                raise TypeError(f"{cls.name} arrays must have integer dtypes, not object elements of {type(v)}.")
+        if flat.size and (min(int(v) for v in flat) < 0 or max(int(v) for v in flat) >= cls._order):
+            raise ValueError(f"{cls.name} arrays must have elements in `0 <= x < {cls._order}`.")
+        return arr
+
+    @classmethod
+    def _wrap(cls, t: torch.Tensor, np_dtype=None) -> "WideFieldArray":
+        obj = object.__new__(cls)
+        obj._t = t
+        obj._np_dtype = np.dtype(object)
+        return obj
+
+    # ---- shape (the trailing limb axis is storage, not shape) ------------------------------------------------
+    @property
+    def shape(self):
+        return tuple(self._t.shape[:-1])
+
+    @property
+    def ndim(self):
+        return self._t.dim() - 1
+
+    @property
+    def size(self):
+        return self._t.numel() // 2
+
+    def __len__(self):
+        if self.ndim == 0:
+            raise TypeError("len() of unsized object")
+        return self._t.shape[0]
+
+    @property
+    def T(self):
+        n = self.ndim
+        return type(self)._wrap(self._t.permute(*reversed(range(n)), n).contiguous())
+
+    def numpy(self) -> np.ndarray:
+        host = self._t.cpu().numpy().view(np.uint64)
+        out = np.empty(host.shape[:-1], dtype=object)
+        flat = out.reshape(-1) if out.ndim else None
+        limbs = host.reshape(-1, 2)
+        if flat is None:
+            return np.array(int(limbs[0, 0]) | (int(limbs[0, 1]) << 64), dtype=object)
+        for i in range(limbs.shape[0]):
+            flat[i] = int(limbs[i, 0]) | (int(limbs[i, 1]) << 64)
+        return out
+
+    def __int__(self):
+        if self.size != 1:
+            raise TypeError("only size-1 arrays can be converted to Python scalars")
+        return int(self.numpy().reshape(-1)[0])
+
+    __index__ = __int__
+
+    def copy(self):
+        return type(self)._wrap(self._t.clone())
+
+    def reshape(self, *shape):
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+        return type(self)._wrap(self._t.reshape(tuple(shape) + (2,)))
+
+    def flatten(self):
+        return type(self)._wrap(self._t.reshape(-1, 2).clone())
+
+    ravel = flatten
+
+    def astype(self, dtype):
+        if np.dtype(dtype) != np.dtype(object):
+            raise TypeError(f"{type(self).name} arrays only support dtypes ['object'], not {np.dtype(dtype).name!r}.")
+        return self.copy()
+
+    def __getitem__(self, key):
+        key = key if isinstance(key, tuple) else (key,)
+        return type(self)._wrap(self._t[key + (Ellipsis, slice(None))] if Ellipsis not in key else self._t[key + (slice(None),)])
+
+    def __setitem__(self, key, value):
+        cls = type(self)
+        v = value if isinstance(value, cls) else cls(value)
+        key = key if isinstance(key, tuple) else (key,)
+        self._t[key + ((Ellipsis, slice(None)) if Ellipsis not in key else (slice(None),))] = v._t
+
+    def __eq__(self, other):
+        cls = type(self)
+        if not isinstance(other, cls):
+            try:
+                other = cls(other)
+            except (TypeError, ValueError):
+                return NotImplemented
+        return (self._t == other._t).all(dim=-1).cpu().numpy()
+
+    def __ne__(self, other):
+        r = self.__eq__(other)
+        return r if r is NotImplemented else ~r
+
+    __hash__ = None
+
+    # ---- constructors ----------------------------------------------------------------------------------------
+    @classmethod
+    def Zeros(cls, shape, dtype=None):
+        shape = (shape,) if isinstance(shape, (int, np.integer)) else tuple(shape)
+        return cls._wrap(torch.zeros(shape + (2,), dtype=torch.int64, device=_device()))
+
+    @classmethod
+    def Ones(cls, shape, dtype=None):
+        z = cls.Zeros(shape)
+        z._t[..., 0] = 1
+        return z
+
+    @classmethod
+    def Random(cls, shape=(), low: int = 0, high=None, seed=None, dtype=None):
+        """Uniform in [low, high) from Python's `random` seeded like the reference's object-dtype path
+        (_domains/_array.py:287-298 uses random.randint per element)."""
+        import random
+
+        high = cls._order if high is None else high
+        if not 0 <= low < high <= cls._order:
+            raise ValueError(f"Arguments must satisfy `0 <= low < high <= order`, not `0 <= {low} < {high} <= {cls._order}`.")
+        shape = (shape,) if isinstance(shape, (int, np.integer)) else tuple(shape)
+        rng = random.Random(None if seed is None else int(np.random.default_rng(seed).integers(0, 2**63)))
+        n = int(np.prod(shape)) if shape else 1
+        vals = np.array([rng.randint(low, high - 1) for _ in range(n)], dtype=object).reshape(shape)
+        return cls(vals)
+
+    @classmethod
+    def Range(cls, start: int, stop: int, step: int = 1, dtype=None):
+        return cls(np.array(list(range(start, stop, step)), dtype=object))
+
+    # ---- arithmetic ------------------------------------------------------------------------------------------
+    def _check_err(self, err):
+        if int(err.item()) & L.DEVERR_ZERO_DIVISION:
+            raise ZeroDivisionError("Cannot compute the multiplicative inverse of 0 in a Galois field.")
+
+    @staticmethod
+    def _bcast(a: torch.Tensor, b: torch.Tensor):
+        sa, sb = tuple(a.shape[:-1]), tuple(b.shape[:-1])
+        shape = tuple(torch.broadcast_shapes(sa, sb))
+        na, nb = a.numel() // 2, b.numel() // 2
+        n = int(np.prod(shape)) if shape else 1
+        ta, stra = (a.reshape(-1, 2).contiguous(), 0) if na == 1 and n != 1 else (a.expand(shape + (2,)).contiguous(), 1)
+        tb, strb = (b.reshape(-1, 2).contiguous(), 0) if nb == 1 and n != 1 else (b.expand(shape + (2,)).contiguous(), 1)
+        return ta, stra, tb, strb, shape, n
+
+    def _binary(self, op, a, b):
+        cls = type(self)
+        ta, sa, tb, sb, shape, n = self._bcast(a._t, b._t)
+        out = torch.empty(shape + (2,), dtype=torch.int64, device=ta.device)
+        err = torch.zeros(1, dtype=torch.int32, device=ta.device) if op == L.OP_DIV else None
+        L.check(L.lib().gfa_wide_binary(cls._wide_handle, op, _ptr(ta), sa, _ptr(tb), sb, _ptr(out), n, _stream(),
+                                        _ptr(err) if err is not None else None), "gfa_wide_binary")
+        if err is not None:
+            self._check_err(err)
+        return cls._wrap(out)
+
+    def _unary(self, op):
+        cls = type(self)
+        t = self._t.contiguous()
+        out = torch.empty_like(t)
+        err = torch.zeros(1, dtype=torch.int32, device=t.device) if op == L.OP_RECIP else None
+        L.check(L.lib().gfa_wide_unary(cls._wide_handle, op, _ptr(t), _ptr(out), t.numel() // 2, _stream(),
+                                       _ptr(err) if err is not None else None), "gfa_wide_unary")
+        if err is not None:
+            self._check_err(err)
+        return cls._wrap(out)
+
+    def _with_int(self, k, is_pow: bool):
+        cls = type(self)
+        if isinstance(k, torch.Tensor):
+            k = k.cpu().numpy()
+        if isinstance(k, (int, np.integer)):
+            ks = np.array(int(k), dtype=object)
+        elif isinstance(k, np.ndarray):
+            if k.dtype != object and not np.issubdtype(k.dtype, np.integer):
+                raise ValueError(f"Operation requires operands with type np.ndarray to have integer dtype, not {k.dtype}.")
+            ks = k.astype(object)
+        else:
+            raise TypeError(f"{'The exponent' if is_pow else 'The integer multiplicand'} must be an integer or an integer np.ndarray, not {type(k)}.")
+        if not is_pow:
+            # field * integer = the integer reduced modulo the characteristic, as a field element (_ufunc.py:392-401)
+            red = np.array([int(v) % cls._characteristic for v in ks.ravel()], dtype=object).reshape(ks.shape)
+            return self._binary(L.OP_MUL, self, cls(red))
+        qm1 = cls._order - 1
+        flat = [int(v) for v in ks.ravel()]
+        e_red = np.array([v % qm1 for v in flat], dtype=object).reshape(ks.shape)
+        sign = torch.from_numpy(np.array([(v > 0) - (v < 0) for v in flat], dtype=np.int8).reshape(ks.shape)).to(self._t.device)
+        te = _split(e_red).to(self._t.device)
+        ta, sa, te2, se, shape, n = self._bcast(self._t, te)
+        sg = sign.reshape(-1) if se == 0 else sign.expand(shape).contiguous()
+        out = torch.empty(shape + (2,), dtype=torch.int64, device=ta.device)
+        err = torch.zeros(1, dtype=torch.int32, device=ta.device)
+        L.check(L.lib().gfa_wide_power(cls._wide_handle, _ptr(ta), sa, _ptr(te2), se, _ptr(sg), _ptr(out), n, _stream(), _ptr(err)),
+                "gfa_wide_power")
+        self._check_err(err)
+        return cls._wrap(out)
+
+    def _unsupported(self, *a, **k):
+        raise NotImplementedError(f"This operation is not implemented for {type(self).name} (order >= 2^64): element-wise ufuncs only.")
+
+    _reduce = _accumulate = _reduceat = _at = _sqrt = log = _unsupported
+
+    @classmethod
+    def _scalar(cls, op, a, b=0):
+        x = cls(np.array(int(a), dtype=object))
+        if op == L.OP_RECIP:
+            return int(np.reciprocal(x))
+        if op == L.OP_NEG:
+            return int(-x)
+        if op == L.OP_POW:
+            return int(x ** int(b))
+        y = cls(np.array(int(b), dtype=object))
+        return int({L.OP_ADD: x + y, L.OP_SUB: x - y, L.OP_MUL: x * y, L.OP_DIV: x / y}[op])
+
+    @classmethod
+    def compile(cls, mode: str):
+        if mode not in ("auto", "jit-calculate", "python-calculate"):
+            raise ValueError(f"Argument 'mode' must be in ['auto', 'jit-calculate'] for {cls.name}, not {mode!r}.")

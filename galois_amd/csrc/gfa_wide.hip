@@ -1,0 +1,396 @@
+// gfa_wide.hip -- element-wise arithmetic in finite fields of order 2^64 <= q < 2^128.
+//
+// The reference runs these fields as dtype=object arrays of Python integers through its pure-Python ufuncs
+// (src/galois/_fields/_ufunc.py:36-48 picks [np.object_], _domains/_meta.py:39-41 the "python-calculate" mode; the scalar
+// kernels are the same _domains/_calculate.py:133-592 as for small fields).  Here an element is two 64-bit limbs
+// (little endian, interleaved: element i at words 2i, 2i+1) and three arithmetic kinds cover what the reference covers:
+//   WPRIME  GF(p), 2^64 <= p < 2^128: two-limb Montgomery products (CIOS), conditional-subtract add / sub, a^(p-2) inverse
+//   WBIN    GF(2^m), 64 < m <= 127:   xor add; shift-and-xor product over 128 bits with a masked reduction (m fixed steps)
+//   WEXT    GF(p^m), p < 2^32, q >= 2^64: base-p digit vectors (128-by-32 long division), schoolbook product with reduction
+//           by the irreducible polynomial, Itoh-Tsujii inverse -- the reference's *_vector / itoh_tsujii formulas
+// One element per lane, grid-stride.  These kernels exist for coverage and exactness (the three Sage folders GF(2^100),
+// GF(36893488147419103183), GF(109987^4) of the reference's test-suite), not for the roofline: they are VALU-bound at a few
+// hundred instructions per element, which is still orders of magnitude above the reference's ~1 us per element.
+#include "gfa_internal.h"
+
+using namespace gfa;
+
+namespace {
+
+struct W128 {
+    u64 lo, hi;
+};
+typedef unsigned __int128 u128;
+
+enum { WKIND_PRIME = 1, WKIND_BIN = 2, WKIND_EXT = 3 };
+
+struct WField {
+    int kind;
+    int m;
+    W128 p;       // WPRIME: the modulus.  WEXT: characteristic in p.lo
+    u64 nprime;   // WPRIME: -p^-1 mod 2^64
+    W128 r2;      // WPRIME: 2^256 mod p
+    W128 pm2;     // WPRIME: p - 2
+    W128 red;     // WBIN: irreducible polynomial without its x^m term
+    W128 qm2;     // WBIN: 2^m - 2
+    W128 itr;     // WEXT: (q - 1) / (p - 1) - 1 (the Itoh-Tsujii exponent r - 1)
+    u32 irr[16];  // WEXT: irreducible polynomial minus x^m, digits of degree m-1..0
+};
+
+__device__ __forceinline__ bool w_is_zero(W128 a) { return (a.lo | a.hi) == 0; }
+__device__ __forceinline__ bool w_ge(W128 a, W128 b) { return a.hi > b.hi || (a.hi == b.hi && a.lo >= b.lo); }
+__device__ __forceinline__ W128 w_sub(W128 a, W128 b) { return W128{a.lo - b.lo, a.hi - b.hi - (a.lo < b.lo ? 1u : 0u)}; }
+__device__ __forceinline__ W128 w_add_carry(W128 a, W128 b, u32 *c)
+{
+    W128 r;
+    r.lo = a.lo + b.lo;
+    const u64 c0 = r.lo < a.lo ? 1u : 0u;
+    const u64 t = a.hi + b.hi;
+    const u64 c1 = t < a.hi ? 1u : 0u;
+    r.hi = t + c0;
+    *c = (u32)(c1 | (r.hi < t ? 1u : 0u));
+    return r;
+}
+
+// ---------------------------------------------------------------- WPRIME
+__device__ __forceinline__ W128 wp_add(const WField &f, W128 a, W128 b)
+{
+    u32 c;
+    W128 s = w_add_carry(a, b, &c);
+    if (c || w_ge(s, f.p)) s = w_sub(s, f.p);
+    return s;
+}
+__device__ __forceinline__ W128 wp_sub(const WField &f, W128 a, W128 b)
+{
+    if (w_ge(a, b)) return w_sub(a, b);
+    u32 c;
+    return w_sub(w_add_carry(a, f.p, &c), b); // a + p - b (the 2^128 carry cancels against the borrow)
+}
+// Montgomery product a * b * 2^-128 mod p (CIOS, two 64-bit limbs)
+__device__ __forceinline__ W128 wp_mont(const WField &f, W128 a, W128 b)
+{
+    const u64 av[2] = {a.lo, a.hi}, bv[2] = {b.lo, b.hi}, pv[2] = {f.p.lo, f.p.hi};
+    u64 t0 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        u128 x = (u128)av[0] * bv[i] + t0;
+        t0 = (u64)x;
+        x = (u128)av[1] * bv[i] + t1 + (u64)(x >> 64);
+        t1 = (u64)x;
+        u128 y = (u128)t2 + (u64)(x >> 64);
+        t2 = (u64)y;
+        const u64 t3 = (u64)(y >> 64);
+        const u64 mq = t0 * f.nprime;
+        x = (u128)mq * pv[0] + t0; // low word becomes zero
+        x = (u128)mq * pv[1] + t1 + (u64)(x >> 64);
+        t0 = (u64)x;
+        y = (u128)t2 + (u64)(x >> 64);
+        t1 = (u64)y;
+        t2 = t3 + (u64)(y >> 64);
+    }
+    W128 r{t0, t1};
+    if (t2 || w_ge(r, f.p)) r = w_sub(r, f.p);
+    return r;
+}
+__device__ __forceinline__ W128 wp_mul(const WField &f, W128 a, W128 b) { return wp_mont(f, wp_mont(f, a, f.r2), b); }
+__device__ W128 wp_pow(const WField &f, W128 a, W128 e)
+{
+    const W128 one_m = wp_mont(f, W128{1, 0}, f.r2); // 1 in Montgomery form
+    W128 am = wp_mont(f, a, f.r2), r = one_m;
+    for (int i = 0; i < 128; i++) {
+        const u64 bit = i < 64 ? (e.lo >> i) & 1 : (e.hi >> (i - 64)) & 1;
+        if (bit) r = wp_mont(f, r, am);
+        am = wp_mont(f, am, am);
+    }
+    return wp_mont(f, r, W128{1, 0});
+}
+
+// ---------------------------------------------------------------- WBIN
+__device__ W128 wb_mul(const WField &f, W128 a, W128 b)
+{
+    const int m = f.m;
+    W128 c{0, 0};
+    for (int i = 0; i < m; i++) {
+        const u64 bit = i < 64 ? (b.lo >> i) & 1 : (b.hi >> (i - 64)) & 1;
+        const u64 bm = (u64)0 - bit;
+        c.lo ^= a.lo & bm;
+        c.hi ^= a.hi & bm;
+        const u64 top = m > 64 ? (a.hi >> (m - 65)) & 1 : (a.lo >> (m - 1)) & 1; // bit m-1
+        const u64 tm = (u64)0 - top;
+        a.hi = (a.hi << 1) | (a.lo >> 63);
+        a.lo <<= 1;
+        // the bit shifted into position m is cleared by masking; the reduction adds the low part of the polynomial
+        if (m < 128) {
+            if (m > 64) a.hi &= ((u64)1 << (m - 64)) - 1;
+            else { a.hi = 0; if (m < 64) a.lo &= ((u64)1 << m) - 1; }
+        }
+        a.lo ^= f.red.lo & tm;
+        a.hi ^= f.red.hi & tm;
+    }
+    return c;
+}
+__device__ W128 wb_pow(const WField &f, W128 a, W128 e)
+{
+    W128 r{1, 0};
+    for (int i = 0; i < 128; i++) {
+        const u64 bit = i < 64 ? (e.lo >> i) & 1 : (e.hi >> (i - 64)) & 1;
+        if (bit) r = wb_mul(f, r, a);
+        if ((i < 64 ? (e.lo >> i) >> 1 : (e.hi >> (i - 64)) >> 1) == 0 && (i >= 64 || e.hi == 0)) break; // no higher bits left
+        a = wb_mul(f, a, a);
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------- WEXT
+struct Digits {
+    u32 d[16]; // most significant digit first, m entries used
+};
+__device__ void we_to_vec(const WField &f, W128 a, Digits &v)
+{
+    const u64 p = f.p.lo;
+    u32 limb[4] = {(u32)a.lo, (u32)(a.lo >> 32), (u32)a.hi, (u32)(a.hi >> 32)};
+    for (int i = f.m - 1; i >= 0; i--) {
+        u64 rem = 0;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            const u64 cur = (rem << 32) | limb[k];
+            limb[k] = (u32)(cur / p);
+            rem = cur % p;
+        }
+        v.d[i] = (u32)rem;
+    }
+}
+__device__ W128 we_from_vec(const WField &f, const Digits &v)
+{
+    const u64 p = f.p.lo;
+    W128 a{0, 0};
+    for (int i = 0; i < f.m; i++) {
+        const u128 lo = (u128)a.lo * p + v.d[i];
+        a.hi = a.hi * p + (u64)(lo >> 64);
+        a.lo = (u64)lo;
+    }
+    return a;
+}
+__device__ void we_mul_vec(const WField &f, const Digits &a, const Digits &b, Digits &c)
+{ // multiply_vector (_domains/_calculate.py:343-383): consume b from its lowest digit, keep a * x^it reduced
+    const u64 p = f.p.lo;
+    const int m = f.m;
+    Digits av = a;
+    for (int i = 0; i < m; i++) c.d[i] = 0;
+    for (int it = 0; it < m; it++) {
+        const u64 bl = b.d[m - 1 - it];
+        if (bl)
+            for (int i = 0; i < m; i++) c.d[i] = (u32)((c.d[i] + bl * av.d[i]) % p);
+        const u64 qd = av.d[0];
+        for (int i = 0; i + 1 < m; i++) av.d[i] = av.d[i + 1];
+        av.d[m - 1] = 0;
+        if (qd)
+            for (int i = 0; i < m; i++) av.d[i] = (u32)((av.d[i] + (p - (qd * f.irr[i]) % p)) % p);
+    }
+}
+__device__ W128 we_mul(const WField &f, W128 a, W128 b)
+{
+    Digits av, bv, cv;
+    we_to_vec(f, a, av);
+    we_to_vec(f, b, bv);
+    we_mul_vec(f, av, bv, cv);
+    return we_from_vec(f, cv);
+}
+template <int OP> // 0 add, 1 sub, 2 neg
+__device__ W128 we_lin(const WField &f, W128 a, W128 b)
+{
+    const u64 p = f.p.lo;
+    Digits av, bv;
+    we_to_vec(f, a, av);
+    if (OP != 2) we_to_vec(f, b, bv);
+    for (int i = 0; i < f.m; i++) {
+        const u64 x = av.d[i], y = OP != 2 ? bv.d[i] : 0;
+        av.d[i] = (u32)(OP == 0 ? (x + y) % p : OP == 1 ? (x + p - y) % p : (p - x) % p);
+    }
+    return we_from_vec(f, av);
+}
+__device__ W128 we_pow(const WField &f, W128 a, W128 e)
+{
+    Digits r, x, t;
+    for (int i = 0; i < f.m; i++) r.d[i] = 0;
+    r.d[f.m - 1] = 1;
+    we_to_vec(f, a, x);
+    for (int i = 0; i < 128; i++) {
+        const u64 bit = i < 64 ? (e.lo >> i) & 1 : (e.hi >> (i - 64)) & 1;
+        if (bit) { we_mul_vec(f, r, x, t); r = t; }
+        if ((i < 64 ? (e.lo >> i) >> 1 : (e.hi >> (i - 64)) >> 1) == 0 && (i >= 64 || e.hi == 0)) break;
+        we_mul_vec(f, x, x, t);
+        x = t;
+    }
+    return we_from_vec(f, r);
+}
+__device__ u64 powmod64(u64 a, u64 e, u64 p)
+{ // p < 2^32
+    u64 r = 1;
+    a %= p;
+    while (e) {
+        if (e & 1) r = r * a % p;
+        a = a * a % p;
+        e >>= 1;
+    }
+    return r;
+}
+// a != 0.  Itoh-Tsujii (reciprocal_itoh_tsujii, _domains/_calculate.py:447-489): a^-1 = (a^r)^-1 * a^(r-1), a^r in GF(p)
+__device__ W128 we_inv(const WField &f, W128 a)
+{
+    const W128 a_r1 = we_pow(f, a, f.itr);
+    const W128 a_r = we_mul(f, a_r1, a); // < p
+    const u64 ninv = powmod64(a_r.lo, f.p.lo - 2, f.p.lo);
+    return we_mul(f, W128{ninv, 0}, a_r1);
+}
+
+// ---------------------------------------------------------------- dispatch on the kind (wave-uniform)
+__device__ W128 wf_add(const WField &f, W128 a, W128 b)
+{
+    return f.kind == WKIND_PRIME ? wp_add(f, a, b) : f.kind == WKIND_BIN ? W128{a.lo ^ b.lo, a.hi ^ b.hi} : we_lin<0>(f, a, b);
+}
+__device__ W128 wf_sub(const WField &f, W128 a, W128 b)
+{
+    return f.kind == WKIND_PRIME ? wp_sub(f, a, b) : f.kind == WKIND_BIN ? W128{a.lo ^ b.lo, a.hi ^ b.hi} : we_lin<1>(f, a, b);
+}
+__device__ W128 wf_neg(const WField &f, W128 a)
+{
+    if (f.kind == WKIND_BIN) return a;
+    if (f.kind == WKIND_PRIME) return w_is_zero(a) ? a : w_sub(f.p, a);
+    return we_lin<2>(f, a, a);
+}
+__device__ W128 wf_mul(const WField &f, W128 a, W128 b)
+{
+    return f.kind == WKIND_PRIME ? wp_mul(f, a, b) : f.kind == WKIND_BIN ? wb_mul(f, a, b) : we_mul(f, a, b);
+}
+__device__ W128 wf_inv(const WField &f, W128 a)
+{ // a != 0
+    return f.kind == WKIND_PRIME ? wp_pow(f, a, f.pm2) : f.kind == WKIND_BIN ? wb_pow(f, a, f.qm2) : we_inv(f, a);
+}
+__device__ W128 wf_pow(const WField &f, W128 a, W128 e)
+{
+    return f.kind == WKIND_PRIME ? wp_pow(f, a, e) : f.kind == WKIND_BIN ? wb_pow(f, a, e) : we_pow(f, a, e);
+}
+
+__device__ __forceinline__ W128 wload(const u64 *p, i64 i) { return W128{p[2 * i], p[2 * i + 1]}; }
+__device__ __forceinline__ void wstore(u64 *p, i64 i, W128 v) { p[2 * i] = v.lo; p[2 * i + 1] = v.hi; }
+
+__global__ __launch_bounds__(256) void wide_binary_kernel(WField f, int op, const u64 *__restrict__ a, int sa, const u64 *__restrict__ b,
+                                                          int sb, u64 *__restrict__ out, i64 n, int32_t *err)
+{
+    bool bad = false;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        const W128 x = wload(a, sa ? i : 0), y = wload(b, sb ? i : 0);
+        W128 r;
+        switch (op) {
+        case GFA_OP_ADD: r = wf_add(f, x, y); break;
+        case GFA_OP_SUB: r = wf_sub(f, x, y); break;
+        case GFA_OP_MUL: r = wf_mul(f, x, y); break;
+        default:
+            if (w_is_zero(y)) { bad = true; r = W128{0, 0}; }
+            else r = wf_mul(f, x, wf_inv(f, y));
+        }
+        wstore(out, i, r);
+    }
+    if (bad && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
+}
+
+__global__ __launch_bounds__(256) void wide_unary_kernel(WField f, int op, const u64 *__restrict__ a, u64 *__restrict__ out, i64 n, int32_t *err)
+{
+    bool bad = false;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        const W128 x = wload(a, i);
+        W128 r;
+        if (op == GFA_OP_NEG) r = wf_neg(f, x);
+        else if (w_is_zero(x)) { bad = true; r = W128{0, 0}; }
+        else r = wf_inv(f, x);
+        wstore(out, i, r);
+    }
+    if (bad && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
+}
+
+// exps: exponent already reduced into [0, q - 1) by the host (two limbs); sign: the sign of the ORIGINAL exponent, which
+// decides the zero-base cases exactly as power_square_and_multiply does (_domains/_calculate.py:558-592)
+__global__ __launch_bounds__(256) void wide_power_kernel(WField f, const u64 *__restrict__ a, int sa, const u64 *__restrict__ exps, int se,
+                                                         const int8_t *__restrict__ sign, u64 *__restrict__ out, i64 n, int32_t *err)
+{
+    bool bad = false;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        const W128 x = wload(a, sa ? i : 0), e = wload(exps, se ? i : 0);
+        const int sg = sign[se ? i : 0];
+        W128 r;
+        if (sg == 0) r = W128{1, 0};
+        else if (w_is_zero(x)) { r = W128{0, 0}; bad |= sg < 0; }
+        else r = wf_pow(f, x, e);
+        wstore(out, i, r);
+    }
+    if (bad && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
+}
+
+} // namespace
+
+struct gfa_wfield {
+    WField f;
+};
+
+extern "C" {
+
+int gfa_wfield_create(int kind, uint32_t m, const uint64_t *params, gfa_wfield_t **out)
+{
+    // params (uint64 words): [0:2] p  [2] nprime  [3:5] r2  [5:7] p-2 | 2^m-2  [7:9] red  [9:11] (q-1)/(p-1)-1  [11:27] irr digits
+    if (!params || !out || kind < WKIND_PRIME || kind > WKIND_EXT || m < 1 || m > 127 || (kind == WKIND_EXT && m > 16)) {
+        set_error("gfa_wfield_create: bad arguments");
+        return GFA_ERR_INVALID;
+    }
+    gfa_wfield *w = new gfa_wfield();
+    WField &f = w->f;
+    f.kind = kind; f.m = (int)m;
+    f.p = W128{params[0], params[1]};
+    f.nprime = params[2];
+    f.r2 = W128{params[3], params[4]};
+    f.pm2 = W128{params[5], params[6]};
+    f.qm2 = f.pm2;
+    f.red = W128{params[7], params[8]};
+    f.itr = W128{params[9], params[10]};
+    for (int i = 0; i < 16; i++) f.irr[i] = (u32)params[11 + i];
+    *out = w;
+    return GFA_OK;
+}
+
+void gfa_wfield_destroy(gfa_wfield_t *w) { delete w; }
+
+int gfa_wide_binary(gfa_wfield_t *w, int op, const void *a, int64_t sa, const void *b, int64_t sb, void *out, int64_t n, gfa_stream_t stream,
+                    int32_t *dev_err)
+{
+    if (!w || !a || !b || !out || n < 0 || op < GFA_OP_ADD || op > GFA_OP_DIV) { set_error("gfa_wide_binary: bad arguments"); return GFA_ERR_INVALID; }
+    if (n == 0) return GFA_OK;
+    const int grid = (int)std::min<i64>((n + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(wide_binary_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w->f, op, (const u64 *)a, (int)sa, (const u64 *)b, (int)sb,
+                       (u64 *)out, n, dev_err);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+int gfa_wide_unary(gfa_wfield_t *w, int op, const void *a, void *out, int64_t n, gfa_stream_t stream, int32_t *dev_err)
+{
+    if (!w || !a || !out || n < 0 || (op != GFA_OP_NEG && op != GFA_OP_RECIP)) { set_error("gfa_wide_unary: bad arguments"); return GFA_ERR_INVALID; }
+    if (n == 0) return GFA_OK;
+    const int grid = (int)std::min<i64>((n + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(wide_unary_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w->f, op, (const u64 *)a, (u64 *)out, n, dev_err);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+int gfa_wide_power(gfa_wfield_t *w, const void *a, int64_t sa, const void *exps, int64_t se, const int8_t *sign, void *out, int64_t n,
+                   gfa_stream_t stream, int32_t *dev_err)
+{
+    if (!w || !a || !exps || !sign || !out || n < 0) { set_error("gfa_wide_power: bad arguments"); return GFA_ERR_INVALID; }
+    if (n == 0) return GFA_OK;
+    const int grid = (int)std::min<i64>((n + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(wide_power_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w->f, (const u64 *)a, (int)sa, (const u64 *)exps, (int)se, sign,
+                       (u64 *)out, n, dev_err);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+} // extern "C"

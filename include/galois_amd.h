@@ -146,6 +146,24 @@ int gfa_log_prepare(gfa_field_t *f, const uint64_t *primes, const uint32_t *mult
 int gfa_log(gfa_field_t *f, const void *a, int64_t a_stride, const void *base, int64_t base_stride, int64_t *out, int64_t n,
             int dtype, gfa_stream_t stream, int32_t *dev_err);
 
+/* ---- Fields of order 2^64 <= q < 2^128 (the reference's dtype=object fields: _fields/_ufunc.py:36-48 selects [np.object_],
+ * _domains/_meta.py:39-41 the python-calculate mode; same scalar formulas _domains/_calculate.py:133-592) ----------------- *
+ * Elements are two little-endian uint64 limbs, interleaved (element i at words 2i, 2i+1).  kind: 1 = GF(p), p >= 2^64
+ * (Montgomery), 2 = GF(2^m), 64 < m <= 127, 3 = GF(p^m) with p < 2^32.  `params` (27 uint64 words, computed by the host):
+ * [0:2] p, [2] -p^-1 mod 2^64, [3:5] 2^256 mod p, [5:7] p - 2 (kind 1) or 2^m - 2 (kind 2), [7:9] the irreducible polynomial
+ * without x^m (kind 2), [9:11] (q-1)/(p-1) - 1 (kind 3), [11:27] digits of the irreducible polynomial minus x^m, degree
+ * m-1..0 (kind 3).  Strides are 0 (broadcast scalar) or 1.  gfa_wide_power takes exponents the host has reduced into
+ * [0, q-1) (two limbs each) plus the SIGN of the original exponents (int8: -1, 0, 1), which decides the zero-base cases as
+ * power_square_and_multiply does (_calculate.py:558-592).  dev_err: sticky GFA_DEVERR_ZERO_DIVISION word, may be NULL. */
+typedef struct gfa_wfield gfa_wfield_t;
+int gfa_wfield_create(int kind, uint32_t m, const uint64_t *params, gfa_wfield_t **out);
+void gfa_wfield_destroy(gfa_wfield_t *w);
+int gfa_wide_binary(gfa_wfield_t *w, int op, const void *a, int64_t sa, const void *b, int64_t sb, void *out, int64_t n,
+                    gfa_stream_t stream, int32_t *dev_err);
+int gfa_wide_unary(gfa_wfield_t *w, int op, const void *a, void *out, int64_t n, gfa_stream_t stream, int32_t *dev_err);
+int gfa_wide_power(gfa_wfield_t *w, const void *a, int64_t sa, const void *exps, int64_t se, const int8_t *sign, void *out,
+                   int64_t n, gfa_stream_t stream, int32_t *dev_err);
+
 /* ---- NTT: replaces fft_jit/ifft_jit `self.jit(x.astype(int64), int64(omega), factors)` (_domains/_function.py:201) *
  * Computes out[k] = sum_j in[j] * omega^(j*k) for each of `batch` contiguous length-n rows, natural order in and
  * out.  `omega` must be a primitive n-th root of unity (for the inverse pass omega^-1, as fft_jit.__call__ does at

@@ -45,6 +45,26 @@ def small(a):
     return a
 
 
+def pack_sage_wide_fields():
+    """The three Sage folders of order >= 2^64 (GF(2^100), GF(36893488147419103183), GF(109987^4)): every number is stored
+    as a decimal string (elements, exponents and integer multiplicands exceed 64 bits, some are negative)."""
+    ops = ["add", "subtract", "multiply", "divide", "additive_inverse", "multiplicative_inverse", "scalar_multiply", "power"]
+    for folder in sorted(os.listdir(os.path.join(REF_TESTS, "fields", "data"))):
+        path = os.path.join(REF_TESTS, "fields", "data", folder)
+        props = json.load(open(os.path.join(path, "properties.json")))
+        if props["order"] < 2**64:
+            continue
+        out = {"properties": np.array(json.dumps(props))}
+        for op in ops:
+            d = pickle.load(open(os.path.join(path, op + ".pkl"), "rb"))
+            for k, v in d.items():
+                a = np.array(v, dtype=object)
+                out[f"{op}_{k}"] = np.array([str(int(t)) for t in a.ravel()]).reshape(a.shape)
+        name = folder.replace("(", "_").replace(")", "").replace("^", "e").replace(", ", "_")
+        np.savez_compressed(os.path.join(OUT_DIR, f"sage_wide_{name}.npz"), **out)
+        print("packed (wide)", folder)
+
+
 def pack_sage_fields():
     ops = ["add", "subtract", "multiply", "divide", "additive_inverse", "multiplicative_inverse", "scalar_multiply",
            "power"]
@@ -421,6 +441,7 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["fields", "rs", "reference", "bch", "reference_bch", "reference_wide", "linalg", "polys"]
     if "fields" in what:
         pack_sage_fields()
+        pack_sage_wide_fields()
     if "rs" in what:
         pack_sage_rs()
     if "reference" in what:

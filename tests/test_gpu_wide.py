@@ -1,0 +1,126 @@
+"""Fields of order 2^64 <= q < 2^128 on the device (galois_amd/_wide.py, csrc/gfa_wide.hip): the reference's three big Sage
+folders table for table (tests/fields/test_arithmetic.py:17-199 runs them as dtype=object arrays), random and edge-case
+operands against the Python-integer oracle, and the array surface (construction, indexing, broadcasting, errors)."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import galois_amd as ga
+from oracle.wide_oracle import WideOracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TAGS = ["GF_2e100", "GF_36893488147419103183", "GF_109987e4"]
+
+
+def _load(tag):
+    d = np.load(os.path.join(H.GOLDEN, f"sage_wide_{tag}.npz"))
+    props = json.loads(str(d["properties"]))
+    p, m = props["characteristic"], props["degree"]
+    if m == 1:
+        GF = ga.GF(p, primitive_element=props["primitive_element"])
+    else:
+        GF = ga.GF(p, m, irreducible_poly=props["irreducible_poly"], primitive_element=props["primitive_element"])
+    return GF, WideOracle(p, m, props["irreducible_poly"] if m > 1 else None), d, props
+
+
+def _obj(a):
+    a = np.asarray(a)
+    return np.array([int(v) for v in a.ravel()], dtype=object).reshape(a.shape)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_sage_vectors_of_the_big_fields(tag):
+    GF, W, d, props = _load(tag)
+    assert GF.order == props["order"] and GF.dtypes == [np.object_] and GF.characteristic == props["characteristic"]
+    for op, fn in [("add", np.add), ("subtract", np.subtract), ("multiply", np.multiply), ("divide", np.true_divide)]:
+        x, y = GF(_obj(d[f"{op}_X"])), GF(_obj(d[f"{op}_Y"]))
+        z = fn(x.reshape(-1, 1), y.reshape(1, -1))
+        assert type(z) is GF and z.dtype == np.dtype(object) and z.shape == (x.size, y.size)
+        H.assert_equal_ints(z.numpy(), _obj(d[f"{op}_Z"]), f"{tag} {op}")
+    x = GF(_obj(d["additive_inverse_X"]))
+    H.assert_equal_ints((-x).numpy(), _obj(d["additive_inverse_Z"]))
+    x = GF(_obj(d["multiplicative_inverse_X"]))
+    H.assert_equal_ints(np.reciprocal(x).numpy(), _obj(d["multiplicative_inverse_Z"]))
+    H.assert_equal_ints((x ** -1).numpy(), _obj(d["multiplicative_inverse_Z"]))
+    x = GF(_obj(d["power_X"]))
+    z = x.reshape(-1, 1) ** _obj(d["power_Y"]).reshape(1, -1)  # exponents of +-100 bits
+    H.assert_equal_ints(z.numpy(), _obj(d["power_Z"]), f"{tag} power")
+    x = GF(_obj(d["scalar_multiply_X"]))
+    z = x.reshape(-1, 1) * _obj(d["scalar_multiply_Y"]).reshape(1, -1)
+    H.assert_equal_ints(z.numpy(), _obj(d["scalar_multiply_Z"]), f"{tag} scalar multiply")
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_random_and_edge_operands_against_the_oracle(tag):
+    GF, W, d, props = _load(tag)
+    q, p = GF.order, GF.characteristic
+    rng = random.Random(7)
+    edge = [0, 1, 2, q - 1, q - 2, p - 1 if p < q else q - 1, (1 << 64) - 1, 1 << 64, (1 << 64) + 1, q // 2, q // 3]
+    edge = [v % q for v in edge]
+    a = edge + [rng.randrange(q) for _ in range(400)]
+    b = [rng.choice(edge) for _ in range(len(edge))] + [rng.randrange(q) for _ in range(400)]
+    A, B = GF(np.array(a, dtype=object)), GF(np.array(b, dtype=object))
+    assert [int(v) for v in (A + B).numpy()] == [W.add(x, y) for x, y in zip(a, b)]
+    assert [int(v) for v in (A - B).numpy()] == [W.sub(x, y) for x, y in zip(a, b)]
+    assert [int(v) for v in (A * B).numpy()] == [W.mul(x, y) for x, y in zip(a, b)]
+    assert [int(v) for v in (-A).numpy()] == [W.neg(x) for x in a]
+    bnz = [y if y else 1 for y in b]
+    Bnz = GF(np.array(bnz, dtype=object))
+    assert [int(v) for v in (A / Bnz).numpy()] == [W.div(x, y) for x, y in zip(a, bnz)]
+    assert [int(v) for v in np.reciprocal(Bnz).numpy()] == [W.inv(y) for y in bnz]
+    es = [0, 1, 2, -1, -2, q - 1, q, -(q - 1), 3 * q + 5] + [rng.randrange(-q, q) for _ in range(40)]
+    sub = a[:len(es)]
+    subnz = [x if x else 3 for x in sub]
+    got = GF(np.array(subnz, dtype=object)) ** np.array(es, dtype=object)
+    assert [int(v) for v in got.numpy()] == [W.pow(x, e) for x, e in zip(subnz, es)]
+    assert int(GF(0) ** 0) == 1 and int(GF(0) ** 5) == 0 and int(np.square(GF(q - 1))) == W.mul(q - 1, q - 1)
+    assert [int(v) for v in (A * 12345678901234567890123).numpy()] == [W.mul(x, 12345678901234567890123 % p) for x in a]
+    # broadcasting against a scalar, and the reference's error behaviour
+    assert [int(v) for v in (A * GF(7)).numpy()] == [W.mul(x, 7 % q) for x in a]
+    with pytest.raises(ZeroDivisionError):
+        A / GF(np.array([0] * len(a), dtype=object))
+    with pytest.raises(ZeroDivisionError):
+        np.reciprocal(GF(0))
+    with pytest.raises(ZeroDivisionError):
+        GF(0) ** -3
+    with pytest.raises(ValueError):
+        GF(q)
+    with pytest.raises(ValueError):
+        GF(-1)
+    with pytest.raises(TypeError):
+        A + 1
+    with pytest.raises(TypeError):
+        GF([1, 2], dtype=np.int64)
+    with pytest.raises(NotImplementedError):
+        np.add.reduce(A)
+
+
+def test_array_surface_of_a_big_field():
+    GF, W, d, props = _load("GF_36893488147419103183")
+    q = GF.order
+    x = GF(np.array([[1, 2, q - 1], [q - 2, 5, 0]], dtype=object))
+    assert x.shape == (2, 3) and x.ndim == 2 and x.size == 6 and len(x) == 2
+    assert int(x[0, 2]) == q - 1 and [int(v) for v in x[1].numpy()] == [q - 2, 5, 0]
+    assert x.T.shape == (3, 2) and int(x.T[2, 0]) == q - 1
+    y = x.reshape(3, 2)
+    assert y.shape == (3, 2) and [int(v) for v in y.flatten().numpy()] == [1, 2, q - 1, q - 2, 5, 0]
+    x[0, 0] = q - 5
+    assert int(x[0, 0]) == q - 5
+    assert (x == x.copy()).all() and not (x == GF.Zeros((2, 3))).all()
+    z = np.add.outer(GF(np.array([1, 2], dtype=object)), GF(np.array([q - 1, 0, 3], dtype=object)))
+    assert z.shape == (2, 3) and [int(v) for v in z.numpy().ravel()] == [0, 1, 4, 1, 2, 5]
+    qd, r = divmod(x, GF(np.array(3, dtype=object)))
+    assert [int(v) for v in r.numpy().ravel()] == [0] * 6 and [int(v) for v in qd.numpy().ravel()] == [W.div(int(v), 3) for v in x.numpy().ravel()]
+    out = GF.Zeros((2, 3))
+    r2 = np.multiply(x, x, out=out)
+    assert r2 is out and [int(v) for v in out.numpy().ravel()] == [W.mul(int(v), int(v)) for v in x.numpy().ravel()]
+    rr = GF.Random((4, 5), seed=3)
+    assert rr.shape == (4, 5) and all(0 <= int(v) < q for v in rr.numpy().ravel())
+    assert repr(GF(np.array([1, 2], dtype=object))).startswith("GF([1, 2]")
+    with pytest.raises(NotImplementedError):
+        ga.GF(2**127 - 1, 2, irreducible_poly=[1, 0, 1], verify=False)  # order >= 2^128: no device representation
