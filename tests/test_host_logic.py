@@ -62,8 +62,11 @@ def test_flyweights_and_properties():
         ga.GF(31, primitive_element=5)
     with pytest.raises(TypeError):
         ga.GF(2.0)
+    # orders in [2^64, 2^128) get the two-limb device representation (the reference: dtype=object); above that there is none
+    big = ga.GF(36893488147419103183, primitive_element=3)
+    assert big.dtypes == [np.object_] and big.order == 36893488147419103183 and big.ufunc_modes == ["jit-calculate"]
     with pytest.raises(NotImplementedError):
-        ga.GF(2**100)
+        ga.GF(2**127 - 1, 2, irreducible_poly=[1, 0, 1], verify=False)
 
 
 def test_dtypes_follow_the_reference_rules():
