@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-extras", action="store_true", help="skip the NTT / Reed-Solomon side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure the HBM traffic")
     ap.add_argument("--dist-extras", action="store_true",
                     help="run the multi-GPU side measurements (sharded RS / NTT, distributed C5 transform) even at world size 1")
     args = ap.parse_args()
@@ -129,13 +130,19 @@ def main():
     # HBM traffic per launch from the PMC counters: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
     # tools/headline_only.py (same kernel, same 1e8-element inputs), corrected as MI355X_MICROARCH.md prescribes;
     # the raw counter files and the derivation are committed under profiles/ (PMC passes cannot run inside this process)
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_headline.json")
-    if os.path.exists(pmc_path):
-        traffic = json.load(open(pmc_path))["traffic_bytes_per_launch"]
+    traffic, traffic_source = None, None
+    if rank == 0 and world == 1 and not args.no_pmc:
+        traffic, traffic_source = measure_traffic()  # live: two rocprofv3 --pmc passes over tools/headline_only.py
+    if traffic is None:
+        for name in ("r02_pmc_headline.json", "r01_pmc_headline.json"):
+            pmc_path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc_path):
+                traffic = json.load(open(pmc_path))["traffic_bytes_per_launch"]
+                traffic_source = f"committed profile profiles/{name} (PMC passes not run in this invocation)"
+                break
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": "tab8_binary_kernel",
-                "kernel_ms": round(ms.value, 5), "algorithmic_bytes_per_launch": alg_bytes}
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": "tab8_binary_kernel", "kernel_ms": round(ms.value, 5), "algorithmic_bytes_per_launch": alg_bytes}
 
     result = None
     if rank == 0:
@@ -206,6 +213,47 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measure_traffic():
+    """HBM bytes per launch of the headline kernel from the PMC counters, measured NOW: separate rocprofv3 passes for
+    FETCH_SIZE and WRITE_SIZE over tools/headline_only.py (same kernel, same 1e8-element inputs; --kernel-trace only, as the
+    guide prescribes), corrected as MI355X_MICROARCH.md's HBM section says for gfx950: FETCH_SIZE counts a wide coalesced
+    streaming read at half its bytes.  Returns (bytes, description) or (None, None) when rocprofv3 is not usable here."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, None
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="gfa_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                                sys.executable, os.path.join(ROOT, "tools", "headline_only.py"), "6"],
+                               cwd="/tmp", env=env, capture_output=True, timeout=300)
+            got = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "tab8_binary" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        got.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not got:
+                return None, None
+            vals[counter] = sum(got) / len(got)  # KiB per dispatch
+        read_b = 2.0 * vals["FETCH_SIZE"] * 1024.0
+        write_b = vals["WRITE_SIZE"] * 1024.0
+        return read_b + write_b, ("live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in this run "
+                                  f"(reported {vals['FETCH_SIZE']:.1f} / {vals['WRITE_SIZE']:.1f} KiB per launch; reads = 2 x FETCH_SIZE on gfx950)")
+    except Exception:
+        return None, None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def extras_distributed(ga, L, lib, stream, dist, rank, world):

@@ -1,22 +1,30 @@
 #!/bin/bash
-# Regenerates the text profiles under profiles/ in ONE call on the GPU box (about 2 GPU-minutes):
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r02'
-# then copy gpurun_out/<round>_*.txt / .json / .csv into profiles/.  PMC passes are separate.
+# Regenerates the text profiles under profiles/ in ONE call on the GPU box (about 5 GPU-minutes):
+#   /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/refresh_profiles.sh r02'
+# then copy gpurun_out/<round>_*.txt / .json / .csv into profiles/.
 set -u
-R=${1:-r01}
+R=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd "$ROOT"
 python bench.py > "$OUT/${R}_bench_final.json" 2> "$OUT/${R}_bench_final.err"
+python bench.py --steps 50 --warmup 5 --dist-extras --no-cpu-baseline --no-pmc > "$OUT/${R}_bench_dist_world1.json" 2>/dev/null
+python tools/ew_bench.py 2>/dev/null | grep field > "$OUT/${R}_ew_bench.txt"
+python tools/fermat_time.py 64 256 1024 4096 2>/dev/null | grep batch > "$OUT/${R}_ntt_fermat_batches.txt"
+python tools/fermat_phases.py 1024 2>/dev/null | grep -E "round|phase|spread" > "$OUT/${R}_ntt_fermat_phases.txt"
+{ echo "# lazy 96-bit registers (default)"; python tools/goldi_time.py 2>/dev/null | grep "2^"; echo "# GFA_NTT_GL=0: plain 64-bit modular arithmetic"; GFA_NTT_GL=0 python tools/goldi_time.py 2>/dev/null | grep "2^"; } > "$OUT/${R}_ntt_goldilocks.txt"
+python tools/ntt_time.py 2>/dev/null | grep "p=" > "$OUT/${R}_ntt_time.txt"
 python tools/c5_local_bench.py > "$OUT/${R}_c5_goldilocks_local.txt" 2>/dev/null
 python tools/ntt_large.py 20 21 22 24 26 28 > "$OUT/${R}_ntt_large.txt" 2>/dev/null
-python tools/ntt3_tune.py > "$OUT/${R}_ntt3_tune.txt" 2>/dev/null
+./tools/ubench/valu_rates2 > "$OUT/${R}_valu_issue_rates.txt" 2>/dev/null
 python tools/wide_codes_bench.py > "$OUT/${R}_wide_codes_bench.txt" 2>/dev/null
 python tools/linalg_bench.py > "$OUT/${R}_linalg_bench.txt" 2>/dev/null
-python tools/headline_sizes.py > "$OUT/${R}_headline_sizes.txt" 2>/dev/null
-{ echo "# GFA_CONVOLVE_CRT=0 (direct kernel)"; GFA_CONVOLVE_CRT=0 python tools/convolve_bench.py 2>/dev/null
-  echo "# GFA_CONVOLVE_CRT_MIN=0 (CRT route wherever it applies)"; GFA_CONVOLVE_CRT_MIN=0 python tools/convolve_bench.py 256 1024 4096 16384 65536 1048576 2>/dev/null; } > "$OUT/${R}_convolve_bench.txt"
-( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_$R && rocprofv3 --kernel-trace --stats -d /tmp/prof_$R -o bench -- python "$ROOT/bench.py" --no-cpu-baseline > /dev/null 2>&1
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_$R && rocprofv3 --kernel-trace --stats -d /tmp/prof_$R -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --no-pmc > /dev/null 2>&1
   DB=$(find /tmp/prof_$R -name "*.db" | head -1); [ -n "$DB" ] && python "$ROOT/tools/export_rocprof_stats.py" "$DB" "$OUT/${R}_bench_kernel_stats.csv" )
-ls -la "$OUT" | tail -12
+bash tools/pmc_run.sh ${R}_pmc_headline tab8_binary -- python tools/headline_only.py 6 > /dev/null 2>&1
+bash tools/pmc_run.sh ${R}_pmc_ntt_fermat ntt_fermat16 -- python tools/fermat_time.py 1024 > /dev/null 2>&1
+bash tools/pmc_run.sh ${R}_pmc_ntt_2e20x64 ntt_reg_kernel -- python tools/ntt_only.py 6 > /dev/null 2>&1
+bash tools/pmc_run.sh ${R}_pmc_ntt_goldilocks ntt_reg_kernel_gl -- python tools/goldi_time.py > /dev/null 2>&1
+bash tools/pmc_run.sh ${R}_pmc_rs_decode rs_ -- python tools/rs_decode_only.py 5 > /dev/null 2>&1
+ls -la "$OUT" | tail -30
