@@ -750,12 +750,20 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
                         const u32 d0 = (u32)__builtin_amdgcn_readlane((int)X, 32);
                         const u32 A = (u32)__builtin_amdgcn_update_dpp((int)X, (int)X, 0x130, 0xC, 0xf, true);  // wave_shl:1, rows 2-3
                         const u32 Bv = (u32)__builtin_amdgcn_update_dpp((int)Y, (int)Y, 0x138, 0x3, 0xf, true); // wave_shr:1, rows 0-1
-                        const u32 t1 = ar.mul_t[(gamma << 8) | A];
-                        const u32 t2 = ar.mul_t[(d0 << 8) | Bv];
-                        const bool change = d0 != 0 && 2 * L <= r;
-                        Y = change ? A : Bv;
-                        X = t1 ^ t2;
-                        if (change) { L = r + 1 - L; gamma = d0; }
+                        // A zero discrepancy (wave-uniform: every step after the 2v-th of a word with v errors) would only
+                        // scale X by gamma.  The scale of X never matters (Y and gamma take their values from X itself, so
+                        // all three stay consistent multiples), so those steps are the shift alone: no table gathers.
+                        if (d0 == 0) {
+                            X = A;
+                            Y = Bv;
+                        } else {
+                            const u32 t1 = ar.mul_t[(gamma << 8) | A];
+                            const u32 t2 = ar.mul_t[(d0 << 8) | Bv];
+                            const bool change = 2 * L <= r;
+                            Y = change ? A : Bv;
+                            X = t1 ^ t2;
+                            if (change) { L = r + 1 - L; gamma = d0; }
+                        }
                     }
                     Creg = lane < 32 ? X : 0u;
                 } else {
