@@ -446,6 +446,15 @@ def extras(ga, L, lib, stream, with_cpu):
             entry["2^20_pt_ntt_per_s"] = entry["transforms_per_s"]
         else:
             entry["2^20_points_per_s_equiv"] = round(points / (1 << 20) / (ms.value * 1e-3), 1)
+            # the same kernel on a batch far larger than the 256 MiB Infinity Cache (4096 transforms: 1 GiB in, 1 GiB out): the
+            # HBM-only rate -- at 1024 transforms the 256 MiB input is partly served by the cache from one launch to the next
+            big = 4096
+            xb = torch.empty((big, N), dtype=torch.int32, device="cuda").random_(0, p)
+            ob = torch.empty_like(xb)
+            L.check(lib.gfa_time_ntt(P._handle, xb.data_ptr(), ob.data_ptr(), N, big, omega, L.U32, stream, 5, ctypes.byref(ms)))
+            entry["hbm_only_batch_4096"] = {"ms_per_launch": round(ms.value, 4), "transforms_per_s": round(big / (ms.value * 1e-3), 1),
+                                            "roofline_frac": round(8.0 * big * N / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            del xb, ob
         # parity of one transform against the oracle port
         FP = O.OracleField(p, 1, None, P._primitive_element_int)
         ref = FP.ntt_u32_pow2(xh[0], omega)

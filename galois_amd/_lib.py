@@ -15,7 +15,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgalois_amd.so")
+LIB_PATH = os.environ.get("GALOIS_AMD_LIB") or os.path.join(_HERE, "libgalois_amd.so")  # (override: tuning builds only)
 
 OK, ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM = 0, 1, 2, 3, 4
 U8, U16, U32, U64 = 0, 1, 2, 3

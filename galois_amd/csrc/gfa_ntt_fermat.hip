@@ -97,7 +97,22 @@ __device__ __forceinline__ u32 fm_canon(int c)
 // the next transform.  LDS operations of a wave complete in order, so lgkmcnt(0) + s_barrier is all the exchange needs.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-constexpr int AUX_NT = 2; // streaming (non-temporal) hint on the data loads / stores: keep the shared twiddle table in L2
+// Cache hints, measured (tools/fermat_variants.sh, two repetitions): non-temporal STORES (the output is never re-read by
+// this kernel; keeps the shared twiddle table in L2) but default-policy LOADS -- with non-temporal loads a batch whose
+// input is about the size of the 256 MiB Infinity Cache (1024 transforms = 256 MiB) loses the hits it otherwise gets from one
+// launch to the next: 0.125 vs 0.139 ms per 1024 transforms; at 4096 transforms (1 GiB, no reuse possible) the four
+// combinations are within noise of each other (0.553 - 0.575 ms).
+#ifndef GFA_FERMAT_AUX_LD
+#define GFA_FERMAT_AUX_LD 0
+#endif
+#ifndef GFA_FERMAT_AUX_ST
+#define GFA_FERMAT_AUX_ST 2
+#endif
+#ifndef GFA_FERMAT_TWW
+#define GFA_FERMAT_TWW 32
+#endif
+constexpr int AUX_NT = GFA_FERMAT_AUX_LD; // streaming (non-temporal) hint on the data loads: keep the shared twiddle table in L2
+constexpr int AUX_ST = GFA_FERMAT_AUX_ST; // ... and on the stores
 
 template <bool NEGATE, bool DBG>
 __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
@@ -145,7 +160,7 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
         // ---- network 0: radix 64 over a (stride 1024); thread m = tid.  Twiddles w^(m * k0), k0 = 1..63, come from the
         // shared 256 KiB table (L2 resident): a rolling window of TWW values is requested ahead of its use so that the L2
         // latency hides behind the network and the products themselves
-        constexpr int TWW = 32;
+        constexpr int TWW = GFA_FERMAT_TWW;
         int tw[TWW];
 #pragma unroll
         for (int i = 0; i < TWW; i++) tw[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(tr, voff, (i + 1) * 4096, 0);
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
             // X[k0 + 64 * (k1 + 32 * k2)], k1 = wv + 16 h: lane offset tid
 #pragma unroll
             for (int k2 = 0; k2 < 32; k2++)
-                __builtin_amdgcn_raw_buffer_store_b32(fm_canon<NEGATE>(z[h][brev_c(k2, 5)]), yr, voff, (2048 * k2 + 1024 * h) * 4, AUX_NT);
+                __builtin_amdgcn_raw_buffer_store_b32(fm_canon<NEGATE>(z[h][brev_c(k2, 5)]), yr, voff, (2048 * k2 + 1024 * h) * 4, AUX_ST);
         };
         net2(0);
         FM_STAMP(6);
