@@ -779,6 +779,47 @@ __global__ __launch_bounds__(256) void ntt_stage_kernel(FieldDev fd, const typen
     }
 }
 
+// Any-radix transform of up to 4096 points entirely in LDS: one workgroup per transform, the same Stockham stages as
+// ntt_stage_kernel (index maps of _function.py:315-384) ping-ponging between two LDS buffers -- ONE launch instead of one per
+// prime factor (the reference's own FFT benchmark sizes are 256*K, K = 1..9: 768 = 2^8*3, 1280 = 2^8*5, 2304 = 2^8*9, ...).
+struct SmallArgs {
+    int nf;
+    int r[24]; // radix of stage s (taken from the end of the ascending factor list, as the reference does)
+};
+
+template <class F>
+__global__ __launch_bounds__(256) void ntt_small_kernel(FieldDev fd, const typename F::elem *__restrict__ in, typename F::elem *__restrict__ out, int n,
+                                                        SmallArgs sa, const typename F::elem *__restrict__ wpow, int do_scale, typename F::elem scale)
+{
+    typedef typename F::elem E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    E *buf0 = reinterpret_cast<E *>(smem_raw), *buf1 = buf0 + n;
+    const E *x = in + (i64)blockIdx.x * n;
+    for (int i = threadIdx.x; i < n; i += 256) buf0[i] = x[i];
+    __syncthreads();
+    E *src = buf0, *dst = buf1;
+    int m = 1;
+    for (int s = 0; s < sa.nf; s++) {
+        const int r = sa.r[s], q = n / (m * r);
+        const bool last = s == sa.nf - 1;
+        for (int o = threadIdx.x; o < n; o += 256) {
+            const int b = o % m, f = (o / m) % r, qi = o / (m * r);
+            const E tw = wpow[((i64)q * (f * m + b)) % n];
+            E acc = src[((r - 1) * q + qi) * m + b];
+            for (int k = r - 2; k >= 0; k--) acc = F::add(fd, F::mul(fd, acc, tw), src[(k * q + qi) * m + b]);
+            if (last) {
+                if (do_scale) acc = F::mul(fd, acc, scale);
+                out[(i64)blockIdx.x * n + o] = acc;
+            } else {
+                dst[o] = acc;
+            }
+        }
+        __syncthreads();
+        E *t = src; src = dst; dst = t;
+        m *= r;
+    }
+}
+
 template <typename E>
 __global__ void convert_in_kernel(const void *src, int dtype, E *dst, i64 n)
 {
@@ -1413,6 +1454,21 @@ int run_generic(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n, 
     const int S = (int)pl->factors.size();
     if (S == 0) { // n == 1
         if (in != out) GFA_HIP(hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, st));
+        return GFA_OK;
+    }
+    if (n <= 4096 && S <= 24 && batch <= 0x7fffffff) { // whole transform in one workgroup's LDS: one launch
+        SmallArgs sa{};
+        sa.nf = S;
+        for (int s = 0; s < S; s++) sa.r[s] = (int)pl->factors[S - 1 - s];
+        auto kern = ntt_small_kernel<F>;
+        static bool attr = false;
+        if (!attr) {
+            GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(256), 2 * sizeof(E) * (size_t)n, st, fd, (const E *)in, (E *)out, (int)n, sa,
+                           (const E *)pl->wpow, do_scale, (E)scale);
+        GFA_HIP(hipGetLastError());
         return GFA_OK;
     }
     if ((rc = pl->sc->ws0.ensure(bytes))) return rc;
