@@ -519,3 +519,90 @@ def test_numpy_functions_stay_in_the_field_or_raise():
     for f in (np.around, np.gradient, np.cross, np.median, np.mean, np.sort):
         with pytest.raises(NotImplementedError):
             f(a) if f is not np.cross else f(a, a)
+
+
+def _big_case(q, dt, n, seed, mode="jit-calculate", GF=None):
+    GF = GF or ga.GF(q)
+    F = O.OracleField(GF.characteristic, GF.degree, int(GF.irreducible_poly) if GF.degree > 1 else None, int(GF.primitive_element))
+    if mode in GF.ufunc_modes:
+        GF.compile(mode)
+    rng = np.random.default_rng(seed)
+    if q > 2**63:
+        a = (rng.integers(0, 2**63, n, dtype=np.uint64) * 2 + 1) % np.uint64(q)
+        b = (rng.integers(0, 2**63, n, dtype=np.uint64) * 2 + 1) % np.uint64(q)
+    else:
+        a = rng.integers(0, q, n, dtype=np.uint64)
+        b = rng.integers(0, q, n, dtype=np.uint64)
+    for arr in (a, b):
+        arr[:6] = [0, 1, q - 1, q - 2, 2, q // 2]
+    bnz = np.where(b == 0, np.uint64(1), b)
+    mk = (lambda v: GF._wrap(__import__("torch").from_numpy(v.view(np.int64)).cuda(), np.object_)) if dt is None else (lambda v: GF(v.astype(dt), dtype=dt))
+    u = lambda x: x._t.cpu().numpy().view(np.uint64) if dt is None else x.numpy().astype(np.uint64)
+    return GF, F, a, b, bnz, mk, u
+
+
+@pytest.mark.parametrize("q,dt", [(65537, np.uint32), (7340033, np.uint32), (65521, np.uint16), (251, np.uint8), (2**61 - 1, None),
+                                  (2**64 - 2**32 + 1, None)])
+def test_prime_field_reciprocal_and_division_on_large_arrays(q, dt):
+    """Large odd-length arrays take the 16-elements-per-lane Montgomery-trick inversion (one exponentiation per 16 elements,
+    vectors nth apart); zeros inside a batch must not disturb their neighbours and must raise."""
+    n = 1_200_003
+    GF, F, a, b, bnz, mk, u = _big_case(q, dt, n, 11)
+    try:
+        A, Bnz = mk(a), mk(bnz)
+        assert np.array_equal(u(np.reciprocal(Bnz)), F.recip(bnz))
+        assert np.array_equal(u(A / Bnz), F.div(a, bnz))
+        assert np.array_equal(u(A / mk(bnz[:1])[0]), F.div(a, np.full(n, bnz[0], dtype=np.uint64)))  # scalar divisor
+        with pytest.raises(ZeroDivisionError):
+            np.reciprocal(mk(b))
+        with pytest.raises(ZeroDivisionError):
+            A / mk(b)
+    finally:
+        GF.compile("auto")
+
+
+@pytest.mark.parametrize("q,dt", [(2**8, np.uint8), (2**3, np.uint8), (2**10, np.uint16), (2**12, np.uint16), (2**16, np.uint16), (2**5, np.uint16),
+                                  (2**20, np.uint32), (2**32, np.uint32), (2**8, np.int64)])
+def test_binary_field_calculate_mode_products_on_large_arrays(q, dt):
+    """Packed shift-and-xor products (four uint8 / two uint16 elements per register), the branch-free 32-bit product, tails,
+    scalar operands and misaligned views, against the oracle."""
+    n = 1_000_003
+    GF, F, a, b, bnz, mk, u = _big_case(q, dt, n, 12)
+    try:
+        A, B = mk(a), mk(b)
+        want = F.mul(a, b)
+        assert np.array_equal(u(A * B), want)
+        assert np.array_equal(u(A * B[3]), F.mul(a, np.full(n, b[3], dtype=np.uint64)))
+        assert np.array_equal(u(A[5] * B), F.mul(np.full(n, a[5], dtype=np.uint64), b))
+        assert np.array_equal(u(A[1:] * B[1:]), want[1:])                     # views that are not 16-byte aligned
+        assert np.array_equal(u(A[:1000] / mk(bnz)[:1000]), F.div(a[:1000], bnz[:1000]))
+        e = np.random.default_rng(5).integers(-20, 300, 2000)
+        anz = np.where(a[:2000] == 0, np.uint64(1), a[:2000])
+        assert np.array_equal(u(mk(anz) ** e), F.pow(anz, e))
+    finally:
+        GF.compile("auto")
+
+
+@pytest.mark.parametrize("q", [7**2, 251**2, 2147483647**2, 46351**2, 3**4, 5**4, 13**4, 3**5, 3**6, 11**6, 7**3, 251**3, 31**5])
+def test_extension_fields_of_every_templated_degree(q):
+    """GF(p^m), 2 <= m <= 6, calculate mode: the per-degree kernels (digits in registers, unreduced 64-bit accumulation -- the
+    largest p for m = 2 sits at the accumulation bound 3 p^2 < 2^64) against the oracle."""
+    p, m = ga._numtheory.prime_power(q)
+    # p = 3 (mod 4): x^2 + 1 is irreducible (no Conway polynomial is shipped for these two characteristics)
+    GF0 = ga.GF(p, m, irreducible_poly=[1, 0, 1]) if q in (2147483647**2, 46351**2) else ga.GF(q)
+    dt = GF0.dtypes[0] if GF0.dtypes != [np.object_] else None
+    n = 50_003
+    GF, F, a, b, bnz, mk, u = _big_case(q, dt, n, 13, GF=GF0)
+    try:
+        A, B = mk(a), mk(b)
+        assert np.array_equal(u(A + B), F.add(a, b))
+        assert np.array_equal(u(A - B), F.sub(a, b))
+        assert np.array_equal(u(-A), F.neg(a))
+        assert np.array_equal(u(A * B), F.mul(a, b))
+        assert np.array_equal(u(A[:3000] / mk(bnz)[:3000]), F.div(a[:3000], bnz[:3000]))
+        e = np.random.default_rng(6).integers(-20, 300, 3000)
+        anz = np.where(a[:3000] == 0, np.uint64(1), a[:3000])
+        assert np.array_equal(u(mk(anz) ** e), F.pow(anz, e))
+        assert np.array_equal(u(A * 12345), F.mul(a, np.full(n, 12345 % GF.characteristic, dtype=np.uint64)))
+    finally:
+        GF.compile("auto")

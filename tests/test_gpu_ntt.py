@@ -544,3 +544,28 @@ def test_c_abi_distributed_transform_owns_its_rccl_exchange():
         torch.cuda.synchronize()
     finally:
         rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("logn", [6, 10, 13, 20])
+def test_goldilocks_lazy_arithmetic_at_the_extremes(logn):
+    """The 96-bit lazy butterflies of the Goldilocks kernel on worst-case inputs (all p - 1, alternating 0 / p - 1, words that
+    sit on the 2^32 limb boundaries, an impulse) and random data, every output against the oracle; forward and inverse."""
+    p = 2**64 - 2**32 + 1
+    GF = ga.GF(p)
+    F = O.OracleField(p, 1, None, GF._primitive_element_int)
+    n = 1 << logn
+    omega = GF._root_of_unity_int(n)
+    rng = np.random.default_rng(logn)
+    edge = np.array([p - 1, p - 2, 2**32 - 1, 2**32, 2**32 + 1, 2**64 - 2**32, 0, 1, 2**63, 0xFFFFFFFF00000000 - 1], dtype=np.uint64)
+    rows = [np.full(n, p - 1, dtype=np.uint64), np.tile(np.array([0, p - 1], dtype=np.uint64), n // 2),
+            np.concatenate([[p - 1], np.zeros(n - 1)]).astype(np.uint64), rng.choice(edge, n),
+            (rng.integers(0, 2**63, n, dtype=np.uint64) * 2 + 1) % np.uint64(p)]
+    import torch
+    from galois_amd._ntt import fft_batched
+
+    X = fft_batched(GF._wrap(torch.from_numpy(np.stack(rows).view(np.int64)).cuda(), np.object_))
+    got = X._t.cpu().numpy().view(np.uint64)
+    for i, r in enumerate(rows):
+        assert np.array_equal(got[i], F.ntt(r.copy(), omega=omega)), f"row {i}"
+    back = fft_batched(X, inverse=True)._t.cpu().numpy().view(np.uint64)
+    assert np.array_equal(back, np.stack(rows))
