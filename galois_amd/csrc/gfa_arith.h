@@ -67,6 +67,8 @@ GFA_HD int clz64(u64 x)
 #endif
 }
 
+GFA_HD int clz32(u32 x) { return clz64((u64)x) - 32; }
+
 // ------------------------------------------------------------------------------------------------
 // GF(p), p < 2^32
 // ------------------------------------------------------------------------------------------------
@@ -101,8 +103,34 @@ struct Prime32 {
         }
         return r;
     }
-    // a != 0.  Fermat: a^(p-2).  (Same value as the reference's extended Euclid, _calculate.py:395-417.)
-    static GFA_HD u32 inv(const FieldDev &f, u32 a) { return pow_u(f, a, f.p - 2); }
+    // Montgomery reduction of x < p * 2^32 for odd p < 2^31: (x + (x * ninv mod 2^32) * p) / 2^32, ninv = -p^-1 mod 2^32
+    static GFA_HD u32 redc32(u64 x, u32 p, u32 ninv)
+    {
+        const u32 m = (u32)x * ninv;
+        const u64 t = (x + (u64)m * p) >> 32; // < 2p; the sum stays below 2^64 because x, m * p < p * 2^32 <= 2^63
+        return (u32)(t >= p ? t - p : t);
+    }
+    // a != 0.  Fermat: a^(p-2) (same value as the reference's extended Euclid, _calculate.py:395-417).  For odd p the whole
+    // exponentiation runs in Montgomery form -- 6 instructions per product instead of the 14 of a 64-bit Barrett reduction;
+    // the constants come from the descriptor: 2^64 mod p = -mu * p (mod 2^64), -p^-1 by Newton's iteration.
+    static GFA_HD u32 inv(const FieldDev &f, u32 a)
+    {
+        const u32 p = (u32)f.p;
+        if (!(p & 1)) return a;                         // GF(2): the only non-zero element
+        if (p >> 31) return pow_u(f, a, f.p - 2);        // 2^31 < p < 2^32: the 64-bit sum inside redc32 could overflow
+        u32 pinv = p;           // p * pinv == 1 (mod 2^32): 3 correct bits to start with, doubled by every step
+        for (int i = 0; i < 4; i++) pinv *= 2u - p * pinv;
+        const u32 ninv = 0u - pinv;
+        const u32 r2 = (u32)((u64)0 - f.mu * f.p); // 2^64 mod p  (mu = floor(2^64 / p))
+        const u32 am = redc32((u64)a * r2, p, ninv);
+        u32 r = redc32((u64)r2, p, ninv);          // 1 in Montgomery form
+        const u32 e = p - 2;
+        for (int i = 31 - clz32(e); i >= 0; i--) {
+            r = redc32((u64)r * r, p, ninv);
+            if ((e >> i) & 1) r = redc32((u64)r * am, p, ninv);
+        }
+        return redc32((u64)r, p, ninv);
+    }
     static GFA_HD u32 from_int(const FieldDev &f, i64 k)
     { // integer -> prime subfield (np.mod(int, characteristic), _ufunc.py:399)
         i64 r = k % (i64)f.p;
