@@ -93,7 +93,7 @@ struct Prime32 {
     static GFA_HD u32 neg(const FieldDev &f, u32 a) { return a == 0 ? 0 : (u32)(f.p - a); }
     static GFA_HD u32 mul(const FieldDev &f, u32 a, u32 b) { return reduce64(f, (u64)a * b); }
     static GFA_HD u32 one(const FieldDev &) { return 1; }
-    static GFA_HD u32 pow_u(const FieldDev &f, u32 a, u64 e)
+    static GFA_HD u32 pow_barrett(const FieldDev &f, u32 a, u64 e)
     {
         u32 r = 1;
         while (e) {
@@ -110,27 +110,27 @@ struct Prime32 {
         const u64 t = (x + (u64)m * p) >> 32; // < 2p; the sum stays below 2^64 because x, m * p < p * 2^32 <= 2^63
         return (u32)(t >= p ? t - p : t);
     }
-    // a != 0.  Fermat: a^(p-2) (same value as the reference's extended Euclid, _calculate.py:395-417).  For odd p the whole
-    // exponentiation runs in Montgomery form -- 6 instructions per product instead of the 14 of a 64-bit Barrett reduction;
-    // the constants come from the descriptor: 2^64 mod p = -mu * p (mod 2^64), -p^-1 by Newton's iteration.
-    static GFA_HD u32 inv(const FieldDev &f, u32 a)
+    // a^e.  For odd p < 2^31 the whole exponentiation runs in Montgomery form -- 6 instructions per product instead of the
+    // 14 of a 64-bit Barrett reduction; the constants come from the descriptor: 2^64 mod p = -mu * p (mod 2^64), -p^-1 by
+    // Newton's iteration.  (2^31 < p < 2^32: the 64-bit sum inside redc32 could overflow; p = 2 has nothing to reduce.)
+    static GFA_HD u32 pow_u(const FieldDev &f, u32 a, u64 e)
     {
         const u32 p = (u32)f.p;
-        if (!(p & 1)) return a;                         // GF(2): the only non-zero element
-        if (p >> 31) return pow_u(f, a, f.p - 2);        // 2^31 < p < 2^32: the 64-bit sum inside redc32 could overflow
-        u32 pinv = p;           // p * pinv == 1 (mod 2^32): 3 correct bits to start with, doubled by every step
+        if (!(p & 1) || (p >> 31) || e < 4) return pow_barrett(f, a, e);
+        u32 pinv = p; // p * pinv == 1 (mod 2^32): 3 correct bits to start with, doubled by every step
         for (int i = 0; i < 4; i++) pinv *= 2u - p * pinv;
         const u32 ninv = 0u - pinv;
         const u32 r2 = (u32)((u64)0 - f.mu * f.p); // 2^64 mod p  (mu = floor(2^64 / p))
         const u32 am = redc32((u64)a * r2, p, ninv);
-        u32 r = redc32((u64)r2, p, ninv);          // 1 in Montgomery form
-        const u32 e = p - 2;
-        for (int i = 31 - clz32(e); i >= 0; i--) {
+        u32 r = am; // the leading one of e
+        for (int i = 62 - clz64(e); i >= 0; i--) {
             r = redc32((u64)r * r, p, ninv);
             if ((e >> i) & 1) r = redc32((u64)r * am, p, ninv);
         }
         return redc32((u64)r, p, ninv);
     }
+    // a != 0.  Fermat: a^(p-2) (same value as the reference's extended Euclid, _calculate.py:395-417).
+    static GFA_HD u32 inv(const FieldDev &f, u32 a) { return f.p == 2 ? a : pow_u(f, a, f.p - 2); }
     static GFA_HD u32 from_int(const FieldDev &f, i64 k)
     { // integer -> prime subfield (np.mod(int, characteristic), _ufunc.py:399)
         i64 r = k % (i64)f.p;
