@@ -1231,6 +1231,17 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
+    {
+        // 256 < q <= 8192 on uint16 storage: tables in LDS.  In lookup mode for every non-trivial operation; in AUTO on the fields
+        // whose products are calculated (GF(2^m), GF(p)) for division only, which would otherwise be an exponentiation.
+        const FieldDev &c = f->calc;
+        const bool trivial_addsub = (op == GFA_OP_ADD || op == GFA_OP_SUB) && (c.p == 2 || c.m == 1);
+        if (!trivial_addsub && f->mode != GFA_MODE_CALCULATE && (f->use_lookup() || op == GFA_OP_DIV) &&
+            mid_eligible(c, ds->mid16, dtype, n)) {
+            rc = mid_binary(f->lut_desc(*ds), ds->mid16, op, a, sa, b, sb, out, n, st, dev_err);
+            if (rc != GFA_ERR_UNSUPPORTED) return rc;
+        }
+    }
     if (f->use_lookup()) {
         const FieldDev &c = f->calc;
         const bool trivial_addsub = (op == GFA_OP_ADD || op == GFA_OP_SUB) && (c.p == 2 || c.m == 1);
@@ -1256,6 +1267,15 @@ int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int d
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
+    {
+        const FieldDev &c = f->calc;
+        const bool trivial_neg = op == GFA_OP_NEG && (c.p == 2 || c.m == 1);
+        if (!trivial_neg && f->mode != GFA_MODE_CALCULATE && (f->use_lookup() || op == GFA_OP_RECIP) &&
+            mid_eligible(c, ds->mid16, dtype, n)) {
+            rc = mid_unary(f->lut_desc(*ds), ds->mid16, op, a, out, n, st, dev_err);
+            if (rc != GFA_ERR_UNSUPPORTED) return rc;
+        }
+    }
     if (f->use_lookup()) {
         const FieldDev &c = f->calc;
         const bool trivial_neg = op == GFA_OP_NEG && (c.p == 2 || c.m == 1);
@@ -1279,6 +1299,10 @@ int gfa_power(gfa_field_t *f, const void *a, int64_t sa, const int64_t *exps, in
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
+    if (sa == 1 && se == 0 && f->mode != GFA_MODE_CALCULATE && mid_eligible(f->calc, ds->mid16, dtype, n)) {
+        rc = mid_power(f->lut_desc(*ds), ds->mid16, a, exps, out, n, (hipStream_t)stream, dev_err);
+        if (rc != GFA_ERR_UNSUPPORTED) return rc;
+    }
     if (f->use_lookup())
         return dispatch_intarg(f->lut_desc(*ds), dtype, true, a, sa, exps, se, out, n, (hipStream_t)stream, dev_err);
     return dispatch_intarg(f->calc, dtype, true, a, sa, exps, se, out, n, (hipStream_t)stream, dev_err);

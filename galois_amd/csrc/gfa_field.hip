@@ -160,6 +160,14 @@ int gfa_field::ensure_device(int *device_out, gfa::FieldDeviceState **st_out)
         if ((rc = upload(&st.neg8, h_neg8))) return rc;
         if ((rc = upload(&st.exp8, h_exp8))) return rc;
         if ((rc = upload(&st.log8, h_log8))) return rc;
+        if (has_lut && calc.q > 256 && calc.q <= 8192) {
+            const size_t q = (size_t)calc.q, qa = (q + 7) & ~(size_t)7;
+            std::vector<uint16_t> image(4 * qa, 0);
+            for (size_t i = 0; i < q; i++) image[i] = (uint16_t)h_log[i];
+            for (size_t i = 0; i < 2 * q; i++) image[qa + i] = (uint16_t)h_exp[i];
+            for (size_t i = 0; i < q; i++) image[3 * qa + i] = (uint16_t)h_zech[i];
+            if ((rc = upload(&st.mid16, image))) return rc;
+        }
         st.ready = true;
     }
     if (device_out) *device_out = d;
@@ -313,6 +321,7 @@ void gfa_field_destroy(gfa_field_t *f)
         (void)hipFree(st.exp_tab); (void)hipFree(st.log_tab); (void)hipFree(st.zech_tab);
         (void)hipFree(st.mul8); (void)hipFree(st.add8); (void)hipFree(st.sub8); (void)hipFree(st.div8);
         (void)hipFree(st.inv8); (void)hipFree(st.neg8); (void)hipFree(st.exp8); (void)hipFree(st.log8);
+        (void)hipFree(st.mid16);
     }
     delete f;
 }

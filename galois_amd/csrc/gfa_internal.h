@@ -54,6 +54,14 @@ int rs_wide_decode(struct ::gfa_rs *code, const void *recv, const uint8_t *eras,
                    i64 batch, bool detect_only, int dtype, hipStream_t st);
 int rs_wide_polydiv(struct ::gfa_rs *code, const void *cw, i64 ns, void *out, i64 batch, int dtype, hipStream_t st);
 
+// element-wise kernels with 16-bit EXP / LOG / Zech tables in LDS, 256 < q <= 8192 on uint16 storage (gfa_elementwise_mid.hip).
+// `lut` is gfa_field::lut_desc(), `image` FieldDeviceState::mid16.  GFA_ERR_UNSUPPORTED = operands not 16-byte aligned.
+bool mid_eligible(const FieldDev &calc, const void *image, int dtype, i64 n);
+int mid_binary(const FieldDev &lut, const void *image, int op, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n,
+               hipStream_t st, int32_t *err);
+int mid_unary(const FieldDev &lut, const void *image, int op, const void *a, void *out, i64 n, hipStream_t st, int32_t *err);
+int mid_power(const FieldDev &lut, const void *image, const void *a, const i64 *e, void *out, i64 n, hipStream_t st, int32_t *err);
+
 // Host scalar arithmetic on a field, dispatched on FieldDev::kind with the same formulas the kernels use.
 struct HostArith {
     static u64 add(const FieldDev &f, u64 a, u64 b);
@@ -72,6 +80,9 @@ struct FieldDeviceState {
     uint8_t *mul8 = nullptr, *add8 = nullptr, *sub8 = nullptr, *div8 = nullptr;
     uint8_t *inv8 = nullptr, *neg8 = nullptr; // 256-entry unary tables (inv8[0] = 0)
     uint8_t *exp8 = nullptr, *log8 = nullptr; // byte EXP (512) / LOG (256) for the RS kernels
+    // 256 < q <= 8192: LOG[qa] | EXP[2 qa] | ZECH[qa] as 16-bit entries, qa = q rounded up to a multiple of 8 -- the image the
+    // LDS-table kernels of gfa_elementwise_mid.hip stage with 16-byte copies
+    uint16_t *mid16 = nullptr;
 };
 
 // can the storage dtype hold every element of a field of order q?

@@ -606,3 +606,49 @@ def test_extension_fields_of_every_templated_degree(q):
         assert np.array_equal(u(A * 12345), F.mul(a, np.full(n, 12345 % GF.characteristic, dtype=np.uint64)))
     finally:
         GF.compile("auto")
+
+
+@pytest.mark.parametrize("q", [3**7, 2**10, 2**13, 5**5, 3191, 8191, 257, 2**9, 17**3, 89**2])
+@pytest.mark.parametrize("mode", ["jit-lookup", "auto"])
+def test_mid_size_fields_with_tables_in_lds(q, mode):
+    """256 < q <= 8192 on uint16 storage: EXP / LOG / Zech held in LDS as 16-bit entries (gfa_elementwise_mid.hip).  Every
+    operation, scalar operands on either side, tails, misaligned views (which fall back to the generic kernels), zeros
+    among the operands and the ZeroDivisionError paths, against the oracle; `auto` routes only division / reciprocal /
+    power of the calculated fields there."""
+    n = 400_003
+    GF, F, a, b, bnz, mk, u = _big_case(q, np.uint16, n, 21, mode=mode)
+    a[100:140] = 0
+    b[120:160] = 0
+    a[1000:1040] = b[1000:1040]                       # a - a = 0, a + (-a)
+    bnz = np.where(b == 0, np.uint64(1), b)
+    full = lambda v: np.full(n, v, dtype=np.uint64)
+    try:
+        A, B, Bnz = mk(a), mk(b), mk(bnz)
+        assert np.array_equal(u(A + B), F.add(a, b))
+        assert np.array_equal(u(A - B), F.sub(a, b))
+        assert np.array_equal(u(A + (-A)), np.zeros(n, dtype=np.uint64))
+        assert np.array_equal(u(-A), F.neg(a))
+        assert np.array_equal(u(A * B), F.mul(a, b))
+        assert np.array_equal(u(A / Bnz), F.div(a, bnz))
+        assert np.array_equal(u(np.reciprocal(Bnz)), F.recip(bnz))
+        for k in (5, 7):                                 # one operand a scalar (k = 5: value q // 2, k = 7 random)
+            assert np.array_equal(u(A * B[k]), F.mul(a, full(b[k])))
+            assert np.array_equal(u(A[k] - B), F.sub(full(a[k]), b))
+            assert np.array_equal(u(A + B[k]), F.add(a, full(b[k])))
+            assert np.array_equal(u(A[k] / Bnz), F.div(full(a[k]), bnz))
+            assert np.array_equal(u(A / Bnz[k]), F.div(a, full(bnz[k])))
+        assert np.array_equal(u(A[0] * B), np.zeros(n, dtype=np.uint64))
+        assert np.array_equal(u(A[3:] * B[3:]), F.mul(a[3:], b[3:]))       # not 16-byte aligned: generic kernels
+        assert np.array_equal(u(A[8:] / Bnz[8:]), F.div(a[8:], bnz[8:]))   # aligned view, odd tail
+        for e in (0, 1, 2, 3, -1, -7, 12345, q - 1, q - 2, -(q - 1), 2**40 + 3, -(2**40) - 3):
+            assert np.array_equal(u(Bnz ** e), F.pow(bnz, np.full(n, e, dtype=np.int64))), e
+        assert np.array_equal(u(A ** 3), F.pow(a, np.full(n, 3, dtype=np.int64)))
+        assert np.array_equal(u(A ** 0), np.ones(n, dtype=np.uint64))
+        with pytest.raises(ZeroDivisionError):
+            A / B
+        with pytest.raises(ZeroDivisionError):
+            np.reciprocal(B)
+        with pytest.raises(ZeroDivisionError):
+            A ** -2
+    finally:
+        GF.compile("auto")

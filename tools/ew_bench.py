@@ -13,7 +13,11 @@ cases = [(31, np.uint8, "auto"), (31, np.uint8, "jit-lookup"), (2**8, np.uint8, 
          (65537, np.uint32, "auto"), (7340033, np.uint32, "auto"), (2147483647, np.uint32, "auto"),
          (2**64 - 2**32 + 1, None, "auto"), (2**16, np.uint16, "auto"), (2**16, np.uint16, "jit-calculate"), (2**32, np.uint32, "auto"),
          (3**5, np.uint8, "auto"), (3**5, np.uint8, "jit-calculate"), (251**3, np.uint32, "auto"),
-         (2**10, np.uint16, "auto"), (2**10, np.uint16, "jit-calculate"), (2**12, np.uint16, "jit-calculate"), (3**7, np.uint16, "auto"), (3**7, np.uint16, "jit-calculate")]
+         (2**10, np.uint16, "auto"), (2**10, np.uint16, "jit-calculate"), (2**12, np.uint16, "jit-calculate"), (3**7, np.uint16, "auto"), (3**7, np.uint16, "jit-calculate"),
+         (2**10, np.uint16, "jit-lookup"), (2**13, np.uint16, "auto"), (2**13, np.uint16, "jit-lookup"), (8191, np.uint16, "auto"),
+         (8191, np.uint16, "jit-lookup"), (5**5, np.uint16, "auto"), (2**16, np.uint16, "jit-lookup")]
+if len(sys.argv) > 1 and sys.argv[1] == "--mid":
+    cases = [c for c in cases if 256 < c[0] <= 2**13 or c[0] == 2**16]
 n = 50_000_000
 for order, dt, mode in cases:
     GF = ga.GF(order)
