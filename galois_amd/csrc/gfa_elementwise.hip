@@ -1212,6 +1212,9 @@ int launch_tab8_unary(const uint8_t *table256, bool check_zero, const void *a, v
     return GFA_OK;
 }
 
+// 8192 < q <= 65536: do products go through the two-phase LOG / EXP kernel?  (division / reciprocal / power always do)
+inline bool big16_products(const gfa_field *f) { return f->use_lookup(); }
+
 } // namespace
 
 extern "C" {
@@ -1231,14 +1234,27 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
-    {
-        // 256 < q <= 8192 on uint16 storage: tables in LDS.  In lookup mode for every non-trivial operation; in AUTO on the fields
-        // whose products are calculated (GF(2^m), GF(p)) for division only, which would otherwise be an exponentiation.
+    if (f->mode != GFA_MODE_CALCULATE) {
+        // uint16 storage, tables in LDS (gfa_elementwise_mid.hip), unless the field was pinned to explicit calculation:
+        //  * 256 < q <= 32768 (LOG and EXP both resident): every operation that is not a plain xor / modular add (measured 0.7-0.8
+        //    of the HBM roofline, above the packed shift-and-xor product and the Montgomery-trick division);
+        //  * 32768 < q <= 65536, two-phase LOG / EXP: division always (it is an exponentiation otherwise), products when the field
+        //    is in lookup mode.
         const FieldDev &c = f->calc;
         const bool trivial_addsub = (op == GFA_OP_ADD || op == GFA_OP_SUB) && (c.p == 2 || c.m == 1);
-        if (!trivial_addsub && f->mode != GFA_MODE_CALCULATE && (f->use_lookup() || op == GFA_OP_DIV) &&
-            mid_eligible(c, ds->mid16, dtype, n)) {
+        const bool zech_op = op == GFA_OP_ADD || op == GFA_OP_SUB;
+        if (!trivial_addsub && mid_eligible(c, ds->mid16, dtype, n) && (!zech_op || mid_has_zech_room(c))) {
             rc = mid_binary(f->lut_desc(*ds), ds->mid16, op, a, sa, b, sb, out, n, st, dev_err);
+            if (rc != GFA_ERR_UNSUPPORTED) return rc;
+        }
+        if ((op == GFA_OP_DIV || (op == GFA_OP_MUL && big16_products(f))) && big16_eligible(c, ds->mid16, dtype, n)) {
+            rc = big16_run(f->lut_desc(*ds), ds->mid16, op, a, sa, b, sb, nullptr, out, n, st, dev_err);
+            if (rc == GFA_OK && (n & 7)) { // the last n & 7 elements
+                const i64 o = n & ~(i64)7;
+                const FieldDev td = f->use_lookup() ? f->lut_desc(*ds) : f->calc;
+                return dispatch_binary(td, dtype, op, (const uint16_t *)a + (sa ? o : 0), sa, (const uint16_t *)b + (sb ? o : 0), sb,
+                                       (uint16_t *)out + o, n & 7, st, dev_err);
+            }
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
     }
@@ -1267,12 +1283,20 @@ int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int d
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
-    {
+    if (f->mode != GFA_MODE_CALCULATE) { // tables in LDS, as in gfa_binary
         const FieldDev &c = f->calc;
         const bool trivial_neg = op == GFA_OP_NEG && (c.p == 2 || c.m == 1);
-        if (!trivial_neg && f->mode != GFA_MODE_CALCULATE && (f->use_lookup() || op == GFA_OP_RECIP) &&
-            mid_eligible(c, ds->mid16, dtype, n)) {
+        if (!trivial_neg && mid_eligible(c, ds->mid16, dtype, n) && (op != GFA_OP_NEG || mid_has_zech_room(c))) {
             rc = mid_unary(f->lut_desc(*ds), ds->mid16, op, a, out, n, st, dev_err);
+            if (rc != GFA_ERR_UNSUPPORTED) return rc;
+        }
+        if (op == GFA_OP_RECIP && big16_eligible(c, ds->mid16, dtype, n)) {
+            rc = big16_run(f->lut_desc(*ds), ds->mid16, op, a, 1, nullptr, 0, nullptr, out, n, st, dev_err);
+            if (rc == GFA_OK && (n & 7)) {
+                const i64 o = n & ~(i64)7;
+                const FieldDev td = f->use_lookup() ? f->lut_desc(*ds) : f->calc;
+                return dispatch_unary(td, dtype, op, (const uint16_t *)a + o, (uint16_t *)out + o, n & 7, st, dev_err);
+            }
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
     }
@@ -1299,9 +1323,21 @@ int gfa_power(gfa_field_t *f, const void *a, int64_t sa, const int64_t *exps, in
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
-    if (sa == 1 && se == 0 && f->mode != GFA_MODE_CALCULATE && mid_eligible(f->calc, ds->mid16, dtype, n)) {
-        rc = mid_power(f->lut_desc(*ds), ds->mid16, a, exps, out, n, (hipStream_t)stream, dev_err);
-        if (rc != GFA_ERR_UNSUPPORTED) return rc;
+    if (sa == 1 && f->mode != GFA_MODE_CALCULATE) { // tables in LDS, as in gfa_binary
+        if (mid_eligible(f->calc, ds->mid16, dtype, n)) {
+            rc = se == 0 ? mid_power(f->lut_desc(*ds), ds->mid16, a, exps, out, n, (hipStream_t)stream, dev_err)
+                         : mid_power_each(f->lut_desc(*ds), ds->mid16, a, exps, out, n, (hipStream_t)stream, dev_err);
+            if (rc != GFA_ERR_UNSUPPORTED) return rc;
+        }
+        if (se == 0 && big16_eligible(f->calc, ds->mid16, dtype, n)) {
+            rc = big16_run(f->lut_desc(*ds), ds->mid16, GFA_OP_POW, a, 1, nullptr, 0, exps, out, n, (hipStream_t)stream, dev_err);
+            if (rc == GFA_OK && (n & 7)) {
+                const i64 o = n & ~(i64)7;
+                const FieldDev td = f->use_lookup() ? f->lut_desc(*ds) : f->calc;
+                return dispatch_intarg(td, dtype, true, (const uint16_t *)a + o, 1, exps, 0, (uint16_t *)out + o, n & 7, (hipStream_t)stream, dev_err);
+            }
+            if (rc != GFA_ERR_UNSUPPORTED) return rc;
+        }
     }
     if (f->use_lookup())
         return dispatch_intarg(f->lut_desc(*ds), dtype, true, a, sa, exps, se, out, n, (hipStream_t)stream, dev_err);

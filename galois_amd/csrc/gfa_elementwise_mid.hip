@@ -22,8 +22,9 @@ typedef uint16_t u16;
 struct MidDesc {
     const u16 *image; // LOG[qa] | EXP[2*qa] | ZECH[qa], qa = q rounded up to a multiple of 8 (gfa_field::ensure_device)
     u32 q, qa, qm1, zech_e;
+    u32 exp_len;      // entries of EXP in the image: 2 qa (q <= 8192) or qa
     const i64 *e_ptr; // power: the one exponent of the call (device memory)
-    u32 mu;           // power: floor(2^32 / (q-1))
+    u32 mu, c32;      // power: floor(2^32 / (q-1)), 2^32 mod (q-1)
 };
 
 struct MidPow {
@@ -37,21 +38,24 @@ struct MidTabs {
     const u16 *lg, *ex, *ze;
 };
 
-template <int OP>
+// REDUCED: EXP holds q (not 2q) entries and every index is brought below q - 1 first (fields above 8192 elements, where the
+// doubled table would not fit next to LOG)
+template <int OP, bool REDUCED>
 __device__ __forceinline__ u32 mid_op(const MidTabs &t, const MidDesc &d, const MidPow &pw, u32 a, u32 b, bool &bad)
 {
+    auto red = [&](u32 s) -> u32 { return REDUCED ? (s >= d.qm1 ? s - d.qm1 : s) : s; };
     if constexpr (OP == GFA_OP_MUL) { // multiply_ufunc.lookup: EXP[LOG[a] + LOG[b]], 0 if either is 0
-        const u32 r = t.ex[(u32)t.lg[a] + (u32)t.lg[b]];
+        const u32 r = t.ex[red((u32)t.lg[a] + (u32)t.lg[b])];
         return (a == 0 || b == 0) ? 0u : r;
     } else if constexpr (OP == GFA_OP_DIV) { // divide_ufunc.lookup: EXP[(q-1) + LOG[a] - LOG[b]]
         bad |= b == 0;
-        const u32 r = t.ex[d.qm1 + (u32)t.lg[a] - (u32)t.lg[b]];
+        const u32 r = t.ex[red(d.qm1 + (u32)t.lg[a] - (u32)t.lg[b])];
         return (a == 0 || b == 0) ? 0u : r;
     } else if constexpr (OP == GFA_OP_ADD) { // add_ufunc.lookup (odd characteristic): EXP[m + ZECH[n - m]], m <= n the two logs
         const u32 la = t.lg[a], lb = t.lg[b];
         const u32 mm = min(la, lb), nn = max(la, lb);
         const u32 z = nn - mm;
-        const u32 r = t.ex[mm + (u32)t.ze[z]];
+        const u32 r = t.ex[red(mm + (u32)t.ze[z])];
         u32 res = z == d.zech_e ? 0u : r;
         res = b == 0 ? a : res;
         res = a == 0 ? b : res;
@@ -63,21 +67,21 @@ __device__ __forceinline__ u32 mid_op(const MidTabs &t, const MidDesc &d, const 
         u32 z = nn - mm;
         const bool cancel = z == d.zech_e;
         z = z >= d.qm1 ? z - d.qm1 : z;
-        const u32 r = t.ex[mm + (u32)t.ze[z]];
+        const u32 r = t.ex[red(mm + (u32)t.ze[z])];
         u32 res = cancel ? 0u : r;
-        if (a == 0) res = t.ex[nn0]; // rare: skipped by the whole wave almost always
+        if (a == 0) res = t.ex[red(nn0)]; // rare: skipped by the whole wave almost always
         res = b == 0 ? a : res;
         return res;
     } else if constexpr (OP == MID_NEG) { // negative_ufunc.lookup: EXP[LOG[a] + ZECH_E]
-        const u32 r = t.ex[(u32)t.lg[a] + d.zech_e];
+        const u32 r = t.ex[red((u32)t.lg[a] + d.zech_e)];
         return a == 0 ? 0u : r;
     } else if constexpr (OP == MID_RECIP) { // reciprocal_ufunc.lookup: EXP[(q-1) - LOG[a]]
         bad |= a == 0;
-        const u32 r = t.ex[d.qm1 - (u32)t.lg[a]];
+        const u32 r = t.ex[red(d.qm1 - (u32)t.lg[a])];
         return a == 0 ? 0u : r;
     } else { // MID_POW, one exponent for the whole array: EXP[(LOG[a] * e) mod (q-1)] (power_ufunc.lookup, _lookup.py:247-270)
-        const u32 x = (u32)t.lg[a] * pw.em; // < 2^26
-        u32 idx = x - __umulhi(x, d.mu) * d.qm1; // in [0, 2(q-1))
+        const u32 x = (u32)t.lg[a] * pw.em;        // < 2^26
+        u32 idx = x - __umulhi(x, d.mu) * d.qm1;   // in [0, 2(q-1)): the quotient estimate is short by at most one
         idx = idx >= d.qm1 ? idx - d.qm1 : idx;
         const u32 r = t.ex[idx];
         bad |= (a == 0) && pw.e_neg;
@@ -85,8 +89,8 @@ __device__ __forceinline__ u32 mid_op(const MidTabs &t, const MidDesc &d, const 
     }
 }
 
-template <int OP>
-__global__ __launch_bounds__(MID_THREADS) void mid_kernel(MidDesc d, const u16 *__restrict__ a, int sa, const u16 *__restrict__ b,
+template <int OP, int THREADS, bool REDUCED>
+__global__ __launch_bounds__(THREADS) void mid_kernel(MidDesc d, const u16 *__restrict__ a, int sa, const u16 *__restrict__ b,
                                                           int sb, u16 *__restrict__ out, i64 n, int32_t *err)
 {
     extern __shared__ __attribute__((aligned(16))) u16 mid_lds[];
@@ -96,8 +100,8 @@ __global__ __launch_bounds__(MID_THREADS) void mid_kernel(MidDesc d, const u16 *
     const u32x4 *av = reinterpret_cast<const u32x4 *>(a);
     const u32x4 *bv = reinterpret_cast<const u32x4 *>(b);
     u32x4 *ov = reinterpret_cast<u32x4 *>(out);
-    const i64 stride = (i64)gridDim.x * MID_THREADS;
-    i64 i = (i64)blockIdx.x * MID_THREADS + threadIdx.x;
+    const i64 stride = (i64)gridDim.x * THREADS;
+    i64 i = (i64)blockIdx.x * THREADS + threadIdx.x;
     u32x4 x = {0, 0, 0, 0}, y = {0, 0, 0, 0};
     if (!sa) { const u32 s = a[0]; x = u32x4{s, s, s, s} * 0x10001u; }
     if (BINARY && !sb) { const u32 s = b[0]; y = u32x4{s, s, s, s} * 0x10001u; }
@@ -107,16 +111,16 @@ __global__ __launch_bounds__(MID_THREADS) void mid_kernel(MidDesc d, const u16 *
         if (BINARY && sb) y = bv[i];
     }
     {
-        const int words = (int)((NEED_ZECH ? 4u : 3u) * d.qa / 8u); // 16-byte units
+        const int words = (int)((d.qa + d.exp_len + (NEED_ZECH ? d.qa : 0u)) / 8u); // 16-byte units
         const uint4 *src = reinterpret_cast<const uint4 *>(d.image);
         uint4 *dst = reinterpret_cast<uint4 *>(mid_lds);
-        for (int t = threadIdx.x; t < words; t += MID_THREADS) dst[t] = src[t];
+        for (int t = threadIdx.x; t < words; t += THREADS) dst[t] = src[t];
     }
     __syncthreads();
     MidTabs t;
     t.lg = mid_lds;
     t.ex = mid_lds + d.qa;
-    t.ze = mid_lds + 3 * d.qa;
+    t.ze = mid_lds + d.qa + d.exp_len;
     MidPow pw{0, false, false};
     if constexpr (OP == MID_POW) {
         const i64 e = d.e_ptr[0];
@@ -135,17 +139,227 @@ __global__ __launch_bounds__(MID_THREADS) void mid_kernel(MidDesc d, const u16 *
         u32x4 r;
 #pragma unroll
         for (int w = 0; w < 4; w++) {
-            const u32 lo = mid_op<OP>(t, d, pw, cx[w] & 0xffffu, cy[w] & 0xffffu, bad);
-            const u32 hi = mid_op<OP>(t, d, pw, cx[w] >> 16, cy[w] >> 16, bad);
+            const u32 lo = mid_op<OP, REDUCED>(t, d, pw, cx[w] & 0xffffu, cy[w] & 0xffffu, bad);
+            const u32 hi = mid_op<OP, REDUCED>(t, d, pw, cx[w] >> 16, cy[w] >> 16, bad);
             r[w] = lo | (hi << 16);
         }
         ov[i] = r;
     }
-    for (i64 j = (nvec << 3) + (i64)blockIdx.x * MID_THREADS + threadIdx.x; j < n; j += stride)
-        out[j] = (u16)mid_op<OP>(t, d, pw, (u32)a[sa ? j : 0], BINARY ? (u32)b[sb ? j : 0] : 0u, bad);
+    for (i64 j = (nvec << 3) + (i64)blockIdx.x * THREADS + threadIdx.x; j < n; j += stride)
+        out[j] = (u16)mid_op<OP, REDUCED>(t, d, pw, (u32)a[sa ? j : 0], BINARY ? (u32)b[sb ? j : 0] : 0u, bad);
     if constexpr (OP == GFA_OP_DIV || OP == MID_RECIP || OP == MID_POW) {
         if (__any(bad)) {
             if ((threadIdx.x & 63) == 0 && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
+        }
+    }
+}
+
+// x mod m for any 32-bit x, mu = floor(2^32 / m): the quotient estimate is short by at most one
+__device__ __forceinline__ u32 mod_barrett(u32 x, u32 m, u32 mu)
+{
+    const u32 r = x - __umulhi(x, mu) * m;
+    return r >= m ? r - m : r;
+}
+
+// e mod m with the sign of a floor modulo (Python's %), m < 2^16, c32 = 2^32 mod m
+__device__ __forceinline__ u32 exponent_mod(i64 e, u32 m, u32 mu, u32 c32)
+{
+    const bool neg = e < 0;
+    const u64 ue = neg ? (u64)0 - (u64)e : (u64)e;
+    const u32 hi = mod_barrett((u32)(ue >> 32), m, mu), lo = mod_barrett((u32)ue, m, mu);
+    const u32 r = mod_barrett(hi * c32 + lo, m, mu); // < 2^32: hi, c32, lo < 2^16
+    return (neg && r != 0) ? m - r : r;
+}
+
+// np.power with one exponent per element (int64 array): EXP[(LOG[a] * (e mod (q-1))) mod (q-1)], tables in LDS as in mid_kernel
+__global__ __launch_bounds__(MID_THREADS) void mid_powv_kernel(MidDesc d, const u16 *__restrict__ a, const i64 *__restrict__ e,
+                                                               u16 *__restrict__ out, i64 n, int32_t *err)
+{
+    extern __shared__ __attribute__((aligned(16))) u16 mid_lds[];
+    const i64 nvec = n >> 3;
+    const u32x4 *av = reinterpret_cast<const u32x4 *>(a);
+    const u32x4 *ev = reinterpret_cast<const u32x4 *>(e); // 4 vectors (8 exponents) per vector of a
+    u32x4 *ov = reinterpret_cast<u32x4 *>(out);
+    const i64 stride = (i64)gridDim.x * MID_THREADS;
+    i64 i = (i64)blockIdx.x * MID_THREADS + threadIdx.x;
+    {
+        const int words = (int)(3u * d.qa / 8u);
+        const uint4 *src = reinterpret_cast<const uint4 *>(d.image);
+        uint4 *dst = reinterpret_cast<uint4 *>(mid_lds);
+        for (int t = threadIdx.x; t < words; t += MID_THREADS) dst[t] = src[t];
+    }
+    __syncthreads();
+    const u16 *lg = mid_lds, *ex = mid_lds + d.qa;
+    bool bad = false;
+    auto one = [&](u32 x, i64 k) -> u32 {
+        const u32 em = exponent_mod(k, d.qm1, d.mu, d.c32);
+        const u32 r = ex[mod_barrett((u32)lg[x] * em, d.qm1, d.mu)];
+        bad |= x == 0 && k < 0;
+        return k == 0 ? 1u : (x == 0 ? 0u : r);
+    };
+    for (; i < nvec; i += stride) {
+        const u32x4 cx = av[i];
+        u32x4 r;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const u32x4 k2 = ev[4 * i + w]; // exponents of elements 2w, 2w + 1
+            const u32 lo = one(cx[w] & 0xffffu, (i64)(((u64)k2[1] << 32) | k2[0]));
+            const u32 hi = one(cx[w] >> 16, (i64)(((u64)k2[3] << 32) | k2[2]));
+            r[w] = lo | (hi << 16);
+        }
+        ov[i] = r;
+    }
+    for (i64 j = (nvec << 3) + (i64)blockIdx.x * MID_THREADS + threadIdx.x; j < n; j += stride) out[j] = (u16)one((u32)a[j], e[j]);
+    if (__any(bad)) {
+        if ((threadIdx.x & 63) == 0 && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 8192 < q <= 65536 on uint16 storage: LOG and EXP are 2q bytes each (up to 128 KiB) -- one of them fits in LDS, not both.
+// One 1024-thread workgroup per CU works on tiles of 1024 * 8 * J elements in two phases: with LOG staged, every lane turns
+// its J operand vectors into exponent indices ((LOG[a] +- LOG[b]) mod (q-1), or 0xFFFF for "the result is 0") that stay in
+// registers; the workgroup then re-stages LDS with EXP[0 .. q-1) and every lane looks its indices up and stores.  The array
+// is read once and written once; the 2 x 2q bytes of table re-staging per tile come out of L2.
+// ------------------------------------------------------------------------------------------------
+constexpr int B16_THREADS = 512;
+
+template <int OP>
+__device__ __forceinline__ u32 big16_index(const u16 *lg, const MidDesc &d, const MidPow &pw, u32 a, u32 b, bool &bad)
+{
+    u32 s;
+    bool zero;
+    if constexpr (OP == GFA_OP_MUL) {
+        s = (u32)lg[a] + (u32)lg[b];
+        zero = a == 0 || b == 0;
+    } else if constexpr (OP == GFA_OP_DIV) {
+        bad |= b == 0;
+        s = d.qm1 + (u32)lg[a] - (u32)lg[b];
+        zero = a == 0 || b == 0;
+    } else if constexpr (OP == MID_RECIP) {
+        bad |= a == 0;
+        s = d.qm1 - (u32)lg[a];
+        zero = a == 0;
+    } else { // MID_POW
+        s = mod_barrett((u32)lg[a] * pw.em, d.qm1, d.mu);
+        bad |= a == 0 && pw.e_neg;
+        zero = a == 0 && !pw.e_zero;
+        s = pw.e_zero ? 0u : s;
+    }
+    s = s >= d.qm1 ? s - d.qm1 : s;
+    return zero ? 0xffffu : s;
+}
+
+template <int OP, int J>
+__global__ __launch_bounds__(B16_THREADS) void big16_kernel(MidDesc d, const u16 *__restrict__ a, int sa, const u16 *__restrict__ b,
+                                                            int sb, u16 *__restrict__ out, i64 nvec, int32_t *err)
+{
+    extern __shared__ __attribute__((aligned(16))) u16 mid_lds[];
+    constexpr bool BINARY = OP == GFA_OP_MUL || OP == GFA_OP_DIV;
+    constexpr int SK = 131072 / 16 / B16_THREADS; // staging vectors per lane for the largest table
+    const u32x4 *av = reinterpret_cast<const u32x4 *>(a);
+    const u32x4 *bv = reinterpret_cast<const u32x4 *>(b);
+    u32x4 *ov = reinterpret_cast<u32x4 *>(out);
+    const int tid = threadIdx.x;
+    const i64 tile_vecs = (i64)B16_THREADS * J;
+    const i64 ntiles = (nvec + tile_vecs - 1) / tile_vecs;
+    const int words = (int)(d.qa / 8u); // 16-byte units of one table
+    const int K = (words + B16_THREADS - 1) / B16_THREADS;
+    u32x4 xs = {0, 0, 0, 0}, ys = {0, 0, 0, 0};
+    if (!sa) { const u32 s = a[0]; xs = u32x4{s, s, s, s} * 0x10001u; }
+    if (BINARY && !sb) { const u32 s = b[0]; ys = u32x4{s, s, s, s} * 0x10001u; }
+    MidPow pw{0, false, false};
+    if constexpr (OP == MID_POW) {
+        const i64 e = d.e_ptr[0];
+        pw = MidPow{exponent_mod(e, d.qm1, d.mu, d.c32), e == 0, e < 0};
+    }
+    bool bad = false;
+    const u32 voff = (u32)tid * 16u;
+    // Buffer addressing throughout: one descriptor per operand and tile (base = first vector of the tile, size = what is left of
+    // the array, at most the tile), the lane offset in one VGPR, the vector index in the scalar offset -- no per-vector 64-bit
+    // addresses in VGPRs, and the hardware bounds check stands in for `v < nvec` (loads past the end return 0, stores are dropped).
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)d.image, 0, 4u * d.qa, 0x00020000); // LOG | EXP
+    u32x4 S[SK], x[J], y[BINARY ? J : 1];
+    auto fetch_table = [&](int which) { // into registers; written to LDS once the previous table is no longer needed
+#pragma unroll
+        for (int k = 0; k < SK; k++)
+            if (k < K) S[k] = __builtin_amdgcn_raw_buffer_load_b128(rt, voff, (int)(which * 2u * d.qa) + k * B16_THREADS * 16, 0);
+    };
+    auto put_table = [&]() {
+        uint4 *dst = reinterpret_cast<uint4 *>(mid_lds);
+#pragma unroll
+        for (int k = 0; k < SK; k++) {
+            const int t = tid + k * B16_THREADS;
+            if (k < K && t < words) dst[t] = uint4{S[k][0], S[k][1], S[k][2], S[k][3]};
+        }
+    };
+    auto tile_bytes = [&](i64 tile) -> u32 {
+        const i64 left = (nvec - tile * tile_vecs) * 16;
+        return (u32)(left < tile_vecs * 16 ? left : tile_vecs * 16);
+    };
+    auto fetch_operands = [&](i64 tile) {
+        const i64 vbase = tile * tile_vecs;
+        const u32 nrec = tile_bytes(tile);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(av + (sa ? vbase : 0)), 0, sa ? nrec : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(bv + (sb ? vbase : 0)), 0, (BINARY && sb) ? nrec : 0u, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            x[j] = xs;
+            if (BINARY) y[j] = ys;
+            if (sa) x[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff, j * B16_THREADS * 16, 0);
+            if (BINARY && sb) y[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, voff, j * B16_THREADS * 16, 0);
+        }
+        if (!BINARY) y[0] = ys;
+    };
+    i64 tile = blockIdx.x;
+    if (tile < ntiles) {
+        fetch_table(0);
+        fetch_operands(tile);
+        for (;;) {
+            put_table(); // LOG
+            __syncthreads();
+            fetch_table(1); // EXP travels while the logarithms are gathered
+            const u32 nrec = tile_bytes(tile);
+            u32x4 idx[J];
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                bool bj = false;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const u32 lo = big16_index<OP>(mid_lds, d, pw, x[j][w] & 0xffffu, y[BINARY ? j : 0][w] & 0xffffu, bj);
+                    const u32 hi = big16_index<OP>(mid_lds, d, pw, x[j][w] >> 16, y[BINARY ? j : 0][w] >> 16, bj);
+                    idx[j][w] = lo | (hi << 16);
+                }
+                bad |= bj && (voff + (u32)(j * B16_THREADS * 16) < nrec); // vectors past the end of the array read zeros
+            }
+            __syncthreads(); // every wave is done with LOG
+            put_table();     // EXP
+            __syncthreads();
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(ov + tile * tile_vecs), 0, nrec, 0x00020000);
+            const i64 next = tile + gridDim.x;
+            if (next < ntiles) { // the next tile's LOG and operands travel while this tile's results are gathered and stored
+                fetch_table(0);
+                fetch_operands(next);
+            }
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                u32x4 r;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const u32 il = idx[j][w] & 0xffffu, ih = idx[j][w] >> 16;
+                    const u32 rl = mid_lds[il], rh = mid_lds[ih];
+                    r[w] = (il == 0xffffu ? 0u : rl) | ((ih == 0xffffu ? 0u : rh) << 16);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(r, ro, voff, j * B16_THREADS * 16, 0);
+            }
+            __syncthreads(); // every wave is done with EXP
+            if (next >= ntiles) break;
+            tile = next;
+        }
+    }
+    if constexpr (OP != GFA_OP_MUL) {
+        if (__any(bad)) {
+            if ((tid & 63) == 0 && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
         }
     }
 }
@@ -166,18 +380,56 @@ template <int OP>
 int mid_launch(const MidDesc &d, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int32_t *err)
 {
     constexpr bool NEED_ZECH = OP == GFA_OP_ADD || OP == GFA_OP_SUB;
-    const size_t lds = (size_t)(NEED_ZECH ? 4 : 3) * d.qa * sizeof(u16);
-    static bool attr = false;
-    auto k = mid_kernel<OP>;
-    if (!attr) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr = true; }
-    // 160 KiB of LDS and 32 waves per CU: up to four 8-wave workgroups when the tables are small
-    i64 per_cu = (i64)(160 * 1024) / (i64)(lds + 1024);
-    per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
-    i64 blocks = ((n >> 3) + MID_THREADS - 1) / MID_THREADS;
-    const i64 cap = (i64)mid_num_cus() * per_cu;
-    if (blocks < 1) blocks = 1;
-    const int grid = (int)(blocks < cap ? blocks : cap);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(MID_THREADS), lds, st, d, (const u16 *)a, (int)sa, (const u16 *)b, (int)sb, (u16 *)out, n, err);
+    const size_t lds = ((size_t)d.qa + d.exp_len + (NEED_ZECH ? d.qa : 0)) * sizeof(u16);
+    const bool reduced = d.exp_len == d.qa;
+    static bool attr[2] = {false, false};
+    const int cus = mid_num_cus();
+    const i64 vec_blocks = (n >> 3);
+    if (reduced) { // 8192 < q <= 32768: up to 160 KiB of tables, one 16-wave workgroup per CU
+        auto k = mid_kernel<OP, 1024, true>;
+        if (!attr[1]) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); attr[1] = true; }
+        i64 blocks = (vec_blocks + 1023) / 1024;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k, dim3((int)(blocks < cus ? blocks : cus)), dim3(1024), lds, st, d, (const u16 *)a, (int)sa, (const u16 *)b, (int)sb,
+                           (u16 *)out, n, err);
+    } else {
+        auto k = mid_kernel<OP, MID_THREADS, false>;
+        if (!attr[0]) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr[0] = true; }
+        // 160 KiB of LDS and 32 waves per CU: up to four 8-wave workgroups when the tables are small
+        i64 per_cu = (i64)(160 * 1024) / (i64)(lds + 1024);
+        per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
+        i64 blocks = (vec_blocks + MID_THREADS - 1) / MID_THREADS;
+        const i64 cap = (i64)cus * per_cu;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k, dim3((int)(blocks < cap ? blocks : cap)), dim3(MID_THREADS), lds, st, d, (const u16 *)a, (int)sa, (const u16 *)b,
+                           (int)sb, (u16 *)out, n, err);
+    }
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+template <int OP>
+int big16_launch(const MidDesc &d, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int32_t *err)
+{
+    const size_t lds = (size_t)d.qa * sizeof(u16);
+    const i64 nvec = n >> 3;
+    const int cus = mid_num_cus();
+    // JB vectors per lane (tiles of 4096 * JB elements) when that
+    // still gives every CU two tiles, else two vectors per lane
+    constexpr int JB = (OP == GFA_OP_MUL || OP == GFA_OP_DIV) ? 4 : 8; // two operand streams: half the vectors per lane (registers)
+    const bool big = (nvec + (i64)B16_THREADS * JB - 1) / ((i64)B16_THREADS * JB) >= 2 * (i64)cus;
+    static bool attr[2] = {false, false};
+    if (big) {
+        auto k = big16_kernel<OP, JB>;
+        if (!attr[1]) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); attr[1] = true; }
+        hipLaunchKernelGGL(k, dim3(cus), dim3(B16_THREADS), lds, st, d, (const u16 *)a, (int)sa, (const u16 *)b, (int)sb, (u16 *)out, nvec, err);
+    } else {
+        auto k = big16_kernel<OP, 2>;
+        if (!attr[0]) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); attr[0] = true; }
+        const i64 tiles = (nvec + (i64)B16_THREADS * 2 - 1) / ((i64)B16_THREADS * 2);
+        hipLaunchKernelGGL(k, dim3((int)(tiles < cus ? tiles : cus)), dim3(B16_THREADS), lds, st, d, (const u16 *)a, (int)sa, (const u16 *)b,
+                           (int)sb, (u16 *)out, nvec, err);
+    }
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }
@@ -190,8 +442,11 @@ MidDesc make_desc(const FieldDev &lut, const u16 *image)
     d.image = image;
     d.q = (u32)lut.q;
     d.qa = (d.q + 7u) & ~7u;
+    d.exp_len = d.q <= 8192 ? 2 * d.qa : d.qa;
     d.qm1 = lut.qm1;
     d.zech_e = lut.zech_e;
+    d.mu = (u32)(0x100000000ull / d.qm1);
+    d.c32 = (u32)(0x100000000ull % d.qm1);
     return d;
 }
 
@@ -205,8 +460,11 @@ static const i64 MID_MIN_N = [] { const char *e = getenv("GFA_MID_MIN_N"); retur
 bool mid_eligible(const FieldDev &calc, const void *image, int dtype, i64 n)
 {
     static const bool enabled = [] { const char *e = getenv("GFA_MID_LDS"); return !(e && e[0] == '0'); }();
-    return enabled && image != nullptr && dtype == GFA_U16 && calc.q > 256 && calc.q <= 8192 && n >= MID_MIN_N;
+    return enabled && image != nullptr && dtype == GFA_U16 && calc.q > 256 && calc.q <= 32768 && n >= MID_MIN_N;
 }
+
+// sums / differences / negation in odd characteristic need ZECH next to LOG and EXP: 6q bytes of LDS above 8192 elements
+bool mid_has_zech_room(const FieldDev &calc) { return calc.q <= 8192 || 6 * ((calc.q + 7) & ~7ull) <= 160 * 1024; }
 
 int mid_binary(const FieldDev &lut, const void *image, int op, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n,
                hipStream_t st, int32_t *err)
@@ -236,8 +494,46 @@ int mid_power(const FieldDev &lut, const void *image, const void *a, const i64 *
     if (!al16(out) || !al16(a)) return GFA_ERR_UNSUPPORTED;
     MidDesc d = make_desc(lut, (const u16 *)image);
     d.e_ptr = e;
-    d.mu = (u32)(0x100000000ull / d.qm1);
     return mid_launch<MID_POW>(d, a, 1, a, 0, out, n, st, err);
+}
+
+int mid_power_each(const FieldDev &lut, const void *image, const void *a, const i64 *e, void *out, i64 n, hipStream_t st, int32_t *err)
+{
+    if (!al16(out) || !al16(a) || !al16(e) || lut.q > 8192) return GFA_ERR_UNSUPPORTED;
+    const MidDesc d = make_desc(lut, (const u16 *)image);
+    const size_t lds = (size_t)3 * d.qa * sizeof(u16);
+    i64 per_cu = (i64)(160 * 1024) / (i64)(lds + 1024);
+    per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
+    i64 blocks = ((n >> 3) + MID_THREADS - 1) / MID_THREADS;
+    const i64 cap = (i64)mid_num_cus() * per_cu;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(mid_powv_kernel, dim3((int)(blocks < cap ? blocks : cap)), dim3(MID_THREADS), lds, st, d, (const u16 *)a, e, (u16 *)out, n, err);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+// ---- 8192 < q <= 65536: two-phase kernels; they cover the first n & ~7 elements, the caller runs the generic kernels on the rest
+static const i64 BIG16_MIN_N = [] { const char *e = getenv("GFA_BIG16_MIN_N"); return e ? (i64)atoll(e) : (i64)1 << 19; }();
+
+bool big16_eligible(const FieldDev &calc, const void *image, int dtype, i64 n)
+{
+    static const bool enabled = [] { const char *e = getenv("GFA_BIG16_LDS"); return !(e && e[0] == '0'); }();
+    return enabled && image != nullptr && dtype == GFA_U16 && calc.q > 32768 && calc.q <= 65536 && n >= BIG16_MIN_N;
+}
+
+int big16_run(const FieldDev &lut, const void *image, int op, const void *a, i64 sa, const void *b, i64 sb, const i64 *e, void *out, i64 n,
+              hipStream_t st, int32_t *err)
+{
+    if (!al16(out) || (sa && !al16(a)) || (b && sb && !al16(b))) return GFA_ERR_UNSUPPORTED;
+    MidDesc d = make_desc(lut, (const u16 *)image);
+    d.e_ptr = e;
+    switch (op) {
+    case GFA_OP_MUL: return big16_launch<GFA_OP_MUL>(d, a, sa, b, sb, out, n, st, err);
+    case GFA_OP_DIV: return big16_launch<GFA_OP_DIV>(d, a, sa, b, sb, out, n, st, err);
+    case GFA_OP_RECIP: return big16_launch<MID_RECIP>(d, a, 1, a, 0, out, n, st, err);
+    case GFA_OP_POW: return big16_launch<MID_POW>(d, a, 1, a, 0, out, n, st, err);
+    default: return GFA_ERR_UNSUPPORTED;
+    }
 }
 
 } // namespace gfa

@@ -167,6 +167,13 @@ int gfa_field::ensure_device(int *device_out, gfa::FieldDeviceState **st_out)
             for (size_t i = 0; i < 2 * q; i++) image[qa + i] = (uint16_t)h_exp[i];
             for (size_t i = 0; i < q; i++) image[3 * qa + i] = (uint16_t)h_zech[i];
             if ((rc = upload(&st.mid16, image))) return rc;
+        } else if (has_lut && calc.q > 8192 && calc.q <= 65536) { // LOG[qa] | EXP[0 .. q) | ZECH[qa]: indices reduced below q - 1
+            const size_t q = (size_t)calc.q, qa = (q + 7) & ~(size_t)7;
+            std::vector<uint16_t> image(3 * qa, 0);
+            for (size_t i = 0; i < q; i++) image[i] = (uint16_t)h_log[i];
+            for (size_t i = 0; i < q; i++) image[qa + i] = (uint16_t)h_exp[i];
+            for (size_t i = 0; i < q; i++) image[2 * qa + i] = (uint16_t)h_zech[i];
+            if ((rc = upload(&st.mid16, image))) return rc;
         }
         st.ready = true;
     }

@@ -521,9 +521,10 @@ def test_numpy_functions_stay_in_the_field_or_raise():
             f(a) if f is not np.cross else f(a, a)
 
 
-def _big_case(q, dt, n, seed, mode="jit-calculate", GF=None):
+def _big_case(q, dt, n, seed, mode="jit-calculate", GF=None, lookup=False):
     GF = GF or ga.GF(q)
-    F = O.OracleField(GF.characteristic, GF.degree, int(GF.irreducible_poly) if GF.degree > 1 else None, int(GF.primitive_element))
+    F = O.OracleField(GF.characteristic, GF.degree, int(GF.irreducible_poly) if GF.degree > 1 else None, int(GF.primitive_element),
+                      lookup=lookup)
     if mode in GF.ufunc_modes:
         GF.compile(mode)
     rng = np.random.default_rng(seed)
@@ -616,7 +617,7 @@ def test_mid_size_fields_with_tables_in_lds(q, mode):
     among the operands and the ZeroDivisionError paths, against the oracle; `auto` routes only division / reciprocal /
     power of the calculated fields there."""
     n = 400_003
-    GF, F, a, b, bnz, mk, u = _big_case(q, np.uint16, n, 21, mode=mode)
+    GF, F, a, b, bnz, mk, u = _big_case(q, np.uint16, n, 21, mode=mode, lookup=True)
     a[100:140] = 0
     b[120:160] = 0
     a[1000:1040] = b[1000:1040]                       # a - a = 0, a + (-a)
@@ -644,6 +645,61 @@ def test_mid_size_fields_with_tables_in_lds(q, mode):
             assert np.array_equal(u(Bnz ** e), F.pow(bnz, np.full(n, e, dtype=np.int64))), e
         assert np.array_equal(u(A ** 3), F.pow(a, np.full(n, 3, dtype=np.int64)))
         assert np.array_equal(u(A ** 0), np.ones(n, dtype=np.uint64))
+        # one exponent per element: small, huge, negative, zero, multiples of q - 1
+        e = np.random.default_rng(22).integers(-2**62, 2**62, n)
+        e[:n // 2] = np.random.default_rng(23).integers(-300, 300, n // 2)
+        e[5:12] = [0, q - 1, -(q - 1), 2 * (q - 1), -2**63, 2**63 - 1, 1]
+        assert np.array_equal(u(Bnz ** e), F.pow(bnz, e))
+        ez = np.abs(e)
+        assert np.array_equal(u(A ** ez), F.pow(a, ez))             # zeros in the base: 0 ** 0 = 1, 0 ** k = 0
+        with pytest.raises(ZeroDivisionError):
+            A / B
+        with pytest.raises(ZeroDivisionError):
+            np.reciprocal(B)
+        with pytest.raises(ZeroDivisionError):
+            A ** -2
+        with pytest.raises(ZeroDivisionError):
+            A ** e
+    finally:
+        GF.compile("auto")
+
+
+@pytest.mark.parametrize("q,n", [(2**16, 600_011), (2**16, 17_000_003), (2**14, 600_011), (3**10, 600_011), (65521, 600_011), (8209, 524_288),
+                                 (251**2, 700_001), (2**15, 4_200_005), (3**9, 600_011), (13**4, 600_011), (32771, 600_011), (32749, 600_011)])
+@pytest.mark.parametrize("mode", ["jit-lookup", "auto"])
+def test_fields_up_to_2e16_with_log_and_exp_staged_in_turn(q, n, mode):
+    """8192 < q <= 65536 on uint16 storage.  Up to 32768 elements LOG and a q-entry EXP are both resident in LDS (indices reduced
+    below q - 1; ZECH too while 6q bytes fit); above, products / quotients / reciprocals / powers go through LOG, then EXP, staged
+    in LDS in two phases per tile (big16_kernel).  Both tile shapes, tails of n & 7 elements, scalar operands, zeros,
+    ZeroDivisionError."""
+    GF, F, a, b, bnz, mk, u = _big_case(q, np.uint16, n, 31, mode=mode, lookup=True)
+    a[100:140] = 0
+    b[120:160] = 0
+    bnz = np.where(b == 0, np.uint64(1), b)
+    full = lambda v: np.full(n, v, dtype=np.uint64)
+    try:
+        A, B, Bnz = mk(a), mk(b), mk(bnz)
+        assert np.array_equal(u(A * B), F.mul(a, b))
+        assert np.array_equal(u(A / Bnz), F.div(a, bnz))
+        assert np.array_equal(u(np.reciprocal(Bnz)), F.recip(bnz))
+        assert np.array_equal(u(A + B), F.add(a, b))
+        assert np.array_equal(u(A - B), F.sub(a, b))
+        assert np.array_equal(u(-A), F.neg(a))
+        if n < 2_000_000:
+            for k in (5, 7):
+                assert np.array_equal(u(A * B[k]), F.mul(a, full(b[k])))
+                assert np.array_equal(u(A[k] - B), F.sub(full(a[k]), b))
+                assert np.array_equal(u(A[k] / Bnz), F.div(full(a[k]), bnz))
+                assert np.array_equal(u(A / Bnz[k]), F.div(a, full(bnz[k])))
+            assert np.array_equal(u(A[8:] / Bnz[8:]), F.div(a[8:], bnz[8:]))
+            assert np.array_equal(u(A[3:] / Bnz[3:]), F.div(a[3:], bnz[3:]))   # not 16-byte aligned: generic kernels
+            for e in (0, 1, 3, -1, 12345, q - 1, q - 2, -(q - 1), 2**40 + 3, -(2**40) - 3):
+                assert np.array_equal(u(Bnz ** e), F.pow(bnz, np.full(n, e, dtype=np.int64))), e
+            assert np.array_equal(u(A ** 3), F.pow(a, np.full(n, 3, dtype=np.int64)))
+            assert np.array_equal(u(A ** 0), np.ones(n, dtype=np.uint64))
+            C = A.copy()
+            np.multiply(C, B, out=C)                                            # in place
+            assert np.array_equal(u(C), F.mul(a, b))
         with pytest.raises(ZeroDivisionError):
             A / B
         with pytest.raises(ZeroDivisionError):

@@ -15,9 +15,10 @@ cases = [(31, np.uint8, "auto"), (31, np.uint8, "jit-lookup"), (2**8, np.uint8, 
          (3**5, np.uint8, "auto"), (3**5, np.uint8, "jit-calculate"), (251**3, np.uint32, "auto"),
          (2**10, np.uint16, "auto"), (2**10, np.uint16, "jit-calculate"), (2**12, np.uint16, "jit-calculate"), (3**7, np.uint16, "auto"), (3**7, np.uint16, "jit-calculate"),
          (2**10, np.uint16, "jit-lookup"), (2**13, np.uint16, "auto"), (2**13, np.uint16, "jit-lookup"), (8191, np.uint16, "auto"),
-         (8191, np.uint16, "jit-lookup"), (5**5, np.uint16, "auto"), (2**16, np.uint16, "jit-lookup")]
+         (8191, np.uint16, "jit-lookup"), (5**5, np.uint16, "auto"), (2**16, np.uint16, "jit-lookup"),
+         (2**14, np.uint16, "auto"), (2**15, np.uint16, "auto"), (3**9, np.uint16, "auto"), (3**10, np.uint16, "auto"), (65521, np.uint16, "auto"), (65521, np.uint16, "jit-lookup")]
 if len(sys.argv) > 1 and sys.argv[1] == "--mid":
-    cases = [c for c in cases if 256 < c[0] <= 2**13 or c[0] == 2**16]
+    cases = [c for c in cases if 256 < c[0] <= 2**16]
 n = 50_000_000
 for order, dt, mode in cases:
     GF = ga.GF(order)
