@@ -1238,8 +1238,8 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
         // uint16 storage, tables in LDS (gfa_elementwise_mid.hip), unless the field was pinned to explicit calculation:
         //  * 256 < q <= 32768 (LOG and EXP both resident): every operation that is not a plain xor / modular add (measured 0.7-0.8
         //    of the HBM roofline, above the packed shift-and-xor product and the Montgomery-trick division);
-        //  * 32768 < q <= 65536, two-phase LOG / EXP: division always (it is an exponentiation otherwise), products when the field
-        //    is in lookup mode.
+        //  * 32768 < q <= 65536, LOG / (ZECH /) EXP staged in turn: division always (it is an exponentiation otherwise); products,
+        //    and sums in odd characteristic, when the field is in lookup mode.
         const FieldDev &c = f->calc;
         const bool trivial_addsub = (op == GFA_OP_ADD || op == GFA_OP_SUB) && (c.p == 2 || c.m == 1);
         const bool zech_op = op == GFA_OP_ADD || op == GFA_OP_SUB;
@@ -1247,7 +1247,8 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
             rc = mid_binary(f->lut_desc(*ds), ds->mid16, op, a, sa, b, sb, out, n, st, dev_err);
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
-        if ((op == GFA_OP_DIV || (op == GFA_OP_MUL && big16_products(f))) && big16_eligible(c, ds->mid16, dtype, n)) {
+        // (reached for 8192 < q <= 32768 only by the sums / differences whose three tables do not fit in LDS together)
+        if ((op == GFA_OP_DIV || (!trivial_addsub && big16_products(f))) && big16_eligible(c, ds->mid16, dtype, n)) {
             rc = big16_run(f->lut_desc(*ds), ds->mid16, op, a, sa, b, sb, nullptr, out, n, st, dev_err);
             if (rc == GFA_OK && (n & 7)) { // the last n & 7 elements
                 const i64 o = n & ~(i64)7;
@@ -1290,7 +1291,7 @@ int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int d
             rc = mid_unary(f->lut_desc(*ds), ds->mid16, op, a, out, n, st, dev_err);
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
-        if (op == GFA_OP_RECIP && big16_eligible(c, ds->mid16, dtype, n)) {
+        if ((op == GFA_OP_RECIP || (!trivial_neg && big16_products(f))) && big16_eligible(c, ds->mid16, dtype, n)) {
             rc = big16_run(f->lut_desc(*ds), ds->mid16, op, a, 1, nullptr, 0, nullptr, out, n, st, dev_err);
             if (rc == GFA_OK && (n & 7)) {
                 const i64 o = n & ~(i64)7;
@@ -1339,7 +1340,9 @@ int gfa_power(gfa_field_t *f, const void *a, int64_t sa, const int64_t *exps, in
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
     }
-    if (f->use_lookup())
+    // GF(2^m), m <= 16, in AUTO: square-and-multiply over shift-and-xor products is far behind two table gathers (14 vs 86 Gop/s)
+    const bool bin_tables = f->mode == GFA_MODE_AUTO && f->has_lut && f->calc.kind == KIND_BIN && f->calc.q <= 65536;
+    if (f->use_lookup() || bin_tables)
         return dispatch_intarg(f->lut_desc(*ds), dtype, true, a, sa, exps, se, out, n, (hipStream_t)stream, dev_err);
     return dispatch_intarg(f->calc, dtype, true, a, sa, exps, se, out, n, (hipStream_t)stream, dev_err);
 }

@@ -172,21 +172,22 @@ __device__ __forceinline__ u32 exponent_mod(i64 e, u32 m, u32 mu, u32 c32)
 }
 
 // np.power with one exponent per element (int64 array): EXP[(LOG[a] * (e mod (q-1))) mod (q-1)], tables in LDS as in mid_kernel
-__global__ __launch_bounds__(MID_THREADS) void mid_powv_kernel(MidDesc d, const u16 *__restrict__ a, const i64 *__restrict__ e,
-                                                               u16 *__restrict__ out, i64 n, int32_t *err)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void mid_powv_kernel(MidDesc d, const u16 *__restrict__ a, const i64 *__restrict__ e,
+                                                           u16 *__restrict__ out, i64 n, int32_t *err)
 {
     extern __shared__ __attribute__((aligned(16))) u16 mid_lds[];
     const i64 nvec = n >> 3;
     const u32x4 *av = reinterpret_cast<const u32x4 *>(a);
     const u32x4 *ev = reinterpret_cast<const u32x4 *>(e); // 4 vectors (8 exponents) per vector of a
     u32x4 *ov = reinterpret_cast<u32x4 *>(out);
-    const i64 stride = (i64)gridDim.x * MID_THREADS;
-    i64 i = (i64)blockIdx.x * MID_THREADS + threadIdx.x;
+    const i64 stride = (i64)gridDim.x * THREADS;
+    i64 i = (i64)blockIdx.x * THREADS + threadIdx.x;
     {
-        const int words = (int)(3u * d.qa / 8u);
+        const int words = (int)((d.qa + d.exp_len) / 8u); // the index is below q - 1 whatever the length of EXP
         const uint4 *src = reinterpret_cast<const uint4 *>(d.image);
         uint4 *dst = reinterpret_cast<uint4 *>(mid_lds);
-        for (int t = threadIdx.x; t < words; t += MID_THREADS) dst[t] = src[t];
+        for (int t = threadIdx.x; t < words; t += THREADS) dst[t] = src[t];
     }
     __syncthreads();
     const u16 *lg = mid_lds, *ex = mid_lds + d.qa;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(MID_THREADS) void mid_powv_kernel(MidDesc d, const 
         }
         ov[i] = r;
     }
-    for (i64 j = (nvec << 3) + (i64)blockIdx.x * MID_THREADS + threadIdx.x; j < n; j += stride) out[j] = (u16)one((u32)a[j], e[j]);
+    for (i64 j = (nvec << 3) + (i64)blockIdx.x * THREADS + threadIdx.x; j < n; j += stride) out[j] = (u16)one((u32)a[j], e[j]);
     if (__any(bad)) {
         if ((threadIdx.x & 63) == 0 && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
     }
@@ -239,6 +240,9 @@ __device__ __forceinline__ u32 big16_index(const u16 *lg, const MidDesc &d, cons
     } else if constexpr (OP == MID_RECIP) {
         bad |= a == 0;
         s = d.qm1 - (u32)lg[a];
+        zero = a == 0;
+    } else if constexpr (OP == MID_NEG) {
+        s = (u32)lg[a] + d.zech_e;
         zero = a == 0;
     } else { // MID_POW
         s = mod_barrett((u32)lg[a] * pw.em, d.qm1, d.mu);
@@ -357,9 +361,150 @@ __global__ __launch_bounds__(B16_THREADS) void big16_kernel(MidDesc d, const u16
             tile = next;
         }
     }
-    if constexpr (OP != GFA_OP_MUL) {
+    if constexpr (OP != GFA_OP_MUL && OP != MID_NEG) {
         if (__any(bad)) {
             if ((tid & 63) == 0 && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
+        }
+    }
+}
+
+// Sums and differences in odd characteristic above 32768 elements: three tables, three phases per tile.
+//   A (LOG):  every element becomes (m, z) = (smaller logarithm, difference of the logarithms); a - b is a + (-b) with
+//             LOG[-b] = (LOG[b] + ZECH_E) mod (q-1).  An operand that is zero makes the element a pass-through (z = 0xFFFF, m = the
+//             logarithm of the result, or 0xFFFF for "result 0").
+//   B (ZECH): index = (m + ZECH[z]) mod (q-1); z = ZECH_E (the operands cancel) gives 0xFFFF.
+//   C (EXP):  result = EXP[index], 0 for 0xFFFF.
+// (m, z) take the registers the operands came in, the index then replaces m.
+template <int OP, int J, int THREADS>
+__global__ __launch_bounds__(THREADS) void big16_addsub_kernel(MidDesc d, const u16 *__restrict__ a, int sa, const u16 *__restrict__ b,
+                                                                   int sb, u16 *__restrict__ out, i64 nvec)
+{
+    extern __shared__ __attribute__((aligned(16))) u16 mid_lds[];
+    constexpr int SK = 131072 / 16 / THREADS;
+    const u32x4 *av = reinterpret_cast<const u32x4 *>(a);
+    const u32x4 *bv = reinterpret_cast<const u32x4 *>(b);
+    u32x4 *ov = reinterpret_cast<u32x4 *>(out);
+    const int tid = threadIdx.x;
+    const i64 tile_vecs = (i64)THREADS * J;
+    const i64 ntiles = (nvec + tile_vecs - 1) / tile_vecs;
+    const int words = (int)(d.qa / 8u);
+    const int K = (words + THREADS - 1) / THREADS;
+    u32x4 xs = {0, 0, 0, 0}, ys = {0, 0, 0, 0};
+    if (!sa) { const u32 s = a[0]; xs = u32x4{s, s, s, s} * 0x10001u; }
+    if (!sb) { const u32 s = b[0]; ys = u32x4{s, s, s, s} * 0x10001u; }
+    const u32 voff = (u32)tid * 16u;
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)d.image, 0, 6u * d.qa, 0x00020000); // LOG | EXP | ZECH
+    u32x4 S[SK], x[J], y[J], xn[J], yn[J];
+    auto fetch_table = [&](int which) {
+#pragma unroll
+        for (int k = 0; k < SK; k++)
+            if (k < K) S[k] = __builtin_amdgcn_raw_buffer_load_b128(rt, voff, (int)(which * 2u * d.qa) + k * THREADS * 16, 0);
+    };
+    auto put_table = [&]() {
+        uint4 *dst = reinterpret_cast<uint4 *>(mid_lds);
+#pragma unroll
+        for (int k = 0; k < SK; k++) {
+            const int t = tid + k * THREADS;
+            if (k < K && t < words) dst[t] = uint4{S[k][0], S[k][1], S[k][2], S[k][3]};
+        }
+    };
+    auto tile_bytes = [&](i64 tile) -> u32 {
+        const i64 left = (nvec - tile * tile_vecs) * 16;
+        return (u32)(left < tile_vecs * 16 ? left : tile_vecs * 16);
+    };
+    auto fetch_operands = [&](i64 tile) {
+        const i64 vbase = tile * tile_vecs;
+        const u32 nrec = tile_bytes(tile);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(av + (sa ? vbase : 0)), 0, sa ? nrec : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(bv + (sb ? vbase : 0)), 0, sb ? nrec : 0u, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            xn[j] = xs;
+            yn[j] = ys;
+            if (sa) xn[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff, j * THREADS * 16, 0);
+            if (sb) yn[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, voff, j * THREADS * 16, 0);
+        }
+    };
+    // phase A on one element: (m, z)
+    auto logs = [&](u32 av_, u32 bv_, u32 &m, u32 &z) {
+        const u32 la = mid_lds[av_];
+        u32 lb = mid_lds[bv_];
+        if constexpr (OP == GFA_OP_SUB) {
+            lb += d.zech_e;
+            lb = lb >= d.qm1 ? lb - d.qm1 : lb;
+        }
+        const u32 mm = min(la, lb), nn = max(la, lb);
+        m = mm;
+        z = nn - mm;
+        if (bv_ == 0) { m = av_ == 0 ? 0xffffu : la; z = 0xffffu; }
+        else if (av_ == 0) { m = lb; z = 0xffffu; }
+    };
+    i64 tile = blockIdx.x;
+    if (tile < ntiles) {
+        fetch_table(0);
+        fetch_operands(tile);
+        for (;;) {
+#pragma unroll
+            for (int j = 0; j < J; j++) { x[j] = xn[j]; y[j] = yn[j]; }
+            put_table(); // LOG
+            __syncthreads();
+            fetch_table(2); // ZECH
+            const u32 nrec = tile_bytes(tile);
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    u32 m0, z0, m1, z1;
+                    logs(x[j][w] & 0xffffu, y[j][w] & 0xffffu, m0, z0);
+                    logs(x[j][w] >> 16, y[j][w] >> 16, m1, z1);
+                    x[j][w] = m0 | (m1 << 16);
+                    y[j][w] = z0 | (z1 << 16);
+                }
+            }
+            __syncthreads();
+            put_table(); // ZECH
+            __syncthreads();
+            fetch_table(1); // EXP
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    u32 r = 0;
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const u32 m = (x[j][w] >> (16 * h)) & 0xffffu, z = (y[j][w] >> (16 * h)) & 0xffffu;
+                        u32 s = m + (u32)mid_lds[z == 0xffffu ? 0u : z];
+                        s = s >= d.qm1 ? s - d.qm1 : s;
+                        s = z == d.zech_e ? 0xffffu : s;
+                        s = z == 0xffffu ? m : s;
+                        r |= s << (16 * h);
+                    }
+                    x[j][w] = r;
+                }
+            }
+            __syncthreads();
+            put_table(); // EXP
+            __syncthreads();
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(ov + tile * tile_vecs), 0, nrec, 0x00020000);
+            const i64 next = tile + gridDim.x;
+            if (next < ntiles) {
+                fetch_table(0);
+                fetch_operands(next);
+            }
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                u32x4 r;
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const u32 il = x[j][w] & 0xffffu, ih = x[j][w] >> 16;
+                    const u32 rl = mid_lds[il], rh = mid_lds[ih];
+                    r[w] = (il == 0xffffu ? 0u : rl) | ((ih == 0xffffu ? 0u : rh) << 16);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(r, ro, voff, j * THREADS * 16, 0);
+            }
+            __syncthreads();
+            if (next >= ntiles) break;
+            tile = next;
         }
     }
 }
@@ -434,6 +579,23 @@ int big16_launch(const MidDesc &d, const void *a, i64 sa, const void *b, i64 sb,
     return GFA_OK;
 }
 
+template <int OP>
+int big16_addsub_launch(const MidDesc &d, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st)
+{
+    constexpr int T = 1024; // 16 waves: the three phases are latency chains (gather, barrier, stage, barrier)
+    const size_t lds = (size_t)d.qa * sizeof(u16);
+    const i64 nvec = n >> 3;
+    const int cus = mid_num_cus();
+    static bool attr = false;
+    auto k = big16_addsub_kernel<OP, 1, T>; // one vector per lane: with two the register allocation spills
+    if (!attr) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); attr = true; }
+    const i64 tiles = (nvec + (i64)T - 1) / (i64)T;
+    hipLaunchKernelGGL(k, dim3((int)(tiles < cus ? tiles : cus)), dim3(T), lds, st, d, (const u16 *)a, (int)sa, (const u16 *)b, (int)sb, (u16 *)out,
+                       nvec);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
 inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 MidDesc make_desc(const FieldDev &lut, const u16 *image)
@@ -499,15 +661,26 @@ int mid_power(const FieldDev &lut, const void *image, const void *a, const i64 *
 
 int mid_power_each(const FieldDev &lut, const void *image, const void *a, const i64 *e, void *out, i64 n, hipStream_t st, int32_t *err)
 {
-    if (!al16(out) || !al16(a) || !al16(e) || lut.q > 8192) return GFA_ERR_UNSUPPORTED;
+    if (!al16(out) || !al16(a) || !al16(e)) return GFA_ERR_UNSUPPORTED;
     const MidDesc d = make_desc(lut, (const u16 *)image);
-    const size_t lds = (size_t)3 * d.qa * sizeof(u16);
-    i64 per_cu = (i64)(160 * 1024) / (i64)(lds + 1024);
-    per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
-    i64 blocks = ((n >> 3) + MID_THREADS - 1) / MID_THREADS;
-    const i64 cap = (i64)mid_num_cus() * per_cu;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(mid_powv_kernel, dim3((int)(blocks < cap ? blocks : cap)), dim3(MID_THREADS), lds, st, d, (const u16 *)a, e, (u16 *)out, n, err);
+    const size_t lds = ((size_t)d.qa + d.exp_len) * sizeof(u16);
+    static bool attr = false;
+    if (d.exp_len == d.qa) { // above 8192 elements: one 16-wave workgroup per CU
+        auto k = mid_powv_kernel<1024>;
+        if (!attr) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); attr = true; }
+        i64 blocks = ((n >> 3) + 1023) / 1024;
+        const i64 cap = mid_num_cus();
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(k, dim3((int)(blocks < cap ? blocks : cap)), dim3(1024), lds, st, d, (const u16 *)a, e, (u16 *)out, n, err);
+    } else {
+        i64 per_cu = (i64)(160 * 1024) / (i64)(lds + 1024);
+        per_cu = per_cu < 1 ? 1 : per_cu > 4 ? 4 : per_cu;
+        i64 blocks = ((n >> 3) + MID_THREADS - 1) / MID_THREADS;
+        const i64 cap = (i64)mid_num_cus() * per_cu;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(mid_powv_kernel<MID_THREADS>, dim3((int)(blocks < cap ? blocks : cap)), dim3(MID_THREADS), lds, st, d, (const u16 *)a, e,
+                           (u16 *)out, n, err);
+    }
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }
@@ -518,7 +691,7 @@ static const i64 BIG16_MIN_N = [] { const char *e = getenv("GFA_BIG16_MIN_N"); r
 bool big16_eligible(const FieldDev &calc, const void *image, int dtype, i64 n)
 {
     static const bool enabled = [] { const char *e = getenv("GFA_BIG16_LDS"); return !(e && e[0] == '0'); }();
-    return enabled && image != nullptr && dtype == GFA_U16 && calc.q > 32768 && calc.q <= 65536 && n >= BIG16_MIN_N;
+    return enabled && image != nullptr && dtype == GFA_U16 && calc.q > 8192 && calc.q <= 65536 && n >= BIG16_MIN_N;
 }
 
 int big16_run(const FieldDev &lut, const void *image, int op, const void *a, i64 sa, const void *b, i64 sb, const i64 *e, void *out, i64 n,
@@ -528,8 +701,11 @@ int big16_run(const FieldDev &lut, const void *image, int op, const void *a, i64
     MidDesc d = make_desc(lut, (const u16 *)image);
     d.e_ptr = e;
     switch (op) {
+    case GFA_OP_ADD: return big16_addsub_launch<GFA_OP_ADD>(d, a, sa, b, sb, out, n, st);
+    case GFA_OP_SUB: return big16_addsub_launch<GFA_OP_SUB>(d, a, sa, b, sb, out, n, st);
     case GFA_OP_MUL: return big16_launch<GFA_OP_MUL>(d, a, sa, b, sb, out, n, st, err);
     case GFA_OP_DIV: return big16_launch<GFA_OP_DIV>(d, a, sa, b, sb, out, n, st, err);
+    case GFA_OP_NEG: return big16_launch<MID_NEG>(d, a, 1, a, 0, out, n, st, err);
     case GFA_OP_RECIP: return big16_launch<MID_RECIP>(d, a, 1, a, 0, out, n, st, err);
     case GFA_OP_POW: return big16_launch<MID_POW>(d, a, 1, a, 0, out, n, st, err);
     default: return GFA_ERR_UNSUPPORTED;

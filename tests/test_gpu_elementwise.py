@@ -700,6 +700,14 @@ def test_fields_up_to_2e16_with_log_and_exp_staged_in_turn(q, n, mode):
             C = A.copy()
             np.multiply(C, B, out=C)                                            # in place
             assert np.array_equal(u(C), F.mul(a, b))
+            C = A.copy()
+            np.subtract(C, B, out=C)
+            assert np.array_equal(u(C), F.sub(a, b))
+            e = np.random.default_rng(32).integers(-2**62, 2**62, n)
+            e[:n // 2] = np.random.default_rng(33).integers(-300, 300, n // 2)
+            e[5:12] = [0, q - 1, -(q - 1), 2 * (q - 1), -2**63, 2**63 - 1, 1]
+            assert np.array_equal(u(Bnz ** e), F.pow(bnz, e))
+            assert np.array_equal(u(A ** np.abs(e)), F.pow(a, np.abs(e)))
         with pytest.raises(ZeroDivisionError):
             A / B
         with pytest.raises(ZeroDivisionError):
