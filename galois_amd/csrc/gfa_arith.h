@@ -226,7 +226,26 @@ struct Goldilocks {
         }
         return r;
     }
-    static GFA_HD u64 inv(const FieldDev &f, u64 a) { return pow_u(f, a, P - 2); }
+    static GFA_HD u64 sqn(const FieldDev &f, u64 a, int k)
+    {
+#pragma unroll 1
+        for (int i = 0; i < k; i++) a = mul(f, a, a);
+        return a;
+    }
+    // a^(p-2), p - 2 = 2^64 - 2^32 - 1 = (2^31 - 1) * 2^33 + (2^32 - 1): 64 squarings and 9 products along the chain
+    // 2^k - 1 for k = 2, 3, 6, 12, 24, 30, 31, 32 (binary square-and-multiply takes 64 + 63)
+    static GFA_HD u64 inv(const FieldDev &f, u64 a)
+    {
+        const u64 x2 = mul(f, sqn(f, a, 1), a);
+        const u64 x3 = mul(f, sqn(f, x2, 1), a);
+        const u64 x6 = mul(f, sqn(f, x3, 3), x3);
+        const u64 x12 = mul(f, sqn(f, x6, 6), x6);
+        const u64 x24 = mul(f, sqn(f, x12, 12), x12);
+        const u64 x30 = mul(f, sqn(f, x24, 6), x6);
+        const u64 x31 = mul(f, sqn(f, x30, 1), a);
+        const u64 x32 = mul(f, sqn(f, x31, 1), a);
+        return mul(f, sqn(f, x31, 33), x32);
+    }
     static GFA_HD u64 from_int(const FieldDev &, i64 k)
     {
         if (k >= 0) return (u64)k % P;

@@ -71,6 +71,12 @@ struct BatchInv {
     static constexpr bool value = std::is_same<F, Prime32>::value || std::is_same<F, Prime64>::value ||
                                   std::is_same<F, Goldilocks>::value;
 };
+// GF(p^M) with the degree fixed: an inversion is ~27 field products (Itoh-Tsujii down to GF(p), then a prime-field power),
+// so sharing one among 16 elements pays as well
+template <int M>
+struct BatchInv<ExtM<M>> {
+    static constexpr bool value = true;
+};
 
 template <class F, int V>
 __device__ __forceinline__ void batch_inverse(const FieldDev &fd, typename F::elem (&x)[V], bool &bad)
