@@ -420,12 +420,26 @@ __global__ __launch_bounds__(TAB8_THREADS) void tab8_binary_claim_kernel(const u
 // Unary / scalar-operand form: out = TABLE256[a].  The 256-entry table is replicated 32x in LDS as dwords,
 // entry v of copy c at dword v*32 + c, and lane l reads copy l%32 => every lane of a 32-lane LDS group hits its
 // own bank, no conflicts for any data.
-template <bool CHECK_ZERO>
+// POW: the table is not read but built by the first 256 lanes of every workgroup as v -> v ** e[0] from the field's EXP / LOG
+// (x ** k with one exponent for the whole array is a unary map of at most 256 values); a zero in the data raises only for
+// e[0] < 0, as the reference's 0 ** negative does.
+template <bool CHECK_ZERO, bool POW = false>
 __global__ __launch_bounds__(TAB8_THREADS) void tab8_unary_kernel(const uint8_t *__restrict__ table256,
                                                                    const uint8_t *__restrict__ a,
-                                                                   uint8_t *__restrict__ out, i64 n, int32_t *err)
+                                                                   uint8_t *__restrict__ out, i64 n, int32_t *err,
+                                                                   FieldDev fd = FieldDev{}, const i64 *__restrict__ e = nullptr)
 {
     __shared__ u32 rep[256 * 32];
+    __shared__ uint8_t powtab[POW ? 256 : 1];
+    if constexpr (POW) {
+        if (threadIdx.x < 256) {
+            u32 r = 0;
+            if (threadIdx.x < fd.q) (void)pow_signed<Lut>(fd, (u32)threadIdx.x, e[0], &r);
+            powtab[threadIdx.x] = (uint8_t)r;
+        }
+        __syncthreads();
+        table256 = powtab;
+    }
     const i64 nvec = n >> 4;
     const u32x4 *av = reinterpret_cast<const u32x4 *>(a);
     u32x4 *ov = reinterpret_cast<u32x4 *>(out);
@@ -457,6 +471,7 @@ __global__ __launch_bounds__(TAB8_THREADS) void tab8_unary_kernel(const uint8_t 
         if (CHECK_ZERO && xb == 0) bad = true;
         out[j] = (uint8_t)my[(u32)xb << 5];
     }
+    if constexpr (POW) bad = bad && e[0] < 0;
     if constexpr (CHECK_ZERO) flag_error(err, bad);
 }
 
@@ -1218,6 +1233,18 @@ int launch_tab8_unary(const uint8_t *table256, bool check_zero, const void *a, v
     return GFA_OK;
 }
 
+// x ** k on uint8 storage, one exponent for the whole array (device memory): tab8_unary_kernel<true, true>, one launch
+int launch_pow8(const FieldDev &lut, const void *a, const i64 *e, void *out, i64 n, hipStream_t st, int32_t *err)
+{
+    i64 blocks = ((n >> 4) + TAB8_THREADS - 1) / TAB8_THREADS;
+    const i64 cap = (i64)num_cus() * 2;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((tab8_unary_kernel<true, true>), dim3((int)(blocks < cap ? blocks : cap)), dim3(TAB8_THREADS), 0, st,
+                       (const uint8_t *)nullptr, (const uint8_t *)a, (uint8_t *)out, n, err, lut, e);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
 // 8192 < q <= 65536: do products go through the two-phase LOG / EXP kernel?  (division / reciprocal / power always do)
 inline bool big16_products(const gfa_field *f) { return f->use_lookup(); }
 
@@ -1330,6 +1357,11 @@ int gfa_power(gfa_field_t *f, const void *a, int64_t sa, const int64_t *exps, in
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
+    if (sa == 1 && se == 0 && dtype == GFA_U8 && f->calc.q <= 256 && n >= 4096 && aligned16(a) && aligned16(out) && f->use_lookup()) {
+        // one exponent, at most 256 field values: a 256-entry map applied at streaming speed (a field pinned to explicit
+        // calculation keeps computing every element)
+        return launch_pow8(f->lut_desc(*ds), a, exps, out, n, (hipStream_t)stream, dev_err);
+    }
     if (sa == 1 && f->mode != GFA_MODE_CALCULATE) { // tables in LDS, as in gfa_binary
         if (mid_eligible(f->calc, ds->mid16, dtype, n)) {
             rc = se == 0 ? mid_power(f->lut_desc(*ds), ds->mid16, a, exps, out, n, (hipStream_t)stream, dev_err)

@@ -716,3 +716,25 @@ def test_fields_up_to_2e16_with_log_and_exp_staged_in_turn(q, n, mode):
             A ** -2
     finally:
         GF.compile("auto")
+
+
+@pytest.mark.parametrize("q", [2**8, 31, 3**5, 251, 2**3, 5**3, 2])
+def test_uint8_power_with_one_exponent_is_a_256_entry_map(q):
+    """x ** k on uint8 storage, one exponent for the whole array (lookup mode): the 256 possible results are computed once on the
+    device and applied by the streaming table kernel.  Every exponent class, zeros present and absent, tails, against the oracle."""
+    n = 300_007
+    GF, F, a, b, bnz, mk, u = _big_case(q, np.uint8, n, 41, mode="jit-lookup", lookup=True)
+    a[:6] = [0, 1, q - 1, max(q - 2, 0), min(2, q - 1), q // 2]
+    anz = np.where(a == 0, np.uint64(1), a)
+    try:
+        A, Anz = mk(a), mk(anz)
+        for e in (0, 1, 2, 3, 7, q - 1, q - 2, 12345, 2**40 + 3, 2**63 - 1):
+            assert np.array_equal(u(A ** e), F.pow(a, np.full(n, e, dtype=np.int64))), e
+        for e in (-1, -2, -(q - 1), -12345, -(2**40) - 3, -2**63):
+            assert np.array_equal(u(Anz ** e), F.pow(anz, np.full(n, e, dtype=np.int64))), e
+            with pytest.raises(ZeroDivisionError):
+                A ** e
+        assert np.array_equal(u(A[16:5000] ** 5), F.pow(a[16:5000], np.full(4984, 5, dtype=np.int64)))
+        assert np.array_equal(u(A[3:5000] ** 5), F.pow(a[3:5000], np.full(4997, 5, dtype=np.int64)))   # misaligned: generic kernel
+    finally:
+        GF.compile("auto")
