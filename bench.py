@@ -428,6 +428,25 @@ def extras(ga, L, lib, stream, with_cpu):
     ex["gf256_reciprocal"] = {"Gop/s": round(n / (ms.value * 1e-3) / 1e9, 2), "kernel_ms": round(ms.value, 5),
                               "roofline_frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_GB/s": round(gbs, 1)}
     del a, o
+    # ---- fields above 256 elements on uint16 storage (EXP / LOG / Zech as 16-bit tables in LDS): 6 B/element ----
+    for tag, order, ops in (("gf3^7_uint16", 3**7, (("add", L.OP_ADD), ("mul", L.OP_MUL), ("div", L.OP_DIV))),
+                            ("gf2^16_uint16", 2**16, (("mul", L.OP_MUL), ("div", L.OP_DIV)))):
+        T = ga.GF(order)
+        nt_ = 50_000_000
+        rng = np.random.default_rng(4)
+        ah, bh = rng.integers(0, order, nt_, dtype=np.uint16), rng.integers(1, order, nt_, dtype=np.uint16)
+        at, bt = torch.from_numpy(ah.view(np.int16)).cuda(), torch.from_numpy(bh.view(np.int16)).cuda()
+        ot = torch.empty_like(at)
+        FT = O.OracleField(T.characteristic, T.degree, int(T.irreducible_poly), int(T.primitive_element), lookup=True)
+        entry = {"elements": nt_, "mode": T.ufunc_mode}
+        for name, op in ops:
+            L.check(lib.gfa_time_binary(T._handle, op, at.data_ptr(), bt.data_ptr(), ot.data_ptr(), nt_, L.U16, stream, 10, ctypes.byref(ms)))
+            want = getattr(FT, name)(ah[:200_000].astype(np.uint64), bh[:200_000].astype(np.uint64))
+            assert np.array_equal(ot[:200_000].cpu().numpy().view(np.uint16).astype(np.uint64), want), f"{tag} {name} differs from the oracle"
+            entry[name] = {"Gop/s": round(nt_ / (ms.value * 1e-3) / 1e9, 1), "kernel_ms": round(ms.value, 5),
+                           "roofline_frac": round(6.0 * nt_ / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        ex[tag] = entry
+        del at, bt, ot
     # ---- NTT: 2^20 points over GF(7340033) (the modulus galois.ntt picks for that size), batch of 64 ----
     for tag, p, logn, batch in (("ntt_2^20_gf7340033", 7340033, 20, 64), ("ntt_16x2^16_gf65537", 65537, 16, 16 * 64)):
         P = ga.GF(p)
