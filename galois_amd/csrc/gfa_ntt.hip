@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256) void ntt_small_kernel(FieldDev fd, const typen
         const bool last = s == sa.nf - 1;
         for (int o = threadIdx.x; o < n; o += 256) {
             const int b = o % m, f = (o / m) % r, qi = o / (m * r);
-            const E tw = wpow[((i64)q * (f * m + b)) % n];
+            const E tw = wpow[q * (f * m + b)]; // f * m + b < m * r, so the exponent stays below q * m * r = n
             E acc = src[((r - 1) * q + qi) * m + b];
             for (int k = r - 2; k >= 0; k--) acc = F::add(fd, F::mul(fd, acc, tw), src[(k * q + qi) * m + b]);
             if (last) {
@@ -1458,8 +1458,12 @@ int run_generic(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n, 
     }
     if (n <= 4096 && S <= 24 && batch <= 0x7fffffff) { // whole transform in one workgroup's LDS: one launch
         SmallArgs sa{};
-        sa.nf = S;
-        for (int s = 0; s < S; s++) sa.r[s] = (int)pl->factors[S - 1 - s];
+        sa.nf = 0;
+        for (int s = 0; s < S; s++) { // pairs of 2 become one radix-4 stage: the same products, half the trips through LDS
+            const int r = (int)pl->factors[S - 1 - s];
+            if (r == 2 && s + 1 < S && pl->factors[S - 2 - s] == 2) { sa.r[sa.nf++] = 4; s++; }
+            else sa.r[sa.nf++] = r;
+        }
         auto kern = ntt_small_kernel<F>;
         static bool attr = false;
         if (!attr) {

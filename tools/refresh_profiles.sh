@@ -18,6 +18,7 @@ python tools/ntt_time.py 2>/dev/null | grep "p=" > "$OUT/${R}_ntt_time.txt"
 python tools/c5_local_bench.py > "$OUT/${R}_c5_goldilocks_local.txt" 2>/dev/null
 python tools/ntt_large.py 20 21 22 24 26 28 > "$OUT/${R}_ntt_large.txt" 2>/dev/null
 ./tools/ubench/valu_rates2 > "$OUT/${R}_valu_issue_rates.txt" 2>/dev/null
+python tools/fft_small_bench.py 2>/dev/null | grep size > "$OUT/${R}_fft_reference_benchmark_sizes.txt"
 python tools/wide_codes_bench.py > "$OUT/${R}_wide_codes_bench.txt" 2>/dev/null
 python tools/linalg_bench.py > "$OUT/${R}_linalg_bench.txt" 2>/dev/null
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_$R && rocprofv3 --kernel-trace --stats -d /tmp/prof_$R -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --no-pmc > /dev/null 2>&1

@@ -8,13 +8,19 @@ import galois_amd as ga
 rng = np.random.default_rng(5)
 
 
-def timed(fn, reps=3):
+def timed(fn, reps=10, trials=3):
+    """Seconds per call on the GPU's own clock: events on the current stream around `reps` back-to-back calls, best of `trials`
+    (the first version timed the host wall clock over 3 calls and spread by 40 % run to run)."""
     fn(); torch.cuda.synchronize()
-    t = time.perf_counter()
-    for _ in range(reps):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t) / reps
+    best = float("inf")
+    for _ in range(trials):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); e1.synchronize()
+        best = min(best, e0.elapsed_time(e1) / reps * 1e-3)
+    return best
 
 
 for name, code, q in (("RS(1023,1003)/GF(2^10)", ga.ReedSolomon(1023, 1003, field=ga.GF(2**10)), 2**10),
