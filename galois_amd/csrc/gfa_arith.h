@@ -68,6 +68,7 @@ GFA_HD int clz64(u64 x)
 }
 
 GFA_HD int clz32(u32 x) { return clz64((u64)x) - 32; }
+GFA_HD int ctz32(u32 x) { return __builtin_ctz(x); } // x != 0
 
 // ------------------------------------------------------------------------------------------------
 // GF(p), p < 2^32
@@ -278,8 +279,70 @@ struct Bin {
         }
         return c;
     }
+    // Carry-less 32 x 32 -> 64-bit product out of INTEGER multiplies ("multiplication with holes"): split each operand into
+    // the four classes of bit positions mod 4; within a class the set bits are four apart, so in an integer product of two
+    // classes every position receives at most 8 partial ones -- a sum that fits the four bits up to the next position of its
+    // class, and whose lowest bit is the parity, i.e. the carry-less sum.  16 products (v_mad_u64_u32), xor by result class, mask.
+    static GFA_HD u64 clmul32(u32 x, u32 y)
+    {
+        const u32 x0 = x & 0x11111111u, x1 = x & 0x22222222u, x2 = x & 0x44444444u, x3 = x & 0x88888888u;
+        const u32 y0 = y & 0x11111111u, y1 = y & 0x22222222u, y2 = y & 0x44444444u, y3 = y & 0x88888888u;
+        const u64 z0 = ((u64)x0 * y0) ^ ((u64)x1 * y3) ^ ((u64)x2 * y2) ^ ((u64)x3 * y1);
+        const u64 z1 = ((u64)x0 * y1) ^ ((u64)x1 * y0) ^ ((u64)x2 * y3) ^ ((u64)x3 * y2);
+        const u64 z2 = ((u64)x0 * y2) ^ ((u64)x1 * y1) ^ ((u64)x2 * y0) ^ ((u64)x3 * y3);
+        const u64 z3 = ((u64)x0 * y3) ^ ((u64)x1 * y2) ^ ((u64)x2 * y1) ^ ((u64)x3 * y0);
+        return (z0 & 0x1111111111111111ull) | (z1 & 0x2222222222222222ull) | (z2 & 0x4444444444444444ull) |
+               (z3 & 0x8888888888888888ull);
+    }
+    // operands below 2^21: three classes of positions mod 3 are enough (at most 7 set bits per class, sums fit three bits) --
+    // 9 products instead of 16
+    static GFA_HD u64 clmul21(u32 x, u32 y)
+    {
+        const u32 x0 = x & 0x49249249u, x1 = x & 0x92492492u, x2 = x & 0x24924924u;
+        const u32 y0 = y & 0x49249249u, y1 = y & 0x92492492u, y2 = y & 0x24924924u;
+        const u64 z0 = ((u64)x0 * y0) ^ ((u64)x1 * y2) ^ ((u64)x2 * y1);
+        const u64 z1 = ((u64)x0 * y1) ^ ((u64)x1 * y0) ^ ((u64)x2 * y2);
+        const u64 z2 = ((u64)x0 * y2) ^ ((u64)x1 * y1) ^ ((u64)x2 * y0);
+        return (z0 & 0x9249249249249249ull) | (z1 & 0x2492492492492492ull) | (z2 & 0x4924924924924924ull);
+    }
+    // rounds of "fold the part above x^m back through g = f - x^m" that clear a (2m-1)-bit product, 0 when that costs more than
+    // the bit-serial product (g with many terms or of high degree).  Stored in FieldDev::mu of a binary field (gfa_field.hip).
+    static GFA_HD u32 fold_rounds(u64 irr, u32 m)
+    {
+        if (m > 32 || m < 2) return 0;
+        const u64 g = irr ^ ((u64)1 << m);
+        int dg = -1, w = 0;
+        for (int i = 0; i < 64; i++)
+            if ((g >> i) & 1) { dg = i; w++; }
+        int deg = 2 * (int)m - 2 - (int)m; // degree of the part above x^m
+        u32 r = 0;
+        while (deg >= 0) {
+            r++;
+            deg = deg + dg - (int)m;
+            if (r > 8) return 0;
+        }
+        // measured on MI355X (tools/ew_bench.py --bin): bit-serial ~7 issue slots per bit of m; this form ~60 (16 products) or
+        // ~35 (9 products, m <= 21) plus ~4 per term of g and round
+        const u32 fold = (m <= 21 ? 35u : 60u) + r * (4u * (u32)w + 4u);
+        return (10u * fold < 9u * 7u * m) ? r : 0;
+    }
+    // a * b mod f for m <= 32: clmul32, then `rounds` folds; the loop over the terms of g is uniform (scalar) on the device
+    static GFA_HD u32 mul_fold(const FieldDev &f, u32 a, u32 b)
+    {
+        const u32 m = f.m;
+        const u64 low = (((u64)1 << m) - 1);
+        const u32 g = (u32)(f.irr ^ ((u64)1 << m));
+        u64 P = m <= 21 ? clmul21(a, b) : clmul32(a, b);
+        for (u32 r = 0; r < (u32)f.mu; r++) {
+            const u64 H = P >> m;
+            P &= low;
+            for (u32 gg = g; gg; gg &= gg - 1) P ^= H << ctz32(gg);
+        }
+        return (u32)P;
+    }
     static GFA_HD u64 mul(const FieldDev &f, u64 a, u64 b)
     { // shift-and-xor with reduction by the irreducible polynomial (value-identical to _calculate.py:308-324)
+        if (f.mu) return mul_fold(f, (u32)a, (u32)b);
 #if defined(__HIP_DEVICE_COMPILE__)
         if (f.m <= 32) return mul32(f, (u32)a, (u32)b);
 #endif

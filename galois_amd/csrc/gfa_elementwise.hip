@@ -77,6 +77,12 @@ template <int M>
 struct BatchInv<ExtM<M>> {
     static constexpr bool value = true;
 };
+// GF(2^m): the Euclidean inversion is a data-dependent loop of up to 2m steps that diverges inside a wavefront (~900 issue slots
+// at m = 32); three products per element (~120 each with the integer-multiply carry-less product) plus one inversion per 16 is less
+template <>
+struct BatchInv<Bin> {
+    static constexpr bool value = true;
+};
 
 template <class F, int V>
 __device__ __forceinline__ void batch_inverse(const FieldDev &fd, typename F::elem (&x)[V], bool &bad)

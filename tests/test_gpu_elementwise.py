@@ -563,10 +563,13 @@ def test_prime_field_reciprocal_and_division_on_large_arrays(q, dt):
 
 
 @pytest.mark.parametrize("q,dt", [(2**8, np.uint8), (2**3, np.uint8), (2**10, np.uint16), (2**12, np.uint16), (2**16, np.uint16), (2**5, np.uint16),
-                                  (2**20, np.uint32), (2**32, np.uint32), (2**8, np.int64)])
+                                  (2**20, np.uint32), (2**32, np.uint32), (2**8, np.int64), (2**17, np.uint32), (2**18, np.uint32),
+                                  (2**21, np.uint32), (2**22, np.uint32), (2**24, np.uint32), (2**27, np.uint32), (2**31, np.uint32),
+                                  (2**16, np.uint32), (2**32, np.int64)])
 def test_binary_field_calculate_mode_products_on_large_arrays(q, dt):
-    """Packed shift-and-xor products (four uint8 / two uint16 elements per register), the branch-free 32-bit product, tails,
-    scalar operands and misaligned views, against the oracle."""
+    """Packed shift-and-xor products (four uint8 / two uint16 elements per register), the branch-free 32-bit product, the
+    integer-multiply carry-less product with folds through the field polynomial (17 <= m <= 32 where the polynomial is sparse
+    enough: 9 or 16 multiplies), tails, scalar operands and misaligned views, against the oracle."""
     n = 1_000_003
     GF, F, a, b, bnz, mk, u = _big_case(q, dt, n, 12)
     try:

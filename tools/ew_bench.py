@@ -16,9 +16,12 @@ cases = [(31, np.uint8, "auto"), (31, np.uint8, "jit-lookup"), (2**8, np.uint8, 
          (2**10, np.uint16, "auto"), (2**10, np.uint16, "jit-calculate"), (2**12, np.uint16, "jit-calculate"), (3**7, np.uint16, "auto"), (3**7, np.uint16, "jit-calculate"),
          (2**10, np.uint16, "jit-lookup"), (2**13, np.uint16, "auto"), (2**13, np.uint16, "jit-lookup"), (8191, np.uint16, "auto"),
          (8191, np.uint16, "jit-lookup"), (5**5, np.uint16, "auto"), (2**16, np.uint16, "jit-lookup"),
+         (2**20, np.uint32, "jit-calculate"), (2**24, np.uint32, "auto"),
          (2**14, np.uint16, "auto"), (2**15, np.uint16, "auto"), (3**9, np.uint16, "auto"), (3**10, np.uint16, "auto"), (65521, np.uint16, "auto"), (65521, np.uint16, "jit-lookup")]
 if len(sys.argv) > 1 and sys.argv[1] == "--mid":
     cases = [c for c in cases if 256 < c[0] <= 2**16]
+if len(sys.argv) > 1 and sys.argv[1] == "--bin":
+    cases = [c for c in cases if c[0] in (2**20, 2**24, 2**32)]
 n = 50_000_000
 for order, dt, mode in cases:
     GF = ga.GF(order)
