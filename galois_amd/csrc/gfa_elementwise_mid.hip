@@ -354,7 +354,11 @@ __global__ __launch_bounds__(B16_THREADS) void big16_kernel(MidDesc d, const u16
                     const u32 rl = mid_lds[il], rh = mid_lds[ih];
                     r[w] = (il == 0xffffu ? 0u : rl) | ((ih == 0xffffu ? 0u : rh) << 16);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(r, ro, voff, j * B16_THREADS * 16, 0);
+                // The vector index goes into the VGPR offset, NOT the scalar offset: a buffer_store_dwordx4 with an SGPR soffset
+                // followed at once by a VALU write of its data registers stored corrupted words on gfx950 (intermittently, words 0
+                // of the vectors whose registers the next vector's index arithmetic reused).  LLVM inserts the wait states this
+                // hazard needs only for the immediate-soffset form (its rule exempts SGPR soffsets); DESIGN.md section 4.2 (7).
+                __builtin_amdgcn_raw_buffer_store_b128(r, ro, voff + (u32)(j * B16_THREADS * 16), 0, 0);
             }
             __syncthreads(); // every wave is done with EXP
             if (next >= ntiles) break;
@@ -377,10 +381,9 @@ __global__ __launch_bounds__(B16_THREADS) void big16_kernel(MidDesc d, const u16
 // (m, z) take the registers the operands came in, the index then replaces m.
 template <int OP, int J, int THREADS>
 __global__ __launch_bounds__(THREADS) void big16_addsub_kernel(MidDesc d, const u16 *__restrict__ a, int sa, const u16 *__restrict__ b,
-                                                                   int sb, u16 *__restrict__ out, i64 nvec)
+                                                               int sb, u16 *__restrict__ out, i64 nvec)
 {
     extern __shared__ __attribute__((aligned(16))) u16 mid_lds[];
-    constexpr int SK = 131072 / 16 / THREADS;
     const u32x4 *av = reinterpret_cast<const u32x4 *>(a);
     const u32x4 *bv = reinterpret_cast<const u32x4 *>(b);
     u32x4 *ov = reinterpret_cast<u32x4 *>(out);
@@ -388,42 +391,15 @@ __global__ __launch_bounds__(THREADS) void big16_addsub_kernel(MidDesc d, const 
     const i64 tile_vecs = (i64)THREADS * J;
     const i64 ntiles = (nvec + tile_vecs - 1) / tile_vecs;
     const int words = (int)(d.qa / 8u);
-    const int K = (words + THREADS - 1) / THREADS;
     u32x4 xs = {0, 0, 0, 0}, ys = {0, 0, 0, 0};
     if (!sa) { const u32 s = a[0]; xs = u32x4{s, s, s, s} * 0x10001u; }
     if (!sb) { const u32 s = b[0]; ys = u32x4{s, s, s, s} * 0x10001u; }
     const u32 voff = (u32)tid * 16u;
-    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)d.image, 0, 6u * d.qa, 0x00020000); // LOG | EXP | ZECH
-    u32x4 S[SK], x[J], y[J], xn[J], yn[J];
-    auto fetch_table = [&](int which) {
-#pragma unroll
-        for (int k = 0; k < SK; k++)
-            if (k < K) S[k] = __builtin_amdgcn_raw_buffer_load_b128(rt, voff, (int)(which * 2u * d.qa) + k * THREADS * 16, 0);
-    };
-    auto put_table = [&]() {
+    auto stage = [&](int which) { // table `which` of the image (0 LOG, 1 EXP, 2 ZECH) into LDS
+        const uint4 *src = reinterpret_cast<const uint4 *>(d.image + (size_t)which * d.qa);
         uint4 *dst = reinterpret_cast<uint4 *>(mid_lds);
-#pragma unroll
-        for (int k = 0; k < SK; k++) {
-            const int t = tid + k * THREADS;
-            if (k < K && t < words) dst[t] = uint4{S[k][0], S[k][1], S[k][2], S[k][3]};
-        }
-    };
-    auto tile_bytes = [&](i64 tile) -> u32 {
-        const i64 left = (nvec - tile * tile_vecs) * 16;
-        return (u32)(left < tile_vecs * 16 ? left : tile_vecs * 16);
-    };
-    auto fetch_operands = [&](i64 tile) {
-        const i64 vbase = tile * tile_vecs;
-        const u32 nrec = tile_bytes(tile);
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(av + (sa ? vbase : 0)), 0, sa ? nrec : 0u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(bv + (sb ? vbase : 0)), 0, sb ? nrec : 0u, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < J; j++) {
-            xn[j] = xs;
-            yn[j] = ys;
-            if (sa) xn[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff, j * THREADS * 16, 0);
-            if (sb) yn[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, voff, j * THREADS * 16, 0);
-        }
+#pragma unroll 4
+        for (int t = tid; t < words; t += THREADS) dst[t] = src[t];
     };
     // phase A on one element: (m, z)
     auto logs = [&](u32 av_, u32 bv_, u32 &m, u32 &z) {
@@ -439,73 +415,69 @@ __global__ __launch_bounds__(THREADS) void big16_addsub_kernel(MidDesc d, const 
         if (bv_ == 0) { m = av_ == 0 ? 0xffffu : la; z = 0xffffu; }
         else if (av_ == 0) { m = lb; z = 0xffffu; }
     };
-    i64 tile = blockIdx.x;
-    if (tile < ntiles) {
-        fetch_table(0);
-        fetch_operands(tile);
-        for (;;) {
+    for (i64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const i64 vbase = tile * tile_vecs;
+        const i64 left = (nvec - vbase) * 16;
+        const u32 nrec = (u32)(left < tile_vecs * 16 ? left : tile_vecs * 16);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void *)(av + (sa ? vbase : 0)), 0, sa ? nrec : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void *)(bv + (sb ? vbase : 0)), 0, sb ? nrec : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(ov + vbase), 0, nrec, 0x00020000);
+        u32x4 x[J], y[J];
 #pragma unroll
-            for (int j = 0; j < J; j++) { x[j] = xn[j]; y[j] = yn[j]; }
-            put_table(); // LOG
-            __syncthreads();
-            fetch_table(2); // ZECH
-            const u32 nrec = tile_bytes(tile);
-#pragma unroll
-            for (int j = 0; j < J; j++) {
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    u32 m0, z0, m1, z1;
-                    logs(x[j][w] & 0xffffu, y[j][w] & 0xffffu, m0, z0);
-                    logs(x[j][w] >> 16, y[j][w] >> 16, m1, z1);
-                    x[j][w] = m0 | (m1 << 16);
-                    y[j][w] = z0 | (z1 << 16);
-                }
-            }
-            __syncthreads();
-            put_table(); // ZECH
-            __syncthreads();
-            fetch_table(1); // EXP
-#pragma unroll
-            for (int j = 0; j < J; j++) {
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    u32 r = 0;
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const u32 m = (x[j][w] >> (16 * h)) & 0xffffu, z = (y[j][w] >> (16 * h)) & 0xffffu;
-                        u32 s = m + (u32)mid_lds[z == 0xffffu ? 0u : z];
-                        s = s >= d.qm1 ? s - d.qm1 : s;
-                        s = z == d.zech_e ? 0xffffu : s;
-                        s = z == 0xffffu ? m : s;
-                        r |= s << (16 * h);
-                    }
-                    x[j][w] = r;
-                }
-            }
-            __syncthreads();
-            put_table(); // EXP
-            __syncthreads();
-            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void *)(ov + tile * tile_vecs), 0, nrec, 0x00020000);
-            const i64 next = tile + gridDim.x;
-            if (next < ntiles) {
-                fetch_table(0);
-                fetch_operands(next);
-            }
-#pragma unroll
-            for (int j = 0; j < J; j++) {
-                u32x4 r;
-#pragma unroll
-                for (int w = 0; w < 4; w++) {
-                    const u32 il = x[j][w] & 0xffffu, ih = x[j][w] >> 16;
-                    const u32 rl = mid_lds[il], rh = mid_lds[ih];
-                    r[w] = (il == 0xffffu ? 0u : rl) | ((ih == 0xffffu ? 0u : rh) << 16);
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(r, ro, voff, j * THREADS * 16, 0);
-            }
-            __syncthreads();
-            if (next >= ntiles) break;
-            tile = next;
+        for (int j = 0; j < J; j++) {
+            x[j] = xs;
+            y[j] = ys;
+            if (sa) x[j] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff, j * THREADS * 16, 0);
+            if (sb) y[j] = __builtin_amdgcn_raw_buffer_load_b128(rb, voff, j * THREADS * 16, 0);
         }
+        stage(0); // LOG
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                u32 m0, z0, m1, z1;
+                logs(x[j][w] & 0xffffu, y[j][w] & 0xffffu, m0, z0);
+                logs(x[j][w] >> 16, y[j][w] >> 16, m1, z1);
+                x[j][w] = m0 | (m1 << 16);
+                y[j][w] = z0 | (z1 << 16);
+            }
+        }
+        __syncthreads();
+        stage(2); // ZECH
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                u32 r = 0;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const u32 m = (x[j][w] >> (16 * h)) & 0xffffu, z = (y[j][w] >> (16 * h)) & 0xffffu;
+                    u32 s = m + (u32)mid_lds[z == 0xffffu ? 0u : z];
+                    s = s >= d.qm1 ? s - d.qm1 : s;
+                    s = z == d.zech_e ? 0xffffu : s;
+                    s = z == 0xffffu ? m : s;
+                    r |= s << (16 * h);
+                }
+                x[j][w] = r;
+            }
+        }
+        __syncthreads();
+        stage(1); // EXP
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            u32x4 r;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const u32 il = x[j][w] & 0xffffu, ih = x[j][w] >> 16;
+                const u32 rl = mid_lds[il], rh = mid_lds[ih];
+                r[w] = (il == 0xffffu ? 0u : rl) | ((ih == 0xffffu ? 0u : rh) << 16);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(r, ro, voff + (u32)(j * THREADS * 16), 0, 0); // VGPR offset: see big16_kernel
+        }
+        __syncthreads();
     }
 }
 
@@ -587,9 +559,9 @@ int big16_addsub_launch(const MidDesc &d, const void *a, i64 sa, const void *b, 
     const i64 nvec = n >> 3;
     const int cus = mid_num_cus();
     static bool attr = false;
-    auto k = big16_addsub_kernel<OP, 1, T>; // one vector per lane: with two the register allocation spills
+    auto k = big16_addsub_kernel<OP, 2, T>;
     if (!attr) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); attr = true; }
-    const i64 tiles = (nvec + (i64)T - 1) / (i64)T;
+    const i64 tiles = (nvec + (i64)T * 2 - 1) / ((i64)T * 2);
     hipLaunchKernelGGL(k, dim3((int)(tiles < cus ? tiles : cus)), dim3(T), lds, st, d, (const u16 *)a, (int)sa, (const u16 *)b, (int)sb, (u16 *)out,
                        nvec);
     GFA_HIP(hipGetLastError());

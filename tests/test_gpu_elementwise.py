@@ -741,3 +741,31 @@ def test_uint8_power_with_one_exponent_is_a_256_entry_map(q):
         assert np.array_equal(u(A[3:5000] ** 5), F.pow(a[3:5000], np.full(4997, 5, dtype=np.int64)))   # misaligned: generic kernel
     finally:
         GF.compile("auto")
+
+
+@pytest.mark.parametrize("q", [2**16, 3**10])
+def test_staged_table_kernels_repeat_identically_over_many_tiles_per_workgroup(q):
+    """Arrays large enough that every workgroup of the staged-table kernels walks several tiles (re-staging LOG / ZECH / EXP each
+    time), every operation repeated with other kernels in between.  The first pipelined version passed single runs and produced
+    intermittent wrong words under exactly this pattern: its 16-byte buffer stores carried the vector index in the SCALAR offset,
+    and on gfx950 such a store followed at once by a VALU write of its data registers stores corrupted words (the compiler
+    inserts the wait states only for the immediate-offset form).  The stores now use the VGPR offset; this test keeps watch."""
+    n = 17_000_003
+    GF, F, a, b, bnz, mk, u = _big_case(q, np.uint16, n, 51, mode="jit-lookup", lookup=True)
+    try:
+        A, B, Bnz = mk(a), mk(b), mk(bnz)
+        e = np.full(n, 12345, dtype=np.int64)
+        want = {"mul": F.mul(a, b), "div": F.div(a, bnz), "recip": F.recip(bnz), "pow": F.pow(bnz, e)}
+        ops = {"mul": lambda: A * B, "div": lambda: A / Bnz, "recip": lambda: np.reciprocal(Bnz), "pow": lambda: Bnz ** 12345}
+        if q % 2:
+            want.update({"add": F.add(a, b), "sub": F.sub(a, b), "neg": F.neg(a)})
+            ops.update({"add": lambda: A + B, "sub": lambda: A - B, "neg": lambda: -A})
+        for mode in ("jit-lookup", "auto"):
+            GF.compile(mode)
+            for rep in range(6):
+                for name, fn in ops.items():
+                    junk = A + B if q % 2 == 0 else A * B           # a different kernel in between
+                    got = u(fn())
+                    assert np.array_equal(got, want[name]), (mode, rep, name, int((got != want[name]).sum()))
+    finally:
+        GF.compile("auto")
