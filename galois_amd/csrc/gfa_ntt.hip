@@ -820,6 +820,66 @@ __global__ __launch_bounds__(256) void ntt_small_kernel(FieldDev fd, const typen
     }
 }
 
+// The same one-workgroup Stockham transform for table fields of at most 32768 elements, carried out on LOGARITHMS: values live
+// in LDS as LOG[x] (0xFFFFFFFF for 0), a twiddle product is an addition mod q - 1 and a sum one Zech-logarithm gather,
+// log(a + b) = m + ZECH[n - m] for the two logs m <= n (add_ufunc.lookup, _lookup.py:153-168) -- one LDS gather per
+// multiply-add instead of the seven table gathers from global memory that EXP[LOG + LOG] followed by the Zech sum costs when
+// every intermediate is converted back (the reference's own FFT benchmark has such a case: 2304 points over GF(127^2)).
+// ZECH is staged in LDS as 16-bit entries; LOG / EXP are touched once per element on the way in and out.
+__global__ __launch_bounds__(256) void ntt_small_log_kernel(FieldDev fd, const u32 *__restrict__ in, u32 *__restrict__ out, int n, SmallArgs sa,
+                                                            u32 omega, int do_scale, u32 scale)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32 *buf0 = reinterpret_cast<u32 *>(smem_raw), *buf1 = buf0 + n;
+    uint16_t *ze = reinterpret_cast<uint16_t *>(buf1 + n);
+    constexpr u32 ZERO = 0xffffffffu;
+    const u32 qm1 = fd.qm1, zech_e = fd.zech_e;
+    for (u32 i = threadIdx.x; i < (u32)fd.q; i += 256) ze[i] = (uint16_t)fd.zech_tab[i];
+    const u32 *x = in + (i64)blockIdx.x * n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const u32 v = x[i];
+        buf0[i] = v ? fd.log_tab[v] : ZERO;
+    }
+    const u32 lw = fd.log_tab[omega];
+    __syncthreads();
+    auto log_add = [&](u32 a, u32 b) -> u32 {
+        const u32 mm = min(a, b), nn = max(a, b); // ZERO is the largest value: it ends up in nn
+        if (nn == ZERO) return mm;                // one operand (or both) zero
+        const u32 z = nn - mm;
+        u32 r = mm + (u32)ze[z];
+        r = r >= qm1 ? r - qm1 : r;
+        return z == zech_e ? ZERO : r;
+    };
+    u32 *src = buf0, *dst = buf1;
+    int m = 1;
+    for (int s = 0; s < sa.nf; s++) {
+        const int r = sa.r[s], q = n / (m * r);
+        const bool last = s == sa.nf - 1;
+        for (int o = threadIdx.x; o < n; o += 256) {
+            const int b = o % m, f = (o / m) % r, qi = o / (m * r);
+            const u32 tl = ((u32)(q * (f * m + b)) * lw) % qm1; // log of w^(q (f m + b)): exponent < n <= 4096, lw < 2^15
+            u32 acc = src[((r - 1) * q + qi) * m + b];
+            for (int k = r - 2; k >= 0; k--) {
+                if (acc != ZERO) {
+                    acc += tl;
+                    acc = acc >= qm1 ? acc - qm1 : acc;
+                }
+                acc = log_add(acc, src[(k * q + qi) * m + b]);
+            }
+            if (last) {
+                u32 v = acc == ZERO ? 0u : fd.exp_tab[acc];
+                if (do_scale) v = Lut::mul(fd, v, scale);
+                out[(i64)blockIdx.x * n + o] = v;
+            } else {
+                dst[o] = acc;
+            }
+        }
+        __syncthreads();
+        u32 *t = src; src = dst; dst = t;
+        m *= r;
+    }
+}
+
 template <typename E>
 __global__ void convert_in_kernel(const void *src, int dtype, E *dst, i64 n)
 {
@@ -1463,6 +1523,20 @@ int run_generic(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n, 
             const int r = (int)pl->factors[S - 1 - s];
             if (r == 2 && s + 1 < S && pl->factors[S - 2 - s] == 2) { sa.r[sa.nf++] = 4; s++; }
             else sa.r[sa.nf++] = r;
+        }
+        if constexpr (std::is_same<F, Lut>::value) {
+            if (fd.q <= 32768) { // on logarithms, ZECH in LDS
+                static bool lattr = false;
+                if (!lattr) {
+                    GFA_HIP(hipFuncSetAttribute((const void *)ntt_small_log_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    lattr = true;
+                }
+                const size_t lds = 2 * sizeof(u32) * (size_t)n + 2 * (((size_t)fd.q + 7) & ~(size_t)7);
+                hipLaunchKernelGGL(ntt_small_log_kernel, dim3((unsigned)batch), dim3(256), lds, st, fd, (const u32 *)in, (u32 *)out, (int)n, sa,
+                                   (u32)omega, do_scale, (u32)scale);
+                GFA_HIP(hipGetLastError());
+                return GFA_OK;
+            }
         }
         auto kern = ntt_small_kernel<F>;
         static bool attr = false;

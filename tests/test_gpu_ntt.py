@@ -90,9 +90,12 @@ def test_batched_and_24bit_sizes():
 
 
 @pytest.mark.parametrize("order,n", [(31, 30), (31, 15), (31, 6), (2**8, 255), (2**8, 85), (2**8, 51), (3**5, 242), (3**5, 22),
-                                     (5**3, 124), (769, 96), (65537, 3 * 0 + 4096), (7340033, 7 * 64), (2**64 - 2**32 + 1, 3 * 5 * 17)])
+                                     (5**3, 124), (769, 96), (65537, 3 * 0 + 4096), (7340033, 7 * 64), (2**64 - 2**32 + 1, 3 * 5 * 17),
+                                     (127**2, 2304), (7681, 1536), (10753, 1792), (769, 768), (2**12, 4095), (2**10, 341), (3**7, 1093)])
 def test_mixed_radix_against_oracle(order, n):
-    """tests/fields/test_fft.py:33-104: any length dividing q - 1, any field."""
+    """tests/fields/test_fft.py:33-104: any length dividing q - 1, any field -- including the sizes of the reference's own FFT
+    benchmark (benchmarks/test_fft.py: 256 K points over the first prime-power field with such a root, e.g. 2304 over GF(127^2));
+    in lookup mode transforms up to 4096 points over at most 32768 elements run on logarithms (ntt_small_log_kernel)."""
     GF = ga.GF(order)
     p, m = GF.characteristic, GF.degree
     F = O.OracleField(p, m, int(GF.irreducible_poly) if m > 1 else None, GF._primitive_element_int)
