@@ -802,16 +802,54 @@ __global__ __launch_bounds__(256) void ntt_small_kernel(FieldDev fd, const typen
     for (int s = 0; s < sa.nf; s++) {
         const int r = sa.r[s], q = n / (m * r);
         const bool last = s == sa.nf - 1;
-        for (int o = threadIdx.x; o < n; o += 256) {
-            const int b = o % m, f = (o / m) % r, qi = o / (m * r);
-            const E tw = wpow[q * (f * m + b)]; // f * m + b < m * r, so the exponent stays below q * m * r = n
-            E acc = src[((r - 1) * q + qi) * m + b];
-            for (int k = r - 2; k >= 0; k--) acc = F::add(fd, F::mul(fd, acc, tw), src[(k * q + qi) * m + b]);
+        auto emit = [&](int o, E v) {
             if (last) {
-                if (do_scale) acc = F::mul(fd, acc, scale);
-                out[(i64)blockIdx.x * n + o] = acc;
+                if (do_scale) v = F::mul(fd, v, scale);
+                out[(i64)blockIdx.x * n + o] = v;
             } else {
-                dst[o] = acc;
+                dst[o] = v;
+            }
+        };
+        if (r <= 4) {
+            // radix 2 / 3 / 4 as butterflies: one work item per group (b, qi) -- inputs x_k = src[(k q + qi) m + b] times the
+            // twiddles w^(q b k) (none in the first stage, where b = 0), then the r-point transform with w_r = w^(n / r):
+            // r - 1 + (r > 2) products per r outputs instead of r (r - 1) for the evaluation form below
+            const E wr = r > 2 ? wpow[n / r] : (E)0; // w_3 or w_4
+            for (int t = threadIdx.x; t < n / r; t += 256) {
+                const int b = t % m, qi = t / m;
+                E y[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) y[k] = k < r ? src[(k * q + qi) * m + b] : (E)0;
+                if (b) {
+#pragma unroll
+                    for (int k = 1; k < 4; k++)
+                        if (k < r) y[k] = F::mul(fd, y[k], wpow[q * b * k]);
+                }
+                const int o0 = qi * r * m + b;
+                if (r == 2) {
+                    emit(o0, F::add(fd, y[0], y[1]));
+                    emit(o0 + m, F::sub(fd, y[0], y[1]));
+                } else if (r == 3) { // w^2 = -1 - w:  X1 = (y0 - y2) + w (y1 - y2),  X2 = (y0 - y1) - w (y1 - y2)
+                    const E u = F::mul(fd, wr, F::sub(fd, y[1], y[2]));
+                    emit(o0, F::add(fd, y[0], F::add(fd, y[1], y[2])));
+                    emit(o0 + m, F::add(fd, F::sub(fd, y[0], y[2]), u));
+                    emit(o0 + 2 * m, F::sub(fd, F::sub(fd, y[0], y[1]), u));
+                } else {
+                    const E t0 = F::add(fd, y[0], y[2]), t1 = F::sub(fd, y[0], y[2]), t2 = F::add(fd, y[1], y[3]);
+                    const E t3 = F::mul(fd, wr, F::sub(fd, y[1], y[3]));
+                    emit(o0, F::add(fd, t0, t2));
+                    emit(o0 + m, F::add(fd, t1, t3));
+                    emit(o0 + 2 * m, F::sub(fd, t0, t2));
+                    emit(o0 + 3 * m, F::sub(fd, t1, t3));
+                }
+            }
+        } else {
+            for (int o = threadIdx.x; o < n; o += 256) {
+                const int b = o % m, f = (o / m) % r, qi = o / (m * r);
+                const E tw = wpow[q * (f * m + b)]; // f * m + b < m * r, so the exponent stays below q * m * r = n
+                E acc = src[((r - 1) * q + qi) * m + b];
+                for (int k = r - 2; k >= 0; k--) acc = F::add(fd, F::mul(fd, acc, tw), src[(k * q + qi) * m + b]);
+                emit(o, acc);
             }
         }
         __syncthreads();
