@@ -13,6 +13,10 @@ X = np.fft.fft(galois.GF(7340033).Random(1 << 20))
 Y = np.fft.fft(galois.GF(2**64 - 2**32 + 1).Random(1 << 26))
 P = galois.GF(2**31 - 1)
 c = np.convolve(P.Random(1 << 20), P.Random(1 << 20))
+T = galois.GF(3**7); t = T.Random(10**7) / T.Random(10**7, low=1)
+big = galois.GF(2**100); w = big(3) ** (2**99 + 12345)
+from galois_amd._ntt import fft_batched
+F = fft_batched(galois.GF(65537).Random((64, 1 << 16)))
 bch = galois.BCH(1023, d=21)
 assert (bch.n, bch.k, bch.t) == (1023, 923, 10)
 A = galois.GF(251).Random((4096, 4096)); B = A @ np.linalg.inv(A)
