@@ -1,14 +1,19 @@
-// gfa_elementwise_mid.hip -- element-wise arithmetic over fields of 257 .. 8192 elements on uint16 storage with the
-// EXP / LOG / Zech-log tables resident in LDS as 16-bit entries.
+// gfa_elementwise_mid.hip -- element-wise arithmetic over fields of 257 .. 65536 elements on uint16 storage with the
+// EXP / LOG / Zech-log tables in LDS as 16-bit entries.
 //
 // Reference seam: the lookup ufuncs of galois/_domains/_lookup.py:153-270 (add / negative / subtract / multiply / reciprocal /
 // divide / power through EXP, LOG, ZECH_LOG) -- same tables (gfa_field.hip builds them entry for entry), same index
 // arithmetic, so results are the same integers as the generic Lut kernels of gfa_elementwise.hip, which gather from
-// global memory (L1 / L2).  Here one workgroup stages LOG (q), EXP (2q) and ZECH (q) once -- 8q bytes, at most 64 KiB -- and
-// then streams 16-byte vectors of the operands through them; every table access is a ds_read_u16.
+// global memory (L1 / L2).  Three regimes, by table size against the CU's 160 KiB:
+//   * q <= 8192   mid_kernel: LOG (q), EXP (2q), ZECH (q) resident, 8q <= 64 KiB, up to four 512-thread workgroups per CU;
+//   * q <= 32768  mid_kernel<.., REDUCED>: EXP shortened to q entries, every index brought below q - 1 first; LOG + EXP (+ ZECH
+//                 while 6q bytes fit) resident, one 1024-thread workgroup per CU;
+//   * q <= 65536  big16_kernel / big16_addsub_kernel: one table at a time -- LOG, (ZECH,) EXP staged in turn per tile, the
+//                 indices in between kept in registers.
+// 16-byte operand vectors throughout; every table access is a ds_read_u16.
 //
-// What bounds it: the LDS random-gather rate (2 gathers for a reciprocal, 3 for a product or quotient, 4 for a sum in odd
-// characteristic), not HBM -- see DESIGN.md section 4.2 (7).
+// What bounds them (measured): HBM up to 32768 elements (0.7-0.8 of the 6 B/element roofline: the
+// LDS random-gather rate of 2-4 gathers per element is just sufficient); LDS -- gathers plus table re-staging -- above.
 #include "gfa_internal.h"
 
 using namespace gfa;
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(THREADS) void mid_powv_kernel(MidDesc d, const u16 
 }
 
 // ------------------------------------------------------------------------------------------------
-// 8192 < q <= 65536 on uint16 storage: LOG and EXP are 2q bytes each (up to 128 KiB) -- one of them fits in LDS, not both.
+// 32768 < q <= 65536 on uint16 storage: LOG and EXP are 2q bytes each (up to 128 KiB) -- one of them fits in LDS, not both.
 // One 1024-thread workgroup per CU works on tiles of 1024 * 8 * J elements in two phases: with LOG staged, every lane turns
 // its J operand vectors into exponent indices ((LOG[a] +- LOG[b]) mod (q-1), or 0xFFFF for "the result is 0") that stay in
 // registers; the workgroup then re-stages LDS with EXP[0 .. q-1) and every lane looks its indices up and stores.  The array
@@ -657,7 +662,7 @@ int mid_power_each(const FieldDev &lut, const void *image, const void *a, const 
     return GFA_OK;
 }
 
-// ---- 8192 < q <= 65536: two-phase kernels; they cover the first n & ~7 elements, the caller runs the generic kernels on the rest
+// ---- above 32768 elements (and sums without room for ZECH above 8192): staged-table kernels; they cover the first n & ~7 elements, the caller runs the generic kernels on the rest
 static const i64 BIG16_MIN_N = [] { const char *e = getenv("GFA_BIG16_MIN_N"); return e ? (i64)atoll(e) : (i64)1 << 19; }();
 
 bool big16_eligible(const FieldDev &calc, const void *image, int dtype, i64 n)
