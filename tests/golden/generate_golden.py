@@ -437,8 +437,61 @@ def reference_wide_codes():
     np.savez_compressed(os.path.join(OUT_DIR, "reference_wide_codes.npz"), **out)
 
 
+TABLE_FIELDS = [("gf3e7", 3**7), ("gf2e10", 2**10), ("gf2e13", 2**13), ("gf5e5", 5**5), ("gf8191", 8191), ("gf2e14", 2**14),
+                ("gf3e9", 3**9), ("gf2e15", 2**15), ("gf32749", 32749), ("gf2e16", 2**16), ("gf3e10", 3**10), ("gf65521", 65521),
+                ("gf251e2", 251**2)]
+
+
+def reference_table_fields():
+    """Fields of 257 .. 65536 elements (the size classes of csrc/gfa_elementwise_mid.hip): element-wise outputs of the reference
+    itself incl. zeros among the operands, one exponent per element and one for the whole array, and mixed-radix transforms of
+    the reference's FFT benchmark sizes over such fields."""
+    import load_reference
+
+    load_reference.load()
+    rng = np.random.default_rng(20260928)
+    out = {}
+    for tag, order in TABLE_FIELDS:
+        GF = load_reference.ref_field(order)
+        n = 256
+        a = rng.integers(0, order, n, dtype=np.uint64)
+        b = rng.integers(0, order, n, dtype=np.uint64)
+        a[:4] = 0
+        b[2:6] = 0
+        a[6:10] = b[6:10]                      # a - a, a / a
+        a[10], b[10] = order - 1, order - 1
+        a[11], b[11] = 1, order - 1
+        bnz, anz = np.where(b == 0, 1, b), np.where(a == 0, 1, a)
+        ga, gb, gbnz, ganz = (GF([int(v) for v in x]) for x in (a, b, bnz, anz))
+        e = rng.integers(-300, 300, n)
+        e[:6] = [0, 1, -1, order - 1, -(order - 1), order - 2]
+        out[f"ew/{tag}/meta"] = np.array(json.dumps({"p": int(GF.characteristic), "m": int(GF.degree),
+                                                     "irr": int(GF.irreducible_poly), "alpha": int(GF.primitive_element)}))
+        out[f"ew/{tag}/a"], out[f"ew/{tag}/b"], out[f"ew/{tag}/e"] = a, b, e
+        out[f"ew/{tag}/add"] = small(ga + gb)
+        out[f"ew/{tag}/sub"] = small(ga - gb)
+        out[f"ew/{tag}/mul"] = small(ga * gb)
+        out[f"ew/{tag}/neg"] = small(-ga)
+        out[f"ew/{tag}/div"] = small(ga / gbnz)
+        out[f"ew/{tag}/recip"] = small(gbnz**-1)
+        out[f"ew/{tag}/pow"] = small(ganz**e)
+        out[f"ew/{tag}/pow12345"] = small(ga**12345)
+        out[f"ew/{tag}/pow_minus7"] = small(ganz**-7)
+        print("table field", tag, flush=True)
+    for tag, order, n in [("gf769_768", 769, 768), ("gf7681_1536", 7681, 1536), ("gf127e2_2304", 127**2, 2304), ("gf2e12_4095", 2**12, 4095),
+                          ("gf3e7_1093", 3**7, 1093)]:
+        GF = load_reference.ref_field(order)
+        x = rng.integers(0, order, n, dtype=np.uint64)
+        out[f"ntt/{tag}/meta"] = np.array(json.dumps({"p": int(GF.characteristic), "m": int(GF.degree),
+                                                      "irr": int(GF.irreducible_poly), "alpha": int(GF.primitive_element)}))
+        out[f"ntt/{tag}/x"] = x
+        out[f"ntt/{tag}/fft"] = small(np.fft.fft(GF([int(v) for v in x])))
+        print("mixed-radix transform", tag, flush=True)
+    np.savez_compressed(os.path.join(OUT_DIR, "reference_table_fields.npz"), **out)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["fields", "rs", "reference", "bch", "reference_bch", "reference_wide", "linalg", "polys"]
+    what = sys.argv[1:] or ["fields", "rs", "reference", "bch", "reference_bch", "reference_wide", "reference_tables", "linalg", "polys"]
     if "fields" in what:
         pack_sage_fields()
         pack_sage_wide_fields()
@@ -456,4 +509,6 @@ if __name__ == "__main__":
         reference_bch_outputs()
     if "reference_wide" in what:
         reference_wide_codes()
+    if "reference_tables" in what:
+        reference_table_fields()
     print("done")

@@ -35,6 +35,10 @@ def reference_outputs():
     return np.load(os.path.join(GOLDEN, "reference_outputs.npz"))
 
 
+def reference_table_fields():
+    return np.load(os.path.join(GOLDEN, "reference_table_fields.npz"))
+
+
 def sage_rs():
     d = np.load(os.path.join(GOLDEN, "sage_rs.npz"))
     names = json.loads(str(d["names"]))

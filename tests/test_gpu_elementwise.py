@@ -78,6 +78,37 @@ def test_reference_outputs(tag):
     GF.compile("auto")
 
 
+@pytest.mark.parametrize("tag", ["gf3e7", "gf2e10", "gf2e13", "gf5e5", "gf8191", "gf2e14", "gf3e9", "gf2e15", "gf32749", "gf2e16", "gf3e10",
+                                 "gf65521", "gf251e2"])
+def test_reference_outputs_for_table_fields_through_the_lds_kernels(tag):
+    """Outputs of the reference itself for fields of 257 .. 65536 elements (tests/golden/reference_table_fields.npz), repeated to
+    2^19 elements on uint16 storage so that the LDS-table kernels (not the generic ones) produce them, in every mode."""
+    d = H.reference_table_fields()
+    meta = json.loads(str(d[f"ew/{tag}/meta"]))
+    p, m = meta["p"], meta["m"]
+    GF = ga.GF(p, m, irreducible_poly=meta["irr"], primitive_element=meta["alpha"]) if m > 1 else ga.GF(p, primitive_element=meta["alpha"])
+    reps = 2048
+    a, b, e = d[f"ew/{tag}/a"], d[f"ew/{tag}/b"], d[f"ew/{tag}/e"]
+    big = lambda v: np.tile(np.asarray(v), reps)
+    mk = lambda v: GF(big(v).astype(np.uint16), dtype=np.uint16)
+    try:
+        for mode in list(GF.ufunc_modes) + ["auto"]:
+            GF.compile(mode)
+            ga_, gb_ = mk(a), mk(b)
+            gbnz, ganz = mk(np.where(b == 0, 1, b)), mk(np.where(a == 0, 1, a))
+            H.assert_equal_ints((ga_ + gb_).numpy(), big(d[f"ew/{tag}/add"]), "add")
+            H.assert_equal_ints((ga_ - gb_).numpy(), big(d[f"ew/{tag}/sub"]), "sub")
+            H.assert_equal_ints((ga_ * gb_).numpy(), big(d[f"ew/{tag}/mul"]), "mul")
+            H.assert_equal_ints((-ga_).numpy(), big(d[f"ew/{tag}/neg"]), "neg")
+            H.assert_equal_ints((ga_ / gbnz).numpy(), big(d[f"ew/{tag}/div"]), "div")
+            H.assert_equal_ints(np.reciprocal(gbnz).numpy(), big(d[f"ew/{tag}/recip"]), "recip")
+            H.assert_equal_ints((ganz ** big(e)).numpy(), big(d[f"ew/{tag}/pow"]), "pow")
+            H.assert_equal_ints((ga_ ** 12345).numpy(), big(d[f"ew/{tag}/pow12345"]), "pow12345")
+            H.assert_equal_ints((ganz ** -7).numpy(), big(d[f"ew/{tag}/pow_minus7"]), "pow_minus7")
+    finally:
+        GF.compile("auto")
+
+
 def test_gf256_full_size_1e8_bit_exact():
     """BASELINE.json configs[1] at full size: 1e8 uint8 elements, every output byte compared with the oracle."""
     n = 100_000_000

@@ -94,6 +94,43 @@ def test_reference_elementwise_outputs(tag):
             F.pow([0], [-1])
 
 
+TABLE_FIELD_TAGS = ["gf3e7", "gf2e10", "gf2e13", "gf5e5", "gf8191", "gf2e14", "gf3e9", "gf2e15", "gf32749", "gf2e16", "gf3e10", "gf65521",
+                    "gf251e2"]
+
+
+@pytest.mark.parametrize("tag", TABLE_FIELD_TAGS)
+def test_reference_outputs_for_table_fields(tag):
+    """Fields of 257 .. 65536 elements -- the size classes the LDS-table kernels serve (csrc/gfa_elementwise_mid.hip) and the GPU
+    tests check against the oracle's lookup ufuncs on large arrays: here the oracle itself, in both of its modes, against outputs
+    of the reference (tests/golden/generate_golden.py reference_tables)."""
+    d = H.reference_table_fields()
+    meta = json.loads(str(d[f"ew/{tag}/meta"]))
+    a, b, e = d[f"ew/{tag}/a"], d[f"ew/{tag}/b"], d[f"ew/{tag}/e"]
+    bnz, anz = np.where(b == 0, 1, b), np.where(a == 0, 1, a)
+    for lookup in (True, False):
+        F = _field_from_meta(meta, lookup)
+        H.assert_equal_ints(F.add(a, b), d[f"ew/{tag}/add"])
+        H.assert_equal_ints(F.sub(a, b), d[f"ew/{tag}/sub"])
+        H.assert_equal_ints(F.mul(a, b), d[f"ew/{tag}/mul"])
+        H.assert_equal_ints(F.neg(a), d[f"ew/{tag}/neg"])
+        H.assert_equal_ints(F.div(a, bnz), d[f"ew/{tag}/div"])
+        H.assert_equal_ints(F.recip(bnz), d[f"ew/{tag}/recip"])
+        H.assert_equal_ints(F.pow(anz, e), d[f"ew/{tag}/pow"])
+        H.assert_equal_ints(F.pow(a, np.full(a.size, 12345, dtype=np.int64)), d[f"ew/{tag}/pow12345"])
+        H.assert_equal_ints(F.pow(anz, np.full(a.size, -7, dtype=np.int64)), d[f"ew/{tag}/pow_minus7"])
+
+
+@pytest.mark.parametrize("tag", ["gf769_768", "gf7681_1536", "gf127e2_2304", "gf2e12_4095", "gf3e7_1093"])
+def test_reference_mixed_radix_transforms_of_the_fft_benchmark_sizes(tag):
+    """np.fft.fft of the reference over the lengths of its own FFT benchmark (benchmarks/test_fft.py: 256 K points over the first
+    prime-power field with such a root -- incl. 2304 points over GF(127^2)) and two odd lengths over table fields."""
+    d = H.reference_table_fields()
+    meta = json.loads(str(d[f"ntt/{tag}/meta"]))
+    for lookup in (True, False):
+        F = _field_from_meta(meta, lookup)
+        H.assert_equal_ints(F.ntt(d[f"ntt/{tag}/x"]), d[f"ntt/{tag}/fft"])
+
+
 def test_reference_ntt_outputs():
     from galois_amd import _numtheory as nt
 

@@ -203,17 +203,17 @@ def test_poly_evaluate_and_log_against_reference(order):
 
 
 def test_committed_reference_vectors_regenerate_identically(tmp_path):
-    """tests/golden/generate_golden.py (reference, reference_bch, reference_wide) run against /root/reference must reproduce
+    """tests/golden/generate_golden.py (reference, reference_bch, reference_wide, reference_tables) run against /root/reference must reproduce
     the committed .npz files array for array: the fixtures are outputs of the reference, not of this repository."""
     import subprocess
     import sys
 
     gen = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "generate_golden.py")
     env = dict(os.environ, GOLDEN_OUT=str(tmp_path))
-    r = subprocess.run([sys.executable, gen, "reference", "reference_bch", "reference_wide"], capture_output=True, text=True, env=env,
-                       cwd=os.path.dirname(gen), timeout=1200)
+    r = subprocess.run([sys.executable, gen, "reference", "reference_bch", "reference_wide", "reference_tables"], capture_output=True, text=True,
+                       env=env, cwd=os.path.dirname(gen), timeout=1800)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    for name in ("reference_outputs.npz", "reference_bch_outputs.npz", "reference_wide_codes.npz"):
+    for name in ("reference_outputs.npz", "reference_bch_outputs.npz", "reference_wide_codes.npz", "reference_table_fields.npz"):
         new = np.load(os.path.join(str(tmp_path), name), allow_pickle=True)
         old = np.load(os.path.join(os.path.dirname(gen), name), allow_pickle=True)
         assert sorted(new.files) == sorted(old.files), name
