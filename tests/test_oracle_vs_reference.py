@@ -219,3 +219,58 @@ def test_committed_reference_vectors_regenerate_identically(tmp_path):
         assert sorted(new.files) == sorted(old.files), name
         for k in new.files:
             assert np.array_equal(new[k], old[k]), (name, k)
+
+
+FACTORY_ORDERS = [2, 3, 5, 7, 31, 251, 257, 509, 3191, 8191, 32749, 65521, 65537, 7340033, 2147483647, 4294967291, 2**61 - 1,
+                  2**64 - 2**32 + 1, 18446744073709551557, 2**2, 2**3, 2**4, 2**8, 2**9, 2**10, 2**12, 2**13, 2**14, 2**15, 2**16, 2**17,
+                  2**20, 2**24, 2**31, 2**32, 3**2, 3**4, 3**5, 3**7, 3**9, 3**10, 5**3, 5**5, 7**3, 7**5, 11**4, 13**4, 127**2, 251**2,
+                  251**3, 31**5, 2**100, 36893488147419103183, 109987**4]
+
+
+@pytest.mark.parametrize("order", FACTORY_ORDERS)
+def test_field_factory_matches_the_reference(order):
+    """galois_amd.GF(order) against galois.GF(order) of the reference, live: name, characteristic / degree / order, default
+    irreducible polynomial (Conway table), default primitive element, is_primitive_poly, the dtype list and the array-free parts
+    of `properties` -- the host side of SURVEY.md 8(a1) / (a3) for every size class the device kernels distinguish."""
+    import galois_amd as ga
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        R = load_reference.ref_field(order)
+    G = ga.GF(order)
+    assert (G.name, G.characteristic, G.degree, G.order) == (R.name, R.characteristic, R.degree, R.order)
+    assert int(G.irreducible_poly) == int(R.irreducible_poly)
+    assert int(G.primitive_element) == int(R.primitive_element)
+    assert bool(G.is_primitive_poly) == bool(R.is_primitive_poly)
+    assert G.is_prime_field == R.is_prime_field and G.is_extension_field == R.is_extension_field
+    assert [np.dtype(d) for d in G.dtypes] == [np.dtype(d) for d in R.dtypes]
+    assert str(G.irreducible_poly) == str(R.irreducible_poly)
+
+
+def test_number_theory_matches_the_reference():
+    """galois_amd/_numtheory.py (what the field factory and galois.ntt's modulus choice stand on) against the reference's functions
+    of the same names, live: primality, factorisation, primitive roots, irreducibility / primitivity of polynomials, the MATLAB
+    default polynomials and the Conway table."""
+    from galois_amd import _numtheory as nt
+
+    galois = load_reference.load()
+    rng = np.random.default_rng(7)
+    numbers = [1, 2, 3, 4, 31, 255, 256, 257, 65535, 65536, 65537, 7340033, 2**31 - 1, 2**32 - 1, 2**32 + 1, 4294967291, 2**61 - 1,
+               2**64 - 2**32 + 1, 2**64 - 2**32, 3**20, 2**63, 1000003 * 999983] + [int(v) for v in rng.integers(2, 2**40, 40)]
+    for n in numbers:
+        assert nt.is_prime(n) == bool(galois.is_prime(n)), n
+        if n > 1:
+            f, e = galois.factors(n)
+            assert nt.factors(n) == ([int(v) for v in f], [int(v) for v in e]), n
+    for p in (2, 3, 5, 7, 31, 257, 769, 7681, 12289, 65537, 7340033, 469762049, 2**31 - 1, 2**61 - 1, 2**64 - 2**32 + 1):
+        assert nt.primitive_root(p) == int(galois.primitive_root(p)), p
+    for p, m in ((2, 2), (2, 8), (2, 16), (2, 32), (3, 5), (3, 10), (5, 4), (7, 3), (127, 2), (251, 3), (2, 100), (109987, 4)):
+        assert nt.conway_poly(p, m) == int(galois.conway_poly(p, m)), (p, m)
+    for p, m in ((2, 2), (2, 3), (2, 4), (2, 7), (2, 8), (2, 16)):  # (odd p: the reference's polynomial search needs its JIT arrays)
+        assert nt.matlab_primitive_poly(p, m) == int(galois.matlab_primitive_poly(p, m)), (p, m)
+    for val in (0x11B, 0x11D, 0x11C, 0x1002D, 0x10001, 0b111, 0b1011, 0b1111, 0x100008299):  # over GF(2)
+        coeffs = nt.poly_from_int(val, 2)
+        ref = galois.Poly.Int(val)
+        assert nt.is_irreducible(coeffs, 2) == bool(ref.is_irreducible()), hex(val)
+        if nt.is_irreducible(coeffs, 2):
+            assert nt.is_primitive_poly(coeffs, 2) == bool(ref.is_primitive()), hex(val)
