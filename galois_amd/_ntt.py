@@ -105,6 +105,15 @@ def _max_value(x) -> int:
     return int(max(int(v) for v in np.asarray(arr).ravel()))
 
 
+def _default_modulus(max_x: int, size: int) -> int:
+    """The prime modulus galois.ntt picks when none is given: the first prime m * size + 1 with m >= ceil(max(x) / size)
+    (_ntt.py:250-254, same floating-point ceiling)."""
+    m = int(np.ceil(max_x / size))
+    while not is_prime(m * size + 1):
+        m += 1
+    return m * size + 1
+
+
 def _ntt(x, size=None, modulus=None, forward=True, scaled=True):
     from ._factory import GF
 
@@ -118,10 +127,7 @@ def _ntt(x, size=None, modulus=None, forward=True, scaled=True):
     size = int(size)
     max_x = _max_value(x)
     if modulus is None:
-        m = int(np.ceil(max_x / size))  # the smallest m such that modulus > max(x) (_ntt.py:250-254)
-        while not is_prime(m * size + 1):
-            m += 1
-        modulus = m * size + 1
+        modulus = _default_modulus(max_x, size)
     modulus = int(modulus)
     if not size >= len(x):
         raise ValueError(f"Argument 'size' must be at least the length of the input which is {len(x)}, not {size}.")

@@ -274,3 +274,23 @@ def test_number_theory_matches_the_reference():
         assert nt.is_irreducible(coeffs, 2) == bool(ref.is_irreducible()), hex(val)
         if nt.is_irreducible(coeffs, 2):
             assert nt.is_primitive_poly(coeffs, 2) == bool(ref.is_primitive()), hex(val)
+
+
+@pytest.mark.parametrize("x,size", [([1, 2, 3, 4], None), ([1, 2, 3, 4], 8), ([0, 0, 0, 0], None), ([100, 200, 300], 4), ([65536] * 16, None),
+                                    ([12288] * 8, 1024), ([7340032, 5], 1 << 20), (list(range(30)), 32), ([2**31, 1, 2, 3], None)])
+def test_default_ntt_modulus_matches_the_reference(x, size):
+    """galois.ntt(x, size) without a modulus: the field the reference's result lives in against galois_amd._ntt._default_modulus."""
+    from galois_amd._ntt import _default_modulus
+
+    galois = load_reference.load()
+    n = size or len(x)
+    want = _default_modulus(max(x), n)
+    if n <= 64:  # run the reference's transform itself for the small cases
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            X = galois.ntt(x, size=size)
+        assert int(type(X).characteristic) == want
+    m = int(np.ceil(max(x) / n))
+    while not galois.is_prime(m * n + 1):
+        m += 1
+    assert want == m * n + 1
