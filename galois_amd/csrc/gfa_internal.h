@@ -32,6 +32,13 @@ void ntt_forget_field(const struct ::gfa_field *f); // drops cached NTT plans of
 bool ntt_fermat16_eligible(const FieldDev &fd, i64 n, i64 batch);
 int ntt_fermat16(const void *in, void *out, i64 batch, u64 omega, int negate, hipStream_t st);
 
+// power-of-two transforms over GF(p), p < 2^26, on signed Montgomery representatives (gfa_ntt_m32.hip); contiguous rows.
+// `ws` holds ntt_m32_scratch_bytes(n, batch) bytes (the two-pass intermediate; 0 for n <= 1024).
+bool ntt_m32_eligible(const FieldDev &fd, i64 n);
+size_t ntt_m32_scratch_bytes(i64 n, i64 batch);
+int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 batch, u64 omega, int do_scale, u64 scale,
+            hipStream_t st);
+
 // discrete logarithms without tables (gfa_dlog.hip)
 void dlog_forget_field(const struct ::gfa_field *f);
 int dlog_run(struct ::gfa_field *f, const void *a, i64 sa, const void *base, i64 sb, int64_t *out, i64 n, int dtype, hipStream_t st,

@@ -1639,6 +1639,14 @@ int run_typed(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *
                 done = rc == GFA_OK;
             }
         }
+        if constexpr (std::is_same<F, Prime32>::value) {
+            // p < 2^26: signed Montgomery butterflies, table twiddles (gfa_ntt_m32.hip)
+            if (!done && ntt_m32_eligible(fd, n) && !g_layout_in.chunk_len && !g_layout_out.chunk_len) {
+                if ((rc = pl->sc->ws0.ensure(ntt_m32_scratch_bytes(n, batch)))) return rc;
+                if ((rc = ntt_m32(fd, ein, eout, pl->sc->ws0.p, n, batch, omega, do_scale, scale, st))) return rc;
+                done = true;
+            }
+        }
         if (done) {
         } else if (lg >= 2 && lg <= 2 * REG_MAX_LOG) {
             if constexpr (std::is_same<F, Prime32>::value) {

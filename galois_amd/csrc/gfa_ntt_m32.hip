@@ -1,0 +1,531 @@
+// gfa_ntt_m32.hip -- power-of-two transforms over GF(p), odd p < 2^26, on SIGNED Montgomery representatives.
+//
+// Replaces fft_jit / ifft_jit (reference: src/galois/_domains/_function.py:246-392) for 32 <= n <= 2^20 points.  Exact field
+// arithmetic: any correct DFT algorithm reproduces the reference's bits.  Same tiling as ntt_reg_kernel (gfa_ntt.hip) --
+// lines of L = R1 * R2 <= 1024 points, R1 points of one line per thread, two in-register decimation-in-frequency networks
+// joined by one LDS exchange, n > 1024 as a four-step transform in two passes -- with the arithmetic and the addressing redone
+// after the round-2 counters (56.5 vector instructions per point and pass, VALU-bound):
+//
+//   * values are int32 representatives of their residue class, never "reduced": a butterfly is v_add + v_sub with no bias
+//     and no conditional correction.  A twiddle product is Montgomery's  (x*w - m*p) / 2^32  with m = x * (w * p^-1 mod
+//     2^32): for ANY int32 x and |w| <= p/2 the result lies in (-p, p) -- v_mul_lo, v_mul_hi_i32, v_mul_hi_i32, v_sub.  A
+//     radix-32 network grows its inputs by at most 2^5, and every value that leaves a network meets one product (the middle
+//     twiddle, the inter-pass twiddle, or the final normalisation that carries the 1/n scale), so |v| < 32 p < 2^31 always;
+//   * twiddles inside the networks are wave-uniform (scalar registers), the middle twiddle w_L^(r*k) comes from a
+//     transposed LDS table addressed by immediates, the inter-pass twiddle w_n^(j2*k1) from an n-entry table laid out like
+//     the pass's output (the old kernel built it per thread as a Montgomery progression: 2 products per point);
+//   * every global access is  scalar base + one per-thread 32-bit offset: no per-point address arithmetic on the vector ALU.
+#include <algorithm>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+#include "gfa_internal.h"
+
+using namespace gfa;
+
+namespace {
+
+typedef int i32;
+
+struct M32Args {
+    i64 in_stride_c, in_stride_t;   // elements: element (line c, position t) at c * stride_c + t * stride_t
+    i64 out_stride_c, out_stride_t;
+    i64 in_batch_stride, out_batch_stride;
+    i64 total_lines; // lines per batch item
+    int tiles_per_batch;
+    int load_along_line, store_along_line; // which index runs fastest across lanes (the contiguous one in memory)
+    int post_twiddle;                      // multiply output by tw[offset of the output inside its batch item]
+    int tile_order;                        // 0: identity; 1: XCD x owns a contiguous range of tiles of every batch item
+    i32 p;
+    u32 pinv;     // p^-1 mod 2^32
+    i32 fin, finp; // last pass: outputs * fin (Montgomery form of 1 or of 1/n), finp = fin * pinv
+};
+
+// v_mul_hi_i32 through inline assembly: the compiler matches the signed high product only while the sign extensions sit in
+// the same basic block; once it hoists sext(p) out of a block it expands every product into four unsigned multiplies.
+// "s": wave-uniform operand in a scalar register (kernel argument or scalar load) -- one constant-bus read per VOP3.
+__device__ __forceinline__ i32 mulhi_vs(i32 x, i32 s)
+{
+    i32 r;
+    asm("v_mul_hi_i32 %0, %1, %2" : "=v"(r) : "v"(x), "s"(s));
+    return r;
+}
+__device__ __forceinline__ i32 mulhi_vv(i32 x, i32 y)
+{
+    i32 r;
+    asm("v_mul_hi_i32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
+// x * w * 2^-32 (mod p) as a representative in (-p, p); any int32 x, |wm| <= p/2, wp = wm * p^-1 mod 2^32
+// (uniform twiddle: wm, wp, p in scalar registers)
+__device__ __forceinline__ i32 mulm(i32 x, i32 wm, i32 wp, i32 p)
+{
+    const i32 m = (i32)((u32)x * (u32)wp);
+    return mulhi_vs(x, wm) - mulhi_vs(m, p);
+}
+// per-lane twiddle (wm, wp in vector registers)
+__device__ __forceinline__ i32 mulm_v(i32 x, i32 wm, i32 wp, i32 p)
+{
+    const i32 m = (i32)((u32)x * (u32)wp);
+    return mulhi_vv(x, wm) - mulhi_vs(m, p);
+}
+
+// the same product when only wm is at hand (table twiddles, 4 bytes per entry): t = x * wm as one 64-bit multiply-add,
+// m = lo(t) * p^-1, result = hi(t + m * (-p)).  (Inline assembly: clang expands the second signed 64-bit product into an
+// unsigned multiply-add plus sign corrections.)
+__device__ __forceinline__ i32 mulm1(i32 x, i32 wm, u32 pinv, i32 negp)
+{
+    long long t, r;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, 0" : "=v"(t) : "v"(x), "v"(wm) : "vcc");
+    const i32 m = (i32)((u32)t * pinv);
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(m), "s"(negp), "v"(t) : "vcc");
+    return (i32)(r >> 32);
+}
+
+constexpr int brev_c(int x, int bits)
+{
+    int r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+// v[bitrev(k)] <- sum_a v[a] * w_R^(a*k);  net[2j], net[2j+1] = Montgomery form of w_R^j and its p^-1 companion (uniform)
+template <int LOGR>
+__device__ __forceinline__ void dif(i32 (&v)[1 << LOGR], const i32 *__restrict__ net, i32 p)
+{
+    constexpr int R = 1 << LOGR;
+#pragma unroll
+    for (int s = LOGR - 1; s >= 0; s--) {
+        const int half = 1 << s;
+#pragma unroll
+        for (int b = 0; b < R; b += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; j++) {
+                const i32 u = v[b + j], x = v[b + j + half];
+                v[b + j] = (i32)((u32)u + (u32)x);
+                const i32 d = (i32)((u32)u - (u32)x);
+                const int tj = j << (LOGR - 1 - s);
+                if (tj != 0) v[b + j + half] = mulm(d, net[2 * tj], net[2 * tj + 1], p);
+                else v[b + j + half] = d;
+            }
+        }
+    }
+}
+
+template <int C>
+constexpr int line_pitch(int rows, int row)
+{ // words per staged line: rows * row rounded up so that the lanes of one LDS access fall into distinct banks
+    // C >= 32: 32 lines per half wave -> odd pitch; C <= 16: pitch = 4 (mod 32) separates 8..16 lines x 4..2 positions
+    const int base = rows * row;
+    const int want = C >= 32 ? 1 : 4;
+    return base + ((want - base) % 32 + 32) % 32;
+}
+
+template <int LOGR1, int LOGR2, int THREADS, bool SPLIT>
+__global__ __launch_bounds__(THREADS) void ntt_m32_kernel(const i32 *__restrict__ in, i32 *__restrict__ out, M32Args a,
+                                                          const i32 *__restrict__ net1, const i32 *__restrict__ net2,
+                                                          const i32 *__restrict__ mid, const i32 *__restrict__ tw)
+{
+    constexpr int R1 = 1 << LOGR1, R2 = 1 << LOGR2, L = R1 * R2;
+    constexpr int C = THREADS / R1; // lines per tile
+    constexpr int LOGC = __builtin_ctz(C);
+    constexpr int ROW = R2 + 1;
+    constexpr int RROWS = SPLIT ? R1 / 2 : R1; // rows of a line resident in LDS at a time
+    constexpr int PC = line_pitch<C>(RROWS, ROW);
+    static_assert(C * R2 <= THREADS, "step A needs C * R2 threads");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    i32 *data = reinterpret_cast<i32 *>(smem_raw);   // C * PC
+    i32 *midl = data + ((C * PC + 1) & ~1);           // [ka][r] pairs (w_L^(r*ka) in Montgomery form, companion)
+
+    const int tid = threadIdx.x;
+    u32 vb = blockIdx.x;
+    if (a.tile_order == 1) {
+        // workgroup b runs on XCD b % 8 (own L2).  XCD x gets tiles [x * per, (x + 1) * per) of every batch item: the two
+        // halves of a 128-byte line of a strided pass meet in one L2, and the slice of the inter-pass table an XCD reads is
+        // 1/8 of the table, re-used for every batch item.
+        const u32 x = vb & 7u, i = vb >> 3, per = (u32)a.tiles_per_batch >> 3;
+        vb = (i / per) * (u32)a.tiles_per_batch + x * per + (i % per);
+    }
+    const u32 batch = vb / (u32)a.tiles_per_batch;
+    const u32 tile = vb % (u32)a.tiles_per_batch;
+    const i64 line0 = (i64)tile * C;
+    const i32 *gin = in + (i64)batch * a.in_batch_stride + line0 * a.in_stride_c;
+    const i64 out_tile = line0 * a.out_stride_c; // offset inside the batch item: also the inter-pass table's index
+    i32 *gout = out + (i64)batch * a.out_batch_stride + out_tile;
+    const i32 *gtw = tw + out_tile;
+    const i32 p = a.p;
+
+    // middle twiddles, transposed: midl[2 * (ka * R2 + r)] -- staged while the first loads are in flight
+    for (int i = tid; i < L; i += THREADS) {
+        const int ka = i >> LOGR2, r = i & (R2 - 1);
+        const int2 wv = reinterpret_cast<const int2 *>(mid)[r * ka];
+        reinterpret_cast<int2 *>(midl)[i] = wv;
+    }
+
+    const bool active_a = (C * R2 == THREADS) || tid < C * R2;
+    int ca, ra_;
+    if (a.load_along_line) { ca = tid >> LOGR2; ra_ = tid & (R2 - 1); }
+    else { ra_ = tid >> LOGC; ca = tid & (C - 1); }
+    int c, ka;
+    if (a.store_along_line) { c = tid >> LOGR1; ka = tid & (R1 - 1); }
+    else { ka = tid >> LOGC; c = tid & (C - 1); }
+
+    i32 v[R2];
+    if (SPLIT) {
+        // v is written in exactly one of the two exchange rounds; tell the compiler so (no instruction), otherwise it
+        // zero-fills the registers ahead of the rounds
+#pragma unroll
+        for (int r = 0; r < R2; r++) asm volatile("" : "=v"(v[r]));
+    }
+    {
+        i32 va[R1];
+        if (C * R2 != THREADS) {
+#pragma unroll
+            for (int k = 0; k < R1; k++) asm volatile("" : "=v"(va[k]));
+        }
+        if (active_a) {
+            const i64 last = a.total_lines - 1 - line0; // lines past the end are clamped (computed, never stored)
+            const u32 cl = (u32)((i64)ca <= last ? ca : last);
+            // buffer addressing: descriptor on the tile base, one per-thread byte offset in a VGPR, the position's byte
+            // offset in the scalar operand -- no vector-ALU address arithmetic per load (the host checks the 32-bit range)
+            const u32 off = (cl * (u32)a.in_stride_c + (u32)ra_ * (u32)a.in_stride_t) * 4u;
+            const u32 step = (u32)R2 * (u32)a.in_stride_t * 4u; // uniform
+            const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)gin, 0, 0xffffffffu, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < R1; k++) va[k] = __builtin_amdgcn_raw_buffer_load_b32(rin, (int)off, (int)(k * step), 0);
+            dif<LOGR1>(va, net1, p);
+        }
+        __syncthreads(); // middle-twiddle table staged
+#pragma unroll
+        for (int h = 0; h < (SPLIT ? 2 : 1); h++) {
+            if (active_a) {
+                i32 *dst = data + ca * PC + ra_;
+                const int2 *mrow = reinterpret_cast<const int2 *>(midl) + ra_;
+#pragma unroll
+                for (int kl = 0; kl < RROWS; kl++) {
+                    const int kaa = h * RROWS + kl;
+                    const int2 wv = mrow[kaa * R2];
+                    dst[kl * ROW] = mulm_v(va[brev_c(kaa, LOGR1)], wv.x, wv.y, p);
+                }
+            }
+            __syncthreads();
+            if (!SPLIT || (ka / RROWS) == h) {
+                const i32 *srcl = data + c * PC + (ka - h * RROWS) * ROW;
+#pragma unroll
+                for (int r = 0; r < R2; r++) v[r] = srcl[r];
+            }
+            if (SPLIT && h == 0) __syncthreads();
+        }
+    }
+    dif<LOGR2>(v, net2, p);
+    const u32 ooff = ((u32)c * (u32)a.out_stride_c + (u32)ka * (u32)a.out_stride_t) * 4u;
+    const u32 ostep = (u32)R1 * (u32)a.out_stride_t * 4u; // uniform
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)gout, 0, 0xffffffffu, 0x00020000);
+    const bool live = line0 + c < a.total_lines;
+    if (a.post_twiddle) {
+        // * w_n^(line * k): one table entry per output, fetched with the store's own offsets (tile bases are uniform)
+        const u32 pinv = a.pinv;
+        const i32 negp = -p;
+        const __amdgpu_buffer_rsrc_t rtw = __builtin_amdgcn_make_buffer_rsrc((void *)gtw, 0, 0xffffffffu, 0x00020000);
+        if (live) {
+#pragma unroll
+            for (int g = 0; g < R2; g += 8) {
+                i32 t[8];
+#pragma unroll
+                for (int kr = g; kr < g + 8 && kr < R2; kr++) t[kr - g] = __builtin_amdgcn_raw_buffer_load_b32(rtw, (int)ooff, (int)(kr * ostep), 0);
+#pragma unroll
+                for (int kr = g; kr < g + 8 && kr < R2; kr++)
+                    __builtin_amdgcn_raw_buffer_store_b32(mulm1(v[brev_c(kr, LOGR2)], t[kr - g], pinv, negp), rout, (int)ooff, (int)(kr * ostep), 0);
+            }
+        }
+    } else {
+        const i32 fin = a.fin, finp = a.finp;
+        if (live) {
+#pragma unroll
+            for (int kr = 0; kr < R2; kr++) {
+                i32 x = mulm(v[brev_c(kr, LOGR2)], fin, finp, p); // (-p, p)
+                x += p & (x >> 31);                                // [0, p)
+                __builtin_amdgcn_raw_buffer_store_b32(x, rout, (int)ooff, (int)(kr * ostep), 0);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: tables and plans
+// ------------------------------------------------------------------------------------------------
+__global__ void m32_interpass_table_kernel(u32 p, u32 omega, int log1, int log2, i32 *tw)
+{ // tw[k1 * n2 + j2] = centred Montgomery form of omega^(j2 * k1)
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 n = (i64)1 << (log1 + log2);
+    if (i >= n) return;
+    const u64 k1 = (u64)i >> log2, j2 = (u64)i & (((u64)1 << log2) - 1);
+    u64 e = (k1 * j2) & (u64)(n - 1), b = omega, r = 1;
+    while (e) {
+        if (e & 1) r = r * b % p;
+        b = b * b % p;
+        e >>= 1;
+    }
+    u64 m = (r << 32) % p;
+    tw[i] = m > p / 2 ? (i32)((i64)m - (i64)p) : (i32)m;
+}
+
+inline u64 powmod(u64 b, u64 e, u64 p)
+{
+    u64 r = 1;
+    b %= p;
+    while (e) {
+        if (e & 1) r = r * b % p;
+        b = b * b % p;
+        e >>= 1;
+    }
+    return r;
+}
+
+inline u32 inv_2_32(u32 p)
+{ // Newton iteration, p odd
+    u32 x = p;
+    for (int i = 0; i < 5; i++) x *= 2u - p * x;
+    return x;
+}
+
+inline i32 mont_centred(u64 w, u64 p)
+{
+    const u64 m = (w << 32) % p;
+    return m > p / 2 ? (i32)((i64)m - (i64)p) : (i32)m;
+}
+
+struct M32Plan {
+    int log1 = 0, log2 = 0;
+    i32 *net1 = nullptr, *net2 = nullptr; // R/2 pairs each
+    i32 *mid1 = nullptr, *mid2 = nullptr; // L pairs: w_L^e, companion
+    i32 *tw = nullptr;                    // n entries (two-pass only)
+};
+
+struct M32Key {
+    u64 p; int device; i64 n; u64 omega;
+    bool operator<(const M32Key &o) const { return std::tie(p, device, n, omega) < std::tie(o.p, o.device, o.n, o.omega); }
+};
+
+std::mutex g_m32_mu;
+std::map<M32Key, M32Plan *> g_m32_plans;
+
+void free_plan(M32Plan *pl)
+{
+    for (void *q : {(void *)pl->net1, (void *)pl->net2, (void *)pl->mid1, (void *)pl->mid2, (void *)pl->tw})
+        if (q) (void)hipFree(q);
+    delete pl;
+}
+
+int upload(const std::vector<i32> &h, i32 **d)
+{
+    GFA_HIP(hipMalloc((void **)d, sizeof(i32) * h.size()));
+    GFA_HIP(hipMemcpy(*d, h.data(), sizeof(i32) * h.size(), hipMemcpyHostToDevice));
+    return GFA_OK;
+}
+
+// pairs (Montgomery form of w^e, companion) for e < count, w = omega^mult
+int pair_table(u64 p, u32 pinv, u64 omega, u64 mult, int count, i32 **d)
+{
+    std::vector<i32> h(2 * (size_t)count);
+    const u64 w = powmod(omega, mult, p);
+    u64 cur = 1;
+    for (int e = 0; e < count; e++) {
+        const i32 wm = mont_centred(cur, p);
+        h[2 * e] = wm;
+        h[2 * e + 1] = (i32)((u32)wm * pinv);
+        cur = cur * w % p;
+    }
+    return upload(h, d);
+}
+
+constexpr int split_log1(int logL) { return (logL + 1) / 2; } // R1 >= R2
+
+int build_plan(M32Plan *pl, u64 p, i64 n, u64 omega, hipStream_t st)
+{
+    int logn = 0;
+    while (((i64)1 << logn) < n) logn++;
+    if (logn <= 10) { pl->log1 = logn; pl->log2 = 0; }
+    else { pl->log1 = (logn + 1) / 2; pl->log2 = logn - pl->log1; }
+    const u32 pinv = inv_2_32((u32)p);
+    int rc;
+    auto line_tables = [&](int logL, i32 **net_a, i32 **net_b_unused, i32 **mid) -> int {
+        (void)net_b_unused;
+        // networks of a line of L = R1 * R2 points: w_R1 = w_L^R2, w_R2 = w_L^R1; both tables in one allocation [R1/2 | R2/2]
+        const int lr1 = split_log1(logL), lr2 = logL - lr1;
+        const i64 Lh = (i64)1 << logL;
+        const u64 wl_mult = (u64)(n / Lh);
+        std::vector<i32> h;
+        for (int part = 0; part < 2; part++) {
+            const int lr = part ? lr2 : lr1;
+            const int R = 1 << lr;
+            const u64 w = powmod(omega, wl_mult * (u64)(Lh / R), p);
+            u64 cur = 1;
+            for (int e = 0; e < std::max(R / 2, 1); e++) {
+                const i32 wm = mont_centred(cur, p);
+                h.push_back(wm);
+                h.push_back((i32)((u32)wm * pinv));
+                cur = cur * w % p;
+            }
+        }
+        if ((rc = upload(h, net_a))) return rc;
+        return pair_table(p, pinv, omega, wl_mult, (int)Lh, mid);
+    };
+    i32 *dummy = nullptr;
+    if ((rc = line_tables(pl->log1, &pl->net1, &dummy, &pl->mid1))) return rc;
+    if (pl->log2) {
+        if ((rc = line_tables(pl->log2, &pl->net2, &dummy, &pl->mid2))) return rc;
+        GFA_HIP(hipMalloc((void **)&pl->tw, sizeof(i32) * (size_t)n));
+        hipLaunchKernelGGL(m32_interpass_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (u32)p, (u32)omega,
+                           pl->log1, pl->log2, pl->tw);
+        GFA_HIP(hipGetLastError());
+        GFA_HIP(hipStreamSynchronize(st)); // the plan may next be used from another stream
+    }
+    return GFA_OK;
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <int LOGR1, int LOGR2, int THREADS, bool SPLIT>
+int launch_tt(const i32 *in, i32 *out, M32Args a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, hipStream_t st)
+{
+    constexpr int R1 = 1 << LOGR1, R2 = 1 << LOGR2, L = R1 * R2, C = THREADS / R1;
+    constexpr int PC = line_pitch<C>(SPLIT ? R1 / 2 : R1, R2 + 1);
+    constexpr size_t lds = sizeof(i32) * (size_t)(((C * PC + 1) & ~1) + 2 * L);
+    a.tiles_per_batch = (int)((a.total_lines + C - 1) / C);
+    const i64 grid = batch * a.tiles_per_batch;
+    if (grid <= 0 || grid > 0x7fffffff) { set_error("m32 NTT: grid out of range"); return GFA_ERR_UNSUPPORTED; }
+    {
+        const i64 lim = (i64)1 << 30; // elements: byte offsets stay below 2^32
+        if ((C - 1) * a.in_stride_c + (L - 1) * a.in_stride_t >= lim || (C - 1) * a.out_stride_c + (L - 1) * a.out_stride_t >= lim) {
+            set_error("m32 NTT: tile extent exceeds the 32-bit offset range");
+            return GFA_ERR_UNSUPPORTED;
+        }
+    }
+    static const int xcd = env_int("GFA_NTT_XCD", 1);
+    a.tile_order = (xcd && (a.tiles_per_batch % 8) == 0 && a.tiles_per_batch >= 16) ? 1 : 0;
+    auto kern = ntt_m32_kernel<LOGR1, LOGR2, THREADS, SPLIT>;
+    static bool attr = false;
+    if (!attr) {
+        GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), lds, st, in, out, a, net, net + R1, mid, tw);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+template <int LOGR1, int LOGR2>
+int launch_t(const i32 *in, i32 *out, const M32Args &a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, hipStream_t st)
+{
+    if constexpr (LOGR1 == 5) {
+        static const int threads = env_int("GFA_M32_THREADS", 512);
+        static const int split = env_int("GFA_M32_SPLIT", 1);
+        if (threads == 1024) return split ? launch_tt<LOGR1, LOGR2, 1024, true>(in, out, a, batch, net, mid, tw, st)
+                                          : launch_tt<LOGR1, LOGR2, 1024, false>(in, out, a, batch, net, mid, tw, st);
+        if (threads == 256) return split ? launch_tt<LOGR1, LOGR2, 256, true>(in, out, a, batch, net, mid, tw, st)
+                                         : launch_tt<LOGR1, LOGR2, 256, false>(in, out, a, batch, net, mid, tw, st);
+        return split ? launch_tt<LOGR1, LOGR2, 512, true>(in, out, a, batch, net, mid, tw, st)
+                     : launch_tt<LOGR1, LOGR2, 512, false>(in, out, a, batch, net, mid, tw, st);
+    } else {
+        return launch_tt<LOGR1, LOGR2, 256, false>(in, out, a, batch, net, mid, tw, st);
+    }
+}
+
+int launch(int logL, const i32 *in, i32 *out, const M32Args &a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, hipStream_t st)
+{
+    switch (logL) {
+    case 5: return launch_t<3, 2>(in, out, a, batch, net, mid, tw, st);
+    case 6: return launch_t<3, 3>(in, out, a, batch, net, mid, tw, st);
+    case 7: return launch_t<4, 3>(in, out, a, batch, net, mid, tw, st);
+    case 8: return launch_t<4, 4>(in, out, a, batch, net, mid, tw, st);
+    case 9: return launch_t<5, 4>(in, out, a, batch, net, mid, tw, st);
+    case 10: return launch_t<5, 5>(in, out, a, batch, net, mid, tw, st);
+    default: set_error("m32 NTT: unsupported line length"); return GFA_ERR_UNSUPPORTED;
+    }
+}
+
+} // namespace
+
+namespace gfa {
+
+bool ntt_m32_eligible(const FieldDev &fd, i64 n)
+{
+    static const int on = env_int("GFA_NTT_M32", 1);
+    if (!on || fd.kind != KIND_PRIME32 || fd.p >= (1ull << 26) || (fd.p & 1) == 0) return false;
+    if (n < 32 || n > ((i64)1 << 20) || (n & (n - 1))) return false;
+    int logn = 0;
+    while (((i64)1 << logn) < n) logn++;
+    return logn <= 10 || (logn - (logn + 1) / 2) >= 5; // both passes of a two-pass transform need lines of >= 32 points
+}
+
+// Scratch for the two-pass form: n * batch elements (the caller owns it).  Contiguous rows only.
+size_t ntt_m32_scratch_bytes(i64 n, i64 batch) { return n > 1024 ? sizeof(i32) * (size_t)n * (size_t)batch : 0; }
+
+int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 batch, u64 omega, int do_scale, u64 scale,
+            hipStream_t st)
+{
+    int dev = 0;
+    GFA_HIP(hipGetDevice(&dev));
+    M32Plan *pl;
+    {
+        std::lock_guard<std::mutex> lock(g_m32_mu);
+        const M32Key key{fd.p, dev, n, omega};
+        auto it = g_m32_plans.find(key);
+        if (it == g_m32_plans.end()) {
+            if (g_m32_plans.size() >= 64) { // bounded cache: hipFree synchronises, so no launch still reads a freed table
+                for (auto &kv : g_m32_plans) free_plan(kv.second);
+                g_m32_plans.clear();
+            }
+            M32Plan *np = new M32Plan();
+            const int rc = build_plan(np, fd.p, n, omega, st);
+            if (rc) { free_plan(np); return rc; }
+            it = g_m32_plans.emplace(key, np).first;
+        }
+        pl = it->second;
+    }
+    const u32 pinv = inv_2_32((u32)fd.p);
+    M32Args base{};
+    base.p = (i32)fd.p;
+    base.pinv = pinv;
+    base.fin = mont_centred(do_scale ? scale % fd.p : 1, fd.p);
+    base.finp = (i32)((u32)base.fin * pinv);
+    const i32 *src = (const i32 *)in;
+    i32 *dst = (i32 *)out;
+    if (pl->log2 == 0) {
+        M32Args a = base;
+        a.in_stride_c = n; a.in_stride_t = 1; a.out_stride_c = n; a.out_stride_t = 1;
+        a.total_lines = batch;
+        a.load_along_line = 1; a.store_along_line = 1;
+        return launch(pl->log1, src, dst, a, 1, pl->net1, pl->mid1, nullptr, st);
+    }
+    const i64 n1 = (i64)1 << pl->log1, n2 = (i64)1 << pl->log2;
+    i32 *w = (i32 *)ws;
+    { // pass 1: the n2 columns (length n1, stride n2), times w^(j2*k1); same layout out
+        M32Args a = base;
+        a.in_stride_c = 1; a.in_stride_t = n2; a.out_stride_c = 1; a.out_stride_t = n2;
+        a.in_batch_stride = n; a.out_batch_stride = n;
+        a.total_lines = n2;
+        a.post_twiddle = 1;
+        const int rc = launch(pl->log1, src, w, a, batch, pl->net1, pl->mid1, pl->tw, st);
+        if (rc) return rc;
+    }
+    { // pass 2: the n1 rows (contiguous), stored transposed: X[k1 + n1*k2]
+        M32Args a = base;
+        a.in_stride_c = n2; a.in_stride_t = 1; a.out_stride_c = 1; a.out_stride_t = n1;
+        a.in_batch_stride = n; a.out_batch_stride = n;
+        a.total_lines = n1;
+        a.load_along_line = 1; a.store_along_line = 0;
+        return launch(pl->log2, w, dst, a, batch, pl->net2, pl->mid2, nullptr, st);
+    }
+}
+
+} // namespace gfa

@@ -572,3 +572,30 @@ def test_goldilocks_lazy_arithmetic_at_the_extremes(logn):
         assert np.array_equal(got[i], F.ntt(r.copy(), omega=omega)), f"row {i}"
     back = fft_batched(X, inverse=True)._t.cpu().numpy().view(np.uint64)
     assert np.array_equal(back, np.stack(rows))
+
+
+@pytest.mark.parametrize("p,logn", [(28311553, l) for l in range(5, 21)] + [(67043329, l) for l in (5, 9, 10, 11, 13, 16)])
+def test_signed_montgomery_kernel_every_line_shape_at_the_magnitude_limit(p, logn):
+    """gfa_ntt_m32.hip (odd p < 2^26): int32 representatives that are never reduced inside a radix-32 network reach 32 p.
+    28311553 = 27 * 2^20 + 1 covers every line shape up to 2^20 points, 67043329 = 1023 * 2^16 + 1 sits 0.1 % below 2^26.
+    Worst-case rows (all p - 1, alternating 0 / p - 1, an impulse, values within 3 of p) plus random rows, five rows so that
+    the single-pass form runs a partly filled tile; forward against the oracle, inverse (1/n folded into the last product)
+    as a round trip."""
+    assert ga.is_prime(p) and p < 2**26 and (p - 1) % (1 << logn) == 0
+    GF = ga.GF(p)
+    F = O.OracleField(p, 1, None, int(GF.primitive_element))
+    n = 1 << logn
+    omega = GF._root_of_unity_int(n)
+    rng = np.random.default_rng(logn)
+    rows = [np.full(n, p - 1, dtype=np.uint32), np.tile(np.array([0, p - 1], dtype=np.uint32), n // 2),
+            np.concatenate([[p - 1], np.zeros(n - 1, dtype=np.uint32)]).astype(np.uint32),
+            rng.integers(0, p, n, dtype=np.uint32), (p - 1 - rng.integers(0, 3, n)).astype(np.uint32)]
+    X = fft_batched(GF(np.stack(rows)))
+    got = X.numpy()
+    for i, r in enumerate(rows):
+        assert np.array_equal(got[i], F.ntt_u32_pow2(r, omega)), f"row {i}"
+    assert np.array_equal(fft_batched(X, inverse=True).numpy(), np.stack(rows))
+    # the 1-D front end (one row, np.fft.fft / ifft) takes the same kernels
+    one = GF(rows[3])
+    assert np.array_equal(np.fft.fft(one).numpy(), got[3])
+    assert np.array_equal(np.fft.ifft(np.fft.fft(one)).numpy(), rows[3])
