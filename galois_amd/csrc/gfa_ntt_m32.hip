@@ -12,9 +12,14 @@
 //     radix-32 network grows its inputs by at most 2^5, and every value that leaves a network meets one product (the middle
 //     twiddle, the inter-pass twiddle, or the final normalisation that carries the 1/n scale), so |v| < 32 p < 2^31 always;
 //   * twiddles inside the networks are wave-uniform (scalar registers), the middle twiddle w_L^(r*k) comes from a
-//     transposed LDS table addressed by immediates, the inter-pass twiddle w_n^(j2*k1) from an n-entry table laid out like
-//     the pass's output (the old kernel built it per thread as a Montgomery progression: 2 products per point);
-//   * every global access is  scalar base + one per-thread 32-bit offset: no per-point address arithmetic on the vector ALU.
+//     transposed LDS table addressed by immediates, the inter-pass twiddle w_n^(j2*k1) is a per-thread Montgomery
+//     progression seeded from two small tables (an n-entry table was measured: slower, see ntt_m32_kernel);
+//   * every global access is  buffer descriptor on the tile + one per-thread 32-bit offset + a scalar offset: no per-point
+//     address arithmetic on the vector ALU.
+// Result (profiles/r03_*): 33 vector instructions per point and pass (56.5), 2^20 x 64 over GF(7340033) 0.283 -> 0.236 ms.
+// Both passes now sit on the memory system: the same access pattern with NO arithmetic (tools/ubench/ntt_access.hip)
+// takes 0.20-0.22 ms, and neither sub-batches that keep the intermediate in the Infinity Cache nor an XCD-fused
+// single-launch form (tools/ubench/ntt_fused_skel.hip) beat two plain passes -- DESIGN.md section 4.3.
 #include <algorithm>
 #include <cstdlib>
 #include <map>
@@ -37,7 +42,6 @@ struct M32Args {
     i64 total_lines; // lines per batch item
     int tiles_per_batch;
     int load_along_line, store_along_line; // which index runs fastest across lanes (the contiguous one in memory)
-    int post_twiddle;                      // multiply output by tw[offset of the output inside its batch item]
     int tile_order;                        // 0: identity; 1: XCD x owns a contiguous range of tiles of every batch item
     i32 p;
     u32 pinv;     // p^-1 mod 2^32
@@ -125,10 +129,21 @@ constexpr int line_pitch(int rows, int row)
     return base + ((want - base) % 32 + 32) % 32;
 }
 
-template <int LOGR1, int LOGR2, int THREADS, bool SPLIT>
-__global__ __launch_bounds__(THREADS) void ntt_m32_kernel(const i32 *__restrict__ in, i32 *__restrict__ out, M32Args a,
+// MODE 0: a whole transform, or the last pass of a four-step one (outputs * fin, canonical).
+// MODE 1: first pass of a four-step transform: output k1 = ka + R1 * kr of column j2 times w_n^(j2 * k1), formed per thread as
+//         the geometric progression t_0 = tw[j2 * R1 + ka] = w_n^(j2 * ka), ratio tw2[j2] = w_n^(j2 * R1).
+// Measured alternatives for that twiddle (profiles/r03_m32_sweep.txt, 2^20 x 64): an n-entry table read with the store's own
+// offsets 0.257-0.264 ms, the same table on the load side of pass 2 (contiguous rows) 0.243-0.252 ms, the progression
+// 0.236-0.247 ms -- the table costs more in the memory system (which bounds both passes) than two products per point cost
+// on the vector ALU (which has slack since the arithmetic went from 56 to 33 instructions per point and pass).
+#ifndef GFA_M32_WAVES
+#define GFA_M32_WAVES 4 // waves per SIMD the register allocation is held to (128 VGPRs): two 512-thread workgroups per CU
+#endif
+template <int LOGR1, int LOGR2, int THREADS, bool SPLIT, int MODE>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_M32_WAVES))) void ntt_m32_kernel(const i32 *__restrict__ in, i32 *__restrict__ out, M32Args a,
                                                           const i32 *__restrict__ net1, const i32 *__restrict__ net2,
-                                                          const i32 *__restrict__ mid, const i32 *__restrict__ tw)
+                                                          const i32 *__restrict__ mid, const i32 *__restrict__ tw,
+                                                          const i32 *__restrict__ tw2)
 {
     constexpr int R1 = 1 << LOGR1, R2 = 1 << LOGR2, L = R1 * R2;
     constexpr int C = THREADS / R1; // lines per tile
@@ -143,10 +158,11 @@ __global__ __launch_bounds__(THREADS) void ntt_m32_kernel(const i32 *__restrict_
 
     const int tid = threadIdx.x;
     u32 vb = blockIdx.x;
-    if (a.tile_order == 1) {
+    if (a.tile_order == 2) { // XCD x owns a contiguous eighth of ALL tiles (whole batch items when there are >= 8 of them)
+        vb = (vb & 7u) * (gridDim.x >> 3) + (vb >> 3);
+    } else if (a.tile_order == 1) {
         // workgroup b runs on XCD b % 8 (own L2).  XCD x gets tiles [x * per, (x + 1) * per) of every batch item: the two
-        // halves of a 128-byte line of a strided pass meet in one L2, and the slice of the inter-pass table an XCD reads is
-        // 1/8 of the table, re-used for every batch item.
+        // halves of a 128-byte line of a strided pass meet in one L2 (identity order: 0.31 instead of 0.25 ms).
         const u32 x = vb & 7u, i = vb >> 3, per = (u32)a.tiles_per_batch >> 3;
         vb = (i / per) * (u32)a.tiles_per_batch + x * per + (i % per);
     }
@@ -154,9 +170,7 @@ __global__ __launch_bounds__(THREADS) void ntt_m32_kernel(const i32 *__restrict_
     const u32 tile = vb % (u32)a.tiles_per_batch;
     const i64 line0 = (i64)tile * C;
     const i32 *gin = in + (i64)batch * a.in_batch_stride + line0 * a.in_stride_c;
-    const i64 out_tile = line0 * a.out_stride_c; // offset inside the batch item: also the inter-pass table's index
-    i32 *gout = out + (i64)batch * a.out_batch_stride + out_tile;
-    const i32 *gtw = tw + out_tile;
+    i32 *gout = out + (i64)batch * a.out_batch_stride + line0 * a.out_stride_c;
     const i32 p = a.p;
 
     // middle twiddles, transposed: midl[2 * (ka * R2 + r)] -- staged while the first loads are in flight
@@ -175,12 +189,6 @@ __global__ __launch_bounds__(THREADS) void ntt_m32_kernel(const i32 *__restrict_
     else { ka = tid >> LOGC; c = tid & (C - 1); }
 
     i32 v[R2];
-    if (SPLIT) {
-        // v is written in exactly one of the two exchange rounds; tell the compiler so (no instruction), otherwise it
-        // zero-fills the registers ahead of the rounds
-#pragma unroll
-        for (int r = 0; r < R2; r++) asm volatile("" : "=v"(v[r]));
-    }
     {
         i32 va[R1];
         if (C * R2 != THREADS) {
@@ -226,20 +234,18 @@ __global__ __launch_bounds__(THREADS) void ntt_m32_kernel(const i32 *__restrict_
     const u32 ostep = (u32)R1 * (u32)a.out_stride_t * 4u; // uniform
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)gout, 0, 0xffffffffu, 0x00020000);
     const bool live = line0 + c < a.total_lines;
-    if (a.post_twiddle) {
-        // * w_n^(line * k): one table entry per output, fetched with the store's own offsets (tile bases are uniform)
+    if (MODE == 1) {
+        // output k1 = ka + R1 * kr of line j2 times w_n^(j2 * k1) = t_0 * ratio^kr, t_0 = w_n^(j2 * ka), ratio = w_n^(j2 * R1)
         const u32 pinv = a.pinv;
         const i32 negp = -p;
-        const __amdgpu_buffer_rsrc_t rtw = __builtin_amdgcn_make_buffer_rsrc((void *)gtw, 0, 0xffffffffu, 0x00020000);
         if (live) {
+            const u32 line = (u32)line0 + (u32)c;
+            i32 t = tw[line * (u32)R1 + (u32)ka];
+            const i32 sr = tw2[line];
 #pragma unroll
-            for (int g = 0; g < R2; g += 8) {
-                i32 t[8];
-#pragma unroll
-                for (int kr = g; kr < g + 8 && kr < R2; kr++) t[kr - g] = __builtin_amdgcn_raw_buffer_load_b32(rtw, (int)ooff, (int)(kr * ostep), 0);
-#pragma unroll
-                for (int kr = g; kr < g + 8 && kr < R2; kr++)
-                    __builtin_amdgcn_raw_buffer_store_b32(mulm1(v[brev_c(kr, LOGR2)], t[kr - g], pinv, negp), rout, (int)ooff, (int)(kr * ostep), 0);
+            for (int kr = 0; kr < R2; kr++) {
+                __builtin_amdgcn_raw_buffer_store_b32(mulm1(v[brev_c(kr, LOGR2)], t, pinv, negp), rout, (int)ooff, (int)(kr * ostep), 0);
+                if (kr + 1 < R2) t = mulm1(t, sr, pinv, negp);
             }
         }
     } else {
@@ -258,20 +264,26 @@ __global__ __launch_bounds__(THREADS) void ntt_m32_kernel(const i32 *__restrict_
 // ------------------------------------------------------------------------------------------------
 // host side: tables and plans
 // ------------------------------------------------------------------------------------------------
-__global__ void m32_interpass_table_kernel(u32 p, u32 omega, int log1, int log2, i32 *tw)
-{ // tw[k1 * n2 + j2] = centred Montgomery form of omega^(j2 * k1)
+__global__ void m32_progression_table_kernel(u32 p, u32 omega, int logn, int log2, int logr1, i32 *t0, i32 *ratio)
+{ // t0[j2 * R1 + ka] = omega^(j2 * ka), ratio[j2] = omega^(j2 * R1): both in Montgomery form, so that the per-thread progression
+    // t <- t * ratio * 2^-32 stays in Montgomery form
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 n = (i64)1 << (log1 + log2);
-    if (i >= n) return;
-    const u64 k1 = (u64)i >> log2, j2 = (u64)i & (((u64)1 << log2) - 1);
-    u64 e = (k1 * j2) & (u64)(n - 1), b = omega, r = 1;
+    const i64 n2 = (i64)1 << log2, R1 = (i64)1 << logr1;
+    if (i >= n2 * (R1 + 1)) return;
+    u64 e;
+    if (i < n2 * R1) e = (u64)(i >> logr1) * (u64)(i & (R1 - 1));
+    else e = (u64)(i - n2 * R1) * (u64)R1;
+    e &= ((u64)1 << logn) - 1;
+    u64 b = omega, r = 1;
     while (e) {
         if (e & 1) r = r * b % p;
         b = b * b % p;
         e >>= 1;
     }
-    u64 m = (r << 32) % p;
-    tw[i] = m > p / 2 ? (i32)((i64)m - (i64)p) : (i32)m;
+    const u64 m = (r << 32) % p;
+    const i32 c = m > p / 2 ? (i32)((i64)m - (i64)p) : (i32)m;
+    if (i < n2 * R1) t0[i] = c;
+    else ratio[i - n2 * R1] = c;
 }
 
 inline u64 powmod(u64 b, u64 e, u64 p)
@@ -303,7 +315,7 @@ struct M32Plan {
     int log1 = 0, log2 = 0;
     i32 *net1 = nullptr, *net2 = nullptr; // R/2 pairs each
     i32 *mid1 = nullptr, *mid2 = nullptr; // L pairs: w_L^e, companion
-    i32 *tw = nullptr;                    // n entries (two-pass only)
+    i32 *pt0 = nullptr, *pratio = nullptr; // progression form of the inter-pass twiddle: n2 * R1 and n2 entries
 };
 
 struct M32Key {
@@ -316,7 +328,7 @@ std::map<M32Key, M32Plan *> g_m32_plans;
 
 void free_plan(M32Plan *pl)
 {
-    for (void *q : {(void *)pl->net1, (void *)pl->net2, (void *)pl->mid1, (void *)pl->mid2, (void *)pl->tw})
+    for (void *q : {(void *)pl->net1, (void *)pl->net2, (void *)pl->mid1, (void *)pl->mid2, (void *)pl->pt0, (void *)pl->pratio})
         if (q) (void)hipFree(q);
     delete pl;
 }
@@ -379,10 +391,15 @@ int build_plan(M32Plan *pl, u64 p, i64 n, u64 omega, hipStream_t st)
     if ((rc = line_tables(pl->log1, &pl->net1, &dummy, &pl->mid1))) return rc;
     if (pl->log2) {
         if ((rc = line_tables(pl->log2, &pl->net2, &dummy, &pl->mid2))) return rc;
-        GFA_HIP(hipMalloc((void **)&pl->tw, sizeof(i32) * (size_t)n));
-        hipLaunchKernelGGL(m32_interpass_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (u32)p, (u32)omega,
-                           pl->log1, pl->log2, pl->tw);
-        GFA_HIP(hipGetLastError());
+        {
+            const int lr1 = split_log1(pl->log1);
+            const i64 n2 = (i64)1 << pl->log2, cnt = n2 * (((i64)1 << lr1) + 1);
+            GFA_HIP(hipMalloc((void **)&pl->pt0, sizeof(i32) * (size_t)(n2 << lr1)));
+            GFA_HIP(hipMalloc((void **)&pl->pratio, sizeof(i32) * (size_t)n2));
+            hipLaunchKernelGGL(m32_progression_table_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, (u32)p, (u32)omega, logn,
+                               pl->log2, lr1, pl->pt0, pl->pratio);
+            GFA_HIP(hipGetLastError());
+        }
         GFA_HIP(hipStreamSynchronize(st)); // the plan may next be used from another stream
     }
     return GFA_OK;
@@ -394,8 +411,8 @@ int env_int(const char *name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
-template <int LOGR1, int LOGR2, int THREADS, bool SPLIT>
-int launch_tt(const i32 *in, i32 *out, M32Args a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, hipStream_t st)
+template <int LOGR1, int LOGR2, int THREADS, bool SPLIT, int MODE>
+int launch_ttm(const i32 *in, i32 *out, M32Args a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, const i32 *tw2, hipStream_t st)
 {
     constexpr int R1 = 1 << LOGR1, R2 = 1 << LOGR2, L = R1 * R2, C = THREADS / R1;
     constexpr int PC = line_pitch<C>(SPLIT ? R1 / 2 : R1, R2 + 1);
@@ -410,45 +427,60 @@ int launch_tt(const i32 *in, i32 *out, M32Args a, i64 batch, const i32 *net, con
             return GFA_ERR_UNSUPPORTED;
         }
     }
-    static const int xcd = env_int("GFA_NTT_XCD", 1);
-    a.tile_order = (xcd && (a.tiles_per_batch % 8) == 0 && a.tiles_per_batch >= 16) ? 1 : 0;
-    auto kern = ntt_m32_kernel<LOGR1, LOGR2, THREADS, SPLIT>;
+    static const int xcd = env_int("GFA_NTT_XCD", 1), order = env_int("GFA_M32_ORDER", 0), order_min = env_int("GFA_M32_ORDER_MIN", 64); // 2^16 x 1024: whole transforms per XCD 0.229 ms, column slices 0.265
+    a.tile_order = 0;
+    if (xcd) {
+        const bool can1 = (a.tiles_per_batch % 8) == 0 && a.tiles_per_batch >= order_min, can2 = (grid % 8) == 0 && grid >= 16;
+        if (order == 2) a.tile_order = can2 ? 2 : 0;
+        else a.tile_order = can1 ? 1 : (can2 ? 2 : 0);
+    }
+    auto kern = ntt_m32_kernel<LOGR1, LOGR2, THREADS, SPLIT, MODE>;
     static bool attr = false;
     if (!attr) {
         GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), lds, st, in, out, a, net, net + R1, mid, tw);
+    static const int lds_pad = env_int("GFA_M32_LDS_PAD", 0); // occupancy experiments only
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), lds + (size_t)lds_pad, st, in, out, a, net, net + R1, mid, tw, tw2);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }
 
+template <int LOGR1, int LOGR2, int THREADS, bool SPLIT>
+int launch_tt(const i32 *in, i32 *out, const M32Args &a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, const i32 *tw2, hipStream_t st, int mode)
+{
+    if (mode == 0) return launch_ttm<LOGR1, LOGR2, THREADS, SPLIT, 0>(in, out, a, batch, net, mid, tw, tw2, st);
+    return launch_ttm<LOGR1, LOGR2, THREADS, SPLIT, 1>(in, out, a, batch, net, mid, tw, tw2, st);
+}
+
 template <int LOGR1, int LOGR2>
-int launch_t(const i32 *in, i32 *out, const M32Args &a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, hipStream_t st)
+int launch_t(const i32 *in, i32 *out, const M32Args &a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, const i32 *tw2, hipStream_t st, int mode)
 {
     if constexpr (LOGR1 == 5) {
         static const int threads = env_int("GFA_M32_THREADS", 512);
-        static const int split = env_int("GFA_M32_SPLIT", 1);
-        if (threads == 1024) return split ? launch_tt<LOGR1, LOGR2, 1024, true>(in, out, a, batch, net, mid, tw, st)
-                                          : launch_tt<LOGR1, LOGR2, 1024, false>(in, out, a, batch, net, mid, tw, st);
-        if (threads == 256) return split ? launch_tt<LOGR1, LOGR2, 256, true>(in, out, a, batch, net, mid, tw, st)
-                                         : launch_tt<LOGR1, LOGR2, 256, false>(in, out, a, batch, net, mid, tw, st);
-        return split ? launch_tt<LOGR1, LOGR2, 512, true>(in, out, a, batch, net, mid, tw, st)
-                     : launch_tt<LOGR1, LOGR2, 512, false>(in, out, a, batch, net, mid, tw, st);
+        // two-round LDS exchange (half the buffer, three workgroups per CU): measured slower than two workgroups per CU with
+        // the whole line staged (0.268 vs 0.236 ms, 2^20 x 64) -- both passes are bound by the memory system, not occupancy
+        static const int split = env_int("GFA_M32_SPLIT", 0);
+        if (threads == 1024) return split ? launch_tt<LOGR1, LOGR2, 1024, true>(in, out, a, batch, net, mid, tw, tw2, st, mode)
+                                          : launch_tt<LOGR1, LOGR2, 1024, false>(in, out, a, batch, net, mid, tw, tw2, st, mode);
+        if (threads == 256) return split ? launch_tt<LOGR1, LOGR2, 256, true>(in, out, a, batch, net, mid, tw, tw2, st, mode)
+                                         : launch_tt<LOGR1, LOGR2, 256, false>(in, out, a, batch, net, mid, tw, tw2, st, mode);
+        return split ? launch_tt<LOGR1, LOGR2, 512, true>(in, out, a, batch, net, mid, tw, tw2, st, mode)
+                     : launch_tt<LOGR1, LOGR2, 512, false>(in, out, a, batch, net, mid, tw, tw2, st, mode);
     } else {
-        return launch_tt<LOGR1, LOGR2, 256, false>(in, out, a, batch, net, mid, tw, st);
+        return launch_tt<LOGR1, LOGR2, 256, false>(in, out, a, batch, net, mid, tw, tw2, st, mode);
     }
 }
 
-int launch(int logL, const i32 *in, i32 *out, const M32Args &a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, hipStream_t st)
+int launch(int logL, const i32 *in, i32 *out, const M32Args &a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, const i32 *tw2, hipStream_t st, int mode)
 {
     switch (logL) {
-    case 5: return launch_t<3, 2>(in, out, a, batch, net, mid, tw, st);
-    case 6: return launch_t<3, 3>(in, out, a, batch, net, mid, tw, st);
-    case 7: return launch_t<4, 3>(in, out, a, batch, net, mid, tw, st);
-    case 8: return launch_t<4, 4>(in, out, a, batch, net, mid, tw, st);
-    case 9: return launch_t<5, 4>(in, out, a, batch, net, mid, tw, st);
-    case 10: return launch_t<5, 5>(in, out, a, batch, net, mid, tw, st);
+    case 5: return launch_t<3, 2>(in, out, a, batch, net, mid, tw, tw2, st, mode);
+    case 6: return launch_t<3, 3>(in, out, a, batch, net, mid, tw, tw2, st, mode);
+    case 7: return launch_t<4, 3>(in, out, a, batch, net, mid, tw, tw2, st, mode);
+    case 8: return launch_t<4, 4>(in, out, a, batch, net, mid, tw, tw2, st, mode);
+    case 9: return launch_t<5, 4>(in, out, a, batch, net, mid, tw, tw2, st, mode);
+    case 10: return launch_t<5, 5>(in, out, a, batch, net, mid, tw, tw2, st, mode);
     default: set_error("m32 NTT: unsupported line length"); return GFA_ERR_UNSUPPORTED;
     }
 }
@@ -505,17 +537,16 @@ int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 
         a.in_stride_c = n; a.in_stride_t = 1; a.out_stride_c = n; a.out_stride_t = 1;
         a.total_lines = batch;
         a.load_along_line = 1; a.store_along_line = 1;
-        return launch(pl->log1, src, dst, a, 1, pl->net1, pl->mid1, nullptr, st);
+        return launch(pl->log1, src, dst, a, 1, pl->net1, pl->mid1, nullptr, nullptr, st, 0);
     }
     const i64 n1 = (i64)1 << pl->log1, n2 = (i64)1 << pl->log2;
     i32 *w = (i32 *)ws;
-    { // pass 1: the n2 columns (length n1, stride n2), times w^(j2*k1); same layout out
+    { // pass 1: the n2 columns (length n1, stride n2), times w^(j2*k1); same layout out: ws[k1 * n2 + j2]
         M32Args a = base;
         a.in_stride_c = 1; a.in_stride_t = n2; a.out_stride_c = 1; a.out_stride_t = n2;
         a.in_batch_stride = n; a.out_batch_stride = n;
         a.total_lines = n2;
-        a.post_twiddle = 1;
-        const int rc = launch(pl->log1, src, w, a, batch, pl->net1, pl->mid1, pl->tw, st);
+        const int rc = launch(pl->log1, src, w, a, batch, pl->net1, pl->mid1, pl->pt0, pl->pratio, st, 1);
         if (rc) return rc;
     }
     { // pass 2: the n1 rows (contiguous), stored transposed: X[k1 + n1*k2]
@@ -524,7 +555,7 @@ int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 
         a.in_batch_stride = n; a.out_batch_stride = n;
         a.total_lines = n1;
         a.load_along_line = 1; a.store_along_line = 0;
-        return launch(pl->log2, w, dst, a, batch, pl->net2, pl->mid2, nullptr, st);
+        return launch(pl->log2, w, dst, a, batch, pl->net2, pl->mid2, nullptr, nullptr, st, 0);
     }
 }
 
