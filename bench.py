@@ -44,7 +44,15 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure the HBM traffic")
     ap.add_argument("--dist-extras", action="store_true",
                     help="run the multi-GPU side measurements (sharded RS / NTT, distributed C5 transform) even at world size 1")
+    ap.add_argument("--print-launch", action="store_true",
+                    help="print the torch.distributed.run command `--gpus N` re-executes itself under, and exit")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (one process per GPU over RCCL)
+        # and pass rank 0's JSON line through.  Refuses to pretend: fewer visible GPUs than ranks is an error unless the
+        # single-device plumbing knob is set.
+        sys.exit(self_launch(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -65,6 +73,7 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == max(args.gpus, 1) or args.dist_extras, (dist.get_world_size(), args.gpus)
 
     if not os.path.exists(os.path.join(ROOT, "galois_amd", "libgalois_amd.so")):
         # a checkout without build artefacts: build the product (rank 0 builds, the others wait at the barrier)
@@ -152,6 +161,7 @@ def main():
             "value": round(value, 2),
             "unit": "Gop/s",
             "n_gpus": world,
+            "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
@@ -213,6 +223,32 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without WORLD_SIZE in the environment: re-execute under torch.distributed.run with N ranks
+    on this node (127.0.0.1 rendezvous, a free port) and return its exit code.  The children print the JSON line."""
+    import socket
+    import subprocess
+
+    single = os.environ.get("GFA_BENCH_SINGLE_DEVICE")
+    if not args.print_launch and single is None:
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible (set GFA_BENCH_SINGLE_DEVICE=<ordinal> and "
+                  f"GFA_BENCH_BACKEND=gloo for a plumbing run with every rank on one GPU)", file=sys.stderr)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != "--print-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    if args.print_launch:
+        print(" ".join(cmd))
+        return 0
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def measure_traffic():
@@ -280,7 +316,7 @@ def extras_distributed(ga, L, lib, stream, dist, rank, world):
     Md = torch.from_numpy(M).cuda()
     Cd = torch.empty((B, 255), dtype=torch.uint8, device="cuda")
     dist.barrier()
-    L.check(lib.gfa_time_rs_encode(rs._handle, Md.data_ptr(), 223, Cd.data_ptr(), B, L.U8, stream, 5, ctypes.byref(ms)))
+    L.check(lib.gfa_time_rs_encode(rs._handle, Md.data_ptr(), 223, Cd.data_ptr(), B, L.U8, stream, 20, ctypes.byref(ms)))
     enc_ms = job_ms(ms.value)
     # errors are planted on the device: ne[i] positions per codeword, distinct, non-zero values
     g = torch.Generator(device="cuda").manual_seed(5 + rank)
@@ -294,7 +330,7 @@ def extras_distributed(ga, L, lib, stream, dist, rank, world):
     Dd = torch.empty_like(Rd)
     Ed = torch.empty(B, dtype=torch.int64, device="cuda")
     dist.barrier()
-    L.check(lib.gfa_time_rs_decode(rs._handle, Rd.data_ptr(), 255, Dd.data_ptr(), Ed.data_ptr(), B, L.U8, stream, 5, ctypes.byref(ms)))
+    L.check(lib.gfa_time_rs_decode(rs._handle, Rd.data_ptr(), 255, Dd.data_ptr(), Ed.data_ptr(), B, L.U8, stream, 20, ctypes.byref(ms)))
     dec_ms = job_ms(ms.value)
     assert torch.equal(Dd, Cd) and torch.equal(Ed, ne), "RS round trip failed"
     ex["rs_255_223_sharded"] = {
@@ -523,7 +559,7 @@ def extras(ga, L, lib, stream, with_cpu):
     M = rng.integers(0, 256, (B, 223), dtype=np.uint8)
     Md = torch.from_numpy(M).cuda()
     Cd = torch.empty((B, 255), dtype=torch.uint8, device="cuda")
-    L.check(lib.gfa_time_rs_encode(rs._handle, Md.data_ptr(), 223, Cd.data_ptr(), B, L.U8, stream, 5, ctypes.byref(ms)))
+    L.check(lib.gfa_time_rs_encode(rs._handle, Md.data_ptr(), 223, Cd.data_ptr(), B, L.U8, stream, 20, ctypes.byref(ms)))
     enc_ms = ms.value
     C = Cd.cpu().numpy()
     rng5 = np.random.default_rng(5)
@@ -536,7 +572,7 @@ def extras(ga, L, lib, stream, with_cpu):
     Rd = torch.from_numpy(R).cuda()
     Dd = torch.empty_like(Rd)
     Ed = torch.empty(B, dtype=torch.int64, device="cuda")
-    L.check(lib.gfa_time_rs_decode(rs._handle, Rd.data_ptr(), 255, Dd.data_ptr(), Ed.data_ptr(), B, L.U8, stream, 5,
+    L.check(lib.gfa_time_rs_decode(rs._handle, Rd.data_ptr(), 255, Dd.data_ptr(), Ed.data_ptr(), B, L.U8, stream, 20,
                                    ctypes.byref(ms)))
     dec_ms = ms.value
     assert np.array_equal(Dd.cpu().numpy(), C) and np.array_equal(Ed.cpu().numpy(), ne), "RS round trip failed"
@@ -556,7 +592,7 @@ def extras(ga, L, lib, stream, with_cpu):
     }
     # the two extremes benchmarks/test_fec.py uses: no errors, and t = 16 errors in every codeword
     Rd.copy_(Cd)
-    L.check(lib.gfa_time_rs_decode(rs._handle, Rd.data_ptr(), 255, Dd.data_ptr(), Ed.data_ptr(), B, L.U8, stream, 5,
+    L.check(lib.gfa_time_rs_decode(rs._handle, Rd.data_ptr(), 255, Dd.data_ptr(), Ed.data_ptr(), B, L.U8, stream, 20,
                                    ctypes.byref(ms)))
     ex["rs_255_223"]["decode_GB/s_no_errors"] = round(255.0 * B / (ms.value * 1e-3) / 1e9, 2)
     R16 = C.copy()
@@ -564,7 +600,7 @@ def extras(ga, L, lib, stream, with_cpu):
     rows = np.arange(B)[:, None]
     R16[rows, cols] ^= rng5.integers(1, 256, (B, 16), dtype=np.uint8)
     Rd.copy_(torch.from_numpy(R16))
-    L.check(lib.gfa_time_rs_decode(rs._handle, Rd.data_ptr(), 255, Dd.data_ptr(), Ed.data_ptr(), B, L.U8, stream, 5,
+    L.check(lib.gfa_time_rs_decode(rs._handle, Rd.data_ptr(), 255, Dd.data_ptr(), Ed.data_ptr(), B, L.U8, stream, 20,
                                    ctypes.byref(ms)))
     assert np.array_equal(Dd.cpu().numpy(), C) and bool((Ed == 16).all()), "RS t=16 round trip failed"
     ex["rs_255_223"]["decode_GB/s_16_errors"] = round(255.0 * B / (ms.value * 1e-3) / 1e9, 2)
@@ -581,7 +617,7 @@ def extras(ga, L, lib, stream, with_cpu):
     bch = ga.BCH(255, 223)
     Mb = rng.integers(0, 2, (B, 223), dtype=np.uint8)
     Mbd = torch.from_numpy(Mb).cuda()
-    L.check(lib.gfa_time_rs_encode(bch._handle, Mbd.data_ptr(), 223, Cd.data_ptr(), B, L.U8, stream, 5, ctypes.byref(ms)))
+    L.check(lib.gfa_time_rs_encode(bch._handle, Mbd.data_ptr(), 223, Cd.data_ptr(), B, L.U8, stream, 20, ctypes.byref(ms)))
     benc_ms = ms.value
     Cb = Cd.cpu().numpy()
     Rb = Cb.copy()
@@ -590,7 +626,7 @@ def extras(ga, L, lib, stream, with_cpu):
     flip = np.arange(4)[None, :] < neb[:, None]
     Rb[np.repeat(np.arange(B)[:, None], 4, axis=1)[flip], colsb[flip]] ^= 1
     Rd.copy_(torch.from_numpy(Rb))
-    L.check(lib.gfa_time_rs_decode(bch._handle, Rd.data_ptr(), 255, Dd.data_ptr(), Ed.data_ptr(), B, L.U8, stream, 5,
+    L.check(lib.gfa_time_rs_decode(bch._handle, Rd.data_ptr(), 255, Dd.data_ptr(), Ed.data_ptr(), B, L.U8, stream, 20,
                                    ctypes.byref(ms)))
     assert np.array_equal(Dd.cpu().numpy(), Cb) and np.array_equal(Ed.cpu().numpy(), neb), "BCH round trip failed"
     ex["bch_255_223"] = {"codewords": B, "errors_per_codeword": "uniform 0..4",

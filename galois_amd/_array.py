@@ -17,6 +17,7 @@ or a GPU every data operation raises.
 from __future__ import annotations
 
 import ctypes
+import threading
 from typing import Any
 
 import numpy as np
@@ -169,6 +170,7 @@ class FieldArray(metaclass=FieldArrayMeta):
     _ufunc_modes: list = []
     _default_ufunc_mode = "jit-calculate"
     _handle = None
+    _limbed = False        # True for fields of order >= 2^64: two 64-bit limbs per element in a trailing storage axis
     _object_dtype = False  # True when the reference would use dtype=object (order-1)^2 > int64 max: stored as uint64
 
     __array_priority__ = 100
@@ -590,15 +592,41 @@ class FieldArray(metaclass=FieldArrayMeta):
         if int(err.item()) & L.DEVERR_ZERO_DIVISION:
             raise ZeroDivisionError("Cannot compute the multiplicative inverse of 0 in a Galois field.")
 
-    _out_target = None  # set by __array_ufunc__ while an element-wise call with `out=` runs
+    _out_tls = threading.local()  # .target: set by __array_ufunc__ while ONE element-wise kernel with `out=` runs (per thread)
 
     def _alloc_out(self, shape) -> torch.Tensor:
         """Result buffer of an element-wise kernel: the caller's `out=` tensor when it fits, else a fresh one."""
-        tgt = FieldArray._out_target
+        tgt = getattr(FieldArray._out_tls, "target", None)
         if tgt is not None and tuple(tgt.shape) == tuple(shape) and tgt.dtype == self._t.dtype and tgt.device == self._t.device:
-            FieldArray._out_target = None
+            FieldArray._out_tls.target = None
             return tgt
         return torch.empty(shape, dtype=self._t.dtype, device=self._t.device)
+
+    @staticmethod
+    def _extent(t: torch.Tensor):
+        """[first byte, one past the last byte) a tensor view can touch."""
+        if t.numel() == 0:
+            return t.data_ptr(), t.data_ptr()
+        span = sum((n - 1) * abs(st) for n, st in zip(t.shape, t.stride()))
+        return t.data_ptr(), t.data_ptr() + (span + 1) * t.element_size()
+
+    @classmethod
+    def _may_write_in_place(cls, target: torch.Tensor, inputs) -> bool:
+        """The kernels read each operand element exactly where they write the result element (pointers are __restrict__): an
+        input may BE the target (same view) or be disjoint from it; a partial overlap (np.add(a[:-1], a[1:], out=a[1:])) must
+        go through a fresh buffer, as NumPy's own overlap handling does."""
+        lo, hi = cls._extent(target)
+        for x in inputs:
+            t = getattr(x, "_t", None)
+            if t is None:
+                continue
+            a, b = cls._extent(t)
+            if b <= lo or hi <= a:
+                continue
+            if a == lo and tuple(t.shape) == tuple(target.shape) and t.stride() == target.stride():
+                continue
+            return False
+        return True
 
     def _binary(self, op: int, a: "FieldArray", b: "FieldArray") -> "FieldArray":
         cls = type(self)
@@ -769,6 +797,8 @@ class FieldArray(metaclass=FieldArrayMeta):
 
     # ---- NumPy ufunc protocol (UFuncMixin.__array_ufunc__, _domains/_ufunc.py:660-713) ----------------------
     _UNARY_ONLY = (np.negative, np.reciprocal, np.square)
+    _SINGLE_KERNEL_UFUNCS = (np.add, np.subtract, np.multiply, np.true_divide, np.floor_divide, np.negative, np.reciprocal,
+                             np.power, np.square)
 
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
         cls = type(self)
@@ -778,13 +808,17 @@ class FieldArray(metaclass=FieldArrayMeta):
             target = out[0] if isinstance(out, tuple) else out
             if not (isinstance(out, tuple) and len(out) == 1 or isinstance(out, FieldArray)) or not isinstance(target, cls):
                 raise TypeError(f"Argument 'out' must be a {cls.name} array (or a 1-tuple holding one), not {type(target)}.")
-            # element-wise calls write straight into the caller's buffer (also when it aliases an input: out[i] depends on
-            # element i only); other methods, or a target of another width / layout, are computed and then stored
-            FieldArray._out_target = target._t if method == "__call__" and target._t.is_contiguous() else None
+            # ufuncs that are ONE element-wise kernel write straight into the caller's buffer (also when an input IS the
+            # target: out[i] depends on element i only).  Composites (np.sqrt: several kernels that re-read their input),
+            # other methods, partially overlapping operands, or a target of another width / layout are computed into a fresh
+            # buffer and then stored.
+            direct = (method == "__call__" and ufunc in cls._SINGLE_KERNEL_UFUNCS and target._t.is_contiguous()
+                      and cls._may_write_in_place(target._t, inputs))
+            FieldArray._out_tls.target = target._t if direct else None
             try:
                 result = self.__array_ufunc__(ufunc, method, *inputs, **kwargs)
             finally:
-                FieldArray._out_target = None
+                FieldArray._out_tls.target = None
             if not isinstance(result, cls) or tuple(result.shape) != tuple(target.shape):
                 raise ValueError(f"Argument 'out' has shape {tuple(target.shape)} but the result has shape "
                                  f"{tuple(getattr(result, 'shape', ()))}.")
@@ -912,6 +946,24 @@ class FieldArray(metaclass=FieldArrayMeta):
         )
 
     # ---- NumPy function protocol (FunctionMixin.__array_function__, _domains/_function.py:453-482) ---------
+    # ---- array <-> "one entry per element" tensors for the data-movement branch of __array_function__ ----
+    def _af_tens(self, v) -> torch.Tensor:
+        cls = type(self)
+        if isinstance(v, cls):
+            return v._t
+        return cls(v, dtype=self._np_dtype if self._np_dtype != np.dtype(object) else None)._t
+
+    def _af_seq(self, ts):
+        dt = max((t.dtype for t in ts), key=lambda d: torch.empty((), dtype=d).element_size())
+        return [_to_storage(t, dt) for t in ts], dt
+
+    def _af_wrap(self, t: torch.Tensor):
+        cls = type(self)
+        size = t.element_size()
+        cands = [np.dtype(object)] if cls._object_dtype else [np.dtype(d) for d in cls._dtypes]
+        np_dtype = self._np_dtype if cls._itemsize(self._np_dtype) == size else next(d for d in cands if cls._itemsize(d) == size)
+        return cls._wrap(t.contiguous(), np_dtype)
+
     def __array_function__(self, func, types, args, kwargs):
         if func is np.fft.fft or func is np.fft.ifft:
             from ._ntt import _field_fft
@@ -955,38 +1007,34 @@ class FieldArray(metaclass=FieldArrayMeta):
             axis = kw("axis", 1, None)
             op = L.OP_ADD if func is np.cumsum else L.OP_MUL
             return x.reshape(-1)._accumulate(op, 0) if axis is None else x._accumulate(op, axis)
+        # Pure data movement: done on the device tensors, result re-viewed as the field (the reference's
+        # _FUNCTIONS_REQUIRING_VIEW and the subclass-preserving ndarray functions).  _af_tens / _af_seq / _af_wrap map an
+        # array to a tensor with ONE entry per field element and back (fields of order >= 2^64 override them: their storage
+        # carries a limb axis that is not a data axis).
+        def tens(v):
+            if isinstance(v, FieldArray) and not isinstance(v, cls):
+                raise TypeError(f"np.{func.__name__} cannot combine arrays over {type(v).name} and {cls.name}.")
+            return self._af_tens(v)
+
+        def seq(v):
+            return self._af_seq([tens(e) for e in v])
+
+        wrap = self._af_wrap
+
         if func is np.trace and isinstance(x, cls):
             no_extra("offset", "axis1", "axis2", "a")
-            d = torch.diagonal(x._t, offset=kw("offset", 1, 0), dim1=kw("axis1", 2, 0), dim2=kw("axis2", 3, 1))
-            return cls._wrap(d.contiguous(), x._np_dtype)._reduce(L.OP_ADD, -1, False)
+            d = torch.diagonal(tens(x), offset=kw("offset", 1, 0), dim1=kw("axis1", 2, 0), dim2=kw("axis2", 3, 1))
+            return wrap(d)._reduce(L.OP_ADD, -1, False)
         if func is np.diff and isinstance(x, cls):
             no_extra("n", "axis", "a")
             n, axis = kw("n", 1, 1), kw("axis", 2, -1)
             r = x
             for _ in range(int(n)):
-                hi = cls._wrap(r._t.narrow(axis, 1, r._t.shape[axis] - 1).contiguous(), r._np_dtype)
-                lo = cls._wrap(r._t.narrow(axis, 0, r._t.shape[axis] - 1).contiguous(), r._np_dtype)
+                tr = tens(r)
+                hi = wrap(tr.narrow(axis, 1, tr.shape[axis] - 1))
+                lo = wrap(tr.narrow(axis, 0, tr.shape[axis] - 1))
                 r = hi - lo
             return r
-        # Pure data movement: done on the device tensors, result re-viewed as the field (the reference's
-        # _FUNCTIONS_REQUIRING_VIEW and the subclass-preserving ndarray functions)
-        def tens(v):
-            if isinstance(v, cls):
-                return v._t
-            if isinstance(v, FieldArray):
-                raise TypeError(f"np.{func.__name__} cannot combine arrays over {type(v).name} and {cls.name}.")
-            return cls(v, dtype=self._np_dtype if self._np_dtype != np.dtype(object) else None)._t
-
-        def seq(v):
-            ts = [tens(e) for e in v]
-            dt = max((t.dtype for t in ts), key=lambda d: torch.empty((), dtype=d).element_size())
-            return [_to_storage(t, dt) for t in ts], dt
-
-        def wrap(t, like=None):
-            size = t.element_size()
-            cands = [np.dtype(object)] if cls._object_dtype else [np.dtype(d) for d in cls._dtypes]
-            np_dtype = self._np_dtype if cls._itemsize(self._np_dtype) == size else next(d for d in cands if cls._itemsize(d) == size)
-            return cls._wrap(t.contiguous(), np_dtype)
 
         if func in (np.concatenate, np.stack, np.vstack, np.hstack, np.dstack, np.column_stack):
             if kwargs.get("out") is not None:
@@ -1000,7 +1048,7 @@ class FieldArray(metaclass=FieldArrayMeta):
             f = {np.vstack: torch.vstack, np.hstack: torch.hstack, np.dstack: torch.dstack, np.column_stack: torch.column_stack}[func]
             return wrap(f(ts))
         if isinstance(x, cls):
-            t = x._t
+            t = tens(x)
             if func is np.broadcast_to:
                 return wrap(t.broadcast_to(tuple(np.atleast_1d(kw("shape", 1, None)).tolist())))
             if func is np.reshape:
@@ -1048,6 +1096,8 @@ class FieldArray(metaclass=FieldArrayMeta):
             if func is np.take:
                 idx = torch.as_tensor(np.asarray(kw("indices", 1, None)), device=t.device)
                 axis = kw("axis", 2, None)
+                if axis is not None:
+                    axis = int(axis) % t.dim()
                 return wrap(t.reshape(-1)[idx] if axis is None else torch.index_select(t, axis, idx.reshape(-1)).reshape(
                     tuple(t.shape[:axis]) + tuple(idx.shape) + tuple(t.shape[axis + 1:])))
             if func is np.array_equal:
@@ -1062,6 +1112,54 @@ class FieldArray(metaclass=FieldArrayMeta):
                 return x.ndim
             if func is np.size:
                 return x.size if len(args) < 2 else x.shape[args[1]]
+        # Ordering and editing by integer value, as NumPy does on the reference's ndarray subclass (np.sort / argsort / unique /
+        # append / insert / delete are not in its _UNSUPPORTED_FUNCTIONS, _domains/_function.py:405-461)
+        if func in (np.sort, np.argsort, np.unique) and isinstance(x, cls) and not cls._limbed:
+            t = tens(x)
+            bits = 8 * t.element_size()
+            key = (t ^ torch.iinfo(torch.int64).min) if bits == 64 else (t.to(torch.int64) & ((1 << bits) - 1))  # unsigned order
+            if func is np.unique:
+                no_extra("ar", "return_inverse", "return_counts")
+                inv, cnt = bool(kwargs.get("return_inverse", False)), bool(kwargs.get("return_counts", False))
+                r = torch.unique(key.reshape(-1), sorted=True, return_inverse=inv, return_counts=cnt)
+                u = r[0] if (inv or cnt) else r
+                u = (u ^ torch.iinfo(torch.int64).min) if bits == 64 else u
+                out = [wrap(u.to(t.dtype))]
+                if inv:
+                    out.append(r[1].reshape(tuple(t.shape)).cpu().numpy())
+                if cnt:
+                    out.append(r[-1].cpu().numpy())
+                return out[0] if len(out) == 1 else tuple(out)
+            no_extra("a", "axis", "kind", "stable")
+            axis = kw("axis", 1, -1)
+            if axis is None:
+                key, t, axis = key.reshape(-1), t.reshape(-1), 0
+            order = torch.argsort(key, dim=axis, stable=True)
+            return order.cpu().numpy() if func is np.argsort else wrap(torch.gather(t, axis, order))
+        if func in (np.append, np.insert, np.delete) and isinstance(x, cls):
+            t = tens(x)
+            axis = kwargs.get("axis", args[3] if func is np.insert and len(args) > 3 else (args[2] if func is not np.insert and len(args) > 2 else None))
+            if func is np.append:
+                ts, _ = seq([x, kw("values", 1, None)])
+                return wrap(torch.cat([u.reshape(-1) for u in ts]) if axis is None else torch.cat(ts, dim=axis))
+            if axis is None:
+                t, axis = t.reshape(-1), 0
+            axis = int(axis) % t.dim()
+            n = t.shape[axis]
+            if func is np.delete:
+                keep = np.delete(np.arange(n), kw("obj", 1, None))
+                return wrap(torch.index_select(t, axis, torch.as_tensor(keep, device=t.device)))
+            # insert: where the new slots go is NumPy's own index arithmetic on a marker array; the elements stay on the device
+            marker = np.insert(np.arange(n, dtype=np.int64), kw("obj", 1, None), -1)
+            slots = np.flatnonzero(marker < 0)
+            (vals, t), _ = self._af_seq([tens(kw("values", 2, None)), t])
+            tm = torch.movedim(t, axis, 0)
+            vm = torch.movedim(vals, axis, 0) if vals.dim() == t.dim() else vals
+            vm = vm.expand((len(slots),) + tuple(tm.shape[1:])) if vm.dim() < tm.dim() or vm.shape[0] != len(slots) else vm
+            out = torch.empty((len(marker),) + tuple(tm.shape[1:]), dtype=tm.dtype, device=tm.device)
+            out[torch.as_tensor(np.flatnonzero(marker >= 0), device=t.device)] = tm
+            out[torch.as_tensor(slots, device=t.device)] = vm.to(tm.dtype)
+            return wrap(torch.movedim(out, 0, axis))
         if func is np.where and len(args) == 3:
             ts, _ = seq(args[1:])
             cond = args[0].numpy() != 0 if isinstance(args[0], FieldArray) else np.asarray(args[0])

@@ -27,6 +27,79 @@ def shard_range(total: int, rank: int, world: int) -> tuple[int, int]:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# ufunc.reduce over an array sharded across the ranks ("local reduce, then combine G partials")
+# ---------------------------------------------------------------------------------------------------------------------
+_DUAL_OP = {L.OP_ADD: L.OP_ADD, L.OP_MUL: L.OP_MUL, L.OP_SUB: L.OP_ADD, L.OP_DIV: L.OP_MUL}
+
+
+def _device_reduce(field, flat: torch.Tensor, op: int) -> torch.Tensor:
+    """One rank's fold of a 1-D shard with gfa_reduce (left fold for SUB / DIV); returns a 1-element tensor."""
+    from ._array import _GFA_DTYPE, _ptr, _stream
+
+    out = torch.empty(1, dtype=flat.dtype, device=flat.device)
+    err = torch.zeros(1, dtype=torch.int32, device=flat.device) if op == L.OP_DIV else None
+    L.check(L.lib().gfa_reduce(field._handle, op, _ptr(flat), _ptr(out), 1, flat.numel(), _GFA_DTYPE[flat.element_size()], _stream(),
+                               _ptr(err) if err is not None else None), "gfa_reduce")
+    if err is not None and int(err.item()) & L.DEVERR_ZERO_DIVISION:
+        raise ZeroDivisionError("Cannot compute the multiplicative inverse of 0 in a Galois field.")
+    return out
+
+
+def _all_gather(t: torch.Tensor, group=None) -> list[torch.Tensor]:
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    if t.is_cuda and dist.get_backend(group) == "gloo":  # plumbing rigs only (see _all_to_all)
+        parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world)]
+        dist.all_gather(parts, t.cpu(), group=group)
+        return [p.to(t.device) for p in parts]
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t.contiguous(), group=group)
+    return parts
+
+
+def reduce_sharded(field, local: torch.Tensor, op: int = L.OP_ADD, group=None, local_reduce: Callable | None = None) -> torch.Tensor:
+    """ufunc.reduce (reference dispatch: _domains/_ufunc.py:686-689, kernels :180-198) of ONE array whose elements are spread
+    over the ranks in rank order -- rank g holds the g-th contiguous slice, e.g. `shard_range`'s -- as a tensor in the field's
+    device storage dtype.  Every rank folds its own slice (gfa_reduce), the G one-element partials are all-gathered (G * 8 bytes:
+    the only traffic between GPUs) and every rank folds those, so all ranks return the same 1-element tensor.
+
+    op: L.OP_ADD / OP_MUL, or the reference's left folds OP_SUB / OP_DIV (a0 - a1 - a2 - ...): rank 0 folds with the op itself,
+    the other ranks with its dual (+ for -, * for /), and the final fold over [p0, p1, ...] uses the op again.  Rank 0's slice
+    must not be empty for SUB / DIV (it holds a0).  `local_reduce(field, flat, op)` defaults to the HIP kernel; the CPU (gloo)
+    tests inject an oracle-backed stand-in."""
+    import torch.distributed as dist
+
+    if op not in _DUAL_OP:
+        raise ValueError("reduce is defined for add, subtract, multiply and divide only")
+    rank = dist.get_rank(group)
+    local_reduce = local_reduce or _device_reduce
+    flat = local.reshape(-1).contiguous()
+    mine_op = op if rank == 0 else _DUAL_OP[op]
+    if flat.numel() == 0:
+        if rank == 0 and op in (L.OP_SUB, L.OP_DIV):
+            raise ValueError("rank 0 must hold at least one element for subtract.reduce / divide.reduce")
+        part = torch.full((1,), 0 if mine_op == L.OP_ADD else 1, dtype=flat.dtype, device=flat.device)  # identity of the fold
+    else:
+        part = local_reduce(field, flat, mine_op)
+    parts = _all_gather(part.reshape(1), group)
+    return local_reduce(field, torch.cat(parts), op)
+
+
+def reduce_distributed(x, ufunc=np.add, group=None):
+    """`ufunc.reduce(x)` for a FieldArray whose flattened elements are this rank's slice of a larger array (device front end
+    of `reduce_sharded`): returns a 0-d array of x's field, identical on every rank."""
+    ops = {np.add: L.OP_ADD, np.subtract: L.OP_SUB, np.multiply: L.OP_MUL, np.true_divide: L.OP_DIV}
+    if ufunc not in ops:
+        raise ValueError("reduce is defined for np.add, np.subtract, np.multiply and np.true_divide only")
+    cls = type(x)
+    if getattr(cls, "_limbed", False):
+        raise NotImplementedError("reduce_distributed: fields of order >= 2^64 are not supported yet")
+    out = reduce_sharded(cls, x._t, ops[ufunc], group)
+    return cls._wrap(out.reshape(()), x._np_dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # distributed four-step NTT
 # ---------------------------------------------------------------------------------------------------------------------
 # View the length-N input as an (n1 x n2) row-major matrix x[j1*n2 + j2] (N = n1*n2, powers of two).

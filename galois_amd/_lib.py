@@ -86,6 +86,7 @@ SIGNATURES = {
     "gfa_time_ntt": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_u64, c_int, c_void_p, c_int, _f32p]),
     "gfa_time_rs_encode": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p, c_int, _f32p]),
     "gfa_time_rs_decode": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_int, _f32p]),
+    "gfa_debug_fermat_stamps": (None, [c_void_p]),
 }
 
 _lib = None

@@ -70,6 +70,7 @@ def _split(values: np.ndarray) -> torch.Tensor:
 
 class WideFieldArray(FieldArray):
     _wide_handle = None
+    _limbed = True
 
     def __init__(self, x, dtype=None, copy: bool = True):
         cls = type(self)
@@ -297,6 +298,20 @@ class WideFieldArray(FieldArray):
                 "gfa_wide_power")
         self._check_err(err)
         return cls._wrap(out)
+
+    # ---- NumPy functions: the data-movement branch of FieldArray.__array_function__ works on tensors with one entry per
+    # element; here an element is the PAIR of limbs, re-viewed as one complex128 value (moved bit for bit, never computed on),
+    # so that no axis argument can reach the limb axis ----
+    def _af_tens(self, v) -> torch.Tensor:
+        cls = type(self)
+        w = v if isinstance(v, cls) else cls(v)
+        return w._t.contiguous().view(torch.complex128).squeeze(-1)
+
+    def _af_seq(self, ts):
+        return list(ts), torch.complex128
+
+    def _af_wrap(self, c: torch.Tensor):
+        return type(self)._wrap(torch.view_as_real(c.contiguous()).view(torch.int64))
 
     def _unsupported(self, *a, **k):
         raise NotImplementedError(f"This operation is not implemented for {type(self).name} (order >= 2^64): element-wise ufuncs only.")

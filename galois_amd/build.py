@@ -19,7 +19,7 @@ SOURCES = ["gfa_field.hip", "gfa_elementwise.hip", "gfa_elementwise_mid.hip", "g
 import glob
 HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc"))) + [
     os.path.join(HERE, "..", "include", "galois_amd.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result"]
 
 
 def _hipcc() -> str:
@@ -57,8 +57,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or jobs or _stale(LIB, objs + [os.path.join(CSRC, "exports.map")]):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

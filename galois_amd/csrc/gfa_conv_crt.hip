@@ -110,7 +110,7 @@ int run_crt(gfa_field *f, const void *a, i64 na, const void *b, i64 nb, void *ou
     int rc = aux_fields(aux);
     if (rc) return rc;
     u32 *buf = nullptr;
-    GFA_HIP(hipMallocAsync((void **)&buf, sizeof(u32) * 6 * (size_t)n_fft, st));
+    GFA_HIP(gfa::scratch_alloc((void **)&buf, sizeof(u32) * 6 * (size_t)n_fft, st));
     const int grid = (int)std::min<i64>((n_fft + 255) / 256, 256 * 16);
     hipLaunchKernelGGL((crt_spread_kernel<T>), dim3(grid), dim3(256), 0, st, (const T *)a, na, (const T *)b, nb, buf, n_fft);
     rc = GFA_OK;
@@ -136,7 +136,7 @@ int run_crt(gfa_field *f, const void *a, i64 na, const void *b, i64 nb, void *ou
         hipLaunchKernelGGL((crt_combine_kernel<T>), dim3(g2), dim3(256), 0, st, fd, (const u32 *)buf, n_fft, (T *)out, n_out, cc);
         if (hipGetLastError() != hipSuccess) rc = GFA_ERR_HIP;
     }
-    (void)hipFreeAsync(buf, st);
+    (void)gfa::scratch_free(buf, st);
     return rc;
 }
 

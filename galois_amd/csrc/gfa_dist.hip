@@ -116,7 +116,7 @@ int gfa_ntt_dist(gfa_field_t *f, void *nccl_comm, int rank, int world, const voi
     const int64_t cols = n2 / world, rows = n1 / world, n_total = n1 * n2;
     const size_t bytes = (size_t)(n1 * cols) * (dtype == GFA_U32 ? 4 : 8);
     char *work = nullptr;
-    GFA_HIP(hipMallocAsync((void **)&work, 2 * bytes, st));
+    GFA_HIP(gfa::scratch_alloc((void **)&work, 2 * bytes, st));
     void *a = work, *recv = work + bytes;
     u64 omega_n2 = 0;
     HostArith::pow(f->calc, omega, n1, &omega_n2);
@@ -124,8 +124,23 @@ int gfa_ntt_dist(gfa_field_t *f, void *nccl_comm, int rank, int world, const voi
     // (3) rows, read from the per-peer chunks recv[s][k1_local][c] in place
     rc = gfa_ntt_columns(f, local_cols, a, n1, cols, (int64_t)rank * cols, n_total, omega, dtype, stream);
     if (!rc) rc = all_to_all(a, recv, (size_t)(rows * cols), dtype, nccl_comm, world, st);
-    if (!rc) rc = gfa_ntt_chunked(f, recv, out_rows, n2, rows, omega_n2, 0, cols, rows * cols, cols, 0, 0, 0, dtype, stream);
-    const hipError_t fe = hipFreeAsync(work, st);
+    if (!rc) {
+        rc = gfa_ntt_chunked(f, recv, out_rows, n2, rows, omega_n2, 0, cols, rows * cols, cols, 0, 0, 0, dtype, stream);
+        if (rc == GFA_ERR_UNSUPPORTED) {
+            // chunk sizes the row kernel does not take in place (cols below its granule, n2 > 2^20): re-lay the per-peer chunks
+            // recv[s][k1_local][c] out as whole rows in the column buffer (free since the exchange) -- as galois_amd/_dist.py does
+            const size_t esz = dtype == GFA_U32 ? 4 : 8;
+            rc = GFA_OK;
+            for (int s = 0; s < world && !rc; s++) {
+                const hipError_t ce = hipMemcpy2DAsync((char *)a + (size_t)s * cols * esz, (size_t)n2 * esz,
+                                                       (const char *)recv + (size_t)s * rows * cols * esz, (size_t)cols * esz,
+                                                       (size_t)cols * esz, (size_t)rows, hipMemcpyDeviceToDevice, st);
+                if (ce != hipSuccess) rc = hip_fail(ce, "hipMemcpy2DAsync (row re-layout)");
+            }
+            if (!rc) rc = gfa_ntt(f, a, out_rows, n2, rows, omega_n2, 0, dtype, stream);
+        }
+    }
+    const hipError_t fe = gfa::scratch_free(work, st);
     if (rc) return rc;
     GFA_HIP(fe);
     return GFA_OK;
@@ -144,13 +159,24 @@ int gfa_intt_dist(gfa_field_t *f, void *nccl_comm, int rank, int world, const vo
     if (!HostArith::inv(f->calc, omega, &omega_inv)) { set_error("gfa_intt_dist: omega is not invertible"); return GFA_ERR_INVALID; }
     HostArith::pow(f->calc, omega_inv, n1, &w_rows);
     char *work = nullptr;
-    GFA_HIP(hipMallocAsync((void **)&work, 2 * bytes, st));
+    GFA_HIP(gfa::scratch_alloc((void **)&work, 2 * bytes, st));
     void *send = work, *recv = work + bytes;
     // (1) rows, written straight into the send buffer send[s][k1_local][c]; (2) the one exchange; (3) pre-twiddle + columns + 1/N
     rc = gfa_ntt_chunked(f, local_rows, send, n2, rows, w_rows, 0, 0, 0, 0, cols, rows * cols, cols, dtype, stream);
+    if (rc == GFA_ERR_UNSUPPORTED) {
+        // whole rows into `recv` (not yet in use), then cut into the per-peer chunks send[s][k1_local][c]
+        const size_t esz = dtype == GFA_U32 ? 4 : 8;
+        rc = gfa_ntt(f, local_rows, recv, n2, rows, w_rows, 0, dtype, stream);
+        for (int s = 0; s < world && !rc; s++) {
+            const hipError_t ce = hipMemcpy2DAsync((char *)send + (size_t)s * rows * cols * esz, (size_t)cols * esz,
+                                                   (const char *)recv + (size_t)s * cols * esz, (size_t)n2 * esz, (size_t)cols * esz,
+                                                   (size_t)rows, hipMemcpyDeviceToDevice, st);
+            if (ce != hipSuccess) rc = hip_fail(ce, "hipMemcpy2DAsync (chunk re-layout)");
+        }
+    }
     if (!rc) rc = all_to_all(send, recv, (size_t)(rows * cols), dtype, nccl_comm, world, st);
     if (!rc) rc = gfa_ntt_columns_inv(f, recv, out_cols, n1, cols, (int64_t)rank * cols, n_total, omega_inv, scale_by_n_inverse, dtype, stream);
-    const hipError_t fe = hipFreeAsync(work, st);
+    const hipError_t fe = gfa::scratch_free(work, st);
     if (rc) return rc;
     GFA_HIP(fe);
     return GFA_OK;

@@ -238,13 +238,13 @@ int dlog_run(gfa_field *f, const void *a, i64 sa, const void *base, i64 sb, int6
     if (rc || !base) return rc;
     const i64 nb = sb ? n : 1;
     u64 *lb = nullptr;
-    GFA_HIP(hipMallocAsync((void **)&lb, sizeof(u64) * (size_t)nb, st));
+    GFA_HIP(gfa::scratch_alloc((void **)&lb, sizeof(u64) * (size_t)nb, st));
     rc = dispatch_dlog(f->calc, dtype, *pd, base, sb, lb, nb, st, err);
     if (!rc) {
         const unsigned blocks = (unsigned)std::max<i64>(1, std::min<i64>((n + 255) / 256, 65535));
         hipLaunchKernelGGL(dlog_rebase_kernel, dim3(blocks), dim3(256), 0, st, (u64 *)out, lb, (int)sb, pd->N, n, err);
     }
-    GFA_HIP(hipFreeAsync(lb, st));
+    GFA_HIP(gfa::scratch_free(lb, st));
     return rc;
 }
 

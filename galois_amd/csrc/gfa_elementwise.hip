@@ -1179,7 +1179,7 @@ int launch_tab8_binary(const uint8_t *table, bool check_zero_b, const void *a, c
     static bool attr[4] = {false, false, false, false};
     if (n >= ((i64)1 << 28)) { // operands beyond the Infinity Cache: claimed blocks (see tab8_binary_claim_kernel)
         unsigned int *counter = nullptr;
-        GFA_HIP(hipMallocAsync((void **)&counter, sizeof(unsigned int), st));
+        GFA_HIP(gfa::scratch_alloc((void **)&counter, sizeof(unsigned int), st));
         GFA_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned int), st));
         if (check_zero_b) {
             auto k = tab8_binary_claim_kernel<true>;
@@ -1193,7 +1193,7 @@ int launch_tab8_binary(const uint8_t *table, bool check_zero_b, const void *a, c
                                (uint8_t *)out, n, err, counter);
         }
         GFA_HIP(hipGetLastError());
-        GFA_HIP(hipFreeAsync(counter, st));
+        GFA_HIP(gfa::scratch_free(counter, st));
         return GFA_OK;
     }
     if (check_zero_b) {

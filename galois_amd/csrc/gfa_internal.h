@@ -26,6 +26,12 @@ int time_loop(hipStream_t st, int iters, float *ms_out, const std::function<int(
         if (_e != hipSuccess) return gfa::hip_fail(_e, #call); \
     } while (0)
 
+// Stream-ordered work buffers of one call (hipMallocFromPoolAsync / hipFreeAsync) from a pool the library owns, one per
+// device, whose release threshold is unbounded: a freed block stays in the pool across synchronisations instead of going
+// back to the driver (the device's default pool releases at every synchronisation -- 0.05 ms per Reed-Solomon decode).
+hipError_t scratch_alloc(void **p, size_t bytes, hipStream_t st);
+hipError_t scratch_free(void *p, hipStream_t st);
+
 void ntt_forget_field(const struct ::gfa_field *f); // drops cached NTT plans of a field being destroyed
 
 // 2^16-point transforms over GF(65537) in one pass over HBM (gfa_ntt_fermat.hip)

@@ -343,8 +343,8 @@ int launch_row_reduce_wide_ft(const FieldDev &fd, void *a, i64 batch, i64 m, i64
 {
     GjState *state = nullptr;
     u64 *factor = nullptr;
-    GFA_HIP(hipMallocAsync((void **)&state, sizeof(GjState) * (size_t)batch, st));
-    GFA_HIP(hipMallocAsync((void **)&factor, sizeof(u64) * (size_t)(batch * m), st));
+    GFA_HIP(gfa::scratch_alloc((void **)&state, sizeof(GjState) * (size_t)batch, st));
+    GFA_HIP(gfa::scratch_alloc((void **)&factor, sizeof(u64) * (size_t)(batch * m), st));
     GFA_HIP(hipMemsetAsync(state, 0, sizeof(GjState) * (size_t)batch, st));
     for (i64 j = 0; j < ncols; j++) {
         hipLaunchKernelGGL((gj_pivot_kernel<F, T>), dim3((unsigned)batch), dim3(1024), 0, st, fd, (T *)a, (int)m, (int)n, (int)j,
@@ -354,8 +354,8 @@ int launch_row_reduce_wide_ft(const FieldDev &fd, void *a, i64 batch, i64 m, i64
     }
     hipLaunchKernelGGL(gj_finish_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, state, rank_out, (int)batch);
     GFA_HIP(hipGetLastError());
-    GFA_HIP(hipFreeAsync(state, st));
-    GFA_HIP(hipFreeAsync(factor, st));
+    GFA_HIP(gfa::scratch_free(state, st));
+    GFA_HIP(gfa::scratch_free(factor, st));
     return GFA_OK;
 }
 int dispatch_row_reduce_wide(const FieldDev &fd, int dtype, void *a, i64 batch, i64 m, i64 n, i64 ncols, i64 *rank_out,

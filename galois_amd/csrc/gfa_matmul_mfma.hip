@@ -190,8 +190,8 @@ int run_mfma(const FieldDev &fd, const void *a, const void *b, void *out, i64 ba
     const i64 Mp = (M + 255) / 256 * 256, Np = (N + 255) / 256 * 256, Kp = (K + BK - 1) / BK * BK;
     const i64 nA = a_bstride ? batch : 1, nB = b_bstride ? batch : 1;
     int8_t *Ac = nullptr, *Bc = nullptr;
-    GFA_HIP(hipMallocAsync((void **)&Ac, (size_t)(nA * Mp * Kp), st));
-    GFA_HIP(hipMallocAsync((void **)&Bc, (size_t)(nB * Np * Kp), st));
+    GFA_HIP(gfa::scratch_alloc((void **)&Ac, (size_t)(nA * Mp * Kp), st));
+    GFA_HIP(gfa::scratch_alloc((void **)&Bc, (size_t)(nB * Np * Kp), st));
     const u32 p = (u32)fd.p;
     {
         const i64 total = Mp * Kp;
@@ -203,8 +203,8 @@ int run_mfma(const FieldDev &fd, const void *a, const void *b, void *out, i64 ba
     }
     int rcg = launch_gemm<T, false>(Ac, Bc, (T *)out, M, N, Mp, Np, Kp, a_bstride ? Mp * Kp : 0, b_bstride ? Np * Kp : 0, batch, (int)p, st);
     if (rcg) return rcg;
-    GFA_HIP(hipFreeAsync(Ac, st));
-    GFA_HIP(hipFreeAsync(Bc, st));
+    GFA_HIP(gfa::scratch_free(Ac, st));
+    GFA_HIP(gfa::scratch_free(Bc, st));
     return GFA_OK;
 }
 
@@ -238,9 +238,9 @@ int run_mfma_limbs(const FieldDev &fd, int nl, const void *a, const void *b, voi
     const i64 plane = M * N;
     int8_t *Ac = nullptr, *Bc = nullptr;
     int *D = nullptr;
-    GFA_HIP(hipMallocAsync((void **)&Ac, (size_t)(nl * Mp * Kp), st));
-    GFA_HIP(hipMallocAsync((void **)&Bc, (size_t)(nl * Np * Kp), st));
-    GFA_HIP(hipMallocAsync((void **)&D, sizeof(int) * (size_t)(ndiag * plane), st));
+    GFA_HIP(gfa::scratch_alloc((void **)&Ac, (size_t)(nl * Mp * Kp), st));
+    GFA_HIP(gfa::scratch_alloc((void **)&Bc, (size_t)(nl * Np * Kp), st));
+    GFA_HIP(gfa::scratch_alloc((void **)&D, sizeof(int) * (size_t)(ndiag * plane), st));
     const u32 p32 = (u32)(fd.p & 0xffffffffu);
     static const int itemsize[4] = {1, 2, 4, 8};
     (void)itemsize;
@@ -267,9 +267,9 @@ int run_mfma_limbs(const FieldDev &fd, int nl, const void *a, const void *b, voi
         hipLaunchKernelGGL(fold_diagonals_kernel<T>, dim3(gf), dim3(256), 0, st, D, ndiag, plane, (T *)out + bi * plane, plane, fd.p, fd.mu);
     }
     GFA_HIP(hipGetLastError());
-    GFA_HIP(hipFreeAsync(Ac, st));
-    GFA_HIP(hipFreeAsync(Bc, st));
-    GFA_HIP(hipFreeAsync(D, st));
+    GFA_HIP(gfa::scratch_free(Ac, st));
+    GFA_HIP(gfa::scratch_free(Bc, st));
+    GFA_HIP(gfa::scratch_free(D, st));
     return GFA_OK;
 }
 

@@ -1407,18 +1407,21 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
             // remainder scratch of THIS call, stream-ordered (two decodes of one code on different streams, or from
             // different host threads, must not share it; no device synchronisation, so the call stays graph-capturable)
             uint8_t *rem = nullptr;
-            GFA_HIP(hipMallocAsync((void **)&rem, need, st));
+            GFA_HIP(gfa::scratch_alloc((void **)&rem, need, st));
             if ((rc = launch_lfsr<false>(code, cd, (const uint8_t *)recv, erasures, (int)ns, (uint8_t *)out_codeword, 0, rem, nullptr,
                                          batch, st))) {
-                (void)hipFreeAsync(rem, st);
+                (void)gfa::scratch_free(rem, st);
                 return rc;
             }
             const RsParams rp = make_params(code);
             const size_t fixed = 65536 + 1280;
             const bool small = (int)code->roots.size() + 4 <= 40;
             const size_t per_wave = small ? WaveScratch2<40>::BYTES : WaveScratch2<64>::BYTES;
-            static int wps = 0;
-            if (!wps) { const char *e = getenv("GFA_RS_WPS"); wps = e ? atoi(e) : 8; if (wps != 4 && wps != 5 && wps != 6) wps = 8; }
+            static const int wps = [] { // initialised once (thread-safe), GFA_RS_WPS: tuning override
+                const char *e = getenv("GFA_RS_WPS");
+                const int w = e ? atoi(e) : 8;
+                return (w == 4 || w == 5 || w == 6) ? w : 8;
+            }();
             const int nwaves = 2 * wps;
             const size_t lds = fixed + nwaves * per_wave;
             const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
@@ -1447,7 +1450,7 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
             }
 #undef GFA_K2
             const hipError_t launch_err = hipGetLastError();
-            GFA_HIP(hipFreeAsync(rem, st));
+            GFA_HIP(gfa::scratch_free(rem, st));
             GFA_HIP(launch_err);
             return GFA_OK;
         }

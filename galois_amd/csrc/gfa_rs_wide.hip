@@ -517,11 +517,11 @@ int polydiv_t(gfa_rs *code, const FieldDev &fd, gfa_rs::Dev *cd, const void *cw,
     const int nwaves = 4;
     const int grid = grid_for_waves(batch, nwaves);
     u32 *scratch = nullptr;
-    GFA_HIP(hipMallocAsync((void **)&scratch, sizeof(u32) * (size_t)grid * nwaves * (size_t)ns, st));
+    GFA_HIP(gfa::scratch_alloc((void **)&scratch, sizeof(u32) * (size_t)grid * nwaves * (size_t)ns, st));
     hipLaunchKernelGGL((wide_polydiv_kernel<TS>), dim3(grid), dim3(nwaves * 64), 0, st, fd, rp, cd->gw, (const TS *)cw, (int)ns, (TS *)out,
                        batch, scratch);
     const hipError_t e = hipGetLastError();
-    (void)hipFreeAsync(scratch, st);
+    (void)gfa::scratch_free(scratch, st);
     GFA_HIP(e);
     return GFA_OK;
 }
@@ -584,10 +584,10 @@ int rs_wide_decode(gfa_rs *code, const void *recv, const uint8_t *eras, i64 ns, 
         // the kernel reads the received row while it writes the output row: decode in place through a copy of the input
         void *tmp = nullptr;
         const size_t bytes = dtype_size(dtype) * (size_t)batch * (size_t)ns;
-        GFA_HIP(hipMallocAsync(&tmp, bytes, st));
+        GFA_HIP(gfa::scratch_alloc(&tmp, bytes, st));
         GFA_HIP(hipMemcpyAsync(tmp, recv, bytes, hipMemcpyDeviceToDevice, st));
         rc = rs_wide_decode(code, tmp, eras, ns, out, nerr, detected, batch, false, dtype, st);
-        (void)hipFreeAsync(tmp, st);
+        (void)gfa::scratch_free(tmp, st);
         return rc;
     }
     GFA_WIDE_DISPATCH(decode_t, code, fd, cd, recv, eras, ns, out, nerr, detected, batch, detect_only, st);

@@ -64,6 +64,12 @@ typedef enum { GFA_MODE_AUTO = 0, GFA_MODE_LOOKUP = 1, GFA_MODE_CALCULATE = 2 } 
 #define GFA_DEVERR_LOG_BASE 8      /* log base that is not a primitive element (_calculate.py:621) */
 #define GFA_DEVERR_NO_LU 2         /* lu_decompose needs a row exchange ("The LU decomposition of 'A' does not exist", _linalg.py:374) */
 
+/* The library is built with -fvisibility=hidden: exactly the entry points declared between this push and the pop at the
+ * end of the file are exported. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 /* ---- library -------------------------------------------------------------------------------------- */
 int gfa_abi_version(void);
 const char *gfa_last_error(void); /* thread-local description of the last non-OK status */
@@ -293,6 +299,13 @@ int gfa_time_rs_encode(gfa_rs_t *code, const void *msg, int64_t ks, void *out, i
                        gfa_stream_t stream, int iters, float *ms_out);
 int gfa_time_rs_decode(gfa_rs_t *code, const void *recv, int64_t ns, void *out_codeword, int64_t *out_n_errors,
                        int64_t batch, int dtype, gfa_stream_t stream, int iters, float *ms_out);
+/* Tuning aid of the GF(65537) one-pass transform (tools/fermat_phases.py): when `buf` is not NULL the kernel records eight
+ * 100 MHz timestamps per (workgroup, round) there; NULL switches the recording off again.  Not part of the product path. */
+void gfa_debug_fermat_stamps(unsigned long long *buf);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

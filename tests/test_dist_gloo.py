@@ -97,6 +97,68 @@ def test_distributed_four_step_ntt_two_ranks(order, n1, n2):
     assert q.get(timeout=5) is True
 
 
+def _reduce_worker(rank, world, port, order, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import galois_amd as ga
+        from galois_amd import _lib as L
+        from galois_amd import dist as gdist
+        from oracle import gf_oracle as O
+
+        GF = ga.GF(order)
+        F = O.OracleField(GF.characteristic, GF.degree, int(GF.irreducible_poly) if GF.degree > 1 else None, GF._primitive_element_int)
+        fold = {L.OP_ADD: F.add, L.OP_SUB: F.sub, L.OP_MUL: F.mul, L.OP_DIV: F.div}
+
+        def local_reduce(field, flat, op):  # same contract as gfa_reduce on one row: a left fold
+            a = flat.numpy().view(np.uint64)
+            acc = np.array([a[0]], dtype=np.uint64)
+            for v in a[1:]:
+                acc = fold[op](acc, np.array([v], dtype=np.uint64))
+            return torch.from_numpy(acc.view(np.int64))
+
+        n = 1001  # uneven shards: 501 + 500
+        x = np.random.default_rng(11).integers(1, order, n, dtype=np.uint64)
+        lo, hi = gdist.shard_range(n, rank, world)
+        ok = True
+        for op in (L.OP_ADD, L.OP_MUL, L.OP_SUB, L.OP_DIV):
+            got = gdist.reduce_sharded(GF, torch.from_numpy(x[lo:hi].copy().view(np.int64)), op, local_reduce=local_reduce)
+            want = np.array([x[0]], dtype=np.uint64)
+            for v in x[1:]:
+                want = fold[op](want, np.array([v], dtype=np.uint64))
+            ok = ok and int(got.numpy().view(np.uint64)[0]) == int(want[0])
+        # an empty shard on the last rank contributes the identity
+        got = gdist.reduce_sharded(GF, torch.from_numpy((x[:7] if rank == 0 else x[:0]).copy().view(np.int64)), L.OP_MUL, local_reduce=local_reduce)
+        want = np.array([x[0]], dtype=np.uint64)
+        for v in x[1:7]:
+            want = F.mul(want, np.array([v], dtype=np.uint64))
+        ok = ok and int(got.numpy().view(np.uint64)[0]) == int(want[0])
+        flags = [None] * world
+        dist.all_gather_object(flags, ok)
+        if rank == 0:
+            q.put(all(flags))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("order", [2**8, 7340033, 3**5])
+def test_reduce_of_an_array_sharded_over_two_ranks(order):
+    """add / multiply / subtract / divide .reduce with one slice per rank: local folds, an all-gather of the two partials,
+    one final fold -- against the oracle's fold of the whole array (left folds for subtract and divide)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reduce_worker, args=(r, 2, port, order, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 def test_layout_helpers_roundtrip():
     sys.path.insert(0, ROOT)
     from galois_amd import dist as gdist

@@ -531,7 +531,10 @@ def test_c_abi_distributed_transform_owns_its_rccl_exchange():
         lib = L.lib()
         st = torch.cuda.current_stream().cuda_stream
         for order, n1, n2, dt, tdt in [(2**64 - 2**32 + 1, 1 << 10, 1 << 12, L.U64, torch.int64), (7340033, 1 << 8, 1 << 10, L.U32, torch.int32),
-                                       (469762049, 1 << 10, 1 << 16, L.U32, torch.int32)]:
+                                       (469762049, 1 << 10, 1 << 16, L.U32, torch.int32),
+                                       # rows of 2^21 points: the in-place chunked row kernel declines (n2 > 2^20) and the C path
+                                       # re-lays the chunks out and runs the plain transform (the fallback _dist.py has)
+                                       (469762049, 4, 1 << 21, L.U32, torch.int32)]:
             GF = ga.GF(order)
             n = n1 * n2
             x = torch.empty(n, dtype=torch.int64, device="cuda").random_(0, min(order, 2**62)).to(tdt)

@@ -124,3 +124,36 @@ def test_array_surface_of_a_big_field():
     assert repr(GF(np.array([1, 2], dtype=object))).startswith("GF([1, 2]")
     with pytest.raises(NotImplementedError):
         ga.GF(2**127 - 1, 2, irreducible_poly=[1, 0, 1], verify=False)  # order >= 2^128: no device representation
+
+
+def test_data_movement_functions_never_touch_the_limb_axis():
+    """FieldArray.__array_function__ moves tensors with one entry per element; for order >= 2^64 the storage has a trailing limb
+    axis, which np.flip / transpose / roll / repeat / take / concatenate(axis=-1) ... must not see (flip without an
+    axis swapped the two limbs of every element)."""
+    GF = ga.GF(2**100)
+    q = GF.order
+    rng = np.random.default_rng(1)
+    h = np.array([int(rng.integers(0, 2**62)) * int(rng.integers(0, 2**38)) % q for _ in range(24)] , dtype=object).reshape(2, 3, 4)
+    h[0, 0, 0], h[1, 2, 3] = q - 1, 1 << 64
+    x = GF(h)
+    eq = lambda a, b: a.shape == b.shape and all(int(u) == int(v) for u, v in zip(np.asarray(a.numpy()).ravel(), b.ravel()))
+    assert eq(np.flip(x), np.flip(h)) and eq(np.flip(x, axis=-1), np.flip(h, axis=-1)) and eq(np.flip(x, axis=(0, 2)), np.flip(h, axis=(0, 2)))
+    assert eq(np.transpose(x), np.transpose(h)) and eq(np.transpose(x, (1, 0, 2)), np.transpose(h, (1, 0, 2)))
+    assert eq(np.swapaxes(x, 0, -1), np.swapaxes(h, 0, -1)) and eq(np.moveaxis(x, -1, 0), np.moveaxis(h, -1, 0))
+    assert eq(np.roll(x, 5), np.roll(h, 5)) and eq(np.roll(x, 1, axis=-1), np.roll(h, 1, axis=-1))
+    assert eq(np.repeat(x, 2), np.repeat(h, 2)) and eq(np.repeat(x, 3, axis=-1), np.repeat(h, 3, axis=-1))
+    assert eq(np.take(x, [3, 0, 23]), np.take(h, [3, 0, 23])) and eq(np.take(x, [3, 0], axis=-1), np.take(h, [3, 0], axis=-1))
+    assert eq(np.concatenate([x, x], axis=-1), np.concatenate([h, h], axis=-1)) and eq(np.concatenate([x, x]), np.concatenate([h, h]))
+    assert eq(np.concatenate([x, x], axis=None), np.concatenate([h, h], axis=None))
+    assert eq(np.stack([x, x], axis=-1), np.stack([h, h], axis=-1)) and eq(np.expand_dims(x, -1), np.expand_dims(h, -1))
+    assert eq(np.tile(x[0, 0], 3), np.tile(h[0, 0], 3)) and eq(np.diag(x[0, 0]), np.diag(h[0, 0]) if False else np.array(
+        [[h[0, 0][i] if i == j else 0 for j in range(4)] for i in range(4)], dtype=object))
+    assert eq(np.diagonal(x[0]), np.diagonal(h[0])) and eq(np.tril(x[0]), np.tril(h[0])) and eq(np.triu(x[0], 1), np.triu(h[0], 1))
+    cond = np.arange(24).reshape(2, 3, 4) % 3 == 0
+    assert eq(np.where(cond, x, GF.Zeros((2, 3, 4))), np.where(cond, h, 0))
+    assert eq(np.squeeze(x[:1]), h[0]) and eq(np.broadcast_to(x[0, 0], (5, 4)), np.broadcast_to(h[0, 0], (5, 4)))
+    assert eq(np.append(x[0, 0], x[1, 1]), np.append(h[0, 0], h[1, 1])) and eq(np.delete(x[0, 0], 1), np.delete(h[0, 0], 1))
+    for v in np.asarray(np.flip(x).numpy()).ravel():
+        assert 0 <= int(v) < q
+    with pytest.raises(NotImplementedError):
+        np.sort(x)

@@ -25,6 +25,19 @@ def test_library_exports_every_declared_symbol(repo_root):
     assert lib.gfa_abi_version() == 1
 
 
+def test_library_exports_nothing_but_the_c_abi():
+    """-fvisibility=hidden + the push/pop in include/galois_amd.h: no C++ internals (gfa::HostArith, kernels' host stubs, ...)
+    in the dynamic symbol table."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = [line.split()[-1] for line in out.splitlines() if line.strip()]
+    stray = [n for n in names if not n.startswith("gfa_") and n not in ("_init", "_fini", "__bss_start", "_edata", "_end")
+             and not n.startswith("__hip_")]
+    assert not stray, stray[:20]
+    assert "gfa_ntt" in names and "gfa_binary" in names
+
+
 def test_product_never_touches_the_oracle(repo_root):
     pkg = os.path.join(repo_root, "galois_amd")
     for dirpath, _, files in os.walk(pkg):
