@@ -667,6 +667,14 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
     const int cm = rp.c % qm1;
     const u32 xroot = ar.exp_t[(la * ((cm + lane) % qm1)) % qm1]; // root_j = alpha^(c+j), j = lane
 
+    // Round 3, measured and not kept (2^17 words, e ~ U{0..16}, 0.261 ms with this loop):
+    //  (i)   CLAIMING codewords instead of dealing them out (a word with v errors costs about 3 + v units and the launch lasts as
+    //        long as its unluckiest wave): a counter in LDS with a vector and with a scalar loop condition, and one global counter
+    //        per workgroup, all hang on the device even when every wave claims exactly once, while this static loop around the
+    //        identical body runs -- cause not isolated within the GPU budget;
+    //  (ii)  syndromes as two half-wave Horner chains (lanes 32-63 take the high coefficients): 0.286 ms -- the select between
+    //        two scalar broadcasts per step (v_cndmask reading VCC: 11 lane-ops/clk/CU) costs what the halved chain saves;
+    //  (iii) leaving Berlekamp-Massey once every remaining discrepancy is zero (one ballot per zero step): 0.281 ms.
     for (i64 cw = (i64)blockIdx.x * nwaves + wave; cw < batch; cw += (i64)gridDim.x * nwaves) {
         uint8_t *orow = out_g + cw * n; // already holds the received row (copied by the pre-pass)
         // remainder coefficient of x^lane (stored highest degree first)
