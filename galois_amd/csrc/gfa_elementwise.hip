@@ -1282,8 +1282,12 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
         const FieldDev &c = f->calc;
         const bool trivial_addsub = (op == GFA_OP_ADD || op == GFA_OP_SUB) && (c.p == 2 || c.m == 1);
         const bool zech_op = op == GFA_OP_ADD || op == GFA_OP_SUB;
-        if (!trivial_addsub && mid_eligible(c, ds->mid16, dtype, n) && (!zech_op || mid_has_zech_room(c))) {
-            rc = mid_binary(f->lut_desc(*ds), ds->mid16, op, a, sa, b, sb, out, n, st, dev_err);
+        // uint32 / int64 storage: products of prime and binary fields stay on the calculated kernels unless the field is in lookup
+        // mode (measured at 50 M elements, profiles/r03_ew_widestore.txt: GF(7919) uint32 0.74 vs 0.66, GF(2^12) int64 0.76 vs 0.68
+        // of the roofline); everything else -- division, reciprocal, power, GF(p^m) sums and products -- gains 1.4-3.5x from LDS
+        const bool wide_calc_mul = dtype != GFA_U16 && op == GFA_OP_MUL && !f->use_lookup() && (c.m == 1 || c.p == 2);
+        if (!trivial_addsub && !wide_calc_mul && mid_eligible(c, ds->mid16, dtype, n) && (!zech_op || mid_has_zech_room(c))) {
+            rc = mid_binary(f->lut_desc(*ds), ds->mid16, dtype, op, a, sa, b, sb, out, n, st, dev_err);
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
         // (reached for 8192 < q <= 32768 only by the sums / differences whose three tables do not fit in LDS together)
@@ -1327,7 +1331,7 @@ int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int d
         const FieldDev &c = f->calc;
         const bool trivial_neg = op == GFA_OP_NEG && (c.p == 2 || c.m == 1);
         if (!trivial_neg && mid_eligible(c, ds->mid16, dtype, n) && (op != GFA_OP_NEG || mid_has_zech_room(c))) {
-            rc = mid_unary(f->lut_desc(*ds), ds->mid16, op, a, out, n, st, dev_err);
+            rc = mid_unary(f->lut_desc(*ds), ds->mid16, dtype, op, a, out, n, st, dev_err);
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
         if ((op == GFA_OP_RECIP || (!trivial_neg && big16_products(f))) && big16_eligible(c, ds->mid16, dtype, n)) {
@@ -1370,8 +1374,9 @@ int gfa_power(gfa_field_t *f, const void *a, int64_t sa, const int64_t *exps, in
     }
     if (sa == 1 && f->mode != GFA_MODE_CALCULATE) { // tables in LDS, as in gfa_binary
         if (mid_eligible(f->calc, ds->mid16, dtype, n)) {
-            rc = se == 0 ? mid_power(f->lut_desc(*ds), ds->mid16, a, exps, out, n, (hipStream_t)stream, dev_err)
-                         : mid_power_each(f->lut_desc(*ds), ds->mid16, a, exps, out, n, (hipStream_t)stream, dev_err);
+            rc = se == 0 ? mid_power(f->lut_desc(*ds), ds->mid16, dtype, a, exps, out, n, (hipStream_t)stream, dev_err)
+                         : (dtype == GFA_U16 ? mid_power_each(f->lut_desc(*ds), ds->mid16, a, exps, out, n, (hipStream_t)stream, dev_err)
+                                             : GFA_ERR_UNSUPPORTED);
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
         if (se == 0 && big16_eligible(f->calc, ds->mid16, dtype, n)) {

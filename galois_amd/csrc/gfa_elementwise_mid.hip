@@ -94,22 +94,33 @@ __device__ __forceinline__ u32 mid_op(const MidTabs &t, const MidDesc &d, const 
     }
 }
 
-template <int OP, int THREADS, bool REDUCED>
-__global__ __launch_bounds__(THREADS) void mid_kernel(MidDesc d, const u16 *__restrict__ a, int sa, const u16 *__restrict__ b,
-                                                          int sb, u16 *__restrict__ out, i64 n, int32_t *err)
+// ESZ = bytes per stored element: 2 (uint16), 4 (uint32 / int32), 8 (int64 -- the `dtype=int` arrays of the reference's
+// documentation, _domains/_array.py:445-451).  Wider storage only changes how many elements a 16-byte vector carries (8 / 4 / 2)
+// and how they are unpacked; the tables, the index arithmetic and therefore the results are the same.
+template <int ESZ> struct MidElem;
+template <> struct MidElem<2> { typedef u16 T; };
+template <> struct MidElem<4> { typedef u32 T; };
+template <> struct MidElem<8> { typedef u64 T; };
+
+template <int OP, int THREADS, bool REDUCED, int ESZ = 2>
+__global__ __launch_bounds__(THREADS) void mid_kernel(MidDesc d, const typename MidElem<ESZ>::T *__restrict__ a, int sa,
+                                                          const typename MidElem<ESZ>::T *__restrict__ b, int sb,
+                                                          typename MidElem<ESZ>::T *__restrict__ out, i64 n, int32_t *err)
 {
+    typedef typename MidElem<ESZ>::T T;
     extern __shared__ __attribute__((aligned(16))) u16 mid_lds[];
     constexpr bool BINARY = OP <= GFA_OP_DIV;
     constexpr bool NEED_ZECH = OP == GFA_OP_ADD || OP == GFA_OP_SUB;
-    const i64 nvec = n >> 3;
+    constexpr int LOGV = ESZ == 2 ? 3 : ESZ == 4 ? 2 : 1; // log2(elements per 16-byte vector)
+    const i64 nvec = n >> LOGV;
     const u32x4 *av = reinterpret_cast<const u32x4 *>(a);
     const u32x4 *bv = reinterpret_cast<const u32x4 *>(b);
     u32x4 *ov = reinterpret_cast<u32x4 *>(out);
     const i64 stride = (i64)gridDim.x * THREADS;
     i64 i = (i64)blockIdx.x * THREADS + threadIdx.x;
     u32x4 x = {0, 0, 0, 0}, y = {0, 0, 0, 0};
-    if (!sa) { const u32 s = a[0]; x = u32x4{s, s, s, s} * 0x10001u; }
-    if (BINARY && !sb) { const u32 s = b[0]; y = u32x4{s, s, s, s} * 0x10001u; }
+    if (!sa) { const u32 s = (u32)a[0]; x = ESZ == 2 ? u32x4{s, s, s, s} * 0x10001u : ESZ == 4 ? u32x4{s, s, s, s} : u32x4{s, 0, s, 0}; }
+    if (BINARY && !sb) { const u32 s = (u32)b[0]; y = ESZ == 2 ? u32x4{s, s, s, s} * 0x10001u : ESZ == 4 ? u32x4{s, s, s, s} : u32x4{s, 0, s, 0}; }
     // the first operand vectors are requested before the tables are staged (as in tab8_binary_kernel)
     if (i < nvec) {
         if (sa) x = av[i];
@@ -142,16 +153,25 @@ __global__ __launch_bounds__(THREADS) void mid_kernel(MidDesc d, const u16 *__re
             if (BINARY && sb) y = bv[nxt];
         }
         u32x4 r;
+        if constexpr (ESZ == 2) {
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
-            const u32 lo = mid_op<OP, REDUCED>(t, d, pw, cx[w] & 0xffffu, cy[w] & 0xffffu, bad);
-            const u32 hi = mid_op<OP, REDUCED>(t, d, pw, cx[w] >> 16, cy[w] >> 16, bad);
-            r[w] = lo | (hi << 16);
+            for (int w = 0; w < 4; w++) {
+                const u32 lo = mid_op<OP, REDUCED>(t, d, pw, cx[w] & 0xffffu, cy[w] & 0xffffu, bad);
+                const u32 hi = mid_op<OP, REDUCED>(t, d, pw, cx[w] >> 16, cy[w] >> 16, bad);
+                r[w] = lo | (hi << 16);
+            }
+        } else if constexpr (ESZ == 4) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) r[w] = mid_op<OP, REDUCED>(t, d, pw, cx[w] & 0xffffu, cy[w] & 0xffffu, bad);
+        } else { // field elements are below 2^16: the upper word of an int64 element is zero on the way in and on the way out
+            r[0] = mid_op<OP, REDUCED>(t, d, pw, cx[0] & 0xffffu, cy[0] & 0xffffu, bad);
+            r[2] = mid_op<OP, REDUCED>(t, d, pw, cx[2] & 0xffffu, cy[2] & 0xffffu, bad);
+            r[1] = 0; r[3] = 0;
         }
         ov[i] = r;
     }
-    for (i64 j = (nvec << 3) + (i64)blockIdx.x * THREADS + threadIdx.x; j < n; j += stride)
-        out[j] = (u16)mid_op<OP, REDUCED>(t, d, pw, (u32)a[sa ? j : 0], BINARY ? (u32)b[sb ? j : 0] : 0u, bad);
+    for (i64 j = (nvec << LOGV) + (i64)blockIdx.x * THREADS + threadIdx.x; j < n; j += stride)
+        out[j] = (T)mid_op<OP, REDUCED>(t, d, pw, (u32)a[sa ? j : 0] & 0xffffu, BINARY ? (u32)b[sb ? j : 0] & 0xffffu : 0u, bad);
     if constexpr (OP == GFA_OP_DIV || OP == MID_RECIP || OP == MID_POW) {
         if (__any(bad)) {
             if ((threadIdx.x & 63) == 0 && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
@@ -498,24 +518,26 @@ int mid_num_cus()
     return cus;
 }
 
-template <int OP>
-int mid_launch(const MidDesc &d, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int32_t *err)
+template <int OP, int ESZ>
+int mid_launch_e(const MidDesc &d, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int32_t *err)
 {
+    typedef typename MidElem<ESZ>::T T;
     constexpr bool NEED_ZECH = OP == GFA_OP_ADD || OP == GFA_OP_SUB;
+    constexpr int LOGV = ESZ == 2 ? 3 : ESZ == 4 ? 2 : 1;
     const size_t lds = ((size_t)d.qa + d.exp_len + (NEED_ZECH ? d.qa : 0)) * sizeof(u16);
     const bool reduced = d.exp_len == d.qa;
     static bool attr[2] = {false, false};
     const int cus = mid_num_cus();
-    const i64 vec_blocks = (n >> 3);
+    const i64 vec_blocks = (n >> LOGV);
     if (reduced) { // 8192 < q <= 32768: up to 160 KiB of tables, one 16-wave workgroup per CU
-        auto k = mid_kernel<OP, 1024, true>;
+        auto k = mid_kernel<OP, 1024, true, ESZ>;
         if (!attr[1]) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 163840)); attr[1] = true; }
         i64 blocks = (vec_blocks + 1023) / 1024;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(k, dim3((int)(blocks < cus ? blocks : cus)), dim3(1024), lds, st, d, (const u16 *)a, (int)sa, (const u16 *)b, (int)sb,
-                           (u16 *)out, n, err);
+        hipLaunchKernelGGL(k, dim3((int)(blocks < cus ? blocks : cus)), dim3(1024), lds, st, d, (const T *)a, (int)sa, (const T *)b, (int)sb,
+                           (T *)out, n, err);
     } else {
-        auto k = mid_kernel<OP, MID_THREADS, false>;
+        auto k = mid_kernel<OP, MID_THREADS, false, ESZ>;
         if (!attr[0]) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr[0] = true; }
         // 160 KiB of LDS and 32 waves per CU: up to four 8-wave workgroups when the tables are small
         i64 per_cu = (i64)(160 * 1024) / (i64)(lds + 1024);
@@ -523,11 +545,22 @@ int mid_launch(const MidDesc &d, const void *a, i64 sa, const void *b, i64 sb, v
         i64 blocks = (vec_blocks + MID_THREADS - 1) / MID_THREADS;
         const i64 cap = (i64)cus * per_cu;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(k, dim3((int)(blocks < cap ? blocks : cap)), dim3(MID_THREADS), lds, st, d, (const u16 *)a, (int)sa, (const u16 *)b,
-                           (int)sb, (u16 *)out, n, err);
+        hipLaunchKernelGGL(k, dim3((int)(blocks < cap ? blocks : cap)), dim3(MID_THREADS), lds, st, d, (const T *)a, (int)sa, (const T *)b,
+                           (int)sb, (T *)out, n, err);
     }
     GFA_HIP(hipGetLastError());
     return GFA_OK;
+}
+
+template <int OP>
+int mid_launch(const MidDesc &d, int dtype, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int32_t *err)
+{
+    switch (dtype) {
+    case GFA_U16: return mid_launch_e<OP, 2>(d, a, sa, b, sb, out, n, st, err);
+    case GFA_U32: return mid_launch_e<OP, 4>(d, a, sa, b, sb, out, n, st, err);
+    case GFA_U64: return mid_launch_e<OP, 8>(d, a, sa, b, sb, out, n, st, err);
+    default: return GFA_ERR_UNSUPPORTED;
+    }
 }
 
 template <int OP>
@@ -599,41 +632,42 @@ static const i64 MID_MIN_N = [] { const char *e = getenv("GFA_MID_MIN_N"); retur
 bool mid_eligible(const FieldDev &calc, const void *image, int dtype, i64 n)
 {
     static const bool enabled = [] { const char *e = getenv("GFA_MID_LDS"); return !(e && e[0] == '0'); }();
-    return enabled && image != nullptr && dtype == GFA_U16 && calc.q > 256 && calc.q <= 32768 && n >= MID_MIN_N;
+    return enabled && image != nullptr && (dtype == GFA_U16 || dtype == GFA_U32 || dtype == GFA_U64) && calc.q > 256 && calc.q <= 32768 &&
+           n >= MID_MIN_N;
 }
 
 // sums / differences / negation in odd characteristic need ZECH next to LOG and EXP: 6q bytes of LDS above 8192 elements
 bool mid_has_zech_room(const FieldDev &calc) { return calc.q <= 8192 || 6 * ((calc.q + 7) & ~7ull) <= 160 * 1024; }
 
-int mid_binary(const FieldDev &lut, const void *image, int op, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n,
+int mid_binary(const FieldDev &lut, const void *image, int dtype, int op, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n,
                hipStream_t st, int32_t *err)
 {
     if (!al16(out) || (sa && !al16(a)) || (sb && !al16(b))) return GFA_ERR_UNSUPPORTED;
     const MidDesc d = make_desc(lut, (const u16 *)image);
     switch (op) {
-    case GFA_OP_ADD: return mid_launch<GFA_OP_ADD>(d, a, sa, b, sb, out, n, st, err);
-    case GFA_OP_SUB: return mid_launch<GFA_OP_SUB>(d, a, sa, b, sb, out, n, st, err);
-    case GFA_OP_MUL: return mid_launch<GFA_OP_MUL>(d, a, sa, b, sb, out, n, st, err);
-    case GFA_OP_DIV: return mid_launch<GFA_OP_DIV>(d, a, sa, b, sb, out, n, st, err);
+    case GFA_OP_ADD: return mid_launch<GFA_OP_ADD>(d, dtype, a, sa, b, sb, out, n, st, err);
+    case GFA_OP_SUB: return mid_launch<GFA_OP_SUB>(d, dtype, a, sa, b, sb, out, n, st, err);
+    case GFA_OP_MUL: return mid_launch<GFA_OP_MUL>(d, dtype, a, sa, b, sb, out, n, st, err);
+    case GFA_OP_DIV: return mid_launch<GFA_OP_DIV>(d, dtype, a, sa, b, sb, out, n, st, err);
     default: return GFA_ERR_UNSUPPORTED;
     }
 }
 
-int mid_unary(const FieldDev &lut, const void *image, int op, const void *a, void *out, i64 n, hipStream_t st, int32_t *err)
+int mid_unary(const FieldDev &lut, const void *image, int dtype, int op, const void *a, void *out, i64 n, hipStream_t st, int32_t *err)
 {
     if (!al16(out) || !al16(a)) return GFA_ERR_UNSUPPORTED;
     const MidDesc d = make_desc(lut, (const u16 *)image);
-    if (op == GFA_OP_NEG) return mid_launch<MID_NEG>(d, a, 1, a, 0, out, n, st, err);
-    if (op == GFA_OP_RECIP) return mid_launch<MID_RECIP>(d, a, 1, a, 0, out, n, st, err);
+    if (op == GFA_OP_NEG) return mid_launch<MID_NEG>(d, dtype, a, 1, a, 0, out, n, st, err);
+    if (op == GFA_OP_RECIP) return mid_launch<MID_RECIP>(d, dtype, a, 1, a, 0, out, n, st, err);
     return GFA_ERR_UNSUPPORTED;
 }
 
-int mid_power(const FieldDev &lut, const void *image, const void *a, const i64 *e, void *out, i64 n, hipStream_t st, int32_t *err)
+int mid_power(const FieldDev &lut, const void *image, int dtype, const void *a, const i64 *e, void *out, i64 n, hipStream_t st, int32_t *err)
 {
     if (!al16(out) || !al16(a)) return GFA_ERR_UNSUPPORTED;
     MidDesc d = make_desc(lut, (const u16 *)image);
     d.e_ptr = e;
-    return mid_launch<MID_POW>(d, a, 1, a, 0, out, n, st, err);
+    return mid_launch<MID_POW>(d, dtype, a, 1, a, 0, out, n, st, err);
 }
 
 int mid_power_each(const FieldDev &lut, const void *image, const void *a, const i64 *e, void *out, i64 n, hipStream_t st, int32_t *err)

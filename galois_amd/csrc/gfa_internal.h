@@ -67,14 +67,15 @@ int rs_wide_decode(struct ::gfa_rs *code, const void *recv, const uint8_t *eras,
                    i64 batch, bool detect_only, int dtype, hipStream_t st);
 int rs_wide_polydiv(struct ::gfa_rs *code, const void *cw, i64 ns, void *out, i64 batch, int dtype, hipStream_t st);
 
-// element-wise kernels with 16-bit EXP / LOG / Zech tables in LDS, 256 < q <= 32768 on uint16 storage (gfa_elementwise_mid.hip).
+// element-wise kernels with 16-bit EXP / LOG / Zech tables in LDS, 256 < q <= 32768 on uint16 / uint32 / int64 storage
+// (gfa_elementwise_mid.hip; mid_power_each: uint16 only).
 // `lut` is gfa_field::lut_desc(), `image` FieldDeviceState::mid16.  GFA_ERR_UNSUPPORTED = operands not 16-byte aligned.
 bool mid_eligible(const FieldDev &calc, const void *image, int dtype, i64 n);
 bool mid_has_zech_room(const FieldDev &calc);
-int mid_binary(const FieldDev &lut, const void *image, int op, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n,
+int mid_binary(const FieldDev &lut, const void *image, int dtype, int op, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n,
                hipStream_t st, int32_t *err);
-int mid_unary(const FieldDev &lut, const void *image, int op, const void *a, void *out, i64 n, hipStream_t st, int32_t *err);
-int mid_power(const FieldDev &lut, const void *image, const void *a, const i64 *e, void *out, i64 n, hipStream_t st, int32_t *err);
+int mid_unary(const FieldDev &lut, const void *image, int dtype, int op, const void *a, void *out, i64 n, hipStream_t st, int32_t *err);
+int mid_power(const FieldDev &lut, const void *image, int dtype, const void *a, const i64 *e, void *out, i64 n, hipStream_t st, int32_t *err);
 int mid_power_each(const FieldDev &lut, const void *image, const void *a, const i64 *e, void *out, i64 n, hipStream_t st, int32_t *err);
 // 32768 < q <= 65536 on uint16 storage: LOG, then EXP, staged in LDS in two phases per tile; op in {MUL, DIV, RECIP, POW (one
 // exponent at e[0])}.  Covers the first n & ~7 elements -- the caller runs the generic kernels on the last n & 7.

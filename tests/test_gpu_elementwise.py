@@ -882,3 +882,41 @@ def test_small_fields_in_wide_storage(q, dt):
             A / B
     finally:
         GF.compile("auto")
+
+
+@pytest.mark.parametrize("q", [3**7, 2**12, 7919, 2**15, 3**9])
+@pytest.mark.parametrize("dt", [np.uint32, np.int64])
+def test_table_fields_up_to_2e15_in_uint32_and_int64_storage(q, dt):
+    """256 < q <= 32768 held in uint32 / int64 arrays (the reference documentation's dtype=int, _domains/_array.py:445-451): the
+    LDS-table kernels of gfa_elementwise_mid.hip unpack 4 / 2 elements per 16-byte vector instead of 8; every operation, scalar
+    operands, tails, aligned and misaligned views, in place, ZeroDivisionError, against the oracle."""
+    if np.dtype(dt) not in [np.dtype(d) for d in ga.GF(q).dtypes]:
+        pytest.skip("dtype not offered for this field")
+    n = 600_011
+    GF, F, a, b, bnz, mk, u = _big_case(q, dt, n, 77, mode="jit-lookup", lookup=True)
+    full = lambda v: np.full(n, v, dtype=np.uint64)
+    try:
+        A, B, Bnz = mk(a), mk(b), mk(bnz)
+        assert A.dtype == np.dtype(dt)
+        assert np.array_equal(u(A + B), F.add(a, b))
+        assert np.array_equal(u(A - B), F.sub(a, b))
+        assert np.array_equal(u(A * B), F.mul(a, b))
+        assert np.array_equal(u(A / Bnz), F.div(a, bnz))
+        assert np.array_equal(u(-A), F.sub(full(0), a))
+        assert np.array_equal(u(np.reciprocal(Bnz)), F.div(full(1), bnz))
+        assert np.array_equal(u(A ** 5), F.pow(a, np.full(n, 5, dtype=np.int64)))
+        assert np.array_equal(u(Bnz ** -3), F.pow(bnz, np.full(n, -3, dtype=np.int64)))
+        assert np.array_equal(u(A * B[7]), F.mul(a, full(b[7])))
+        assert np.array_equal(u(A[7] - B), F.sub(full(a[7]), b))
+        assert np.array_equal(u(A[7] / Bnz), F.div(full(a[7]), bnz))
+        step = 16 // np.dtype(dt).itemsize
+        assert np.array_equal(u(A[step:] * B[step:]), F.mul(a[step:], b[step:]))   # aligned view
+        assert np.array_equal(u(A[1:] / Bnz[1:]), F.div(a[1:], bnz[1:]))           # misaligned: generic kernel
+        C = A.copy()
+        np.multiply(C, B, out=C)
+        assert np.array_equal(u(C), F.mul(a, b))
+        assert (A * B).dtype == np.dtype(dt)
+        with pytest.raises(ZeroDivisionError):
+            A / B
+    finally:
+        GF.compile("auto")
