@@ -259,7 +259,11 @@ def _make_wide_class(p: int, m: int, irr_int: int, alpha: int, is_primitive_poly
         "__module__": __name__,
         "__hash__": None,
     }
-    return FieldArrayMeta(name, (WideFieldArray,), ns)
+    cls = FieldArrayMeta(name, (WideFieldArray,), ns)
+    import weakref
+
+    weakref.finalize(cls, L.lib().gfa_wfield_destroy, handle)  # the class owns its device-side descriptor
+    return cls
 
 
 def Field(*args, **kwargs):

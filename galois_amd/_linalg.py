@@ -30,6 +30,10 @@ def _verify_same_field(a, b, what: str):
 def _matmul_3d(cls, ta: torch.Tensor, tb: torch.Tensor, a_stride: int, b_stride: int, batch: int, M: int, K: int, N: int,
                gfa_dtype: int) -> torch.Tensor:
     out = torch.empty((batch, M, N), dtype=ta.dtype, device=ta.device)
+    if cls._limbed:  # order >= 2^64: ta / tb carry one complex128 entry (= two 64-bit limbs) per element
+        L.check(L.lib().gfa_wide_matmul(cls._wide_handle, _ptr(ta), _ptr(tb), _ptr(out), batch, M, K, N, a_stride, b_stride, _stream()),
+                "gfa_wide_matmul")
+        return out
     L.check(L.lib().gfa_matmul(cls._handle, _ptr(ta), _ptr(tb), _ptr(out), batch, M, K, N, a_stride, b_stride, gfa_dtype,
                                _stream()), "gfa_matmul")
     return out
@@ -41,7 +45,7 @@ def matmul(A: FieldArray, B: FieldArray) -> FieldArray:
     cls = type(A)
     if not (A.ndim >= 1 and B.ndim >= 1):
         raise ValueError(f"Operation 'matmul' requires both arrays have dimension at least 1, not {A.ndim}-D and {B.ndim}-D.")
-    ta, tb = A._t, A._same_storage(B)
+    ta, tb = (A._af_tens(A), A._af_tens(B)) if cls._limbed else (A._t, A._same_storage(B))
     a_vec, b_vec = ta.dim() == 1, tb.dim() == 1
     if a_vec:
         ta = ta.reshape(1, -1)
@@ -64,7 +68,7 @@ def matmul(A: FieldArray, B: FieldArray) -> FieldArray:
 
     ta3, sa = lay_out(ta, M, K)
     tb3, sb = lay_out(tb, K, N)
-    out = _matmul_3d(cls, ta3, tb3, sa, sb, batch, M, K, N, A._gfa_dtype())
+    out = _matmul_3d(cls, ta3, tb3, sa, sb, batch, M, K, N, None if cls._limbed else A._gfa_dtype())
     if a_vec and b_vec:
         final = batch_shape
     elif a_vec:
@@ -73,6 +77,8 @@ def matmul(A: FieldArray, B: FieldArray) -> FieldArray:
         final = batch_shape + (M,)
     else:
         final = batch_shape + (M, N)
+    if cls._limbed:
+        return A._af_wrap(out.reshape(final))
     return cls._wrap(out.reshape(final), A._np_dtype)
 
 
@@ -90,7 +96,7 @@ def dot(a: FieldArray, b: FieldArray) -> FieldArray:
         return matmul(a, b)
     if a.ndim >= 2 and b.ndim == 1:
         return matmul(a, b)
-    if not cls.is_prime_field:
+    if not cls.is_prime_field or cls._limbed:
         raise NotImplementedError(
             "Currently 'dot' is only supported up to 2-D matrices. "
             "Please open a GitHub issue at https://github.com/mhostetter/galois/issues."
@@ -128,7 +134,7 @@ def inner(a: FieldArray, b: FieldArray) -> FieldArray:
         raise ValueError(
             f"Operation 'inner' requires 'a' and 'b' to have the same last dimension, not {tuple(a.shape)} and {tuple(b.shape)}."
         )
-    if cls.is_prime_field:
+    if cls.is_prime_field and not cls._limbed:
         # np.inner: out[i..., j...] = sum_k a[i..., k] b[j..., k]
         K = a.shape[-1]
         a2 = a.reshape(-1, K)

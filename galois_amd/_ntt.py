@@ -80,6 +80,8 @@ def _field_convolve(a: FieldArray, b: FieldArray, mode: str = "full") -> FieldAr
     if a.ndim != 1 or b.ndim != 1 or a.size == 0 or b.size == 0:
         raise ValueError("Operation 'convolve' requires non-empty 1-D arrays.")
     cls = type(a)
+    if cls._limbed:  # order >= 2^64: two limbs per element, direct kernel (gfa_wide_convolve)
+        return a._convolve(b)
     na, nb = a.size, b.size
     n_out = na + nb - 1
     n_fft = 1 << (n_out - 1).bit_length()

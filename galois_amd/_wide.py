@@ -5,8 +5,10 @@ _domains/_meta.py:39-41: arrays of Python integers through the pure-Python ufunc
 Here the elements live on the GPU as two 64-bit limbs (an int64 tensor with a trailing axis of 2); the host sees Python
 integers (`numpy()` returns dtype=object) exactly as with the reference.  The element-wise ufunc surface is covered --
 add, subtract, multiply, divide, negative, reciprocal, power (arbitrary-size integer exponents), field * integer, square,
-divmod / remainder, ==, indexing and reshaping -- through the kernels of csrc/gfa_wide.hip.  Reductions, NTTs, linear algebra
-and codes over these fields are not implemented and raise NotImplementedError.
+divmod / remainder, ==, indexing, reshaping and the data-movement NumPy functions -- through the kernels of csrc/gfa_wide.hip,
+and since round 3 ufunc.reduce / accumulate (np.sum, prod, cumsum, cumprod), np.convolve, @ / np.matmul / dot / vdot / inner
+(gfa_wide_reduce, gfa_wide_convolve, gfa_wide_matmul: what the reference's Sage fixtures for these fields pin).  reduceat / at,
+sqrt, log, NTTs, row reduction and codes over these fields are not implemented and raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -316,7 +318,51 @@ class WideFieldArray(FieldArray):
     def _unsupported(self, *a, **k):
         raise NotImplementedError(f"This operation is not implemented for {type(self).name} (order >= 2^64): element-wise ufuncs only.")
 
-    _reduce = _accumulate = _reduceat = _at = _sqrt = log = _unsupported
+    _reduceat = _at = _sqrt = log = _unsupported
+
+    # ---- ufunc.reduce / accumulate, np.convolve, @ : the reference runs them as object-dtype loops over the same scalar
+    # kernels (_fields/_ufunc.py:36-48, _domains/_function.py:141-167, _domains/_linalg.py:286-308) ----
+    def _fold(self, op, axis, accumulate: bool):
+        cls = type(self)
+        c = self._af_tens(self)  # one complex128 entry per element (two limbs), moved bit for bit
+        if c.dim() == 0:
+            raise TypeError("cannot reduce on a scalar")
+        if axis is None:
+            c2, lead = c.reshape(1, -1), ()
+        else:
+            axis = axis % c.dim()
+            c2 = c.movedim(axis, -1)
+            lead = tuple(c2.shape[:-1])
+            c2 = c2.reshape(-1, c2.shape[-1])
+        c2 = c2.contiguous()
+        n_outer, n_inner = c2.shape
+        if n_inner == 0:
+            raise ValueError("zero-size array to reduction operation which has no identity on this device path")
+        out = torch.empty((n_outer, n_inner) if accumulate else (n_outer,), dtype=torch.complex128, device=c.device)
+        err = torch.zeros(1, dtype=torch.int32, device=c.device) if op == L.OP_DIV else None
+        L.check(L.lib().gfa_wide_reduce(cls._wide_handle, op, _ptr(c2), _ptr(out), n_outer, n_inner, 1 if accumulate else 0, _stream(),
+                                        _ptr(err) if err is not None else None), "gfa_wide_reduce")
+        if err is not None:
+            self._check_err(err)
+        return out, lead, axis
+
+    def _reduce(self, op, axis, keepdims: bool):
+        out, lead, axis_n = self._fold(op, axis, False)
+        out = out.reshape(lead)
+        if keepdims:
+            out = out.reshape((1,) * self.ndim) if axis is None else out.unsqueeze(axis_n)
+        return self._af_wrap(out)
+
+    def _accumulate(self, op, axis):
+        out, lead, axis_n = self._fold(op, axis, True)
+        return self._af_wrap(out.reshape(lead + (out.shape[-1],)).movedim(-1, axis_n))
+
+    def _convolve(self, other):
+        cls = type(self)
+        a, b = self._af_tens(self).contiguous(), self._af_tens(other).contiguous()
+        out = torch.empty(a.numel() + b.numel() - 1, dtype=torch.complex128, device=a.device)
+        L.check(L.lib().gfa_wide_convolve(cls._wide_handle, _ptr(a), a.numel(), _ptr(b), b.numel(), _ptr(out), _stream()), "gfa_wide_convolve")
+        return self._af_wrap(out)
 
     @classmethod
     def _scalar(cls, op, a, b=0):

@@ -327,6 +327,78 @@ __global__ __launch_bounds__(256) void wide_power_kernel(WField f, const u64 *__
     if (bad && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
 }
 
+// ---------------------------------------------------------------- reductions, convolution, matrix product
+// The reference runs ufunc.reduce / accumulate, np.convolve and @ on these fields as object-dtype loops over the same scalar
+// kernels (_fields/_ufunc.py:36-48, _domains/_function.py:141-167, _domains/_linalg.py:286-308).  Coverage paths: exact, simple.
+__device__ __forceinline__ W128 wf_op(const WField &f, int op, W128 x, W128 y, bool &bad)
+{
+    switch (op) {
+    case GFA_OP_ADD: return wf_add(f, x, y);
+    case GFA_OP_SUB: return wf_sub(f, x, y);
+    case GFA_OP_MUL: return wf_mul(f, x, y);
+    default:
+        if (w_is_zero(y)) { bad = true; return W128{0, 0}; }
+        return wf_mul(f, x, wf_inv(f, y));
+    }
+}
+
+// One workgroup per row.  reduce: a[0] op (a[1] dual a[2] dual ...) with dual = + for -, * for / -- the left fold the
+// reference computes, regrouped so that the tail is an associative, commutative fold the 256 threads can share.
+// accumulate (every prefix) is inherently sequential per row: thread 0 walks the row.
+__global__ __launch_bounds__(256) void wide_reduce_kernel(WField f, int op, const u64 *__restrict__ a, u64 *__restrict__ out, i64 n_inner,
+                                                          int accumulate, int32_t *err)
+{
+    __shared__ W128 part[256];
+    const i64 row = blockIdx.x;
+    const u64 *ar = a + 2 * row * n_inner;
+    bool bad = false;
+    if (accumulate) {
+        if (threadIdx.x == 0) {
+            W128 acc = wload(ar, 0);
+            wstore(out + 2 * row * n_inner, 0, acc);
+            for (i64 i = 1; i < n_inner; i++) {
+                acc = wf_op(f, op, acc, wload(ar, i), bad);
+                wstore(out + 2 * row * n_inner, i, acc);
+            }
+        }
+    } else {
+        const int dual = (op == GFA_OP_ADD || op == GFA_OP_SUB) ? GFA_OP_ADD : GFA_OP_MUL;
+        W128 acc = dual == GFA_OP_ADD ? W128{0, 0} : W128{1, 0};
+        for (i64 i = 1 + threadIdx.x; i < n_inner; i += 256) acc = wf_op(f, dual, acc, wload(ar, i), bad);
+        part[threadIdx.x] = acc;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) part[threadIdx.x] = wf_op(f, dual, part[threadIdx.x], part[threadIdx.x + s], bad);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) wstore(out, row, n_inner > 1 ? wf_op(f, op, wload(ar, 0), part[0], bad) : wload(ar, 0));
+    }
+    if (bad && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
+}
+
+__global__ __launch_bounds__(256) void wide_convolve_kernel(WField f, const u64 *__restrict__ a, i64 na, const u64 *__restrict__ b, i64 nb,
+                                                            u64 *__restrict__ out)
+{ // out[k] = sum_i a[i] * b[k - i]
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= na + nb - 1) return;
+    const i64 lo = k - (nb - 1) > 0 ? k - (nb - 1) : 0, hi = k < na - 1 ? k : na - 1;
+    W128 acc{0, 0};
+    for (i64 i = lo; i <= hi; i++) acc = wf_add(f, acc, wf_mul(f, wload(a, i), wload(b, k - i)));
+    wstore(out, k, acc);
+}
+
+__global__ __launch_bounds__(256) void wide_matmul_kernel(WField f, const u64 *__restrict__ a, const u64 *__restrict__ b, u64 *__restrict__ out,
+                                                          i64 batch, i64 M, i64 K, i64 N, i64 a_bstride, i64 b_bstride)
+{ // out[t][i][j] = sum_k a[t][i][k] * b[t][k][j]; batch strides in elements (0: one matrix for every batch item)
+    const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * M * N) return;
+    const i64 t = idx / (M * N), i = (idx / N) % M, j = idx % N;
+    const u64 *ap = a + 2 * (t * a_bstride + i * K), *bp = b + 2 * (t * b_bstride + j);
+    W128 acc{0, 0};
+    for (i64 k = 0; k < K; k++) acc = wf_add(f, acc, wf_mul(f, wload(ap, k), wload(bp, k * N)));
+    wstore(out, idx, acc);
+}
+
 } // namespace
 
 struct gfa_wfield {
@@ -389,6 +461,42 @@ int gfa_wide_power(gfa_wfield_t *w, const void *a, int64_t sa, const void *exps,
     const int grid = (int)std::min<i64>((n + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(wide_power_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w->f, (const u64 *)a, (int)sa, (const u64 *)exps, (int)se, sign,
                        (u64 *)out, n, dev_err);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+int gfa_wide_reduce(gfa_wfield_t *w, int op, const void *a, void *out, int64_t n_outer, int64_t n_inner, int accumulate, gfa_stream_t stream,
+                    int32_t *dev_err)
+{
+    if (!w || !a || !out || n_outer < 0 || n_inner < 1 || op < GFA_OP_ADD || op > GFA_OP_DIV || n_outer > 0x7fffffff) {
+        set_error("gfa_wide_reduce: bad arguments");
+        return GFA_ERR_INVALID;
+    }
+    if (n_outer == 0) return GFA_OK;
+    hipLaunchKernelGGL(wide_reduce_kernel, dim3((unsigned)n_outer), dim3(256), 0, (hipStream_t)stream, w->f, op, (const u64 *)a, (u64 *)out, n_inner,
+                       accumulate, dev_err);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+int gfa_wide_convolve(gfa_wfield_t *w, const void *a, int64_t na, const void *b, int64_t nb, void *out, gfa_stream_t stream)
+{
+    if (!w || !a || !b || !out || na < 1 || nb < 1) { set_error("gfa_wide_convolve: bad arguments"); return GFA_ERR_INVALID; }
+    const i64 n = na + nb - 1;
+    hipLaunchKernelGGL(wide_convolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w->f, (const u64 *)a, na,
+                       (const u64 *)b, nb, (u64 *)out);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+int gfa_wide_matmul(gfa_wfield_t *w, const void *a, const void *b, void *out, int64_t batch, int64_t M, int64_t K, int64_t N, int64_t a_bstride,
+                    int64_t b_bstride, gfa_stream_t stream)
+{
+    if (!w || !a || !b || !out || batch < 0 || M < 0 || K < 0 || N < 0) { set_error("gfa_wide_matmul: bad arguments"); return GFA_ERR_INVALID; }
+    const i64 n = batch * M * N;
+    if (n == 0) return GFA_OK;
+    hipLaunchKernelGGL(wide_matmul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w->f, (const u64 *)a, (const u64 *)b,
+                       (u64 *)out, batch, M, K, N, a_bstride, b_bstride);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }

@@ -169,6 +169,15 @@ int gfa_wide_binary(gfa_wfield_t *w, int op, const void *a, int64_t sa, const vo
 int gfa_wide_unary(gfa_wfield_t *w, int op, const void *a, void *out, int64_t n, gfa_stream_t stream, int32_t *dev_err);
 int gfa_wide_power(gfa_wfield_t *w, const void *a, int64_t sa, const void *exps, int64_t se, const int8_t *sign, void *out,
                    int64_t n, gfa_stream_t stream, int32_t *dev_err);
+/* ufunc.reduce (accumulate = 0: n_outer results) / ufunc.accumulate (accumulate = 1: n_outer x n_inner prefixes) over the last axis
+ * of an (n_outer, n_inner) array, op in {ADD, SUB, MUL, DIV}, left folds as the reference's object-dtype loops compute them
+ * (_domains/_ufunc.py:686-689 with _fields/_ufunc.py:36-48); np.convolve(a, b) "full" (_domains/_function.py:141-167: the
+ * object-dtype branch of convolve_jit); batched C = A B (_domains/_linalg.py:286-308), batch strides in elements, 0 = broadcast. */
+int gfa_wide_reduce(gfa_wfield_t *w, int op, const void *a, void *out, int64_t n_outer, int64_t n_inner, int accumulate,
+                    gfa_stream_t stream, int32_t *dev_err);
+int gfa_wide_convolve(gfa_wfield_t *w, const void *a, int64_t na, const void *b, int64_t nb, void *out, gfa_stream_t stream);
+int gfa_wide_matmul(gfa_wfield_t *w, const void *a, const void *b, void *out, int64_t batch, int64_t M, int64_t K, int64_t N,
+                    int64_t a_bstride, int64_t b_bstride, gfa_stream_t stream);
 
 /* ---- NTT: replaces fft_jit/ifft_jit `self.jit(x.astype(int64), int64(omega), factors)` (_domains/_function.py:201) *
  * Computes out[k] = sum_j in[j] * omega^(j*k) for each of `batch` contiguous length-n rows, natural order in and

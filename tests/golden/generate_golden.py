@@ -60,6 +60,13 @@ def pack_sage_wide_fields():
             for k, v in d.items():
                 a = np.array(v, dtype=object)
                 out[f"{op}_{k}"] = np.array([str(int(t)) for t in a.ravel()]).reshape(a.shape)
+        for op in ("convolve", "matrix_multiply"):  # lists of cases of different shapes: one entry per case
+            d = pickle.load(open(os.path.join(path, op + ".pkl"), "rb"))
+            out[f"{op}_count"] = np.array(len(d["X"]))
+            for k, cases in d.items():
+                for i, v in enumerate(cases):
+                    a = np.array(v, dtype=object)
+                    out[f"{op}_{k}_{i}"] = np.array([str(int(t)) for t in a.ravel()]).reshape(a.shape)
         name = folder.replace("(", "_").replace(")", "").replace("^", "e").replace(", ", "_")
         np.savez_compressed(os.path.join(OUT_DIR, f"sage_wide_{name}.npz"), **out)
         print("packed (wide)", folder)

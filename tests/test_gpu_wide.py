@@ -97,7 +97,7 @@ def test_random_and_edge_operands_against_the_oracle(tag):
     with pytest.raises(TypeError):
         GF([1, 2], dtype=np.int64)
     with pytest.raises(NotImplementedError):
-        np.add.reduce(A)
+        np.add.reduceat(A, [0, 1])
 
 
 def test_array_surface_of_a_big_field():
@@ -157,3 +157,79 @@ def test_data_movement_functions_never_touch_the_limb_axis():
         assert 0 <= int(v) < q
     with pytest.raises(NotImplementedError):
         np.sort(x)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_sage_convolve_and_matrix_multiply_of_the_big_fields(tag):
+    """convolve.pkl and matrix_multiply.pkl of the three Sage folders of order >= 2^64 (the reference runs them as object-dtype
+    loops: _domains/_function.py:141-167, _domains/_linalg.py:286-308): 16 / 16 field folders for rows f1 and f2."""
+    GF, W, d, props = _load(tag)
+    for i in range(int(d["convolve_count"])):
+        x, y = GF(_obj(d[f"convolve_X_{i}"])), GF(_obj(d[f"convolve_Y_{i}"]))
+        z = np.convolve(x, y)
+        assert type(z) is GF
+        H.assert_equal_ints(z.numpy(), _obj(d[f"convolve_Z_{i}"]), f"{tag} convolve {i}")
+    for i in range(int(d["matrix_multiply_count"])):
+        x, y = GF(_obj(d[f"matrix_multiply_X_{i}"])), GF(_obj(d[f"matrix_multiply_Y_{i}"]))
+        z = x @ y
+        assert type(z) is GF and z.shape == (x.shape[0], y.shape[1])
+        H.assert_equal_ints(z.numpy(), _obj(d[f"matrix_multiply_Z_{i}"]), f"{tag} matmul {i}")
+        H.assert_equal_ints(np.matmul(x, y).numpy(), _obj(d[f"matrix_multiply_Z_{i}"]))
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_reductions_of_the_big_fields_against_the_oracle(tag):
+    """ufunc.reduce / accumulate (left folds for subtract and divide), np.sum / prod / cumsum, vector products and batched
+    matrix products against the Python-integer oracle."""
+    GF, W, d, props = _load(tag)
+    q = GF.order
+    rnd = random.Random(7)
+    h = np.array([rnd.randrange(1, q) for _ in range(3 * 700)], dtype=object).reshape(3, 700)
+    h[0, 0], h[1, 5], h[2, 699] = q - 1, 1, q - 2
+    x = GF(h)
+    fold = {np.add: W.add, np.subtract: W.sub, np.multiply: W.mul, np.true_divide: W.div}
+
+    def left_fold(f, row):
+        acc = int(row[0])
+        out = [acc]
+        for v in row[1:]:
+            acc = f(acc, int(v))
+            out.append(acc)
+        return out
+
+    for uf, f in fold.items():
+        want = [left_fold(f, h[r]) for r in range(3)]
+        H.assert_equal_ints(uf.reduce(x, axis=1).numpy(), np.array([w[-1] for w in want], dtype=object), f"{tag} {uf.__name__}.reduce")
+        H.assert_equal_ints(uf.accumulate(x[:, :40], axis=1).numpy(), np.array([left_fold(f, h[r, :40]) for r in range(3)], dtype=object))
+    col = [left_fold(W.add, h[:, c])[-1] for c in range(700)]
+    H.assert_equal_ints(np.add.reduce(x, axis=0).numpy(), np.array(col, dtype=object))
+    assert np.add.reduce(x, axis=1, keepdims=True).shape == (3, 1)
+    assert int(np.sum(x)) == left_fold(W.add, h.ravel())[-1] and int(np.prod(x[0, :50])) == left_fold(W.mul, h[0, :50])[-1]
+    H.assert_equal_ints(np.cumsum(x[1, :30]).numpy(), np.array(left_fold(W.add, h[1, :30]), dtype=object))
+    assert int(np.add.reduce(x[0, :1])) == int(h[0, 0])
+    z = GF(np.array([3, 0, 5], dtype=object))
+    with pytest.raises(ZeroDivisionError):
+        np.true_divide.reduce(z)
+    # products: vector . vector, matrix @ vector, batched matrices with a broadcast right operand
+    a, b = h[0, :25], h[1, :25]
+    dotv = 0
+    for u, v in zip(a, b):
+        dotv = W.add(dotv, W.mul(int(u), int(v)))
+    assert int(np.dot(GF(a), GF(b))) == dotv and int(np.vdot(GF(a), GF(b))) == dotv and int(np.inner(GF(a), GF(b))) == dotv
+    A = h[:, :12].reshape(3, 3, 4)
+    Bm = h[1, 100:112].reshape(4, 3)
+    got = (GF(A) @ GF(Bm)).numpy()
+    for t in range(3):
+        for i in range(3):
+            for j in range(3):
+                acc = 0
+                for k in range(4):
+                    acc = W.add(acc, W.mul(int(A[t, i, k]), int(Bm[k, j])))
+                assert int(got[t, i, j]) == acc
+    c = np.convolve(GF(h[0, :33]), GF(h[2, :7])).numpy()
+    for k in (0, 5, 38):
+        acc = 0
+        for i in range(33):
+            if 0 <= k - i < 7:
+                acc = W.add(acc, W.mul(int(h[0, i]), int(h[2, k - i])))
+        assert int(c[k]) == acc
