@@ -190,6 +190,9 @@ def main():
                                             f"(C restatement of the reference's jit-lookup multiply, -O3, 1 thread; "
                                             f"host has {os.cpu_count()} cores)"}
 
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline_reference"] = reference_timing()
+
     if rank == 0 and world == 1 and not args.no_extras:
         result["extra"] = extras(ga, L, lib, stream, world == 1 and not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
@@ -249,6 +252,18 @@ def self_launch(args):
         return 0
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.run(cmd, env=env).returncode
+
+
+def reference_timing():
+    """the ACTUAL reference on a stated subsample.  The reference is pure Python, is not vendored
+    (and must not be) and /root/reference does not exist on a GPU box, so it cannot be timed in this process: this is the committed
+    record of tools/time_reference_here.py -- the reference imported in place in the build container (python-calculate mode; its
+    Numba mode is not installable there), labelled with where and on what it ran."""
+    rec_path = os.path.join(ROOT, "profiles", "r03_reference_timings.json")
+    if not os.path.exists(rec_path):
+        return None
+    return {"kind": "reference", "timed_in_this_run": False,
+            "source": "profiles/r03_reference_timings.json (tools/time_reference_here.py, build container)", **json.load(open(rec_path))}
 
 
 def measure_traffic():
