@@ -127,12 +127,14 @@ def local_to_natural(parts: list[np.ndarray], n1: int, n2: int) -> np.ndarray:
     return out
 
 
-def _device_column_pass(field, local: torch.Tensor, n1: int, cols: int, col0: int, n_total: int, omega: int) -> torch.Tensor:
+def _device_column_pass(field, local: torch.Tensor, n1: int, cols: int, col0: int, n_total: int, omega: int, in_pitch: int = 0) -> torch.Tensor:
+    """`local`: an (n1, cols) array, or -- with in_pitch -- a view of `cols` adjacent columns of a wider row-major array whose
+    rows are in_pitch elements apart (read in place).  The result is a compact (n1, cols) array."""
     from ._array import _GFA_DTYPE, _ptr, _stream
 
-    out = torch.empty_like(local)
-    L.check(L.lib().gfa_ntt_columns(field._handle, _ptr(local), _ptr(out), n1, cols, col0, n_total, omega,
-                                    _GFA_DTYPE[local.element_size()], _stream()), "gfa_ntt_columns")
+    out = torch.empty((n1, cols), dtype=local.dtype, device=local.device)
+    L.check(L.lib().gfa_ntt_columns_pitched(field._handle, _ptr(local), in_pitch or cols, _ptr(out), cols, n1, cols, col0, n_total, omega,
+                                            _GFA_DTYPE[local.element_size()], _stream()), "gfa_ntt_columns")
     return out
 
 
@@ -235,9 +237,49 @@ class _Stamps:
                 self.sink.setdefault(name, []).append(e0.elapsed_time(e1))
 
 
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = str(device)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+def _all_to_all_lists(outs: list[torch.Tensor], ins: list[torch.Tensor], group=None) -> None:
+    """List form of the exchange (one contiguous block per peer on either side).  gloo with device tensors: through the host."""
+    import torch.distributed as dist
+
+    if ins[0].is_cuda and dist.get_backend(group) == "gloo":
+        r = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        _gloo_all_to_all(r, [i.contiguous().cpu() for i in ins], group)
+        for o, h in zip(outs, r):
+            o.copy_(h)
+    elif dist.get_backend(group) == "gloo":
+        r = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        _gloo_all_to_all(r, [i.contiguous() for i in ins], group)
+        for o, h in zip(outs, r):
+            o.copy_(h)
+    else:
+        dist.all_to_all(outs, [i.contiguous() for i in ins], group=group)
+
+
+def _gloo_all_to_all(outs: list[torch.Tensor], ins: list[torch.Tensor], group=None) -> None:
+    """gloo has no list all_to_all: one flat all_to_all_single of equal blocks instead (test rigs only)."""
+    import torch.distributed as dist
+
+    flat_in = torch.cat([i.reshape(-1) for i in ins])
+    flat_out = torch.empty_like(flat_in)
+    dist.all_to_all_single(flat_out, flat_in, group=group)
+    n = ins[0].numel()
+    for k, o in enumerate(outs):
+        o.copy_(flat_out[k * n:(k + 1) * n].reshape(o.shape))
+
+
 def ntt_four_step_distributed(field, local_cols: torch.Tensor, n1: int, n2: int, omega: int | None = None, group=None,
                               column_pass: Callable | None = None, row_pass: Callable | None = None,
-                              timings: dict | None = None) -> torch.Tensor:
+                              timings: dict | None = None, nsub: int | None = None) -> torch.Tensor:
     """
     One rank's part of a single length-(n1*n2) NTT over `field` spread over the ranks of `group`.
 
@@ -262,20 +304,45 @@ def ntt_four_step_distributed(field, local_cols: torch.Tensor, n1: int, n2: int,
     row_pass = row_pass or _device_row_pass
     st = _Stamps(timings)
     st.mark("start")
-    # (1) columns: A[k1][c] = w^((col0+c)*k1) * sum_j1 x[j1][c] * w_n1^(j1*k1)
-    a = column_pass(field, local_cols.contiguous(), n1, cols, rank * cols, n_total, omega)
-    st.mark("column_pass_ms")
-    # (2) the one exchange: rank r receives, from every rank s, rows [r*rows, (r+1)*rows) of s's column block
-    recv = torch.empty((world, rows, cols), dtype=a.dtype, device=a.device)
-    _all_to_all(recv, a, group)
-    st.mark("all_to_all_ms")
+    # (1) columns: A[k1][c] = w^((col0+c)*k1) * sum_j1 x[j1][c] * w_n1^(j1*k1), in `nsub` sub-blocks of adjacent columns;
+    # (2) the one exchange, issued per sub-block: rank r receives, from every rank p, rows [r*rows, (r+1)*rows) of p's sub-block s
+    #     at recv[p][s] -- on a side stream under RCCL, so that sub-block s travels while sub-block s+1 is being transformed (the
+    #     kernels and the exchange cost about the same in C5).  Still ONE logical all-to-all, in nsub grouped send / recv halves.
+    nsub = int(nsub) if nsub else (2 if cols % 2 == 0 and cols >= 64 else 1)
+    if cols % nsub:
+        raise ValueError("the number of local columns must be divisible by nsub")
+    csub = cols // nsub
+    local_cols = local_cols.contiguous()
+    recv = torch.empty((world, nsub, rows, csub), dtype=local_cols.dtype, device=local_cols.device)
+    overlap = local_cols.is_cuda and dist.get_backend(group) == "nccl" and nsub > 1
+    side = _side_stream(local_cols.device) if overlap else None
+    for sb in range(nsub):
+        if column_pass is _device_column_pass:
+            a = _device_column_pass(field, local_cols[:, sb * csub:(sb + 1) * csub], n1, csub, rank * cols + sb * csub, n_total, omega,
+                                    in_pitch=cols)
+        else:
+            a = column_pass(field, local_cols[:, sb * csub:(sb + 1) * csub].contiguous(), n1, csub, rank * cols + sb * csub, n_total, omega)
+        outs = [recv[p, sb] for p in range(world)]
+        ins = [a[p * rows:(p + 1) * rows] for p in range(world)]
+        if overlap:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                dist.all_to_all(outs, ins, group=group)
+            a.record_stream(side)
+        else:
+            _all_to_all_lists(outs, ins, group)
+    if overlap:
+        torch.cuda.current_stream().wait_stream(side)
+    st.mark("columns_and_exchange_ms")
     # (3) rows: X[k1 + n1*k2] = sum_j2 A[k1][j2] * w_n2^(j2*k2),  w_n2 = w^n1.  recv[s][k1_local][c] is column s*cols + c of
     # row k1_local: the device row pass reads those per-peer chunks in place; stand-ins (and chunk sizes the kernel does not
     # take) get the (rows, n2) row-major copy
     omega_n2 = field._scalar(L.OP_POW, omega, n1)
-    out = _device_row_pass_from_chunks(field, recv, n2, omega_n2) if row_pass is _device_row_pass and recv.is_cuda else None
+    out = _device_row_pass_from_chunks(field, recv.view(world * nsub, rows, csub), n2, omega_n2) if row_pass is _device_row_pass and recv.is_cuda else None
     if out is None:
-        mine = recv.permute(1, 0, 2).reshape(rows, n2).contiguous()
+        mine = recv.permute(2, 0, 1, 3).reshape(rows, n2).contiguous()
         st.mark("relayout_ms")
         out = row_pass(field, mine, n2, omega_n2)
     st.mark("row_pass_ms")

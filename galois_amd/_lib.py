@@ -64,6 +64,7 @@ SIGNATURES = {
     "gfa_ntt_dist": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_i64, c_i64, c_u64, c_int, c_void_p]),
     "gfa_intt_dist": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_i64, c_i64, c_u64, c_int, c_int, c_void_p]),
     "gfa_ntt_columns": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_u64, c_int, c_void_p]),
+    "gfa_ntt_columns_pitched": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_u64, c_int, c_void_p]),
     "gfa_ntt_columns_inv": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_u64, c_int, c_int, c_void_p]),
     "gfa_berlekamp_massey": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_int, c_void_p]),
     "gfa_vector": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_i64, c_void_p]),

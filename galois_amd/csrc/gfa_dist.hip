@@ -86,6 +86,20 @@ int all_to_all(const void *send, void *recv, size_t count, int dtype, void *comm
     return GFA_OK;
 }
 
+// one non-blocking side stream per device for the overlapped exchange (created at first use, kept for the process)
+int side_stream(hipStream_t *out)
+{
+    static std::mutex mu;
+    static hipStream_t streams[64] = {};
+    int dev = 0;
+    GFA_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev < 0 || dev >= 64) { set_error("gfa_ntt_dist: device ordinal out of range"); return GFA_ERR_UNSUPPORTED; }
+    if (!streams[dev]) GFA_HIP(hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking));
+    *out = streams[dev];
+    return GFA_OK;
+}
+
 int check_dist_args(gfa_field_t *f, const void *a, const void *b, void *comm, int rank, int world, int64_t n1, int64_t n2, int dtype,
                     const char *what)
 {
@@ -114,33 +128,74 @@ int gfa_ntt_dist(gfa_field_t *f, void *nccl_comm, int rank, int world, const voi
     if ((rc = bind_rccl())) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int64_t cols = n2 / world, rows = n1 / world, n_total = n1 * n2;
-    const size_t bytes = (size_t)(n1 * cols) * (dtype == GFA_U32 ? 4 : 8);
+    const size_t esz = dtype == GFA_U32 ? 4 : 8;
+    const size_t bytes = (size_t)(n1 * cols) * esz;
+    // The column pass and the exchange cost about the same (C5, 8 ranks: 0.145 ms of kernels, ~0.11 ms on the links), so the
+    // columns are transformed in two sub-blocks and the first one travels while the second is computed: still ONE logical
+    // all-to-all, issued as two grouped send / recv halves on a side stream.  GFA_DIST_NSUB=1: one ncclAllToAll, no overlap.
+    static const int nsub_env = [] { const char *e = getenv("GFA_DIST_NSUB"); return e ? atoi(e) : 2; }();
+    const bool p2p = g_rccl.send && g_rccl.recv && g_rccl.group_start && g_rccl.group_end;
+    const int nsub = (p2p && nsub_env >= 2 && cols % 2 == 0 && cols >= 64) ? 2 : 1;
+    const int64_t csub = cols / nsub;
+    hipStream_t side = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    if (nsub > 1) {
+        if ((rc = side_stream(&side))) return rc;
+        for (auto &e : ev) GFA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     char *work = nullptr;
     GFA_HIP(gfa::scratch_alloc((void **)&work, 2 * bytes, st));
-    void *a = work, *recv = work + bytes;
+    char *a = work, *recv = work + bytes;
     u64 omega_n2 = 0;
     HostArith::pow(f->calc, omega, n1, &omega_n2);
-    // (1) columns + twiddle, (2) the one exchange: block r of `a` (rows [r*rows, (r+1)*rows) of the column block) goes to rank r,
-    // (3) rows, read from the per-peer chunks recv[s][k1_local][c] in place
-    rc = gfa_ntt_columns(f, local_cols, a, n1, cols, (int64_t)rank * cols, n_total, omega, dtype, stream);
-    if (!rc) rc = all_to_all(a, recv, (size_t)(rows * cols), dtype, nccl_comm, world, st);
+    // (1) columns + twiddle, sub-block s written as its own compact (n1 x csub) array, (2) the exchange: rows [r*rows, (r+1)*rows)
+    // of sub-block s go to rank r and land at recv[peer][s][k1_local][c], (3) rows, read from those chunks in place
+    rc = GFA_OK;
+    if (nsub == 1) {
+        rc = gfa_ntt_columns(f, local_cols, a, n1, cols, (int64_t)rank * cols, n_total, omega, dtype, stream);
+        if (!rc) rc = all_to_all(a, recv, (size_t)(rows * cols), dtype, nccl_comm, world, st);
+    } else {
+        const int nccl_type = dtype == GFA_U32 ? 3 /* ncclUint32 */ : 5 /* ncclUint64 */;
+        const size_t blk = (size_t)(rows * csub); // elements per (peer, sub-block) chunk
+        for (int s = 0; s < nsub && !rc; s++) {
+            char *as = a + (size_t)s * (size_t)(n1 * csub) * esz;
+            rc = gfa_ntt_columns_pitched(f, (const char *)local_cols + (size_t)s * csub * esz, cols, as, csub, n1, csub,
+                                         (int64_t)rank * cols + s * csub, n_total, omega, dtype, stream);
+            if (rc) break;
+            hipError_t he = hipEventRecord(ev[s], st);
+            if (he == hipSuccess) he = hipStreamWaitEvent(side, ev[s], 0);
+            if (he != hipSuccess) { rc = hip_fail(he, "gfa_ntt_dist: event"); break; }
+            int nr;
+            if ((nr = g_rccl.group_start())) { rc = nccl_fail(nr, "ncclGroupStart"); break; }
+            for (int p = 0; p < world && !rc; p++) {
+                if ((nr = g_rccl.send(as + (size_t)p * blk * esz, blk, nccl_type, p, nccl_comm, side))) rc = nccl_fail(nr, "ncclSend");
+                else if ((nr = g_rccl.recv(recv + ((size_t)p * nsub + s) * blk * esz, blk, nccl_type, p, nccl_comm, side))) rc = nccl_fail(nr, "ncclRecv");
+            }
+            if ((nr = g_rccl.group_end()) && !rc) rc = nccl_fail(nr, "ncclGroupEnd");
+        }
+        if (!rc) {
+            hipError_t he = hipEventRecord(ev[2], side);
+            if (he == hipSuccess) he = hipStreamWaitEvent(st, ev[2], 0);
+            if (he != hipSuccess) rc = hip_fail(he, "gfa_ntt_dist: event");
+        }
+    }
     if (!rc) {
-        rc = gfa_ntt_chunked(f, recv, out_rows, n2, rows, omega_n2, 0, cols, rows * cols, cols, 0, 0, 0, dtype, stream);
+        rc = gfa_ntt_chunked(f, recv, out_rows, n2, rows, omega_n2, 0, csub, rows * csub, csub, 0, 0, 0, dtype, stream);
         if (rc == GFA_ERR_UNSUPPORTED) {
-            // chunk sizes the row kernel does not take in place (cols below its granule, n2 > 2^20): re-lay the per-peer chunks
-            // recv[s][k1_local][c] out as whole rows in the column buffer (free since the exchange) -- as galois_amd/_dist.py does
-            const size_t esz = dtype == GFA_U32 ? 4 : 8;
+            // chunk sizes the row kernel does not take in place (chunks below its granule, n2 > 2^20): re-lay the chunks
+            // recv[peer][s][k1_local][c] out as whole rows in the column buffer (free since the exchange) -- as galois_amd/_dist.py does
             rc = GFA_OK;
-            for (int s = 0; s < world && !rc; s++) {
-                const hipError_t ce = hipMemcpy2DAsync((char *)a + (size_t)s * cols * esz, (size_t)n2 * esz,
-                                                       (const char *)recv + (size_t)s * rows * cols * esz, (size_t)cols * esz,
-                                                       (size_t)cols * esz, (size_t)rows, hipMemcpyDeviceToDevice, st);
+            for (int ch = 0; ch < world * nsub && !rc; ch++) {
+                const hipError_t ce = hipMemcpy2DAsync(a + (size_t)ch * csub * esz, (size_t)n2 * esz, recv + (size_t)ch * rows * csub * esz,
+                                                       (size_t)csub * esz, (size_t)csub * esz, (size_t)rows, hipMemcpyDeviceToDevice, st);
                 if (ce != hipSuccess) rc = hip_fail(ce, "hipMemcpy2DAsync (row re-layout)");
             }
             if (!rc) rc = gfa_ntt(f, a, out_rows, n2, rows, omega_n2, 0, dtype, stream);
         }
     }
     const hipError_t fe = gfa::scratch_free(work, st);
+    for (auto &e : ev)
+        if (e) (void)hipEventDestroy(e);
     if (rc) return rc;
     GFA_HIP(fe);
     return GFA_OK;

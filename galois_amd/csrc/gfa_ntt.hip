@@ -1761,8 +1761,14 @@ int gfa_ntt(gfa_field_t *f, const void *in, void *out, int64_t n, int64_t batch,
 }
 
 static int ntt_columns_impl(gfa_field_t *f, const void *in, void *out, int64_t n1, int64_t cols, int64_t col0, int64_t n_total,
-                            uint64_t omega, int dtype, gfa_stream_t stream, bool inverse_form, int scale_by_n_total_inverse)
+                            uint64_t omega, int dtype, gfa_stream_t stream, bool inverse_form, int scale_by_n_total_inverse,
+                            int64_t in_pitch = 0, int64_t out_pitch = 0)
 {
+    // pitches: elements between consecutive rows of the local array (0 = cols: a contiguous (n1 x cols) array); a sub-block of
+    // the columns of a wider array is transformed in place with in_pitch = the wider array's row length
+    if (in_pitch == 0) in_pitch = cols;
+    if (out_pitch == 0) out_pitch = cols;
+    if (in_pitch < cols || out_pitch < cols) { set_error("gfa_ntt_columns: a pitch below the number of columns"); return GFA_ERR_INVALID; }
     if (!f || !in || !out || n1 < 2 || cols < 1 || col0 < 0 || n_total < n1 || (n_total % n1) != 0 || !is_pow2(n1) ||
         !is_pow2(n_total) || !is_pow2(cols)) {
         set_error("gfa_ntt_columns: bad arguments (power-of-two n1, cols, n_total required)");
@@ -1801,7 +1807,7 @@ static int ntt_columns_impl(gfa_field_t *f, const void *in, void *out, int64_t n
                 pl->reg_ready = true;
             }
             RegArgs ra{};
-            ra.in_stride_c = 1; ra.in_stride_t = cols; ra.out_stride_c = 1; ra.out_stride_t = cols;
+            ra.in_stride_c = 1; ra.in_stride_t = in_pitch; ra.out_stride_c = 1; ra.out_stride_t = out_pitch;
             ra.total_lines = cols;
             ra.post_twiddle = inverse_form ? 0 : 1; ra.pre_twiddle = inverse_form ? 1 : 0;
             ra.lo_bits = pl->lo_bits; ra.n_mask = (u64)n_total - 1; ra.line_offset = col0;
@@ -1827,7 +1833,7 @@ static int ntt_columns_impl(gfa_field_t *f, const void *in, void *out, int64_t n
         ta.logL = lg1;
         ta.lines_per_tile = choose_lines(lg1, sizeof(E), cols);
         ta.tiles_per_batch = (int)(cols / ta.lines_per_tile);
-        ta.in_stride_c = 1; ta.in_stride_t = cols; ta.out_stride_c = 1; ta.out_stride_t = cols;
+        ta.in_stride_c = 1; ta.in_stride_t = in_pitch; ta.out_stride_c = 1; ta.out_stride_t = out_pitch;
         ta.post_twiddle = 1; ta.lo_bits = pl->lo_bits; ta.n_mask = (u64)n_total - 1; ta.line_offset = col0;
         ta.tw_in_lds = lg1 <= 12;
         if constexpr (std::is_same<TW, TwShoupLazy>::value || std::is_same<TW, TwShoupWide>::value) {
@@ -1881,6 +1887,12 @@ int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64
                     uint64_t omega, int dtype, gfa_stream_t stream)
 {
     return ntt_columns_impl(f, in, out, n1, cols, col0, n_total, omega, dtype, stream, false, 0);
+}
+
+int gfa_ntt_columns_pitched(gfa_field_t *f, const void *in, int64_t in_pitch, void *out, int64_t out_pitch, int64_t n1, int64_t cols,
+                            int64_t col0, int64_t n_total, uint64_t omega, int dtype, gfa_stream_t stream)
+{
+    return ntt_columns_impl(f, in, out, n1, cols, col0, n_total, omega, dtype, stream, false, 0, in_pitch, out_pitch);
 }
 
 int gfa_ntt_columns_inv(gfa_field_t *f, const void *in, void *out, int64_t n1, int64_t cols, int64_t col0, int64_t n_total,

@@ -204,6 +204,11 @@ int gfa_ntt_chunked(gfa_field_t *f, const void *in, void *out, int64_t n, int64_
  * dtype must be the field's native device width (GFA_U32 for p < 2^32, GFA_U64 otherwise). */
 int gfa_ntt_columns(gfa_field_t *f, const void *in, void *out, int64_t n1, int64_t cols, int64_t col0, int64_t n_total,
                     uint64_t omega, int dtype, gfa_stream_t stream);
+/* The same column pass on a SUB-BLOCK of the rank's columns: `in` points at column col0 - (rank's first column) of the rank's
+ * (n1 x in_pitch) array, `cols` columns are transformed and written as an (n1 x out_pitch) array (pitches in elements, 0 = cols).
+ * Splitting the column pass lets the exchange of one sub-block run while the next is being transformed (gfa_ntt_dist does). */
+int gfa_ntt_columns_pitched(gfa_field_t *f, const void *in, int64_t in_pitch, void *out, int64_t out_pitch, int64_t n1, int64_t cols,
+                            int64_t col0, int64_t n_total, uint64_t omega, int dtype, gfa_stream_t stream);
 /* Per-rank LAST kernel of the distributed INVERSE transform (ifft_jit semantics, _domains/_function.py:387-392, spread
  * over G GPUs).  The inverse runs the forward steps backwards: a plain batched gfa_ntt of length n2 (root omega^n1) on the
  * rank's row block, the one all-to-all back to column blocks, then THIS call on the local (n1 x cols) array: element
@@ -219,7 +224,9 @@ int gfa_ntt_columns_inv(gfa_field_t *f, const void *in, void *out, int64_t n1, i
  * process per GPU).  `nccl_comm` is the caller's ncclComm_t (RCCL; bound with dlsym at first use, so the library has no
  * link-time dependency on it).  Forward: local_cols = the rank's (n1 x n2/world) column block of the row-major (n1 x n2)
  * view, out_rows = its (n1/world x n2) block of the result, X[k1 + n1*k2] at [k1 - rank*n1/world][k2]; steps:
- * gfa_ntt_columns, ONE ncclAllToAll over xGMI, gfa_ntt_chunked on the receive buffer.  The inverse consumes that row-block
+ * gfa_ntt_columns, ONE all-to-all over xGMI, gfa_ntt_chunked on the receive buffer.  When RCCL's send / recv are available the
+ * column pass runs in two sub-blocks and the exchange of the first (grouped ncclSend / ncclRecv on a side stream: still one logical
+ * all-to-all, in two halves) overlaps the transform of the second.  The inverse consumes that row-block
  * layout and returns the column-block layout (`omega` is the FORWARD root in both calls).  n1 <= 2^10 for the inverse,
  * n2 <= 2^20; dtype = the field's native device width; input and output buffers must differ. */
 int gfa_ntt_dist(gfa_field_t *f, void *nccl_comm, int rank, int world, const void *local_cols, void *out_rows, int64_t n1, int64_t n2,

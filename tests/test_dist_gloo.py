@@ -67,7 +67,11 @@ def _worker(rank, world, port, order, n1, n2, q):
             return torch.from_numpy(out.view(np.int64))
 
         local = torch.from_numpy(gdist.columns_to_local(x, rank, world, n1, n2).view(np.int64))
-        mine = gdist.ntt_four_step_distributed(GF, local, n1, n2, omega=omega, column_pass=column_pass, row_pass=row_pass)
+        # the column pass in two sub-blocks, each with its own grouped exchange (the overlapped form of the device path)
+        mine = gdist.ntt_four_step_distributed(GF, local, n1, n2, omega=omega, column_pass=column_pass, row_pass=row_pass,
+                                               nsub=2 if (n2 // world) % 2 == 0 else 1)
+        one = gdist.ntt_four_step_distributed(GF, local, n1, n2, omega=omega, column_pass=column_pass, row_pass=row_pass, nsub=1)
+        assert torch.equal(mine, one)
         # the inverse consumes the row-block layout directly and returns the column-block layout: two exchanges in total
         back = gdist.intt_four_step_distributed(GF, mine, n1, n2, omega=omega, row_pass=row_pass, column_pass_inv=column_pass_inv)
         round_trip_ok = bool(torch.equal(back, local))
