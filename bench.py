@@ -518,6 +518,11 @@ def extras(ga, L, lib, stream, with_cpu):
                  "roofline_frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_point": 8}
         if logn == 20:
             entry["2^20_pt_ntt_per_s"] = entry["transforms_per_s"]
+            entry["note"] = ("two passes over the array (16 B/point of traffic against the 8 B/point algorithmic minimum this fraction "
+                             "is priced on): the same access pattern with NO arithmetic takes 0.20-0.22 ms for this batch "
+                             "(tools/ubench/ntt_access.hip, profiles/r03_ntt_access_skeleton.txt), i.e. 0.30-0.335 is the ceiling of any "
+                             "two-pass form on this part; sub-batching through the Infinity Cache and an XCD-fused single launch "
+                             "were measured and do not beat it (DESIGN.md section 4.3)")
         else:
             entry["2^20_points_per_s_equiv"] = round(points / (1 << 20) / (ms.value * 1e-3), 1)
             # the same kernel on a batch far larger than the 256 MiB Infinity Cache (4096 transforms: 1 GiB in, 1 GiB out): the
