@@ -103,7 +103,7 @@ int main(int argc, char **argv)
             }
         });
         printf("pair, sub-batches of %2d transforms (intermediate %3d MiB)    %8.4f ms  = %5.3f of the one-round-trip roofline at 8 TB/s\n", sub, sub * 4, ms,
-               (gb / 8e3) / ms);
+               (gb / 8.0) / ms); // gb GB at 8000 GB/s = gb / 8 ms
     }
     return 0;
 }
