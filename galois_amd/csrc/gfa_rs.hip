@@ -43,6 +43,7 @@ struct RsParams {
     int qm1;      // q - 1
     int log_alpha; // LOG[alpha]
     int base_p;    // 0 = Reed-Solomon; p = BCH over GF(p): corrections use SUBTRACT_BASE (_bch.py:1310, 1573)
+    int per_block; // codewords per workgroup (host-computed: no 64-bit division in the kernel)
 };
 
 template <bool BIN>
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     Arith8<true> ar;
-    uint8_t *free_l = stage_tables<true>(lds_raw, t, ar, rp.qm1, blockDim.x);
+    uint8_t *free_l = stage_tables<true>(lds_raw + 16, t, ar, rp.qm1, blockDim.x); // bytes 0..15: the claim counter (ds_append wants a 16-bit address)
     const int dd = rp.nroots, qm1 = rp.qm1, la = rp.log_alpha;
     const int nk = rp.n - rp.k; // length of the remainder r(x) mod g(x); equals dd for Reed-Solomon, larger for BCH
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
@@ -667,15 +668,27 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
     const int cm = rp.c % qm1;
     const u32 xroot = ar.exp_t[(la * ((cm + lane) % qm1)) % qm1]; // root_j = alpha^(c+j), j = lane
 
-    // Round 3, measured and not kept (2^17 words, e ~ U{0..16}, 0.261 ms with this loop):
-    //  (i)   CLAIMING codewords instead of dealing them out (a word with v errors costs about 3 + v units and the launch lasts as
-    //        long as its unluckiest wave): a counter in LDS with a vector and with a scalar loop condition, and one global counter
-    //        per workgroup, all hang on the device even when every wave claims exactly once, while this static loop around the
-    //        identical body runs -- cause not isolated within the GPU budget;
-    //  (ii)  syndromes as two half-wave Horner chains (lanes 32-63 take the high coefficients): 0.286 ms -- the select between
-    //        two scalar broadcasts per step (v_cndmask reading VCC: 11 lane-ops/clk/CU) costs what the halved chain saves;
-    //  (iii) leaving Berlekamp-Massey once every remaining discrepancy is zero (one ballot per zero step): 0.281 ms.
-    for (i64 cw = (i64)blockIdx.x * nwaves + wave; cw < batch; cw += (i64)gridDim.x * nwaves) {
+    // Codewords are CLAIMED, not dealt out: a word with v errors costs about 3 + v units, every wave is resident from the start, and
+    // with a static deal the launch lasts as long as its unluckiest wave (+38 % over the mean for 16 words per wave at e ~ U{0..16}).
+    // Each workgroup owns a contiguous range; a wave takes its next word with ONE ds_append on a counter at LDS offset 0 (returns the
+    // counter, adds the 64 active lanes; wave-uniform result).  Two things found the hard way: the counter
+    // must sit BELOW 64 KiB -- ds_append takes its address through M0[15:0], and with the counter behind the tables (offset 71296)
+    // words were claimed twice or never; and the `if (lane == 0) atomicAdd(...)` + readfirstlane form hangs in this kernel (LDS or
+    // global counter alike, even as a bare loop), cause not isolated.
+    // Measured and not kept: syndromes as two half-wave Horner chains (0.286 vs 0.261 ms: the select between two scalar
+    // broadcasts per step is a v_cndmask on VCC), leaving Berlekamp-Massey at the first all-zero tail (0.281 ms).
+    unsigned int *claim_p = reinterpret_cast<unsigned int *>(lds_raw);
+    if (threadIdx.x == 0) *claim_p = 0;
+    __syncthreads();
+    const i64 per_block = rp.per_block; // host-computed
+    const i64 cw_lo = (i64)blockIdx.x * per_block;
+    const i64 cw_hi_ = cw_lo + per_block < batch ? cw_lo + per_block : batch;
+    const unsigned int count = (unsigned int)__builtin_amdgcn_readfirstlane((int)(cw_hi_ > cw_lo ? cw_hi_ - cw_lo : 0));
+    for (;;) {
+        typedef __attribute__((address_space(3))) int lds_int;
+        const unsigned int idx = (unsigned int)__builtin_amdgcn_ds_append((lds_int *)claim_p) >> 6;
+        if (idx >= count) break;
+        const i64 cw = cw_lo + (i64)idx;
         uint8_t *orow = out_g + cw * n; // already holds the received row (copied by the pre-pass)
         // remainder coefficient of x^lane (stored highest degree first)
         const u32 remc = lane < nk ? rem_g[cw * nk + (nk - 1 - lane)] : 0;
@@ -710,7 +723,7 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
                 if (lane < dd) ws.synd()[lane] = (uint8_t)acc;
             }
             wave_sync();
-            // ---- 2. erasure locator (_bch.py:1389-1393) ----
+                // ---- 2. erasure locator (_bch.py:1389-1393) ----
             int glen = 1;
             if (lane == 0) ws.gamma()[0] = 1;
             wave_sync();
@@ -736,7 +749,7 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
                 ws.sprime()[lane] = (uint8_t)acc;
             }
             wave_sync();
-            // ---- 4. Berlekamp-Massey on S'[u:], coefficients one per lane (_lfsr.py:1647-1702) ----
+                // ---- 4. Berlekamp-Massey on S'[u:], coefficients one per lane (_lfsr.py:1647-1702) ----
             int llen = 1;
             const int nsq = dd - u;
             u32 Creg = lane == 0 ? 1u : 0u;
@@ -802,7 +815,7 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
                 const unsigned long long mk = __ballot(lane < clen && Creg != 0);
                 llen = mk ? 64 - __clzll((long long)mk) : 1;
             }
-            if (lane < dd + 4) ws.lam()[lane] = lane < llen ? (uint8_t)Creg : 0;
+                if (lane < dd + 4) ws.lam()[lane] = lane < llen ? (uint8_t)Creg : 0;
             v = llen - 1;
             wave_sync();
             if (2 * v + u > dd) {
@@ -1334,7 +1347,7 @@ static int launch_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasur
     int nwaves = 16;
     while (nwaves > 1 && fixed + nwaves * per_wave > 160 * 1024) nwaves /= 2;
     if (fixed + nwaves * per_wave > 160 * 1024) { set_error("gfa_rs_decode: code too large for LDS"); return GFA_ERR_UNSUPPORTED; }
-    const size_t lds = fixed + nwaves * per_wave;
+    const size_t lds = fixed + ((nwaves * per_wave + 15) & ~(size_t)15) + 16;
     const int threads = nwaves * 64;
     const int grid = (int)std::min<i64>((batch + nwaves - 1) / nwaves, (i64)cu_count());
     static bool a[4] = {false, false, false, false};
@@ -1431,14 +1444,16 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
                 return (w == 4 || w == 5 || w == 6) ? w : 8;
             }();
             const int nwaves = 2 * wps;
-            const size_t lds = fixed + nwaves * per_wave;
+            const size_t lds = fixed + ((nwaves * per_wave + 15) & ~(size_t)15) + 16;
             const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
             const int grid = (int)std::max<i64>(1, std::min<i64>((batch + nwaves - 1) / nwaves, (i64)cu_count() * per_cu));
+            RsParams rpk = rp;
+            rpk.per_block = (int)((batch + grid - 1) / grid);
 #define GFA_K2(SV, W, IDX)                                                                                              \
     do {                                                                                                                \
         static bool attr = false;                                                                                       \
         if ((rc = set_lds_limit(rs_decode_bin_kernel<SV, W>, &attr))) return rc;                                        \
-        hipLaunchKernelGGL((rs_decode_bin_kernel<SV, W>), dim3(grid), dim3(nwaves * 64), lds, st, make_tables(*ds), rp, \
+        hipLaunchKernelGGL((rs_decode_bin_kernel<SV, W>), dim3(grid), dim3(nwaves * 64), lds, st, make_tables(*ds), rpk, \
                            erasures, rem, (int)ns, (uint8_t *)out_codeword, (i64 *)out_n_errors, batch);                \
     } while (0)
             if (small) {
