@@ -351,6 +351,7 @@ struct RegArgs {
     // The kernel needs 2^in_split >= R2 and 2^out_split >= R1 (the per-lane part of a position never crosses a chunk).
     int in_split = 31, out_split = 31;
     i64 in_chunk_stride = 0, out_chunk_stride = 0; // elements
+    int perm1 = 1, perm2 = 1; // Goldilocks shift-twiddle networks: input permutations (see ntt_reg_kernel_gl)
 };
 
 // byte offset of position t0 (a multiple of the lane-owned low part; wave-uniform => scalar arithmetic)
@@ -637,7 +638,58 @@ __device__ __forceinline__ void reg_dif_gl(gl::G3 (&v)[1 << LOGR], const u64 *__
     }
 }
 
-template <int LOGR1, int LOGR2, int THREADS, bool SPLIT>
+// x * 2^(6k), k = 1 .. 15: after unrolling k is a constant and the switch folds to one gl::mul_pow2 instance
+__device__ __forceinline__ gl::G3 gl_mul_pow2_6k(gl::G3 x, int k)
+{
+    switch (k) {
+    case 1: return gl::mul_pow2<6>(x);
+    case 2: return gl::mul_pow2<12>(x);
+    case 3: return gl::mul_pow2<18>(x);
+    case 4: return gl::mul_pow2<24>(x);
+    case 5: return gl::mul_pow2<30>(x);
+    case 6: return gl::mul_pow2<36>(x);
+    case 7: return gl::mul_pow2<42>(x);
+    case 8: return gl::mul_pow2<48>(x);
+    case 9: return gl::mul_pow2<54>(x);
+    case 10: return gl::mul_pow2<60>(x);
+    case 11: return gl::mul_pow2<66>(x);
+    case 12: return gl::mul_pow2<72>(x);
+    case 13: return gl::mul_pow2<78>(x);
+    case 14: return gl::mul_pow2<84>(x);
+    default: return gl::mul_pow2<90>(x);
+    }
+}
+
+// The same network for the CANONICAL root w_R = 2^(192/R) (2 has order 192 modulo p): every twiddle is a power of two, i.e. a
+// shift and a fold (gl::mul_pow2, 14-20 instructions) instead of a general product (~32).  A transform whose root is
+// w_R = canonical^u (u odd) is served by feeding the inputs in the order a' = u * a mod R -- the caller's job.
+template <int LOGR>
+__device__ __forceinline__ void reg_dif_gl_shift(gl::G3 (&v)[1 << LOGR])
+{
+    constexpr int R = 1 << LOGR;
+    constexpr int UNIT6 = 32 >> LOGR; // 2^(192/R) = 2^(6 * UNIT6)
+#pragma unroll
+    for (int s = LOGR - 1; s >= 0; s--) {
+        const int half = 1 << s;
+#pragma unroll
+        for (int b = 0; b < R; b += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; j++) {
+                const gl::G3 u = v[b + j], x = v[b + j + half];
+                v[b + j] = gl::add(u, x);
+                const int tj = j << (LOGR - 1 - s);
+                if (tj != 0) v[b + j + half] = gl_mul_pow2_6k(gl::sub(u, x), tj * UNIT6);
+                else v[b + j + half] = gl::sub(u, x);
+            }
+        }
+    }
+}
+
+// SHIFT: networks on the canonical roots with shift twiddles; the input permutations that make them compute the wanted
+// transform are ra.perm1 (register a' of the first network loads position (perm1 * a') mod R1) and ra.perm2 (the thread that
+// owns column r of the exchange writes it at position (perm2 * r) mod R2).  Not combined with pre_twiddle (whose progression
+// runs over the registers in position order).
+template <int LOGR1, int LOGR2, int THREADS, bool SPLIT, bool SHIFT = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_GL_WAVES, GFA_GL_WAVES))) void ntt_reg_kernel_gl(FieldDev fdk, const u64 *__restrict__ in, u64 *__restrict__ out, RegArgs ra,
                                                              const u64 *__restrict__ wL, const u64 *__restrict__ powA,
                                                              const u64 *__restrict__ powB)
@@ -683,9 +735,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_GL_
             const u32 off = cl * isc + (u32)ra_ * ist;
             const u32 icb = (u32)ra.in_chunk_stride * 8u;
 #pragma unroll
-            for (int a = 0; a < R1; a++)
-                va[a] = gl::from_u64(*reinterpret_cast<const E *>(ginb + (off + pos_offset((u32)(a * R2), ra.in_split, ist, icb))));
-            if (ra.pre_twiddle) {
+            for (int a = 0; a < R1; a++) {
+                const u32 pa = SHIFT ? (((u32)ra.perm1 * (u32)a) & (u32)(R1 - 1)) : (u32)a; // uniform: scalar arithmetic
+                va[a] = gl::from_u64(*reinterpret_cast<const E *>(ginb + (off + pos_offset(pa * (u32)R2, ra.in_split, ist, icb))));
+            }
+            if (!SHIFT && ra.pre_twiddle) {
                 // * w_N^(line * (r + R2*a)): per-thread geometric progression, one table fetch for its start and its ratio
                 const u32 line = (u32)(ra.line_offset + line0 + cl);
                 const u32 e0 = (line * (u32)ra_) & nmask, es = (line * (u32)R2) & nmask;
@@ -697,13 +751,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_GL_
                     if (a + 1 < R1) t = gl::to_u64(gl::mul_u64(t, sr));
                 }
             }
-            reg_dif_gl<LOGR1>(va, wL, R2); // w_R1 = w_L^R2
+            if constexpr (SHIFT) reg_dif_gl_shift<LOGR1>(va);
+            else reg_dif_gl<LOGR1>(va, wL, R2); // w_R1 = w_L^R2
         }
         __syncthreads(); // middle-twiddle table staged
 #pragma unroll
         for (int h = 0; h < (SPLIT ? 2 : 1); h++) {
             if (active_a) {
-                E *dst = data + ca * PC + ra_;
+                E *dst = data + ca * PC + (SHIFT ? (int)(((u32)ra.perm2 * (u32)ra_) & (u32)(R2 - 1)) : ra_);
                 u32 idx = (u32)ra_ * (u32)(h * RROWS); // r * ka
 #pragma unroll
                 for (int kl = 0; kl < RROWS; kl++) {
@@ -722,7 +777,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_GL_
             if (SPLIT && h == 0) __syncthreads();
         }
     }
-    reg_dif_gl<LOGR2>(v, wL, R1); // w_R2 = w_L^R1
+    if constexpr (SHIFT) reg_dif_gl_shift<LOGR2>(v);
+    else reg_dif_gl<LOGR2>(v, wL, R1); // w_R2 = w_L^R1
     // results are reduced to the canonical [0, p) and stored one by one, so that the registers of v[] free up as they go
     const bool live = line0 + c < ra.total_lines;
     char *const obase = goutb + ((u32)c * osc + (u32)ka * ost);
@@ -1212,6 +1268,44 @@ inline int env_int_now(const char *name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
+// Goldilocks shift-twiddle networks: for the line table at `wl` (w_L = omega^(n_total / L), L = R1 * R2) the odd exponents u1, u2
+// with w_L^R2 = (2^(192/R1))^u1 and w_L^R1 = (2^(192/R2))^u2, stored as the kernel wants them: perm1 = u1^-1 mod R1, perm2 = u2.
+struct GlPerm { int perm1, perm2; };
+std::mutex g_glperm_mu;
+std::map<const void *, GlPerm> g_glperm;
+
+inline bool goldi_shift_enabled()
+{ // GFA_NTT_GL_SHIFT=0: general products for the network twiddles as well (A/B measurements)
+    static const bool on = [] { const char *e = getenv("GFA_NTT_GL_SHIFT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+inline void goldi_register_perms(const FieldDev &fd, u64 omega, i64 n_total, int logL, const void *wl)
+{
+    const int l1 = (logL + 1) / 2, l2 = logL / 2; // the (R1, R2) split launch_reg uses
+    u64 wL = 0;
+    HostArith::pow(fd, omega, (i64)(n_total >> logL), &wL);
+    auto find_u = [&](int lr, int lother) -> int { // odd u with (w_L^(2^lother)) == (2^(192 / 2^lr))^u, 0 if none
+        if (lr == 0) return 1;
+        u64 w = 0, canon = 0;
+        HostArith::pow(fd, wL, (i64)1 << lother, &w);
+        HostArith::pow(fd, 2, (i64)(192 >> lr), &canon);
+        for (int u = 1; u < (1 << lr) || u == 1; u += 2) {
+            u64 c = 0;
+            HostArith::pow(fd, canon, u, &c);
+            if (c == w) return u;
+        }
+        return 0;
+    };
+    const int u1 = find_u(l1, l2), u2 = find_u(l2, l1);
+    if (!u1 || !u2) return; // (cannot happen for a primitive root of unity; the kernel then keeps the general products)
+    int inv1 = 1;
+    for (int t = 1; t < (1 << l1); t += 2)
+        if (((t * u1) & ((1 << l1) - 1)) == 1) inv1 = t;
+    std::lock_guard<std::mutex> lock(g_glperm_mu);
+    g_glperm[wl] = GlPerm{inv1, u2};
+}
+
 template <class F, class TW, int LOGR1, int LOGR2, int THREADS, bool SPLIT = false>
 int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64 batch, const void *wl, const void *wlq,
                   const void *pa, const void *paq, const void *pb, const void *pbq, const void *pam, hipStream_t st)
@@ -1234,14 +1328,31 @@ int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64
     }
     static const int lds_pad = env_int("GFA_NTT_LDS_PAD", 0); // occupancy experiments only
     if constexpr (std::is_same<TW, TwGoldi>::value) {
-        auto kern = ntt_reg_kernel_gl<LOGR1, LOGR2, THREADS, SPLIT>;
-        static bool attr = false;
-        if (!attr) {
-            GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr = true;
+        bool shift = false;
+        if (goldi_shift_enabled() && !ra.pre_twiddle) {
+            std::lock_guard<std::mutex> lock(g_glperm_mu);
+            auto it = g_glperm.find(wl);
+            if (it != g_glperm.end()) { ra.perm1 = it->second.perm1; ra.perm2 = it->second.perm2; shift = true; }
         }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds + (size_t)lds_pad, st, fd, (const u64 *)in, (u64 *)out, ra, (const u64 *)wl,
-                           (const u64 *)pa, (const u64 *)pb);
+        if (shift) {
+            auto kern = ntt_reg_kernel_gl<LOGR1, LOGR2, THREADS, SPLIT, true>;
+            static bool attr = false;
+            if (!attr) {
+                GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr = true;
+            }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds + (size_t)lds_pad, st, fd, (const u64 *)in, (u64 *)out, ra, (const u64 *)wl,
+                               (const u64 *)pa, (const u64 *)pb);
+        } else {
+            auto kern = ntt_reg_kernel_gl<LOGR1, LOGR2, THREADS, SPLIT, false>;
+            static bool attr = false;
+            if (!attr) {
+                GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr = true;
+            }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds + (size_t)lds_pad, st, fd, (const u64 *)in, (u64 *)out, ra, (const u64 *)wl,
+                               (const u64 *)pa, (const u64 *)pb);
+        }
     } else {
         auto kern = ntt_reg_kernel<F, TW, LOGR1, LOGR2, THREADS, SPLIT>;
         static bool attr = false;
@@ -1310,6 +1421,7 @@ int build_line_tables(const FieldDev &fd, u64 omega, i64 n_total, int logL, void
     int rc;
     if ((rc = build_pow_table<F>(fd, omega, (u64)(n_total / L), L, wl, st))) return rc;
     if (TW::HAS_SHOUP && (rc = build_shoup(fd, *wl, L, wlq, st, qbits_of<TW>()))) return rc;
+    if constexpr (std::is_same<F, Goldilocks>::value) goldi_register_perms(fd, omega, n_total, logL, *wl);
     return GFA_OK;
 }
 
@@ -1706,6 +1818,10 @@ void ntt_forget_field(const gfa_field *f)
     for (auto it = g_plans.begin(); it != g_plans.end();) {
         if (it->first.f == f) {
             Plan *pl = it->second;
+            {
+                std::lock_guard<std::mutex> gl_lock(g_glperm_mu);
+                for (const void *p : {(const void *)pl->wl0, (const void *)pl->wl1, (const void *)pl->wl2}) g_glperm.erase(p);
+            }
             for (void *p : {pl->w1, pl->w1q, pl->w2, pl->w2q, pl->powA, pl->powB, pl->powAq, pl->powBq, pl->powAm, pl->wl1, pl->wl1q, pl->wl2,
                             pl->wl2q, pl->wpow, pl->wl0, pl->wl0q, pl->powA2, pl->powB2, pl->powA2q,
                             pl->powB2q, pl->powA2m})
