@@ -513,10 +513,8 @@ int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 
         const M32Key key{fd.p, dev, n, omega};
         auto it = g_m32_plans.find(key);
         if (it == g_m32_plans.end()) {
-            if (g_m32_plans.size() >= 64) { // bounded cache: hipFree synchronises, so no launch still reads a freed table
-                for (auto &kv : g_m32_plans) free_plan(kv.second);
-                g_m32_plans.clear();
-            }
+            // plans are kept for the life of the process (another host thread may be launching from one): a plan is ~140 KiB of
+            // tables for a 2^20-point transform, one per (p, device, n, omega) ever used
             M32Plan *np = new M32Plan();
             const int rc = build_plan(np, fd.p, n, omega, st);
             if (rc) { free_plan(np); return rc; }
