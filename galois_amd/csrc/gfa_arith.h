@@ -591,7 +591,7 @@ struct Ext {
         return from_vec_m<M>(f, out);
     }
     // degrees the element-wise kernels are instantiated for (ExtM below)
-    static GFA_HD bool fixed_degree(const FieldDev &f) { return f.m >= 2 && f.m <= 6 && f.p < (1ull << 31); }
+    static GFA_HD bool fixed_degree(const FieldDev &f) { return f.m >= 2 && f.m <= 8 && f.p < (1ull << 31); }
     static GFA_HD u64 add(const FieldDev &f, u64 a, u64 b)
     {
         u32 av[GFA_MAX_EXT_DEGREE], bv[GFA_MAX_EXT_DEGREE];

@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void bin_swar_mul_kernel(const T *__restrict__
     (void)PER;
 }
 
-// GF(p^m), 2 <= m <= 6, calculate mode: the kernels are instantiated per degree (ExtM<M>: digit arrays in registers)
+// GF(p^m), 2 <= m <= 8, calculate mode: the kernels are instantiated per degree (ExtM<M>: digit arrays in registers)
 #define GFA_EXT_FIXED_T(FUNC, M, dtype, ...)                                      \
     switch (dtype) {                                                              \
     case GFA_U8: return FUNC<ExtM<M>, uint8_t>(__VA_ARGS__);                      \
@@ -649,7 +649,9 @@ __global__ __launch_bounds__(256) void bin_swar_mul_kernel(const T *__restrict__
         case 3: GFA_EXT_FIXED_T(FUNC, 3, dtype, __VA_ARGS__)                      \
         case 4: GFA_EXT_FIXED_T(FUNC, 4, dtype, __VA_ARGS__)                      \
         case 5: GFA_EXT_FIXED_T(FUNC, 5, dtype, __VA_ARGS__)                      \
-        default: GFA_EXT_FIXED_T(FUNC, 6, dtype, __VA_ARGS__)                     \
+        case 6: GFA_EXT_FIXED_T(FUNC, 6, dtype, __VA_ARGS__)                      \
+        case 7: GFA_EXT_FIXED_T(FUNC, 7, dtype, __VA_ARGS__)                      \
+        default: GFA_EXT_FIXED_T(FUNC, 8, dtype, __VA_ARGS__)                     \
         }                                                                         \
     }
 

@@ -667,7 +667,8 @@ def test_binary_field_calculate_mode_products_on_large_arrays(q, dt):
         GF.compile("auto")
 
 
-@pytest.mark.parametrize("q", [7**2, 251**2, 2147483647**2, 46351**2, 3**4, 5**4, 13**4, 3**5, 3**6, 11**6, 7**3, 251**3, 31**5])
+@pytest.mark.parametrize("q", [7**2, 251**2, 2147483647**2, 46351**2, 3**4, 5**4, 13**4, 3**5, 3**6, 11**6, 7**3, 251**3, 31**5,
+                               3**7, 7**7, 251**7, 3**8, 5**8, 251**8])
 def test_extension_fields_of_every_templated_degree(q):
     """GF(p^m), 2 <= m <= 6, calculate mode: the per-degree kernels (digits in registers, unreduced 64-bit accumulation -- the
     largest p for m = 2 sits at the accumulation bound 3 p^2 < 2^64) against the oracle."""
