@@ -262,6 +262,113 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_M32
 }
 
 // ------------------------------------------------------------------------------------------------
+// 2^11 .. 2^15 points in ONE pass over HBM: one workgroup owns one whole transform
+// ------------------------------------------------------------------------------------------------
+// n = R0 * 1024, R0 = 2 .. 32, T = n / 32 = 32 * R0 threads, 32 points per thread throughout, three register networks and two
+// exchanges through LDS -- the array is read once and written once (8 B/point; the two-pass form moves 16):
+//   phase 1: thread t holds, for its P = 32 / R0 positions j = t + T*i of the 1024-point sub-lines, the R0 points x[j + 1024*a0];
+//            radix-R0 network over a0, times w_n^(j*k0) (a per-position Montgomery progression), to LDS at [k0][j];
+//   phase 2: thread (k0, r) reads sub-line k0 at positions r + 32*a: radix-32 network over a, times w_1024^(r*ka), to LDS at [k0][ka][r];
+//   phase 3: thread (ka, k0) reads its row r = 0..31: radix-32 network over r; output kr goes to X[k0 + R0*(ka + 32*kr)] = out[t + T*kr].
+// Loads and stores are fully coalesced (consecutive threads, consecutive words) in every phase, LDS accesses conflict-free
+// (sub-line pitch = 32*33 + pad with pitch = 32/R0 mod 32).
+struct M32OneArgs {
+    i32 p;
+    u32 pinv;
+    i32 one, onep; // Montgomery form of 1 and its companion (normalises the untwiddled k0 = 0 outputs of phase 1)
+    i32 fin, finp; // last product: Montgomery form of 1 or of 1/n
+};
+
+template <int LOGR0>
+constexpr int one_pitch()
+{
+    constexpr int base = 32 * 33, want = 32 >> LOGR0;
+    return base + ((want - base) % 32 + 32) % 32;
+}
+
+// G transforms per workgroup (G * T threads, one staged middle-twiddle table for all of them): 2^11- and 2^12-point transforms would
+// otherwise run in 64- and 128-thread workgroups whose 8 KiB table limits the CU to 9-12 waves.
+template <int LOGR0, int G>
+__global__ __launch_bounds__(G * (32 << LOGR0)) void ntt_m32_one_kernel(const i32 *__restrict__ in, i32 *__restrict__ out, M32OneArgs a,
+                                                                       const i32 *__restrict__ net0, const i32 *__restrict__ net1,
+                                                                       const i32 *__restrict__ mid, const i32 *__restrict__ wj, i64 batch)
+{
+    constexpr int R0 = 1 << LOGR0, T = 32 * R0, P = 32 / R0, PITCH = one_pitch<LOGR0>(), THREADS = G * T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    i32 *midl = reinterpret_cast<i32 *>(smem_raw);                              // [ka][r] pairs of w_1024^(r*ka), shared by the G transforms
+    const int g = (int)threadIdx.x / T, tid = (int)threadIdx.x % T;
+    i32 *data = midl + 2 * 1024 + g * (R0 * PITCH);                             // R0 * PITCH words per transform, both exchanges
+    const i64 n = (i64)1024 * R0;
+    const i64 which = (i64)blockIdx.x * G + g;
+    const bool live = which < batch;                                            // a partly filled last workgroup repeats the last transform
+    const i64 row = live ? which : batch - 1;
+    const i32 *gin = in + row * n;
+    i32 *gout = out + row * n;
+    const i32 p = a.p, negp = -a.p;
+    const u32 pinv = a.pinv;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)gin, 0, (u32)(n * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)gout, 0, (u32)(n * 4), 0x00020000);
+
+    // ---- phase 1 ----
+    i32 va[P][R0];
+#pragma unroll
+    for (int i = 0; i < P; i++)
+#pragma unroll
+        for (int a0 = 0; a0 < R0; a0++) va[i][a0] = __builtin_amdgcn_raw_buffer_load_b32(rin, tid * 4, (i * T + a0 * 1024) * 4, 0);
+    for (int i = (int)threadIdx.x; i < 1024; i += THREADS) {
+        const int ka = i >> 5, r = i & 31;
+        reinterpret_cast<int2 *>(midl)[i] = reinterpret_cast<const int2 *>(mid)[r * ka];
+    }
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        dif<LOGR0>(va[i], net0, p);
+        const i32 ratio = wj[tid + i * T]; // w_n^j in Montgomery form
+        i32 t = ratio;
+        i32 *dst = data + tid + i * T;
+        dst[0] = mulm(va[i][0], a.one, a.onep, p);
+#pragma unroll
+        for (int k0 = 1; k0 < R0; k0++) {
+            dst[k0 * PITCH] = mulm1(va[i][brev_c(k0, LOGR0)], t, pinv, negp);
+            if (k0 + 1 < R0) t = mulm1(t, ratio, pinv, negp);
+        }
+    }
+    __syncthreads();
+    // ---- phase 2 ----
+    i32 v[32];
+    {
+        const int k0 = tid >> 5, r = tid & 31;
+        const i32 *src = data + k0 * PITCH + r;
+#pragma unroll
+        for (int x = 0; x < 32; x++) v[x] = src[32 * x];
+        dif<5>(v, net1, p);
+        __syncthreads(); // every thread has read its sub-line: the buffer can take the second layout
+        i32 *dst = data + k0 * PITCH + r;
+        const int2 *mrow = reinterpret_cast<const int2 *>(midl) + r;
+#pragma unroll
+        for (int ka = 0; ka < 32; ka++) {
+            const int2 wv = mrow[ka * 32];
+            dst[ka * 33] = mulm_v(v[brev_c(ka, 5)], wv.x, wv.y, p);
+        }
+    }
+    __syncthreads();
+    // ---- phase 3 ----
+    {
+        const int k0 = tid & (R0 - 1), ka = tid >> LOGR0;
+        const i32 *src = data + k0 * PITCH + ka * 33;
+#pragma unroll
+        for (int r = 0; r < 32; r++) v[r] = src[r];
+        dif<5>(v, net1, p);
+        const i32 fin = a.fin, finp = a.finp;
+#pragma unroll
+        for (int kr = 0; kr < 32; kr++) {
+            i32 x = mulm(v[brev_c(kr, 5)], fin, finp, p);
+            x += p & (x >> 31);
+            if (live) __builtin_amdgcn_raw_buffer_store_b32(x, rout, tid * 4, kr * T * 4, 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side: tables and plans
 // ------------------------------------------------------------------------------------------------
 __global__ void m32_progression_table_kernel(u32 p, u32 omega, int logn, int log2, int logr1, i32 *t0, i32 *ratio)
@@ -316,6 +423,8 @@ struct M32Plan {
     i32 *net1 = nullptr, *net2 = nullptr; // R/2 pairs each
     i32 *mid1 = nullptr, *mid2 = nullptr; // L pairs: w_L^e, companion
     i32 *pt0 = nullptr, *pratio = nullptr; // progression form of the inter-pass twiddle: n2 * R1 and n2 entries
+    // one-pass form (2^11 .. 2^15 points): radix-R0 network twiddles, radix-32 network twiddles, w_1024^e pairs, w_n^j (j < 1024)
+    i32 *one_net0 = nullptr, *one_net1 = nullptr, *one_mid = nullptr, *one_wj = nullptr;
 };
 
 struct M32Key {
@@ -328,7 +437,8 @@ std::map<M32Key, M32Plan *> g_m32_plans;
 
 void free_plan(M32Plan *pl)
 {
-    for (void *q : {(void *)pl->net1, (void *)pl->net2, (void *)pl->mid1, (void *)pl->mid2, (void *)pl->pt0, (void *)pl->pratio})
+    for (void *q : {(void *)pl->net1, (void *)pl->net2, (void *)pl->mid1, (void *)pl->mid2, (void *)pl->pt0, (void *)pl->pratio, (void *)pl->one_net0,
+                    (void *)pl->one_net1, (void *)pl->one_mid, (void *)pl->one_wj})
         if (q) (void)hipFree(q);
     delete pl;
 }
@@ -387,6 +497,27 @@ int build_plan(M32Plan *pl, u64 p, i64 n, u64 omega, hipStream_t st)
         if ((rc = upload(h, net_a))) return rc;
         return pair_table(p, pinv, omega, wl_mult, (int)Lh, mid);
     };
+    if (logn >= 11 && logn <= 15) {
+        const int R0 = (int)(n >> 10);
+        auto pairs = [&](u64 w, int count, i32 **d) -> int { // Montgomery form of w^e and its companion, e < count
+            std::vector<i32> h;
+            u64 cur = 1;
+            for (int e = 0; e < count; e++) {
+                const i32 wm = mont_centred(cur, p);
+                h.push_back(wm);
+                h.push_back((i32)((u32)wm * pinv));
+                cur = cur * w % p;
+            }
+            return upload(h, d);
+        };
+        if ((rc = pairs(powmod(omega, 1024, p), std::max(R0 / 2, 1), &pl->one_net0))) return rc;       // w_R0 = w_n^1024
+        if ((rc = pairs(powmod(omega, (u64)R0 * 32, p), 16, &pl->one_net1))) return rc;                // w_32 = w_1024^32, w_1024 = w_n^R0
+        if ((rc = pair_table(p, pinv, omega, (u64)R0, 1024, &pl->one_mid))) return rc;                 // w_1024^e
+        std::vector<i32> hw(1024);
+        u64 cur = 1;
+        for (int j = 0; j < 1024; j++) { hw[j] = mont_centred(cur, p); cur = cur * omega % p; }          // w_n^j
+        if ((rc = upload(hw, &pl->one_wj))) return rc;
+    }
     i32 *dummy = nullptr;
     if ((rc = line_tables(pl->log1, &pl->net1, &dummy, &pl->mid1))) return rc;
     if (pl->log2) {
@@ -485,6 +616,38 @@ int launch(int logL, const i32 *in, i32 *out, const M32Args &a, i64 batch, const
     }
 }
 
+template <int LOGR0>
+int launch_one_t(const i32 *in, i32 *out, const M32OneArgs &oa, i64 batch, const M32Plan *pl, hipStream_t st)
+{
+    constexpr int R0 = 1 << LOGR0;
+    // transforms per workgroup, measured (ms for 2^26 points; run-to-run spread about 5 %): 2^11 one per 64-thread workgroup 0.177, four per
+    // 256 threads 0.162, eight per 512 threads 0.145; 2^12 one 0.155, two 0.161, four 0.148; 2^13 one per 256 threads 0.140-0.150, two 0.152
+    constexpr int G = R0 <= 4 ? 16 / R0 : 1;
+    constexpr size_t lds = sizeof(i32) * (size_t)(2 * 1024 + G * R0 * one_pitch<LOGR0>());
+    auto kern = ntt_m32_one_kernel<LOGR0, G>;
+    static bool attr = false;
+    if (!attr) {
+        GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((batch + G - 1) / G)), dim3(G * 32 * R0), lds, st, in, out, oa, pl->one_net0, pl->one_net1, pl->one_mid,
+                       pl->one_wj, batch);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+int launch_one(int logr0, const i32 *in, i32 *out, const M32OneArgs &oa, i64 batch, const M32Plan *pl, hipStream_t st)
+{
+    switch (logr0) {
+    case 1: return launch_one_t<1>(in, out, oa, batch, pl, st);
+    case 2: return launch_one_t<2>(in, out, oa, batch, pl, st);
+    case 3: return launch_one_t<3>(in, out, oa, batch, pl, st);
+    case 4: return launch_one_t<4>(in, out, oa, batch, pl, st);
+    case 5: return launch_one_t<5>(in, out, oa, batch, pl, st);
+    default: set_error("m32 NTT: unsupported one-pass length"); return GFA_ERR_UNSUPPORTED;
+    }
+}
+
 } // namespace
 
 namespace gfa {
@@ -536,6 +699,14 @@ int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 
         a.total_lines = batch;
         a.load_along_line = 1; a.store_along_line = 1;
         return launch(pl->log1, src, dst, a, 1, pl->net1, pl->mid1, nullptr, nullptr, st, 0);
+    }
+    static const int one_pass = env_int("GFA_M32_ONE", 1);
+    if (one_pass && pl->one_wj && batch <= 0x7fffffff) {
+        M32OneArgs oa{};
+        oa.p = base.p; oa.pinv = pinv;
+        oa.one = mont_centred(1, fd.p); oa.onep = (i32)((u32)oa.one * pinv);
+        oa.fin = base.fin; oa.finp = base.finp;
+        return launch_one((int)(pl->log1 + pl->log2 - 10), src, dst, oa, batch, pl, st);
     }
     const i64 n1 = (i64)1 << pl->log1, n2 = (i64)1 << pl->log2;
     i32 *w = (i32 *)ws;
