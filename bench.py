@@ -503,7 +503,8 @@ def extras(ga, L, lib, stream, with_cpu):
         ex[tag] = entry
         del at, bt, ot
     # ---- NTT: 2^20 points over GF(7340033) (the modulus galois.ntt picks for that size), batch of 64 ----
-    for tag, p, logn, batch in (("ntt_2^20_gf7340033", 7340033, 20, 64), ("ntt_16x2^16_gf65537", 65537, 16, 16 * 64)):
+    for tag, p, logn, batch in (("ntt_2^20_gf7340033", 7340033, 20, 64), ("ntt_16x2^16_gf65537", 65537, 16, 16 * 64),
+                                ("ntt_2^14_gf7340033", 7340033, 14, 4096)):
         P = ga.GF(p)
         N = 1 << logn
         omega = P._root_of_unity_int(N)
@@ -516,7 +517,9 @@ def extras(ga, L, lib, stream, with_cpu):
         entry = {"transforms_per_s": round(batch / (ms.value * 1e-3), 1), "points_per_s": round(points / (ms.value * 1e-3), 0),
                  "ms_per_launch": round(ms.value, 4), "batch": batch, "algorithmic_GB/s": round(gbs, 1),
                  "roofline_frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_point": 8}
-        if logn == 20:
+        if logn == 14:
+            entry["note"] = "one pass over HBM: one workgroup per transform, three register networks, two LDS exchanges (gfa_ntt_m32.hip)"
+        elif logn == 20:
             entry["2^20_pt_ntt_per_s"] = entry["transforms_per_s"]
             entry["note"] = ("two passes over the array (16 B/point of traffic against the 8 B/point algorithmic minimum this fraction "
                              "is priced on): the same access pattern with NO arithmetic takes 0.20-0.22 ms for this batch "
