@@ -288,6 +288,10 @@ constexpr int one_pitch()
 
 // G transforms per workgroup (G * T threads, one staged middle-twiddle table for all of them): 2^11- and 2^12-point transforms would
 // otherwise run in 64- and 128-thread workgroups whose 8 KiB table limits the CU to 9-12 waves.
+// LDS operations of a wave complete in order, so lgkmcnt(0) + s_barrier is all an exchange needs; __syncthreads() would also wait
+// for the next transform's loads that are in flight by design.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int LOGR0, int G>
 __global__ __launch_bounds__(G * (32 << LOGR0)) void ntt_m32_one_kernel(const i32 *__restrict__ in, i32 *__restrict__ out, M32OneArgs a,
                                                                        const i32 *__restrict__ net0, const i32 *__restrict__ net1,
@@ -299,71 +303,78 @@ __global__ __launch_bounds__(G * (32 << LOGR0)) void ntt_m32_one_kernel(const i3
     const int g = (int)threadIdx.x / T, tid = (int)threadIdx.x % T;
     i32 *data = midl + 2 * 1024 + g * (R0 * PITCH);                             // R0 * PITCH words per transform, both exchanges
     const i64 n = (i64)1024 * R0;
-    const i64 which = (i64)blockIdx.x * G + g;
-    const bool live = which < batch;                                            // a partly filled last workgroup repeats the last transform
-    const i64 row = live ? which : batch - 1;
-    const i32 *gin = in + row * n;
-    i32 *gout = out + row * n;
+    const i64 nblk = (batch + G - 1) / G;
     const i32 p = a.p, negp = -a.p;
     const u32 pinv = a.pinv;
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)gin, 0, (u32)(n * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)gout, 0, (u32)(n * 4), 0x00020000);
-
-    // ---- phase 1 ----
+    // persistent workgroups: block index blk, blk + gridDim.x, ...; a partly filled last block repeats the last transform
+    auto row_of = [&](i64 blk) -> i64 { const i64 w = blk * G + g; return w < batch ? w : batch - 1; };
     i32 va[P][R0];
+    auto load_inputs = [&](i64 blk) {
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)(in + row_of(blk) * n), 0, (u32)(n * 4), 0x00020000);
 #pragma unroll
-    for (int i = 0; i < P; i++)
+        for (int i = 0; i < P; i++)
 #pragma unroll
-        for (int a0 = 0; a0 < R0; a0++) va[i][a0] = __builtin_amdgcn_raw_buffer_load_b32(rin, tid * 4, (i * T + a0 * 1024) * 4, 0);
+            for (int a0 = 0; a0 < R0; a0++) va[i][a0] = __builtin_amdgcn_raw_buffer_load_b32(rin, tid * 4, (i * T + a0 * 1024) * 4, 0);
+    };
+    i64 blk = blockIdx.x;
+    load_inputs(blk);
     for (int i = (int)threadIdx.x; i < 1024; i += THREADS) {
         const int ka = i >> 5, r = i & 31;
         reinterpret_cast<int2 *>(midl)[i] = reinterpret_cast<const int2 *>(mid)[r * ka];
     }
+    for (; blk < nblk; blk += gridDim.x) {
+        const bool live = blk * G + g < batch;
+        // ---- phase 1 ----
 #pragma unroll
-    for (int i = 0; i < P; i++) {
-        dif<LOGR0>(va[i], net0, p);
-        const i32 ratio = wj[tid + i * T]; // w_n^j in Montgomery form
-        i32 t = ratio;
-        i32 *dst = data + tid + i * T;
-        dst[0] = mulm(va[i][0], a.one, a.onep, p);
+        for (int i = 0; i < P; i++) {
+            dif<LOGR0>(va[i], net0, p);
+            const i32 ratio = wj[tid + i * T]; // w_n^j in Montgomery form
+            i32 t = ratio;
+            i32 *dst = data + tid + i * T;
+            dst[0] = mulm(va[i][0], a.one, a.onep, p);
 #pragma unroll
-        for (int k0 = 1; k0 < R0; k0++) {
-            dst[k0 * PITCH] = mulm1(va[i][brev_c(k0, LOGR0)], t, pinv, negp);
-            if (k0 + 1 < R0) t = mulm1(t, ratio, pinv, negp);
+            for (int k0 = 1; k0 < R0; k0++) {
+                dst[k0 * PITCH] = mulm1(va[i][brev_c(k0, LOGR0)], t, pinv, negp);
+                if (k0 + 1 < R0) t = mulm1(t, ratio, pinv, negp);
+            }
         }
-    }
-    __syncthreads();
-    // ---- phase 2 ----
-    i32 v[32];
-    {
-        const int k0 = tid >> 5, r = tid & 31;
-        const i32 *src = data + k0 * PITCH + r;
+        lds_barrier();
+        // the registers of va are free: the next transform's loads travel while this one runs its last two phases
+        if (blk + gridDim.x < nblk) load_inputs(blk + gridDim.x);
+        // ---- phase 2 ----
+        i32 v[32];
+        {
+            const int k0 = tid >> 5, r = tid & 31;
+            const i32 *src = data + k0 * PITCH + r;
 #pragma unroll
-        for (int x = 0; x < 32; x++) v[x] = src[32 * x];
-        dif<5>(v, net1, p);
-        __syncthreads(); // every thread has read its sub-line: the buffer can take the second layout
-        i32 *dst = data + k0 * PITCH + r;
-        const int2 *mrow = reinterpret_cast<const int2 *>(midl) + r;
+            for (int x = 0; x < 32; x++) v[x] = src[32 * x];
+            dif<5>(v, net1, p);
+            lds_barrier(); // every thread has read its sub-line: the buffer can take the second layout
+            i32 *dst = data + k0 * PITCH + r;
+            const int2 *mrow = reinterpret_cast<const int2 *>(midl) + r;
 #pragma unroll
-        for (int ka = 0; ka < 32; ka++) {
-            const int2 wv = mrow[ka * 32];
-            dst[ka * 33] = mulm_v(v[brev_c(ka, 5)], wv.x, wv.y, p);
+            for (int ka = 0; ka < 32; ka++) {
+                const int2 wv = mrow[ka * 32];
+                dst[ka * 33] = mulm_v(v[brev_c(ka, 5)], wv.x, wv.y, p);
+            }
         }
-    }
-    __syncthreads();
-    // ---- phase 3 ----
-    {
-        const int k0 = tid & (R0 - 1), ka = tid >> LOGR0;
-        const i32 *src = data + k0 * PITCH + ka * 33;
+        lds_barrier();
+        // ---- phase 3 ----
+        {
+            const int k0 = tid & (R0 - 1), ka = tid >> LOGR0;
+            const i32 *src = data + k0 * PITCH + ka * 33;
 #pragma unroll
-        for (int r = 0; r < 32; r++) v[r] = src[r];
-        dif<5>(v, net1, p);
-        const i32 fin = a.fin, finp = a.finp;
+            for (int r = 0; r < 32; r++) v[r] = src[r];
+            lds_barrier(); // the rows are in registers: the next iteration's phase 1 may overwrite the buffer
+            dif<5>(v, net1, p);
+            const i32 fin = a.fin, finp = a.finp;
+            const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(out + row_of(blk) * n), 0, (u32)(n * 4), 0x00020000);
 #pragma unroll
-        for (int kr = 0; kr < 32; kr++) {
-            i32 x = mulm(v[brev_c(kr, 5)], fin, finp, p);
-            x += p & (x >> 31);
-            if (live) __builtin_amdgcn_raw_buffer_store_b32(x, rout, tid * 4, kr * T * 4, 0);
+            for (int kr = 0; kr < 32; kr++) {
+                i32 x = mulm(v[brev_c(kr, 5)], fin, finp, p);
+                x += p & (x >> 31);
+                if (live) __builtin_amdgcn_raw_buffer_store_b32(x, rout, tid * 4, kr * T * 4, 0);
+            }
         }
     }
 }
@@ -630,8 +641,16 @@ int launch_one_t(const i32 *in, i32 *out, const M32OneArgs &oa, i64 batch, const
         GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((batch + G - 1) / G)), dim3(G * 32 * R0), lds, st, in, out, oa, pl->one_net0, pl->one_net1, pl->one_mid,
-                       pl->one_wj, batch);
+    // persistent: as many workgroups as fit the chip at once (LDS-limited), each looping over transforms with the next one's loads in flight
+    static const int cus = [] { int dev = 0, n = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }();
+    // measured: persistence + prefetch gains 14 % at 2^15 points (one workgroup per CU: nothing else overlaps its load phase) and
+    // nothing or a loss below (2^14: 0.150 -> 0.163 ms), where two or three workgroups per CU overlap each other
+    static const int persist_env = env_int("GFA_M32_ONE_PERSIST", -1);
+    const bool persist = persist_env >= 0 ? persist_env != 0 : LOGR0 == 5;
+    const i64 nblk = (batch + G - 1) / G;
+    const i64 per_cu = std::max<i64>(1, (i64)(160 * 1024) / (i64)lds);
+    const i64 grid = persist ? std::min<i64>(nblk, (i64)cus * per_cu) : nblk;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G * 32 * R0), lds, st, in, out, oa, pl->one_net0, pl->one_net1, pl->one_mid, pl->one_wj, batch);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }
