@@ -17,6 +17,8 @@ python tools/fermat_phases.py 1024 2>/dev/null | grep -E "round|phase|spread" > 
 python tools/ntt_time.py 2>/dev/null | grep "p=" > "$OUT/${R}_ntt_time.txt"
 { echo "# signed-Montgomery kernels (gfa_ntt_m32.hip, default)"; python tools/m32_time.py 2>/dev/null | grep "p="; echo "# GFA_NTT_M32=0: round-2 register kernels"; GFA_NTT_M32=0 python tools/m32_time.py 2>/dev/null | grep "p="; } > "$OUT/${R}_m32_time.txt"
 python tools/ew_bench.py --widestore 2>/dev/null | grep field > "$OUT/${R}_ew_widestore.txt"
+python tools/ew_bench.py --ext 2>/dev/null | grep field > "$OUT/${R}_ew_ext_calculate.txt"
+{ echo "# one pass (default)"; python tools/ntt_mid_time.py 2>/dev/null | grep "p="; echo "# GFA_M32_ONE=0: two passes"; GFA_M32_ONE=0 python tools/ntt_mid_time.py 2>/dev/null | grep "p="; } > "$OUT/${R}_ntt_mid_sizes.txt"
 ./tools/ubench/ntt_access 64 > "$OUT/${R}_ntt_access_skeleton.txt" 2>/dev/null
 ./tools/ubench/ntt_fused_skel 64 > "$OUT/${R}_ntt_fused_skeleton.txt" 2>/dev/null
 ./tools/ubench/mfma_dft16 > "$OUT/${R}_mfma_dft16.txt" 2>/dev/null
