@@ -352,6 +352,7 @@ struct RegArgs {
     int in_split = 31, out_split = 31;
     i64 in_chunk_stride = 0, out_chunk_stride = 0; // elements
     int perm1 = 1, perm2 = 1; // Goldilocks shift-twiddle networks: input permutations (see ntt_reg_kernel_gl)
+    int waves4 = 0;           // Goldilocks: hold the kernel to 128 VGPRs (four waves per SIMD); set by the three-pass driver
 };
 
 // byte offset of position t0 (a multiple of the lane-owned low part; wave-uniform => scalar arithmetic)
@@ -689,8 +690,11 @@ __device__ __forceinline__ void reg_dif_gl_shift(gl::G3 (&v)[1 << LOGR])
 // transform are ra.perm1 (register a' of the first network loads position (perm1 * a') mod R1) and ra.perm2 (the thread that
 // owns column r of the exchange writes it at position (perm2 * r) mod R2).  Not combined with pre_twiddle (whose progression
 // runs over the registers in position order).
-template <int LOGR1, int LOGR2, int THREADS, bool SPLIT, bool SHIFT = false>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_GL_WAVES, GFA_GL_WAVES))) void ntt_reg_kernel_gl(FieldDev fdk, const u64 *__restrict__ in, u64 *__restrict__ out, RegArgs ra,
+// WAVES: waves per SIMD the register allocation is held to (3: 168 VGPRs, 4: 128).  Measured: the two strided passes of the
+// three-pass transform (2^24, 2^26 points) run 5-6 % faster with four (more loads in flight); the column pass of a two-pass
+// 2^20-point transform 9 % slower and contiguous 1024-point lines 18 % slower (the tighter allocation) -- so only RegArgs::waves4.
+template <int LOGR1, int LOGR2, int THREADS, bool SPLIT, bool SHIFT = false, int WAVES = GFA_GL_WAVES>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void ntt_reg_kernel_gl(FieldDev fdk, const u64 *__restrict__ in, u64 *__restrict__ out, RegArgs ra,
                                                              const u64 *__restrict__ wL, const u64 *__restrict__ powA,
                                                              const u64 *__restrict__ powB)
 {
@@ -1334,25 +1338,24 @@ int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64
             auto it = g_glperm.find(wl);
             if (it != g_glperm.end()) { ra.perm1 = it->second.perm1; ra.perm2 = it->second.perm2; shift = true; }
         }
-        if (shift) {
-            auto kern = ntt_reg_kernel_gl<LOGR1, LOGR2, THREADS, SPLIT, true>;
-            static bool attr = false;
-            if (!attr) {
-                GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr = true;
-            }
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds + (size_t)lds_pad, st, fd, (const u64 *)in, (u64 *)out, ra, (const u64 *)wl,
-                               (const u64 *)pa, (const u64 *)pb);
-        } else {
-            auto kern = ntt_reg_kernel_gl<LOGR1, LOGR2, THREADS, SPLIT, false>;
-            static bool attr = false;
-            if (!attr) {
-                GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr = true;
-            }
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds + (size_t)lds_pad, st, fd, (const u64 *)in, (u64 *)out, ra, (const u64 *)wl,
-                               (const u64 *)pa, (const u64 *)pb);
-        }
+        // four waves per SIMD for the strided passes of the three-pass driver (see WAVES above)
+        static const int w4 = env_int("GFA_NTT_GL_W4", 1);
+        const bool strided = w4 && ra.waves4 && !ra.load_along_line && !ra.store_along_line && LOGR1 == 5;
+#define GFA_GL_LAUNCH(SH, WV)                                                                                                                    \
+    do {                                                                                                                                         \
+        auto kern = ntt_reg_kernel_gl<LOGR1, LOGR2, THREADS, SPLIT, SH, WV>;                                                                     \
+        static bool attr = false;                                                                                                                \
+        if (!attr) {                                                                                                                             \
+            GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                            \
+            attr = true;                                                                                                                         \
+        }                                                                                                                                        \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds + (size_t)lds_pad, st, fd, (const u64 *)in, (u64 *)out, ra, (const u64 *)wl,     \
+                           (const u64 *)pa, (const u64 *)pb);                                                                                    \
+    } while (0)
+        if (shift && strided) GFA_GL_LAUNCH(true, 4);
+        else if (shift) GFA_GL_LAUNCH(true, GFA_GL_WAVES);
+        else GFA_GL_LAUNCH(false, GFA_GL_WAVES);
+#undef GFA_GL_LAUNCH
     } else {
         auto kern = ntt_reg_kernel<F, TW, LOGR1, LOGR2, THREADS, SPLIT>;
         static bool attr = false;
@@ -1619,7 +1622,7 @@ int run_pow2_reg3(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n
         {
             RegArgs ra{};
             ra.in_stride_c = 1; ra.in_stride_t = M; ra.out_stride_c = 1; ra.out_stride_t = M;
-            ra.total_lines = M;
+            ra.total_lines = M; ra.waves4 = 1;
             ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits; ra.n_mask = (u64)n - 1; ra.pinv = inverse_mod_2_32(fd.p);
             if ((rc = launch_reg<F, TW>(fd, log0, src, ws, ra, 1, pl->wl0, pl->wl0q, pl->powA, pl->powAq, pl->powB, pl->powBq,
                                         pl->powAm, st)))
@@ -1629,7 +1632,7 @@ int run_pow2_reg3(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n
             RegArgs ra{};
             ra.in_stride_c = 1; ra.in_stride_t = L2; ra.out_stride_c = 1; ra.out_stride_t = L2;
             ra.in_batch_stride = M; ra.out_batch_stride = M;
-            ra.total_lines = L2;
+            ra.total_lines = L2; ra.waves4 = 1;
             ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits2; ra.n_mask = (u64)M - 1; ra.pinv = inverse_mod_2_32(fd.p);
             if ((rc = launch_reg<F, TW>(fd, log1, ws, ws, ra, L0, pl->wl1, pl->wl1q, pl->powA2, pl->powA2q, pl->powB2,
                                         pl->powB2q, pl->powA2m, st)))
