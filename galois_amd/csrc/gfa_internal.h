@@ -201,6 +201,7 @@ struct gfa_rs {
         uint8_t *roots8 = nullptr; // n-k
         uint8_t *g8 = nullptr;     // generator polynomial, highest degree first, n-k+1 coefficients
         uint32_t *lfsr = nullptr;  // 256 x (n-k)/4 words: rows f * (g_{nk-1} .. g_0) of the byte-wide LFSR (binary fields)
+        uint8_t *aux8 = nullptr;   // rs_decode_bin_kernel: 64 syndrome points by lane, 64 source lanes, 256 positions by field element
         // codes over fields above 256 elements (gfa_rs_wide.hip): 32-bit copies instead of the byte arrays
         uint32_t *Pw = nullptr, *rootsw = nullptr, *gw = nullptr;
     };

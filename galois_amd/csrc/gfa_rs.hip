@@ -643,6 +643,24 @@ struct WaveScratch2 {
     __device__ __forceinline__ uint8_t *errloc() const { return base + 6 * S; }
 };
 
+// LDS accesses by 32-bit LDS address (no generic-pointer arithmetic): the product table is symmetric, so the product of a
+// per-lane (or wave-uniform) factor f and a running value a is the byte at row(f) + a with row(f) = table + 256 f held in a
+// register, and a Horner step  a' = T[a] ^ c  followed by the next address  row + a'  is ONE v_xad_u32 ((T ^ c) + row).
+typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
+__device__ __forceinline__ u32 lds_addr(const uint8_t *p) { return (u32)(size_t)(lds_cu8 *)p; }
+__device__ __forceinline__ u32 lds_ld8(u32 a) { return *(lds_cu8 *)(size_t)a; }
+// One Horner step on an ADDRESS register a = (running value << 8) | x (x: the lane's fixed evaluation point, byte 0): with
+// T = table[a] just gathered, byte 1 of a becomes (T ^ c) and byte 0 stays -- the next gather address in ONE instruction
+// (SDWA destination byte select, the rest of the register preserved).  c is wave-uniform; only its low byte takes part.
+__device__ __forceinline__ void horner_step(u32 &a, u32 T, u32 c)
+{
+    asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:DWORD" : "+v"(a) : "v"(T), "s"(c));
+}
+// Chien search: the four evaluation points of lane l are xl | CHIEN_X(s), xl = ((l & 31) << 2) | (l >> 5): the elements of the
+// field enumerated by VALUE, so that the 32 lanes of a half-wave read 32 different LDS banks whatever the running values are
+// (bank = bits 2..6 of the column); the position a point stands for comes from a 256-byte table built with the code.
+#define CHIEN_X(s) ((((s) & 1) << 1) | (((s) >> 1) << 7))
+
 __device__ __forceinline__ int lane_shift_up1(int v, int)
 { // lane i <- lane i-1 across the whole wavefront, lane 0 <- 0: one DPP move (wave_shr:1, GFX9 family incl. gfx950;
   // checked on hardware by tools/ubench/wave_shr.hip).  The row_shr + 3 readlane + 3 select form it replaces cost 7.
@@ -651,8 +669,8 @@ __device__ __forceinline__ int lane_shift_up1(int v, int)
 
 // WPS = resident waves per SIMD the register budget is sized for (block = 2 * WPS waves, two blocks per CU)
 template <int S, int WPS>
-__global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables t, RsParams rp, const uint8_t *__restrict__ eras_g,
-                                                             const uint8_t *__restrict__ rem_g, int n,
+__global__ __launch_bounds__(128 * WPS) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) void rs_decode_bin_kernel(RsTables t, RsParams rp, const uint8_t *__restrict__ eras_g,
+                                                             const uint8_t *__restrict__ rem_g, const uint8_t *__restrict__ aux_g, int n,
                                                              uint8_t *__restrict__ out_g, i64 *__restrict__ nerr_g, i64 batch)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -664,10 +682,20 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
     WaveScratch2<S> ws;
     ws.base = free_l + (size_t)wave * WaveScratch2<S>::BYTES;
     __syncthreads();
-    const unsigned long long lt_mask = ((unsigned long long)1 << lane) - 1;
-    const int cm = rp.c % qm1;
-    const u32 xroot = ar.exp_t[(la * ((cm + lane) % qm1)) % qm1]; // root_j = alpha^(c+j), j = lane
-
+    // The product table is used in two ways.  (a) One operand wave-uniform (Berlekamp-Massey, Omega): row = that operand, the
+    // lanes read one 256-byte row, at most two dwords per bank.  (b) Horner's rule at a per-lane point x (syndromes, Chien,
+    // Forney): row = running value, column = x, so the bank depends on x alone and the lane <-> point assignment decides the
+    // conflicts: the Chien points are enumerated by value (no conflicts), the syndrome roots are dealt to the lanes by the host
+    // so that a half-wave holds one root per bank where the roots allow it (aux: 64 x-values, 64 source lanes, 256 positions).
+    // PMC history of this kernel (2^17 words, e ~ U{0..16}): r02 89 M vector instructions / 81 M LDS cycles (50 % conflicts);
+    // every product as row(x) + value, one v_xad per step: 53 M / 121 M (72 % conflicts, slower); this arrangement: see DESIGN.
+    if (lds_addr(lds_raw) != 0) __builtin_trap(); // the Horner gathers add the table offset as an immediate
+    constexpr u32 TBL = 16;
+    const u32 synp = (u32)aux_g[lane] | ((u32)aux_g[64 + lane] << 10); // byte 0: root evaluated by this lane; bits 8..15: 4 * (lane holding S_lane)
+    const u32 xl = (u32)((lane & 31) << 2) | (u32)(lane >> 5);
+    u32 posp = 0; // positions of the four Chien points of this lane (255: not a position of the code)
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) posp |= (u32)aux_g[128 + (xl | CHIEN_X(s4))] << (8 * s4);
     // Codewords are CLAIMED, not dealt out: a word with v errors costs about 3 + v units, every wave is resident from the start, and
     // with a static deal the launch lasts as long as its unluckiest wave (+38 % over the mean for 16 words per wave at e ~ U{0..16}).
     // Each workgroup owns a contiguous range; a wave takes its next word with ONE ds_append on a counter at LDS offset 0 (returns the
@@ -684,15 +712,27 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
     const i64 cw_lo = (i64)blockIdx.x * per_block;
     const i64 cw_hi_ = cw_lo + per_block < batch ? cw_lo + per_block : batch;
     const unsigned int count = (unsigned int)__builtin_amdgcn_readfirstlane((int)(cw_hi_ > cw_lo ? cw_hi_ - cw_lo : 0));
+    const u32 tbl = lds_addr(ar.mul_t);
+    const bool nk32 = nk == 32; // the remainder is eight aligned words: read through the scalar cache, bytes picked by s_bfe
     for (;;) {
         typedef __attribute__((address_space(3))) int lds_int;
-        const unsigned int idx = (unsigned int)__builtin_amdgcn_ds_append((lds_int *)claim_p) >> 6;
+        const unsigned int idx = (unsigned int)__builtin_amdgcn_readfirstlane((int)((unsigned int)__builtin_amdgcn_ds_append((lds_int *)claim_p) >> 6));
         if (idx >= count) break;
         const i64 cw = cw_lo + (i64)idx;
         uint8_t *orow = out_g + cw * n; // already holds the received row (copied by the pre-pass)
-        // remainder coefficient of x^lane (stored highest degree first)
-        const u32 remc = lane < nk ? rem_g[cw * nk + (nk - 1 - lane)] : 0;
-        const bool any_nz = __any(remc != 0);
+        // remainder, stored highest degree first: rw[] (wave-uniform words) when n - k = 32, else coefficient of x^lane per lane
+        u32 rw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        u32 remc = 0;
+        bool any_nz;
+        if (nk32) {
+            const u32 *rp32 = reinterpret_cast<const u32 *>(rem_g + cw * 32);
+#pragma unroll
+            for (int i = 0; i < 8; i++) rw[i] = rp32[i];
+            any_nz = (rw[0] | rw[1] | rw[2] | rw[3] | rw[4] | rw[5] | rw[6] | rw[7]) != 0;
+        } else {
+            remc = lane < nk ? rem_g[cw * nk + (nk - 1 - lane)] : 0;
+            any_nz = __builtin_amdgcn_ballot_w64(remc != 0) != 0;
+        }
         if (!any_nz && !eras_g) { // clean word (_bch.py:1373-1376)
             if (lane == 0) nerr_g[cw] = 0;
             continue;
@@ -703,8 +743,9 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
             for (int base = 0; base < n; base += 64) {
                 const int i = base + lane;
                 const bool er = i < n && eras_g[cw * n + (n - 1 - i)] != 0;
-                const unsigned long long m = __ballot(er);
-                if (er && u + __popcll(m & lt_mask) < dd + 4) ws.epos()[u + __popcll(m & lt_mask)] = (uint8_t)i;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(er);
+                const int before = (int)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                if (er && u + before < dd + 4) ws.epos()[u + before] = (uint8_t)i;
                 u += __popcll(m);
             }
         }
@@ -715,41 +756,60 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
             status = 1;
         } else {
             // ---- 1. syndromes from the remainder: S_j = rem(root_j) by Horner's rule through the product table ----
-            // (lane j evaluates at root_j; two VALU instructions + one LDS gather per term)
+            // (per term one LDS gather and one SDWA xor, see horner_step)
+            u32 synd;
             {
-                u32 acc = (u32)__builtin_amdgcn_readlane((int)remc, nk - 1);
-                for (int tt = nk - 2; tt >= 0; tt--)
-                    acc = ar.mul_t[(acc << 8) | xroot] ^ (u32)__builtin_amdgcn_readlane((int)remc, tt);
-                if (lane < dd) ws.synd()[lane] = (uint8_t)acc;
+                u32 a, last;
+                if (nk32) {
+                    a = (synp & 0xffu) | ((rw[0] & 0xffu) << 8);
+#pragma unroll
+                    for (int b = 1; b < 31; b++) horner_step(a, lds_ld8(a + TBL), rw[b >> 2] >> (8 * (b & 3)));
+                    last = rw[7] >> 24;
+                } else {
+                    a = (synp & 0xffu) | ((u32)__builtin_amdgcn_readlane((int)remc, nk - 1) << 8);
+                    for (int tt = nk - 2; tt >= 1; tt--) horner_step(a, lds_ld8(a + TBL), (u32)__builtin_amdgcn_readlane((int)remc, tt));
+                    last = (u32)__builtin_amdgcn_readlane((int)remc, 0);
+                }
+                // the lane that evaluated root j hands S_j to lane j
+                synd = (u32)__builtin_amdgcn_ds_bpermute((int)(synp >> 8), (int)(lds_ld8(a + TBL) ^ last));
             }
-            wave_sync();
-                // ---- 2. erasure locator (_bch.py:1389-1393) ----
+            // The word without erasures over a code with d - 1 <= 32 (the common case) keeps S' = S, Gamma = 1 and Lambda in
+            // registers; everything else goes through the per-wave LDS arrays as before.
+            const bool inreg = u == 0 && dd <= 32;
             int glen = 1;
-            if (lane == 0) ws.gamma()[0] = 1;
-            wave_sync();
-            for (int k = 0; k < u; k++) {
-                const int e = ws.epos()[k];
-                const u32 Yk = ar.exp_t[(la * e) % qm1];
-                u32 g = 0;
-                if (lane <= glen) {
-                    const u32 gi = lane < glen ? ws.gamma()[lane] : 0;
-                    const u32 gm = lane >= 1 ? ws.gamma()[lane - 1] : 0;
-                    g = gi ^ ar.mul(gm, Yk);
+            u32 sp; // S'[lane] (0 from lane d - 1 upward)
+            if (inreg) {
+                sp = lane < dd ? synd : 0u;
+            } else {
+                if (lane < dd) ws.synd()[lane] = (uint8_t)synd;
+                wave_sync();
+                // ---- 2. erasure locator (_bch.py:1389-1393) ----
+                if (lane == 0) ws.gamma()[0] = 1;
+                wave_sync();
+                for (int k = 0; k < u; k++) {
+                    const int e = ws.epos()[k];
+                    const u32 Yk = ar.exp_t[(la * e) % qm1];
+                    u32 g = 0;
+                    if (lane <= glen) {
+                        const u32 gi = lane < glen ? ws.gamma()[lane] : 0;
+                        const u32 gm = lane >= 1 ? ws.gamma()[lane - 1] : 0;
+                        g = gi ^ ar.mul(gm, Yk);
+                    }
+                    wave_sync();
+                    if (lane <= glen) ws.gamma()[lane] = (uint8_t)g;
+                    glen++;
+                    wave_sync();
+                }
+                // ---- 3. modified syndromes S' = Gamma * S mod x^(d-1) (_bch.py:1408-1409) ----
+                sp = 0;
+                if (lane < dd) {
+                    const int imax = lane < glen - 1 ? lane : glen - 1;
+                    for (int i = 0; i <= imax; i++) sp ^= ar.mul(ws.gamma()[i], ws.synd()[lane - i]);
+                    ws.sprime()[lane] = (uint8_t)sp;
                 }
                 wave_sync();
-                if (lane <= glen) ws.gamma()[lane] = (uint8_t)g;
-                glen++;
-                wave_sync();
             }
-            // ---- 3. modified syndromes S' = Gamma * S mod x^(d-1) (_bch.py:1408-1409) ----
-            if (lane < dd) {
-                u32 acc = 0;
-                const int imax = lane < glen - 1 ? lane : glen - 1;
-                for (int i = 0; i <= imax; i++) acc ^= ar.mul(ws.gamma()[i], ws.synd()[lane - i]);
-                ws.sprime()[lane] = (uint8_t)acc;
-            }
-            wave_sync();
-                // ---- 4. Berlekamp-Massey on S'[u:], coefficients one per lane (_lfsr.py:1647-1702) ----
+            // ---- 4. Berlekamp-Massey on S'[u:], coefficients one per lane (_lfsr.py:1647-1702) ----
             int llen = 1;
             const int nsq = dd - u;
             u32 Creg = lane == 0 ? 1u : 0u;
@@ -757,36 +817,44 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
             if (nsq > 0) {
                 if (dd <= 32) {
                     // Inversionless Berlekamp-Massey without a discrepancy reduction (the RiBM arrangement of Sarwate &
-                    // Shanbhag): lanes 0..31 hold Lambda (X) and B (Y), lanes 32.. hold the coefficients r.. of
-                    // Lambda*S (X) and B*S (Y), so the discrepancy of step r is simply X[32].  One step for every lane:
-                    //     X' = gamma*A - d0*Bv,  Y' = (d0 != 0 && 2L <= r) ? A : Bv
-                    // with (A, Bv) = (X, Y shifted up) in the locator half and (X shifted down, Y) in the product half.
-                    // Lambda comes out multiplied by a non-zero constant; Omega' = Lambda*S' carries the same constant
-                    // and Forney's quotient, the roots and the degree are unchanged.  7 VALU + 2 gathers per step
-                    // instead of ~25 + 2 for the division form with a wave-wide XOR reduction.
-                    u32 X = lane == 0 ? 1u : ((lane >= 32 && lane - 32 < nsq) ? (u32)ws.sprime()[u + lane - 32] : 0u);
+                    // Shanbhag) in a frame that moves down one lane per step, so that ONE full-wave shift serves both halves:
+                    // lanes 0..31 hold the coefficients r.. of Lambda*S (X) and B*S (Y), the discrepancy of step r is X[0];
+                    // the locator half starts at lane 63 and after r steps Lambda_i (X) and (x^k B)_i (Y) sit at lane 63 - r + i.
+                    //     A = X shifted down one lane (zero fill),   X' = gamma*A - d0*Y,   Y' = (d0 != 0 && 2L <= r) ? A : Y
+                    // (in the old static frame: Lambda stays and x*B moves up, the products move down and stay).  The halves never
+                    // meet (the gap between them is zero) except in the 32nd step of a 32-step run, when Lambda_0 lands on lane 31:
+                    // the product half of Y, no longer needed then, is cleared first.  Lambda comes out multiplied by a non-zero
+                    // constant; Omega' = Lambda*S' carries the same constant and Forney's quotient, the roots and the degree are
+                    // unchanged.  Per step with a non-zero discrepancy: v_readfirstlane, v_add_dpp (index of gamma*A: row(gamma) is
+                    // a register refreshed when gamma changes), v_add (index of d0*Y: row(d0) is scalar), two gathers, v_xor.
+                    u32 X = lane == 63 ? 1u : (lane < nsq ? (inreg ? sp : (u32)ws.sprime()[u + lane]) : 0u);
                     u32 Y = X;
-                    u32 gamma = 1;
-                    for (int r = 0; r < nsq; r++) {
-                        const u32 d0 = (u32)__builtin_amdgcn_readlane((int)X, 32);
-                        const u32 A = (u32)__builtin_amdgcn_update_dpp((int)X, (int)X, 0x130, 0xC, 0xf, true);  // wave_shl:1, rows 2-3
-                        const u32 Bv = (u32)__builtin_amdgcn_update_dpp((int)Y, (int)Y, 0x138, 0x3, 0xf, true); // wave_shr:1, rows 0-1
+                    u32 grow = tbl + (1u << 8); // row(gamma)
+                    auto step = [&](int r) {
+                        const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)X);
+                        const u32 A = (u32)__builtin_amdgcn_update_dpp(0, (int)X, 0x130, 0xf, 0xf, true); // wave_shl:1: lane i <- lane i + 1
                         // A zero discrepancy (wave-uniform: every step after the 2v-th of a word with v errors) would only
                         // scale X by gamma.  The scale of X never matters (Y and gamma take their values from X itself, so
                         // all three stay consistent multiples), so those steps are the shift alone: no table gathers.
                         if (d0 == 0) {
                             X = A;
-                            Y = Bv;
                         } else {
-                            const u32 t1 = ar.mul_t[(gamma << 8) | A];
-                            const u32 t2 = ar.mul_t[(d0 << 8) | Bv];
-                            const bool change = 2 * L <= r;
-                            Y = change ? A : Bv;
+                            const u32 t1 = lds_ld8(A + grow);
+                            const u32 t2 = lds_ld8(Y + (tbl + (d0 << 8)));
                             X = t1 ^ t2;
-                            if (change) { L = r + 1 - L; gamma = d0; }
+                            asm("" : "+v"(X)); // keeps the loop value 32 bits wide (narrowed to i8 it costs a v_and per step)
+                            if (2 * L <= r) { Y = A; L = r + 1 - L; grow = tbl + (d0 << 8); }
                         }
+                    };
+                    const int rmain = nsq < 31 ? nsq : 31;
+                    for (int r = 0; r < rmain; r++) step(r);
+                    if (nsq == 32) {
+                        Y = lane < 32 ? 0u : Y;
+                        step(31);
                     }
-                    Creg = lane < 32 ? X : 0u;
+                    // Lambda_i is at lane 63 - nsq + i: bring it to lane i
+                    const u32 moved = (u32)__builtin_amdgcn_ds_bpermute(((lane + 63 - nsq) & 63) << 2, (int)X);
+                    Creg = (lane < 32 && lane <= nsq) ? moved : 0u;
                 } else {
                     const int Sall = lane < nsq ? (int)ws.sprime()[u + lane] : 0;
                     // Bs holds x^m * B(x) / b, so the update C -= (d/b) x^m B is ONE table gather on the critical path
@@ -812,49 +880,68 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
                     }
                 }
                 const int clen = L + 1 < nsq ? L + 1 : nsq;
-                const unsigned long long mk = __ballot(lane < clen && Creg != 0);
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(lane < clen && Creg != 0);
                 llen = mk ? 64 - __clzll((long long)mk) : 1;
             }
-                if (lane < dd + 4) ws.lam()[lane] = lane < llen ? (uint8_t)Creg : 0;
+            Creg = lane < llen ? Creg : 0u;
             v = llen - 1;
-            wave_sync();
             if (2 * v + u > dd) {
                 status = -1; // _bch.py:1431-1433
             } else {
                 // ---- 5. Lambda_total = Gamma * Lambda ----
                 const int ltlen = glen + llen - 1;
-                u32 ltk = 0;
-                if (lane < ltlen) {
-                    const int ilo = lane - (llen - 1) > 0 ? lane - (llen - 1) : 0;
-                    const int ihi = lane < glen - 1 ? lane : glen - 1;
+                u32 ltk = Creg; // Gamma = 1 without erasures
+                if (u > 0) {
+                    if (lane < dd + 4) ws.lam()[lane] = (uint8_t)Creg;
+                    wave_sync();
+                    ltk = 0;
+                    if (lane < ltlen) {
+                        const int ilo = lane - (llen - 1) > 0 ? lane - (llen - 1) : 0;
+                        const int ihi = lane < glen - 1 ? lane : glen - 1;
 #pragma unroll 4
-                    for (int i = ilo; i <= ihi; i++) ltk ^= ar.mul(ws.gamma()[i], ws.lam()[lane - i]);
+                        for (int i = ilo; i <= ihi; i++) ltk ^= ar.mul(ws.gamma()[i], ws.lam()[lane - i]);
+                    }
                 }
-                // ---- 6. Chien search: Lambda_total(alpha^-i) by Horner's rule, positions lane, lane+64, lane+128, lane+192
-                u32 xinv[4], acc[4];
+                // ---- 6. Chien search: Lambda_total(x) by Horner's rule at the four points of this lane (see CHIEN_X)
+                u32 acc[4];
+                {
+                    const u32 top = (u32)__builtin_amdgcn_readlane((int)ltk, ltlen - 1);
+                    if (ltlen >= 2) {
+                        u32 a[4];
 #pragma unroll
-                for (int s4 = 0; s4 < 4; s4++) {
-                    const int i = lane + 64 * s4;
-                    xinv[s4] = ar.exp_t[(qm1 - (la * i) % qm1) % qm1]; // alpha^(-i)
-                    acc[s4] = (u32)__builtin_amdgcn_readlane((int)ltk, ltlen - 1);
-                }
-                for (int k = ltlen - 2; k >= 0; k--) {
-                    const u32 lk = (u32)__builtin_amdgcn_readlane((int)ltk, k);
+                        for (int s4 = 0; s4 < 4; s4++) a[s4] = xl | ((top << 8) | CHIEN_X(s4));
+                        for (int k = ltlen - 2; k >= 1; k--) {
+                            const u32 lk = (u32)__builtin_amdgcn_readlane((int)ltk, k);
+                            u32 T[4];
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; s4++) acc[s4] = ar.mul_t[(acc[s4] << 8) | xinv[s4]] ^ lk;
+                            for (int s4 = 0; s4 < 4; s4++) T[s4] = lds_ld8(a[s4] + TBL);
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; s4++) horner_step(a[s4], T[s4], lk);
+                        }
+                        const u32 l0 = (u32)__builtin_amdgcn_readlane((int)ltk, 0);
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; s4++) acc[s4] = lds_ld8(a[s4] + TBL) ^ l0;
+                    } else {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; s4++) acc[s4] = top;
+                    }
                 }
                 int v_total = 0;
                 bool out_of_range_root = false;
+                u32 pp = posp;
+                asm volatile("" : "+v"(pp)); // the position tests below are two v_cmp per word; hoisted out of the word loop they
+                                             // become eight SGPR-pair masks that spill (the kernel has 72 SGPRs at 8 waves per SIMD)
 #pragma unroll
                 for (int s4 = 0; s4 < 4; s4++) {
-                    const int i = lane + 64 * s4;
-                    const bool root = i < rp.n && acc[s4] == 0;
-                    if (__any(root && i >= n)) out_of_range_root = true;
+                    const int i = (int)((pp >> (8 * s4)) & 0xffu);
+                    const bool root = acc[s4] == 0 && i < rp.n;
                     const bool rec = root && i < n;
-                    const unsigned long long mk = __ballot(rec);
+                    const unsigned long long mroot = __builtin_amdgcn_ballot_w64(root);
+                    const unsigned long long mk = __builtin_amdgcn_ballot_w64(rec);
+                    if (mroot != mk) out_of_range_root = true;
                     if (rec) {
-                        const int slot = v_total + __popcll(mk & lt_mask);
-                        if (slot < dd + 4) { ws.errpos()[slot] = (uint8_t)i; ws.errloc()[slot] = (uint8_t)xinv[s4]; }
+                        const int slot = v_total + (int)__builtin_amdgcn_mbcnt_hi((u32)(mk >> 32), __builtin_amdgcn_mbcnt_lo((u32)mk, 0u));
+                        if (slot < dd + 4) { ws.errpos()[slot] = (uint8_t)i; ws.errloc()[slot] = (uint8_t)(xl | CHIEN_X(s4)); }
                     }
                     v_total += __popcll(mk);
                 }
@@ -864,13 +951,16 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
                 } else {
                     // ---- 7. Omega' = Lambda * S' mod x^(d-1) ----
                     // Berlekamp-Massey guarantees sum_i Lambda_i S'_(k-i) = 0 for u + L <= k < d - 1, so the coefficients
-                    // from u + L upward are exactly zero: neither computed nor fed to Horner's rule below.
+                    // from u + L upward are exactly zero: not fed to Horner's rule below.  Lane k accumulates
+                    // Lambda_i * S'_(k-i): Lambda_i is a scalar (its table row a scalar address), S' moves up one lane per term.
                     const int oplen = u + L < dd ? (u + L > 0 ? u + L : 1) : dd;
-                    u32 om = 0;
-                    if (lane < oplen) {
-                        const int ihi = lane < llen - 1 ? lane : llen - 1;
-#pragma unroll 4
-                        for (int i = 0; i <= ihi; i++) om ^= ar.mul(ws.lam()[i], ws.sprime()[lane - i]);
+                    u32 om = lds_ld8(sp + (tbl + ((u32)__builtin_amdgcn_readlane((int)Creg, 0) << 8)));
+                    {
+                        u32 cur = sp;
+                        for (int i = 1; i < llen; i++) {
+                            cur = (u32)lane_shift_up1((int)cur, lane);
+                            om ^= lds_ld8(cur + (tbl + ((u32)__builtin_amdgcn_readlane((int)Creg, i) << 8)));
+                        }
                     }
                     // ---- 8./9./10. Forney, one located symbol per lane: numerator Omega'(x) and denominator
                     // Lambda_total'(x) by Horner's rule at x = X^-1.  Characteristic 2: the formal derivative keeps the
@@ -879,13 +969,21 @@ __global__ __launch_bounds__(128 * WPS, WPS) void rs_decode_bin_kernel(RsTables 
                     const bool act = lane < v_total;
                     const u32 x = act ? (u32)ws.errloc()[lane] : 0u;
                     u32 num = (u32)__builtin_amdgcn_readlane((int)om, oplen - 1);
-                    for (int tt = oplen - 2; tt >= 0; tt--) num = ar.mul_t[(num << 8) | x] ^ (u32)__builtin_amdgcn_readlane((int)om, tt);
-                    const u32 x2 = ar.mul_t[(x << 8) | x];
+                    if (oplen >= 2) {
+                        u32 a = x | (num << 8);
+                        for (int tt = oplen - 2; tt >= 1; tt--) horner_step(a, lds_ld8(a + TBL), (u32)__builtin_amdgcn_readlane((int)om, tt));
+                        num = lds_ld8(a + TBL) ^ (u32)__builtin_amdgcn_readlane((int)om, 0);
+                    }
+                    const u32 x2 = lds_ld8(x * 257u + TBL);
                     const int jtop = (L_total & 1) ? L_total : L_total - 1; // highest odd degree
                     u32 den = 0;
                     if (jtop >= 1) {
                         den = (u32)__builtin_amdgcn_readlane((int)ltk, jtop);
-                        for (int j = jtop - 2; j >= 1; j -= 2) den = ar.mul_t[(den << 8) | x2] ^ (u32)__builtin_amdgcn_readlane((int)ltk, j);
+                        if (jtop >= 3) {
+                            u32 a = x2 | (den << 8);
+                            for (int j = jtop - 2; j >= 3; j -= 2) horner_step(a, lds_ld8(a + TBL), (u32)__builtin_amdgcn_readlane((int)ltk, j));
+                            den = lds_ld8(a + TBL) ^ (u32)__builtin_amdgcn_readlane((int)ltk, 1);
+                        }
                     }
                     if (act) {
                         // corrected = received - E; an erased symbol was taken as zero, so it becomes E itself
@@ -1151,6 +1249,45 @@ int gfa_rs::ensure_device(int *device_out, Dev **out)
                 }
             GFA_HIP(hipMalloc((void **)&st.lfsr, rows.size() * sizeof(uint32_t)));
             GFA_HIP(hipMemcpy(st.lfsr, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            // rs_decode_bin_kernel's lane tables.  [128 + x]: the position i < n with alpha^-i = x (255: none).  [lane]: the
+            // syndrome root that lane evaluates, [64 + j]: the lane that evaluates root j.  The LDS bank of a Horner gather is
+            // bits 2..6 of the root, so the roots are dealt out one per bank and half-wave as far as they allow; idle lanes
+            // repeat a root of their own half-wave (same address as its owner: a broadcast, no conflict).
+            std::vector<uint8_t> aux(384, 0);
+            const uint8_t *mul8 = field->h_mul8.data();
+            std::fill(aux.begin() + 128, aux.end(), (uint8_t)255);
+            {
+                uint32_t ainv = 1;
+                for (uint32_t y = 1; y < field->calc.q; y++)
+                    if (mul8[((uint32_t)alpha << 8) | y] == 1) { ainv = y; break; }
+                uint32_t x = 1;
+                for (int64_t i = 0; i < n && i < 255; i++) {
+                    if (aux[128 + x] == 255) aux[128 + x] = (uint8_t)i;
+                    x = mul8[(x << 8) | ainv];
+                }
+            }
+            if (roots.size() <= 64) {
+                bool used[2][32] = {};
+                int filled[2] = {0, 0};
+                int lane_of[64];
+                std::vector<int> later;
+                for (size_t j = 0; j < roots.size(); j++) {
+                    const int bank = (int)((roots[j] >> 2) & 31);
+                    const int h = !used[0][bank] && filled[0] < 32 ? 0 : (!used[1][bank] && filled[1] < 32 ? 1 : -1);
+                    if (h < 0) { later.push_back((int)j); continue; }
+                    used[h][bank] = true;
+                    lane_of[j] = 32 * h + filled[h]++;
+                }
+                for (int j : later) { // a third root on one bank: any free lane
+                    const int h = filled[0] <= filled[1] && filled[0] < 32 ? 0 : 1;
+                    lane_of[j] = 32 * h + filled[h]++;
+                }
+                for (size_t j = 0; j < roots.size(); j++) { aux[lane_of[j]] = (uint8_t)roots[j]; aux[64 + j] = (uint8_t)lane_of[j]; }
+                for (int h = 0; h < 2; h++)
+                    for (int l = filled[h]; l < 32; l++) aux[32 * h + l] = filled[h] ? aux[32 * h] : (uint8_t)0;
+            }
+            GFA_HIP(hipMalloc((void **)&st.aux8, aux.size()));
+            GFA_HIP(hipMemcpy(st.aux8, aux.data(), aux.size(), hipMemcpyHostToDevice));
         }
         st.ready = true;
     }
@@ -1251,7 +1388,7 @@ void gfa_rs_destroy(gfa_rs_t *code)
 {
     if (!code) return;
     for (auto &st : code->dev)
-        if (st.ready) { (void)hipFree(st.P8); (void)hipFree(st.roots8); (void)hipFree(st.lfsr); (void)hipFree(st.g8); (void)hipFree(st.Pw); (void)hipFree(st.rootsw); (void)hipFree(st.gw); }
+        if (st.ready) { (void)hipFree(st.P8); (void)hipFree(st.roots8); (void)hipFree(st.lfsr); (void)hipFree(st.aux8); (void)hipFree(st.g8); (void)hipFree(st.Pw); (void)hipFree(st.rootsw); (void)hipFree(st.gw); }
     delete code;
 }
 
@@ -1454,7 +1591,7 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
         static bool attr = false;                                                                                       \
         if ((rc = set_lds_limit(rs_decode_bin_kernel<SV, W>, &attr))) return rc;                                        \
         hipLaunchKernelGGL((rs_decode_bin_kernel<SV, W>), dim3(grid), dim3(nwaves * 64), lds, st, make_tables(*ds), rpk, \
-                           erasures, rem, (int)ns, (uint8_t *)out_codeword, (i64 *)out_n_errors, batch);                \
+                           erasures, rem, cd->aux8, (int)ns, (uint8_t *)out_codeword, (i64 *)out_n_errors, batch);      \
     } while (0)
             if (small) {
                 switch (wps) {
