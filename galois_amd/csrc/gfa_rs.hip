@@ -20,6 +20,17 @@
 
 using namespace gfa;
 
+#ifndef GFA_RS_BMSTOP
+#define GFA_RS_BMSTOP 0 // measured: 0.226 ms against 0.188 (2^17 words, e ~ U{0..16}) -- the early stop saves the zero steps but the
+                        // branch-free step costs more per non-zero step than it saves; kept for reference
+#endif
+#ifndef GFA_RS_SPLIT
+#define GFA_RS_SPLIT 1
+#endif
+#ifndef GFA_RS_BYTESEL
+#define GFA_RS_BYTESEL 1
+#endif
+
 namespace {
 
 __device__ __forceinline__ void wave_sync()
@@ -656,6 +667,33 @@ __device__ __forceinline__ void horner_step(u32 &a, u32 T, u32 c)
 {
     asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:DWORD" : "+v"(a) : "v"(T), "s"(c));
 }
+// the same with c = byte B of a wave-uniform word (the byte select of the second source: no scalar shift)
+template <int B>
+__device__ __forceinline__ void horner_step_byte(u32 &a, u32 T, u32 w)
+{
+    if constexpr (B == 0) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0" : "+v"(a) : "v"(T), "s"(w));
+    if constexpr (B == 1) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_1" : "+v"(a) : "v"(T), "s"(w));
+    if constexpr (B == 2) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_2" : "+v"(a) : "v"(T), "s"(w));
+    if constexpr (B == 3) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_3" : "+v"(a) : "v"(T), "s"(w));
+}
+template <int B0, int B1>
+__device__ __forceinline__ void horner_bytes(u32 &a, const u32 (&w)[8], u32 tbl_off)
+{ // steps for bytes B0 .. B1 - 1 of the eight words (memory order)
+    if constexpr (B0 < B1) {
+        horner_step_byte<B0 & 3>(a, lds_ld8(a + tbl_off), w[B0 >> 2]);
+        horner_bytes<B0 + 1, B1>(a, w, tbl_off);
+    }
+}
+template <int B0, int B1>
+__device__ __forceinline__ void horner_bytes2(u32 &a1, u32 &a2, const u32 (&w)[8], u32 tbl_off)
+{ // two independent chains side by side: a1 takes bytes B0 .. B1 - 1 of the eight words (memory order), a2 bytes 16 + B0 ..
+    if constexpr (B0 < B1) {
+        const u32 T1 = lds_ld8(a1 + tbl_off), T2 = lds_ld8(a2 + tbl_off);
+        horner_step_byte<B0 & 3>(a1, T1, w[B0 >> 2]);
+        horner_step_byte<B0 & 3>(a2, T2, w[4 + (B0 >> 2)]);
+        horner_bytes2<B0 + 1, B1>(a1, a2, w, tbl_off);
+    }
+}
 // Chien search: the four evaluation points of lane l are xl | CHIEN_X(s), xl = ((l & 31) << 2) | (l >> 5): the elements of the
 // field enumerated by VALUE, so that the 32 lanes of a half-wave read 32 different LDS banks whatever the running values are
 // (bank = bits 2..6 of the column); the position a point stands for comes from a 256-byte table built with the code.
@@ -691,7 +729,12 @@ __global__ __launch_bounds__(128 * WPS) __attribute__((amdgpu_waves_per_eu(WPS, 
     // every product as row(x) + value, one v_xad per step: 53 M / 121 M (72 % conflicts, slower); this arrangement: see DESIGN.
     if (lds_addr(lds_raw) != 0) __builtin_trap(); // the Horner gathers add the table offset as an immediate
     constexpr u32 TBL = 16;
-    const u32 synp = (u32)aux_g[lane] | ((u32)aux_g[64 + lane] << 10); // byte 0: root evaluated by this lane; bits 8..15: 4 * (lane holding S_lane)
+    u32 synp = (u32)aux_g[lane] | ((u32)aux_g[64 + lane] << 10); // byte 0: root evaluated by this lane; bits 8..15: 4 * (lane holding S_lane)
+    { // byte 2: the root's 16th power
+        u32 x16 = synp & 0xffu;
+        for (int i = 0; i < 4; i++) x16 = ar.mul_t[(x16 << 8) | x16];
+        synp |= x16 << 16;
+    }
     const u32 xl = (u32)((lane & 31) << 2) | (u32)(lane >> 5);
     u32 posp = 0; // positions of the four Chien points of this lane (255: not a position of the code)
 #pragma unroll
@@ -712,7 +755,6 @@ __global__ __launch_bounds__(128 * WPS) __attribute__((amdgpu_waves_per_eu(WPS, 
     const i64 cw_lo = (i64)blockIdx.x * per_block;
     const i64 cw_hi_ = cw_lo + per_block < batch ? cw_lo + per_block : batch;
     const unsigned int count = (unsigned int)__builtin_amdgcn_readfirstlane((int)(cw_hi_ > cw_lo ? cw_hi_ - cw_lo : 0));
-    const u32 tbl = lds_addr(ar.mul_t);
     const bool nk32 = nk == 32; // the remainder is eight aligned words: read through the scalar cache, bytes picked by s_bfe
     for (;;) {
         typedef __attribute__((address_space(3))) int lds_int;
@@ -761,17 +803,30 @@ __global__ __launch_bounds__(128 * WPS) __attribute__((amdgpu_waves_per_eu(WPS, 
             {
                 u32 a, last;
                 if (nk32) {
+#if GFA_RS_SPLIT
+                    // r(x) = H1(x) x^16 + H2(x): two 15-step chains side by side (half the dependent gathers), then one product
+                    // by this lane's x^16 (byte 2 of synp) and one xor
+                    u32 a1 = (synp & 0xffu) | ((rw[0] & 0xffu) << 8), a2 = (synp & 0xffu) | ((rw[4] & 0xffu) << 8);
+                    horner_bytes2<1, 16>(a1, a2, rw, TBL);
+                    a = __builtin_amdgcn_perm(a1, synp, 0x0c0c0502u); // byte 1 <- H1, byte 0 <- x^16
+                    last = a2 >> 8;
+#else
                     a = (synp & 0xffu) | ((rw[0] & 0xffu) << 8);
+#if GFA_RS_BYTESEL
+                    horner_bytes<1, 31>(a, rw, TBL);
+#else
 #pragma unroll
                     for (int b = 1; b < 31; b++) horner_step(a, lds_ld8(a + TBL), rw[b >> 2] >> (8 * (b & 3)));
+#endif
                     last = rw[7] >> 24;
+#endif
                 } else {
                     a = (synp & 0xffu) | ((u32)__builtin_amdgcn_readlane((int)remc, nk - 1) << 8);
                     for (int tt = nk - 2; tt >= 1; tt--) horner_step(a, lds_ld8(a + TBL), (u32)__builtin_amdgcn_readlane((int)remc, tt));
                     last = (u32)__builtin_amdgcn_readlane((int)remc, 0);
                 }
                 // the lane that evaluated root j hands S_j to lane j
-                synd = (u32)__builtin_amdgcn_ds_bpermute((int)(synp >> 8), (int)(lds_ld8(a + TBL) ^ last));
+                synd = (u32)__builtin_amdgcn_ds_bpermute((int)((synp >> 8) & 0xffu), (int)(lds_ld8(a + TBL) ^ last));
             }
             // The word without erasures over a code with d - 1 <= 32 (the common case) keeps S' = S, Gamma = 1 and Lambda in
             // registers; everything else goes through the per-wave LDS arrays as before.
@@ -829,7 +884,50 @@ __global__ __launch_bounds__(128 * WPS) __attribute__((amdgpu_waves_per_eu(WPS, 
                     // a register refreshed when gamma changes), v_add (index of d0*Y: row(d0) is scalar), two gathers, v_xor.
                     u32 X = lane == 63 ? 1u : (lane < nsq ? (inreg ? sp : (u32)ws.sprime()[u + lane]) : 0u);
                     u32 Y = X;
-                    u32 grow = tbl + (1u << 8); // row(gamma)
+#if GFA_RS_BMSTOP
+                    u32 grow = 1u << 8; // row(gamma), relative to the table
+#else
+                    u32 grow = TBL + (1u << 8);
+#endif
+#if GFA_RS_BMSTOP
+                    // A zero discrepancy needs no branch of its own (the d0 * Y gather returns zeros, X becomes gamma * A; the scale
+                    // of X never matters: Y and gamma take their values from X itself, so all three stay consistent multiples).
+                    // Stop test: when the discrepancy is zero and every discrepancy still to come -- lanes 1 .. nsq - r - 1 of X -- is
+                    // zero too, which is the first zero step of a word with v <= t errors, the rest of the run is shifts alone: stop
+                    // there, the frame has moved r lanes.
+#define GFA_BM_TAIL_ZERO(R) (((u32)__builtin_amdgcn_ballot_w64(X != 0) & (0xffffffffu >> (32 - (nsq - (R))))) == 0)
+#define GFA_BM_STEP(R)                                                                                                          \
+    {                                                                                                                           \
+        const u32 A = (u32)__builtin_amdgcn_update_dpp(0, (int)X, 0x130, 0xf, 0xf, true); /* wave_shl:1: lane i <- lane i + 1 */ \
+        u32 t1 = lds_ld8(A + grow + TBL);                                                                                             \
+        const u32 t2 = lds_ld8(Y + (d0 << 8) + TBL);                                                                          \
+        asm("" : "+v"(t1)); /* keeps the loop value 32 bits wide (narrowed to i8 it costs a v_and per step) */                  \
+        X = t1 ^ t2;                                                                                                            \
+        if (d0 != 0 && 2 * L <= (R)) { Y = A; L = (R) + 1 - L; grow = d0 << 8; }                                        \
+    }
+                    const int rmain = nsq < 31 ? nsq : 31;
+                    int moves = 0; // steps taken = lanes the frame has moved
+                    while (moves < rmain) {
+                        const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)X);
+                        if (d0 == 0 && GFA_BM_TAIL_ZERO(moves)) break;
+                        GFA_BM_STEP(moves)
+                        moves++;
+                    }
+                    if (moves == 31 && nsq == 32) { // (the loop cannot stop at 31: it tests before step 30 at the latest)
+                        const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)X);
+                        if (!(d0 == 0 && GFA_BM_TAIL_ZERO(31))) {
+                            Y = lane < 32 ? 0u : Y;
+                            GFA_BM_STEP(31)
+                            moves = 32;
+                        }
+                    }
+#undef GFA_BM_STEP
+#undef GFA_BM_TAIL_ZERO
+                    // Lambda_i is at lane 63 - moves + i: bring it to lane i
+                    const u32 moved = (u32)__builtin_amdgcn_ds_bpermute(((lane + 63 - moves) & 63) << 2, (int)X);
+                    Creg = (lane < 32 && lane <= moves) ? moved : 0u;
+#else
+                    const u32 tbl = TBL;
                     auto step = [&](int r) {
                         const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)X);
                         const u32 A = (u32)__builtin_amdgcn_update_dpp(0, (int)X, 0x130, 0xf, 0xf, true); // wave_shl:1: lane i <- lane i + 1
@@ -855,6 +953,7 @@ __global__ __launch_bounds__(128 * WPS) __attribute__((amdgpu_waves_per_eu(WPS, 
                     // Lambda_i is at lane 63 - nsq + i: bring it to lane i
                     const u32 moved = (u32)__builtin_amdgcn_ds_bpermute(((lane + 63 - nsq) & 63) << 2, (int)X);
                     Creg = (lane < 32 && lane <= nsq) ? moved : 0u;
+#endif
                 } else {
                     const int Sall = lane < nsq ? (int)ws.sprime()[u + lane] : 0;
                     // Bs holds x^m * B(x) / b, so the update C -= (d/b) x^m B is ONE table gather on the critical path
@@ -954,12 +1053,12 @@ __global__ __launch_bounds__(128 * WPS) __attribute__((amdgpu_waves_per_eu(WPS, 
                     // from u + L upward are exactly zero: not fed to Horner's rule below.  Lane k accumulates
                     // Lambda_i * S'_(k-i): Lambda_i is a scalar (its table row a scalar address), S' moves up one lane per term.
                     const int oplen = u + L < dd ? (u + L > 0 ? u + L : 1) : dd;
-                    u32 om = lds_ld8(sp + (tbl + ((u32)__builtin_amdgcn_readlane((int)Creg, 0) << 8)));
+                    u32 om = lds_ld8(sp + ((u32)__builtin_amdgcn_readlane((int)Creg, 0) << 8) + TBL);
                     {
                         u32 cur = sp;
                         for (int i = 1; i < llen; i++) {
                             cur = (u32)lane_shift_up1((int)cur, lane);
-                            om ^= lds_ld8(cur + (tbl + ((u32)__builtin_amdgcn_readlane((int)Creg, i) << 8)));
+                            om ^= lds_ld8(cur + ((u32)__builtin_amdgcn_readlane((int)Creg, i) << 8) + TBL);
                         }
                     }
                     // ---- 8./9./10. Forney, one located symbol per lane: numerator Omega'(x) and denominator
