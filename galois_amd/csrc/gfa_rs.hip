@@ -24,6 +24,9 @@ using namespace gfa;
 #define GFA_RS_BMSTOP 0 // measured: 0.226 ms against 0.188 (2^17 words, e ~ U{0..16}) -- the early stop saves the zero steps but the
                         // branch-free step costs more per non-zero step than it saves; kept for reference
 #endif
+#ifndef GFA_RS_BMASM
+#define GFA_RS_BMASM 1
+#endif
 #ifndef GFA_RS_SPLIT
 #define GFA_RS_SPLIT 1
 #endif
@@ -699,6 +702,62 @@ __device__ __forceinline__ void horner_bytes2(u32 &a1, u32 &a2, const u32 (&w)[8
 // (bank = bits 2..6 of the column); the position a point stands for comes from a 256-byte table built with the code.
 #define CHIEN_X(s) ((((s) & 1) << 1) | (((s) >> 1) << 7))
 
+// Berlekamp-Massey steps r .. limit - 1 in the moving frame (see the kernel), written out instruction by instruction: the
+// compiler's versions of this loop carry 6-8 vector instructions per step, this one 4 (v_readfirstlane, v_add_dpp = index of
+// gamma * (X shifted), v_add = index of d0 * Y, v_xor) plus two on the steps that change Y and gamma, and a zero discrepancy
+// with nothing but zeros ahead (lanes 0 .. nsq - r - 1 of X: the first zero step of a word with v <= t errors) ends the run.
+// X, Y: the two polynomials; G: 256 * gamma in every lane; L: the LFSR length; r: steps taken (the frame has moved r lanes).
+// The product table sits at LDS offset 16 (checked at kernel entry).  Manual wait states: a DPP read needs two instructions
+// after the vector write of its source (there are at least five on every path).
+__device__ __forceinline__ void bm_run(u32 &X, u32 &Y, u32 &G, int &L, int &r, int limit, int nsq)
+{
+    u32 a1, a2, t1, t2;
+    int d0, row, tmp, twoL;
+    asm volatile(
+        "s_cmp_ge_i32 %[r], %[limit]\n\t"
+        "s_cbranch_scc1 BM_END%=\n\t"
+        "s_lshl_b32 %[twoL], %[L], 1\n\t"
+        "BM_TOP%=:\n\t"
+        "v_readfirstlane_b32 %[d0], %[X]\n\t"
+        "s_cmp_eq_u32 %[d0], 0\n\t"
+        "s_cbranch_scc1 BM_ZERO%=\n\t"
+        "s_lshl_b32 %[row], %[d0], 8\n\t"
+        "v_add_u32_dpp %[a1], %[X], %[G] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_u32_e32 %[a2], %[row], %[Y]\n\t"
+        "ds_read_u8 %[t1], %[a1] offset:16\n\t"
+        "ds_read_u8 %[t2], %[a2] offset:16\n\t"
+        "s_cmp_gt_i32 %[twoL], %[r]\n\t"
+        "s_cbranch_scc1 BM_SAME%=\n\t"
+        "v_mov_b32_dpp %[Y], %[X] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mov_b32_e32 %[G], %[row]\n\t"
+        "s_sub_i32 %[L], %[r], %[L]\n\t"
+        "s_add_i32 %[L], %[L], 1\n\t"
+        "s_lshl_b32 %[twoL], %[L], 1\n\t"
+        "BM_SAME%=:\n\t"
+        "s_add_i32 %[r], %[r], 1\n\t"
+        "s_cmp_lt_i32 %[r], %[limit]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_xor_b32_e32 %[X], %[t1], %[t2]\n\t"
+        "s_cbranch_scc1 BM_TOP%=\n\t"
+        "s_branch BM_END%=\n\t"
+        "BM_ZERO%=:\n\t"
+        "v_cmp_ne_u32_e32 vcc, 0, %[X]\n\t"
+        "s_sub_i32 %[tmp], %[nsq], %[r]\n\t"
+        "s_sub_i32 %[tmp], 32, %[tmp]\n\t"
+        "s_lshl_b32 %[tmp], vcc_lo, %[tmp]\n\t"
+        "s_cmp_eq_u32 %[tmp], 0\n\t"
+        "s_cbranch_scc1 BM_END%=\n\t"
+        "s_add_i32 %[r], %[r], 1\n\t"
+        "v_mov_b32_dpp %[X], %[X] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_cmp_lt_i32 %[r], %[limit]\n\t"
+        "s_cbranch_scc1 BM_TOP%=\n\t"
+        "BM_END%=:"
+        : [X] "+v"(X), [Y] "+v"(Y), [G] "+v"(G), [L] "+s"(L), [r] "+s"(r), [a1] "=&v"(a1), [a2] "=&v"(a2), [t1] "=&v"(t1),
+          [t2] "=&v"(t2), [d0] "=&s"(d0), [row] "=&s"(row), [tmp] "=&s"(tmp), [twoL] "=&s"(twoL)
+        : [limit] "s"(limit), [nsq] "s"(nsq)
+        : "vcc", "scc", "memory");
+}
+
 __device__ __forceinline__ int lane_shift_up1(int v, int)
 { // lane i <- lane i-1 across the whole wavefront, lane 0 <- 0: one DPP move (wave_shr:1, GFX9 family incl. gfx950;
   // checked on hardware by tools/ubench/wave_shr.hip).  The row_shr + 3 readlane + 3 select form it replaces cost 7.
@@ -884,12 +943,27 @@ __global__ __launch_bounds__(128 * WPS) __attribute__((amdgpu_waves_per_eu(WPS, 
                     // a register refreshed when gamma changes), v_add (index of d0*Y: row(d0) is scalar), two gathers, v_xor.
                     u32 X = lane == 63 ? 1u : (lane < nsq ? (inreg ? sp : (u32)ws.sprime()[u + lane]) : 0u);
                     u32 Y = X;
-#if GFA_RS_BMSTOP
+#if GFA_RS_BMASM
+                    int moves = 0; // steps taken = lanes the frame has moved
+                    {
+                        u32 G = 1u << 8;
+                        const int rmain = nsq < 31 ? nsq : 31;
+                        bm_run(X, Y, G, L, moves, rmain, nsq);
+                        if (moves == 31 && nsq == 32) { // (a run cannot stop at 31: its last test is before step 30)
+                            Y = lane < 32 ? 0u : Y;
+                            bm_run(X, Y, G, L, moves, 32, nsq);
+                        }
+                    }
+                    // Lambda_i is at lane 63 - moves + i: bring it to lane i
+                    const u32 moved = (u32)__builtin_amdgcn_ds_bpermute(((lane + 63 - moves) & 63) << 2, (int)X);
+                    Creg = (lane < 32 && lane <= moves) ? moved : 0u;
+#elif GFA_RS_BMSTOP
                     u32 grow = 1u << 8; // row(gamma), relative to the table
 #else
                     u32 grow = TBL + (1u << 8);
 #endif
-#if GFA_RS_BMSTOP
+#if GFA_RS_BMASM
+#elif GFA_RS_BMSTOP
                     // A zero discrepancy needs no branch of its own (the d0 * Y gather returns zeros, X becomes gamma * A; the scale
                     // of X never matters: Y and gamma take their values from X itself, so all three stay consistent multiples).
                     // Stop test: when the discrepancy is zero and every discrepancy still to come -- lanes 1 .. nsq - r - 1 of X -- is
