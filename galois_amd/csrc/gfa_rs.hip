@@ -557,6 +557,69 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
         for (int d = 0; d < NKW; d++) st[d] = 0;
         if (rowi < count) {
             const uint8_t *row = stage + rowi * ((ENCODE && !parity_only) ? ns_out : len);
+            if constexpr (NKW % 4 == 0) {
+                // PLANAR state: plane p holds the state bytes p, p + 4, p + 8, ... (W = NKW / 4 words, first byte on top).  Moving
+                // the whole state up one byte turns plane p + 1 into plane p -- a renaming, free in the unrolled loop -- and only
+                // the old plane 0, shifted one byte with the new symbol at the bottom, becomes the new plane 3: W shift
+                // instructions per symbol instead of NKW.  The table rows are stored in the same planar order (host side).
+                constexpr int W = NKW / 4;
+                u32 P[4][W];
+#pragma unroll
+                for (int p = 0; p < 4; p++)
+#pragma unroll
+                    for (int h = 0; h < W; h++) P[p][h] = 0;
+                // one symbol; K = symbols taken so far mod 4: the plane in role r is P[(r + K) & 3]
+                auto step = [&](auto kc, u32 sym) {
+                    constexpr int K = decltype(kc)::value;
+                    const u32 top = P[K & 3][0] >> 24;
+                    const u32 f = ENCODE ? (sym ^ top) : top;
+#pragma unroll
+                    for (int h = 0; h + 1 < W; h++) P[K & 3][h] = __builtin_amdgcn_alignbit(P[K & 3][h], P[K & 3][h + 1], 24);
+                    P[K & 3][W - 1] = (P[K & 3][W - 1] << 8) | (ENCODE ? 0u : sym);
+#pragma unroll
+                    for (int c4 = 0; c4 < NKW / 4; c4++) {
+                        const uint4 rv = *reinterpret_cast<const uint4 *>(T + c4 * 1024 + f * 4);
+                        const u32 w[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            constexpr int dummy = 0; (void)dummy;
+                            const int q = 4 * c4 + j;                  // planar word: role q / W, word q % W
+                            P[(q / W + K + 1) & 3][q % W] ^= w[j];
+                        }
+                    }
+                };
+                int i = 0;
+                for (; i + 4 <= len; i += 4) {
+                    step(std::integral_constant<int, 0>{}, row[i]);
+                    step(std::integral_constant<int, 1>{}, row[i + 1]);
+                    step(std::integral_constant<int, 2>{}, row[i + 2]);
+                    step(std::integral_constant<int, 3>{}, row[i + 3]);
+                }
+                const int tail = len - i; // 0 .. 3 symbols left; afterwards role r is P[(r + tail) & 3]
+                if (tail > 0) step(std::integral_constant<int, 0>{}, row[i]);
+                if (tail > 1) step(std::integral_constant<int, 1>{}, row[i + 1]);
+                if (tail > 2) step(std::integral_constant<int, 2>{}, row[i + 2]);
+                // back to consecutive bytes: a 4 x 4 byte transpose per word index (8 v_perm)
+                auto unplane = [&](auto kc) {
+                    constexpr int K = decltype(kc)::value;
+#pragma unroll
+                    for (int h = 0; h < W; h++) {
+                        const u32 A = P[K & 3][h], B = P[(K + 1) & 3][h], C = P[(K + 2) & 3][h], D = P[(K + 3) & 3][h];
+                        const u32 t0 = __builtin_amdgcn_perm(A, B, 0x07030602u), t1 = __builtin_amdgcn_perm(A, B, 0x05010400u);
+                        const u32 u0 = __builtin_amdgcn_perm(C, D, 0x07030602u), u1 = __builtin_amdgcn_perm(C, D, 0x05010400u);
+                        st[4 * h + 0] = __builtin_amdgcn_perm(t0, u0, 0x07060302u);
+                        st[4 * h + 1] = __builtin_amdgcn_perm(t0, u0, 0x05040100u);
+                        st[4 * h + 2] = __builtin_amdgcn_perm(t1, u1, 0x07060302u);
+                        st[4 * h + 3] = __builtin_amdgcn_perm(t1, u1, 0x05040100u);
+                    }
+                };
+                switch (tail) {
+                case 0: unplane(std::integral_constant<int, 0>{}); break;
+                case 1: unplane(std::integral_constant<int, 1>{}); break;
+                case 2: unplane(std::integral_constant<int, 2>{}); break;
+                default: unplane(std::integral_constant<int, 3>{}); break;
+                }
+            } else {
             for (int i = 0; i < len; i++) {
                 const u32 sym = row[i];
                 const u32 top = st[0] >> 24;
@@ -576,6 +639,7 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
 #pragma unroll
                     for (int d = 0; d < NKW % 4; d++) st[(NKW / 4) * 4 + d] ^= r[d];
                 }
+            }
             }
         }
         wave_sync();
@@ -1413,7 +1477,11 @@ int gfa_rs::ensure_device(int *device_out, Dev **out)
                 for (size_t d = 0; d < nkw; d++) {
                     uint32_t w = 0;
                     for (int b = 0; b < 4; b++) {
-                        const uint64_t gc = gpoly[1 + 4 * d + b];
+                        // consecutive order: byte b of word d multiplies state byte 4d + b.  Planar order (nkw % 4 == 0, see
+                        // rs_lfsr_kernel): word d = plane d / W, word d % W of the plane; its byte b is state byte p + 4 (4h + b)
+                        const size_t Wp = nkw / 4;
+                        const size_t si = nkw % 4 == 0 ? (d / Wp) + 4 * (4 * (d % Wp) + b) : 4 * d + b;
+                        const uint64_t gc = gpoly[1 + si];
                         w = (w << 8) | (fb < field->calc.q && gc < field->calc.q ? field->h_mul8[(fb << 8) | gc] : 0);
                     }
                     const size_t c4 = d / 4;
