@@ -473,22 +473,36 @@ __global__ __launch_bounds__(1024) void rs_decode_kernel(RsTables t, RsParams rp
 //   ENCODE:  state <- m(x) * x^(n-k) mod g(x)   = the systematic parity symbols   (_LinearCode._encode_message)
 //   !ENCODE: state <- r(x) mod g(x)             = 0 iff all syndromes vanish      (_detect_errors; decoder pre-pass)
 // Identical values to the reference's matrix products: parity = message @ P is by construction -(m x^(n-k) mod g).
-template <int NKW, bool ENCODE>
-__global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ rowtab, const uint8_t *__restrict__ in,
+// REP4 (NKW = 4 or 8, one 512-thread workgroup per CU): every 16-byte table chunk is stored FOUR times, 32 bytes apart, rows 2m
+// and 2m + 1 interleaved in one 128-byte block, and lane l reads copy (l >> kshift) & 3 -- the lanes the LDS serves in one cycle
+// then touch disjoint bank groups wherever their feedback bytes allow it (the kernel is bound by the LDS queue: two ds_read_b128
+// per symbol with random 16-byte offsets; PMC before: 59 % of the LDS cycles were bank conflicts).
+template <int NKW, bool ENCODE, bool REP4 = false>
+__global__ __launch_bounds__(REP4 ? 512 : 256) void rs_lfsr_kernel(const u32 *__restrict__ rowtab, const uint8_t *__restrict__ in,
                                                       const uint8_t *__restrict__ eras, int len, uint8_t *__restrict__ out,
                                                       int parity_only, uint8_t *__restrict__ rem_out,
-                                                      uint8_t *__restrict__ flag_out, i64 batch, int stage_bytes, u32 div_magic)
+                                                      uint8_t *__restrict__ flag_out, i64 batch, int stage_bytes, u32 div_magic, int kshift)
 {
     constexpr int NK = NKW * 4;
+    constexpr int TABLE_BYTES = REP4 ? (NKW / 4) * 16384 : 256 * NK;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     u32 *T = reinterpret_cast<u32 *>(lds_raw); // 256 rows x NKW words
-    for (int i = threadIdx.x; i < 256 * NKW; i += blockDim.x) T[i] = rowtab[i];
+    if constexpr (REP4) {
+        // source: chunk c of row f at rowtab[c * 1024 + f * 4 ..]; copy k of it at byte c * 16384 + (f >> 1) * 128 + k * 32 + (f & 1) * 16
+        for (int i = threadIdx.x; i < (NKW / 4) * 1024 * 4; i += blockDim.x) {
+            const int wd = i & 3, k = (i >> 2) & 3, f = (i >> 4) & 255, c = i >> 12;
+            T[c * 4096 + (f >> 1) * 32 + k * 8 + (f & 1) * 4 + wd] = rowtab[c * 1024 + f * 4 + wd];
+        }
+    } else {
+        for (int i = threadIdx.x; i < 256 * NKW; i += blockDim.x) T[i] = rowtab[i];
+    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const u32 kofs = (u32)((lane >> kshift) & 3) << 5;
     // Lane l divides row rowi = 4*(l % 16) + l/16 of the wave's 64 staged rows.  With the natural pitch of n = 255 bytes,
     // rows r and r+1 start 63.75 dwords apart, so four CONSECUTIVE rows share an LDS bank; the interleave leaves at most
     // two lanes of a 32-lane group on one bank for the per-symbol byte read.
     const int rowi = ((lane & 15) << 2) | (lane >> 4);
-    uint8_t *stage = lds_raw + 256 * NK + (size_t)wave * stage_bytes;
+    uint8_t *stage = lds_raw + TABLE_BYTES + (size_t)wave * stage_bytes;
     __syncthreads();
     const int ns_out = len + NK;
     for (i64 cw0 = ((i64)blockIdx.x * nwaves + wave) * 64; cw0 < batch; cw0 += (i64)gridDim.x * nwaves * 64) {
@@ -578,7 +592,8 @@ __global__ __launch_bounds__(256) void rs_lfsr_kernel(const u32 *__restrict__ ro
                     P[K & 3][W - 1] = (P[K & 3][W - 1] << 8) | (ENCODE ? 0u : sym);
 #pragma unroll
                     for (int c4 = 0; c4 < NKW / 4; c4++) {
-                        const uint4 rv = *reinterpret_cast<const uint4 *>(T + c4 * 1024 + f * 4);
+                        const uint4 rv = REP4 ? *reinterpret_cast<const uint4 *>(lds_raw + c4 * 16384 + (((f >> 1) << 7) | ((f & 1) << 4) | kofs))
+                                              : *reinterpret_cast<const uint4 *>(T + c4 * 1024 + f * 4);
                         const u32 w[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
@@ -1407,18 +1422,40 @@ int launch_lfsr(gfa_rs *code, gfa_rs::Dev *cd, const uint8_t *in, const uint8_t 
     const int nk = (int)(code->n - code->k), nkw = nk / 4;
     const int stage_bytes = ((64 * (ENCODE ? len + nk : std::max(len, nk)) + 15) / 16) * 16;
     const u32 div_magic = (u32)((((u64)1 << 32) + (u64)len - 1) / (u64)len); // ceil(2^32 / len): exact quotients below 2^16
-    const int threads = 256;
-    const size_t lds = (size_t)256 * nk + (size_t)(threads / 64) * stage_bytes;
+    // four table copies and eight waves per workgroup when that fits the 160 KiB of a CU (RS(255,223): 32 KiB + 8 x 16320 B)
+    static const int rep_env = [] { const char *e = getenv("GFA_RS_LFSR_REP4"); return e ? atoi(e) : 1; }();
+    static const int kshift = [] { const char *e = getenv("GFA_RS_LFSR_KSHIFT"); return e ? atoi(e) : 1; }();
+    const bool rep4 = rep_env && (nkw == 4 || nkw == 8) && (size_t)(nkw / 4) * 16384 + 8 * (size_t)stage_bytes <= 160 * 1024 &&
+                      (batch >= 64 * 8 * (i64)cu_count() / 2 || rep_env == 2); // smaller batches: more, smaller workgroups (2: always)
+    const int threads = rep4 ? 512 : 256;
+    const size_t lds = (rep4 ? (size_t)(nkw / 4) * 16384 : (size_t)256 * nk) + (size_t)(threads / 64) * stage_bytes;
     const i64 blocks = (batch + threads - 1) / threads;
-    const int grid = (int)std::max<i64>(1, std::min<i64>(blocks, (i64)cu_count() * 2));
+    const int grid = (int)std::max<i64>(1, std::min<i64>(blocks, (i64)cu_count() * (rep4 ? 1 : 2)));
 #define GFA_LFSR(W)                                                                                                     \
     case W: {                                                                                                           \
         static bool attr = false;                                                                                       \
         int rc = set_lds_limit(rs_lfsr_kernel<W, ENCODE>, &attr);                                                       \
         if (rc) return rc;                                                                                              \
         hipLaunchKernelGGL((rs_lfsr_kernel<W, ENCODE>), dim3(grid), dim3(threads), lds, st, cd->lfsr, in, eras, len, out, \
-                           parity_only, rem_out, flag_out, batch, stage_bytes, div_magic);                              \
+                           parity_only, rem_out, flag_out, batch, stage_bytes, div_magic, kshift);                      \
         break;                                                                                                          \
+    }
+#define GFA_LFSR_REP(W)                                                                                                 \
+    case W: {                                                                                                           \
+        static bool attr = false;                                                                                       \
+        int rc = set_lds_limit(rs_lfsr_kernel<W, ENCODE, true>, &attr);                                                 \
+        if (rc) return rc;                                                                                              \
+        hipLaunchKernelGGL((rs_lfsr_kernel<W, ENCODE, true>), dim3(grid), dim3(threads), lds, st, cd->lfsr, in, eras, len, out, \
+                           parity_only, rem_out, flag_out, batch, stage_bytes, div_magic, kshift);                      \
+        break;                                                                                                          \
+    }
+    if (rep4) {
+        switch (nkw) {
+            GFA_LFSR_REP(4) GFA_LFSR_REP(8)
+        default: break;
+        }
+        GFA_HIP(hipGetLastError());
+        return GFA_OK;
     }
     switch (nkw) {
         GFA_LFSR(1) GFA_LFSR(2) GFA_LFSR(3) GFA_LFSR(4) GFA_LFSR(5) GFA_LFSR(6) GFA_LFSR(7) GFA_LFSR(8)
@@ -1426,6 +1463,7 @@ int launch_lfsr(gfa_rs *code, gfa_rs::Dev *cd, const uint8_t *in, const uint8_t 
     default: set_error("lfsr: unsupported parity length"); return GFA_ERR_UNSUPPORTED;
     }
 #undef GFA_LFSR
+#undef GFA_LFSR_REP
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }

@@ -17,3 +17,13 @@ def test_fuzz(tool, seed, extra):
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "identical to the oracle" in r.stdout
+
+
+def test_fuzz_codes_with_the_replicated_lfsr_table_forced():
+    """rs_lfsr_kernel's four-copy table layout is chosen for batches of 2^16 words and more; GFA_RS_LFSR_REP4=2 forces it on the
+    fuzzer's small batches (codes with n - k = 16 or 32), so that every code shape the fuzzer draws goes through it too."""
+    env = dict(os.environ, GFA_RS_LFSR_REP4="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_codes.py"), "8", "29"], capture_output=True, text=True, timeout=600,
+                       env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "identical to the oracle" in r.stdout

@@ -1,6 +1,6 @@
 """RS(255,223), 2^17 codewords: encode (full codewords), decode at e ~ U{0..16}, decode of clean words -- kernel time from
 gfa_time_rs_* (HIP events on the launch stream), with a parity check of every output.  Knobs are read from the environment by
-the library (GFA_RS_LFSR_COPIES_LOG, GFA_RS_LFSR_THREADS, GFA_RS_WPS)."""
+the library (GFA_RS_LFSR_REP4, GFA_RS_LFSR_KSHIFT, GFA_RS_WPS)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -34,5 +34,5 @@ L.check(lib.gfa_time_rs_decode(rs._handle, Cd.data_ptr(), 255, Dd.data_ptr(), Ed
 assert np.array_equal(Dd.cpu().numpy(), C)
 tc = ms.value
 gb = B * 255 / 1e9
-print(f"copies_log={os.environ.get('GFA_RS_LFSR_COPIES_LOG', 'auto')} threads={os.environ.get('GFA_RS_LFSR_THREADS', 'auto')}: "
+print(f"rep4={os.environ.get('GFA_RS_LFSR_REP4', 'auto')} wps={os.environ.get('GFA_RS_WPS', 'auto')}: "
       f"encode {te:.4f} ms = {gb / te * 1e3:.0f} GB/s   decode e~U{{0..16}} {td:.4f} ms = {gb / td * 1e3:.0f} GB/s   clean {tc:.4f} ms = {gb / tc * 1e3:.0f} GB/s")
