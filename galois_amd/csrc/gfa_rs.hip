@@ -473,6 +473,9 @@ __global__ __launch_bounds__(1024) void rs_decode_kernel(RsTables t, RsParams rp
 //   ENCODE:  state <- m(x) * x^(n-k) mod g(x)   = the systematic parity symbols   (_LinearCode._encode_message)
 //   !ENCODE: state <- r(x) mod g(x)             = 0 iff all syndromes vanish      (_detect_errors; decoder pre-pass)
 // Identical values to the reference's matrix products: parity = message @ P is by construction -(m x^(n-k) mod g).
+// Measured and not kept (r03): a look-ahead for the feedback byte (next top byte = role-1 plane's top byte ^ one byte of this
+// symbol's row, from a 256-byte table, so that the 16-byte row reads leave the symbol-to-symbol chain): encode 0.0389 -> 0.0421 ms.
+// The kernel is bound by the LDS queue (two ds_read_b128 per lane and symbol), not by the latency of one read; a third read costs.
 // REP4 (NKW = 4 or 8, one 512-thread workgroup per CU): every 16-byte table chunk is stored FOUR times, 32 bytes apart, rows 2m
 // and 2m + 1 interleaved in one 128-byte block, and lane l reads copy (l >> kshift) & 3 -- the lanes the LDS serves in one cycle
 // then touch disjoint bank groups wherever their feedback bytes allow it (the kernel is bound by the LDS queue: two ds_read_b128
