@@ -4,10 +4,23 @@
 # then copy gpurun_out/<round>_*.txt / .json / .csv into profiles/.
 set -u
 R=${1:-r03}
+ONLY=${2:-all} # "codes": only the files the Reed-Solomon / BCH and Goldilocks kernels feed (about 2 GPU-minutes)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd "$ROOT"
+if [ "$ONLY" = codes ]; then
+    python bench.py > "$OUT/${R}_bench_final.json" 2> "$OUT/${R}_bench_final.err"
+    { echo "# lazy 96-bit registers (default)"; python tools/goldi_time.py 2>/dev/null | grep "2^"; echo "# GFA_NTT_GL=0: plain 64-bit modular arithmetic"; GFA_NTT_GL=0 python tools/goldi_time.py 2>/dev/null | grep "2^"; } > "$OUT/${R}_ntt_goldilocks.txt"
+    python tools/rs_time.py 2>/dev/null | tail -1 > "$OUT/${R}_rs_time.txt"
+    python tools/ntt_large.py 20 21 22 24 26 28 > "$OUT/${R}_ntt_large.txt" 2>/dev/null
+    ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_$R && rocprofv3 --kernel-trace --stats -d /tmp/prof_$R -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --no-pmc > /dev/null 2>&1
+      DB=$(find /tmp/prof_$R -name "*.db" | head -1); [ -n "$DB" ] && python "$ROOT/tools/export_rocprof_stats.py" "$DB" "$OUT/${R}_bench_kernel_stats.csv" )
+    bash tools/pmc_run.sh ${R}_pmc_ntt_goldilocks ntt_reg_kernel_gl -- python tools/goldi_time.py > /dev/null 2>&1
+    bash tools/pmc_run.sh ${R}_pmc_rs_decode rs_ -- python tools/rs_decode_only.py 5 > /dev/null 2>&1
+    ls -la "$OUT" | tail -12
+    exit 0
+fi
 python bench.py > "$OUT/${R}_bench_final.json" 2> "$OUT/${R}_bench_final.err"
 python bench.py --steps 50 --warmup 5 --dist-extras --no-cpu-baseline --no-pmc > "$OUT/${R}_bench_dist_world1.json" 2>/dev/null
 python tools/ew_bench.py 2>/dev/null | grep field > "$OUT/${R}_ew_bench.txt"
