@@ -716,12 +716,12 @@ __global__ __launch_bounds__(REP4 ? 512 : 256) void rs_lfsr_kernel(const u32 *__
 // ------------------------------------------------------------------------------------------------
 // rs_lfsr_kernel has already reduced every received word modulo g(x) and copied the received rows to the output.  Words
 // with a zero remainder and no erasures need nothing more.  The rest are decoded ONE CODEWORD PER WAVEFRONT with the same
-// mathematics and failure exits as rs_decode_kernel / bch_decode_jit; the kernel is VALU-issue bound (PMC: LDS busy 27 %),
-// so every stage is arranged for the fewest vector instructions:
-//   * syndromes S_j = rem(root_j), Chien search Lambda_total(alpha^-i) (four positions per lane) and Forney's numerator /
-//     denominator are Horner recurrences through the 64 KiB LDS product table: per term one v_lshl_or (index), one byte
-//     gather, one v_xor with the broadcast coefficient;
-//   * Berlekamp-Massey in the inversionless RiBM arrangement: no discrepancy reduction, 7 VALU + 2 gathers per step;
+// mathematics and failure exits as rs_decode_kernel / bch_decode_jit.  r02's version was vector-issue bound (PMC: 89 M vector
+// instructions per 2^17 words); this one halves them and keeps the LDS gathers off each other's banks:
+//   * syndromes S_j = rem(root_j), Chien search Lambda_total(x) (four points per lane) and Forney's numerator / denominator are
+//     Horner recurrences through the 64 KiB LDS product table: per term one byte gather and ONE vector instruction (horner_step);
+//   * Berlekamp-Massey in the inversionless RiBM arrangement, in a frame that moves one lane per step (bm_run, written in
+//     assembly: 4 vector instructions + 2 gathers per step, early stop on an all-zero tail);
 //   * corrected symbols are patched into the output row in place (erased symbols become E, others r ^ E).
 // Per-wave LDS scratch with a compile-time layout: every array is `base + constant`, so the addresses ride in the
 // immediate offset field of the LDS instructions instead of ten live VGPRs (the kernel is register-bound).
