@@ -248,7 +248,10 @@ __global__ __launch_bounds__(THREADS) void mid_powv_kernel(MidDesc d, const u16 
 // registers; the workgroup then re-stages LDS with EXP[0 .. q-1) and every lane looks its indices up and stores.  The array
 // is read once and written once; the 2 x 2q bytes of table re-staging per tile come out of L2.
 // ------------------------------------------------------------------------------------------------
-constexpr int B16_THREADS = 512;
+#ifndef GFA_B16_THREADS
+#define GFA_B16_THREADS 512
+#endif
+constexpr int B16_THREADS = GFA_B16_THREADS;
 
 template <int OP>
 __device__ __forceinline__ u32 big16_index(const u16 *lg, const MidDesc &d, const MidPow &pw, u32 a, u32 b, bool &bad)
@@ -571,7 +574,7 @@ int big16_launch(const MidDesc &d, const void *a, i64 sa, const void *b, i64 sb,
     const int cus = mid_num_cus();
     // JB vectors per lane (tiles of 4096 * JB elements) when that
     // still gives every CU two tiles, else two vectors per lane
-    constexpr int JB = (OP == GFA_OP_MUL || OP == GFA_OP_DIV) ? 4 : 8; // two operand streams: half the vectors per lane (registers)
+    constexpr int JB = ((OP == GFA_OP_MUL || OP == GFA_OP_DIV) ? 4 : 8) * 512 / B16_THREADS; // two operand streams: half the vectors per lane (registers)
     const bool big = (nvec + (i64)B16_THREADS * JB - 1) / ((i64)B16_THREADS * JB) >= 2 * (i64)cus;
     static bool attr[2] = {false, false};
     if (big) {

@@ -25,6 +25,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--ext":  # GF(p^m) pinned to explicit c
     cases = [(3**5, np.uint8, "jit-calculate"), (3**7, np.uint16, "jit-calculate"), (3**8, np.uint16, "jit-calculate"), (251**3, np.uint32, "auto"), (7**7, np.uint32, "auto")]
 if len(sys.argv) > 1 and sys.argv[1] == "--mid":
     cases = [c for c in cases if 256 < c[0] <= 2**16]
+if len(sys.argv) > 1 and sys.argv[1] == "--big16":  # 32768 < q <= 65536: one table in LDS at a time
+    cases = [(2**16, np.uint16, "auto"), (3**10, np.uint16, "auto"), (65521, np.uint16, "jit-lookup")]
 if len(sys.argv) > 1 and sys.argv[1] == "--bin":
     cases = [c for c in cases if c[0] in (2**20, 2**24, 2**32)]
 n = 50_000_000
