@@ -78,7 +78,9 @@ def test_reference_generated_cases():
 
 
 @pytest.mark.parametrize("q,n,k,c", [(2**8, 255, 223, 1), (2**8, 255, 239, 0), (2**8, 85, 65, 1), (2**4, 15, 9, 2), (3**4, 80, 60, 1),
-                                     (3**3, 26, 20, 1), (31, 30, 22, 1), (2**8, 255, 127, 1), (5**3, 124, 100, 3)])
+                                     (3**3, 26, 20, 1), (31, 30, 22, 1), (2**8, 255, 127, 1), (5**3, 124, 100, 3),
+                                     (2**8, 255, 215, 0), (2**8, 255, 203, 1), (2**8, 51, 19, 1)])  # d - 1 = 40, 52 (the wave kernel's 64-slot form, the
+                                     # division-form Berlekamp-Massey), and 32 roots over a 51-point subgroup
 def test_random_batches_against_oracle(q, n, k, c):
     if q == 2**8 and n == 255:
         rs = ga.ReedSolomon(n, k, c=c)  # default field: GF(2^8) with the Matlab primitive polynomial
