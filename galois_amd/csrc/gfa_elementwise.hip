@@ -694,6 +694,56 @@ __global__ __launch_bounds__(256) void bin16_holes_mul_kernel(const uint16_t *__
         out[i] = (uint16_t)mul2((u32)a[sa ? i : 0], (u32)b[sb ? i : 0]);
 }
 
+// GF(2^m), 17 <= m <= 32 on uint32 storage: Bin::clmul21 / clmul32 (carry-less product out of 9 / 16 integer multiplies), then the
+// part above x^m is reduced through four 256-entry tables in LDS, one per byte of it (h(x) x^(m+8k) mod f, k = 0..3; each table is
+// the previous one times x^8, so building them costs eight reduction steps per entry) instead of `rounds` folds of one 64-bit
+// shift-and-xor per term of the irreducible polynomial (GF(2^32): 2 x 6 terms).
+__global__ __launch_bounds__(256) void bin32_tab_mul_kernel(const u32 *__restrict__ a, int sa, const u32 *__restrict__ b, int sb,
+                                                            u32 *__restrict__ out, i64 n, int m, u64 irr)
+{
+    __shared__ u32 R[4 * 256];
+    {
+        auto reduce8 = [&](u64 v) { // v < 2^(m+8)
+            for (int bit = m + 7; bit >= m; bit--)
+                if ((v >> bit) & 1u) v ^= irr << (bit - m);
+            return v;
+        };
+        u64 v = reduce8((u64)threadIdx.x << m);
+        R[threadIdx.x] = (u32)v;
+#pragma unroll
+        for (int k = 1; k < 4; k++) {
+            v = reduce8(v << 8);
+            R[k * 256 + threadIdx.x] = (u32)v;
+        }
+    }
+    __syncthreads();
+    const u64 low = m == 32 ? 0xffffffffull : (((u64)1 << m) - 1);
+    const bool small = m <= 21, three = m <= 24; // operands below 2^21: nine products; the part above x^m below 2^24: three tables
+    auto mul1 = [&](u32 x, u32 y) -> u32 {
+        const u64 P = small ? Bin::clmul21(x, y) : Bin::clmul32(x, y);
+        const u32 H = (u32)(P >> m);
+        u32 r = (u32)(P & low) ^ R[H & 0xffu] ^ R[256 + ((H >> 8) & 0xffu)] ^ R[512 + ((H >> 16) & 0xffu)];
+        if (!three) r ^= R[768 + (H >> 24)];
+        return r;
+    };
+    const i64 nvec = n / 4;
+    const u32 a0 = sa ? 0u : a[0], b0 = sb ? 0u : b[0];
+    for (i64 blk = (i64)blockIdx.x * BIN16_VECS; blk * 256 < nvec; blk += (i64)gridDim.x * BIN16_VECS) {
+#pragma unroll 1
+        for (int k = 0; k < BIN16_VECS; k++) {
+            const i64 i = (blk + k) * 256 + threadIdx.x;
+            if (i >= nvec) break;
+            const uint4 av = sa ? reinterpret_cast<const uint4 *>(a)[i] : make_uint4(a0, a0, a0, a0);
+            const uint4 bv = sb ? reinterpret_cast<const uint4 *>(b)[i] : make_uint4(b0, b0, b0, b0);
+            uint4 ov;
+            ov.x = mul1(av.x, bv.x); ov.y = mul1(av.y, bv.y); ov.z = mul1(av.z, bv.z); ov.w = mul1(av.w, bv.w);
+            reinterpret_cast<uint4 *>(out)[i] = ov;
+        }
+    }
+    const i64 tid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    for (i64 i = nvec * 4 + tid; i < n; i += (i64)gridDim.x * blockDim.x) out[i] = mul1(a[sa ? i : 0], b[sb ? i : 0]);
+}
+
 // GF(p^m), 2 <= m <= 8, calculate mode: the kernels are instantiated per degree (ExtM<M>: digit arrays in registers)
 #define GFA_EXT_FIXED_T(FUNC, M, dtype, ...)                                      \
     switch (dtype) {                                                              \
@@ -739,6 +789,17 @@ int dispatch_binary(const FieldDev &fd, int dtype, int op, const void *a, i64 sa
                                (const uint16_t *)b, (int)sb, (uint16_t *)out, n, (int)fd.m, irr_low);
         GFA_HIP(hipGetLastError());
         return GFA_OK;
+    }
+    if (fd.kind == KIND_BIN && op == GFA_OP_MUL && dtype == GFA_U32 && fd.m >= 17 && fd.m <= 32 && aligned16(out) && (sa == 0 || aligned16(a)) &&
+        (sb == 0 || aligned16(b))) {
+        static const int tab = [] { const char *e = getenv("GFA_BIN32_TAB"); return e ? atoi(e) : 1; }();
+        if (tab) {
+            const int hgrid = grid_flat((n + 4 * BIN16_VECS - 1) / (4 * BIN16_VECS), 256);
+            hipLaunchKernelGGL(bin32_tab_mul_kernel, dim3(hgrid), dim3(256), 0, st, (const u32 *)a, (int)sa, (const u32 *)b, (int)sb, (u32 *)out, n,
+                               (int)fd.m, (u64)fd.irr);
+            GFA_HIP(hipGetLastError());
+            return GFA_OK;
+        }
     }
     GFA_EXT_FIXED(launch_binary_ft, fd, dtype, fd, op, a, sa, b, sb, out, n, st, err);
     GFA_DISPATCH_FT(launch_binary_ft, fd, dtype, fd, op, a, sa, b, sb, out, n, st, err);
