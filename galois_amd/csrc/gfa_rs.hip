@@ -20,19 +20,6 @@
 
 using namespace gfa;
 
-#ifndef GFA_RS_BMSTOP
-#define GFA_RS_BMSTOP 0 // measured: 0.226 ms against 0.188 (2^17 words, e ~ U{0..16}) -- the early stop saves the zero steps but the
-                        // branch-free step costs more per non-zero step than it saves; kept for reference
-#endif
-#ifndef GFA_RS_BMASM
-#define GFA_RS_BMASM 1
-#endif
-#ifndef GFA_RS_SPLIT
-#define GFA_RS_SPLIT 1
-#endif
-#ifndef GFA_RS_BYTESEL
-#define GFA_RS_BYTESEL 1
-#endif
 
 namespace {
 
@@ -762,14 +749,6 @@ __device__ __forceinline__ void horner_step_byte(u32 &a, u32 T, u32 w)
     if constexpr (B == 3) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_3" : "+v"(a) : "v"(T), "s"(w));
 }
 template <int B0, int B1>
-__device__ __forceinline__ void horner_bytes(u32 &a, const u32 (&w)[8], u32 tbl_off)
-{ // steps for bytes B0 .. B1 - 1 of the eight words (memory order)
-    if constexpr (B0 < B1) {
-        horner_step_byte<B0 & 3>(a, lds_ld8(a + tbl_off), w[B0 >> 2]);
-        horner_bytes<B0 + 1, B1>(a, w, tbl_off);
-    }
-}
-template <int B0, int B1>
 __device__ __forceinline__ void horner_bytes2(u32 &a1, u32 &a2, const u32 (&w)[8], u32 tbl_off)
 { // two independent chains side by side: a1 takes bytes B0 .. B1 - 1 of the eight words (memory order), a2 bytes 16 + B0 ..
     if constexpr (B0 < B1) {
@@ -944,23 +923,12 @@ __global__ __launch_bounds__(128 * WPS) __attribute__((amdgpu_waves_per_eu(WPS, 
             {
                 u32 a, last;
                 if (nk32) {
-#if GFA_RS_SPLIT
                     // r(x) = H1(x) x^16 + H2(x): two 15-step chains side by side (half the dependent gathers), then one product
                     // by this lane's x^16 (byte 2 of synp) and one xor
                     u32 a1 = (synp & 0xffu) | ((rw[0] & 0xffu) << 8), a2 = (synp & 0xffu) | ((rw[4] & 0xffu) << 8);
                     horner_bytes2<1, 16>(a1, a2, rw, TBL);
                     a = __builtin_amdgcn_perm(a1, synp, 0x0c0c0502u); // byte 1 <- H1, byte 0 <- x^16
                     last = a2 >> 8;
-#else
-                    a = (synp & 0xffu) | ((rw[0] & 0xffu) << 8);
-#if GFA_RS_BYTESEL
-                    horner_bytes<1, 31>(a, rw, TBL);
-#else
-#pragma unroll
-                    for (int b = 1; b < 31; b++) horner_step(a, lds_ld8(a + TBL), rw[b >> 2] >> (8 * (b & 3)));
-#endif
-                    last = rw[7] >> 24;
-#endif
                 } else {
                     a = (synp & 0xffu) | ((u32)__builtin_amdgcn_readlane((int)remc, nk - 1) << 8);
                     for (int tt = nk - 2; tt >= 1; tt--) horner_step(a, lds_ld8(a + TBL), (u32)__builtin_amdgcn_readlane((int)remc, tt));
@@ -1025,7 +993,6 @@ __global__ __launch_bounds__(128 * WPS) __attribute__((amdgpu_waves_per_eu(WPS, 
                     // a register refreshed when gamma changes), v_add (index of d0*Y: row(d0) is scalar), two gathers, v_xor.
                     u32 X = lane == 63 ? 1u : (lane < nsq ? (inreg ? sp : (u32)ws.sprime()[u + lane]) : 0u);
                     u32 Y = X;
-#if GFA_RS_BMASM
                     int moves = 0; // steps taken = lanes the frame has moved
                     {
                         u32 G = 1u << 8;
@@ -1039,77 +1006,6 @@ __global__ __launch_bounds__(128 * WPS) __attribute__((amdgpu_waves_per_eu(WPS, 
                     // Lambda_i is at lane 63 - moves + i: bring it to lane i
                     const u32 moved = (u32)__builtin_amdgcn_ds_bpermute(((lane + 63 - moves) & 63) << 2, (int)X);
                     Creg = (lane < 32 && lane <= moves) ? moved : 0u;
-#elif GFA_RS_BMSTOP
-                    u32 grow = 1u << 8; // row(gamma), relative to the table
-#else
-                    u32 grow = TBL + (1u << 8);
-#endif
-#if GFA_RS_BMASM
-#elif GFA_RS_BMSTOP
-                    // A zero discrepancy needs no branch of its own (the d0 * Y gather returns zeros, X becomes gamma * A; the scale
-                    // of X never matters: Y and gamma take their values from X itself, so all three stay consistent multiples).
-                    // Stop test: when the discrepancy is zero and every discrepancy still to come -- lanes 1 .. nsq - r - 1 of X -- is
-                    // zero too, which is the first zero step of a word with v <= t errors, the rest of the run is shifts alone: stop
-                    // there, the frame has moved r lanes.
-#define GFA_BM_TAIL_ZERO(R) (((u32)__builtin_amdgcn_ballot_w64(X != 0) & (0xffffffffu >> (32 - (nsq - (R))))) == 0)
-#define GFA_BM_STEP(R)                                                                                                          \
-    {                                                                                                                           \
-        const u32 A = (u32)__builtin_amdgcn_update_dpp(0, (int)X, 0x130, 0xf, 0xf, true); /* wave_shl:1: lane i <- lane i + 1 */ \
-        u32 t1 = lds_ld8(A + grow + TBL);                                                                                             \
-        const u32 t2 = lds_ld8(Y + (d0 << 8) + TBL);                                                                          \
-        asm("" : "+v"(t1)); /* keeps the loop value 32 bits wide (narrowed to i8 it costs a v_and per step) */                  \
-        X = t1 ^ t2;                                                                                                            \
-        if (d0 != 0 && 2 * L <= (R)) { Y = A; L = (R) + 1 - L; grow = d0 << 8; }                                        \
-    }
-                    const int rmain = nsq < 31 ? nsq : 31;
-                    int moves = 0; // steps taken = lanes the frame has moved
-                    while (moves < rmain) {
-                        const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)X);
-                        if (d0 == 0 && GFA_BM_TAIL_ZERO(moves)) break;
-                        GFA_BM_STEP(moves)
-                        moves++;
-                    }
-                    if (moves == 31 && nsq == 32) { // (the loop cannot stop at 31: it tests before step 30 at the latest)
-                        const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)X);
-                        if (!(d0 == 0 && GFA_BM_TAIL_ZERO(31))) {
-                            Y = lane < 32 ? 0u : Y;
-                            GFA_BM_STEP(31)
-                            moves = 32;
-                        }
-                    }
-#undef GFA_BM_STEP
-#undef GFA_BM_TAIL_ZERO
-                    // Lambda_i is at lane 63 - moves + i: bring it to lane i
-                    const u32 moved = (u32)__builtin_amdgcn_ds_bpermute(((lane + 63 - moves) & 63) << 2, (int)X);
-                    Creg = (lane < 32 && lane <= moves) ? moved : 0u;
-#else
-                    const u32 tbl = TBL;
-                    auto step = [&](int r) {
-                        const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)X);
-                        const u32 A = (u32)__builtin_amdgcn_update_dpp(0, (int)X, 0x130, 0xf, 0xf, true); // wave_shl:1: lane i <- lane i + 1
-                        // A zero discrepancy (wave-uniform: every step after the 2v-th of a word with v errors) would only
-                        // scale X by gamma.  The scale of X never matters (Y and gamma take their values from X itself, so
-                        // all three stay consistent multiples), so those steps are the shift alone: no table gathers.
-                        if (d0 == 0) {
-                            X = A;
-                        } else {
-                            const u32 t1 = lds_ld8(A + grow);
-                            const u32 t2 = lds_ld8(Y + (tbl + (d0 << 8)));
-                            X = t1 ^ t2;
-                            asm("" : "+v"(X)); // keeps the loop value 32 bits wide (narrowed to i8 it costs a v_and per step)
-                            if (2 * L <= r) { Y = A; L = r + 1 - L; grow = tbl + (d0 << 8); }
-                        }
-                    };
-                    const int rmain = nsq < 31 ? nsq : 31;
-                    for (int r = 0; r < rmain; r++) step(r);
-                    if (nsq == 32) {
-                        Y = lane < 32 ? 0u : Y;
-                        step(31);
-                    }
-                    // Lambda_i is at lane 63 - nsq + i: bring it to lane i
-                    const u32 moved = (u32)__builtin_amdgcn_ds_bpermute(((lane + 63 - nsq) & 63) << 2, (int)X);
-                    Creg = (lane < 32 && lane <= nsq) ? moved : 0u;
-#endif
                 } else {
                     const int Sall = lane < nsq ? (int)ws.sprime()[u + lane] : 0;
                     // Bs holds x^m * B(x) / b, so the update C -= (d/b) x^m B is ONE table gather on the critical path
