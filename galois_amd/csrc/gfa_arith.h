@@ -305,6 +305,31 @@ struct Bin {
         const u64 z2 = ((u64)x0 * y2) ^ ((u64)x1 * y1) ^ ((u64)x2 * y0);
         return (z0 & 0x9249249249249249ull) | (z1 & 0x2492492492492492ull) | (z2 & 0x4924924924924924ull);
     }
+    // 16 x 16 -> 31-bit carry-less products of the LOW halves / of the HIGH halves of two registers, nine integer multiplies each
+    // (three classes of bit positions mod 3, at most six set bits per class: a position of an integer product of two classes
+    // receives at most six partial ones, which fits the three bits up to the next position of its class; the lowest bit of the
+    // sum is the carry-less sum).  The high halves are multiplied in place: (x << 16)(y << 16) = xy << 32, i.e. the high word.
+    static GFA_HD u32 holes16_pick(u32 z0, u32 z1, u32 z2) { return (z0 & 0x49249249u) | (z1 & 0x92492492u) | (z2 & 0x24924924u); }
+    static GFA_HD u32 clmul16_lo(u32 x, u32 y)
+    {
+        const u32 x0 = x & 0x9249u, x1 = x & 0x2492u, x2 = x & 0x4924u, y0 = y & 0x9249u, y1 = y & 0x2492u, y2 = y & 0x4924u;
+        return holes16_pick((x0 * y0) ^ (x1 * y2) ^ (x2 * y1), (x0 * y1) ^ (x1 * y0) ^ (x2 * y2), (x0 * y2) ^ (x1 * y1) ^ (x2 * y0));
+    }
+    static GFA_HD u32 mulhi32(u32 a, u32 b) { return (u32)(((u64)a * b) >> 32); }
+    static GFA_HD u32 clmul16_hi(u32 x, u32 y)
+    {
+        const u32 x0 = x & 0x92490000u, x1 = x & 0x24920000u, x2 = x & 0x49240000u;
+        const u32 y0 = y & 0x92490000u, y1 = y & 0x24920000u, y2 = y & 0x49240000u;
+        return holes16_pick(mulhi32(x0, y0) ^ mulhi32(x1, y2) ^ mulhi32(x2, y1), mulhi32(x0, y1) ^ mulhi32(x1, y0) ^ mulhi32(x2, y2),
+                            mulhi32(x0, y2) ^ mulhi32(x1, y1) ^ mulhi32(x2, y0));
+    }
+    // v(x) mod f for v below 2^(m + extra): the entries of the byte-indexed reduction tables (h(x) x^(m + 8k) mod f)
+    static GFA_HD u64 reduce_bits(u64 v, int m, int extra, u64 irr)
+    {
+        for (int bit = m + extra - 1; bit >= m; bit--)
+            if ((v >> bit) & 1u) v ^= irr << (bit - m);
+        return v;
+    }
     // rounds of "fold the part above x^m back through g = f - x^m" that clear a (2m-1)-bit product, 0 when that costs more than
     // the bit-serial product (g with many terms or of high degree).  Stored in FieldDev::mu of a binary field (gfa_field.hip).
     static GFA_HD u32 fold_rounds(u64 irr, u32 m)

@@ -649,30 +649,13 @@ __global__ __launch_bounds__(256) void bin16_holes_mul_kernel(const uint16_t *__
                                                               uint16_t *__restrict__ out, i64 n, int m, u32 irr)
 {
     __shared__ uint16_t R[512];
-    {
-        auto reduce = [&](u32 v) {
-            for (int bit = 31; bit >= m; bit--)
-                if ((v >> bit) & 1u) v ^= irr << (bit - m);
-            return (uint16_t)v;
-        };
-        R[threadIdx.x] = reduce((u32)threadIdx.x << m);
-        R[256 + threadIdx.x] = reduce((u32)threadIdx.x << (m + 8));
-    }
+    R[threadIdx.x] = (uint16_t)Bin::reduce_bits((u64)threadIdx.x << m, m, 8, irr);
+    R[256 + threadIdx.x] = (uint16_t)Bin::reduce_bits((u64)threadIdx.x << (m + 8), m, 16, irr);
     __syncthreads();
     const u32 low = (1u << m) - 1u;
-    constexpr u32 C0 = 0x9249u, C1 = 0x2492u, C2 = 0x4924u;             // bit positions = 0, 1, 2 mod 3 of a 16-bit element
-    constexpr u32 M0 = 0x49249249u, M1 = 0x92492492u, M2 = 0x24924924u; // the same classes of the 31-bit product
-    auto finish = [&](u32 z0, u32 z1, u32 z2) -> u32 {
-        const u32 P = (z0 & M0) | (z1 & M1) | (z2 & M2);
-        return (P & low) ^ (u32)R[(P >> m) & 0xffu] ^ (u32)R[256 + (P >> (m + 8))];
-    };
-    auto mul2 = [&](u32 x, u32 y) -> u32 { // two elements per register
-        const u32 xl0 = x & C0, xl1 = x & C1, xl2 = x & C2, yl0 = y & C0, yl1 = y & C1, yl2 = y & C2;
-        const u32 xh0 = x & (C0 << 16), xh1 = x & (C1 << 16), xh2 = x & (C2 << 16), yh0 = y & (C0 << 16), yh1 = y & (C1 << 16), yh2 = y & (C2 << 16);
-        const u32 lo = finish((xl0 * yl0) ^ (xl1 * yl2) ^ (xl2 * yl1), (xl0 * yl1) ^ (xl1 * yl0) ^ (xl2 * yl2), (xl0 * yl2) ^ (xl1 * yl1) ^ (xl2 * yl0));
-        const u32 hi = finish(__umulhi(xh0, yh0) ^ __umulhi(xh1, yh2) ^ __umulhi(xh2, yh1), __umulhi(xh0, yh1) ^ __umulhi(xh1, yh0) ^ __umulhi(xh2, yh2),
-                              __umulhi(xh0, yh2) ^ __umulhi(xh1, yh1) ^ __umulhi(xh2, yh0));
-        return lo | (hi << 16);
+    auto finish = [&](u32 P) -> u32 { return (P & low) ^ (u32)R[(P >> m) & 0xffu] ^ (u32)R[256 + (P >> (m + 8))]; };
+    auto mul2 = [&](u32 x, u32 y) -> u32 { // two elements per register (Bin::clmul16_lo / _hi, gfa_arith.h)
+        return finish(Bin::clmul16_lo(x, y)) | (finish(Bin::clmul16_hi(x, y)) << 16);
     };
     // a workgroup takes BIN16_VECS consecutive blocks of 256 vectors (the table set-up is a quarter of one block's work)
     const i64 nvec = n / 8;
@@ -703,16 +686,11 @@ __global__ __launch_bounds__(256) void bin32_tab_mul_kernel(const u32 *__restric
 {
     __shared__ u32 R[4 * 256];
     {
-        auto reduce8 = [&](u64 v) { // v < 2^(m+8)
-            for (int bit = m + 7; bit >= m; bit--)
-                if ((v >> bit) & 1u) v ^= irr << (bit - m);
-            return v;
-        };
-        u64 v = reduce8((u64)threadIdx.x << m);
+        u64 v = Bin::reduce_bits((u64)threadIdx.x << m, m, 8, irr);
         R[threadIdx.x] = (u32)v;
 #pragma unroll
         for (int k = 1; k < 4; k++) {
-            v = reduce8(v << 8);
+            v = Bin::reduce_bits(v << 8, m, 8, irr);
             R[k * 256 + threadIdx.x] = (u32)v;
         }
     }
