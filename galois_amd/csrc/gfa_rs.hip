@@ -17,6 +17,7 @@
 #include <algorithm>
 
 #include "gfa_internal.h"
+#include "gfa_rs_host.h"
 
 using namespace gfa;
 
@@ -1405,65 +1406,12 @@ int gfa_rs::ensure_device(int *device_out, Dev **out)
             GFA_HIP(hipMemcpy(st.g8, g8.data(), g8.size(), hipMemcpyHostToDevice));
         }
         if (field->has_tab8 && field->calc.p == 2 && nk >= 4 && nk <= 64 && nk % 4 == 0) {
-            // LFSR rows: word d of row f packs f * gpoly[1 + 4d .. 4d + 3] (coefficients of x^(nk-1-4d) ..), first in the top byte
-            // chunked layout (see rs_lfsr_kernel): full 4-word chunks first, chunk c of row f at c*1024 + f*4; the
-            // remaining nkw % 4 words of row f at (nkw/4)*1024 + f*(nkw % 4)
-            const size_t nkw = nk / 4, full = nkw / 4, tail = nkw % 4;
-            std::vector<uint32_t> rows(256 * nkw);
-            for (uint32_t fb = 0; fb < 256; fb++)
-                for (size_t d = 0; d < nkw; d++) {
-                    uint32_t w = 0;
-                    for (int b = 0; b < 4; b++) {
-                        // consecutive order: byte b of word d multiplies state byte 4d + b.  Planar order (nkw % 4 == 0, see
-                        // rs_lfsr_kernel): word d = plane d / W, word d % W of the plane; its byte b is state byte p + 4 (4h + b)
-                        const size_t Wp = nkw / 4;
-                        const size_t si = nkw % 4 == 0 ? (d / Wp) + 4 * (4 * (d % Wp) + b) : 4 * d + b;
-                        const uint64_t gc = gpoly[1 + si];
-                        w = (w << 8) | (fb < field->calc.q && gc < field->calc.q ? field->h_mul8[(fb << 8) | gc] : 0);
-                    }
-                    const size_t c4 = d / 4;
-                    const size_t idx = c4 < full ? c4 * 1024 + fb * 4 + (d % 4) : full * 1024 + fb * tail + (d - full * 4);
-                    rows[idx] = w;
-                }
+            // tables built by gfa_rs_host.h (checked on the host by tests/csrc/rs_host_test.cpp): the LFSR rows in the order
+            // rs_lfsr_kernel reads them, and the lane tables of rs_decode_bin_kernel
+            const std::vector<uint32_t> rows = rs_lfsr_rows(field->h_mul8.data(), field->calc.q, gpoly, nk);
             GFA_HIP(hipMalloc((void **)&st.lfsr, rows.size() * sizeof(uint32_t)));
             GFA_HIP(hipMemcpy(st.lfsr, rows.data(), rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-            // rs_decode_bin_kernel's lane tables.  [128 + x]: the position i < n with alpha^-i = x (255: none).  [lane]: the
-            // syndrome root that lane evaluates, [64 + j]: the lane that evaluates root j.  The LDS bank of a Horner gather is
-            // bits 2..6 of the root, so the roots are dealt out one per bank and half-wave as far as they allow; idle lanes
-            // repeat a root of their own half-wave (same address as its owner: a broadcast, no conflict).
-            std::vector<uint8_t> aux(384, 0);
-            const uint8_t *mul8 = field->h_mul8.data();
-            std::fill(aux.begin() + 128, aux.end(), (uint8_t)255);
-            {
-                uint32_t ainv = 1;
-                for (uint32_t y = 1; y < field->calc.q; y++)
-                    if (mul8[((uint32_t)alpha << 8) | y] == 1) { ainv = y; break; }
-                uint32_t x = 1;
-                for (int64_t i = 0; i < n && i < 255; i++) {
-                    if (aux[128 + x] == 255) aux[128 + x] = (uint8_t)i;
-                    x = mul8[(x << 8) | ainv];
-                }
-            }
-            if (roots.size() <= 64) {
-                bool used[2][32] = {};
-                int filled[2] = {0, 0};
-                int lane_of[64];
-                std::vector<int> later;
-                for (size_t j = 0; j < roots.size(); j++) {
-                    const int bank = (int)((roots[j] >> 2) & 31);
-                    const int h = !used[0][bank] && filled[0] < 32 ? 0 : (!used[1][bank] && filled[1] < 32 ? 1 : -1);
-                    if (h < 0) { later.push_back((int)j); continue; }
-                    used[h][bank] = true;
-                    lane_of[j] = 32 * h + filled[h]++;
-                }
-                for (int j : later) { // a third root on one bank: any free lane
-                    const int h = filled[0] <= filled[1] && filled[0] < 32 ? 0 : 1;
-                    lane_of[j] = 32 * h + filled[h]++;
-                }
-                for (size_t j = 0; j < roots.size(); j++) { aux[lane_of[j]] = (uint8_t)roots[j]; aux[64 + j] = (uint8_t)lane_of[j]; }
-                for (int h = 0; h < 2; h++)
-                    for (int l = filled[h]; l < 32; l++) aux[32 * h + l] = filled[h] ? aux[32 * h] : (uint8_t)0;
-            }
+            const std::vector<uint8_t> aux = rs_decode_lane_tables(field->h_mul8.data(), field->calc.q, alpha, n, roots);
             GFA_HIP(hipMalloc((void **)&st.aux8, aux.size()));
             GFA_HIP(hipMemcpy(st.aux8, aux.data(), aux.size(), hipMemcpyHostToDevice));
         }

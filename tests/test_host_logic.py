@@ -327,11 +327,26 @@ def test_lazy_goldilocks_arithmetic_header_on_the_host(tmp_path, repo_root):
 
 def test_field_arithmetic_header_on_the_host(tmp_path, repo_root):
     """galois_amd/csrc/gfa_arith.h on the host: the Goldilocks inversion chain (64 squarings + 9 products for p - 2) against binary
-    square-and-multiply and a * a^-1 = 1, the 32-bit Montgomery power against the Barrett power (tests/csrc/arith_host_test.cpp)."""
+    square-and-multiply and a * a^-1 = 1, the 32-bit Montgomery power against the Barrett power, the carry-less products of the binary-field
+    kernels (16 / 9 integer multiplies + folds, nine multiplies on 16-bit halves + byte-indexed reduction tables) against shift-and-xor
+    (tests/csrc/arith_host_test.cpp)."""
     import subprocess
 
     exe = str(tmp_path / "arith_test")
     subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(repo_root, "galois_amd", "csrc"),
                     os.path.join(repo_root, "tests", "csrc", "arith_host_test.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "fails 0" in r.stdout, r.stdout + r.stderr
+
+
+def test_reed_solomon_table_builders_on_the_host(tmp_path, repo_root):
+    """galois_amd/csrc/gfa_rs_host.h on the host: the LFSR row table in consecutive and in planar order, run through a host model
+    of rs_lfsr_kernel's state handling and compared with schoolbook division for n - k = 4 .. 64; the decoder's lane tables
+    (positions by field element, root <-> lane bijection, one root per LDS bank and half-wave) -- tests/csrc/rs_host_test.cpp."""
+    import subprocess
+
+    exe = str(tmp_path / "rs_test")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(repo_root, "galois_amd", "csrc"),
+                    os.path.join(repo_root, "tests", "csrc", "rs_host_test.cpp"), "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "fails 0" in r.stdout, r.stdout + r.stderr
