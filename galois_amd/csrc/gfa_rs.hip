@@ -837,7 +837,7 @@ __global__ __launch_bounds__(128 * WPS) __attribute__((amdgpu_waves_per_eu(WPS, 
     uint8_t *free_l = stage_tables<true>(lds_raw + 16, t, ar, rp.qm1, blockDim.x); // bytes 0..15: the claim counter (ds_append wants a 16-bit address)
     const int dd = rp.nroots, qm1 = rp.qm1, la = rp.log_alpha;
     const int nk = rp.n - rp.k; // length of the remainder r(x) mod g(x); equals dd for Reed-Solomon, larger for BCH
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     WaveScratch2<S> ws;
     ws.base = free_l + (size_t)wave * WaveScratch2<S>::BYTES;
     __syncthreads();
