@@ -588,7 +588,6 @@ __global__ __launch_bounds__(REP4 ? 512 : 256) void rs_lfsr_kernel(const u32 *__
                         const u32 w[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
-                            constexpr int dummy = 0; (void)dummy;
                             const int q = 4 * c4 + j;                  // planar word: role q / W, word q % W
                             P[(q / W + K + 1) & 3][q % W] ^= w[j];
                         }
