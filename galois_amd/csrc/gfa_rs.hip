@@ -927,6 +927,10 @@ __global__ __launch_bounds__(128 * WPS) __attribute__((amdgpu_waves_per_eu(WPS, 
                     // by this lane's x^16 (byte 2 of synp) and one xor
                     u32 a1 = (synp & 0xffu) | ((rw[0] & 0xffu) << 8), a2 = (synp & 0xffu) | ((rw[4] & 0xffu) << 8);
                     horner_bytes2<1, 16>(a1, a2, rw, TBL);
+                    // gfx940-class parts want one wait state between an SDWA write with a byte destination and a VECTOR instruction that
+                    // reads the register (the compiler inserts it for its own SDWA code, not behind inline assembly); the LDS reads
+                    // that follow every other horner_step are not affected
+                    asm("s_nop 0" : "+v"(a1), "+v"(a2));
                     a = __builtin_amdgcn_perm(a1, synp, 0x0c0c0502u); // byte 1 <- H1, byte 0 <- x^16
                     last = a2 >> 8;
                 } else {
