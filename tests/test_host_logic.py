@@ -350,3 +350,15 @@ def test_reed_solomon_table_builders_on_the_host(tmp_path, repo_root):
                     os.path.join(repo_root, "tests", "csrc", "rs_host_test.cpp"), "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0 and "fails 0" in r.stdout, r.stdout + r.stderr
+
+
+def test_berlekamp_massey_arrangement_of_the_wave_kernel_on_the_host(tmp_path, repo_root):
+    """tests/csrc/bm_host_test.cpp: a lane-by-lane host model of rs_decode_bin_kernel's Berlekamp-Massey loop (inversionless recurrence
+    in a frame that moves one lane per step, early stop, the cleared half before the 32nd step) against Massey's algorithm with
+    divisions on 400 000 syndrome sequences of every length 1..32 -- same LFSR length, same polynomial up to its leading scale."""
+    import subprocess
+
+    exe = str(tmp_path / "bm_test")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(repo_root, "tests", "csrc", "bm_host_test.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "fails 0" in r.stdout, r.stdout + r.stderr
