@@ -1149,16 +1149,28 @@ class FieldArray(metaclass=FieldArrayMeta):
             if func is np.delete:
                 keep = np.delete(np.arange(n), kw("obj", 1, None))
                 return wrap(torch.index_select(t, axis, torch.as_tensor(keep, device=t.device)))
-            # insert: where the new slots go is NumPy's own index arithmetic on a marker array; the elements stay on the device
-            marker = np.insert(np.arange(n, dtype=np.int64), kw("obj", 1, None), -1)
-            slots = np.flatnonzero(marker < 0)
+            # insert: where the new slots go -- and WHICH value lands in each -- is NumPy's own index arithmetic on a marker array
+            # of distinct negative ids (it pairs values[i] with obj[i] also when obj is unsorted, and a scalar obj takes every
+            # value, numpy/lib/_function_base_impl.py insert); the elements stay on the device
+            obj = kw("obj", 1, None)
             (vals, t), _ = self._af_seq([tens(kw("values", 2, None)), t])
             tm = torch.movedim(t, axis, 0)
-            vm = torch.movedim(vals, axis, 0) if vals.dim() == t.dim() else vals
-            vm = vm.expand((len(slots),) + tuple(tm.shape[1:])) if vm.dim() < tm.dim() or vm.shape[0] != len(slots) else vm
+            while vals.dim() < t.dim():
+                vals = vals.unsqueeze(0)  # ndmin = arr.ndim
+            if np.ndim(obj) == 0 and not isinstance(obj, slice):
+                vm = vals  # NumPy moves the FIRST axis of the values to `axis`: it is the one that counts the new elements
+            else:
+                vm = torch.movedim(vals, axis, 0)
+                count = len(np.insert(np.arange(n, dtype=np.int64), obj, 0)) - n
+                if vm.shape[0] != count:
+                    vm = vm.expand((count,) + tuple(vm.shape[1:]))
+            ids = -(1 + np.arange(vm.shape[0], dtype=np.int64))
+            marker = np.insert(np.arange(n, dtype=np.int64), obj, ids)
+            slots = np.flatnonzero(marker < 0)
+            vm = vm.expand((vm.shape[0],) + tuple(tm.shape[1:]))
             out = torch.empty((len(marker),) + tuple(tm.shape[1:]), dtype=tm.dtype, device=tm.device)
             out[torch.as_tensor(np.flatnonzero(marker >= 0), device=t.device)] = tm
-            out[torch.as_tensor(slots, device=t.device)] = vm.to(tm.dtype)
+            out[torch.as_tensor(slots, device=t.device)] = vm.to(tm.dtype)[torch.as_tensor(-marker[slots] - 1, device=t.device)]
             return wrap(torch.movedim(out, 0, axis))
         if func is np.where and len(args) == 3:
             ts, _ = seq(args[1:])

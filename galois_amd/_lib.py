@@ -36,6 +36,7 @@ SIGNATURES = {
     "gfa_abi_version": (c_int, []),
     "gfa_last_error": (ctypes.c_char_p, []),
     "gfa_device_count": (c_int, []),
+    "gfa_trim_scratch": (c_int, [c_u64]),
     "gfa_field_create": (c_int, [c_u64, c_u32, _u64p, c_u64, ctypes.POINTER(c_void_p)]),
     "gfa_field_destroy": (None, [c_void_p]),
     "gfa_field_set_mode": (c_int, [c_void_p, c_int]),

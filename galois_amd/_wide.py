@@ -337,7 +337,15 @@ class WideFieldArray(FieldArray):
         c2 = c2.contiguous()
         n_outer, n_inner = c2.shape
         if n_inner == 0:
-            raise ValueError("zero-size array to reduction operation which has no identity on this device path")
+            # NumPy (and the reference's object-dtype loops): add / multiply have identities, subtract / divide do not
+            if accumulate:
+                return torch.empty((n_outer, 0), dtype=torch.complex128, device=c.device), lead, axis
+            if op not in (L.OP_ADD, L.OP_MUL):
+                raise ValueError("zero-size array to reduction operation which has no identity")
+            limbs = torch.zeros((n_outer, 2), dtype=torch.int64, device=c.device)
+            if op == L.OP_MUL:
+                limbs[:, 0] = 1
+            return torch.view_as_complex(limbs.view(torch.float64)), lead, axis
         out = torch.empty((n_outer, n_inner) if accumulate else (n_outer,), dtype=torch.complex128, device=c.device)
         err = torch.zeros(1, dtype=torch.int32, device=c.device) if op == L.OP_DIV else None
         L.check(L.lib().gfa_wide_reduce(cls._wide_handle, op, _ptr(c2), _ptr(out), n_outer, n_inner, 1 if accumulate else 0, _stream(),

@@ -2,6 +2,7 @@
 // Replaces the arithmetic set-up done by the reference's class factory (src/galois/_fields/_factory.py:364-532)
 // and UFuncMixin._build_lookup_tables (src/galois/_domains/_lookup.py:319-371).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "gfa_internal.h"
@@ -42,7 +43,11 @@ hipError_t scratch_alloc(void **p, size_t bytes, hipStream_t st)
             props.location.id = dev;
             hipMemPool_t np = nullptr;
             if (hipMemPoolCreate(&np, &props) == hipSuccess) {
-                uint64_t keep = UINT64_MAX;
+                // Freed blocks up to this many bytes stay in the pool across synchronisations (the point of the private pool: no
+                // driver round trip per Reed-Solomon decode); anything above goes back at the next synchronisation, so one huge
+                // call cannot pin memory that the host framework's own allocator then fails to get.  GFA_SCRATCH_KEEP_MB overrides.
+                const char *env = getenv("GFA_SCRATCH_KEEP_MB");
+                uint64_t keep = (uint64_t)(env ? strtoull(env, nullptr, 10) : 256ull) << 20;
                 (void)hipMemPoolSetAttribute(np, hipMemPoolAttrReleaseThreshold, &keep);
                 g_pools[dev] = np;
             } else {
@@ -56,6 +61,22 @@ hipError_t scratch_alloc(void **p, size_t bytes, hipStream_t st)
 }
 
 hipError_t scratch_free(void *p, hipStream_t st) { return hipFreeAsync(p, st); }
+
+// returns the pool's unused blocks beyond `keep_bytes` to the driver (current device); GFA_OK when no pool exists yet
+int scratch_trim(size_t keep_bytes)
+{
+    int dev = 0;
+    GFA_HIP(hipGetDevice(&dev));
+    hipMemPool_t pool = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        if (dev < (int)g_pools.size()) pool = g_pools[dev];
+    }
+    if (!pool) return GFA_OK;
+    GFA_HIP(hipDeviceSynchronize()); // blocks freed on streams still running are not trimmable
+    GFA_HIP(hipMemPoolTrimTo(pool, keep_bytes));
+    return GFA_OK;
+}
 
 int time_loop(hipStream_t st, int iters, float *ms_out, const std::function<int()> &launch)
 { // three warm-up calls (table upload, attribute set-up, work-buffer pools), then three groups of `iters` back-to-back calls
@@ -247,6 +268,8 @@ int gfa_device_count(void)
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+
+int gfa_trim_scratch(uint64_t keep_bytes) { return scratch_trim((size_t)keep_bytes); }
 
 int gfa_field_create(uint64_t p, uint32_t m, const uint64_t *irr, uint64_t alpha, gfa_field_t **out)
 {

@@ -27,10 +27,12 @@ int time_loop(hipStream_t st, int iters, float *ms_out, const std::function<int(
     } while (0)
 
 // Stream-ordered work buffers of one call (hipMallocFromPoolAsync / hipFreeAsync) from a pool the library owns, one per
-// device, whose release threshold is unbounded: a freed block stays in the pool across synchronisations instead of going
-// back to the driver (the device's default pool releases at every synchronisation -- 0.05 ms per Reed-Solomon decode).
+// device, with a release threshold of 256 MiB (GFA_SCRATCH_KEEP_MB): freed blocks up to that total stay in the pool across
+// synchronisations instead of going back to the driver (the device's default pool releases at every synchronisation --
+// 0.05 ms per Reed-Solomon decode); gfa_trim_scratch() returns the rest on demand.
 hipError_t scratch_alloc(void **p, size_t bytes, hipStream_t st);
 hipError_t scratch_free(void *p, hipStream_t st);
+int scratch_trim(size_t keep_bytes); // synchronises the device, returns unused pool memory beyond keep_bytes to the driver
 
 void ntt_forget_field(const struct ::gfa_field *f); // drops cached NTT plans of a field being destroyed
 

@@ -74,6 +74,13 @@ typedef enum { GFA_MODE_AUTO = 0, GFA_MODE_LOOKUP = 1, GFA_MODE_CALCULATE = 2 } 
 int gfa_abi_version(void);
 const char *gfa_last_error(void); /* thread-local description of the last non-OK status */
 int gfa_device_count(void);       /* number of visible HIP devices (0 if none / no driver) */
+/* Work buffers of the data-path calls (Reed-Solomon remainders, NTT intermediates, panel copies ...) come from a
+ * library-owned stream-ordered pool per device, so that the reference's per-call scratch arrays (e.g. the int64 copies of
+ * _codes/_bch.py:1281-1299, _domains/_function.py:201-202) cost no driver round trip.  The pool keeps at most
+ * GFA_SCRATCH_KEEP_MB (default 256) MiB of freed blocks across synchronisations; this call synchronises the current
+ * device and returns everything unused beyond keep_bytes to the driver (call it when the host framework's allocator
+ * runs out of memory, e.g. next to torch.cuda.empty_cache()). */
+int gfa_trim_scratch(uint64_t keep_bytes);
 
 /* ---- fields: replaces the class factory's arithmetic set-up --------------------------------------- *
  * galois.GF(...) -> _GF_prime/_GF_extension (_fields/_factory.py:364-532) and

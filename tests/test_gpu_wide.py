@@ -207,6 +207,13 @@ def test_reductions_of_the_big_fields_against_the_oracle(tag):
     assert int(np.sum(x)) == left_fold(W.add, h.ravel())[-1] and int(np.prod(x[0, :50])) == left_fold(W.mul, h[0, :50])[-1]
     H.assert_equal_ints(np.cumsum(x[1, :30]).numpy(), np.array(left_fold(W.add, h[1, :30]), dtype=object))
     assert int(np.add.reduce(x[0, :1])) == int(h[0, 0])
+    # empty reduction axis: identities for add / multiply, ValueError for subtract / divide (NumPy's rule, the reference's too)
+    e = x[:, :0]
+    H.assert_equal_ints(np.add.reduce(e, axis=1).numpy(), np.array([0, 0, 0], dtype=object))
+    H.assert_equal_ints(np.multiply.reduce(e, axis=1).numpy(), np.array([1, 1, 1], dtype=object))
+    assert int(np.sum(x[0, :0])) == 0 and int(np.prod(x[0, :0])) == 1 and np.add.accumulate(e, axis=1).shape == (3, 0)
+    with pytest.raises(ValueError):
+        np.subtract.reduce(e, axis=1)
     z = GF(np.array([3, 0, 5], dtype=object))
     with pytest.raises(ZeroDivisionError):
         np.true_divide.reduce(z)

@@ -1,0 +1,602 @@
+// Round-4 experiments on the GF(65537) 2^16-point kernel that LOST (kept for the record; results: profiles/r04_fermat_experiments.txt).
+// A drop-in replacement of galois_amd/csrc/gfa_ntt_fermat.hip at commit f428319: copy it there and rebuild to reproduce.
+//   GFA_NTT_FERMAT_PAIR=1   512-thread workgroups x 128 points per thread (meant as two workgroups per CU)
+//   GFA_NTT_FERMAT_SKEL=1|2 the same kernel without HBM traffic / without arithmetic
+//   GFA_NTT_FERMAT_SCHED=1  the 1024-thread kernel with the next transform's loads requested during exchange 2 (EARLY_A/B/C macros)
+// gfa_ntt_fermat.hip -- 2^16-point transforms over the Fermat prime field GF(65537) in ONE pass over HBM.
+//
+// Replaces fft_jit / ifft_jit (reference: src/galois/_domains/_function.py:246-392) for BASELINE config C3-i
+// (batches of 2^16-point transforms over GF(65537)).  Exact integer arithmetic, so any correct DFT algorithm reproduces
+// the reference's bits; the structure here is chosen for the machine:
+//
+//   * one 1024-thread workgroup owns one whole transform: 64 points per thread live in VGPRs (256 KiB of the CU's 512 KiB
+//     register file), the array is read once and written once (8 B/point, the algorithmic minimum);
+//   * N = 64 * 32 * 32: three fully unrolled in-register decimation-in-frequency networks (radix 64, 32, 32) joined by
+//     two exchanges through LDS (each in two rounds of 128 KiB);
+//   * 2 has order 32 and sqrt(2) = 2^12 - 2^4 order 64 modulo 2^16 + 1, so every twiddle INSIDE a network is a shift (or
+//     one product with a 16-bit constant) followed by a fold  lo16(x) - (x >> 16)  -- one v_sub_u32_sdwa.  Values stay
+//     loose signed 32-bit representatives; tools/gen_fermat_net.py places the folds with exact interval tracking
+//     (gfa_fermat_nets.inc is its output);
+//   * only the two twiddles BETWEEN networks are general products: balanced 16-bit factors, one v_mul_lo_u32 + two folds.
+//     w^(m*k0) comes from a 256 KiB table that every workgroup shares (L2 resident), w_1024^(r*k1) from a 4 KiB LDS table;
+//   * the networks use the canonical roots (sqrt(2), 2).  A transform with root of unity w has w^(N/64) = sqrt(2)^u for
+//     one odd u; feeding network inputs in the order a' = u*a mod R turns the canonical network into the wanted one, and
+//     that permutation is folded into the global load addresses and the LDS write positions (no instructions).
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "gfa_internal.h"
+
+using namespace gfa;
+
+namespace {
+
+__device__ __forceinline__ int fm_add(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+__device__ __forceinline__ int fm_sub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+__device__ __forceinline__ int fm_shl(int a, int k) { return (int)((unsigned)a << k); }
+__device__ __forceinline__ int fm_mulc(int a, int c) { return (int)((unsigned)a * (unsigned)c); }
+// x == lo16(x) - (x >> 16)  (mod 2^16 + 1); any int32 -> [-32767, 98303]
+__device__ __forceinline__ int fm_fold(int t)
+{
+    int r;
+    asm("v_sub_u32_sdwa %0, %1, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(r) : "v"(t));
+    return r;
+}
+// balanced fold: x == sext16(x) - ((x + 2^15) >> 16); |x| < 2^29 -> |result| <= 32768 + 2^13 + 1
+__device__ __forceinline__ int fm_bfold(int t)
+{
+    const int t2 = fm_add(t, 0x8000);
+    int r;
+    asm("v_sub_u32_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1"
+        : "=v"(r)
+        : "v"(t), "v"(t2));
+    return r;
+}
+
+#include "gfa_fermat_nets.inc"
+
+constexpr int brev_c(int x, int bits)
+{
+    int r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+// general product with a balanced table factor |w| <= 32768: |x| < 2^29 in, [-32767, 98303] out
+__device__ __forceinline__ int fm_mul_tw(int x, int w) { return fm_fold(fm_mulc(fm_bfold(x), w)); }
+
+constexpr int E2_PITCH = 33;                  // exchange 2: r' runs fastest, k0 pitch 33 words (conflict-free both ways)
+constexpr int EX_WORDS = 16 * 64 * E2_PITCH;  // 33792 words >= exchange 1's 32 * 1024
+constexpr int FERMAT_LDS_BYTES = (EX_WORDS + 1024) * 4;
+
+struct FermatArgs {
+    const u32 *in;
+    u32 *out;
+    const int *tw1; // [64][1024]: balanced w^(m * k0)
+    const int *tw2; // [32][32]:   balanced w^(64 * r * k1), index k1 * 32 + r
+    int u, uinv;    // w^(N/64) == sqrt(2)^u, uinv = u^-1 mod 64
+    int batch;
+    int stagger;    // first-round start offset between the four workgroup groups, in units of 4096 clocks (0: none)
+    unsigned long long *dbg; // optional phase timestamps (100 MHz), 8 per (workgroup, round); nullptr in production
+};
+#define FM_STAMP(i)                                     \
+    do {                                                \
+        if (DBG) ts[i] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+
+// final reduction of a network output |c| < 2^29 to the canonical [0, 65536] (NEGATE: of -c, the 1/N of the inverse):
+// adding a multiple of p first makes the value non-negative, the first fold then ends in [-2^14, 65535] and the second
+// in [0, 65536] -- no conditional step
+constexpr int FM_OFFSET = 65537 * 8192; // == 0 mod p, >= 2^29
+template <bool NEGATE>
+__device__ __forceinline__ u32 fm_canon(int c)
+{
+    c = NEGATE ? fm_sub(FM_OFFSET, c) : fm_add(c, FM_OFFSET);
+    return (u32)fm_fold(fm_fold(c));
+}
+
+// Workgroup barrier for LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL access (vmcnt(0)), which
+// would stall each exchange on the twiddle loads in flight, on the stores of the finished half and on the early loads of
+// the next transform.  LDS operations of a wave complete in order, so lgkmcnt(0) + s_barrier is all the exchange needs.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Cache hints, measured (tools/fermat_variants.sh, two repetitions): non-temporal STORES (the output is never re-read by
+// this kernel; keeps the shared twiddle table in L2) but default-policy LOADS -- with non-temporal loads a batch whose
+// input is about the size of the 256 MiB Infinity Cache (1024 transforms = 256 MiB) loses the hits it otherwise gets from one
+// launch to the next: 0.125 vs 0.139 ms per 1024 transforms; at 4096 transforms (1 GiB, no reuse possible) the four
+// combinations are within noise of each other (0.553 - 0.575 ms).
+#ifndef GFA_FERMAT_AUX_LD
+#define GFA_FERMAT_AUX_LD 0
+#endif
+#ifndef GFA_FERMAT_AUX_ST
+#define GFA_FERMAT_AUX_ST 2
+#endif
+#ifndef GFA_FERMAT_TWW
+#define GFA_FERMAT_TWW 32
+#endif
+#ifndef GFA_FERMAT_LD_FIRST
+#define GFA_FERMAT_LD_FIRST 1
+#endif
+#ifndef GFA_FERMAT_EARLY_B
+#define GFA_FERMAT_EARLY_B 32
+#endif
+#ifndef GFA_FERMAT_EARLY_C
+#define GFA_FERMAT_EARLY_C 64
+#endif
+#ifndef GFA_FERMAT_EARLY_A
+#define GFA_FERMAT_EARLY_A 16 // SCHED 1: loads of the next transform requested after exchange 1 (the rest of the first half after exchange 2's first write)
+#endif
+constexpr int AUX_NT = GFA_FERMAT_AUX_LD; // streaming (non-temporal) hint on the data loads: keep the shared twiddle table in L2
+constexpr int AUX_ST = GFA_FERMAT_AUX_ST; // ... and on the stores
+
+template <bool NEGATE, bool DBG, int SCHED>
+__global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
+{
+    extern __shared__ int lds[];
+    int *ex = lds;
+    int *tw2l = lds + EX_WORDS;
+    const unsigned tid = threadIdx.x;
+    const int voff = (int)(tid * 4u);
+    const int g = (int)(tid >> 5), r = (int)(tid & 31);   // exchange 1 / network 1 coordinates
+    const int l = (int)(tid & 63), wv = (int)(tid >> 6);  // exchange 2 / network 2 coordinates
+    const int wpos1 = (((a.u * g) & 31) << 5) + r;        // exchange 1 write slot b' = u * b mod 32
+    const int wpos2 = ((a.u * r) & 31);                   // exchange 2 write slot r' = u * r mod 32
+    int *const e1w = ex + wpos1;
+    const int *const e1r = ex + g * 1024 + r;
+    int *const e2w = ex + g * E2_PITCH + wpos2;
+    const int *const e2r = ex + wv * (64 * E2_PITCH) + l * E2_PITCH;
+    const __amdgpu_buffer_rsrc_t tr = __builtin_amdgcn_make_buffer_rsrc((void *)a.tw1, 0, 65536 * 4, 0x00020000);
+    tw2l[tid] = a.tw2[tid];
+    // Workgroups are persistent (one per CU) and all run the same program, so without help every CU would read, compute
+    // and write at the same moments and HBM would idle while the chip computes.  The first round is staggered in four
+    // groups (each XCD holds all four): group j starts j * stagger later, and the offset persists from round to round.
+    if (a.stagger > 0) {
+        const int grp = (int)((blockIdx.x >> 3) & 3u);
+        for (int i = 0; i < grp * a.stagger; i++) __builtin_amdgcn_s_sleep(64);
+    }
+    // every global access is `buffer_* v, v_off, s[rsrc], s_off offen`: lane offset tid*4 in one VGPR, row offset in an
+    // SGPR, descriptors from kernel arguments and the (wave-uniform) transform index -- no vector address arithmetic
+    auto in_rsrc = [&](unsigned t) { return __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (size_t)t * 65536u), 0, 65536 * 4, 0x00020000); };
+    int v[64];
+    {
+        const __amdgpu_buffer_rsrc_t xr = in_rsrc(blockIdx.x);
+#pragma unroll
+        for (int ap = 0; ap < 64; ap++) v[ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xr, voff, (int)((((unsigned)a.uinv * ap) & 63u) << 12), AUX_NT);
+    }
+    for (unsigned tr_i = blockIdx.x; tr_i < (unsigned)a.batch; tr_i += gridDim.x) {
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (size_t)tr_i * 65536u), 0, 65536 * 4, 0x00020000);
+        const unsigned tr_next = tr_i + gridDim.x;
+        const bool has_next = tr_next < (unsigned)a.batch;
+        const __amdgpu_buffer_rsrc_t xn = in_rsrc(has_next ? tr_next : tr_i);
+        unsigned uinv = (unsigned)a.uinv;
+        asm volatile("" : "+s"(uinv)); // keep the 64 row offsets out of loop-invariant SGPRs (they are 3 scalar ops each)
+        unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // phase timestamps: scalar registers, written out once at the end
+        FM_STAMP(0);
+        // ---- network 0: radix 64 over a (stride 1024); thread m = tid.  Twiddles w^(m * k0), k0 = 1..63, come from the
+        // shared 256 KiB table (L2 resident): a rolling window of TWW values is requested ahead of its use so that the L2
+        // latency hides behind the network and the products themselves
+        constexpr int TWW = GFA_FERMAT_TWW;
+        int tw[TWW];
+#pragma unroll
+        for (int i = 0; i < TWW; i++) tw[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(tr, voff, (i + 1) * 4096, 0);
+        fermat_net64_canon(v);
+        FM_STAMP(1);
+        v[0] = fm_fold(v[0]);
+        auto tw1_range = [&](int lo, int hi) {
+#pragma unroll
+            for (int k0 = lo; k0 < hi; k0++) {
+                int &q = v[brev_c(k0, 6)];
+                q = fm_mul_tw(q, tw[(k0 - 1) % TWW]);
+                if (k0 + TWW < 64) tw[(k0 - 1) % TWW] = (int)__builtin_amdgcn_raw_buffer_load_b32(tr, voff, (k0 + TWW) * 4096, 0);
+            }
+        };
+        tw1_range(1, 32);
+        FM_STAMP(2);
+        // ---- exchange 1 + network 1: thread (g, r) takes k0 = g and g + 32, radix 32 over b (m = 32 b + r).  Each LDS
+        // write burst is followed by arithmetic that does not depend on it, so the LDS pipe and the VALU overlap ----
+        int w[2][32];
+        lds_barrier(); // the previous transform's exchange-2 reads (first round: the staging of tw2l) are complete
+#pragma unroll
+        for (int kl = 0; kl < 32; kl++) e1w[kl * 1024] = v[brev_c(kl, 6)];
+        tw1_range(32, 64);
+        lds_barrier();
+#pragma unroll
+        for (int bp = 0; bp < 32; bp++) w[0][bp] = e1r[bp * 32];
+        lds_barrier();
+#pragma unroll
+        for (int kl = 0; kl < 32; kl++) e1w[kl * 1024] = v[brev_c(kl + 32, 6)];
+        FM_STAMP(3);
+        // SCHED 1: every register of v and of the twiddle window is free from here to the end of exchange 2: the next transform's
+        // first half is requested NOW, so that the memory system has work during the two register networks and exchange 2
+        auto early = [&](int lo, int hi) { // (v is dead from here on: the loads go straight into the next round's registers)
+            if (SCHED == 1 && has_next) {
+#pragma unroll
+                for (int ap = lo; ap < hi; ap++) v[ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xn, voff, (int)(((uinv * ap) & 63u) << 12), AUX_NT);
+            }
+        };
+        early(0, GFA_FERMAT_EARLY_A);
+        auto net1 = [&](int h) {
+            fermat_net32_fold(w[h]);
+            w[h][0] = fm_fold(w[h][0]);
+#pragma unroll
+            for (int k1 = 1; k1 < 32; k1++) {
+                int &q = w[h][brev_c(k1, 5)];
+                q = fm_mul_tw(q, tw2l[k1 * 32 + r]);
+            }
+        };
+        net1(0);
+        lds_barrier();
+#pragma unroll
+        for (int bp = 0; bp < 32; bp++) w[1][bp] = e1r[bp * 32];
+        net1(1);
+        FM_STAMP(4);
+        // ---- exchange 2 + network 2: thread (lane l = k0, wave wv) takes k1 = wv and wv + 16, radix 32 over r ----
+        int z[2][32];
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int kl = 0; kl < 16; kl++) e2w[kl * (64 * E2_PITCH) + 32 * i * E2_PITCH] = w[i][brev_c(kl, 5)];
+        early(GFA_FERMAT_EARLY_A, GFA_FERMAT_EARLY_B);
+        lds_barrier();
+#pragma unroll
+        for (int rp = 0; rp < 32; rp++) z[0][rp] = e2r[rp];
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int kl = 0; kl < 16; kl++) e2w[kl * (64 * E2_PITCH) + 32 * i * E2_PITCH] = w[i][brev_c(kl + 16, 5)];
+        FM_STAMP(5);
+        auto net2 = [&](int h) {
+            fermat_net32_fold(z[h]);
+            // X[k0 + 64 * (k1 + 32 * k2)], k1 = wv + 16 h: lane offset tid
+            if (SCHED == 1 && h == 0 && GFA_FERMAT_LD_FIRST) {
+                // outputs first, then the next transform's second half AHEAD of the stores in the memory queue
+#pragma unroll
+                for (int k2 = 0; k2 < 32; k2++) z[h][brev_c(k2, 5)] = (int)fm_canon<NEGATE>(z[h][brev_c(k2, 5)]);
+                early(GFA_FERMAT_EARLY_B, GFA_FERMAT_EARLY_C);
+#pragma unroll
+                for (int k2 = 0; k2 < 32; k2++) __builtin_amdgcn_raw_buffer_store_b32(z[h][brev_c(k2, 5)], yr, voff, (2048 * k2 + 1024 * h) * 4, AUX_ST);
+                return;
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 32; k2++)
+                __builtin_amdgcn_raw_buffer_store_b32(fm_canon<NEGATE>(z[h][brev_c(k2, 5)]), yr, voff, (2048 * k2 + 1024 * h) * 4, AUX_ST);
+        };
+        net2(0);
+        if (!GFA_FERMAT_LD_FIRST) early(GFA_FERMAT_EARLY_B, GFA_FERMAT_EARLY_C);
+        FM_STAMP(6);
+        // SCHED 0: the next transform's first half is requested as soon as registers are free
+        if (SCHED == 0 && has_next) {
+#pragma unroll
+            for (int ap = 0; ap < 32; ap++) v[ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xn, voff, (int)(((uinv * ap) & 63u) << 12), AUX_NT);
+        }
+        lds_barrier();
+#pragma unroll
+        for (int rp = 0; rp < 32; rp++) z[1][rp] = e2r[rp];
+        net2(1);
+        if (SCHED == 0 && has_next) {
+#pragma unroll
+            for (int ap = 32; ap < 64; ap++) v[ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xn, voff, (int)(((uinv * ap) & 63u) << 12), AUX_NT);
+        }
+        early(GFA_FERMAT_EARLY_C, 64);
+        FM_STAMP(7);
+        if (DBG && tid == 0) {
+            unsigned long long *d = a.dbg + ((size_t)(tr_i / gridDim.x) * gridDim.x + blockIdx.x) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) d[i] = ts[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Two transforms per CU: 512-thread workgroups, 128 points per thread
+// ------------------------------------------------------------------------------------------------
+// The 1024-thread kernel above owns a CU alone, so its load, exchange and store phases cannot hide behind anything (r03
+// counters: 41 % of all wave cycles waiting).  Here a transform lives in 512 threads x 128 registers, two workgroups share a
+// CU (2 waves per SIMD, 256 VGPRs each), and their barriers are independent: one transform's loads, LDS exchanges and stores
+// run under the other's register networks.  Same decomposition N = 64 * 32 * 32 and the same generated networks:
+//   phase 0: thread t holds m = t and t + 512: two radix-64 networks over a (stride 1024), times w^(m * k0);
+//   exchange 1 in four rounds of 16 k0 (64 KiB): thread (gl, r) collects k0 = gl + 16 q, q = 0..3 -- four radix-32 networks over b;
+//   exchange 2 in four rounds of 8 k1: thread (k0 = lane, wv) collects k1 = wv + 8 q -- four radix-32 networks over r;
+//   X[k0 + 64 * (k1 + 32 * k2)] is word t + 512 q + 2048 k2 of the output row: every global access is a full 256-byte wave access.
+// Registers freed by an exchange-2 round take the next transform's loads at once (32 per round).
+constexpr int X2_WORDS = 8 * 64 * E2_PITCH; // 16896 words >= exchange 1's 16 * 1024
+constexpr int FERMAT_X2_LDS_BYTES = (X2_WORDS + 1024) * 4;
+
+#define PAIR_STAMP(i)                                                             \
+    do {                                                                          \
+        if (DBG) {                                                                \
+            const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();       \
+            if (tid == 0) __builtin_nontemporal_store(t_, dts + (i));             \
+        }                                                                         \
+    } while (0)
+template <bool NEGATE, int SKEL, bool DBG>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void ntt_fermat16_pair_kernel(FermatArgs a)
+{
+    extern __shared__ int lds[];
+    int *ex = lds;
+    int *tw2l = lds + X2_WORDS;
+    const unsigned tid = threadIdx.x;
+    const int voff = (int)(tid * 4u);
+    const int gl = (int)(tid >> 5), r = (int)(tid & 31);  // exchange 1 / network 1 coordinates
+    const int l = (int)(tid & 63), wv = (int)(tid >> 6);  // exchange 2 / network 2 coordinates
+    // exchange 1 write slots of m = tid + 512 s (b = gl + 16 s): [k0 local][b' = u * b mod 32][r]
+    int *const e1w0 = ex + (((a.u * gl) & 31) << 5) + r;
+    int *const e1w1 = ex + (((a.u * (gl + 16)) & 31) << 5) + r;
+    const int *const e1r = ex + gl * 1024 + r;
+    // exchange 2: [k1 local][k0][r' = u * r mod 32], k0 pitch 33
+    int *const e2w = ex + gl * E2_PITCH + ((a.u * r) & 31);
+    const int *const e2r = ex + wv * (64 * E2_PITCH) + l * E2_PITCH;
+    const __amdgpu_buffer_rsrc_t tr = __builtin_amdgcn_make_buffer_rsrc((void *)a.tw1, 0, 65536 * 4, 0x00020000);
+    tw2l[tid] = a.tw2[tid];
+    tw2l[tid + 512] = a.tw2[tid + 512];
+    if (a.stagger > 0) {
+        // the second workgroup of a CU (its LDS allocation does not start at 0) begins half a round later
+        const unsigned base = __builtin_amdgcn_s_getreg((6 << 0) | (0 << 6) | (7 << 11)) ; // HW_REG_LDS_ALLOC, LDS_BASE[7:0]
+        if (base != 0)
+            for (int i = 0; i < a.stagger; i++) __builtin_amdgcn_s_sleep(64);
+    }
+    auto in_rsrc = [&](unsigned t) { return __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (size_t)t * 65536u), 0, 65536 * 4, 0x00020000); };
+    constexpr int TWW = DBG ? 20 : GFA_FERMAT_TWW; // (the stamped build needs a few registers for the stamps)
+    int v[2][64];
+    int tw[TWW];
+    auto tw_load = [&](int j) { // stream position j: s = j / 63, k0 = j % 63 + 1
+        return (int)__builtin_amdgcn_raw_buffer_load_b32(tr, voff + 2048 * (j / 63), (j % 63 + 1) * 4096, 0);
+    };
+    {
+        const __amdgpu_buffer_rsrc_t xr = in_rsrc(blockIdx.x);
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+            for (int ap = 0; ap < 64; ap++)
+                v[s][ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xr, voff + 2048 * s, (int)((((unsigned)a.uinv * ap) & 63u) << 12), AUX_NT);
+    }
+    int acc = 0; // SKEL 1: stands in for the stores
+#pragma unroll
+    for (int i = 0; i < TWW; i++) tw[i] = tw_load(i);
+    for (unsigned tr_i = blockIdx.x; tr_i < (unsigned)a.batch; tr_i += gridDim.x) {
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (size_t)tr_i * 65536u), 0, 65536 * 4, 0x00020000);
+        const unsigned tr_next = tr_i + gridDim.x;
+        const bool has_next = tr_next < (unsigned)a.batch;
+        const __amdgpu_buffer_rsrc_t xn = in_rsrc(has_next ? tr_next : tr_i);
+        unsigned uinv = (unsigned)a.uinv;
+        asm volatile("" : "+s"(uinv)); // keep the 64 row offsets out of loop-invariant SGPRs
+        unsigned long long *const dts = DBG ? a.dbg + ((size_t)(tr_i / gridDim.x) * gridDim.x + blockIdx.x) * 8 : nullptr;
+        PAIR_STAMP(0);
+        // products with the stream of first twiddles w^(m * k0); the window slot of a used value is refilled TWW positions ahead
+        auto tw1_range = [&](int s, int lo, int hi) {
+#pragma unroll
+            for (int k0 = lo; k0 < hi; k0++) {
+                const int j = 63 * s + k0 - 1;
+                int &q = v[s][brev_c(k0, 6)];
+                q = fm_mul_tw(q, tw[j % TWW]);
+                if (j + TWW < 126) tw[j % TWW] = tw_load(j + TWW);
+            }
+        };
+        if (SKEL != 2) {
+        // ---- network 0 ----
+        fermat_net64_canon(v[0]);
+        v[0][0] = fm_fold(v[0][0]);
+        tw1_range(0, 1, 64);
+        PAIR_STAMP(1);
+        fermat_net64_canon(v[1]);
+        v[1][0] = fm_fold(v[1][0]);
+        PAIR_STAMP(2);
+        }
+        // ---- exchange 1 + network 1 ----
+        int w[4][32];
+        auto net1 = [&](int h) {
+            fermat_net32_fold(w[h]);
+            w[h][0] = fm_fold(w[h][0]);
+#pragma unroll
+            for (int k1 = 1; k1 < 32; k1++) {
+                int &q = w[h][brev_c(k1, 5)];
+                q = fm_mul_tw(q, tw2l[k1 * 32 + r]);
+            }
+        };
+        if (SKEL != 2) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            tw1_range(1, q == 0 ? 1 : 16 * q, 16 * q + 16);
+            lds_barrier(); // the reads of the previous round (q = 0: of the previous transform's exchange 2) are complete
+#pragma unroll
+            for (int kl = 0; kl < 16; kl++) {
+                e1w0[kl * 1024] = v[0][brev_c(16 * q + kl, 6)];
+                e1w1[kl * 1024] = v[1][brev_c(16 * q + kl, 6)];
+            }
+            if (q > 0) net1(q - 1); // arithmetic that does not depend on the writes in flight
+            lds_barrier();
+#pragma unroll
+            for (int bp = 0; bp < 32; bp++) w[q][bp] = e1r[bp * 32];
+        }
+        PAIR_STAMP(3);
+        net1(3);
+        PAIR_STAMP(4);
+        }
+        // ---- exchange 2 + network 2 + stores; freed registers take the next transform's loads ----
+        int z[4][32];
+        auto net2 = [&](int h) {
+            if (SKEL == 2) {
+#pragma unroll
+                for (int k2 = 0; k2 < 32; k2++) __builtin_amdgcn_raw_buffer_store_b32(v[h / 2][32 * (h % 2) + k2], yr, voff, (2048 * k2 + 512 * h) * 4, AUX_ST);
+                return;
+            }
+            fermat_net32_fold(z[h]);
+#pragma unroll
+            for (int k2 = 0; k2 < 32; k2++) {
+                const u32 o = fm_canon<NEGATE>(z[h][brev_c(k2, 5)]);
+                if (SKEL == 1) acc ^= (int)o;
+                else __builtin_amdgcn_raw_buffer_store_b32(o, yr, voff, (2048 * k2 + 512 * h) * 4, AUX_ST);
+            }
+        };
+        auto next_loads = [&](int part) { // quarter `part` of the 128 loads: s = part / 2, ap in [32 * (part % 2), +32)
+            if (SKEL == 1) {
+#pragma unroll
+                for (int i = 0; i < 32; i++) v[part / 2][32 * (part % 2) + i] = (int)fm_canon<NEGATE>(z[part][i]);
+            } else if (has_next) {
+#pragma unroll
+                for (int i = 0; i < 32; i++) {
+                    const int ap = 32 * (part % 2) + i;
+                    v[part / 2][ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xn, voff + 2048 * (part / 2), (int)(((uinv * ap) & 63u) << 12), AUX_NT);
+                }
+            }
+        };
+        if (SKEL == 2) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) { net2(q); next_loads(q); }
+        } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            lds_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int kl = 0; kl < 8; kl++) e2w[kl * (64 * E2_PITCH) + 16 * i * E2_PITCH] = w[i][brev_c(8 * q + kl, 5)];
+            if (q > 0) {
+                net2(q - 1);
+                next_loads(q - 1);
+            }
+            lds_barrier();
+#pragma unroll
+            for (int rp = 0; rp < 32; rp++) z[q][rp] = e2r[rp];
+        }
+        }
+        PAIR_STAMP(5);
+        net2(3);
+        PAIR_STAMP(6);
+        if (has_next) {
+#pragma unroll
+            for (int i = 0; i < TWW; i++) tw[i] = tw_load(i); // ahead of the last quarter: loads return in order
+        }
+        next_loads(3);
+        PAIR_STAMP(7);
+        if (DBG && tid == 0) {
+            const size_t rounds = ((size_t)a.batch + gridDim.x - 1) / gridDim.x;
+            if (tr_i == blockIdx.x) // placement record: HW_ID in the low word, LDS_ALLOC in the high word
+                a.dbg[rounds * gridDim.x * 8 + blockIdx.x] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
+                                                             ((unsigned long long)__builtin_amdgcn_s_getreg((6 << 0) | (0 << 6) | (31 << 11)) << 32);
+        }
+    }
+    if (SKEL == 1 && acc == 0x7fffffff) a.out[tid] = (u32)acc;
+}
+
+unsigned long long *g_fermat_dbg = nullptr;
+
+struct FermatPlan {
+    int *tw1 = nullptr, *tw2 = nullptr;
+    int u = 0, uinv = 0, cus = 256;
+    bool ok = false;
+};
+std::mutex g_mu;
+std::map<std::pair<int, u64>, FermatPlan> g_plans; // (device, omega)
+
+inline u32 mulmod(u32 a, u32 b) { return (u32)(((u64)a * b) % 65537u); }
+inline int balanced(u32 c) { return c > 32768u ? (int)c - 65537 : (int)c; }
+
+} // namespace
+
+namespace gfa {
+
+bool ntt_fermat16_eligible(const FieldDev &fd, i64 n, i64 batch)
+{
+    static const int min_batch = [] { const char *e = getenv("GFA_NTT_FERMAT_MIN_BATCH"); return e ? atoi(e) : 64; }();
+    return fd.kind == KIND_PRIME32 && fd.p == 65537 && n == 65536 && batch >= min_batch;
+}
+
+// in / out: uint32, batch transforms of 2^16 points.  Returns GFA_ERR_UNSUPPORTED (nothing launched) when omega is not a
+// primitive 2^16-th root of unity.
+int ntt_fermat16(const void *in, void *out, i64 batch, u64 omega, int negate, hipStream_t st)
+{
+    int dev = 0;
+    GFA_HIP(hipGetDevice(&dev));
+    FermatPlan pl;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        FermatPlan &p = g_plans[std::make_pair(dev, omega)];
+        if (!p.tw1 && !p.ok) {
+            // w must have order exactly 2^16: w^(2^15) == -1
+            u32 t = (u32)omega;
+            for (int i = 0; i < 15; i++) t = mulmod(t, t);
+            if (t != 65536u) return GFA_ERR_UNSUPPORTED;
+            u32 w64 = (u32)omega; // w^(N/64) = w^1024
+            for (int i = 0; i < 10; i++) w64 = mulmod(w64, w64);
+            u32 z = 4080u, zz = mulmod(z, z), cur = z; // sqrt(2)^u for odd u
+            int u = 0;
+            for (int c = 1; c < 64; c += 2) {
+                if (cur == w64) { u = c; break; }
+                cur = mulmod(cur, zz);
+            }
+            if (!u) return GFA_ERR_UNSUPPORTED;
+            int uinv = 1;
+            while ((u * uinv) % 64 != 1) uinv += 2;
+            std::vector<int> t1(64 * 1024), t2(32 * 32);
+            std::vector<u32> pw(65536);
+            pw[0] = 1;
+            for (int e = 1; e < 65536; e++) pw[e] = mulmod(pw[e - 1], (u32)omega);
+            for (int k0 = 0; k0 < 64; k0++)
+                for (int m = 0; m < 1024; m++) t1[k0 * 1024 + m] = balanced(pw[(m * k0) & 65535]);
+            for (int k1 = 0; k1 < 32; k1++)
+                for (int r = 0; r < 32; r++) t2[k1 * 32 + r] = balanced(pw[(64 * r * k1) & 65535]);
+            GFA_HIP(hipMalloc((void **)&p.tw1, t1.size() * sizeof(int)));
+            GFA_HIP(hipMalloc((void **)&p.tw2, t2.size() * sizeof(int)));
+            GFA_HIP(hipMemcpy(p.tw1, t1.data(), t1.size() * sizeof(int), hipMemcpyHostToDevice));
+            GFA_HIP(hipMemcpy(p.tw2, t2.data(), t2.size() * sizeof(int), hipMemcpyHostToDevice));
+            hipDeviceProp_t prop;
+            GFA_HIP(hipGetDeviceProperties(&prop, dev));
+            p.u = u; p.uinv = uinv; p.cus = prop.multiProcessorCount; p.ok = true;
+            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_kernel<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_kernel<true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_kernel<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_kernel<false, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_kernel<true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_kernel<false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_pair_kernel<false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_pair_kernel<true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_pair_kernel<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_pair_kernel<false, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_pair_kernel<false, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        }
+        pl = p;
+    }
+    static const int stagger_env = [] { const char *e = getenv("GFA_NTT_FERMAT_STAGGER"); return e ? atoi(e) : 2; }();
+    static const int grid_env = [] { const char *e = getenv("GFA_NTT_FERMAT_GRID"); return e ? atoi(e) : 0; }();
+    static const int pair_env = [] { const char *e = getenv("GFA_NTT_FERMAT_PAIR"); return e ? atoi(e) : 0; }();
+    if (pair_env) {
+        static const int pstagger = [] { const char *e = getenv("GFA_NTT_FERMAT_PSTAGGER"); return e ? atoi(e) : 0; }();
+        const i64 pgrid = std::min<i64>(batch, grid_env > 0 ? grid_env : 2 * pl.cus);
+        static const int skel = [] { const char *e = getenv("GFA_NTT_FERMAT_SKEL"); return e ? atoi(e) : 0; }(); // tuning only: 1 no HBM traffic, 2 no arithmetic
+        FermatArgs pa{(const u32 *)in, (u32 *)out, pl.tw1, pl.tw2, pl.u, pl.uinv, (int)batch, pstagger, g_fermat_dbg};
+        if (negate) hipLaunchKernelGGL((ntt_fermat16_pair_kernel<true, 0, false>), dim3((unsigned)pgrid), dim3(512), FERMAT_X2_LDS_BYTES, st, pa);
+        else if (pa.dbg) hipLaunchKernelGGL((ntt_fermat16_pair_kernel<false, 0, true>), dim3((unsigned)pgrid), dim3(512), FERMAT_X2_LDS_BYTES, st, pa);
+        else if (skel == 1) hipLaunchKernelGGL((ntt_fermat16_pair_kernel<false, 1, false>), dim3((unsigned)pgrid), dim3(512), FERMAT_X2_LDS_BYTES, st, pa);
+        else if (skel == 2) hipLaunchKernelGGL((ntt_fermat16_pair_kernel<false, 2, false>), dim3((unsigned)pgrid), dim3(512), FERMAT_X2_LDS_BYTES, st, pa);
+        else hipLaunchKernelGGL((ntt_fermat16_pair_kernel<false, 0, false>), dim3((unsigned)pgrid), dim3(512), FERMAT_X2_LDS_BYTES, st, pa);
+        GFA_HIP(hipGetLastError());
+        return GFA_OK;
+    }
+    const i64 grid = std::min<i64>(batch, grid_env > 0 ? grid_env : pl.cus);
+    // the stagger only pays when every group has later rounds to keep busy
+    FermatArgs a{(const u32 *)in, (u32 *)out, pl.tw1, pl.tw2, pl.u, pl.uinv, (int)batch, batch >= 2 * grid ? stagger_env : 0, g_fermat_dbg};
+    static const int sched = [] { const char *e = getenv("GFA_NTT_FERMAT_SCHED"); return e ? atoi(e) : 1; }();
+#define FERMAT_LAUNCH(NEG, DBGF, SCH) hipLaunchKernelGGL((ntt_fermat16_kernel<NEG, DBGF, SCH>), dim3((unsigned)grid), dim3(1024), FERMAT_LDS_BYTES, st, a)
+    if (sched == 1) {
+        if (a.dbg && !negate) FERMAT_LAUNCH(false, true, 1);
+        else if (negate) FERMAT_LAUNCH(true, false, 1);
+        else FERMAT_LAUNCH(false, false, 1);
+    } else {
+        if (a.dbg && !negate) FERMAT_LAUNCH(false, true, 0);
+        else if (negate) FERMAT_LAUNCH(true, false, 0);
+        else FERMAT_LAUNCH(false, false, 0);
+    }
+#undef FERMAT_LAUNCH
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+// tuning aid (tools/fermat_phases.py): device buffer of 8 timestamps per (round, workgroup), or nullptr to switch off
+extern "C" void gfa_debug_fermat_stamps(unsigned long long *buf) { g_fermat_dbg = buf; }
+
+} // namespace gfa
