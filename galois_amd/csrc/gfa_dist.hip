@@ -86,17 +86,27 @@ int all_to_all(const void *send, void *recv, size_t count, int dtype, void *comm
     return GFA_OK;
 }
 
-// one non-blocking side stream per device for the overlapped exchange (created at first use, kept for the process)
-int side_stream(hipStream_t *out)
+// The overlapped exchange's side resources, one set per device, created at first use and kept for the process: a non-blocking
+// side stream, the three events that order it against the caller's stream, and a lock held while one call ENQUEUES its exchange
+// (host-side work only) so that two host threads cannot interleave their records / waits on the shared events.
+struct SideSet {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    std::mutex issue;
+};
+int side_set(SideSet **out)
 {
     static std::mutex mu;
-    static hipStream_t streams[64] = {};
+    static SideSet sets[64];
     int dev = 0;
     GFA_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(mu);
     if (dev < 0 || dev >= 64) { set_error("gfa_ntt_dist: device ordinal out of range"); return GFA_ERR_UNSUPPORTED; }
-    if (!streams[dev]) GFA_HIP(hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking));
-    *out = streams[dev];
+    SideSet &ss = sets[dev];
+    if (!ss.stream) GFA_HIP(hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking));
+    for (auto &e : ss.ev)
+        if (!e) GFA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *out = &ss;
     return GFA_OK;
 }
 
@@ -137,12 +147,8 @@ int gfa_ntt_dist(gfa_field_t *f, void *nccl_comm, int rank, int world, const voi
     const bool p2p = g_rccl.send && g_rccl.recv && g_rccl.group_start && g_rccl.group_end;
     const int nsub = (p2p && nsub_env >= 2 && cols % 2 == 0 && cols >= 64) ? 2 : 1;
     const int64_t csub = cols / nsub;
-    hipStream_t side = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    if (nsub > 1) {
-        if ((rc = side_stream(&side))) return rc;
-        for (auto &e : ev) GFA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
+    SideSet *ss = nullptr;
+    if (nsub > 1 && (rc = side_set(&ss))) return rc;
     char *work = nullptr;
     GFA_HIP(gfa::scratch_alloc((void **)&work, 2 * bytes, st));
     char *a = work, *recv = work + bytes;
@@ -157,26 +163,35 @@ int gfa_ntt_dist(gfa_field_t *f, void *nccl_comm, int rank, int world, const voi
     } else {
         const int nccl_type = dtype == GFA_U32 ? 3 /* ncclUint32 */ : 5 /* ncclUint64 */;
         const size_t blk = (size_t)(rows * csub); // elements per (peer, sub-block) chunk
+        std::lock_guard<std::mutex> issue(ss->issue);
+        hipStream_t side = ss->stream;
+        bool side_used = false;
         for (int s = 0; s < nsub && !rc; s++) {
             char *as = a + (size_t)s * (size_t)(n1 * csub) * esz;
             rc = gfa_ntt_columns_pitched(f, (const char *)local_cols + (size_t)s * csub * esz, cols, as, csub, n1, csub,
                                          (int64_t)rank * cols + s * csub, n_total, omega, dtype, stream);
             if (rc) break;
-            hipError_t he = hipEventRecord(ev[s], st);
-            if (he == hipSuccess) he = hipStreamWaitEvent(side, ev[s], 0);
+            hipError_t he = hipEventRecord(ss->ev[s], st);
+            if (he == hipSuccess) he = hipStreamWaitEvent(side, ss->ev[s], 0);
             if (he != hipSuccess) { rc = hip_fail(he, "gfa_ntt_dist: event"); break; }
             int nr;
             if ((nr = g_rccl.group_start())) { rc = nccl_fail(nr, "ncclGroupStart"); break; }
+            side_used = true;
             for (int p = 0; p < world && !rc; p++) {
                 if ((nr = g_rccl.send(as + (size_t)p * blk * esz, blk, nccl_type, p, nccl_comm, side))) rc = nccl_fail(nr, "ncclSend");
                 else if ((nr = g_rccl.recv(recv + ((size_t)p * nsub + s) * blk * esz, blk, nccl_type, p, nccl_comm, side))) rc = nccl_fail(nr, "ncclRecv");
             }
             if ((nr = g_rccl.group_end()) && !rc) rc = nccl_fail(nr, "ncclGroupEnd");
         }
-        if (!rc) {
-            hipError_t he = hipEventRecord(ev[2], side);
-            if (he == hipSuccess) he = hipStreamWaitEvent(st, ev[2], 0);
-            if (he != hipSuccess) rc = hip_fail(he, "gfa_ntt_dist: event");
+        if (side_used) {
+            // also on a failed step: whatever already runs on the side stream may still touch `work`, which goes back to the
+            // pool ordered on `st` alone -- `st` joins the side stream before anything else (the free included) is enqueued
+            hipError_t he = hipEventRecord(ss->ev[2], side);
+            if (he == hipSuccess) he = hipStreamWaitEvent(st, ss->ev[2], 0);
+            if (he != hipSuccess) {
+                (void)hipStreamSynchronize(side);
+                if (!rc) rc = hip_fail(he, "gfa_ntt_dist: event");
+            }
         }
     }
     if (!rc) {
@@ -194,8 +209,6 @@ int gfa_ntt_dist(gfa_field_t *f, void *nccl_comm, int rank, int world, const voi
         }
     }
     const hipError_t fe = gfa::scratch_free(work, st);
-    for (auto &e : ev)
-        if (e) (void)hipEventDestroy(e);
     if (rc) return rc;
     GFA_HIP(fe);
     return GFA_OK;

@@ -380,6 +380,138 @@ __global__ __launch_bounds__(G * (32 << LOGR0)) void ntt_m32_one_kernel(const i3
 }
 
 // ------------------------------------------------------------------------------------------------
+// 2^16 points in ONE pass over HBM: one 1024-thread workgroup owns one whole transform, 64 points per thread
+// ------------------------------------------------------------------------------------------------
+// The shape of the GF(65537) kernel (gfa_ntt_fermat.hip) with Montgomery arithmetic: N = 64 * 32 * 32,
+//   n = 1024 a + m, m = 32 b + r,  k = k0 + 64 (k1 + 32 k2):   n k = 1024 a k0 + m k0 + 2048 b k1 + 64 r k1 + 2048 r k2  (mod 2^16)
+//   network 0: thread m = tid, radix 64 over a (stride 1024: every load a full 256-byte wave access), times w^(m k0) -- a per-thread
+//              Montgomery progression seeded with w^m (as in the 2^11..2^15 kernel: a 256 KiB table costs more in the memory system);
+//   exchange 1 (two rounds of 128 KiB): thread (g, r) collects k0 = g and g + 32: radix 32 over b, times w^(64 r k1) from LDS;
+//   exchange 2 (two rounds): thread (k0 = lane, wv) collects k1 = wv and wv + 16: radix 32 over r; X[k0 + 64 (k1 + 32 k2)] is word
+//              tid + 1024 h + 2048 k2 of the output row.
+// The radix-64 network grows its inputs by 2^6 before the first product: p < 2^25.  Workgroups are persistent (one per CU); the next
+// transform's loads are issued as registers come free.  8 B/point of HBM traffic (the two-pass form moves 16).
+constexpr int B16_E2_PITCH = 33;
+constexpr int B16_EX_WORDS = 16 * 64 * B16_E2_PITCH; // 33792 words >= exchange 1's 32 * 1024
+constexpr size_t B16_LDS_BYTES = sizeof(i32) * (size_t)(B16_EX_WORDS + 2 * 1024);
+
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 5))) void ntt_m32_2e16_kernel(const i32 *in, i32 *out, M32OneArgs a, const i32 *__restrict__ net0,
+                                                            const i32 *__restrict__ net1, const i32 *__restrict__ mid, const i32 *__restrict__ wj, i64 batch)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    i32 *ex = reinterpret_cast<i32 *>(smem_raw);
+    i32 *midl = ex + B16_EX_WORDS; // [k1][r] pairs of w^(64 r k1)
+    const int tid = (int)threadIdx.x;
+    const int voff = tid * 4;
+    const int g = tid >> 5, r = tid & 31;  // exchange 1 / network 1 coordinates
+    const int l = tid & 63, wv = tid >> 6; // exchange 2 / network 2 coordinates
+    i32 *const e1w = ex + tid;
+    const i32 *const e1r = ex + g * 1024 + r;
+    i32 *const e2w = ex + g * B16_E2_PITCH + r;
+    const i32 *const e2r = ex + wv * (64 * B16_E2_PITCH) + l * B16_E2_PITCH;
+    const i32 p = a.p, negp = -a.p;
+    const u32 pinv = a.pinv;
+    {
+        const int k1 = tid >> 5;
+        reinterpret_cast<int2 *>(midl)[tid] = reinterpret_cast<const int2 *>(mid)[r * k1];
+    }
+    const i32 ratio = wj[tid]; // w^m in Montgomery form
+    auto in_rsrc = [&](i64 t) { return __builtin_amdgcn_make_buffer_rsrc((void *)(in + t * 65536), 0, 65536 * 4, 0x00020000); };
+    i32 v[64];
+    {
+        const __amdgpu_buffer_rsrc_t xr = in_rsrc(blockIdx.x);
+#pragma unroll
+        for (int ap = 0; ap < 64; ap++) v[ap] = __builtin_amdgcn_raw_buffer_load_b32(xr, voff, ap * 4096, 0);
+    }
+    for (i64 tr_i = blockIdx.x; tr_i < batch; tr_i += gridDim.x) {
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)(out + tr_i * 65536), 0, 65536 * 4, 0x00020000);
+        const bool has_next = tr_i + gridDim.x < batch;
+        const __amdgpu_buffer_rsrc_t xn = in_rsrc(has_next ? tr_i + gridDim.x : tr_i);
+        // ---- network 0 and the first twiddle: Y[k0] * w^(m k0), t <- t * w^m ----
+        dif<6>(v, net0, p);
+        v[0] = mulm(v[0], a.one, a.onep, p);
+        {
+            i32 t = ratio;
+#pragma unroll
+            for (int k0 = 1; k0 < 64; k0++) {
+                v[brev_c(k0, 6)] = mulm1(v[brev_c(k0, 6)], t, pinv, negp);
+                if (k0 + 1 < 64) t = mulm1(t, ratio, pinv, negp);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- exchange 1 + network 1 ----
+        i32 w[2][32];
+        auto net1f = [&](int h) {
+            dif<5>(w[h], net1, p);
+            const int2 *mrow = reinterpret_cast<const int2 *>(midl) + r;
+            w[h][0] = mulm(w[h][0], a.one, a.onep, p);
+#pragma unroll
+            for (int k1 = 1; k1 < 32; k1++) {
+                const int2 wt = mrow[k1 * 32];
+                w[h][brev_c(k1, 5)] = mulm_v(w[h][brev_c(k1, 5)], wt.x, wt.y, p);
+            }
+        };
+        lds_barrier(); // the previous transform's exchange-2 reads (first round: the staging of midl) are complete
+#pragma unroll
+        for (int kl = 0; kl < 32; kl++) e1w[kl * 1024] = v[brev_c(kl, 6)];
+        lds_barrier();
+#pragma unroll
+        for (int bp = 0; bp < 32; bp++) w[0][bp] = e1r[bp * 32];
+        lds_barrier();
+#pragma unroll
+        for (int kl = 0; kl < 32; kl++) e1w[kl * 1024] = v[brev_c(kl + 32, 6)];
+        net1f(0);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();
+#pragma unroll
+        for (int bp = 0; bp < 32; bp++) w[1][bp] = e1r[bp * 32];
+        net1f(1);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- exchange 2 + network 2 ----
+        i32 z[2][32];
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int kl = 0; kl < 16; kl++) e2w[kl * (64 * B16_E2_PITCH) + 32 * i * B16_E2_PITCH] = w[i][brev_c(kl, 5)];
+        lds_barrier();
+#pragma unroll
+        for (int rp = 0; rp < 32; rp++) z[0][rp] = e2r[rp];
+        lds_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int kl = 0; kl < 16; kl++) e2w[kl * (64 * B16_E2_PITCH) + 32 * i * B16_E2_PITCH] = w[i][brev_c(kl + 16, 5)];
+        const i32 fin = a.fin, finp = a.finp;
+        auto net2f = [&](int h) {
+            dif<5>(z[h], net1, p);
+#pragma unroll
+            for (int k2 = 0; k2 < 32; k2++) {
+                i32 x = mulm(z[h][brev_c(k2, 5)], fin, finp, p); // (-p, p)
+                x += p & (x >> 31);                               // [0, p)
+                __builtin_amdgcn_raw_buffer_store_b32(x, yr, voff, (2048 * k2 + 1024 * h) * 4, 0);
+            }
+        };
+        net2f(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) {
+#pragma unroll
+            for (int ap = 0; ap < 32; ap++) v[ap] = __builtin_amdgcn_raw_buffer_load_b32(xn, voff, ap * 4096, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();
+#pragma unroll
+        for (int rp = 0; rp < 32; rp++) z[1][rp] = e2r[rp];
+        net2f(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) {
+#pragma unroll
+            for (int ap = 32; ap < 64; ap++) v[ap] = __builtin_amdgcn_raw_buffer_load_b32(xn, voff, ap * 4096, 0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side: tables and plans
 // ------------------------------------------------------------------------------------------------
 __global__ void m32_progression_table_kernel(u32 p, u32 omega, int logn, int log2, int logr1, i32 *t0, i32 *ratio)
@@ -508,7 +640,7 @@ int build_plan(M32Plan *pl, u64 p, i64 n, u64 omega, hipStream_t st)
         if ((rc = upload(h, net_a))) return rc;
         return pair_table(p, pinv, omega, wl_mult, (int)Lh, mid);
     };
-    if (logn >= 11 && logn <= 15) {
+    if (logn >= 11 && logn <= 16) {
         const int R0 = (int)(n >> 10);
         auto pairs = [&](u64 w, int count, i32 **d) -> int { // Montgomery form of w^e and its companion, e < count
             std::vector<i32> h;
@@ -655,6 +787,20 @@ int launch_one_t(const i32 *in, i32 *out, const M32OneArgs &oa, i64 batch, const
     return GFA_OK;
 }
 
+int launch_2e16(const i32 *in, i32 *out, const M32OneArgs &oa, i64 batch, const M32Plan *pl, hipStream_t st)
+{
+    static bool attr = false;
+    if (!attr) {
+        GFA_HIP(hipFuncSetAttribute((const void *)ntt_m32_2e16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    static const int cus = [] { int dev = 0, n = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }();
+    const i64 grid = std::min<i64>(batch, cus); // persistent: one workgroup per CU (LDS-limited)
+    hipLaunchKernelGGL(ntt_m32_2e16_kernel, dim3((unsigned)grid), dim3(1024), B16_LDS_BYTES, st, in, out, oa, pl->one_net0, pl->one_net1, pl->one_mid, pl->one_wj, batch);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
 int launch_one(int logr0, const i32 *in, i32 *out, const M32OneArgs &oa, i64 batch, const M32Plan *pl, hipStream_t st)
 {
     switch (logr0) {
@@ -720,11 +866,15 @@ int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 
         return launch(pl->log1, src, dst, a, 1, pl->net1, pl->mid1, nullptr, nullptr, st, 0);
     }
     static const int one_pass = env_int("GFA_M32_ONE", 1);
-    if (one_pass && pl->one_wj && batch <= 0x7fffffff) {
+    // 2^16 points: one workgroup per transform needs p < 2^25 (the radix-64 network's growth) and enough transforms to fill the chip
+    static const int min16 = env_int("GFA_M32_2E16_MIN_BATCH", 64);
+    const bool is16 = pl->log1 + pl->log2 == 16;
+    if (one_pass && pl->one_wj && batch <= 0x7fffffff && (!is16 || (fd.p < (1ull << 25) && batch >= min16))) {
         M32OneArgs oa{};
         oa.p = base.p; oa.pinv = pinv;
         oa.one = mont_centred(1, fd.p); oa.onep = (i32)((u32)oa.one * pinv);
         oa.fin = base.fin; oa.finp = base.finp;
+        if (is16) return launch_2e16(src, dst, oa, batch, pl, st);
         return launch_one((int)(pl->log1 + pl->log2 - 10), src, dst, oa, batch, pl, st);
     }
     const i64 n1 = (i64)1 << pl->log1, n2 = (i64)1 << pl->log2;

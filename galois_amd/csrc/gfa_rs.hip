@@ -847,7 +847,9 @@ __global__ __launch_bounds__(128 * WPS) __attribute__((amdgpu_waves_per_eu(WPS, 
     // so that a half-wave holds one root per bank where the roots allow it (aux: 64 x-values, 64 source lanes, 256 positions).
     // PMC history of this kernel (2^17 words, e ~ U{0..16}): r02 89 M vector instructions / 81 M LDS cycles (50 % conflicts);
     // every product as row(x) + value, one v_xad per step: 53 M / 121 M (72 % conflicts, slower); this arrangement: see DESIGN.
-    if (lds_addr(lds_raw) != 0) __builtin_trap(); // the Horner gathers add the table offset as an immediate
+    // The Horner gathers add the table offset as an immediate and ds_append addresses the claim counter through M0[15:0]: the
+    // dynamic LDS block must start at address 0, i.e. the kernel must own no static LDS -- checked on the host before the launch
+    // (decode_lds_base_is_zero; GFA_ERR_UNSUPPORTED instead of a device trap).
     constexpr u32 TBL = 16;
     u32 synp = (u32)aux_g[lane] | ((u32)aux_g[64 + lane] << 10); // byte 0: root evaluated by this lane; bits 8..15: 4 * (lane holding S_lane)
     { // byte 2: the root's 16th power
@@ -1255,6 +1257,19 @@ RsTables make_tables(const FieldDeviceState &ds)
     RsTables t;
     t.mul8 = ds.mul8; t.add8 = ds.add8; t.neg8 = ds.neg8; t.inv8 = ds.inv8; t.exp8 = ds.exp8; t.log8 = ds.log8;
     return t;
+}
+
+// rs_decode_bin_kernel needs its dynamic LDS at address 0 (see the kernel): true exactly when the compiled kernel has no static LDS
+template <typename K>
+int decode_lds_base_is_zero(K kern)
+{
+    hipFuncAttributes fa;
+    GFA_HIP(hipFuncGetAttributes(&fa, (const void *)kern));
+    if (fa.sharedSizeBytes != 0) {
+        set_error("Reed-Solomon wave decoder: the kernel image carries static LDS, its tables would not start at LDS address 0");
+        return GFA_ERR_UNSUPPORTED;
+    }
+    return GFA_OK;
 }
 
 template <typename K>
@@ -1718,6 +1733,10 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
 #define GFA_K2(SV, W, IDX)                                                                                              \
     do {                                                                                                                \
         static bool attr = false;                                                                                       \
+        if (!attr && (rc = decode_lds_base_is_zero(rs_decode_bin_kernel<SV, W>))) {                                     \
+            (void)gfa::scratch_free(rem, st);                                                                           \
+            return rc;                                                                                                  \
+        }                                                                                                               \
         if ((rc = set_lds_limit(rs_decode_bin_kernel<SV, W>, &attr))) return rc;                                        \
         hipLaunchKernelGGL((rs_decode_bin_kernel<SV, W>), dim3(grid), dim3(nwaves * 64), lds, st, make_tables(*ds), rpk, \
                            erasures, rem, cd->aux8, (int)ns, (uint8_t *)out_codeword, (i64 *)out_n_errors, batch);      \

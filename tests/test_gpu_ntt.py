@@ -602,3 +602,44 @@ def test_signed_montgomery_kernel_every_line_shape_at_the_magnitude_limit(p, log
     one = GF(rows[3])
     assert np.array_equal(np.fft.fft(one).numpy(), got[3])
     assert np.array_equal(np.fft.ifft(np.fft.fft(one)).numpy(), rows[3])
+
+
+@pytest.mark.parametrize("p", [7340033, 33292289, 67043329])
+def test_2e16_points_in_one_workgroup_over_generic_primes(p):
+    """2^16-point transforms over odd p < 2^25 in batches >= 64 run as ONE pass over HBM (ntt_m32_2e16_kernel: 64 points per
+    thread, radix 64 x 32 x 32).  33292289 = 508 * 2^16 + 1 sits 0.8 % below 2^25, the bound the radix-64 network's growth
+    sets; 67043329 is above it and must keep the two-pass route with identical results.  Worst-case rows (all p - 1,
+    alternating 0 / p - 1, an impulse, values within 3 of p) against the oracle, every row against the two-pass kernels
+    (batches below 64 take those), scaled inverse in place as a round trip, 65 rows so that a persistent workgroup runs a
+    second, shorter round."""
+    import torch
+    from galois_amd import _lib as L
+
+    lib = L.lib()
+    GF = ga.GF(p)
+    F = O.OracleField(p, 1, None, int(GF.primitive_element))
+    n, batch = 1 << 16, 65
+    rng = np.random.default_rng(p & 0xffff)
+    x = rng.integers(0, p, (batch, n), dtype=np.uint32)
+    x[0] = p - 1
+    x[1, ::2] = 0; x[1, 1::2] = p - 1
+    x[2] = 0; x[2, 0] = p - 1
+    x[3] = (p - 1 - rng.integers(0, 3, n)).astype(np.uint32)
+    x[4, : n // 2] = p - 1; x[4, n // 2:] = 1
+    xt = torch.from_numpy(x.view(np.int32)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    w = GF._root_of_unity_int(n)
+    for j in (1, 3):
+        wj = pow(w, j, p)
+        out = torch.empty_like(xt)
+        L.check(lib.gfa_ntt(GF._handle, xt.data_ptr(), out.data_ptr(), n, batch, wj, 0, L.U32, st))
+        got = out.cpu().numpy().view(np.uint32)
+        for i in (0, 1, 2, 3, 4, 17, 64):
+            H.assert_equal_ints(got[i], F.ntt_u32_pow2(x[i], wj), f"p={p} root w^{j}, row {i}")
+        ref = torch.empty_like(xt)
+        for b0 in range(0, batch, 13):
+            b1 = min(batch, b0 + 13)
+            L.check(lib.gfa_ntt(GF._handle, xt[b0:b1].data_ptr(), ref[b0:b1].data_ptr(), n, b1 - b0, wj, 0, L.U32, st))
+        assert torch.equal(out, ref), f"p={p} root w^{j}: one-pass and two-pass kernels differ"
+        L.check(lib.gfa_ntt(GF._handle, out.data_ptr(), out.data_ptr(), n, batch, pow(wj, p - 2, p), 1, L.U32, st))
+        assert torch.equal(out, xt), f"p={p} inverse, root w^{j}"
