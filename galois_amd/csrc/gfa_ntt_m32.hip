@@ -395,7 +395,7 @@ constexpr int B16_E2_PITCH = 33;
 constexpr int B16_EX_WORDS = 16 * 64 * B16_E2_PITCH; // 33792 words >= exchange 1's 32 * 1024
 constexpr size_t B16_LDS_BYTES = sizeof(i32) * (size_t)(B16_EX_WORDS + 2 * 1024);
 
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 5))) void ntt_m32_2e16_kernel(const i32 *in, i32 *out, M32OneArgs a, const i32 *__restrict__ net0,
+__global__ __launch_bounds__(1024) void ntt_m32_2e16_kernel(const i32 *in, i32 *out, M32OneArgs a, const i32 *__restrict__ net0,
                                                             const i32 *__restrict__ net1, const i32 *__restrict__ mid, const i32 *__restrict__ wj, i64 batch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -429,12 +429,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 5))) vo
         const __amdgpu_buffer_rsrc_t xn = in_rsrc(has_next ? tr_i + gridDim.x : tr_i);
         // ---- network 0 and the first twiddle: Y[k0] * w^(m k0), t <- t * w^m ----
         dif<6>(v, net0, p);
+        __builtin_amdgcn_sched_barrier(0);
         v[0] = mulm(v[0], a.one, a.onep, p);
         {
             i32 t = ratio;
 #pragma unroll
             for (int k0 = 1; k0 < 64; k0++) {
-                v[brev_c(k0, 6)] = mulm1(v[brev_c(k0, 6)], t, pinv, negp);
+                // the application in 32-bit registers only (companion = one more multiply), the progression through the 64-bit
+                // multiply-add: with BOTH as v_mad_i64_i32 the even-aligned register pairs beside 64 live points cost 52-108 bytes
+                // of scratch per thread and 8-15 % of the kernel (profiles/r04_m32_2e16.txt)
+                v[brev_c(k0, 6)] = mulm_v(v[brev_c(k0, 6)], t, (i32)((u32)t * pinv), p);
                 if (k0 + 1 < 64) t = mulm1(t, ratio, pinv, negp);
             }
         }
@@ -483,6 +487,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 5))) vo
 #pragma unroll
             for (int kl = 0; kl < 16; kl++) e2w[kl * (64 * B16_E2_PITCH) + 32 * i * B16_E2_PITCH] = w[i][brev_c(kl + 16, 5)];
         const i32 fin = a.fin, finp = a.finp;
+        auto next_loads = [&](int lo, int hi) { // unconditional (the last round re-reads its own row): no control flow in the loop body
+#pragma unroll
+            for (int ap = lo; ap < hi; ap++) v[ap] = __builtin_amdgcn_raw_buffer_load_b32(xn, voff, ap * 4096, 0);
+        };
         auto net2f = [&](int h) {
             dif<5>(z[h], net1, p);
 #pragma unroll
@@ -494,20 +502,14 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 5))) vo
         };
         net2f(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (has_next) {
-#pragma unroll
-            for (int ap = 0; ap < 32; ap++) v[ap] = __builtin_amdgcn_raw_buffer_load_b32(xn, voff, ap * 4096, 0);
-        }
+        next_loads(0, 32);
         __builtin_amdgcn_sched_barrier(0);
         lds_barrier();
 #pragma unroll
         for (int rp = 0; rp < 32; rp++) z[1][rp] = e2r[rp];
         net2f(1);
         __builtin_amdgcn_sched_barrier(0);
-        if (has_next) {
-#pragma unroll
-            for (int ap = 32; ap < 64; ap++) v[ap] = __builtin_amdgcn_raw_buffer_load_b32(xn, voff, ap * 4096, 0);
-        }
+        next_loads(32, 64);
     }
 }
 

@@ -583,7 +583,7 @@ def test_ordering_and_editing_functions_follow_numpy_on_the_integer_values(order
     assert np.array_equal(ints(np.insert(row, [5, 1], mk([1, 2]))), np.insert(h[0], [5, 1], [1, 2]))
     assert np.array_equal(ints(np.insert(row, [3, 3, 0], mk([1, 2, 3]))), np.insert(h[0], [3, 3, 0], [1, 2, 3]))
     assert np.array_equal(ints(np.insert(x, [4, 1], mk([[1], [2]]), axis=0)), np.insert(h, [4, 1], [[1], [2]], axis=0))
-    assert np.array_equal(ints(np.insert(x, 3, mk([1, 2]), axis=1)), np.insert(h, 3, [1, 2], axis=1))
+    assert np.array_equal(ints(np.insert(x, 3, mk([1, 2, 3, 4, 5]), axis=1)), np.insert(h, 3, [1, 2, 3, 4, 5], axis=1))
     assert np.array_equal(ints(np.take(x, [0, 8, 3], axis=-1)), np.take(h, [0, 8, 3], axis=-1))
     assert np.array_equal(ints(np.take(x, [[0, 1], [2, 3]], axis=-2)), np.take(h, [[0, 1], [2, 3]], axis=-2))
 
