@@ -333,7 +333,7 @@ class WideFieldArray(FieldArray):
             axis = axis % c.dim()
             c2 = c.movedim(axis, -1)
             lead = tuple(c2.shape[:-1])
-            c2 = c2.reshape(-1, c2.shape[-1])
+            c2 = c2.reshape(int(np.prod(lead, dtype=np.int64)), c2.shape[-1])  # (an explicit row count: the axis may be empty)
         c2 = c2.contiguous()
         n_outer, n_inner = c2.shape
         if n_inner == 0:

@@ -825,6 +825,63 @@ __device__ __forceinline__ int lane_shift_up1(int v, int)
     return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);
 }
 
+// ---- test-only: the hand-assembled bm_run against a loop the COMPILER generates from the same recurrence ----
+// One wave per sequence S[0 .. nsq - 1] (bytes of GF(2^8)); both forms start from the kernel's initial frame and run the kernel's
+// two calls (31 steps, then the 32nd with the product half of Y cleared).  Every lane's X and Y, gamma's row, L and the step
+// count must agree; out[seq] = number of lanes that differ (+ 64 per differing scalar).
+__device__ __forceinline__ void bm_ref_run(u32 &X, u32 &Y, u32 &G, int &L, int &r, int limit, int nsq, const uint8_t *mul_t, int lane)
+{
+    while (r < limit) {
+        const u32 d0 = (u32)__builtin_amdgcn_readfirstlane((int)X);
+        const u32 A = (u32)__builtin_amdgcn_update_dpp(0, (int)X, 0x130, 0xf, 0xf, true); // lane l <- lane l + 1, lane 63 <- 0
+        if (d0 == 0) {
+            const unsigned long long nz = __builtin_amdgcn_ballot_w64(X != 0 && lane < nsq - r);
+            if (nz == 0) return; // nothing but zero discrepancies to come
+            X = A;
+            r++;
+            continue;
+        }
+        const u32 Xn = (u32)mul_t[G + A] ^ (u32)mul_t[(d0 << 8) + Y];
+        if (!(2 * L > r)) { Y = A; G = d0 << 8; L = r + 1 - L; }
+        X = Xn;
+        r++;
+    }
+}
+
+__global__ __launch_bounds__(256) void rs_bm_selftest_kernel(const uint8_t *__restrict__ mul8, const uint8_t *__restrict__ seqs,
+                                                             const int *__restrict__ lens, int *__restrict__ out, i64 nseq)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    uint8_t *mul_t = lds_raw + 16; // where bm_run's immediates expect the product table (dynamic LDS starts at 0: no static LDS here)
+    {
+        const uint4 *s = reinterpret_cast<const uint4 *>(mul8);
+        uint4 *d = reinterpret_cast<uint4 *>(mul_t);
+        for (int i = threadIdx.x; i < 4096; i += blockDim.x) d[i] = s[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const i64 wave0 = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((i64)gridDim.x * blockDim.x) >> 6;
+    for (i64 q = wave0; q < nseq; q += nwaves) {
+        const int nsq = __builtin_amdgcn_readfirstlane(lens[q]);
+        const u32 x0 = lane == 63 ? 1u : (lane < nsq ? (u32)seqs[q * 32 + lane] : 0u);
+        u32 Xa = x0, Ya = x0, Ga = 1u << 8, Xb = x0, Yb = x0, Gb = 1u << 8;
+        int La = 0, ra = 0, Lb = 0, rb = 0;
+        const int rmain = nsq < 31 ? nsq : 31;
+        bm_run(Xa, Ya, Ga, La, ra, rmain, nsq);
+        if (ra == 31 && nsq == 32) {
+            Ya = lane < 32 ? 0u : Ya;
+            bm_run(Xa, Ya, Ga, La, ra, 32, nsq);
+        }
+        bm_ref_run(Xb, Yb, Gb, Lb, rb, rmain, nsq, mul_t, lane);
+        if (rb == 31 && nsq == 32) {
+            Yb = lane < 32 ? 0u : Yb;
+            bm_ref_run(Xb, Yb, Gb, Lb, rb, 32, nsq, mul_t, lane);
+        }
+        const unsigned long long bad = __builtin_amdgcn_ballot_w64(Xa != Xb || Ya != Yb || Ga != Gb);
+        if (lane == 0) out[q] = __popcll(bad) + (La != Lb ? 64 : 0) + (ra != rb ? 64 : 0);
+    }
+}
+
 // WPS = resident waves per SIMD the register budget is sized for (block = 2 * WPS waves, two blocks per CU)
 template <int S, int WPS>
 __global__ __launch_bounds__(128 * WPS) __attribute__((amdgpu_waves_per_eu(WPS, WPS))) void rs_decode_bin_kernel(RsTables t, RsParams rp, const uint8_t *__restrict__ eras_g,
@@ -1802,6 +1859,71 @@ int gfa_time_rs_decode(gfa_rs_t *code, const void *recv, int64_t ns, void *out_c
     return gfa::time_loop((hipStream_t)stream, iters, ms_out, [&]() {
         return gfa_rs_decode(code, recv, nullptr, ns, out_codeword, out_n_errors, batch, dtype, stream);
     });
+}
+
+// Test-only (tests/test_gpu_rs.py): runs rs_bm_selftest_kernel on `nseq` sequences drawn from `seed` -- a third random bytes of
+// random length 1..32, a third outputs of random LFSRs of length <= 16 (what a correctable word produces: the run ends early on
+// zero discrepancies), a third with leading / embedded zeros -- and returns the number of sequences on which the hand-assembled
+// loop and the compiler-generated one disagree.
+int gfa_debug_rs_bm_selftest(gfa_field_t *f, int64_t nseq, uint64_t seed, int64_t *mismatches, gfa_stream_t stream)
+{
+    if (!f || !mismatches || nseq < 1 || !f->has_tab8 || f->calc.p != 2 || gfa_field_order(f) != 256) {
+        set_error("gfa_debug_rs_bm_selftest: a GF(2^8) field, nseq >= 1");
+        return GFA_ERR_INVALID;
+    }
+    int rc, dev = 0;
+    FieldDeviceState *ds = nullptr;
+    if ((rc = f->ensure_device(&dev, &ds))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<uint8_t> seqs((size_t)nseq * 32), mul(65536);
+    std::vector<int> lens((size_t)nseq);
+    for (u32 a = 0; a < 256; a++)
+        for (u32 b = 0; b < 256; b++) mul[(a << 8) | b] = (uint8_t)HostArith::mul(f->calc, a, b);
+    u64 sd = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto rnd = [&]() { sd ^= sd << 13; sd ^= sd >> 7; sd ^= sd << 17; return (u32)(sd >> 24); };
+    for (i64 q = 0; q < nseq; q++) {
+        uint8_t *S = &seqs[(size_t)q * 32];
+        const int nsq = (q % 4 == 3) ? 32 : 1 + (int)(rnd() % 32);
+        lens[(size_t)q] = nsq;
+        const int cls = (int)(q % 3);
+        if (cls == 0) {
+            for (int i = 0; i < 32; i++) S[i] = (uint8_t)rnd();
+        } else if (cls == 1) { // S_i = sum_j c_j S_{i-j}: an LFSR of length len <= 16
+            const int len = 1 + (int)(rnd() % 16);
+            uint8_t c[16];
+            for (int j = 0; j < len; j++) c[j] = (uint8_t)rnd();
+            for (int i = 0; i < 32; i++) {
+                if (i < len) { S[i] = (uint8_t)rnd(); continue; }
+                u32 acc = 0;
+                for (int j = 0; j < len; j++) acc ^= mul[((u32)c[j] << 8) | S[i - 1 - j]];
+                S[i] = (uint8_t)acc;
+            }
+        } else {
+            const int z = (int)(rnd() % 33);
+            for (int i = 0; i < 32; i++) S[i] = (i < z || rnd() % 4 == 0) ? 0 : (uint8_t)rnd();
+        }
+    }
+    uint8_t *d_seq = nullptr;
+    int *d_len = nullptr, *d_out = nullptr;
+    GFA_HIP(gfa::scratch_alloc((void **)&d_seq, seqs.size(), st));
+    GFA_HIP(gfa::scratch_alloc((void **)&d_len, lens.size() * sizeof(int), st));
+    GFA_HIP(gfa::scratch_alloc((void **)&d_out, lens.size() * sizeof(int), st));
+    GFA_HIP(hipMemcpyAsync(d_seq, seqs.data(), seqs.size(), hipMemcpyHostToDevice, st));
+    GFA_HIP(hipMemcpyAsync(d_len, lens.data(), lens.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    static bool attr = false;
+    if ((rc = decode_lds_base_is_zero(rs_bm_selftest_kernel))) return rc;
+    if ((rc = set_lds_limit(rs_bm_selftest_kernel, &attr))) return rc;
+    const int grid = (int)std::max<i64>(1, std::min<i64>((nseq + 3) / 4, 4 * (i64)cu_count()));
+    hipLaunchKernelGGL(rs_bm_selftest_kernel, dim3(grid), dim3(256), 65536 + 16, st, ds->mul8, d_seq, d_len, d_out, (i64)nseq);
+    GFA_HIP(hipGetLastError());
+    std::vector<int> out((size_t)nseq);
+    GFA_HIP(hipMemcpyAsync(out.data(), d_out, out.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    GFA_HIP(hipStreamSynchronize(st));
+    (void)gfa::scratch_free(d_seq, st); (void)gfa::scratch_free(d_len, st); (void)gfa::scratch_free(d_out, st);
+    i64 bad = 0;
+    for (int v : out) bad += v != 0;
+    *mismatches = bad;
+    return GFA_OK;
 }
 
 } // extern "C"

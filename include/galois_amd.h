@@ -325,6 +325,10 @@ int gfa_time_rs_decode(gfa_rs_t *code, const void *recv, int64_t ns, void *out_c
 /* Tuning aid of the GF(65537) one-pass transform (tools/fermat_phases.py): when `buf` is not NULL the kernel records eight
  * 100 MHz timestamps per (workgroup, round) there; NULL switches the recording off again.  Not part of the product path. */
 void gfa_debug_fermat_stamps(unsigned long long *buf);
+/* Test-only: the hand-assembled Berlekamp-Massey loop of the Reed-Solomon wave decoder (replaces berlekamp_massey_jit,
+ * _lfsr.py:1647-1702, inside bch_decode_jit) against a compiler-generated loop of the same recurrence, on `nseq` syndrome
+ * sequences derived from `seed` over a GF(2^8) field; *mismatches = sequences on which the two disagree (must be 0). */
+int gfa_debug_rs_bm_selftest(gfa_field_t *f, int64_t nseq, uint64_t seed, int64_t *mismatches, gfa_stream_t stream);
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop

@@ -472,8 +472,9 @@ def test_distributed_inverse_emulated_on_one_gpu():
 
 def test_c5_full_size_emulated_on_one_gpu():
     """BASELINE config C5 at its real size: 2^26 Goldilocks points split 1024 x 65536 over G = 8 ranks, every rank's kernels
-    run on this GPU with the exchange emulated, compared with the single-GPU three-pass transform (itself pinned by the
-    oracle at 2^21 / 2^23 and by the properties below), then inverted back through the distributed inverse."""
+    run on this GPU with the exchange emulated.  The ORACLE (oracle/gf_oracle.c, the reference's fft_jit restated) transforms
+    the same 2^26 points on the host -- about a minute -- and EVERY output of both the single-GPU three-pass transform and
+    the four-step emulation is compared with it; then the distributed inverse takes the result back."""
     import torch
     from galois_amd import dist as gdist
 
@@ -491,6 +492,10 @@ def test_c5_full_size_emulated_on_one_gpu():
     omega = GF._root_of_unity_int(n)
     gx = GF._wrap(x, np.object_)
     want = np.fft.fft(gx)._t  # single-GPU path
+    F = O.OracleField(order, 1, None, int(GF.primitive_element))
+    oracle_X = F.ntt(xu.copy(), omega=omega)
+    assert np.array_equal(want.cpu().numpy().view(np.uint64), oracle_X), "single-GPU 2^26-point transform differs from the oracle"
+    del oracle_X  # (from here on `want` IS the oracle's vector)
     cols = n2 // G
     xm = x.view(n1, n2)
     locals_ = [xm[:, g * cols:(g + 1) * cols].contiguous() for g in range(G)]
@@ -643,3 +648,33 @@ def test_2e16_points_in_one_workgroup_over_generic_primes(p):
         assert torch.equal(out, ref), f"p={p} root w^{j}: one-pass and two-pass kernels differ"
         L.check(lib.gfa_ntt(GF._handle, out.data_ptr(), out.data_ptr(), n, batch, pow(wj, p - 2, p), 1, L.U32, st))
         assert torch.equal(out, xt), f"p={p} inverse, root w^{j}"
+
+
+def test_2e26_points_over_a_32_bit_prime_against_the_oracle_in_full():
+    """The other half of the C5 pin: 2^26 points over GF(469762049) (7 * 2^26 + 1, the CRT-convolution prime and a default
+    `galois.ntt` modulus for large inputs, _ntt.py:250-254), single-GPU transform and the four-step emulation over 8 ranks,
+    every output against oracle/gf_oracle.c."""
+    import torch
+    from galois_amd import dist as gdist
+
+    p = 469762049
+    GF = ga.GF(p)
+    F = O.OracleField(p, 1, None, int(GF.primitive_element))
+    G = 8
+    n = 1 << 26
+    n1, n2 = gdist.choose_split(n, G)
+    rng = np.random.default_rng(26)
+    xu = rng.integers(0, p, n, dtype=np.uint32)
+    xu[:4] = (p - 1, 0, p - 1, 1)
+    omega = GF._root_of_unity_int(n)
+    want = F.ntt_u32_pow2(xu, omega)
+    x = torch.from_numpy(xu.view(np.int32)).cuda()
+    got = np.fft.fft(GF._wrap(x, np.uint32))._t
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want), "single-GPU 2^26-point transform differs from the oracle"
+    cols, rows = n2 // G, n1 // G
+    xm = x.view(n1, n2)
+    locals_ = [xm[:, g * cols:(g + 1) * cols].contiguous() for g in range(G)]
+    fwd = _emulate_forward(GF, locals_, n1, n2, G, omega)
+    wv = torch.from_numpy(want.view(np.int32)).cuda().view(n2, n1)  # X[k1 + n1*k2] -> [k2][k1]
+    for g in range(G):
+        assert torch.equal(fwd[g], wv[:, g * rows:(g + 1) * rows].t().contiguous()), f"rank {g}"

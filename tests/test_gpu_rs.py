@@ -325,3 +325,34 @@ def test_c_abi_decode_in_place_wide_field():
                                   torch.cuda.current_stream().cuda_stream), "gfa_rs_decode")
     assert np.array_equal(nerr.cpu().numpy(), wn)
     assert np.array_equal(buf.cpu().numpy().astype(np.int64), want.astype(np.int64))
+
+
+@pytest.mark.parametrize("wps", ["4", "5", "6", "8"])
+def test_wave_decoder_stress_at_every_occupancy_setting(wps):
+    """tools/rs_decode_stress.py in its own process per GFA_RS_WPS (the library reads the knob once): 2^20 words per case at
+    0 / t / t + 1 errors, with and without erasures, every word checked by property, a sample by the oracle."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rs_decode_stress.py")], cwd=root, capture_output=True, text=True,
+                       timeout=1200, env=dict(os.environ, GFA_RS_WPS=wps))
+    assert r.returncode == 0 and "rs decode stress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("poly", [0x11D, 0x11B])
+def test_assembled_berlekamp_massey_loop_against_the_compiler_generated_one(poly):
+    """bm_run (inline assembly, hand-placed wait states) and a plain loop compiled from the same recurrence run side by side on
+    the device over 600 000 syndrome sequences per field (random, LFSR-generated with early termination, zero-ridden; lengths
+    1..32 incl. the 32nd-step corner): every lane of both polynomials, gamma, L and the step count must agree."""
+    import ctypes
+    import torch
+    from galois_amd import _lib as L
+
+    GF = ga.GF(2**8, irreducible_poly=poly)
+    st = torch.cuda.current_stream().cuda_stream
+    for seed in (1, 2, 3):
+        bad = ctypes.c_int64(-1)
+        L.check(L.lib().gfa_debug_rs_bm_selftest(GF._handle, 200_000, seed, ctypes.byref(bad), st), "gfa_debug_rs_bm_selftest")
+        assert bad.value == 0, f"poly {poly:#x} seed {seed}: {bad.value} sequences differ"
