@@ -416,6 +416,33 @@ def extras_distributed(ga, L, lib, stream, dist, rank, world):
     return ex
 
 
+def _all_cores(fn_of_index, seconds=3.0):
+    """Calls fn_of_index(i) from one thread per host core for about `seconds` (the oracle's C entry points release the GIL):
+    (calls completed, elapsed seconds, threads) -- the all-cores leg of a cpu_baseline."""
+    import concurrent.futures as cf
+    import itertools
+    import threading
+
+    cores = max(1, min(os.cpu_count() or 1, 128))
+    counter = itertools.count()
+    done = [0] * cores
+    stop = threading.Event()
+
+    def worker(w):
+        while not stop.is_set():
+            fn_of_index(next(counter))
+            done[w] += 1
+
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(max_workers=cores) as ex_:
+        futs = [ex_.submit(worker, w) for w in range(cores)]
+        time.sleep(seconds)
+        stop.set()
+        for f in futs:
+            f.result()
+    return sum(done), time.perf_counter() - t0, cores
+
+
 def extras(ga, L, lib, stream, with_cpu):
     """The NTT and Reed-Solomon parts of the composite metric, on this rank's GPU (not part of the timed region)."""
     from oracle import gf_oracle as O
@@ -504,7 +531,7 @@ def extras(ga, L, lib, stream, with_cpu):
         del at, bt, ot
     # ---- NTT: 2^20 points over GF(7340033) (the modulus galois.ntt picks for that size), batch of 64 ----
     for tag, p, logn, batch in (("ntt_2^20_gf7340033", 7340033, 20, 64), ("ntt_16x2^16_gf65537", 65537, 16, 16 * 64),
-                                ("ntt_2^14_gf7340033", 7340033, 14, 4096)):
+                                ("ntt_2^16_gf7340033", 7340033, 16, 1024), ("ntt_2^14_gf7340033", 7340033, 14, 4096)):
         P = ga.GF(p)
         N = 1 << logn
         omega = P._root_of_unity_int(N)
@@ -519,8 +546,14 @@ def extras(ga, L, lib, stream, with_cpu):
                  "roofline_frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_point": 8}
         if logn == 14:
             entry["note"] = "one pass over HBM: one workgroup per transform, three register networks, two LDS exchanges (gfa_ntt_m32.hip)"
+        elif logn == 16 and p != 65537:
+            entry["note"] = ("one pass over HBM: one 1024-thread workgroup per transform, 64 points per thread, radix 64 x 32 x 32 "
+                             "(ntt_m32_2e16_kernel, r04; the two-pass form of r03 measured 0.30)")
         elif logn == 20:
             entry["2^20_pt_ntt_per_s"] = entry["transforms_per_s"]
+            entry["ceiling_frac"] = 0.333
+            entry["ceiling_source"] = ("profiles/r03_ntt_access_skeleton.txt: the two passes' access pattern with no arithmetic, "
+                                       "0.105 + 0.097 ms for this batch")
             entry["note"] = ("two passes over the array (16 B/point of traffic against the 8 B/point algorithmic minimum this fraction "
                              "is priced on): the same access pattern with NO arithmetic takes 0.20-0.22 ms for this batch "
                              "(tools/ubench/ntt_access.hip, profiles/r03_ntt_access_skeleton.txt), i.e. 0.30-0.335 is the ceiling of any "
@@ -528,6 +561,10 @@ def extras(ga, L, lib, stream, with_cpu):
                              "were measured and do not beat it (DESIGN.md section 4.3)")
         else:
             entry["2^20_points_per_s_equiv"] = round(points / (1 << 20) / (ms.value * 1e-3), 1)
+            entry["ceiling_frac"] = 0.73
+            entry["ceiling_source"] = ("profiles/r04_fermat_experiments.txt section 3: the transform's arithmetic + LDS exchanges with NO HBM traffic run at "
+                                       "the equivalent of 0.62-0.74 (23-27 us per transform and CU), its loads and stores alone at 0.70-0.87; a CU's 512 KiB "
+                                       "register file holds exactly two 2^16-point transforms, so no second one can be resident to cover the first")
             # the same kernel on a batch far larger than the 256 MiB Infinity Cache (4096 transforms: 1 GiB in, 1 GiB out): the
             # HBM-only rate -- at 1024 transforms the 256 MiB input is partly served by the cache from one launch to the next
             big = 4096
@@ -550,6 +587,9 @@ def extras(ga, L, lib, stream, with_cpu):
             dt = time.perf_counter() - t1
             entry["cpu_baseline"] = {"transforms_per_s": round(reps / dt, 2), "cores": 1, "kind": "port",
                                      "sample": f"{reps} transforms of 2^{logn} points, oracle/gf_oracle.c"}
+            calls, dt_all, cores = _all_cores(lambda i: FP.ntt_u32_pow2(xh[i % batch], omega))
+            entry["cpu_baseline_all_cores"] = {"transforms_per_s": round(calls / dt_all, 2), "cores": cores, "kind": "port",
+                                               "sample": f"{calls} transforms of 2^{logn} points from {cores} threads, oracle/gf_oracle.c"}
         ex[tag] = entry
         del xd, od
     # ---- ONE long transform (three passes of the register kernel) and a long polynomial product that needs the CRT route ----
@@ -631,6 +671,26 @@ def extras(ga, L, lib, stream, with_cpu):
                                    ctypes.byref(ms)))
     assert np.array_equal(Dd.cpu().numpy(), C) and bool((Ed == 16).all()), "RS t=16 round trip failed"
     ex["rs_255_223"]["decode_GB/s_16_errors"] = round(255.0 * B / (ms.value * 1e-3) / 1e9, 2)
+    # the whole C4 batch on ONE GPU (2^20 words: 267 MB per array, beyond the 256 MiB Infinity Cache): the HBM-only rates
+    Bf = 1 << 20
+    Mf = torch.empty((Bf, 223), dtype=torch.uint8, device="cuda").random_(0, 256)
+    Cf = torch.empty((Bf, 255), dtype=torch.uint8, device="cuda")
+    L.check(lib.gfa_time_rs_encode(rs._handle, Mf.data_ptr(), 223, Cf.data_ptr(), Bf, L.U8, stream, 5, ctypes.byref(ms)))
+    encf_ms = ms.value
+    Rf = Cf.clone()
+    nef = torch.randint(0, 17, (Bf,), device="cuda")
+    posf = torch.argsort(torch.rand((Bf, 255), device="cuda"), dim=1)[:, :16]
+    valf = torch.randint(1, 256, (Bf, 16), device="cuda", dtype=torch.uint8)
+    valf = torch.where(torch.arange(16, device="cuda")[None, :] < nef[:, None], valf, torch.zeros_like(valf))
+    Rf.scatter_(1, posf, torch.gather(Rf, 1, posf) ^ valf)
+    Df = torch.empty_like(Rf)
+    Ef = torch.empty(Bf, dtype=torch.int64, device="cuda")
+    L.check(lib.gfa_time_rs_decode(rs._handle, Rf.data_ptr(), 255, Df.data_ptr(), Ef.data_ptr(), Bf, L.U8, stream, 5, ctypes.byref(ms)))
+    assert bool(torch.equal(Df, Cf)) and bool(torch.equal(Ef, nef)), "RS round trip failed at 2^20 codewords"
+    ex["rs_255_223"]["hbm_only_2^20_codewords"] = {"encode_GB/s": round(255.0 * Bf / (encf_ms * 1e-3) / 1e9, 2),
+                                                   "decode_GB/s": round(255.0 * Bf / (ms.value * 1e-3) / 1e9, 2),
+                                                   "encode_ms": round(encf_ms, 4), "decode_ms": round(ms.value, 4)}
+    del Mf, Cf, Rf, Df, Ef, posf, valf
     if with_cpu:
         t1 = time.perf_counter()
         OR.encode_u8(M[:2048])
@@ -640,6 +700,11 @@ def extras(ga, L, lib, stream, with_cpu):
         td = time.perf_counter() - t1
         ex["rs_255_223"]["cpu_baseline"] = {"encode_GB/s": round(255.0 * 2048 / te / 1e9, 5), "decode_GB/s": round(255.0 * 2048 / td / 1e9, 5),
                                             "cores": 1, "kind": "port", "sample": "2048 codewords, oracle/gf_oracle.c"}
+        ce, dte, cores = _all_cores(lambda i: OR.encode_u8(M[(i % 256) * 256:(i % 256) * 256 + 256]))
+        cd_, dtd, _ = _all_cores(lambda i: OR.decode_u8(R[(i % 256) * 256:(i % 256) * 256 + 256]))
+        ex["rs_255_223"]["cpu_baseline_all_cores"] = {"encode_GB/s": round(255.0 * 256 * ce / dte / 1e9, 4), "decode_GB/s": round(255.0 * 256 * cd_ / dtd / 1e9, 4),
+                                                      "cores": cores, "kind": "port",
+                                                      "sample": f"{256 * ce} / {256 * cd_} codewords in 256-word calls from {cores} threads, oracle/gf_oracle.c"}
     # ---- binary BCH(255, 223), t = 4: same entry points, symbols in GF(2), syndromes in GF(2^8) ----
     bch = ga.BCH(255, 223)
     Mb = rng.integers(0, 2, (B, 223), dtype=np.uint8)
