@@ -108,8 +108,9 @@ struct Prime32 {
     static GFA_HD u32 redc32(u64 x, u32 p, u32 ninv)
     {
         const u32 m = (u32)x * ninv;
-        const u64 t = (x + (u64)m * p) >> 32; // < 2p; the sum stays below 2^64 because x, m * p < p * 2^32 <= 2^63
-        return (u32)(t >= p ? t - p : t);
+        const u32 t = (u32)((x + (u64)m * p) >> 32); // < 2p < 2^32; the sum stays below 2^64 because x, m * p < p * 2^32 <= 2^63
+        const u32 d = t - p;
+        return d < t ? d : t; // min(t, t - p): t - p wraps above t exactly when t < p (no compare-and-select on the condition mask)
     }
     // a^e.  For odd p < 2^31 the whole exponentiation runs in Montgomery form -- 6 instructions per product instead of the
     // 14 of a 64-bit Barrett reduction; the constants come from the descriptor: 2^64 mod p = -mu * p (mod 2^64), -p^-1 by

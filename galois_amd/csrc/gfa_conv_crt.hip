@@ -147,10 +147,9 @@ namespace gfa {
 // GFA_CONVOLVE_CRT=0 keeps every product on the direct kernel (A/B measurements)
 bool convolve_crt_eligible(const FieldDev &fd, i64 na, i64 nb)
 {
-    static const int enabled = [] { const char *e = getenv("GFA_CONVOLVE_CRT"); return (e && e[0] == '0') ? 0 : 1; }();
-    if (!enabled || fd.kind != KIND_PRIME32 || fd.m != 1) return false;
+    if (fd.kind != KIND_PRIME32 || fd.m != 1) return false;
     const i64 lo = std::min(na, nb), n_out = na + nb - 1;
-    static const i64 min_work = [] { const char *e = getenv("GFA_CONVOLVE_CRT_MIN"); return e ? atoll(e) : ((i64)1 << 22); }();
+    constexpr i64 min_work = (i64)1 << 22;
     if (lo < 64 || n_out > ((i64)1 << CRT_MAX_LOG)) return false;
     // the CRT route costs ~0.1 ms whatever the size (15 launches); the direct kernel is faster below ~2^22 multiply-adds
     // (tools/convolve_bench.py: 4096 x 4096 terms 0.55 ms direct, 0.094 ms here; 2^20 x 2^20 terms 0.38 ms here)

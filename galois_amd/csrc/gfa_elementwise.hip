@@ -84,10 +84,22 @@ struct BatchInv<Bin> {
     static constexpr bool value = true;
 };
 
+// elements one lane inverts together.  32 for 32-bit primes was measured (profiles/r04_ew_prime_recip.txt): the inversion's share halves
+// but the kernel drops to three waves per SIMD -- GF(65537) reciprocal 0.57 against 0.64 with 16
+template <class F, typename T>
+struct BatchN {
+    static constexpr int value = 16;
+};
+
+// 1 for a non-zero element, 0 for zero -- by arithmetic: a select on a compare is a v_cmp + a v_cndmask that reads the condition
+// mask, the slowest vector instruction there is on this part (profiles/r03_valu_issue_rates.txt: 11 lane-ops/clk/CU against 57-110)
+__device__ __forceinline__ u32 nz_flag(u32 x) { return x < 1u ? x : 1u; } // v_min_u32
+
 template <class F, int V>
 __device__ __forceinline__ void batch_inverse(const FieldDev &fd, typename F::elem (&x)[V], bool &bad)
 {
     typedef typename F::elem E;
+    // (64-bit elements keep compare-and-select for the zeros: measured, the arithmetic flags of batch_inverse_m31 cost more there)
     E pre[V]; // pre[j] = x'[0] * ... * x'[j]
     E acc = F::one(fd);
 #pragma unroll
@@ -107,6 +119,57 @@ __device__ __forceinline__ void batch_inverse(const FieldDev &fd, typename F::el
     }
 }
 
+// The same for a prime field with odd p < 2^31 in SKEWED Montgomery form: every product of the trick is a Montgomery reduction
+// (5 instructions: v_mad_u64_u32, v_mul_lo, v_mad_u64_u32, v_sub, v_min) instead of a 64-bit Barrett reduction (14), and no
+// conversion is needed at either end.  pre[j] = redc(pre[j-1] * x_j) = x_0 ... x_j * R^-j, so the plain inverse of the total,
+// T^-1 = (x_0 ... x_{V-1})^-1 * R^(V-1), is exactly the start value the way back needs: with I_j = (x_0 ... x_j)^-1 * R^j,
+// redc(I_j * pre[j-1]) = x_j^-1 (plain) and redc(I_j * x_j) = I_{j-1}.
+template <int V>
+__device__ __forceinline__ void batch_inverse_m31(const FieldDev &fd, u32 (&x)[V], bool &bad)
+{
+    const u32 p = (u32)fd.p;
+    u32 pinv = p; // p * pinv == 1 (mod 2^32)
+    for (int i = 0; i < 4; i++) pinv *= 2u - p * pinv;
+    const u32 ninv = 0u - pinv;
+    auto mm = [&](u32 a, u32 b) -> u32 {
+        const u64 t = (u64)a * b;
+        const u32 m = (u32)t * ninv;
+        const u32 r = (u32)((t + (u64)m * p) >> 32); // < 2p < 2^32
+        const u32 d = r - p;
+        return d < r ? d : r; // min(r, r - p) as unsigned: r - p wraps above r exactly when r < p
+    };
+    u32 pre[V], nz[V];
+    u32 acc = 1, any_zero = 0;
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+        nz[j] = nz_flag(x[j]);
+        const u32 xj = x[j] | (nz[j] ^ 1u);
+        any_zero |= nz[j] ^ 1u;
+        acc = j == 0 ? xj : mm(acc, xj);
+        pre[j] = acc;
+    }
+    bad |= any_zero != 0;
+    u32 inv = Prime32::inv(fd, acc);
+#pragma unroll
+    for (int j = V - 1; j >= 0; j--) {
+        const u32 xj = x[j] | (nz[j] ^ 1u);
+        const u32 r = j == 0 ? inv : mm(inv, pre[j - 1]);
+        inv = mm(inv, xj);
+        x[j] = r & (0u - nz[j]);
+    }
+}
+template <class F, int V>
+__device__ __forceinline__ void batch_inverse_fast(const FieldDev &fd, typename F::elem (&x)[V], bool &bad)
+{
+    if constexpr (std::is_same<F, Prime32>::value) {
+        if ((fd.p & 1) && !(fd.p >> 31)) { // wave-uniform
+            batch_inverse_m31<V>(fd, x, bad);
+            return;
+        }
+    }
+    batch_inverse<F, V>(fd, x, bad);
+}
+
 template <class F, typename T, int OP, bool VEC>
 __global__ __launch_bounds__(256) void ew_binary_kernel(FieldDev fd, const T *__restrict__ a, int sa,
                                                         const T *__restrict__ b, int sb, T *__restrict__ out, i64 n,
@@ -122,18 +185,19 @@ __global__ __launch_bounds__(256) void ew_binary_kernel(FieldDev fd, const T *__
         const E a0 = sa ? 0 : (E)a[0];
         const E b0 = sb ? 0 : (E)b[0];
         i64 i0 = tid;
+        constexpr int NB = BatchN<F, T>::value;
         if constexpr (OP == GFA_OP_DIV && BatchInv<F>::value && (V < 16)) {
             if (sb) { // divisors are an array: invert 16 of them per lane with one exponentiation (see ew_unary_kernel)
-                constexpr int NV = 16 / V;
+                constexpr int NV = NB / V;
                 for (; i0 + (i64)(NV - 1) * nth < nvec; i0 += (i64)NV * nth) {
-                    E yv[16];
+                    E yv[NB];
 #pragma unroll
                     for (int k = 0; k < NV; k++) {
                         const Vec16<T> bv = reinterpret_cast<const Vec16<T> *>(b)[i0 + (i64)k * nth];
 #pragma unroll
                         for (int j = 0; j < V; j++) yv[k * V + j] = (E)bv.v[j];
                     }
-                    batch_inverse<F, 16>(fd, yv, bad);
+                    batch_inverse_fast<F, NB>(fd, yv, bad);
 #pragma unroll
                     for (int k = 0; k < NV; k++) {
                         Vec16<T> av, ov;
@@ -153,7 +217,7 @@ __global__ __launch_bounds__(256) void ew_binary_kernel(FieldDev fd, const T *__
                 E yv[V];
 #pragma unroll
                 for (int j = 0; j < V; j++) yv[j] = sb ? (E)bv.v[j] : b0;
-                batch_inverse<F, V>(fd, yv, bad);
+                batch_inverse_fast<F, V>(fd, yv, bad);
 #pragma unroll
                 for (int j = 0; j < V; j++) ov.v[j] = (T)F::mul(fd, sa ? (E)av.v[j] : a0, yv[j]);
             } else {
@@ -187,19 +251,20 @@ __global__ __launch_bounds__(256) void ew_unary_kernel(FieldDev fd, const T *__r
         constexpr int V = Vec16<T>::N;
         const i64 nvec = n / V;
         i64 i0 = tid;
+        constexpr int NB = BatchN<F, T>::value;
         if constexpr (OP == GFA_OP_RECIP && BatchInv<F>::value && (V < 16)) {
             // Montgomery's trick over 16 elements per lane (16 / V vectors, nth apart so that every load stays coalesced):
             // one exponentiation a^(p-2) per 16 elements instead of one per vector
-            constexpr int NV = 16 / V;
+            constexpr int NV = NB / V;
             for (; i0 + (i64)(NV - 1) * nth < nvec; i0 += (i64)NV * nth) {
-                E xv[16];
+                E xv[NB];
 #pragma unroll
                 for (int k = 0; k < NV; k++) {
                     const Vec16<T> av = reinterpret_cast<const Vec16<T> *>(a)[i0 + (i64)k * nth];
 #pragma unroll
                     for (int j = 0; j < V; j++) xv[k * V + j] = (E)av.v[j];
                 }
-                batch_inverse<F, 16>(fd, xv, bad);
+                batch_inverse_fast<F, NB>(fd, xv, bad);
 #pragma unroll
                 for (int k = 0; k < NV; k++) {
                     Vec16<T> ov;
@@ -215,7 +280,7 @@ __global__ __launch_bounds__(256) void ew_unary_kernel(FieldDev fd, const T *__r
                 E xv[V];
 #pragma unroll
                 for (int j = 0; j < V; j++) xv[j] = (E)av.v[j];
-                batch_inverse<F, V>(fd, xv, bad);
+                batch_inverse_fast<F, V>(fd, xv, bad);
 #pragma unroll
                 for (int j = 0; j < V; j++) ov.v[j] = (T)xv[j];
             } else {
@@ -526,7 +591,7 @@ int launch_binary_ft(const FieldDev &fd, int op, const void *a, i64 sa, const vo
     const bool vec = aligned16(out) && (sa == 0 || aligned16(a)) && (sb == 0 || aligned16(b));
     constexpr int V = Vec16<T>::N;
     // array / array division in a prime field inverts 16 divisors per lane at a time: 16 / V vectors per thread
-    const int per_thread = (op == GFA_OP_DIV && sb != 0 && BatchInv<F>::value && V < 16) ? 16 / V : 1;
+    const int per_thread = (op == GFA_OP_DIV && sb != 0 && BatchInv<F>::value && V < 16) ? BatchN<F, T>::value / V : 1;
     const int grid = grid_flat(vec ? ((n + V - 1) / V + per_thread - 1) / per_thread : n, 256);
 #define GFA_LAUNCH_B(OPC)                                                                                              \
     if (vec) hipLaunchKernelGGL((ew_binary_kernel<F, T, OPC, true>), dim3(grid), dim3(256), 0, st, fd, pa, (int)sa, pb, \
@@ -552,7 +617,7 @@ int launch_unary_ft(const FieldDev &fd, int op, const void *a, void *out, i64 n,
     T *po = (T *)out;
     const bool vec = aligned16(out) && aligned16(a);
     constexpr int V = Vec16<T>::N;
-    const int per_thread = (op == GFA_OP_RECIP && BatchInv<F>::value && V < 16) ? 16 / V : 1; // see ew_unary_kernel
+    const int per_thread = (op == GFA_OP_RECIP && BatchInv<F>::value && V < 16) ? BatchN<F, T>::value / V : 1; // see ew_unary_kernel
     const int grid = grid_flat(vec ? ((n + V - 1) / V + per_thread - 1) / per_thread : n, 256);
 #define GFA_LAUNCH_U(OPC)                                                                                             \
     if (vec) hipLaunchKernelGGL((ew_unary_kernel<F, T, OPC, true>), dim3(grid), dim3(256), 0, st, fd, pa, po, n, err); \
@@ -751,8 +816,7 @@ int dispatch_binary(const FieldDev &fd, int dtype, int op, const void *a, i64 sa
         const u32 irr_low = (u32)(fd.irr ^ ((u64)1 << fd.m));
         const int V = dtype == GFA_U8 ? 16 : 8;
         const int grid = grid_flat((n + V - 1) / V, 256);
-        static const int holes = [] { const char *e = getenv("GFA_BIN16_HOLES"); return e ? atoi(e) : 1; }();
-        if (dtype == GFA_U16 && fd.m >= 9 && holes) {
+        if (dtype == GFA_U16 && fd.m >= 9) {
             const int hgrid = grid_flat((n + 8 * BIN16_VECS - 1) / (8 * BIN16_VECS), 256);
             hipLaunchKernelGGL(bin16_holes_mul_kernel, dim3(hgrid), dim3(256), 0, st, (const uint16_t *)a, (int)sa, (const uint16_t *)b, (int)sb,
                                (uint16_t *)out, n, (int)fd.m, (u32)fd.irr);
@@ -770,14 +834,11 @@ int dispatch_binary(const FieldDev &fd, int dtype, int op, const void *a, i64 sa
     }
     if (fd.kind == KIND_BIN && op == GFA_OP_MUL && dtype == GFA_U32 && fd.m >= 17 && fd.m <= 32 && aligned16(out) && (sa == 0 || aligned16(a)) &&
         (sb == 0 || aligned16(b))) {
-        static const int tab = [] { const char *e = getenv("GFA_BIN32_TAB"); return e ? atoi(e) : 1; }();
-        if (tab) {
-            const int hgrid = grid_flat((n + 4 * BIN16_VECS - 1) / (4 * BIN16_VECS), 256);
-            hipLaunchKernelGGL(bin32_tab_mul_kernel, dim3(hgrid), dim3(256), 0, st, (const u32 *)a, (int)sa, (const u32 *)b, (int)sb, (u32 *)out, n,
-                               (int)fd.m, (u64)fd.irr);
-            GFA_HIP(hipGetLastError());
-            return GFA_OK;
-        }
+        const int hgrid = grid_flat((n + 4 * BIN16_VECS - 1) / (4 * BIN16_VECS), 256);
+        hipLaunchKernelGGL(bin32_tab_mul_kernel, dim3(hgrid), dim3(256), 0, st, (const u32 *)a, (int)sa, (const u32 *)b, (int)sb, (u32 *)out, n,
+                           (int)fd.m, (u64)fd.irr);
+        GFA_HIP(hipGetLastError());
+        return GFA_OK;
     }
     GFA_EXT_FIXED(launch_binary_ft, fd, dtype, fd, op, a, sa, b, sb, out, n, st, err);
     GFA_DISPATCH_FT(launch_binary_ft, fd, dtype, fd, op, a, sa, b, sb, out, n, st, err);
@@ -1326,7 +1387,7 @@ int launch_tab8_unary(const uint8_t *table256, bool check_zero, const void *a, v
     // Arrays far beyond the Infinity Cache: statically strided persistent workgroups drift apart over a long launch and the
     // DRAM page set spreads (section 4 of DESIGN.md); consecutive launches over 2^26-element slices keep them in step
     // (reciprocal of 1e9 elements: 5.07 -> 5.27 TB/s, tools/unary_big.py).
-    static const i64 slice = [] { const char *e = getenv("GFA_TAB8_UNARY_SLICE"); return e ? (i64)atoll(e) : ((i64)1 << 26); }();
+    constexpr i64 slice = (i64)1 << 26;
     if (slice > 0 && n >= ((i64)1 << 28)) {
         for (i64 o = 0; o < n; o += slice) {
             const int rc = launch_tab8_unary(table256, check_zero, (const uint8_t *)a + o, (uint8_t *)out + o, std::min(slice, n - o), st, err);

@@ -630,12 +630,11 @@ MidDesc make_desc(const FieldDev &lut, const u16 *image)
 namespace gfa {
 
 // arrays below this many elements stay on the generic kernels (staging 8q bytes per workgroup would dominate)
-static const i64 MID_MIN_N = [] { const char *e = getenv("GFA_MID_MIN_N"); return e ? (i64)atoll(e) : (i64)1 << 17; }();
+constexpr i64 MID_MIN_N = (i64)1 << 17;
 
 bool mid_eligible(const FieldDev &calc, const void *image, int dtype, i64 n)
 {
-    static const bool enabled = [] { const char *e = getenv("GFA_MID_LDS"); return !(e && e[0] == '0'); }();
-    return enabled && image != nullptr && (dtype == GFA_U16 || dtype == GFA_U32 || dtype == GFA_U64) && calc.q > 256 && calc.q <= 32768 &&
+    return image != nullptr && (dtype == GFA_U16 || dtype == GFA_U32 || dtype == GFA_U64) && calc.q > 256 && calc.q <= 32768 &&
            n >= MID_MIN_N;
 }
 
@@ -700,12 +699,11 @@ int mid_power_each(const FieldDev &lut, const void *image, const void *a, const 
 }
 
 // ---- above 32768 elements (and sums without room for ZECH above 8192): staged-table kernels; they cover the first n & ~7 elements, the caller runs the generic kernels on the rest
-static const i64 BIG16_MIN_N = [] { const char *e = getenv("GFA_BIG16_MIN_N"); return e ? (i64)atoll(e) : (i64)1 << 19; }();
+constexpr i64 BIG16_MIN_N = (i64)1 << 19;
 
 bool big16_eligible(const FieldDev &calc, const void *image, int dtype, i64 n)
 {
-    static const bool enabled = [] { const char *e = getenv("GFA_BIG16_LDS"); return !(e && e[0] == '0'); }();
-    return enabled && image != nullptr && dtype == GFA_U16 && calc.q > 8192 && calc.q <= 65536 && n >= BIG16_MIN_N;
+    return image != nullptr && dtype == GFA_U16 && calc.q > 8192 && calc.q <= 65536 && n >= BIG16_MIN_N;
 }
 
 int big16_run(const FieldDev &lut, const void *image, int op, const void *a, i64 sa, const void *b, i64 sb, const i64 *e, void *out, i64 n,

@@ -320,7 +320,6 @@ int gfa_field_create(uint64_t p, uint32_t m, const uint64_t *irr, uint64_t alpha
             for (u32 i = 0; i <= m; i++) v = (v << 1) | irr[i];
             d.irr = v;
             d.mu = Bin::fold_rounds(v, m); // > 0: products as an integer-multiply carry-less product + that many folds through f
-            if (const char *e = getenv("GFA_BIN_FOLD")) { if (e[0] == '0') d.mu = 0; }
         } else {
             if (p >= ((u64)1 << 32) || m > GFA_MAX_EXT_DEGREE) {
                 delete f;

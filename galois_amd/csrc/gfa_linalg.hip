@@ -516,9 +516,7 @@ int gfa_matmul(gfa_field_t *f, const void *a, const void *b, void *out, int64_t 
         const char *pa = (const char *)a + (size_t)(b0 * a_batch_stride) * isz;
         const char *pb = (const char *)b + (size_t)(b0 * b_batch_stride) * isz;
         char *po = (char *)out + (size_t)(b0 * M * N) * isz;
-        static int use_mfma = -1; // GFA_MATMUL_MFMA=0 forces the vector-ALU kernels (A/B comparison in tests and tools)
-        if (use_mfma < 0) { const char *e = getenv("GFA_MATMUL_MFMA"); use_mfma = (e && e[0] == '0') ? 0 : 1; }
-        if (use_mfma && matmul_mfma_eligible(f->calc, M, K, N)) {
+        if (matmul_mfma_eligible(f->calc, M, K, N)) {
             rc = matmul_mfma(f->calc, dtype, pa, pb, po, nb, M, K, N, a_batch_stride, b_batch_stride, (hipStream_t)stream);
         } else if (f->has_tab8 && f->calc.p == 2 && dtype == GFA_U8 && f->use_lookup()) {
             static bool attr = false;

@@ -164,9 +164,7 @@ template <typename T, bool RAW>
 int launch_gemm(const int8_t *A, const int8_t *Bt, T *C, i64 M, i64 N, i64 Mp, i64 Np, i64 Kp, i64 a_bstride, i64 b_bstride, i64 batch,
                 int p, hipStream_t st)
 {
-    static int big_env = -1; // GFA_MFMA_TILE=128 forces the small tiles (A/B measurements)
-    if (big_env < 0) { const char *e = getenv("GFA_MFMA_TILE"); big_env = (e && atoi(e) == 128) ? 0 : 1; }
-    if (big_env && M >= 1024 && N >= 1024) {
+    if (M >= 1024 && N >= 1024) {
         auto k = gemm_i8_nt_kernel<T, RAW, 4, 4>;
         constexpr size_t lds = 2 * (256 + 256) * PITCH;
         static bool attr = false;

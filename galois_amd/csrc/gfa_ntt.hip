@@ -390,20 +390,6 @@ __device__ __forceinline__ void reg_dif(typename TW::Ctx fd, typename F::elem (&
     }
 }
 
-inline bool ntt_wide_enabled()
-{ // GFA_NTT_UNREDUCED=0 selects the always-reduced lazy butterflies for p < 2^24 as well (A/B measurements)
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("GFA_NTT_UNREDUCED"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v != 0;
-}
-
-inline bool ntt_goldi_enabled()
-{ // GFA_NTT_GL=0 selects the plain 64-bit modular arithmetic for Goldilocks (A/B measurements)
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("GFA_NTT_GL"); v = (e && e[0] == '0') ? 0 : 1; }
-    return v != 0;
-}
-
 template <class TW, class = void>
 struct LazyTrait { static constexpr bool value = false; };
 template <class TW>
@@ -1260,29 +1246,11 @@ int run_pow2(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *o
 }
 
 
-int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
-inline int env_int_now(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 // Goldilocks shift-twiddle networks: for the line table at `wl` (w_L = omega^(n_total / L), L = R1 * R2) the odd exponents u1, u2
 // with w_L^R2 = (2^(192/R1))^u1 and w_L^R1 = (2^(192/R2))^u2, stored as the kernel wants them: perm1 = u1^-1 mod R1, perm2 = u2.
 struct GlPerm { int perm1, perm2; };
 std::mutex g_glperm_mu;
 std::map<const void *, GlPerm> g_glperm;
-
-inline bool goldi_shift_enabled()
-{ // GFA_NTT_GL_SHIFT=0: general products for the network twiddles as well (A/B measurements)
-    static const bool on = [] { const char *e = getenv("GFA_NTT_GL_SHIFT"); return !(e && e[0] == '0'); }();
-    return on;
-}
 
 inline void goldi_register_perms(const FieldDev &fd, u64 omega, i64 n_total, int logL, const void *wl)
 {
@@ -1319,8 +1287,7 @@ int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64
     constexpr size_t lds = sizeof(E) * ((size_t)C * ((SPLIT ? R1 / 2 : R1) * (R2 + 1) + 1) + (TW::HAS_SHOUP ? 2 : 1) * L); // quotient table only with Shoup twiddles
     ra.tiles_per_batch = (int)((ra.total_lines + C - 1) / C);
     const unsigned grid = (unsigned)(batch * ra.tiles_per_batch);
-    static const int xcd = env_int("GFA_NTT_XCD", 1);
-    ra.xcd_remap = (xcd && (grid % 8) == 0 && grid >= 16) ? 1 : 0;
+    ra.xcd_remap = ((grid % 8) == 0 && grid >= 16) ? 1 : 0; // XCD-aware tile order (plain order: 0.31 instead of 0.25 ms at 2^20 x 64)
     {
         const i64 lim = ((i64)1 << 31) / (i64)sizeof(E);
         const i64 in_chunks = ra.in_split < 31 ? ((i64)L >> ra.in_split) : 0, out_chunks = ra.out_split < 31 ? ((i64)L >> ra.out_split) : 0;
@@ -1330,17 +1297,15 @@ int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64
             return GFA_ERR_UNSUPPORTED;
         }
     }
-    static const int lds_pad = env_int("GFA_NTT_LDS_PAD", 0); // occupancy experiments only
     if constexpr (std::is_same<TW, TwGoldi>::value) {
         bool shift = false;
-        if (goldi_shift_enabled() && !ra.pre_twiddle) {
+        if (!ra.pre_twiddle) {
             std::lock_guard<std::mutex> lock(g_glperm_mu);
             auto it = g_glperm.find(wl);
             if (it != g_glperm.end()) { ra.perm1 = it->second.perm1; ra.perm2 = it->second.perm2; shift = true; }
         }
         // four waves per SIMD for the strided passes of the three-pass driver (see WAVES above)
-        static const int w4 = env_int("GFA_NTT_GL_W4", 1);
-        const bool strided = w4 && ra.waves4 && !ra.load_along_line && !ra.store_along_line && LOGR1 == 5;
+        const bool strided = ra.waves4 && !ra.load_along_line && !ra.store_along_line && LOGR1 == 5;
 #define GFA_GL_LAUNCH(SH, WV)                                                                                                                    \
     do {                                                                                                                                         \
         auto kern = ntt_reg_kernel_gl<LOGR1, LOGR2, THREADS, SPLIT, SH, WV>;                                                                     \
@@ -1349,7 +1314,7 @@ int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64
             GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                            \
             attr = true;                                                                                                                         \
         }                                                                                                                                        \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds + (size_t)lds_pad, st, fd, (const u64 *)in, (u64 *)out, ra, (const u64 *)wl,     \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, fd, (const u64 *)in, (u64 *)out, ra, (const u64 *)wl,     \
                            (const u64 *)pa, (const u64 *)pb);                                                                                    \
     } while (0)
         if (shift && strided) GFA_GL_LAUNCH(true, 4);
@@ -1363,7 +1328,7 @@ int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64
             GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr = true;
         }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds + (size_t)lds_pad, st, fd, (const E *)in, (E *)out, ra, (const E *)wl,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds, st, fd, (const E *)in, (E *)out, ra, (const E *)wl,
                            (const E *)wlq, (const E *)pa, (const E *)paq, (const E *)pb, (const E *)pbq, (const E *)pam);
     }
     GFA_HIP(hipGetLastError());
@@ -1377,19 +1342,13 @@ int launch_reg_t(const FieldDev &fd, const void *in, void *out, const RegArgs &r
     typedef typename F::elem E;
     if constexpr (sizeof(E) == 4 && LOGR1 == 5) {
         // 32 lines per tile (128-byte global segments, one 1024-thread workgroup per CU) or 16 lines (two 512-thread ones)
-        static const int wide = env_int("GFA_NTT_WIDE", 0);
-        if (wide) return launch_reg_tt<F, TW, LOGR1, LOGR2, 1024>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
-        static const int split = env_int("GFA_NTT_SPLIT", 1); // two-round LDS exchange: 3 workgroups per CU instead of 2
-        if (split) return launch_reg_tt<F, TW, LOGR1, LOGR2, 512, true>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
-        return launch_reg_tt<F, TW, LOGR1, LOGR2, 512>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
+        // (measured and dropped: 1024-thread workgroups, and the whole line staged in one round)
+        return launch_reg_tt<F, TW, LOGR1, LOGR2, 512, true>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st); // two-round LDS exchange: 3 workgroups per CU
     } else if constexpr (sizeof(E) == 8 && LOGR1 == 5 && !TW::HAS_SHOUP) {
         // 64-bit elements: 16 lines per tile (128-byte global segments) in one 512-thread workgroup per CU, or 8 lines in
         // 256-thread workgroups, two per CU now that the unused quotient table is no longer reserved (GFA_NTT_T64=256)
-        static const int t64 = env_int("GFA_NTT_T64", 256);
-        static const int split64 = env_int("GFA_NTT_SPLIT64", 1); // two-round exchange: half the LDS buffer, three workgroups per CU (Goldilocks 2^20 x 16: 0.283 -> 0.251 ms)
-        if (split64) return launch_reg_tt<F, TW, LOGR1, LOGR2, 256, true>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
-        if (t64 == 512) return launch_reg_tt<F, TW, LOGR1, LOGR2, 512>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
-        return launch_reg_tt<F, TW, LOGR1, LOGR2, 256>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
+        // two-round exchange: half the LDS buffer, three workgroups per CU (Goldilocks 2^20 x 16: 0.283 -> 0.251 ms)
+        return launch_reg_tt<F, TW, LOGR1, LOGR2, 256, true>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
     } else {
         return launch_reg_tt<F, TW, LOGR1, LOGR2, 256>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
     }
@@ -1530,15 +1489,9 @@ int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n,
         out_split = sp - pl->log1;
     }
     const i64 in_row = li.chunk_len ? li.row_stride : n, out_row = lo.chunk_len ? lo.row_stride : n;
-    // Sub-batches keep the pass-1 -> pass-2 intermediate small enough to stay in the 256 MiB Infinity Cache instead of
-    // making a round trip through HBM.
-    static const int sub_mb = env_int("GFA_NTT_SUBBATCH_MB", 0);
-    i64 sub = batch;
-    if (sub_mb > 0) {
-        sub = ((i64)sub_mb << 20) / (i64)(sizeof(E) * (size_t)n);
-        if (sub < 1) sub = 1;
-        if (sub > batch) sub = batch;
-    }
+    // (sub-batches that keep the pass-1 -> pass-2 intermediate inside the 256 MiB Infinity Cache were measured and lose to two plain
+    // passes over the whole batch, profiles/r03_ntt_fused_skeleton.txt)
+    const i64 sub = batch;
     if ((rc = pl->sc->ws0.ensure(sizeof(E) * (size_t)(n * sub)))) return rc;
     for (i64 b0 = 0; b0 < batch; b0 += sub) {
         const i64 nb = std::min(sub, batch - b0);
@@ -1588,13 +1541,7 @@ int run_pow2_reg3(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n
     while (((i64)1 << logn) < n) logn++;
     // measured on 2^22 .. 2^26 points (tools/ntt3_tune.py): longest lines in the widest-strided pass, shortest in the last
     int log0 = (logn + 2) / 3, log1 = (logn - log0 + 1) / 2;
-    if (!pl->reg3_ready) { // GFA_NTT3_LOG0 / GFA_NTT3_LOG1: tuning overrides, read when the plan is built
-        const int e0 = env_int_now("GFA_NTT3_LOG0", 0), e1 = env_int_now("GFA_NTT3_LOG1", 0);
-        if (e0 >= 2 && e0 <= REG_MAX_LOG) { log0 = e0; log1 = (logn - log0 + 1) / 2; }
-        if (e1 >= 2 && e1 <= REG_MAX_LOG && logn - log0 - e1 >= 2) log1 = e1;
-    } else {
-        log0 = pl->log0; log1 = pl->log1;
-    }
+    if (pl->reg3_ready) { log0 = pl->log0; log1 = pl->log1; }
     const int log2 = logn - log0 - log1;
     const i64 L0 = (i64)1 << log0, L1 = (i64)1 << log1, L2 = (i64)1 << log2, M = L1 * L2;
     {
@@ -1765,13 +1712,12 @@ int run_typed(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *
         if (done) {
         } else if (lg >= 2 && lg <= 2 * REG_MAX_LOG) {
             if constexpr (std::is_same<F, Prime32>::value) {
-                if (fd.p < (1ull << 24) && ntt_wide_enabled()) rc = run_pow2_reg<F, TwShoupWide>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+                if (fd.p < (1ull << 24)) rc = run_pow2_reg<F, TwShoupWide>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
                 else if (fd.p < (1ull << 30)) rc = run_pow2_reg<F, TwShoupLazy>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
                 else if (fd.p < (1ull << 31)) rc = run_pow2_reg<F, TwShoup32>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
                 else rc = run_pow2_reg<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
             } else if constexpr (std::is_same<F, Goldilocks>::value) {
-                if (ntt_goldi_enabled()) rc = run_pow2_reg<F, TwGoldi>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
-                else rc = run_pow2_reg<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+                rc = run_pow2_reg<F, TwGoldi>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
             } else {
                 rc = run_pow2_reg<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
             }
@@ -1784,8 +1730,7 @@ int run_typed(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *
                 else if (fd.p < (1ull << 31)) rc = run_pow2_reg3<F, TwShoup32>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
                 else rc = run_pow2_reg3<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
             } else if constexpr (std::is_same<F, Goldilocks>::value) {
-                if (ntt_goldi_enabled()) rc = run_pow2_reg3<F, TwGoldi>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
-                else rc = run_pow2_reg3<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
+                rc = run_pow2_reg3<F, TwGoldi>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
             } else {
                 rc = run_pow2_reg3<F, Tw<F>>(fd, pl, ein, eout, n, batch, omega, do_scale, scale, st);
             }
@@ -1964,13 +1909,13 @@ static int ntt_columns_impl(gfa_field_t *f, const void *in, void *out, int64_t n
     };
     switch (c.kind) {
     case KIND_PRIME32:
-        if (c.p < (1ull << 24) && n1 <= ((i64)1 << REG_MAX_LOG) && ntt_wide_enabled()) return run(Prime32{}, TwShoupWide{});
+        if (c.p < (1ull << 24) && n1 <= ((i64)1 << REG_MAX_LOG) ) return run(Prime32{}, TwShoupWide{});
         if (c.p < (1ull << 30) && n1 <= ((i64)1 << REG_MAX_LOG)) return run(Prime32{}, TwShoupLazy{});
         if (c.p < (1ull << 31)) return run(Prime32{}, TwShoup32{});
         return run(Prime32{}, Tw<Prime32>{});
     case KIND_PRIME64: return run(Prime64{}, Tw<Prime64>{});
     case KIND_GOLDILOCKS:
-        if (ntt_goldi_enabled() && n1 <= ((i64)1 << REG_MAX_LOG)) return run(Goldilocks{}, TwGoldi{});
+        if (n1 <= ((i64)1 << REG_MAX_LOG)) return run(Goldilocks{}, TwGoldi{});
         return run(Goldilocks{}, Tw<Goldilocks>{});
     default: set_error("gfa_ntt_columns: prime fields only"); return GFA_ERR_UNSUPPORTED;
     }

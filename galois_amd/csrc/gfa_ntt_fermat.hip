@@ -272,8 +272,7 @@ namespace gfa {
 
 bool ntt_fermat16_eligible(const FieldDev &fd, i64 n, i64 batch)
 {
-    static const int min_batch = [] { const char *e = getenv("GFA_NTT_FERMAT_MIN_BATCH"); return e ? atoi(e) : 64; }();
-    return fd.kind == KIND_PRIME32 && fd.p == 65537 && n == 65536 && batch >= min_batch;
+    return fd.kind == KIND_PRIME32 && fd.p == 65537 && n == 65536 && batch >= 64; // one persistent workgroup per CU: fewer leave the chip idle
 }
 
 // in / out: uint32, batch transforms of 2^16 points.  Returns GFA_ERR_UNSUPPORTED (nothing launched) when omega is not a
@@ -323,9 +322,8 @@ int ntt_fermat16(const void *in, void *out, i64 batch, u64 omega, int negate, hi
         }
         pl = p;
     }
-    static const int stagger_env = [] { const char *e = getenv("GFA_NTT_FERMAT_STAGGER"); return e ? atoi(e) : 2; }();
-    static const int grid_env = [] { const char *e = getenv("GFA_NTT_FERMAT_GRID"); return e ? atoi(e) : 0; }();
-    const i64 grid = std::min<i64>(batch, grid_env > 0 ? grid_env : pl.cus);
+    constexpr int stagger_env = 2; // first-round stagger of the four workgroup groups, in units of 4096 clocks (measured against 0 and 4)
+    const i64 grid = std::min<i64>(batch, pl.cus);
     // the stagger only pays when every group has later rounds to keep busy
     FermatArgs a{(const u32 *)in, (u32 *)out, pl.tw1, pl.tw2, pl.u, pl.uinv, (int)batch, batch >= 2 * grid ? stagger_env : 0, g_fermat_dbg};
     if (a.dbg && !negate) hipLaunchKernelGGL((ntt_fermat16_kernel<false, true>), dim3((unsigned)grid), dim3(1024), FERMAT_LDS_BYTES, st, a);

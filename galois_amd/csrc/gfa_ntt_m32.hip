@@ -136,6 +136,15 @@ constexpr int line_pitch(int rows, int row)
 // offsets 0.257-0.264 ms, the same table on the load side of pass 2 (contiguous rows) 0.243-0.252 ms, the progression
 // 0.236-0.247 ms -- the table costs more in the memory system (which bounds both passes) than two products per point cost
 // on the vector ALU (which has slack since the arithmetic went from 56 to 33 instructions per point and pass).
+#ifndef M32_LD_AUX
+#define M32_LD_AUX 0
+#endif
+#ifndef M32_ST1_AUX
+#define M32_ST1_AUX 0
+#endif
+#ifndef M32_ST2_AUX
+#define M32_ST2_AUX 0
+#endif
 #ifndef GFA_M32_WAVES
 #define GFA_M32_WAVES 4 // waves per SIMD the register allocation is held to (128 VGPRs): two 512-thread workgroups per CU
 #endif
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_M32
             const u32 step = (u32)R2 * (u32)a.in_stride_t * 4u; // uniform
             const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)gin, 0, 0xffffffffu, 0x00020000);
 #pragma unroll
-            for (int k = 0; k < R1; k++) va[k] = __builtin_amdgcn_raw_buffer_load_b32(rin, (int)off, (int)(k * step), 0);
+            for (int k = 0; k < R1; k++) va[k] = __builtin_amdgcn_raw_buffer_load_b32(rin, (int)off, (int)(k * step), MODE == 0 ? M32_LD_AUX : 0);
             dif<LOGR1>(va, net1, p);
         }
         __syncthreads(); // middle-twiddle table staged
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_M32
             const i32 sr = tw2[line];
 #pragma unroll
             for (int kr = 0; kr < R2; kr++) {
-                __builtin_amdgcn_raw_buffer_store_b32(mulm1(v[brev_c(kr, LOGR2)], t, pinv, negp), rout, (int)ooff, (int)(kr * ostep), 0);
+                __builtin_amdgcn_raw_buffer_store_b32(mulm1(v[brev_c(kr, LOGR2)], t, pinv, negp), rout, (int)ooff, (int)(kr * ostep), M32_ST1_AUX);
                 if (kr + 1 < R2) t = mulm1(t, sr, pinv, negp);
             }
         }
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_M32
             for (int kr = 0; kr < R2; kr++) {
                 i32 x = mulm(v[brev_c(kr, LOGR2)], fin, finp, p); // (-p, p)
                 x += p & (x >> 31);                                // [0, p)
-                __builtin_amdgcn_raw_buffer_store_b32(x, rout, (int)ooff, (int)(kr * ostep), 0);
+                __builtin_amdgcn_raw_buffer_store_b32(x, rout, (int)ooff, (int)(kr * ostep), M32_ST2_AUX);
             }
         }
     }
@@ -681,12 +690,6 @@ int build_plan(M32Plan *pl, u64 p, i64 n, u64 omega, hipStream_t st)
     return GFA_OK;
 }
 
-int env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-
 template <int LOGR1, int LOGR2, int THREADS, bool SPLIT, int MODE>
 int launch_ttm(const i32 *in, i32 *out, M32Args a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, const i32 *tw2, hipStream_t st)
 {
@@ -703,12 +706,11 @@ int launch_ttm(const i32 *in, i32 *out, M32Args a, i64 batch, const i32 *net, co
             return GFA_ERR_UNSUPPORTED;
         }
     }
-    static const int xcd = env_int("GFA_NTT_XCD", 1), order = env_int("GFA_M32_ORDER", 0), order_min = env_int("GFA_M32_ORDER_MIN", 64); // 2^16 x 1024: whole transforms per XCD 0.229 ms, column slices 0.265
-    a.tile_order = 0;
-    if (xcd) {
-        const bool can1 = (a.tiles_per_batch % 8) == 0 && a.tiles_per_batch >= order_min, can2 = (grid % 8) == 0 && grid >= 16;
-        if (order == 2) a.tile_order = can2 ? 2 : 0;
-        else a.tile_order = can1 ? 1 : (can2 ? 2 : 0);
+    // tile order (measured, profiles/r03_m32_sweep.txt): column slices per XCD from 64 tiles per transform (2^20 x 64: identity order 0.31 ms,
+    // slices 0.25), whole transforms per XCD below that (2^16 x 1024: 0.229 vs 0.265 ms)
+    {
+        const bool can1 = (a.tiles_per_batch % 8) == 0 && a.tiles_per_batch >= 64, can2 = (grid % 8) == 0 && grid >= 16;
+        a.tile_order = can1 ? 1 : (can2 ? 2 : 0);
     }
     auto kern = ntt_m32_kernel<LOGR1, LOGR2, THREADS, SPLIT, MODE>;
     static bool attr = false;
@@ -716,8 +718,7 @@ int launch_ttm(const i32 *in, i32 *out, M32Args a, i64 batch, const i32 *net, co
         GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
-    static const int lds_pad = env_int("GFA_M32_LDS_PAD", 0); // occupancy experiments only
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), lds + (size_t)lds_pad, st, in, out, a, net, net + R1, mid, tw, tw2);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(THREADS), lds, st, in, out, a, net, net + R1, mid, tw, tw2);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }
@@ -732,20 +733,10 @@ int launch_tt(const i32 *in, i32 *out, const M32Args &a, i64 batch, const i32 *n
 template <int LOGR1, int LOGR2>
 int launch_t(const i32 *in, i32 *out, const M32Args &a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, const i32 *tw2, hipStream_t st, int mode)
 {
-    if constexpr (LOGR1 == 5) {
-        static const int threads = env_int("GFA_M32_THREADS", 512);
-        // two-round LDS exchange (half the buffer, three workgroups per CU): measured slower than two workgroups per CU with
-        // the whole line staged (0.268 vs 0.236 ms, 2^20 x 64) -- both passes are bound by the memory system, not occupancy
-        static const int split = env_int("GFA_M32_SPLIT", 0);
-        if (threads == 1024) return split ? launch_tt<LOGR1, LOGR2, 1024, true>(in, out, a, batch, net, mid, tw, tw2, st, mode)
-                                          : launch_tt<LOGR1, LOGR2, 1024, false>(in, out, a, batch, net, mid, tw, tw2, st, mode);
-        if (threads == 256) return split ? launch_tt<LOGR1, LOGR2, 256, true>(in, out, a, batch, net, mid, tw, tw2, st, mode)
-                                         : launch_tt<LOGR1, LOGR2, 256, false>(in, out, a, batch, net, mid, tw, tw2, st, mode);
-        return split ? launch_tt<LOGR1, LOGR2, 512, true>(in, out, a, batch, net, mid, tw, tw2, st, mode)
-                     : launch_tt<LOGR1, LOGR2, 512, false>(in, out, a, batch, net, mid, tw, tw2, st, mode);
-    } else {
-        return launch_tt<LOGR1, LOGR2, 256, false>(in, out, a, batch, net, mid, tw, tw2, st, mode);
-    }
+    // 1024-point lines: 512-thread workgroups, two per CU, the whole line staged (measured against 256 / 1024 threads and a two-round
+    // exchange with three workgroups per CU: 0.236 vs 0.268 ms at 2^20 x 64, profiles/r03_m32_sweep.txt); shorter lines: 256 threads
+    if constexpr (LOGR1 == 5) return launch_tt<LOGR1, LOGR2, 512, false>(in, out, a, batch, net, mid, tw, tw2, st, mode);
+    else return launch_tt<LOGR1, LOGR2, 256, false>(in, out, a, batch, net, mid, tw, tw2, st, mode);
 }
 
 int launch(int logL, const i32 *in, i32 *out, const M32Args &a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, const i32 *tw2, hipStream_t st, int mode)
@@ -779,8 +770,7 @@ int launch_one_t(const i32 *in, i32 *out, const M32OneArgs &oa, i64 batch, const
     static const int cus = [] { int dev = 0, n = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }();
     // measured: persistence + prefetch gains 14 % at 2^15 points (one workgroup per CU: nothing else overlaps its load phase) and
     // nothing or a loss below (2^14: 0.150 -> 0.163 ms), where two or three workgroups per CU overlap each other
-    static const int persist_env = env_int("GFA_M32_ONE_PERSIST", -1);
-    const bool persist = persist_env >= 0 ? persist_env != 0 : LOGR0 == 5;
+    const bool persist = LOGR0 == 5;
     const i64 nblk = (batch + G - 1) / G;
     const i64 per_cu = std::max<i64>(1, (i64)(160 * 1024) / (i64)lds);
     const i64 grid = persist ? std::min<i64>(nblk, (i64)cus * per_cu) : nblk;
@@ -821,8 +811,7 @@ namespace gfa {
 
 bool ntt_m32_eligible(const FieldDev &fd, i64 n)
 {
-    static const int on = env_int("GFA_NTT_M32", 1);
-    if (!on || fd.kind != KIND_PRIME32 || fd.p >= (1ull << 26) || (fd.p & 1) == 0) return false;
+    if (fd.kind != KIND_PRIME32 || fd.p >= (1ull << 26) || (fd.p & 1) == 0) return false;
     if (n < 32 || n > ((i64)1 << 20) || (n & (n - 1))) return false;
     int logn = 0;
     while (((i64)1 << logn) < n) logn++;
@@ -867,11 +856,11 @@ int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 
         a.load_along_line = 1; a.store_along_line = 1;
         return launch(pl->log1, src, dst, a, 1, pl->net1, pl->mid1, nullptr, nullptr, st, 0);
     }
-    static const int one_pass = env_int("GFA_M32_ONE", 1);
-    // 2^16 points: one workgroup per transform needs p < 2^25 (the radix-64 network's growth) and enough transforms to fill the chip
-    static const int min16 = env_int("GFA_M32_2E16_MIN_BATCH", 64);
+    // 2^11 .. 2^16 points: one workgroup per transform (one pass over HBM: 0.41-0.48 of the roofline against 0.29-0.35 in two passes,
+    // profiles/r03_ntt_mid_sizes.txt, r04_m32_2e16.txt).  2^16 points need p < 2^25 (the radix-64 network's growth) and at least 64
+    // transforms (one persistent workgroup per CU); smaller batches and 2^25 <= p < 2^26 keep the two-pass form.
     const bool is16 = pl->log1 + pl->log2 == 16;
-    if (one_pass && pl->one_wj && batch <= 0x7fffffff && (!is16 || (fd.p < (1ull << 25) && batch >= min16))) {
+    if (pl->one_wj && batch <= 0x7fffffff && (!is16 || (fd.p < (1ull << 25) && batch >= 64))) {
         M32OneArgs oa{};
         oa.p = base.p; oa.pinv = pinv;
         oa.one = mont_centred(1, fd.p); oa.onep = (i32)((u32)oa.one * pinv);

@@ -1399,7 +1399,7 @@ int launch_lfsr(gfa_rs *code, gfa_rs::Dev *cd, const uint8_t *in, const uint8_t 
     const u32 div_magic = (u32)((((u64)1 << 32) + (u64)len - 1) / (u64)len); // ceil(2^32 / len): exact quotients below 2^16
     // four table copies and eight waves per workgroup when that fits the 160 KiB of a CU (RS(255,223): 32 KiB + 8 x 16320 B)
     static const int rep_env = [] { const char *e = getenv("GFA_RS_LFSR_REP4"); return e ? atoi(e) : 1; }();
-    static const int kshift = [] { const char *e = getenv("GFA_RS_LFSR_KSHIFT"); return e ? atoi(e) : 1; }();
+    constexpr int kshift = 1; // which lanes share a table copy: pairs (measured against 0 and 2)
     const bool rep4 = rep_env && (nkw == 4 || nkw == 8) && (size_t)(nkw / 4) * 16384 + 8 * (size_t)stage_bytes <= 160 * 1024 &&
                       (batch >= 64 * 8 * (i64)cu_count() / 2 || rep_env == 2); // smaller batches: more, smaller workgroups (2: always)
     const int threads = rep4 ? 512 : 256;

@@ -451,10 +451,9 @@ int grid_for_waves(i64 batch, int nwaves, size_t lds_bytes = 0)
 // LDS words for the staged tables, or 0 when the field is too large for them (then the kernels read global memory)
 size_t lut_lds_words(const FieldDev &fd, size_t other_words)
 {
-    static const int enabled = [] { const char *e = getenv("GFA_RS_WIDE_LDS"); return (e && e[0] == '0') ? 0 : 1; }();
     const size_t q = (size_t)fd.qm1 + 1;
     const size_t words = 3 * q + ((fd.p != 2 && fd.m > 1) ? q : 0);
-    if (!enabled || q > 8192 || sizeof(u32) * (words + other_words) > 160 * 1024) return 0;
+    if (q > 8192 || sizeof(u32) * (words + other_words) > 160 * 1024) return 0;
     return words;
 }
 

@@ -1,5 +1,5 @@
 """np.convolve over GF(2^31 - 1) (no power-of-two roots: direct kernel or three NTT primes + CRT inside gfa_convolve).
-Run once with GFA_CONVOLVE_CRT=0 (direct) and once with GFA_CONVOLVE_CRT_MIN=0 (CRT everywhere it applies)."""
+(The route is chosen by size inside gfa_convolve: CRT from 2^22 multiply-adds; the crossover was measured with knobs that r04 removed.)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,8 +1,7 @@
 """Timing of the signed-Montgomery NTT kernels (gfa_ntt_m32.hip) against the round-2 register kernels.
 
     python tools/m32_time.py            # 2^20 x 64 over GF(7340033) and a few other shapes, HIP events (gfa_time_ntt)
-Environment knobs are read by the library at first use: GFA_NTT_M32=0 (old kernels), GFA_M32_THREADS, GFA_M32_SPLIT,
-GFA_M32_SUBBATCH_MB."""
+(The r03 tuning knobs are gone: their winners are hard-coded, the sweep is profiles/r03_m32_sweep.txt.)"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the text profiles under profiles/ in ONE call on the GPU box (about 5 GPU-minutes):
-#   /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/refresh_profiles.sh r03'
+#   /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/refresh_profiles.sh r04'
 # then copy gpurun_out/<round>_*.txt / .json / .csv into profiles/.
 set -u
-R=${1:-r03}
+R=${1:-r04}
 ONLY=${2:-all} # "codes": only the files the Reed-Solomon / BCH and Goldilocks kernels feed (about 2 GPU-minutes)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 cd "$ROOT"
 if [ "$ONLY" = codes ]; then
     python bench.py > "$OUT/${R}_bench_final.json" 2> "$OUT/${R}_bench_final.err"
-    { echo "# lazy 96-bit registers (default)"; python tools/goldi_time.py 2>/dev/null | grep "2^"; echo "# GFA_NTT_GL=0: plain 64-bit modular arithmetic"; GFA_NTT_GL=0 python tools/goldi_time.py 2>/dev/null | grep "2^"; } > "$OUT/${R}_ntt_goldilocks.txt"
+    python tools/goldi_time.py 2>/dev/null | grep "2^" > "$OUT/${R}_ntt_goldilocks.txt"
     python tools/rs_time.py 2>/dev/null | tail -1 > "$OUT/${R}_rs_time.txt"
     python tools/ntt_large.py 20 21 22 24 26 28 > "$OUT/${R}_ntt_large.txt" 2>/dev/null
     ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_$R && rocprofv3 --kernel-trace --stats -d /tmp/prof_$R -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --no-pmc > /dev/null 2>&1
@@ -26,12 +26,12 @@ python bench.py --steps 50 --warmup 5 --dist-extras --no-cpu-baseline --no-pmc >
 python tools/ew_bench.py 2>/dev/null | grep field > "$OUT/${R}_ew_bench.txt"
 python tools/fermat_time.py 64 256 1024 4096 2>/dev/null | grep batch > "$OUT/${R}_ntt_fermat_batches.txt"
 python tools/fermat_phases.py 1024 2>/dev/null | grep -E "round|phase|spread" > "$OUT/${R}_ntt_fermat_phases.txt"
-{ echo "# lazy 96-bit registers (default)"; python tools/goldi_time.py 2>/dev/null | grep "2^"; echo "# GFA_NTT_GL=0: plain 64-bit modular arithmetic"; GFA_NTT_GL=0 python tools/goldi_time.py 2>/dev/null | grep "2^"; } > "$OUT/${R}_ntt_goldilocks.txt"
+python tools/goldi_time.py 2>/dev/null | grep "2^" > "$OUT/${R}_ntt_goldilocks.txt"
 python tools/ntt_time.py 2>/dev/null | grep "p=" > "$OUT/${R}_ntt_time.txt"
-{ echo "# signed-Montgomery kernels (gfa_ntt_m32.hip, default)"; python tools/m32_time.py 2>/dev/null | grep "p="; echo "# GFA_NTT_M32=0: round-2 register kernels"; GFA_NTT_M32=0 python tools/m32_time.py 2>/dev/null | grep "p="; } > "$OUT/${R}_m32_time.txt"
+python tools/m32_time.py 2>/dev/null | grep "p=" > "$OUT/${R}_m32_time.txt"
 python tools/ew_bench.py --widestore 2>/dev/null | grep field > "$OUT/${R}_ew_widestore.txt"
 python tools/ew_bench.py --ext 2>/dev/null | grep field > "$OUT/${R}_ew_ext_calculate.txt"
-{ echo "# one pass (default)"; python tools/ntt_mid_time.py 2>/dev/null | grep "p="; echo "# GFA_M32_ONE=0: two passes"; GFA_M32_ONE=0 python tools/ntt_mid_time.py 2>/dev/null | grep "p="; } > "$OUT/${R}_ntt_mid_sizes.txt"
+python tools/ntt_mid_time.py 2>/dev/null | grep "p=" > "$OUT/${R}_ntt_mid_sizes.txt"
 ./tools/ubench/ntt_access 64 > "$OUT/${R}_ntt_access_skeleton.txt" 2>/dev/null
 ./tools/ubench/ntt_fused_skel 64 > "$OUT/${R}_ntt_fused_skeleton.txt" 2>/dev/null
 ./tools/ubench/mfma_dft16 > "$OUT/${R}_mfma_dft16.txt" 2>/dev/null
@@ -47,6 +47,8 @@ python tools/linalg_bench.py > "$OUT/${R}_linalg_bench.txt" 2>/dev/null
 bash tools/pmc_run.sh ${R}_pmc_headline tab8_binary -- python tools/headline_only.py 6 > /dev/null 2>&1
 bash tools/pmc_run.sh ${R}_pmc_ntt_fermat ntt_fermat16 -- python tools/fermat_time.py 1024 > /dev/null 2>&1
 bash tools/pmc_run.sh ${R}_pmc_ntt_2e20x64 ntt_m32_kernel -- python tools/m32_time.py 1 > /dev/null 2>&1
+bash tools/pmc_run.sh ${R}_pmc_ntt_m32_one ntt_m32_one -- python tools/ntt_mid_time.py > /dev/null 2>&1
+bash tools/pmc_run.sh ${R}_pmc_ntt_m32_2e16 ntt_m32_2e16 -- python tools/ntt_mid_time.py 16 > /dev/null 2>&1
 bash tools/pmc_run.sh ${R}_pmc_ntt_goldilocks ntt_reg_kernel_gl -- python tools/goldi_time.py > /dev/null 2>&1
 bash tools/pmc_run.sh ${R}_pmc_rs_decode rs_ -- python tools/rs_decode_only.py 5 > /dev/null 2>&1
 ls -la "$OUT" | tail -30

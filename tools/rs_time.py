@@ -1,6 +1,6 @@
 """RS(255,223), 2^17 codewords: encode (full codewords), decode at e ~ U{0..16}, decode of clean words -- kernel time from
 gfa_time_rs_* (HIP events on the launch stream), with a parity check of every output.  Knobs are read from the environment by
-the library (GFA_RS_LFSR_REP4, GFA_RS_LFSR_KSHIFT, GFA_RS_WPS)."""
+the library (GFA_RS_LFSR_REP4, GFA_RS_WPS)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
