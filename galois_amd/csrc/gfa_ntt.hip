@@ -1255,6 +1255,11 @@ std::map<const void *, GlPerm> g_glperm;
 inline void goldi_register_perms(const FieldDev &fd, u64 omega, i64 n_total, int logL, const void *wl)
 {
     const int l1 = (logL + 1) / 2, l2 = logL / 2; // the (R1, R2) split launch_reg uses
+    {   // the map is keyed by the table's device address: an entry left by a freed table whose address is reused must not
+        // outlive this call, whichever way it ends (a stale pair would switch the kernel to shift twiddles with the wrong permutations)
+        std::lock_guard<std::mutex> lock(g_glperm_mu);
+        g_glperm.erase(wl);
+    }
     u64 wL = 0;
     HostArith::pow(fd, omega, (i64)(n_total >> logL), &wL);
     auto find_u = [&](int lr, int lother) -> int { // odd u with (w_L^(2^lother)) == (2^(192 / 2^lr))^u, 0 if none

@@ -136,19 +136,13 @@ constexpr int line_pitch(int rows, int row)
 // offsets 0.257-0.264 ms, the same table on the load side of pass 2 (contiguous rows) 0.243-0.252 ms, the progression
 // 0.236-0.247 ms -- the table costs more in the memory system (which bounds both passes) than two products per point cost
 // on the vector ALU (which has slack since the arithmetic went from 56 to 33 instructions per point and pass).
-#ifndef M32_LD_AUX
-#define M32_LD_AUX 0
-#endif
-#ifndef M32_ST1_AUX
-#define M32_ST1_AUX 0
-#endif
-#ifndef M32_ST2_AUX
-#define M32_ST2_AUX 0
-#endif
+// NT (last pass of a two-pass transform only): non-temporal loads and stores.  Measured (profiles/r04_m32_aux.txt): when the batch's
+// intermediate fits the 256 MiB Infinity Cache the last pass then finds it there -- 2^20 x 64: 0.230 -> 0.217 ms -- while on larger batches
+// the hint costs 4 % (2^20 x 256), so the host sets it by size.
 #ifndef GFA_M32_WAVES
 #define GFA_M32_WAVES 4 // waves per SIMD the register allocation is held to (128 VGPRs): two 512-thread workgroups per CU
 #endif
-template <int LOGR1, int LOGR2, int THREADS, bool SPLIT, int MODE>
+template <int LOGR1, int LOGR2, int THREADS, bool SPLIT, int MODE, bool NT>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_M32_WAVES))) void ntt_m32_kernel(const i32 *__restrict__ in, i32 *__restrict__ out, M32Args a,
                                                           const i32 *__restrict__ net1, const i32 *__restrict__ net2,
                                                           const i32 *__restrict__ mid, const i32 *__restrict__ tw,
@@ -213,7 +207,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_M32
             const u32 step = (u32)R2 * (u32)a.in_stride_t * 4u; // uniform
             const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)gin, 0, 0xffffffffu, 0x00020000);
 #pragma unroll
-            for (int k = 0; k < R1; k++) va[k] = __builtin_amdgcn_raw_buffer_load_b32(rin, (int)off, (int)(k * step), MODE == 0 ? M32_LD_AUX : 0);
+            for (int k = 0; k < R1; k++) va[k] = __builtin_amdgcn_raw_buffer_load_b32(rin, (int)off, (int)(k * step), NT ? 2 : 0);
             dif<LOGR1>(va, net1, p);
         }
         __syncthreads(); // middle-twiddle table staged
@@ -253,7 +247,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_M32
             const i32 sr = tw2[line];
 #pragma unroll
             for (int kr = 0; kr < R2; kr++) {
-                __builtin_amdgcn_raw_buffer_store_b32(mulm1(v[brev_c(kr, LOGR2)], t, pinv, negp), rout, (int)ooff, (int)(kr * ostep), M32_ST1_AUX);
+                __builtin_amdgcn_raw_buffer_store_b32(mulm1(v[brev_c(kr, LOGR2)], t, pinv, negp), rout, (int)ooff, (int)(kr * ostep), 0);
                 if (kr + 1 < R2) t = mulm1(t, sr, pinv, negp);
             }
         }
@@ -264,7 +258,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_M32
             for (int kr = 0; kr < R2; kr++) {
                 i32 x = mulm(v[brev_c(kr, LOGR2)], fin, finp, p); // (-p, p)
                 x += p & (x >> 31);                                // [0, p)
-                __builtin_amdgcn_raw_buffer_store_b32(x, rout, (int)ooff, (int)(kr * ostep), M32_ST2_AUX);
+                __builtin_amdgcn_raw_buffer_store_b32(x, rout, (int)ooff, (int)(kr * ostep), NT ? 2 : 0);
             }
         }
     }
@@ -690,7 +684,7 @@ int build_plan(M32Plan *pl, u64 p, i64 n, u64 omega, hipStream_t st)
     return GFA_OK;
 }
 
-template <int LOGR1, int LOGR2, int THREADS, bool SPLIT, int MODE>
+template <int LOGR1, int LOGR2, int THREADS, bool SPLIT, int MODE, bool NT>
 int launch_ttm(const i32 *in, i32 *out, M32Args a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, const i32 *tw2, hipStream_t st)
 {
     constexpr int R1 = 1 << LOGR1, R2 = 1 << LOGR2, L = R1 * R2, C = THREADS / R1;
@@ -712,7 +706,7 @@ int launch_ttm(const i32 *in, i32 *out, M32Args a, i64 batch, const i32 *net, co
         const bool can1 = (a.tiles_per_batch % 8) == 0 && a.tiles_per_batch >= 64, can2 = (grid % 8) == 0 && grid >= 16;
         a.tile_order = can1 ? 1 : (can2 ? 2 : 0);
     }
-    auto kern = ntt_m32_kernel<LOGR1, LOGR2, THREADS, SPLIT, MODE>;
+    auto kern = ntt_m32_kernel<LOGR1, LOGR2, THREADS, SPLIT, MODE, NT>;
     static bool attr = false;
     if (!attr) {
         GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -726,8 +720,9 @@ int launch_ttm(const i32 *in, i32 *out, M32Args a, i64 batch, const i32 *net, co
 template <int LOGR1, int LOGR2, int THREADS, bool SPLIT>
 int launch_tt(const i32 *in, i32 *out, const M32Args &a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, const i32 *tw2, hipStream_t st, int mode)
 {
-    if (mode == 0) return launch_ttm<LOGR1, LOGR2, THREADS, SPLIT, 0>(in, out, a, batch, net, mid, tw, tw2, st);
-    return launch_ttm<LOGR1, LOGR2, THREADS, SPLIT, 1>(in, out, a, batch, net, mid, tw, tw2, st);
+    if (mode == 0) return launch_ttm<LOGR1, LOGR2, THREADS, SPLIT, 0, false>(in, out, a, batch, net, mid, tw, tw2, st);
+    if (mode == 2) return launch_ttm<LOGR1, LOGR2, THREADS, SPLIT, 0, true>(in, out, a, batch, net, mid, tw, tw2, st); // last pass, non-temporal
+    return launch_ttm<LOGR1, LOGR2, THREADS, SPLIT, 1, false>(in, out, a, batch, net, mid, tw, tw2, st);
 }
 
 template <int LOGR1, int LOGR2>
@@ -884,7 +879,8 @@ int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 
         a.in_batch_stride = n; a.out_batch_stride = n;
         a.total_lines = n1;
         a.load_along_line = 1; a.store_along_line = 0;
-        return launch(pl->log2, w, dst, a, batch, pl->net2, pl->mid2, nullptr, nullptr, st, 0);
+        const bool in_cache = (size_t)n * (size_t)batch * sizeof(i32) <= ((size_t)256 << 20); // the intermediate fits the Infinity Cache
+        return launch(pl->log2, w, dst, a, batch, pl->net2, pl->mid2, nullptr, nullptr, st, in_cache ? 2 : 0);
     }
 }
 
