@@ -701,6 +701,136 @@ __global__ __launch_bounds__(REP4 ? 512 : 256) void rs_lfsr_kernel(const u32 *__
 // ------------------------------------------------------------------------------------------------
 // Fast decoder for characteristic-2 codes with n-k <= 60: second kernel of the two-kernel decode
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// The same LFSR with the codeword ROW in registers (r04): n - k = 32, full-length rows of LEN = 223 / 255 symbols
+// ------------------------------------------------------------------------------------------------
+// rs_lfsr_kernel stages 64 rows per wave in LDS (16 KiB), which leaves a CU eight waves and a 4-copy table whose reads conflict:
+// LDS array 69 % busy, 64 % of it conflicts, two waves per SIMD to hide the table-read -> xor -> next-feedback chain.  Here every
+// lane loads ITS OWN row straight from global memory with 16-byte loads (rows start at any byte: gfx950 serves unaligned vector
+// accesses under HSA; all of a row's loads are issued at once, so each 128-byte line is fetched once), the row lives in 56 / 64
+// VGPRs, and LDS holds nothing but the table -- sixteen private copies, one per lane of a ds_read_b128 lane group, so NO read can
+// conflict: byte offset f * 512 + c * 256 + s * 16 for chunk c of row f, copy s = lane & 15.  One 1024-thread workgroup per CU
+// (four waves per SIMD).  Per symbol: one SDWA xor (feedback = state's top byte ^ the symbol's byte of its row register), one
+// address, two conflict-free 16-byte reads, the planar state update of rs_lfsr_kernel.  Outputs leave as 16-byte stores per lane
+// (the last 15 bytes of a 255-byte row as 12 + 2 + 1).
+// MODE 0: parity appended (full codewords), 1: parity only.  Measured (profiles/r04_rs_lfsr_reg.txt): 862 / 989 / 984 / 1069 GB/s of
+// codewords at 2^17 / 2^18 / 2^20 / 2^22 words against 860 / 920 / 934 / 947 for rs_lfsr_kernel; LDS array 22 % and vector ALU 21 %
+// busy, zero-conflict reads -- the kernel now waits on its scattered 16-byte global accesses (64 lines per wave instruction; PMC:
+// 1.45x the algorithmic bytes read, 1.36x written).  A decoder pre-pass in this form (+ a verbatim copy of the row: 18 more scattered
+// stores) LOST to the staged kernel (647 vs 685 GB/s at 2^20 clean words) and was not kept; encode takes it from 2^18 words.
+struct __attribute__((packed, aligned(1))) RowVec { u32 x, y, z, w; };
+struct __attribute__((packed, aligned(1))) RowVec3 { u32 x, y, z; };
+struct __attribute__((packed, aligned(1))) RowHalf { uint16_t v; };
+
+template <int B> // top byte of p ^ byte B of r, zero-extended: ONE instruction
+__device__ __forceinline__ u32 xor_top_byte(u32 p, u32 r)
+{
+    u32 f;
+    if constexpr (B == 0) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_0" : "=v"(f) : "v"(p), "v"(r));
+    if constexpr (B == 1) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_1" : "=v"(f) : "v"(p), "v"(r));
+    if constexpr (B == 2) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_2" : "=v"(f) : "v"(p), "v"(r));
+    if constexpr (B == 3) asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(f) : "v"(p), "v"(r));
+    return f;
+}
+
+template <class F, int... Js>
+__device__ __forceinline__ void for_each_index(F &&f, std::integer_sequence<int, Js...>)
+{
+    (f(std::integral_constant<int, Js>{}), ...);
+}
+
+constexpr size_t LFSR_REG_LDS = 256 * 512; // 128 KiB: 256 rows x 2 chunks x 16 copies x 16 bytes
+
+template <int LEN, int MODE>
+__global__ __launch_bounds__(1024) void rs_lfsr_reg_kernel(const u32 *__restrict__ rowtab, const uint8_t *in, uint8_t *out, i64 batch)
+{
+    constexpr int NKW = 8, W = 2, NCH = (LEN + 15) / 16, LAST = LEN - 16; // the last chunk ENDS at the row's end (it overlaps its predecessor)
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) { // 16-byte chunk c of row f: ONE load, sixteen copies
+        const int c = i & 1, f = i >> 1;
+        const uint4 v = reinterpret_cast<const uint4 *>(rowtab)[c * 256 + f];
+        uint4 *d = reinterpret_cast<uint4 *>(lds_raw + f * 512 + c * 256);
+#pragma unroll
+        for (int k = 0; k < 16; k++) d[k] = v;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const u32 slot = (u32)(lane & 15) << 4;
+    __syncthreads();
+    for (i64 cw0 = ((i64)blockIdx.x * nwaves + wave) * 64; cw0 < batch; cw0 += (i64)gridDim.x * nwaves * 64) {
+        const i64 cw = cw0 + lane;
+        const bool live = cw < batch;
+        const uint8_t *row = in + (live ? cw : batch - 1) * LEN;
+        RowVec R[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; c++) R[c] = *reinterpret_cast<const RowVec *>(row + (c + 1 < NCH ? 16 * c : LAST));
+        u32 P[4][W];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int h = 0; h < W; h++) P[q][h] = 0;
+        // symbol j: register word and byte inside the row's chunks
+        auto sym_word = [&](auto jc) -> u32 {
+            constexpr int J = decltype(jc)::value;
+            constexpr int C = J < 16 * (NCH - 1) ? J / 16 : NCH - 1, B = J < 16 * (NCH - 1) ? J % 16 : J - LAST;
+            const RowVec &r = R[C];
+            return B / 4 == 0 ? r.x : (B / 4 == 1 ? r.y : (B / 4 == 2 ? r.z : r.w));
+        };
+        auto step = [&](auto jc) {
+            constexpr int J = decltype(jc)::value, K = J & 3;
+            constexpr int BQ = (J < 16 * (NCH - 1) ? J % 16 : J - LAST) & 3;
+            const u32 rw = sym_word(jc);
+            const u32 f = xor_top_byte<BQ>(P[K][0], rw);
+            P[K][0] = __builtin_amdgcn_alignbit(P[K][0], P[K][1], 24);
+            P[K][1] = P[K][1] << 8;
+            const u32 a = (f << 9) | slot;
+            const uint4 r0 = *reinterpret_cast<const uint4 *>(lds_raw + a), r1 = *reinterpret_cast<const uint4 *>(lds_raw + a + 256);
+            const u32 w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+            for (int q = 0; q < 8; q++) P[(q / W + K + 1) & 3][q % W] ^= w[q]; // planar word q: role q / W, word q % W
+        };
+        for_each_index(step, std::make_integer_sequence<int, LEN>{});
+        // back to consecutive bytes (role r is P[(r + LEN) & 3]); S[d] = the d-th remainder word in MEMORY order (highest degree first)
+        u32 S[NKW];
+        {
+            constexpr int K = LEN & 3;
+#pragma unroll
+            for (int h = 0; h < W; h++) {
+                const u32 A = P[K & 3][h], Bv = P[(K + 1) & 3][h], C = P[(K + 2) & 3][h], D = P[(K + 3) & 3][h];
+                const u32 t0 = __builtin_amdgcn_perm(A, Bv, 0x07030602u), t1 = __builtin_amdgcn_perm(A, Bv, 0x05010400u);
+                const u32 u0 = __builtin_amdgcn_perm(C, D, 0x07030602u), u1 = __builtin_amdgcn_perm(C, D, 0x05010400u);
+                S[4 * h + 0] = __builtin_bswap32(__builtin_amdgcn_perm(t0, u0, 0x07060302u));
+                S[4 * h + 1] = __builtin_bswap32(__builtin_amdgcn_perm(t0, u0, 0x05040100u));
+                S[4 * h + 2] = __builtin_bswap32(__builtin_amdgcn_perm(t1, u1, 0x07060302u));
+                S[4 * h + 3] = __builtin_bswap32(__builtin_amdgcn_perm(t1, u1, 0x05040100u));
+            }
+        }
+        if (!live) continue;
+        if constexpr (MODE == 1) {
+            uint4 *dst = reinterpret_cast<uint4 *>(out + cw * 32);
+            dst[0] = make_uint4(S[0], S[1], S[2], S[3]);
+            dst[1] = make_uint4(S[4], S[5], S[6], S[7]);
+        } else {
+            static_assert(MODE != 0 || LEN % 16 == 15, "tail of 15 bytes");
+            uint8_t *orow = out + cw * (LEN + 32);
+#pragma unroll
+            for (int c = 0; c + 1 < NCH; c++) *reinterpret_cast<RowVec *>(orow + 16 * c) = R[c];
+            const RowVec &t = R[NCH - 1];
+            // bytes LEN-15 .. LEN+31 = the row's last 15 bytes, then the 32 parity bytes: 47 bytes as 16 + 16 + 12 + 2 + 1
+            const u32 x0 = __builtin_amdgcn_alignbyte(t.y, t.x, 1), x1 = __builtin_amdgcn_alignbyte(t.z, t.y, 1), x2 = __builtin_amdgcn_alignbyte(t.w, t.z, 1);
+            const u32 x3 = __builtin_amdgcn_alignbyte(S[0], t.w, 1);
+            u32 y[8];
+#pragma unroll
+            for (int d = 0; d < 7; d++) y[d] = __builtin_amdgcn_alignbyte(S[d + 1], S[d], 1);
+            y[7] = S[7] >> 8;
+            *reinterpret_cast<RowVec *>(orow + LEN - 15) = RowVec{x0, x1, x2, x3};
+            *reinterpret_cast<RowVec *>(orow + LEN + 1) = RowVec{y[0], y[1], y[2], y[3]};
+            *reinterpret_cast<RowVec3 *>(orow + LEN + 17) = RowVec3{y[4], y[5], y[6]};
+            reinterpret_cast<RowHalf *>(orow + LEN + 29)->v = (uint16_t)y[7];
+            orow[LEN + 31] = (uint8_t)(y[7] >> 16);
+        }
+    }
+}
+
 // rs_lfsr_kernel has already reduced every received word modulo g(x) and copied the received rows to the output.  Words
 // with a zero remainder and no erasures need nothing more.  The rest are decoded ONE CODEWORD PER WAVEFRONT with the same
 // mathematics and failure exits as rs_decode_kernel / bch_decode_jit.  r02's version was vector-issue bound (PMC: 89 M vector
@@ -1395,6 +1525,22 @@ int launch_lfsr(gfa_rs *code, gfa_rs::Dev *cd, const uint8_t *in, const uint8_t 
                 int parity_only, uint8_t *rem_out, uint8_t *flag_out, i64 batch, hipStream_t st)
 {
     const int nk = (int)(code->n - code->k), nkw = nk / 4;
+    if constexpr (ENCODE) { // full-length messages of RS(255,223)-shaped codes in large batches: the register-resident form
+        if (nkw == 8 && !eras && len == 223 && batch >= ((i64)1 << 18)) {
+            const int grid = (int)std::max<i64>(1, std::min<i64>((batch + 1023) / 1024, (i64)cu_count())); // one workgroup per CU (LDS)
+            static bool attr0 = false, attr1 = false;
+            int rc;
+            if (parity_only) {
+                if ((rc = set_lds_limit(rs_lfsr_reg_kernel<223, 1>, &attr1))) return rc;
+                hipLaunchKernelGGL((rs_lfsr_reg_kernel<223, 1>), dim3(grid), dim3(1024), LFSR_REG_LDS, st, cd->lfsr, in, out, batch);
+            } else {
+                if ((rc = set_lds_limit(rs_lfsr_reg_kernel<223, 0>, &attr0))) return rc;
+                hipLaunchKernelGGL((rs_lfsr_reg_kernel<223, 0>), dim3(grid), dim3(1024), LFSR_REG_LDS, st, cd->lfsr, in, out, batch);
+            }
+            GFA_HIP(hipGetLastError());
+            return GFA_OK;
+        }
+    }
     const int stage_bytes = ((64 * (ENCODE ? len + nk : std::max(len, nk)) + 15) / 16) * 16;
     const u32 div_magic = (u32)((((u64)1 << 32) + (u64)len - 1) / (u64)len); // ceil(2^32 / len): exact quotients below 2^16
     // four table copies and eight waves per workgroup when that fits the 160 KiB of a CU (RS(255,223): 32 KiB + 8 x 16320 B)

@@ -129,6 +129,8 @@ def test_full_size_2e20_codewords_round_trip():
     Ch = C.numpy()
     assert np.array_equal(Ch[:, :223], M)
     assert not rs.detect(C).any()
+    # (from 2^18 words the encoder is the register-resident LFSR kernel: its parity-only form against the full codewords above)
+    assert np.array_equal(rs.encode(M[: 1 << 18], output="parity").numpy(), Ch[: 1 << 18, 223:])
     # errors: e_i ~ U{0..16} at random positions -- vectorised construction (argsort of random keys)
     ne = rng.integers(0, 17, B)
     keys = rng.random((B, 255), dtype=np.float32)
