@@ -566,6 +566,93 @@ int mid_launch(const MidDesc &d, int dtype, const void *a, i64 sa, const void *b
     }
 }
 
+// ---- the same two phases as TWO streaming kernels (r04), for arrays large enough to hide a second launch ----
+// big16_kernel re-stages 2 x 2q bytes of table per tile behind three workgroup barriers (PMC: vector ALU 27 %, LDS 40 % busy:
+// barrier-bound, 0.30-0.38 of the roofline).  Here each table is staged ONCE per persistent workgroup and the array streams through it:
+// pass A turns the operands into exponent indices (two gathers per element, 2 B written per element), pass B looks the indices up
+// (one gather).  10 instead of 6 bytes per element cross the memory system, but the 2-byte index array of up to ~1e8 elements is
+// written and re-read through the 256 MiB Infinity Cache, and neither pass has a barrier in its loop.  Measured at 5e7 elements
+// (profiles/r04_ew_big16_split.txt): GF(3^10) mul 494 -> 540 Gop/s, GF(65521) lookup-mode mul 469 -> 533, div 459 -> 519.
+template <int OP, int T>
+__global__ __launch_bounds__(T) void big16_index_kernel(MidDesc d, const u16 *__restrict__ a, int sa, const u16 *__restrict__ b, int sb,
+                                                        u16 *__restrict__ idx_out, i64 nvec, int32_t *err)
+{
+    extern __shared__ __attribute__((aligned(16))) u16 mid_lds[];
+    constexpr bool BINARY = OP == GFA_OP_MUL || OP == GFA_OP_DIV;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(d.image); // LOG: qa entries
+        uint4 *dst = reinterpret_cast<uint4 *>(mid_lds);
+        for (int i = threadIdx.x; i < (int)(d.qa / 8u); i += T) dst[i] = src[i];
+    }
+    MidPow pw{0, false, false};
+    if constexpr (OP == MID_POW) {
+        const i64 e = d.e_ptr[0];
+        pw = MidPow{exponent_mod(e, d.qm1, d.mu, d.c32), e == 0, e < 0};
+    }
+    u32x4 xs = {0, 0, 0, 0}, ys = {0, 0, 0, 0};
+    if (!sa) { const u32 s = a[0]; xs = u32x4{s, s, s, s} * 0x10001u; }
+    if (BINARY && !sb) { const u32 s = b[0]; ys = u32x4{s, s, s, s} * 0x10001u; }
+    const u32x4 *av = reinterpret_cast<const u32x4 *>(a), *bv = reinterpret_cast<const u32x4 *>(b);
+    u32x4 *ov = reinterpret_cast<u32x4 *>(idx_out);
+    bool bad = false;
+    __syncthreads();
+    const i64 stride = (i64)gridDim.x * T;
+    i64 i = (i64)blockIdx.x * T + threadIdx.x;
+    u32x4 x = xs, y = ys;
+    if (i < nvec) { if (sa) x = av[i]; if (BINARY && sb) y = bv[i]; }
+    while (i < nvec) {
+        const i64 nx = i + stride;
+        u32x4 xn = xs, yn = ys;
+        if (nx < nvec) { if (sa) xn = av[nx]; if (BINARY && sb) yn = bv[nx]; } // the next vectors travel while this one is gathered
+        u32x4 r;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const u32 lo = big16_index<OP>(mid_lds, d, pw, x[w] & 0xffffu, y[w] & 0xffffu, bad);
+            const u32 hi = big16_index<OP>(mid_lds, d, pw, x[w] >> 16, y[w] >> 16, bad);
+            r[w] = lo | (hi << 16);
+        }
+        ov[i] = r;
+        x = xn; y = yn; i = nx;
+    }
+    if constexpr (OP != GFA_OP_MUL && OP != MID_NEG) {
+        if (__any(bad)) {
+            if ((threadIdx.x & 63) == 0 && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
+        }
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void big16_exp_kernel(MidDesc d, const u16 *__restrict__ idx, u16 *__restrict__ out, i64 nvec)
+{
+    extern __shared__ __attribute__((aligned(16))) u16 mid_lds[];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(d.image + d.qa); // EXP: the second table of the image
+        uint4 *dst = reinterpret_cast<uint4 *>(mid_lds);
+        for (int i = threadIdx.x; i < (int)(d.qa / 8u); i += T) dst[i] = src[i];
+    }
+    const u32x4 *iv = reinterpret_cast<const u32x4 *>(idx);
+    u32x4 *ov = reinterpret_cast<u32x4 *>(out);
+    __syncthreads();
+    const i64 stride = (i64)gridDim.x * T;
+    i64 i = (i64)blockIdx.x * T + threadIdx.x;
+    u32x4 x = {0, 0, 0, 0};
+    if (i < nvec) x = iv[i];
+    while (i < nvec) {
+        const i64 nx = i + stride;
+        u32x4 xn = {0, 0, 0, 0};
+        if (nx < nvec) xn = iv[nx];
+        u32x4 r;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const u32 il = x[w] & 0xffffu, ih = x[w] >> 16;
+            const u32 rl = mid_lds[il == 0xffffu ? 0u : il], rh = mid_lds[ih == 0xffffu ? 0u : ih];
+            r[w] = (il == 0xffffu ? 0u : rl) | ((ih == 0xffffu ? 0u : rh) << 16);
+        }
+        ov[i] = r;
+        x = xn; i = nx;
+    }
+}
+
 template <int OP>
 int big16_launch(const MidDesc &d, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int32_t *err)
 {
@@ -577,6 +664,27 @@ int big16_launch(const MidDesc &d, const void *a, i64 sa, const void *b, i64 sb,
     constexpr int JB = ((OP == GFA_OP_MUL || OP == GFA_OP_DIV) ? 4 : 8) * 512 / B16_THREADS; // two operand streams: half the vectors per lane (registers)
     const bool big = (nvec + (i64)B16_THREADS * JB - 1) / ((i64)B16_THREADS * JB) >= 2 * (i64)cus;
     static bool attr[2] = {false, false};
+    // products and quotients of >= 2^22 elements: two streaming passes through an index array (see big16_index_kernel): 0.36-0.37 -> 0.40;
+    // reciprocal / power / negative LOSE that way (4 instead of 8 B/element to begin with: 0.38 -> 0.33) and keep the fused kernel
+    if ((OP == GFA_OP_MUL || OP == GFA_OP_DIV) && nvec >= ((i64)1 << 19)) {
+        constexpr int T = 1024;
+        auto ka = big16_index_kernel<OP, T>;
+        auto kb = big16_exp_kernel<T>;
+        static bool sattr = false;
+        if (!sattr) {
+            GFA_HIP(hipFuncSetAttribute((const void *)ka, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            GFA_HIP(hipFuncSetAttribute((const void *)kb, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+            sattr = true;
+        }
+        u16 *idx = nullptr;
+        GFA_HIP(gfa::scratch_alloc((void **)&idx, (size_t)nvec * 16, st));
+        hipLaunchKernelGGL(ka, dim3(cus), dim3(T), lds, st, d, (const u16 *)a, (int)sa, (const u16 *)b, (int)sb, idx, nvec, err);
+        hipLaunchKernelGGL(kb, dim3(cus), dim3(T), lds, st, d, (const u16 *)idx, (u16 *)out, nvec);
+        const hipError_t le = hipGetLastError();
+        GFA_HIP(gfa::scratch_free(idx, st));
+        GFA_HIP(le);
+        return GFA_OK;
+    }
     if (big) {
         auto k = big16_kernel<OP, JB>;
         if (!attr[1]) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072)); attr[1] = true; }

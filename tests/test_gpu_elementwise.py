@@ -755,7 +755,7 @@ def test_mid_size_fields_with_tables_in_lds(q, mode):
         GF.compile("auto")
 
 
-@pytest.mark.parametrize("q,n", [(2**16, 600_011), (2**16, 17_000_003), (2**14, 600_011), (3**10, 600_011), (65521, 600_011), (8209, 524_288),
+@pytest.mark.parametrize("q,n", [(2**16, 600_011), (2**16, 17_000_003), (3**10, 4_300_003), (65521, 4_194_304), (2**14, 600_011), (3**10, 600_011), (65521, 600_011), (8209, 524_288),
                                  (251**2, 700_001), (2**15, 4_200_005), (3**9, 600_011), (13**4, 600_011), (32771, 600_011), (32749, 600_011)])
 @pytest.mark.parametrize("mode", ["jit-lookup", "auto"])
 def test_fields_up_to_2e16_with_log_and_exp_staged_in_turn(q, n, mode):
@@ -776,6 +776,11 @@ def test_fields_up_to_2e16_with_log_and_exp_staged_in_turn(q, n, mode):
         assert np.array_equal(u(A + B), F.add(a, b))
         assert np.array_equal(u(A - B), F.sub(a, b))
         assert np.array_equal(u(-A), F.neg(a))
+        if n >= 2_000_000:  # (from 2^22 elements: the two streaming passes through an index array, big16_index_kernel / big16_exp_kernel)
+            for e in (12345, -3):
+                assert np.array_equal(u(Bnz ** e), F.pow(bnz, np.full(n, e, dtype=np.int64))), e
+            assert np.array_equal(u(A * B[7]), F.mul(a, full(b[7])))
+            assert np.array_equal(u(A[9] / Bnz), F.div(full(a[9]), bnz))
         if n < 2_000_000:
             for k in (5, 7):
                 assert np.array_equal(u(A * B[k]), F.mul(a, full(b[k])))
