@@ -699,28 +699,21 @@ __global__ __launch_bounds__(REP4 ? 512 : 256) void rs_lfsr_kernel(const u32 *__
 
 
 // ------------------------------------------------------------------------------------------------
-// Fast decoder for characteristic-2 codes with n-k <= 60: second kernel of the two-kernel decode
-// ------------------------------------------------------------------------------------------------
-// ------------------------------------------------------------------------------------------------
 // The same LFSR with the codeword ROW in registers (r04): n - k = 32, full-length rows of LEN = 223 / 255 symbols
 // ------------------------------------------------------------------------------------------------
 // rs_lfsr_kernel stages 64 rows per wave in LDS (16 KiB), which leaves a CU eight waves and a 4-copy table whose reads conflict:
-// LDS array 69 % busy, 64 % of it conflicts, two waves per SIMD to hide the table-read -> xor -> next-feedback chain.  Here every
-// lane loads ITS OWN row straight from global memory with 16-byte loads (rows start at any byte: gfx950 serves unaligned vector
-// accesses under HSA; all of a row's loads are issued at once, so each 128-byte line is fetched once), the row lives in 56 / 64
-// VGPRs, and LDS holds nothing but the table -- sixteen private copies, one per lane of a ds_read_b128 lane group, so NO read can
-// conflict: byte offset f * 512 + c * 256 + s * 16 for chunk c of row f, copy s = lane & 15.  One 1024-thread workgroup per CU
-// (four waves per SIMD).  Per symbol: one SDWA xor (feedback = state's top byte ^ the symbol's byte of its row register), one
-// address, two conflict-free 16-byte reads, the planar state update of rs_lfsr_kernel.  Outputs leave as 16-byte stores per lane
-// (the last 15 bytes of a 255-byte row as 12 + 2 + 1).
-// MODE 0: parity appended (full codewords), 1: parity only.  Measured (profiles/r04_rs_lfsr_reg.txt): 862 / 989 / 984 / 1069 GB/s of
-// codewords at 2^17 / 2^18 / 2^20 / 2^22 words against 860 / 920 / 934 / 947 for rs_lfsr_kernel; LDS array 22 % and vector ALU 21 %
-// busy, zero-conflict reads -- the kernel now waits on its scattered 16-byte global accesses (64 lines per wave instruction; PMC:
-// 1.45x the algorithmic bytes read, 1.36x written).  A decoder pre-pass in this form (+ a verbatim copy of the row: 18 more scattered
-// stores) LOST to the staged kernel (647 vs 685 GB/s at 2^20 clean words) and was not kept; encode takes it from 2^18 words.
-struct __attribute__((packed, aligned(1))) RowVec { u32 x, y, z, w; };
-struct __attribute__((packed, aligned(1))) RowVec3 { u32 x, y, z; };
-struct __attribute__((packed, aligned(1))) RowHalf { uint16_t v; };
+// LDS array 69 % busy, 64 % of it conflicts, two waves per SIMD to hide the table-read -> xor -> next-feedback chain.  Here the row
+// lives in 64 VGPRs of its lane (rows start at any byte: gfx950 serves unaligned vector accesses under HSA), and LDS holds nothing
+// but the table -- sixteen private copies, one per lane of a ds_read_b128 lane group, so NO read can conflict: byte offset
+// f * 512 + c * 256 + s * 16 for chunk c of row f, copy s = lane & 15.  One workgroup per CU, four waves per SIMD.  Per symbol: one SDWA
+// xor (feedback = state's top byte ^ the symbol's byte of its row register), one address, two conflict-free 16-byte reads, the planar
+// state update of rs_lfsr_kernel (12 vector instructions).
+// MODE 0: parity appended (full codewords), 1: parity only, 2: decoder pre-pass (remainder, non-zero flag, verbatim copy of the rows).
+// Measured (profiles/r04_rs_lfsr_reg.txt, GB/s of codewords at 2^17 / 2^18 / 2^20 / 2^22 words): encode 891 / 983 / 1081 / 1144 against
+// 861 / 930 / 945 / 958 for rs_lfsr_kernel; pre-pass 498 / 611 / 782 / 802 against 562 / 656 / 688 / 732.  With one lane per row and
+// plain per-lane 16-byte accesses (the first version: 64 cache lines per wave instruction) encode stood at 862 / 989 / 984 / 1069 and the
+// kernel waited on its global accesses (PMC: LDS array 22 %, vector ALU 21 % busy, 1.45x the algorithmic bytes read, 1.36x written).
+typedef u32 rs_u32x4 __attribute__((ext_vector_type(4)));
 
 template <int B> // top byte of p ^ byte B of r, zero-extended: ONE instruction
 __device__ __forceinline__ u32 xor_top_byte(u32 p, u32 r)
@@ -741,10 +734,36 @@ __device__ __forceinline__ void for_each_index(F &&f, std::integer_sequence<int,
 
 constexpr size_t LFSR_REG_LDS = 256 * 512; // 128 KiB: 256 rows x 2 chunks x 16 copies x 16 bytes
 
+// Global accesses (v2): a quad of lanes owns four consecutive rows.  Load r of a 64-byte block takes the block of row 4Q + r with
+// the quad's four lanes side by side (64 contiguous bytes per quad: 16-32 cache lines per wave instruction instead of 64), and a
+// 4 x 4 transpose inside the quad -- two rounds of a DPP exchange and a bit-field select per register -- hands every lane the four
+// chunks of its OWN row.  Stores run the same way backwards.  LEN = 223 / 255: blocks at bytes 0, 64, 128 and LEN - 64 (the last
+// one ends at the row's end and overlaps its predecessor; its registers serve the symbols from byte 192 on).
+__device__ __forceinline__ void quad_transpose(u32 (&t)[4], u32 m0, u32 m1)
+{ // t[r] of lane k <-> t[k] of lane r within a quad; m0 / m1: all-ones on lanes whose bit 0 / bit 1 is clear
+#pragma unroll
+    for (int a = 0; a < 4; a += 2) {
+        const u32 x = (u32)__builtin_amdgcn_update_dpp(0, (int)t[a], 0xB1, 0xf, 0xf, false);     // quad_perm [1,0,3,2]
+        const u32 y = (u32)__builtin_amdgcn_update_dpp(0, (int)t[a + 1], 0xB1, 0xf, 0xf, false);
+        t[a + 1] = (m0 & x) | (~m0 & t[a + 1]);
+        t[a] = (m0 & t[a]) | (~m0 & y);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++) {
+        const u32 x = (u32)__builtin_amdgcn_update_dpp(0, (int)t[a], 0x4E, 0xf, 0xf, false);     // quad_perm [2,3,0,1]
+        const u32 y = (u32)__builtin_amdgcn_update_dpp(0, (int)t[a + 2], 0x4E, 0xf, 0xf, false);
+        t[a + 2] = (m1 & x) | (~m1 & t[a + 2]);
+        t[a] = (m1 & t[a]) | (~m1 & y);
+    }
+}
+
 template <int LEN, int MODE>
-__global__ __launch_bounds__(1024) void rs_lfsr_reg_kernel(const u32 *__restrict__ rowtab, const uint8_t *in, uint8_t *out, i64 batch)
+__global__ __launch_bounds__(1024) void rs_lfsr_reg_kernel(const u32 *__restrict__ rowtab, const uint8_t *in, uint8_t *out, uint8_t *__restrict__ rem_out,
+                                                           uint8_t *__restrict__ flag_out, i64 batch)
 {
-    constexpr int NKW = 8, W = 2, NCH = (LEN + 15) / 16, LAST = LEN - 16; // the last chunk ENDS at the row's end (it overlaps its predecessor)
+    static_assert(LEN == 223 || LEN == 255, "three whole 64-byte blocks and an end-aligned fourth");
+    constexpr int NKW = 8, W = 2, LASTB = LEN - 64; // byte offset of the fourth block
+    constexpr bool ENCODE = MODE != 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     for (int i = threadIdx.x; i < 512; i += blockDim.x) { // 16-byte chunk c of row f: ONE load, sixteen copies
         const int c = i & 1, f = i >> 1;
@@ -755,33 +774,70 @@ __global__ __launch_bounds__(1024) void rs_lfsr_reg_kernel(const u32 *__restrict
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const u32 slot = (u32)(lane & 15) << 4;
+    const u32 m0 = (lane & 1) ? 0u : ~0u, m1 = (lane & 2) ? 0u : ~0u;
+    const int kq = lane & 3; // this lane's chunk inside a quad access
     __syncthreads();
     for (i64 cw0 = ((i64)blockIdx.x * nwaves + wave) * 64; cw0 < batch; cw0 += (i64)gridDim.x * nwaves * 64) {
         const i64 cw = cw0 + lane;
-        const bool live = cw < batch;
-        const uint8_t *row = in + (live ? cw : batch - 1) * LEN;
-        RowVec R[NCH];
+        // D[g][4 c + w]: word w of chunk c of block g of this lane's own row (after the transposes)
+        u32 D[4][16];
+        // buffer addressing: descriptors on this wave's 64 rows (input pitch LEN, output pitch LEN / 255), ONE 32-bit lane offset, row and
+        // block offsets as immediates; rows past the end of the batch are out of range (loads return 0, stores are dropped)
+        const i64 rows_left = batch - cw0 < 64 ? batch - cw0 : 64;
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)(in + cw0 * LEN), 0, (u32)(rows_left * LEN), 0x00020000);
+        const u32 vin = (u32)(lane & ~3) * (u32)LEN + 16u * (u32)kq;
+        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(out + cw0 * 255), 0, MODE == 0 ? (u32)(rows_left * 255) : 0u, 0x00020000);
+        const u32 vout = (u32)(lane & ~3) * 255u + 16u * (u32)kq;
+        rs_u32x4 T[2][4]; // two blocks in flight: block g + 1 travels while block g is transposed (all four at once would not fit 128 registers)
+        auto load_block = [&](auto gc, rs_u32x4 (&t)[4]) {
+            constexpr int G = decltype(gc)::value;
 #pragma unroll
-        for (int c = 0; c < NCH; c++) R[c] = *reinterpret_cast<const RowVec *>(row + (c + 1 < NCH ? 16 * c : LAST));
+            for (int r = 0; r < 4; r++) t[r] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)(vin + (u32)(r * LEN + (G < 3 ? 64 * G : LASTB))), 0, 0);
+        };
+        load_block(std::integral_constant<int, 0>{}, T[0]);
+        auto take_block = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g + 1 < 4) load_block(std::integral_constant<int, g + 1>{}, T[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            rs_u32x4(&t)[4] = T[g & 1];
+            if constexpr (MODE == 2) { // the received rows, verbatim, in the very form they arrived in
+                if (out && out != in) {
+                    const __amdgpu_buffer_rsrc_t rcp = __builtin_amdgcn_make_buffer_rsrc((void *)(out + cw0 * LEN), 0, (u32)(rows_left * LEN), 0x00020000);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) __builtin_amdgcn_raw_buffer_store_b128(t[r], rcp, (int)(vin + (u32)(r * LEN + (g < 3 ? 64 * g : LASTB))), 0, 0);
+                }
+            }
+            if constexpr (MODE == 0 && g < 3) { // message bytes 0 .. 191 go to the output rows (pitch 255) as they arrived; the rest leaves with the parity
+#pragma unroll
+                for (int r = 0; r < 4; r++) __builtin_amdgcn_raw_buffer_store_b128(t[r], rout, (int)(vout + (u32)(r * 255 + 64 * g)), 0, 0);
+            }
+            u32 tx[4] = {t[0][0], t[1][0], t[2][0], t[3][0]}, ty[4] = {t[0][1], t[1][1], t[2][1], t[3][1]};
+            u32 tz[4] = {t[0][2], t[1][2], t[2][2], t[3][2]}, tw[4] = {t[0][3], t[1][3], t[2][3], t[3][3]};
+            quad_transpose(tx, m0, m1);
+            __builtin_amdgcn_sched_barrier(0);
+            quad_transpose(ty, m0, m1);
+            __builtin_amdgcn_sched_barrier(0);
+            quad_transpose(tz, m0, m1);
+            __builtin_amdgcn_sched_barrier(0);
+            quad_transpose(tw, m0, m1);
+#pragma unroll
+            for (int c = 0; c < 4; c++) { D[g][4 * c + 0] = tx[c]; D[g][4 * c + 1] = ty[c]; D[g][4 * c + 2] = tz[c]; D[g][4 * c + 3] = tw[c]; }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for_each_index(take_block, std::make_integer_sequence<int, 4>{});
         u32 P[4][W];
 #pragma unroll
         for (int q = 0; q < 4; q++)
 #pragma unroll
             for (int h = 0; h < W; h++) P[q][h] = 0;
-        // symbol j: register word and byte inside the row's chunks
-        auto sym_word = [&](auto jc) -> u32 {
-            constexpr int J = decltype(jc)::value;
-            constexpr int C = J < 16 * (NCH - 1) ? J / 16 : NCH - 1, B = J < 16 * (NCH - 1) ? J % 16 : J - LAST;
-            const RowVec &r = R[C];
-            return B / 4 == 0 ? r.x : (B / 4 == 1 ? r.y : (B / 4 == 2 ? r.z : r.w));
-        };
         auto step = [&](auto jc) {
             constexpr int J = decltype(jc)::value, K = J & 3;
-            constexpr int BQ = (J < 16 * (NCH - 1) ? J % 16 : J - LAST) & 3;
-            const u32 rw = sym_word(jc);
-            const u32 f = xor_top_byte<BQ>(P[K][0], rw);
+            constexpr int G = J < 192 ? J / 64 : 3, BB = J < 192 ? J % 64 : J - LASTB, BQ = BB & 3; // block, byte inside it
+            const u32 rw = D[G][BB / 4];
+            const u32 f = ENCODE ? xor_top_byte<BQ>(P[K][0], rw) : P[K][0] >> 24;
             P[K][0] = __builtin_amdgcn_alignbit(P[K][0], P[K][1], 24);
-            P[K][1] = P[K][1] << 8;
+            if constexpr (ENCODE) P[K][1] = P[K][1] << 8;
+            else P[K][1] = __builtin_amdgcn_perm(P[K][1], rw, 0x06050400u + (u32)BQ); // {P.b2, P.b1, P.b0, rw.byte BQ}
             const u32 a = (f << 9) | slot;
             const uint4 r0 = *reinterpret_cast<const uint4 *>(lds_raw + a), r1 = *reinterpret_cast<const uint4 *>(lds_raw + a + 256);
             const u32 w[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
@@ -795,42 +851,42 @@ __global__ __launch_bounds__(1024) void rs_lfsr_reg_kernel(const u32 *__restrict
             constexpr int K = LEN & 3;
 #pragma unroll
             for (int h = 0; h < W; h++) {
-                const u32 A = P[K & 3][h], Bv = P[(K + 1) & 3][h], C = P[(K + 2) & 3][h], D = P[(K + 3) & 3][h];
+                const u32 A = P[K & 3][h], Bv = P[(K + 1) & 3][h], C = P[(K + 2) & 3][h], Dd = P[(K + 3) & 3][h];
                 const u32 t0 = __builtin_amdgcn_perm(A, Bv, 0x07030602u), t1 = __builtin_amdgcn_perm(A, Bv, 0x05010400u);
-                const u32 u0 = __builtin_amdgcn_perm(C, D, 0x07030602u), u1 = __builtin_amdgcn_perm(C, D, 0x05010400u);
+                const u32 u0 = __builtin_amdgcn_perm(C, Dd, 0x07030602u), u1 = __builtin_amdgcn_perm(C, Dd, 0x05010400u);
                 S[4 * h + 0] = __builtin_bswap32(__builtin_amdgcn_perm(t0, u0, 0x07060302u));
                 S[4 * h + 1] = __builtin_bswap32(__builtin_amdgcn_perm(t0, u0, 0x05040100u));
                 S[4 * h + 2] = __builtin_bswap32(__builtin_amdgcn_perm(t1, u1, 0x07060302u));
                 S[4 * h + 3] = __builtin_bswap32(__builtin_amdgcn_perm(t1, u1, 0x05040100u));
             }
         }
-        if (!live) continue;
-        if constexpr (MODE == 1) {
-            uint4 *dst = reinterpret_cast<uint4 *>(out + cw * 32);
-            dst[0] = make_uint4(S[0], S[1], S[2], S[3]);
-            dst[1] = make_uint4(S[4], S[5], S[6], S[7]);
+        if constexpr (MODE == 1 || MODE == 2) { // 32 bytes per word, the wave's 64 words contiguous: plain aligned stores
+            if (cw < batch) {
+                uint4 *dst = reinterpret_cast<uint4 *>((MODE == 1 ? out : rem_out) + cw * 32);
+                dst[0] = make_uint4(S[0], S[1], S[2], S[3]);
+                dst[1] = make_uint4(S[4], S[5], S[6], S[7]);
+                if (MODE == 2 && flag_out) flag_out[cw] = (S[0] | S[1] | S[2] | S[3] | S[4] | S[5] | S[6] | S[7]) != 0;
+            }
         } else {
-            static_assert(MODE != 0 || LEN % 16 == 15, "tail of 15 bytes");
-            uint8_t *orow = out + cw * (LEN + 32);
+            // the last 64 bytes of the 255-byte output row (from byte 191): message bytes 191 .. 222 = words 8 .. 15 of the fourth message
+            // block (which starts at byte 159), then the 32 parity bytes
+            u32 tx[4], ty[4], tz[4], tw[4];
 #pragma unroll
-            for (int c = 0; c + 1 < NCH; c++) *reinterpret_cast<RowVec *>(orow + 16 * c) = R[c];
-            const RowVec &t = R[NCH - 1];
-            // bytes LEN-15 .. LEN+31 = the row's last 15 bytes, then the 32 parity bytes: 47 bytes as 16 + 16 + 12 + 2 + 1
-            const u32 x0 = __builtin_amdgcn_alignbyte(t.y, t.x, 1), x1 = __builtin_amdgcn_alignbyte(t.z, t.y, 1), x2 = __builtin_amdgcn_alignbyte(t.w, t.z, 1);
-            const u32 x3 = __builtin_amdgcn_alignbyte(S[0], t.w, 1);
-            u32 y[8];
+            for (int c = 0; c < 4; c++) {
+                if (c < 2) { tx[c] = D[3][8 + 4 * c]; ty[c] = D[3][9 + 4 * c]; tz[c] = D[3][10 + 4 * c]; tw[c] = D[3][11 + 4 * c]; }
+                else { tx[c] = S[4 * (c - 2)]; ty[c] = S[4 * (c - 2) + 1]; tz[c] = S[4 * (c - 2) + 2]; tw[c] = S[4 * (c - 2) + 3]; }
+            }
+            quad_transpose(tx, m0, m1); quad_transpose(ty, m0, m1); quad_transpose(tz, m0, m1); quad_transpose(tw, m0, m1);
 #pragma unroll
-            for (int d = 0; d < 7; d++) y[d] = __builtin_amdgcn_alignbyte(S[d + 1], S[d], 1);
-            y[7] = S[7] >> 8;
-            *reinterpret_cast<RowVec *>(orow + LEN - 15) = RowVec{x0, x1, x2, x3};
-            *reinterpret_cast<RowVec *>(orow + LEN + 1) = RowVec{y[0], y[1], y[2], y[3]};
-            *reinterpret_cast<RowVec3 *>(orow + LEN + 17) = RowVec3{y[4], y[5], y[6]};
-            reinterpret_cast<RowHalf *>(orow + LEN + 29)->v = (uint16_t)y[7];
-            orow[LEN + 31] = (uint8_t)(y[7] >> 16);
+            for (int r = 0; r < 4; r++)
+                __builtin_amdgcn_raw_buffer_store_b128(rs_u32x4{tx[r], ty[r], tz[r], tw[r]}, rout, (int)(vout + (u32)(r * 255 + 191)), 0, 0);
         }
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast decoder for characteristic-2 codes with n-k <= 60: second kernel of the two-kernel decode
+// ------------------------------------------------------------------------------------------------
 // rs_lfsr_kernel has already reduced every received word modulo g(x) and copied the received rows to the output.  Words
 // with a zero remainder and no erasures need nothing more.  The rest are decoded ONE CODEWORD PER WAVEFRONT with the same
 // mathematics and failure exits as rs_decode_kernel / bch_decode_jit.  r02's version was vector-issue bound (PMC: 89 M vector
@@ -1525,18 +1581,24 @@ int launch_lfsr(gfa_rs *code, gfa_rs::Dev *cd, const uint8_t *in, const uint8_t 
                 int parity_only, uint8_t *rem_out, uint8_t *flag_out, i64 batch, hipStream_t st)
 {
     const int nk = (int)(code->n - code->k), nkw = nk / 4;
-    if constexpr (ENCODE) { // full-length messages of RS(255,223)-shaped codes in large batches: the register-resident form
-        if (nkw == 8 && !eras && len == 223 && batch >= ((i64)1 << 18)) {
-            const int grid = (int)std::max<i64>(1, std::min<i64>((batch + 1023) / 1024, (i64)cu_count())); // one workgroup per CU (LDS)
-            static bool attr0 = false, attr1 = false;
-            int rc;
-            if (parity_only) {
-                if ((rc = set_lds_limit(rs_lfsr_reg_kernel<223, 1>, &attr1))) return rc;
-                hipLaunchKernelGGL((rs_lfsr_reg_kernel<223, 1>), dim3(grid), dim3(1024), LFSR_REG_LDS, st, cd->lfsr, in, out, batch);
-            } else {
-                if ((rc = set_lds_limit(rs_lfsr_reg_kernel<223, 0>, &attr0))) return rc;
-                hipLaunchKernelGGL((rs_lfsr_reg_kernel<223, 0>), dim3(grid), dim3(1024), LFSR_REG_LDS, st, cd->lfsr, in, out, batch);
-            }
+    {   // full-length rows of RS(255,223)-shaped codes: the register-resident form (rs_lfsr_reg_kernel)
+        // measured against the staged kernel (profiles/r04_rs_lfsr_reg.txt): encode wins from 2^16 words (891 vs 861 GB/s at 2^17, 1081 vs 945 at
+        // 2^20), the decoder's pre-pass only from 2^19 (782 vs 688 GB/s of clean words at 2^20; 498 vs 562 at 2^17)
+        const bool shape = nkw == 8 && !eras && ((ENCODE && len == 223 && batch >= ((i64)1 << 16)) || (!ENCODE && len == 255 && rem_out && batch >= ((i64)1 << 19)));
+        if (shape) {
+            const int threads = batch >= (i64)1024 * cu_count() ? 1024 : 512; // one workgroup per CU (LDS); smaller ones cover every CU sooner
+            const int grid = (int)std::max<i64>(1, std::min<i64>((batch + threads - 1) / threads, (i64)cu_count()));
+#define GFA_LFSR_REG(LENV, MODEV)                                                                                        \
+    do {                                                                                                                \
+        static bool attr = false;                                                                                       \
+        int rc = set_lds_limit(rs_lfsr_reg_kernel<LENV, MODEV>, &attr);                                                 \
+        if (rc) return rc;                                                                                              \
+        hipLaunchKernelGGL((rs_lfsr_reg_kernel<LENV, MODEV>), dim3(grid), dim3(threads), LFSR_REG_LDS, st, cd->lfsr, in, out, rem_out, flag_out, batch); \
+    } while (0)
+            if (ENCODE && parity_only) GFA_LFSR_REG(223, 1);
+            else if (ENCODE) GFA_LFSR_REG(223, 0);
+            else GFA_LFSR_REG(255, 2);
+#undef GFA_LFSR_REG
             GFA_HIP(hipGetLastError());
             return GFA_OK;
         }
