@@ -709,10 +709,10 @@ __global__ __launch_bounds__(REP4 ? 512 : 256) void rs_lfsr_kernel(const u32 *__
 // xor (feedback = state's top byte ^ the symbol's byte of its row register), one address, two conflict-free 16-byte reads, the planar
 // state update of rs_lfsr_kernel (12 vector instructions).
 // MODE 0: parity appended (full codewords), 1: parity only, 2: decoder pre-pass (remainder, non-zero flag, verbatim copy of the rows).
-// Measured (profiles/r04_rs_lfsr_reg.txt, GB/s of codewords at 2^17 / 2^18 / 2^20 / 2^22 words): encode 891 / 983 / 1081 / 1144 against
-// 861 / 930 / 945 / 958 for rs_lfsr_kernel; pre-pass 498 / 611 / 782 / 802 against 562 / 656 / 688 / 732.  With one lane per row and
-// plain per-lane 16-byte accesses (the first version: 64 cache lines per wave instruction) encode stood at 862 / 989 / 984 / 1069 and the
-// kernel waited on its global accesses (PMC: LDS array 22 %, vector ALU 21 % busy, 1.45x the algorithmic bytes read, 1.36x written).
+// Measured (profiles/r04_rs_lfsr_reg.txt, GB/s of codewords at 2^17 / 2^18 / 2^20 / 2^22 words): encode 880 / 1075 / 1065 / 1219 against
+// 861 / 930 / 945 / 958 for rs_lfsr_kernel; pre-pass 498 / 611 / 782 / 802 against 562 / 656 / 688 / 732.  Probes of the same kernel: WITHOUT its
+// table reads it runs no faster (the LFSR loop is not what it waits for); storing only the last 64 bytes of every row it reaches
+// 1.6-1.8 TB/s, parity only 1.65-2.06: what is left is the 255-byte-pitch output written in 64-byte pieces.
 typedef u32 rs_u32x4 __attribute__((ext_vector_type(4)));
 
 template <int B> // top byte of p ^ byte B of r, zero-extended: ONE instruction
@@ -807,10 +807,6 @@ __global__ __launch_bounds__(1024) void rs_lfsr_reg_kernel(const u32 *__restrict
                     for (int r = 0; r < 4; r++) __builtin_amdgcn_raw_buffer_store_b128(t[r], rcp, (int)(vin + (u32)(r * LEN + (g < 3 ? 64 * g : LASTB))), 0, 0);
                 }
             }
-            if constexpr (MODE == 0 && g < 3) { // message bytes 0 .. 191 go to the output rows (pitch 255) as they arrived; the rest leaves with the parity
-#pragma unroll
-                for (int r = 0; r < 4; r++) __builtin_amdgcn_raw_buffer_store_b128(t[r], rout, (int)(vout + (u32)(r * 255 + 64 * g)), 0, 0);
-            }
             u32 tx[4] = {t[0][0], t[1][0], t[2][0], t[3][0]}, ty[4] = {t[0][1], t[1][1], t[2][1], t[3][1]};
             u32 tz[4] = {t[0][2], t[1][2], t[2][2], t[3][2]}, tw[4] = {t[0][3], t[1][3], t[2][3], t[3][3]};
             quad_transpose(tx, m0, m1);
@@ -868,8 +864,21 @@ __global__ __launch_bounds__(1024) void rs_lfsr_reg_kernel(const u32 *__restrict
                 if (MODE == 2 && flag_out) flag_out[cw] = (S[0] | S[1] | S[2] | S[3] | S[4] | S[5] | S[6] | S[7]) != 0;
             }
         } else {
-            // the last 64 bytes of the 255-byte output row (from byte 191): message bytes 191 .. 222 = words 8 .. 15 of the fourth message
-            // block (which starts at byte 159), then the 32 parity bytes
+            // ALL of a row leaves at the end of the pass, within a few microseconds.  Message blocks stored as they arrive would leave every
+            // 128-byte line of the output half written for the ~50 us of the LFSR loop; the L2 (4 MiB per XCD, 8 MB written per pass) evicts
+            // them partial, and the kernel ran at 1.06 instead of the 1.6-1.8 TB/s it reaches without those stores.  Holding the message in
+            // registers until here costs 384 bytes of scratch and is slower still (0.81 TB/s) -- so message bytes 0 .. 191 are READ AGAIN
+            // (in the quad form they are stored in: no transposes; the rows are a pass old and come from L2 / the Infinity Cache) and
+            // stored at once; the block at byte 191 is message bytes 191 .. 222 (words 8 .. 15 of the fourth message block, which starts
+            // at byte 159) and the 32 parity bytes (profiles/r04_rs_lfsr_reg.txt).
+#pragma unroll
+            for (int g = 0; g < 3; g++) {
+                rs_u32x4 t[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) t[r] = __builtin_amdgcn_raw_buffer_load_b128(rin, (int)(vin + (u32)(r * LEN + 64 * g)), 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) __builtin_amdgcn_raw_buffer_store_b128(t[r], rout, (int)(vout + (u32)(r * 255 + 64 * g)), 0, 0);
+            }
             u32 tx[4], ty[4], tz[4], tw[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
