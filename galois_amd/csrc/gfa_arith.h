@@ -13,6 +13,7 @@
 #else
 #define GFA_HD inline
 #endif
+#include "gfa_goldilocks.h"
 
 namespace gfa {
 
@@ -216,37 +217,40 @@ struct Goldilocks {
     }
     static GFA_HD u64 sub(const FieldDev &, u64 a, u64 b) { return a >= b ? a - b : a + (P - b); }
     static GFA_HD u64 neg(const FieldDev &, u64 a) { return a == 0 ? 0 : P - a; }
-    static GFA_HD u64 mul(const FieldDev &, u64 a, u64 b) { return reduce128(a * b, mulhi64(a, b)); }
+    // products through gl::mul_red (gfa_goldilocks.h): 4 multiply-adds and a fold on carries, any 64-bit representatives in
+    // and out; chains (powers, the inversion ladder) stay on such representatives and only their result is brought to [0, p)
+    static GFA_HD u64 mul_lazy(u64 a, u64 b) { return gl::mul_red(a, b); }
+    static GFA_HD u64 mul(const FieldDev &, u64 a, u64 b) { return gl::canon_u64(gl::mul_red(a, b)); }
     static GFA_HD u64 one(const FieldDev &) { return 1; }
-    static GFA_HD u64 pow_u(const FieldDev &f, u64 a, u64 e)
+    static GFA_HD u64 pow_u(const FieldDev &, u64 a, u64 e)
     {
         u64 r = 1;
         while (e) {
-            if (e & 1) r = mul(f, r, a);
-            a = mul(f, a, a);
+            if (e & 1) r = mul_lazy(r, a);
+            a = mul_lazy(a, a);
             e >>= 1;
         }
-        return r;
+        return gl::canon_u64(r);
     }
-    static GFA_HD u64 sqn(const FieldDev &f, u64 a, int k)
+    static GFA_HD u64 sqn_lazy(u64 a, int k)
     {
 #pragma unroll 1
-        for (int i = 0; i < k; i++) a = mul(f, a, a);
+        for (int i = 0; i < k; i++) a = mul_lazy(a, a);
         return a;
     }
     // a^(p-2), p - 2 = 2^64 - 2^32 - 1 = (2^31 - 1) * 2^33 + (2^32 - 1): 64 squarings and 9 products along the chain
     // 2^k - 1 for k = 2, 3, 6, 12, 24, 30, 31, 32 (binary square-and-multiply takes 64 + 63)
     static GFA_HD u64 inv(const FieldDev &f, u64 a)
     {
-        const u64 x2 = mul(f, sqn(f, a, 1), a);
-        const u64 x3 = mul(f, sqn(f, x2, 1), a);
-        const u64 x6 = mul(f, sqn(f, x3, 3), x3);
-        const u64 x12 = mul(f, sqn(f, x6, 6), x6);
-        const u64 x24 = mul(f, sqn(f, x12, 12), x12);
-        const u64 x30 = mul(f, sqn(f, x24, 6), x6);
-        const u64 x31 = mul(f, sqn(f, x30, 1), a);
-        const u64 x32 = mul(f, sqn(f, x31, 1), a);
-        return mul(f, sqn(f, x31, 33), x32);
+        const u64 x2 = mul_lazy(sqn_lazy(a, 1), a);
+        const u64 x3 = mul_lazy(sqn_lazy(x2, 1), a);
+        const u64 x6 = mul_lazy(sqn_lazy(x3, 3), x3);
+        const u64 x12 = mul_lazy(sqn_lazy(x6, 6), x6);
+        const u64 x24 = mul_lazy(sqn_lazy(x12, 12), x12);
+        const u64 x30 = mul_lazy(sqn_lazy(x24, 6), x6);
+        const u64 x31 = mul_lazy(sqn_lazy(x30, 1), a);
+        const u64 x32 = mul_lazy(sqn_lazy(x31, 1), a);
+        return gl::canon_u64(mul_lazy(sqn_lazy(x31, 33), x32));
     }
     static GFA_HD u64 from_int(const FieldDev &, i64 k)
     {

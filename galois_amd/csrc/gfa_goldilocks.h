@@ -1,15 +1,17 @@
 // gfa_goldilocks.h -- lazy arithmetic modulo p = 2^64 - 2^32 + 1 for the register NTT networks.
 //
-// Inside a network every value is a 96-bit two's-complement integer in three 32-bit limbs (G3): any representative of
-// its residue class with |value| < 2^70.  Then
+// Inside a network every value is a 96-bit two's-complement integer (G3): any representative of its residue class with
+// |value| < 2^70.  Then
 //   * add / sub are three carry-chained 32-bit instructions and never reduce (a radix-32 network grows a value by 5 bits);
-//   * a product with a 64-bit twiddle first folds the operand to 64 bits (2^64 == 2^32 - 1: one 32x32+64 multiply-add per
-//     round, two rounds), forms the 128-bit product with four v_mad_u64_u32 and folds it back with one more
-//     (2^64 == 2^32 - 1, 2^96 == -1): no compare / select chains anywhere;
+//   * a twiddle that is a power of two is a bit shift, a word rotation and one fold (2^64 == 2^32 - 1, 2^96 == -1):
+//     9-12 instructions (mul_pow2_small);
+//   * a product with a 64-bit twiddle first folds the operand to 64 bits, forms the 128-bit product with four
+//     v_mad_u64_u32 and folds it back with 32-bit carry chains: no compare / select chains anywhere;
 //   * only values that leave the registers (LDS exchange, global store) are brought to 64 bits / to the canonical [0, p).
-// On the device the carry chains are inline assembly (clang's own lowering of the same expressions goes through 64-bit
-// compares and v_cndmask); the portable expressions below them are what the host compiles, and
-// tests/test_host_logic.py checks those against Python integers (the device path is pinned by the NTT parity tests).
+// The value type is a native 96-bit integer (_BitInt(96); __int128 where the host compiler has no _BitInt in C++), so the
+// SAME expressions compile for the device and for the host: tests/csrc/goldilocks_host_test.cpp checks them against 128-bit
+// integer arithmetic, and the compiler -- not inline assembly with tied operands -- allocates the limbs (the round-3 form of
+// this header spent a fifth of the kernel's vector instructions on register copies around its asm statements).
 #pragma once
 #include <cstdint>
 
@@ -26,53 +28,42 @@ namespace gl {
 
 typedef uint32_t gu32;
 typedef uint64_t gu64;
+#if defined(__clang__)
+typedef signed _BitInt(96) gint;
+typedef unsigned _BitInt(96) guint;
+#else
+typedef __int128 gint; // host g++: the checked ranges never leave 96 bits
+typedef unsigned __int128 guint;
+#endif
 
 struct G3 {
-    gu32 lo, mid;
-    int32_t hi; // value = lo + 2^32 * mid + 2^64 * hi
+    gint v;
 };
 
 constexpr gu64 P = 0xFFFFFFFF00000001ull;
 
-GFA_HD G3 from_u64(gu64 x) { return G3{(gu32)x, (gu32)(x >> 32), 0}; }
-
-GFA_HD G3 add(G3 a, G3 b)
+GFA_HD gu32 limb0(G3 x) { return (gu32)x.v; }
+GFA_HD gu32 limb1(G3 x) { return (gu32)(x.v >> 32); }
+GFA_HD int32_t limb2(G3 x) { return (int32_t)(gu32)(x.v >> 64); }
+// lo + 2^32 * mid + 2^64 * hi (hi signed)
+GFA_HD G3 from_limbs(gu32 lo, gu32 mid, int32_t hi)
 {
-#ifdef __HIP_DEVICE_COMPILE__
-    asm("v_add_co_u32 %0, vcc, %0, %3\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\tv_addc_co_u32 %2, vcc, %2, %5, vcc"
-        : "+v"(a.lo), "+v"(a.mid), "+v"(a.hi)
-        : "v"(b.lo), "v"(b.mid), "v"(b.hi)
-        : "vcc");
-    return a;
-#else
-    const gu64 s0 = (gu64)a.lo + b.lo;
-    const gu64 s1 = (gu64)a.mid + b.mid + (s0 >> 32);
-    return G3{(gu32)s0, (gu32)s1, (int32_t)((gu32)a.hi + (gu32)b.hi + (gu32)(s1 >> 32))};
-#endif
+    return G3{(gint)(guint)(((gu64)mid << 32) | lo) + (gint)hi * ((gint)1 << 64)};
 }
+GFA_HD G3 from_u64(gu64 x) { return G3{(gint)(guint)x}; }
+GFA_HD G3 from_i64(int64_t x) { return G3{(gint)x}; }
 
-GFA_HD G3 sub(G3 a, G3 b)
-{
-#ifdef __HIP_DEVICE_COMPILE__
-    asm("v_sub_co_u32 %0, vcc, %0, %3\n\tv_subb_co_u32 %1, vcc, %1, %4, vcc\n\tv_subb_co_u32 %2, vcc, %2, %5, vcc"
-        : "+v"(a.lo), "+v"(a.mid), "+v"(a.hi)
-        : "v"(b.lo), "v"(b.mid), "v"(b.hi)
-        : "vcc");
-    return a;
-#else
-    const gu64 d0 = (gu64)a.lo - b.lo; // bit 63 set <=> borrow
-    const gu64 d1 = (gu64)a.mid - b.mid - (d0 >> 63);
-    return G3{(gu32)d0, (gu32)d1, (int32_t)((gu32)a.hi - (gu32)b.hi - (gu32)(d1 >> 63))};
-#endif
-}
+GFA_HD G3 add(G3 a, G3 b) { return G3{a.v + b.v}; }
+GFA_HD G3 sub(G3 a, G3 b) { return G3{a.v - b.v}; }
 
 // acc + a * (2^32 - 1) as (64-bit result, carry out)
 GFA_HD gu64 mad_eps_carry(gu64 acc, gu32 a, gu32 *carry)
 {
 #ifdef __HIP_DEVICE_COMPILE__
     gu32 c;
-    const gu32 zero = 0;
-    asm("v_mad_u64_u32 %0, vcc, %2, -1, %0\n\tv_addc_co_u32 %1, vcc, 0, %3, vcc" : "+v"(acc), "=v"(c) : "v"(a), "v"(zero) : "vcc");
+    // s_nop 1: the two wait states the gfx940 family wants between a VALU write of VCC and a VALU read of it as carry-in (the
+    // compiler pads its own chains the same way; nothing inside an asm string is padded for us)
+    asm("v_mad_u64_u32 %0, vcc, %2, -1, %0\n\ts_nop 1\n\tv_addc_co_u32_e64 %1, vcc, 0, 0, vcc" : "+v"(acc), "=v"(c) : "v"(a) : "vcc");
     *carry = c;
     return acc;
 #else
@@ -87,44 +78,25 @@ GFA_HD gu64 mad_eps_carry(gu64 acc, gu32 a, gu32 *carry)
 // multiply-add.  The sum is below 2^64 + 2^39, so a carry out leaves a small low part and the second fold cannot carry.
 GFA_HD gu64 to_u64(G3 x)
 {
-#ifdef __HIP_DEVICE_COMPILE__
-    const gu32 k64 = 64u, km64 = 0xFFFFFFC0u, k63 = 63u;
-    asm("v_add_co_u32 %0, vcc, %0, %3\n\tv_addc_co_u32 %1, vcc, %1, %4, vcc\n\tv_addc_co_u32 %2, vcc, %2, %5, vcc"
-        : "+v"(x.lo), "+v"(x.mid), "+v"(x.hi)
-        : "v"(k64), "v"(km64), "v"(k63)
-        : "vcc");
+    const gint bias = (gint)(guint)0xFFFFFFC000000040ull + (gint)63 * ((gint)1 << 64);
+    const G3 y{x.v + bias};
     gu32 c;
-    const gu64 w = mad_eps_carry(((gu64)x.mid << 32) | x.lo, (gu32)x.hi, &c);
+    const gu64 w = mad_eps_carry((gu64)(guint)y.v, (gu32)limb2(y), &c);
     return w + (gu64)c * 0xFFFFFFFFu;
-#else
-    const gu64 s0 = (gu64)x.lo + 64u;
-    const gu64 s1 = (gu64)x.mid + 0xFFFFFFC0u + (s0 >> 32);
-    const gu32 h = (gu32)x.hi + 63u + (gu32)(s1 >> 32);
-    gu32 c;
-    const gu64 w = mad_eps_carry(((gu64)(gu32)s1 << 32) | (gu32)s0, h, &c);
-    return w + (gu64)c * 0xFFFFFFFFu;
-#endif
 }
 
 // canonical residue in [0, p) of any 64-bit representative
 GFA_HD gu64 canon_u64(gu64 y)
 {
-#ifdef __HIP_DEVICE_COMPILE__
-    // y + (2^32 - 1) == y - p (mod 2^64) carries exactly when y >= p; the carry then selects it through an arithmetic mask
-    gu32 c;
-    const gu64 t = mad_eps_carry(y, 1u, &c);
-    const gu64 m = (gu64)0 - (gu64)c;
-    return (t & m) | (y & ~m);
-#else
+    // y + (2^32 - 1) == y - p (mod 2^64) carries exactly when y >= p
     const gu64 t = y + 0xFFFFFFFFull;
     return t < y ? t : y;
-#endif
 }
 
 GFA_HD gu64 canon(G3 x) { return canon_u64(to_u64(x)); }
 
 // y * w for 64-bit y, w (w need not be canonical): 4 multiply-adds for the 128-bit product [r0 r1 r2 r3], then
-// r0 + 2^32 r1 + (2^32 - 1) r2 - r3 as a G3 with -1 <= hi <= 1
+// (r0 - r2 - r3) + 2^32 (r1 + r2): a G3 with -2 <= hi <= 1
 GFA_HD G3 mul_u64(gu64 y, gu64 w)
 {
     const gu32 y0 = (gu32)y, y1 = (gu32)(y >> 32), w0 = (gu32)w, w1 = (gu32)(w >> 32);
@@ -132,11 +104,28 @@ GFA_HD G3 mul_u64(gu64 y, gu64 w)
     const gu64 t1 = (gu64)y0 * w1 + (t0 >> 32);
     const gu64 t2 = (gu64)y1 * w0 + (gu32)t1;
     const gu64 t3 = (gu64)y1 * w1 + (t1 >> 32) + (t2 >> 32); // < 2^64
-    const gu64 lo64 = ((gu64)(gu32)t2 << 32) | (gu32)t0;    // r0 + 2^32 r1
+    const gu32 r0 = (gu32)t0, r1 = (gu32)t2, r2 = (gu32)t3, r3 = (gu32)(t3 >> 32);
+    const gint hi = ((gint)(guint)((gu64)r1 + r2)) << 32;
+    return G3{hi + (gint)(guint)r0 - (gint)(guint)((gu64)r2 + r3)};
+}
+
+// y * w as a 64-bit representative (not canonical): the 128-bit product [r0 r1 r2 r3] is lo64 - r3 + (2^32 - 1) r2 modulo p; a
+// borrow of the subtraction wraps by 2^64 == 2^32 - 1 and is taken back at once (the wrapped value is >= 2^64 - 2^32), a carry
+// of the multiply-add likewise (the wrapped value is < (2^32 - 1)^2)
+GFA_HD gu64 mul_red(gu64 y, gu64 w)
+{
+    const gu32 y0 = (gu32)y, y1 = (gu32)(y >> 32), w0 = (gu32)w, w1 = (gu32)(w >> 32);
+    const gu64 t0 = (gu64)y0 * w0;
+    const gu64 t1 = (gu64)y0 * w1 + (t0 >> 32);
+    const gu64 t2 = (gu64)y1 * w0 + (gu32)t1;
+    const gu64 t3 = (gu64)y1 * w1 + (t1 >> 32) + (t2 >> 32); // < 2^64
+    const gu64 lo64 = ((gu64)(gu32)t2 << 32) | (gu32)t0;
     const gu32 r2 = (gu32)t3, r3 = (gu32)(t3 >> 32);
+    gu64 t = lo64 - r3;
+    t -= lo64 < (gu64)r3 ? 0xFFFFFFFFull : 0ull;
     gu32 c;
-    const gu64 u = mad_eps_carry(lo64, r2, &c);
-    return sub(G3{(gu32)u, (gu32)(u >> 32), (int32_t)c}, G3{r3, 0u, 0});
+    const gu64 u = mad_eps_carry(t, r2, &c);
+    return u + (gu64)c * 0xFFFFFFFFu;
 }
 
 GFA_HD G3 mul(G3 x, gu64 w) { return mul_u64(to_u64(x), w); }
@@ -148,40 +137,129 @@ GFA_HD G3 mul(G3 x, gu64 w) { return mul_u64(to_u64(x), w); }
 //   q = 0:  (t0 - t2 - t3) + 2^32 (t1 + t2)
 //   q = 1:  (-t1 - t2)     + 2^32 (t0 + t1 - t3)
 //   q = 2:  (-t0 - t1 + t3) + 2^32 (t0 - t2 - t3)
-// as three to five carry-chained 96-bit add / sub (3 instructions each) after four shifts: 14-20 instructions against ~32 for
-// a general product.  Any |x| < 2^94 (|hi| < 2^30); the result has |value| < 2^66.
+// Any |x| < 2^94 (|hi| < 2^30); the result has |value| < 2^66.
 template <int S>
 GFA_HD G3 mul_pow2(G3 x)
 {
     static_assert(S > 0 && S < 96, "shift out of range");
     constexpr int q = S / 32, r = S % 32;
+    const gu32 a = limb0(x), b = limb1(x);
+    const int32_t c = limb2(x);
     gu32 t0, t1, t2;
     int32_t t3;
     if (r == 0) {
-        t0 = x.lo; t1 = x.mid; t2 = (gu32)x.hi; t3 = x.hi >> 31;
+        t0 = a; t1 = b; t2 = (gu32)c; t3 = c >> 31;
     } else {
-        t0 = x.lo << r;
-        t1 = (x.mid << r) | (x.lo >> (32 - r));
-        t2 = ((gu32)x.hi << r) | (x.mid >> (32 - r));
-        t3 = x.hi >> (32 - r);
+        t0 = a << r;
+        t1 = (b << r) | (a >> ((32 - r) & 31));
+        t2 = ((gu32)c << r) | (b >> ((32 - r) & 31));
+        t3 = c >> ((32 - r) & 31);
     }
-    const int32_t sx = t3 >> 31; // sign extension of t3
-    if (q == 0) {
-        G3 v = sub(G3{t0, t1, 0}, G3{t2, 0u, 0});
-        v = add(v, G3{0u, t2, 0});
-        return sub(v, G3{(gu32)t3, (gu32)sx, sx});
-    } else if (q == 1) {
-        G3 v = add(G3{0u, t0, 0}, G3{0u, t1, 0});
-        v = sub(v, G3{t1, 0u, 0});
-        v = sub(v, G3{t2, 0u, 0});
-        return sub(v, G3{0u, (gu32)t3, sx});
-    } else {
-        G3 v = sub(G3{0u, t0, 0}, G3{t0, 0u, 0});
-        v = sub(v, G3{t1, 0u, 0});
-        v = sub(v, G3{0u, t2, 0});
-        v = add(v, G3{(gu32)t3, (gu32)sx, sx});
-        return sub(v, G3{0u, (gu32)t3, sx});
+    const gint T0 = (gint)(guint)t0, T1 = (gint)(guint)t1, T2 = (gint)(guint)t2, T3 = (gint)t3;
+    if (q == 0) return G3{T0 - T2 - T3 + ((T1 + T2) << 32)};
+    if (q == 1) return G3{-T1 - T2 + ((T0 + T1 - T3) << 32)};
+    return G3{-T0 - T1 + T3 + ((T0 - T2 - T3) << 32)};
+}
+
+// The same product for |x| < 2^(95 - r), r = S mod 32 > 0: the shifted high limb t2 = (hi << r) | (mid >> (32 - r)) then holds
+// its value as a SIGNED 32-bit number and no fourth limb exists:
+//   q = 0:  (t0 - t2) + 2^32 (t1 + t2)
+//   q = 1:  (-t1 - t2) + 2^32 (t0 + t1)
+//   q = 2:  (-t0 - t1) + 2^32 (t0 - t2)
+// 9 / 12 / 11 instructions.  Inside the radix-32 / radix-16 networks of the NTT kernel the operand of a shift by 32 q + r at
+// butterfly level s has |x| < 2^(69 - s) (gl_shift_bound in gfa_ntt.hip), which is within the precondition for every shift used;
+// tests/csrc/goldilocks_host_test.cpp replays the networks' schedule with exact bounds.  |result| < 2^66.
+template <int S>
+GFA_HD G3 mul_pow2_small(G3 x)
+{
+    static_assert(S > 0 && S < 96 && S % 32 != 0, "shift out of range");
+    constexpr int q = S / 32, r = S % 32;
+    const gu32 a = limb0(x), b = limb1(x);
+    const int32_t c = limb2(x);
+    const gu32 t0 = a << r;
+    const gu32 t1 = (b << r) | (a >> (32 - r));
+    const int32_t t2 = (int32_t)(((gu32)c << r) | (b >> (32 - r)));
+    const gint T0 = (gint)(guint)t0, T1 = (gint)(guint)t1, T2 = (gint)t2;
+    if (q == 0) return G3{T0 - T2 + ((T1 + T2) << 32)};
+    if (q == 1) return G3{-T1 - T2 + ((T0 + T1) << 32)};
+    return G3{-T0 - T1 + ((T0 - T2) << 32)};
+}
+
+// x * 2^(6k), k = 1 .. 15: after unrolling k is a constant and the switch folds to one instance
+GFA_HD G3 mul_pow2_6k(G3 x, int k)
+{
+    switch (k) {
+    case 1: return mul_pow2_small<6>(x);
+    case 2: return mul_pow2_small<12>(x);
+    case 3: return mul_pow2_small<18>(x);
+    case 4: return mul_pow2_small<24>(x);
+    case 5: return mul_pow2_small<30>(x);
+    case 6: return mul_pow2_small<36>(x);
+    case 7: return mul_pow2_small<42>(x);
+    case 8: return mul_pow2_small<48>(x);
+    case 9: return mul_pow2_small<54>(x);
+    case 10: return mul_pow2_small<60>(x);
+    case 11: return mul_pow2_small<66>(x);
+    case 12: return mul_pow2_small<72>(x);
+    case 13: return mul_pow2_small<78>(x);
+    case 14: return mul_pow2_small<84>(x);
+    default: return mul_pow2_small<90>(x);
     }
+}
+
+// Radix-R decimation-in-frequency network on the CANONICAL root w_R = 2^(192/R) (2 has order 192 modulo p), R = 2^LOGR <= 32:
+// v[bitrev(k)] <- sum_a v[a] * w_R^(a k).  Every twiddle is a power of two (mul_pow2_small).  A transform whose root is
+// w_R = canonical^u (u odd) is served by feeding the inputs in the order a' = u * a mod R -- the caller's job.
+// Inputs: any |v[a]| <= 2^64 (the kernel feeds [0, 2^64)).  Bounds, with B(x) = bits of |x|: every butterfly adds one bit and a
+// shifted value restarts at 66, so the operand of a shift at level s (half = 2^s, the first level being s = LOGR - 1) is
+// below 2^(65 + LOGR - 1 - s) <= 2^69 -- the largest shift remainders r = 30, 28 only occur at the first two levels (odd and
+// singly-even multiples of 6), where 65 <= 95 - 30 and 67 <= 95 - 28 hold: dif_shift_bounds_ok() replays exactly this.
+template <int LOGR>
+GFA_HD void dif_shift(G3 (&v)[1 << LOGR])
+{
+    constexpr int R = 1 << LOGR;
+    constexpr int UNIT6 = 32 >> LOGR; // 2^(192/R) = 2^(6 * UNIT6)
+#pragma unroll
+    for (int s = LOGR - 1; s >= 0; s--) {
+        const int half = 1 << s;
+#pragma unroll
+        for (int b = 0; b < R; b += 2 * half) {
+#pragma unroll
+            for (int j = 0; j < half; j++) {
+                const G3 u = v[b + j], x = v[b + j + half];
+                v[b + j] = add(u, x);
+                const int tj = j << (LOGR - 1 - s);
+                if (tj != 0) v[b + j + half] = mul_pow2_6k(sub(u, x), tj * UNIT6);
+                else v[b + j + half] = sub(u, x);
+            }
+        }
+    }
+}
+
+// the schedule of dif_shift<LOGR> on magnitude bounds alone (bits[i]: |v[i]| < 2^bits[i], 64 on entry): true when every
+// mul_pow2_small meets its precondition and every result stays below 2^70 (to_u64's range)
+inline bool dif_shift_bounds_ok(int logr)
+{
+    const int R = 1 << logr, unit6 = 32 >> logr;
+    int bits[32];
+    for (int i = 0; i < R; i++) bits[i] = 64;
+    for (int s = logr - 1; s >= 0; s--) {
+        const int half = 1 << s;
+        for (int b = 0; b < R; b += 2 * half)
+            for (int j = 0; j < half; j++) {
+                const int m = (bits[b + j] > bits[b + j + half] ? bits[b + j] : bits[b + j + half]) + 1;
+                bits[b + j] = m;
+                const int tj = j << (logr - 1 - s);
+                if (tj != 0) {
+                    const int r = (6 * tj * unit6) % 32;
+                    if (r == 0 || m > 95 - r) return false;
+                    bits[b + j + half] = 66;
+                } else bits[b + j + half] = m;
+            }
+    }
+    for (int i = 0; i < R; i++)
+        if (bits[i] > 70) return false;
+    return true;
 }
 
 } // namespace gl

@@ -205,6 +205,20 @@ __global__ void shoup_table_kernel(u32 p, const u32 *w, u32 *wq, i64 count, int 
     if (i < count) wq[i] = (u32)((((u64)w[i]) << qbits) / p);
 }
 
+// Goldilocks inter-pass twiddles as a table: T[line + lines * k] = w^(line * k mod count), count = lines * L entries -- the
+// layout of the column pass's output inside one transform, so a thread reads its twiddle at the offset it stores to (the same
+// 64-byte segments), and every transform of the batch shares the table through L2 / the Infinity Cache.  This replaces the
+// per-thread progression t <- t * ratio: one product per point instead of two in that pass.
+__global__ void gl_post_table_kernel(const u64 *__restrict__ powA, const u64 *__restrict__ powB, int lo_bits, u64 *__restrict__ out,
+                                     u32 lines, u32 count)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const u32 line = i % lines, k = i / lines;
+    const u32 e = (line * k) & (count - 1); // count is a power of two <= 2^20: the product fits 32 bits
+    out[i] = gl::canon_u64(gl::mul_red(powA[e >> lo_bits], powB[e & ((1u << lo_bits) - 1)]));
+}
+
 // ------------------------------------------------------------------------------------------------
 // LDS tile transform
 // ------------------------------------------------------------------------------------------------
@@ -336,7 +350,8 @@ struct RegArgs {
     i64 total_lines; // lines per batch item
     int tiles_per_batch;
     int load_along_line, store_along_line; // which index is contiguous in memory (runs fastest across lanes)
-    int post_twiddle; // multiply output (line, k) by w_N^((line_offset + line) * k) = A[e >> lo_bits] * B[e & mask]
+    int post_twiddle; // multiply output (line, k) by w_N^((line_offset + line) * k) = A[e >> lo_bits] * B[e & mask]; 2 (Goldilocks
+                      // kernel only): the products come from a table passed in place of A, laid out like the output of one transform
     int pre_twiddle;  // multiply INPUT (line, t) by w_N^((line_offset + line) * t) before the transform (inverse four-step)
     int lo_bits;
     u64 n_mask;
@@ -353,6 +368,7 @@ struct RegArgs {
     i64 in_chunk_stride = 0, out_chunk_stride = 0; // elements
     int perm1 = 1, perm2 = 1; // Goldilocks shift-twiddle networks: input permutations (see ntt_reg_kernel_gl)
     int waves4 = 0;           // Goldilocks: hold the kernel to 128 VGPRs (four waves per SIMD); set by the three-pass driver
+    int lazy_out = 0;         // Goldilocks, twiddled output that only feeds the next pass: any 64-bit representative, not the canonical one
 };
 
 // byte offset of position t0 (a multiple of the lane-owned low part; wave-uniform => scalar arithmetic)
@@ -625,53 +641,6 @@ __device__ __forceinline__ void reg_dif_gl(gl::G3 (&v)[1 << LOGR], const u64 *__
     }
 }
 
-// x * 2^(6k), k = 1 .. 15: after unrolling k is a constant and the switch folds to one gl::mul_pow2 instance
-__device__ __forceinline__ gl::G3 gl_mul_pow2_6k(gl::G3 x, int k)
-{
-    switch (k) {
-    case 1: return gl::mul_pow2<6>(x);
-    case 2: return gl::mul_pow2<12>(x);
-    case 3: return gl::mul_pow2<18>(x);
-    case 4: return gl::mul_pow2<24>(x);
-    case 5: return gl::mul_pow2<30>(x);
-    case 6: return gl::mul_pow2<36>(x);
-    case 7: return gl::mul_pow2<42>(x);
-    case 8: return gl::mul_pow2<48>(x);
-    case 9: return gl::mul_pow2<54>(x);
-    case 10: return gl::mul_pow2<60>(x);
-    case 11: return gl::mul_pow2<66>(x);
-    case 12: return gl::mul_pow2<72>(x);
-    case 13: return gl::mul_pow2<78>(x);
-    case 14: return gl::mul_pow2<84>(x);
-    default: return gl::mul_pow2<90>(x);
-    }
-}
-
-// The same network for the CANONICAL root w_R = 2^(192/R) (2 has order 192 modulo p): every twiddle is a power of two, i.e. a
-// shift and a fold (gl::mul_pow2, 14-20 instructions) instead of a general product (~32).  A transform whose root is
-// w_R = canonical^u (u odd) is served by feeding the inputs in the order a' = u * a mod R -- the caller's job.
-template <int LOGR>
-__device__ __forceinline__ void reg_dif_gl_shift(gl::G3 (&v)[1 << LOGR])
-{
-    constexpr int R = 1 << LOGR;
-    constexpr int UNIT6 = 32 >> LOGR; // 2^(192/R) = 2^(6 * UNIT6)
-#pragma unroll
-    for (int s = LOGR - 1; s >= 0; s--) {
-        const int half = 1 << s;
-#pragma unroll
-        for (int b = 0; b < R; b += 2 * half) {
-#pragma unroll
-            for (int j = 0; j < half; j++) {
-                const gl::G3 u = v[b + j], x = v[b + j + half];
-                v[b + j] = gl::add(u, x);
-                const int tj = j << (LOGR - 1 - s);
-                if (tj != 0) v[b + j + half] = gl_mul_pow2_6k(gl::sub(u, x), tj * UNIT6);
-                else v[b + j + half] = gl::sub(u, x);
-            }
-        }
-    }
-}
-
 // SHIFT: networks on the canonical roots with shift twiddles; the input permutations that make them compute the wanted
 // transform are ra.perm1 (register a' of the first network loads position (perm1 * a') mod R1) and ra.perm2 (the thread that
 // owns column r of the exchange writes it at position (perm2 * r) mod R2).  Not combined with pre_twiddle (whose progression
@@ -733,15 +702,15 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
                 // * w_N^(line * (r + R2*a)): per-thread geometric progression, one table fetch for its start and its ratio
                 const u32 line = (u32)(ra.line_offset + line0 + cl);
                 const u32 e0 = (line * (u32)ra_) & nmask, es = (line * (u32)R2) & nmask;
-                u64 t = gl::to_u64(gl::mul_u64(powA[e0 >> ra.lo_bits], powB[e0 & lo_mask]));
-                const u64 sr = gl::to_u64(gl::mul_u64(powA[es >> ra.lo_bits], powB[es & lo_mask]));
+                u64 t = gl::mul_red(powA[e0 >> ra.lo_bits], powB[e0 & lo_mask]);
+                const u64 sr = gl::mul_red(powA[es >> ra.lo_bits], powB[es & lo_mask]);
 #pragma unroll
                 for (int a = 0; a < R1; a++) {
-                    va[a] = gl::from_u64(gl::to_u64(gl::mul_u64(gl::to_u64(va[a]), t))); // back to [0, 2^64): the network's input range
-                    if (a + 1 < R1) t = gl::to_u64(gl::mul_u64(t, sr));
+                    va[a] = gl::from_u64(gl::mul_red(gl::to_u64(va[a]), t)); // back to [0, 2^64): the network's input range
+                    if (a + 1 < R1) t = gl::mul_red(t, sr);
                 }
             }
-            if constexpr (SHIFT) reg_dif_gl_shift<LOGR1>(va);
+            if constexpr (SHIFT) gl::dif_shift<LOGR1>(va);
             else reg_dif_gl<LOGR1>(va, wL, R2); // w_R1 = w_L^R2
         }
         __syncthreads(); // middle-twiddle table staged
@@ -754,7 +723,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
                 for (int kl = 0; kl < RROWS; kl++) {
                     const int kaa = h * RROWS + kl;
                     if (kaa == 0) dst[0] = gl::to_u64(va[0]);
-                    else dst[kl * ROW] = gl::to_u64(gl::mul(va[brev_c(kaa, LOGR1)], twl[idx]));
+                    else dst[kl * ROW] = gl::mul_red(gl::to_u64(va[brev_c(kaa, LOGR1)]), twl[idx]);
                     idx += (u32)ra_;
                 }
             }
@@ -767,27 +736,44 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(WAVES, 
             if (SPLIT && h == 0) __syncthreads();
         }
     }
-    if constexpr (SHIFT) reg_dif_gl_shift<LOGR2>(v);
+    if constexpr (SHIFT) gl::dif_shift<LOGR2>(v);
     else reg_dif_gl<LOGR2>(v, wL, R1); // w_R2 = w_L^R1
     // results are reduced to the canonical [0, p) and stored one by one, so that the registers of v[] free up as they go
     const bool live = line0 + c < ra.total_lines;
     char *const obase = goutb + ((u32)c * osc + (u32)ka * ost);
     const u32 ocb = (u32)ra.out_chunk_stride * 8u;
-    if (ra.post_twiddle) {
+    if (ra.post_twiddle == 2) {
+        // twiddles from the table (powA), laid out like this pass's output within one transform
+        const char *const tbase = reinterpret_cast<const char *>(powA) + ((u32)(line0 + (live ? c : 0)) * osc + (u32)ka * ost);
+        constexpr int G = R2 < 8 ? R2 : 8; // twiddles in flight (16 registers beside the values still to be stored)
+#pragma unroll
+        for (int k0 = 0; k0 < R2; k0 += G) {
+            u64 tw[G];
+#pragma unroll
+            for (int g = 0; g < G; g++) tw[g] = *reinterpret_cast<const E *>(tbase + (u32)((k0 + g) * R1) * ost);
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                u64 y = gl::mul_red(gl::to_u64(v[brev_c(k0 + g, LOGR2)]), tw[g]);
+                if (!ra.lazy_out) y = gl::canon_u64(y);
+                if (live) *reinterpret_cast<E *>(obase + (u32)((k0 + g) * R1) * ost) = y;
+            }
+        }
+    } else if (ra.post_twiddle) {
         const u32 line = (u32)(ra.line_offset + line0 + c);
         const u32 e0 = (line * (u32)ka) & nmask, es = (line * (u32)R1) & nmask;
-        u64 t = gl::to_u64(gl::mul_u64(powA[e0 >> ra.lo_bits], powB[e0 & lo_mask]));
-        const u64 sr = gl::to_u64(gl::mul_u64(powA[es >> ra.lo_bits], powB[es & lo_mask]));
+        u64 t = gl::mul_red(powA[e0 >> ra.lo_bits], powB[e0 & lo_mask]);
+        const u64 sr = gl::mul_red(powA[es >> ra.lo_bits], powB[es & lo_mask]);
 #pragma unroll
         for (int kr = 0; kr < R2; kr++) {
-            const u64 y = gl::canon(gl::mul(v[brev_c(kr, LOGR2)], t));
+            u64 y = gl::mul_red(gl::to_u64(v[brev_c(kr, LOGR2)]), t);
+            if (!ra.lazy_out) y = gl::canon_u64(y);
             if (live) *reinterpret_cast<E *>(obase + pos_offset((u32)(kr * R1), ra.out_split, ost, ocb)) = y;
-            if (kr + 1 < R2) t = gl::to_u64(gl::mul_u64(t, sr));
+            if (kr + 1 < R2) t = gl::mul_red(t, sr);
         }
     } else if (ra.do_scale) {
 #pragma unroll
         for (int kr = 0; kr < R2; kr++) {
-            const u64 y = gl::canon(gl::mul(v[brev_c(kr, LOGR2)], ra.scale));
+            const u64 y = gl::canon_u64(gl::mul_red(gl::to_u64(v[brev_c(kr, LOGR2)]), ra.scale));
             if (live) *reinterpret_cast<E *>(obase + pos_offset((u32)(kr * R1), ra.out_split, ost, ocb)) = y;
         }
     } else {
@@ -1025,6 +1011,8 @@ struct Plan {
     void *wl0 = nullptr, *wl0q = nullptr;
     void *powA2 = nullptr, *powB2 = nullptr, *powA2q = nullptr, *powB2q = nullptr, *powA2m = nullptr; // w_M^e, M = n >> log0
     bool reg3_ready = false;
+    // Goldilocks: inter-pass twiddles w^(line * k) as a table laid out like one transform's intermediate (see gl_post_table_kernel)
+    void *gl_ptab2 = nullptr;
     // generic path
     void *wpow = nullptr; // n entries
     std::vector<i64> factors;
@@ -1310,7 +1298,7 @@ int launch_reg_tt(const FieldDev &fd, const void *in, void *out, RegArgs ra, i64
             if (it != g_glperm.end()) { ra.perm1 = it->second.perm1; ra.perm2 = it->second.perm2; shift = true; }
         }
         // four waves per SIMD for the strided passes of the three-pass driver (see WAVES above)
-        const bool strided = ra.waves4 && !ra.load_along_line && !ra.store_along_line && LOGR1 == 5;
+        const bool strided = ra.waves4 && !ra.load_along_line && !ra.store_along_line && LOGR1 == 5 && LOGR2 == 4; // (32 x 32: 128 registers spill)
 #define GFA_GL_LAUNCH(SH, WV)                                                                                                                    \
     do {                                                                                                                                         \
         auto kern = ntt_reg_kernel_gl<LOGR1, LOGR2, THREADS, SPLIT, SH, WV>;                                                                     \
@@ -1353,6 +1341,10 @@ int launch_reg_t(const FieldDev &fd, const void *in, void *out, const RegArgs &r
         // 64-bit elements: 16 lines per tile (128-byte global segments) in one 512-thread workgroup per CU, or 8 lines in
         // 256-thread workgroups, two per CU now that the unused quotient table is no longer reserved (GFA_NTT_T64=256)
         // two-round exchange: half the LDS buffer, three workgroups per CU (Goldilocks 2^20 x 16: 0.283 -> 0.251 ms)
+        // r04: with the cheaper Goldilocks arithmetic the strided passes of the three-pass transform are no longer bound by the
+        // vector ALU alone, and 16-line tiles (128-byte segments, 512 threads) win there: 2^26 points 0.92 -> 0.86 ms; two-pass
+        // column passes and contiguous lines still prefer 8 lines (2^20 x 16: 0.19 against 0.22 ms; 2^10 x 16384: 0.072 / 0.098)
+        if (ra.waves4) return launch_reg_tt<F, TW, LOGR1, LOGR2, 512, true>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
         return launch_reg_tt<F, TW, LOGR1, LOGR2, 256, true>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
     } else {
         return launch_reg_tt<F, TW, LOGR1, LOGR2, 256>(fd, in, out, ra, batch, wl, wlq, pa, paq, pb, pbq, pam, st);
@@ -1424,6 +1416,16 @@ int build_post_tables(const FieldDev &fd, u64 omega, i64 n_total, Plan *pl, hipS
 {
     return build_post_tables_at<F, TW>(fd, omega, n_total, 1, &pl->powA, &pl->powB, &pl->powAq, &pl->powBq, &pl->powAm,
                                        &pl->lo_bits, st);
+}
+
+// Goldilocks: the inter-pass twiddle table of a column pass with `lines` lines of length count / lines (gl_post_table_kernel)
+inline int build_gl_post_table(const void *powA, const void *powB, int lo_bits, i64 lines, i64 count, void **out, hipStream_t st)
+{
+    GFA_HIP(hipMalloc(out, sizeof(u64) * (size_t)count));
+    hipLaunchKernelGGL(gl_post_table_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, (const u64 *)powA, (const u64 *)powB,
+                       lo_bits, (u64 *)*out, (u32)lines, (u32)count);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
 }
 
 // Where the rows of a batched transform live.  Contiguous (chunk_len == 0): row b at b * n.  Chunked (the exchange buffers of
@@ -1509,6 +1511,8 @@ int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n,
             ra.in_split = in_split; ra.in_chunk_stride = li.chunk_stride;
             ra.total_lines = n2;
             ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits; ra.n_mask = (u64)n - 1; ra.pinv = inverse_mod_2_32(fd.p);
+            // (Goldilocks: a table of the n twiddles in place of the per-thread progression was measured here too and loses,
+            // 2^20 x 16 0.188 -> 0.199 ms: 8 MiB of table do not stay in L2 beside the data)
             if ((rc = launch_reg<F, TW>(fd, pl->log1, src, pl->sc->ws0.p, ra, nb, pl->wl1, pl->wl1q, pl->powA, pl->powAq, pl->powB,
                                         pl->powBq, pl->powAm, st)))
                 return rc;
@@ -1574,7 +1578,7 @@ int run_pow2_reg3(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n
         {
             RegArgs ra{};
             ra.in_stride_c = 1; ra.in_stride_t = M; ra.out_stride_c = 1; ra.out_stride_t = M;
-            ra.total_lines = M; ra.waves4 = 1;
+            ra.total_lines = M; ra.waves4 = 1; ra.lazy_out = 1;
             ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits; ra.n_mask = (u64)n - 1; ra.pinv = inverse_mod_2_32(fd.p);
             if ((rc = launch_reg<F, TW>(fd, log0, src, ws, ra, 1, pl->wl0, pl->wl0q, pl->powA, pl->powAq, pl->powB, pl->powBq,
                                         pl->powAm, st)))
@@ -1584,9 +1588,16 @@ int run_pow2_reg3(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n
             RegArgs ra{};
             ra.in_stride_c = 1; ra.in_stride_t = L2; ra.out_stride_c = 1; ra.out_stride_t = L2;
             ra.in_batch_stride = M; ra.out_batch_stride = M;
-            ra.total_lines = L2; ra.waves4 = 1;
+            ra.total_lines = L2; ra.waves4 = 1; ra.lazy_out = 1;
             ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits2; ra.n_mask = (u64)M - 1; ra.pinv = inverse_mod_2_32(fd.p);
-            if ((rc = launch_reg<F, TW>(fd, log1, ws, ws, ra, L0, pl->wl1, pl->wl1q, pl->powA2, pl->powA2q, pl->powB2,
+            const void *pa = pl->powA2;
+            if constexpr (std::is_same<TW, TwGoldi>::value) {
+                // the L0 sub-transforms of M points share one table of M twiddles (at most 8 MiB)
+                // (2^26 points: 0.874 -> 0.847 ms)
+                if (!pl->gl_ptab2 && (rc = build_gl_post_table(pl->powA2, pl->powB2, pl->lo_bits2, L2, M, &pl->gl_ptab2, st))) return rc;
+                ra.post_twiddle = 2; pa = pl->gl_ptab2;
+            }
+            if ((rc = launch_reg<F, TW>(fd, log1, ws, ws, ra, L0, pl->wl1, pl->wl1q, pa, pl->powA2q, pl->powB2,
                                         pl->powB2q, pl->powA2m, st)))
                 return rc;
         }
@@ -1777,7 +1788,7 @@ void ntt_forget_field(const gfa_field *f)
             }
             for (void *p : {pl->w1, pl->w1q, pl->w2, pl->w2q, pl->powA, pl->powB, pl->powAq, pl->powBq, pl->powAm, pl->wl1, pl->wl1q, pl->wl2,
                             pl->wl2q, pl->wpow, pl->wl0, pl->wl0q, pl->powA2, pl->powB2, pl->powA2q,
-                            pl->powB2q, pl->powA2m})
+                            pl->powB2q, pl->powA2m, pl->gl_ptab2})
                 if (p) (void)hipFree(p);
             delete pl;
             it = g_plans.erase(it);
