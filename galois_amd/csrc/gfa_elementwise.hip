@@ -316,6 +316,23 @@ __global__ __launch_bounds__(256) void ew_intarg_kernel(FieldDev fd, const T *__
         for (i64 i = tid; i < nvec; i += nth) {
             const Vec16<T> av = reinterpret_cast<const Vec16<T> *>(a)[i];
             Vec16<T> ov;
+            if constexpr (IS_POW && BatchInv<F>::value && (V > 1)) {
+                if (k0 < 0) {
+                    // x^-k = (x^k)^-1: the V powers of this vector share one inversion (Montgomery's trick) instead of V
+                    E y[V];
+#pragma unroll
+                    for (int j = 0; j < V; j++) {
+                        E r;
+                        (void)pow_signed<F>(fd, (E)av.v[j], -k0, &r); // x = 0 gives 0, which batch_inverse flags
+                        y[j] = r;
+                    }
+                    batch_inverse_fast<F, V>(fd, y, bad);
+#pragma unroll
+                    for (int j = 0; j < V; j++) ov.v[j] = (T)y[j];
+                    reinterpret_cast<Vec16<T> *>(out)[i] = ov;
+                    continue;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < V; j++) {
                 const i64 k = se ? e[i * V + j] : k0;
@@ -331,7 +348,49 @@ __global__ __launch_bounds__(256) void ew_intarg_kernel(FieldDev fd, const T *__
         }
         done = nvec * V;
     }
-    for (i64 i = done + tid; i < n; i += nth) {
+    i64 i1 = done + tid;
+    if constexpr (IS_POW && BatchInv<F>::value) {
+        if (se) {
+            // One exponent per element.  Eight elements per lane and round (each a coalesced access of the wavefront): their
+            // powers x^|k| first, then ONE inversion for the negative exponents among them -- an inversion is an exponentiation
+            // by p - 2 (or ~27 products in GF(p^m)), and with a few negative exponents anywhere in a wavefront every lane used to
+            // wait for one per element.  |k| is reduced modulo q - 1 only where it is not below it already (a 64-bit division).
+            constexpr int PB = 8;
+            for (; i1 + (i64)(PB - 1) * nth < n; i1 += (i64)PB * nth) {
+                E y[PB];
+                bool ng[PB];
+                bool anyneg = false;
+#pragma unroll
+                for (int k = 0; k < PB; k++) {
+                    const i64 idx = i1 + (i64)k * nth;
+                    const E x = (E)a[sa ? idx : 0];
+                    const i64 kk = e[idx];
+                    u64 ue = kk < 0 ? (u64)0 - (u64)kk : (u64)kk;
+                    if (fd.q != 0 && ue >= fd.q - 1) ue %= (fd.q - 1);
+                    E r;
+                    if (kk == 0) r = F::one(fd);
+                    else if (x == 0) r = 0;
+                    else r = F::pow_u(fd, x, ue);
+                    bad |= (x == 0 && kk < 0);
+                    ng[k] = kk < 0 && x != 0;
+                    anyneg |= ng[k];
+                    y[k] = r;
+                }
+                if (anyneg) {
+                    E z[PB];
+                    bool unused = false;
+#pragma unroll
+                    for (int k = 0; k < PB; k++) z[k] = ng[k] ? y[k] : F::one(fd);
+                    batch_inverse_fast<F, PB>(fd, z, unused);
+#pragma unroll
+                    for (int k = 0; k < PB; k++) y[k] = ng[k] ? z[k] : y[k];
+                }
+#pragma unroll
+                for (int k = 0; k < PB; k++) out[i1 + (i64)k * nth] = (T)y[k];
+            }
+        }
+    }
+    for (i64 i = i1; i < n; i += nth) {
         E x = (E)a[sa ? i : 0];
         i64 k = e[se ? i : 0];
         E r;

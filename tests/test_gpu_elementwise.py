@@ -197,6 +197,40 @@ def test_large_random_against_oracle(order):
     GF.compile("auto")
 
 
+@pytest.mark.parametrize("order", [65537, 2147483647, 4294967291, 2**64 - 2**32 + 1, 18446744073709551557, 2**32, 251**3])
+def test_power_with_one_exponent_per_element_edges(order):
+    """np.power with an exponent array on the calculate-mode kernels (ew_intarg_kernel: eight powers per lane share one inversion
+    for the negative exponents among them): zero bases under zero / positive exponents, exponents far beyond q - 1 on both
+    sides, lengths around the eight-per-lane rounds, and 0 ** negative anywhere in the array raising as the reference does
+    (_lookup.py:262-263, _calculate.py:447-489)."""
+    GF = ga.GF(order)
+    p, m = GF.characteristic, GF.degree
+    F = O.OracleField(p, m, int(GF.irreducible_poly) if m > 1 else None, GF._primitive_element_int, lookup=False)
+    rng = np.random.default_rng(order % 1013)
+    mk = (lambda v: GF(np.array([int(t) for t in v], dtype=object))) if GF.dtypes == [np.object_] else (lambda v: GF(v.astype(GF.dtypes[-1])))
+    for n in (1, 7, 8, 9, 1000, 65536 * 8 + 5, 1_500_003):
+        if order <= 2**63:
+            a = rng.integers(0, order, n, dtype=np.uint64)
+        else:
+            a = (rng.integers(0, 2**63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)) % np.uint64(order)
+        e = rng.integers(-60, 1200, n)
+        big = rng.random(n) < 0.02
+        e[big] = rng.integers(-(2**62), 2**62, int(big.sum()))
+        zero = rng.random(n) < 0.05
+        a[zero] = 0
+        e[zero] = np.abs(e[zero]) * (rng.random(int(zero.sum())) < 0.5)  # zero bases: exponent 0 or positive
+        e[a == 0] = np.abs(e[a == 0])  # (zeros the generator drew by itself)
+        H.assert_equal_ints((mk(a) ** e).numpy().astype(np.uint64), F.pow(a, e), f"n={n}")
+    a = np.arange(1, 2001, dtype=np.uint64) % np.uint64(min(order, 2**63))
+    a[1234] = 0
+    e = np.full(2000, 5)
+    e[1234] = -3
+    with pytest.raises(ZeroDivisionError):
+        mk(a) ** e
+    e[1234] = 0
+    assert int((mk(a) ** e).numpy()[1234]) == 1
+
+
 def test_reductions_and_outer():
     for order in [2**8, 31, 3**5, 65537]:
         GF = ga.GF(order)

@@ -27,6 +27,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--mid":
     cases = [c for c in cases if 256 < c[0] <= 2**16]
 if len(sys.argv) > 1 and sys.argv[1] == "--big16":  # 32768 < q <= 65536: one table in LDS at a time
     cases = [(2**16, np.uint16, "auto"), (3**10, np.uint16, "auto"), (65521, np.uint16, "jit-lookup")]
+if len(sys.argv) > 1 and sys.argv[1] == "--calc":  # fields whose default route is explicit calculation
+    cases = [c for c in cases if c[2] == "jit-calculate" and c[0] > 2**16 or c[0] in (65537, 2**64 - 2**32 + 1)] + [(251**3, np.uint32, "auto")]
 if len(sys.argv) > 1 and sys.argv[1] == "--bin":
     cases = [c for c in cases if c[0] in (2**20, 2**24, 2**32)]
 n = 50_000_000
