@@ -37,8 +37,10 @@ N_ELEMENTS = 100_000_000
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # defaults: ~0.1 s of warm-up and ~0.1 s timed.  After the host-side set-up (a second of numpy) the part needs tens of
+    # milliseconds of load before its clocks are back up: 20 / 200 steps (1 ms / 10 ms) read 3-4 % low (profiles/r04_bench_clock_ramp.txt)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--no-extras", action="store_true", help="skip the NTT / Reed-Solomon side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure the HBM traffic")

@@ -79,13 +79,30 @@ int scratch_trim(size_t keep_bytes)
 }
 
 int time_loop(hipStream_t st, int iters, float *ms_out, const std::function<int()> &launch)
-{ // three warm-up calls (table upload, attribute set-up, work-buffer pools), then three groups of `iters` back-to-back calls
-    // bracketed by HIP events on the launch stream; the MEDIAN of the three group averages is reported
+{ // three warm-up calls (table upload, attribute set-up, work-buffer pools), then about 50 ms more of the same call, then three
+    // groups of `iters` back-to-back calls bracketed by HIP events on the launch stream; the MEDIAN of the three group averages is
+    // reported.  The 50 ms are for the clocks: after a host-side pause (generating the next test input takes a second) the part
+    // needs tens of milliseconds of load to come back up, and a 0.2 ms kernel timed straight away reads 10-15 % slow
+    // (profiles/r04_bench_clock_ramp.txt: the same 2^20 x 64 transform 0.249 -> 0.230 -> 0.220 ms over three consecutive timings).
     int rc;
-    for (int i = 0; i < 3; i++)
-        if ((rc = launch())) return rc;
     hipEvent_t e[4];
     for (auto &ev : e) GFA_HIP(hipEventCreate(&ev));
+    GFA_HIP(hipStreamSynchronize(st));
+    {
+        float total = 0.f;
+        long launched = 0;
+        for (int chunk = 3; total < 50.f && launched < 20000; chunk = chunk < 1024 ? chunk * 2 : chunk) {
+            GFA_HIP(hipEventRecord(e[0], st));
+            for (int i = 0; i < chunk; i++)
+                if ((rc = launch())) return rc;
+            GFA_HIP(hipEventRecord(e[1], st));
+            GFA_HIP(hipEventSynchronize(e[1]));
+            float t = 0.f;
+            GFA_HIP(hipEventElapsedTime(&t, e[0], e[1]));
+            if (launched > 0) total += t; // the first chunk carries table uploads and attribute set-up: not load
+            launched += chunk;
+        }
+    }
     GFA_HIP(hipStreamSynchronize(st));
     const int n = iters > 0 ? iters : 1;
     GFA_HIP(hipEventRecord(e[0], st));
