@@ -37,8 +37,7 @@ N_ELEMENTS = 100_000_000
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: ~0.1 s of warm-up and ~0.1 s timed.  After the host-side set-up (a second of numpy) the part needs tens of
-    # milliseconds of load before its clocks are back up: 20 / 200 steps (1 ms / 10 ms) read 3-4 % low (profiles/r04_bench_clock_ramp.txt)
+    # defaults: ~0.1 s of warm-up steps and ~0.1 s timed (wall clock around 20 steps = 1 ms carries the launch / sync latency)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--no-extras", action="store_true", help="skip the NTT / Reed-Solomon side measurements")
@@ -105,6 +104,16 @@ def main():
         if rc:
             L.check(rc, "gfa_binary")
 
+    # Clock pre-warm, untimed and outside the W + K steps: the set-up above leaves the GPU idle for seconds, and it then needs tens
+    # of milliseconds of load before its clocks are back up -- a kernel timed straight away reads 3-15 % slow
+    # (profiles/r04_bench_clock_ramp.txt).  ~0.1 s of the same launch; reported in the JSON line as "clock_prewarm".
+    prewarm_steps, t_pw = 0, time.perf_counter()
+    while time.perf_counter() - t_pw < 0.1:
+        for _ in range(64):
+            step()
+        torch.cuda.synchronize()
+        prewarm_steps += 64
+    prewarm_ms = (time.perf_counter() - t_pw) * 1e3
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -166,6 +175,8 @@ def main():
             "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
             "steps": args.steps,
             "warmup": args.warmup,
+            "clock_prewarm": {"steps": prewarm_steps, "ms": round(prewarm_ms, 1), "timed": False,
+                              "why": "GPU clocks ramp for tens of ms after the idle set-up phase; see profiles/r04_bench_clock_ramp.txt"},
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True,
             "scaling": "weak",
