@@ -309,7 +309,9 @@ int gfa_rs_decode(gfa_rs_t *code, const void *recv, const uint8_t *erasures, int
 
 /* ---- measurement support (bench.py) --------------------------------------------------------------- *
  * Times `iters` back-to-back launches of the named hot kernel on `stream` with HIP events recorded on that same
- * stream and returns the average milliseconds per launch in *ms_out. */
+ * stream and returns the average milliseconds per launch in *ms_out: about 50 ms of the same call run first, untimed
+ * (table uploads, work-buffer pools, and the clocks -- after an idle phase the part needs tens of milliseconds of load
+ * before a short kernel times at its steady rate), then three groups of `iters` launches; the median group is reported. */
 int gfa_time_matmul(gfa_field_t *f, const void *a, const void *b, void *out, int64_t batch, int64_t M, int64_t K, int64_t N,
                     int dtype, gfa_stream_t stream, int iters, float *ms_out);
 int gfa_time_binary(gfa_field_t *f, int op, const void *a, const void *b, void *out, int64_t n, int dtype,
