@@ -467,20 +467,37 @@ struct Lut {
         if (a == 0) return 0;
         return f.exp_tab[f.qm1 + f.log_tab[a] - f.log_tab[b]];
     }
+    // x mod m for x < 2^52, 0 < m < 2^21, through one double-precision quotient estimate (exact after one correction either
+    // way): a 64-bit `%` is a ~100-instruction software division on the device, and pow_nz needs two per element
+    static GFA_HD u64 mod52(u64 x, u64 m)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const double q = __builtin_floor((double)x * (1.0 / (double)m));
+        i64 r = (i64)x - (i64)q * (i64)m;
+        if (r < 0) r += (i64)m;
+        if (r >= (i64)m) r -= (i64)m;
+        return (u64)r;
+#else
+        return x % m;
+#endif
+    }
     // a != 0, any signed exponent: EXP[(LOG[a] * b) mod (q-1)] with a floor modulo (power_ufunc.lookup, _lookup.py:247-270)
     static GFA_HD u32 pow_nz(const FieldDev &f, u32 a, i64 e)
     {
-        i64 em = e % (i64)f.qm1; // reduce first: mathematically identical, cannot overflow (the reference's TODO)
-        if (em < 0) em += f.qm1;
-        u64 idx = ((u64)f.log_tab[a] * (u64)em) % f.qm1;
+        const u64 m = f.qm1; // < 2^20
+        const u64 ae = e < 0 ? (u64)0 - (u64)e : (u64)e;
+        u64 em = ae < ((u64)1 << 52) ? mod52(ae, m) : ae % m; // reduce first: mathematically identical, cannot overflow (the reference's TODO)
+        if (e < 0 && em != 0) em = m - em;
+        const u64 idx = mod52((u64)f.log_tab[a] * em, m); // < 2^40
         return f.exp_tab[idx];
     }
     static GFA_HD u32 pow_u(const FieldDev &f, u32 a, u64 e)
     {
         if (e == 0) return 1;
         if (a == 0) return 0;
-        u64 em = e % f.qm1;
-        u64 idx = ((u64)f.log_tab[a] * em) % f.qm1;
+        const u64 m = f.qm1;
+        const u64 em = e < ((u64)1 << 52) ? mod52(e, m) : e % m;
+        const u64 idx = mod52((u64)f.log_tab[a] * em, m);
         return f.exp_tab[idx];
     }
     static GFA_HD u32 from_int(const FieldDev &f, i64 k)

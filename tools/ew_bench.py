@@ -29,6 +29,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--big16":  # 32768 < q <= 65536: one ta
     cases = [(2**16, np.uint16, "auto"), (3**10, np.uint16, "auto"), (65521, np.uint16, "jit-lookup")]
 if len(sys.argv) > 1 and sys.argv[1] == "--calc":  # fields whose default route is explicit calculation
     cases = [c for c in cases if c[2] == "jit-calculate" and c[0] > 2**16 or c[0] in (65537, 2**64 - 2**32 + 1)] + [(251**3, np.uint32, "auto")]
+if len(sys.argv) > 1 and sys.argv[1] == "--lutpow":  # fields whose np.power with an exponent array runs on the generic table kernel
+    cases = [(31, np.uint8, "auto"), (3**5, np.uint8, "auto"), (2**8, np.int64, "jit-lookup"), (3**10, np.uint16, "auto"), (65521, np.uint16, "jit-lookup")]
 if len(sys.argv) > 1 and sys.argv[1] == "--bin":
     cases = [c for c in cases if c[0] in (2**20, 2**24, 2**32)]
 n = 50_000_000
