@@ -167,8 +167,8 @@ GFA_HD G3 mul_pow2(G3 x)
 //   q = 1:  (-t1 - t2) + 2^32 (t0 + t1)
 //   q = 2:  (-t0 - t1) + 2^32 (t0 - t2)
 // 9 / 12 / 11 instructions.  Inside the radix-32 / radix-16 networks of the NTT kernel the operand of a shift by 32 q + r at
-// butterfly level s has |x| < 2^(69 - s) (gl_shift_bound in gfa_ntt.hip), which is within the precondition for every shift used;
-// tests/csrc/goldilocks_host_test.cpp replays the networks' schedule with exact bounds.  |result| < 2^66.
+// butterfly level s has |x| < 2^(69 - s), which is within the precondition for every shift used: dif_shift_bounds_ok() below
+// replays the networks' schedule on bounds, and tests/csrc/goldilocks_host_test.cpp runs both.  |result| < 2^66.
 template <int S>
 GFA_HD G3 mul_pow2_small(G3 x)
 {
