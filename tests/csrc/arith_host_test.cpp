@@ -6,11 +6,46 @@
 //     bin16_holes_mul_kernel / bin32_tab_mul_kernel, against shift-and-xor.
 #include "gfa_arith.h"
 #include <cstdio>
+#include <initializer_list>
 using namespace gfa;
+
+// Ext::mul_m_small (32-bit accumulators, p < 2^13) against Ext::mul_m_wide (64-bit) on random and extreme digit vectors
+template <int M>
+static int check_ext_small(u32 p)
+{
+    int fails = 0;
+    FieldDev f{};
+    f.p = p; f.m = M; f.kind = KIND_EXT;
+    f.q = 1;
+    for (int i = 0; i < M; i++) {
+        if (f.q > (((u64)1 << 63) / p)) return 0; // p^M beyond 63 bits: not a u64-element field
+        f.q *= p;
+    }
+    f.mu = ~(u64)0 / p;
+    if ((p & (p - 1)) == 0) f.mu += 1; // floor(2^64 / p) for a power of two (p = 2 never reaches these kernels; kept exact anyway)
+    u64 x = 0x9E3779B97F4A7C15ull ^ p ^ (M * 1315423911u);
+    for (int trial = 0; trial < 6; trial++) {
+        for (int j = 0; j < M; j++) { x = x * 6364136223846793005ull + 1442695040888963407ull; f.ext_irr[j] = trial == 0 ? p - 1 : (u32)((x >> 33) % p); }
+        for (int i = 0; i < 3000; i++) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            u64 a = (x >> 11) % f.q;
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            u64 b = (x >> 11) % f.q;
+            if (i % 50 == 0) a = f.q - 1; // every digit p - 1
+            if (i % 75 == 0) b = f.q - 1;
+            if (Ext::mul_m_small<M>(f, a, b) != Ext::mul_m_wide<M>(f, a, b)) fails++;
+        }
+    }
+    return fails;
+}
 
 int main()
 {
     int fails = 0;
+    for (u32 p : {3u, 5u, 7u, 251u, 257u, 4099u, 8191u})
+        fails += check_ext_small<2>(p) + check_ext_small<3>(p) + check_ext_small<4>(p) + check_ext_small<5>(p) +
+                 (p <= 251 ? check_ext_small<7>(p) + check_ext_small<8>(p) : 0);
+    if (fails) printf("Ext::mul_m_small mismatches: %d\n", fails);
     {
         FieldDev f{};
         f.p = Goldilocks::P;
