@@ -800,8 +800,125 @@ class FieldArray(metaclass=FieldArrayMeta):
     _SINGLE_KERNEL_UFUNCS = (np.add, np.subtract, np.multiply, np.true_divide, np.floor_divide, np.negative, np.reciprocal,
                              np.power, np.square)
 
+    # ---- the `where=` and `initial=` keywords (the reference forwards every keyword to the NumPy ufunc it built,
+    # _domains/_ufunc.py:349, 364, 379, 403, 418; NumPy's semantics on the integer values are the contract) ----
+    @staticmethod
+    def _kw_given(v) -> bool:
+        return not (v is None or v is True or v is np._NoValue)
+
+    def _where_mask(self, where, shape) -> torch.Tensor:
+        """`where` as a device bool tensor broadcast to `shape` (NumPy casts the mask with the 'safe' rule: bool only)."""
+        if isinstance(where, torch.Tensor):
+            m = where
+            if m.dtype != torch.bool:
+                raise TypeError(f"Cannot cast the 'where' mask from {m.dtype} to bool according to the rule 'safe'.")
+        else:
+            m = np.asarray(where)
+            if m.dtype != np.bool_:
+                raise TypeError(f"Cannot cast array data from {m.dtype!r} to dtype('bool') according to the rule 'safe'")
+            m = torch.from_numpy(np.ascontiguousarray(m))
+        return m.to(self._t.device).broadcast_to(tuple(shape))
+
+    def _ufunc_masked(self, ufunc, method, where, inputs, kwargs):
+        """ufunc(..., where=mask[, out=target]): positions where the mask is False are NOT computed -- they keep the target's
+        value (zero in a fresh result; NumPy leaves them uninitialised) and can raise nothing.  Computed on the whole array with
+        the field operands replaced by 1 at masked-out positions (1/1, 1**k, log 1, sqrt 1 are all defined), then blended."""
+        cls = type(self)
+        out = kwargs.pop("out", None)
+        target = None
+        if out is not None:
+            target = out[0] if isinstance(out, tuple) else out
+            if isinstance(out, tuple) and len(out) != 1:
+                raise NotImplementedError("The `where=` keyword with several `out` arrays is not supported on device-resident arrays.")
+        if method == "outer":
+            a, b = inputs
+            sa, sb = tuple(np.shape(a)), tuple(np.shape(b))
+            rs = lambda v, shp: v.reshape(shp) if isinstance(v, FieldArray) else np.asarray(v).reshape(shp)
+            inputs = (rs(a, sa + (1,) * len(sb)), rs(b, (1,) * len(sa) + sb))
+        shapes = [tuple(x.shape) if isinstance(x, (FieldArray, torch.Tensor)) else np.shape(x) for x in inputs]
+        wshape = tuple(where.shape) if isinstance(where, torch.Tensor) else np.shape(where)
+        full = tuple(np.broadcast_shapes(*shapes, wshape))
+        mask = self._where_mask(where, full)
+        one = self._af_tens(cls.Ones(()))
+        safe = []
+        for x in inputs:
+            if isinstance(x, cls):
+                tx = self._af_tens(x).broadcast_to(full)
+                safe.append(self._af_wrap(torch.where(mask, tx, one.to(tx.dtype))))
+            else:
+                safe.append(x)
+        res = self.__array_ufunc__(ufunc, "__call__", *safe, **kwargs)
+        parts = res if isinstance(res, tuple) else (res,)
+        blended = []
+        for r in parts:
+            if isinstance(r, FieldArray):
+                tr = self._af_tens(r).broadcast_to(full)
+                if target is not None:
+                    if not isinstance(target, cls):
+                        raise TypeError(f"Argument 'out' must be a {cls.name} array (or a 1-tuple holding one), not {type(target)}.")
+                    if tuple(target.shape) != full:
+                        raise ValueError(f"non-broadcastable output operand with shape {tuple(target.shape)} doesn't match the broadcast shape {full}")
+                    tt = self._af_tens(target)
+                    new = self._af_wrap(torch.where(mask, tr.to(tt.dtype), tt))
+                    target._t.copy_(new._t.reshape(target._t.shape))
+                    blended.append(target)
+                else:
+                    blended.append(self._af_wrap(torch.where(mask, tr, torch.zeros((), dtype=tr.dtype, device=tr.device))))
+            else:  # integer / boolean host results (np.log, comparisons)
+                hr = np.broadcast_to(np.asarray(r), full)
+                hm = mask.cpu().numpy()
+                if target is not None:
+                    if not isinstance(target, np.ndarray):
+                        raise TypeError(f"Argument 'out' of {ufunc.__name__!r} must be a np.ndarray, not {type(target)}.")
+                    np.copyto(target, hr, where=hm, casting="unsafe")
+                    blended.append(target)
+                else:
+                    blended.append(np.where(hm, hr, np.zeros((), dtype=hr.dtype)))
+        return tuple(blended) if isinstance(res, tuple) else blended[0]
+
+    def _reduce_kw(self, ufunc, op: int, axis, keepdims: bool, where, initial) -> "FieldArray":
+        """ufunc.reduce(x, axis, keepdims, where=mask, initial=v) with NumPy's meaning: masked-out elements do not take part,
+        the fold starts from `initial` -- ((v op x0) op x1) ..., i.e. v op (x0 dual x1 dual ...) with dual = + for -, * for /."""
+        cls = type(self)
+        has_where, has_initial = self._kw_given(where), self._kw_given(initial)
+        if not has_where and not has_initial:
+            return self._reduce(op, axis, keepdims)
+        if self.ndim == 0:
+            raise TypeError("cannot reduce on a scalar")
+        dual = L.OP_ADD if op in (L.OP_ADD, L.OP_SUB) else L.OP_MUL
+        x = self
+        if has_where:
+            # the reference's ufuncs are numba.vectorize products WITHOUT an identity, except np.bitwise_xor (characteristic 2
+            # add / subtract) and np.bitwise_and (GF(2) multiply): _fields/_ufunc.py:59-61, _fields/_gf2.py:93-96
+            has_identity = (cls._characteristic == 2 and dual == L.OP_ADD) or (cls._order == 2 and op == L.OP_MUL)
+            if not has_initial and not has_identity:
+                raise ValueError(f"reduction operation '{ufunc.__name__}' does not have an identity, so to use a where mask one has to specify 'initial'")
+            mask = self._where_mask(where, self.shape)
+            tx = self._af_tens(self)
+            fill = self._af_tens(cls.Zeros(()) if dual == L.OP_ADD else cls.Ones(())).to(tx.dtype)
+            x = self._af_wrap(torch.where(mask, tx, fill))
+        if not has_initial:
+            return x._reduce(op, axis, keepdims)  # an identity exists: the filled-in elements are neutral
+        init = initial if isinstance(initial, cls) else cls(initial)
+        if init.ndim != 0 and init.size != 1:
+            raise ValueError("Argument 'initial' of a reduction must be a scalar.")
+        init = init.reshape(())
+        n_axis = x.size if axis is None else x.shape[axis % x.ndim]
+        if n_axis == 0:
+            lead = () if axis is None else tuple(d for i, d in enumerate(x.shape) if i != axis % x.ndim)
+            if keepdims:
+                lead = (1,) * x.ndim if axis is None else tuple(1 if i == axis % x.ndim else d for i, d in enumerate(x.shape))
+            return self._af_wrap(self._af_tens(init).broadcast_to(lead).clone())
+        body = x._reduce(dual, axis, keepdims)
+        return self._binary(op, init, body)
+
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
         cls = type(self)
+        if self._kw_given(kwargs.get("where", None)) and method in ("__call__", "outer"):
+            where = kwargs.pop("where")
+            if self._kw_given(kwargs.get("initial", None)):
+                raise TypeError(f"{ufunc.__name__}() got an unexpected keyword argument 'initial'")
+            return self._ufunc_masked(ufunc, method, where, inputs, kwargs)
         out = kwargs.pop("out", None)
         if out is not None:
             # the kernel result is written into the caller's array (_ufunc.py:309-319); same field and shape required
@@ -827,11 +944,12 @@ class FieldArray(metaclass=FieldArrayMeta):
             return target
         # keywords: `casting` is overridden by the reference itself ("unsafe", _ufunc.py:678-680) and `dtype` only names the
         # intermediate type of a result that is cast back to the array's dtype (:686-687, :322-330) -- neither changes a
-        # value here.  `where` masks and reduction seeds are not implemented on the device: refuse rather than ignore.
-        for key in ("where", "initial"):
-            v = kwargs.get(key, None)
-            if v is not None and v is not True and v is not np._NoValue:
-                raise NotImplementedError(f"The {key!r} keyword of ufuncs is not supported on device-resident {cls.name} arrays.")
+        # value here.  `where` masks: _ufunc_masked above (calls) and _reduce_kw (reductions, with `initial`); NumPy accepts
+        # neither on accumulate / reduceat / at.
+        if method != "reduce":
+            for key in ("where", "initial"):
+                if self._kw_given(kwargs.get(key, None)):
+                    raise TypeError(f"{ufunc.__name__}.{method}() got an unexpected keyword argument {key!r}")
         unknown = set(kwargs) - {"where", "initial", "casting", "dtype", "order", "subok", "axis", "keepdims", "signature"}
         if unknown:
             raise TypeError(f"Unsupported keyword argument(s) {sorted(unknown)} for ufunc {ufunc.__name__!r} on {cls.name} arrays.")
@@ -863,7 +981,8 @@ class FieldArray(metaclass=FieldArrayMeta):
                 return self._binary(op, inputs[0], inputs[1])
             if method == "reduce":
                 same_field()
-                return inputs[0]._reduce(op, kwargs.get("axis", 0), bool(kwargs.get("keepdims", False)))
+                return inputs[0]._reduce_kw(ufunc, op, kwargs.get("axis", 0), bool(kwargs.get("keepdims", False)),
+                                            kwargs.get("where", None), kwargs.get("initial", None))
             if method == "accumulate":
                 same_field()
                 return inputs[0]._accumulate(op, kwargs.get("axis", 0))
@@ -994,14 +1113,18 @@ class FieldArray(metaclass=FieldArrayMeta):
                 raise NotImplementedError(f"Keyword(s) {bad} of np.{func.__name__} are not supported on device-resident {cls.name} arrays.")
 
         if func in (np.sum, np.prod) and isinstance(x, cls):
-            no_extra("axis", "keepdims", "a")
+            no_extra("axis", "keepdims", "a", "where", "initial")
             op = L.OP_ADD if func is np.sum else L.OP_MUL
+            uf = np.add if func is np.sum else np.multiply
             axis = kw("axis", 1, None)
             keep = bool(kwargs.get("keepdims", False)) if kwargs.get("keepdims", False) is not np._NoValue else False
+            where, initial = kwargs.get("where", None), kwargs.get("initial", None)
             if axis is None:
-                r = x.reshape(-1)._reduce(op, 0, False)
+                if x._kw_given(where):
+                    where = x._where_mask(where, x.shape).reshape(-1)
+                r = x.reshape(-1)._reduce_kw(uf, op, 0, False, where, initial)
                 return r.reshape((1,) * x.ndim) if keep else r
-            return x._reduce(op, axis, keep)
+            return x._reduce_kw(uf, op, axis, keep, where, initial)
         if func in (np.cumsum, np.cumprod) and isinstance(x, cls):
             no_extra("axis", "a")
             axis = kw("axis", 1, None)
@@ -1157,8 +1280,11 @@ class FieldArray(metaclass=FieldArrayMeta):
             tm = torch.movedim(t, axis, 0)
             while vals.dim() < t.dim():
                 vals = vals.unsqueeze(0)  # ndmin = arr.ndim
+            obj_arr = None if isinstance(obj, slice) else np.asarray(obj)
             if np.ndim(obj) == 0 and not isinstance(obj, slice):
                 vm = vals  # NumPy moves the FIRST axis of the values to `axis`: it is the one that counts the new elements
+            elif obj_arr is not None and obj_arr.dtype != bool and obj_arr.ndim == 1 and obj_arr.size == 1:
+                vm = torch.movedim(vals, axis, 0)  # a size-1 index sequence takes NumPy's scalar path: EVERY value goes in at that index
             else:
                 vm = torch.movedim(vals, axis, 0)
                 count = len(np.insert(np.arange(n, dtype=np.int64), obj, 0)) - n

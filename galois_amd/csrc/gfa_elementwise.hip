@@ -320,11 +320,14 @@ __global__ __launch_bounds__(256) void ew_intarg_kernel(FieldDev fd, const T *__
                 if (k0 < 0) {
                     // x^-k = (x^k)^-1: the V powers of this vector share one inversion (Montgomery's trick) instead of V
                     E y[V];
+                    // |k0| as an unsigned value (k0 == INT64_MIN has no signed negation), reduced modulo q - 1 like the
+                    // exponent-array loop below
+                    u64 ue = (u64)0 - (u64)k0;
+                    if (fd.q != 0 && ue >= fd.q - 1) ue %= (fd.q - 1);
 #pragma unroll
                     for (int j = 0; j < V; j++) {
-                        E r;
-                        (void)pow_signed<F>(fd, (E)av.v[j], -k0, &r); // x = 0 gives 0, which batch_inverse flags
-                        y[j] = r;
+                        const E x = (E)av.v[j];
+                        y[j] = x == 0 ? (E)0 : F::pow_u(fd, x, ue); // x = 0 gives 0, which batch_inverse flags
                     }
                     batch_inverse_fast<F, V>(fd, y, bad);
 #pragma unroll

@@ -676,14 +676,24 @@ int big16_launch(const MidDesc &d, const void *a, i64 sa, const void *b, i64 sb,
             GFA_HIP(hipFuncSetAttribute((const void *)kb, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
             sattr = true;
         }
+        // The gain rests on the 2-byte index array staying in the 256 MiB Infinity Cache between the two kernels, so the
+        // array is walked in slices of 2^26 elements (a 128 MiB index slice) that share ONE work buffer: a multi-GB operand
+        // costs no more scratch than a small one.  Without a work buffer the fused kernel below does the job.
+        const i64 slice = std::min<i64>(nvec, (i64)1 << 23);
         u16 *idx = nullptr;
-        GFA_HIP(gfa::scratch_alloc((void **)&idx, (size_t)nvec * 16, st));
-        hipLaunchKernelGGL(ka, dim3(cus), dim3(T), lds, st, d, (const u16 *)a, (int)sa, (const u16 *)b, (int)sb, idx, nvec, err);
-        hipLaunchKernelGGL(kb, dim3(cus), dim3(T), lds, st, d, (const u16 *)idx, (u16 *)out, nvec);
-        const hipError_t le = hipGetLastError();
-        GFA_HIP(gfa::scratch_free(idx, st));
-        GFA_HIP(le);
-        return GFA_OK;
+        if (gfa::scratch_alloc((void **)&idx, (size_t)slice * 16, st) == hipSuccess) {
+            for (i64 v0 = 0; v0 < nvec; v0 += slice) {
+                const i64 cnt = std::min<i64>(slice, nvec - v0);
+                hipLaunchKernelGGL(ka, dim3(cus), dim3(T), lds, st, d, (const u16 *)a + (sa ? v0 * 8 : 0), (int)sa, (const u16 *)b + (sb ? v0 * 8 : 0),
+                                   (int)sb, idx, cnt, err);
+                hipLaunchKernelGGL(kb, dim3(cus), dim3(T), lds, st, d, (const u16 *)idx, (u16 *)out + v0 * 8, cnt);
+            }
+            const hipError_t le = hipGetLastError();
+            GFA_HIP(gfa::scratch_free(idx, st));
+            GFA_HIP(le);
+            return GFA_OK;
+        }
+        (void)hipGetLastError(); // allocation failed: clear the sticky error and take the fused kernel, which needs no scratch
     }
     if (big) {
         auto k = big16_kernel<OP, JB>;

@@ -1421,10 +1421,17 @@ int build_post_tables(const FieldDev &fd, u64 omega, i64 n_total, Plan *pl, hipS
 // Goldilocks: the inter-pass twiddle table of a column pass with `lines` lines of length count / lines (gl_post_table_kernel)
 inline int build_gl_post_table(const void *powA, const void *powB, int lo_bits, i64 lines, i64 count, void **out, hipStream_t st)
 {
-    GFA_HIP(hipMalloc(out, sizeof(u64) * (size_t)count));
+    if (*out) return GFA_OK;
+    void *tab = nullptr;
+    GFA_HIP(hipMalloc(&tab, sizeof(u64) * (size_t)count));
     hipLaunchKernelGGL(gl_post_table_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, (const u64 *)powA, (const u64 *)powB,
-                       lo_bits, (u64 *)*out, (u32)lines, (u32)count);
-    GFA_HIP(hipGetLastError());
+                       lo_bits, (u64 *)tab, (u32)lines, (u32)count);
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+        (void)hipFree(tab); // *out stays null: a later call builds the table again
+        return gfa::hip_fail(le, "gl_post_table_kernel");
+    }
+    *out = tab;
     return GFA_OK;
 }
 
@@ -1460,6 +1467,7 @@ int run_pow2_reg(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n,
             if ((rc = build_line_tables<F, TW>(fd, omega, n, pl->log2, &pl->wl2, &pl->wl2q, st))) return rc;
             if ((rc = build_post_tables<F, TW>(fd, omega, n, pl, st))) return rc;
         }
+        GFA_HIP(hipStreamSynchronize(st)); // tables filled on this stream; the shared plan may next run on another
         pl->reg_ready = true;
     }
     // chunked rows: the lane-owned low part of a position (R2 values on the load side, R1 on the store side) must not
@@ -1570,6 +1578,13 @@ int run_pow2_reg3(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n
         if ((rc = build_post_tables_at<F, TW>(fd, omega, M, (u64)L0, &pl->powA2, &pl->powB2, &pl->powA2q, &pl->powB2q,
                                               &pl->powA2m, &pl->lo_bits2, st)))
             return rc;
+        if constexpr (std::is_same<TW, TwGoldi>::value) {
+            // Goldilocks: the L0 sub-transforms of M points share one table of M inter-pass twiddles (at most 8 MiB;
+            // 2^26 points: 0.874 -> 0.847 ms).  Built here with the other tables of the plan.
+            if ((rc = build_gl_post_table(pl->powA2, pl->powB2, pl->lo_bits2, L2, M, &pl->gl_ptab2, st))) return rc;
+        }
+        // the tables were filled by kernels on THIS stream; the plan is shared and may next be used from another one
+        GFA_HIP(hipStreamSynchronize(st));
         pl->reg3_ready = true;
     }
     if ((rc = pl->sc->ws0.ensure(sizeof(E) * (size_t)n))) return rc;
@@ -1594,10 +1609,7 @@ int run_pow2_reg3(const FieldDev &fd, Plan *pl, const void *in, void *out, i64 n
             ra.post_twiddle = 1; ra.lo_bits = pl->lo_bits2; ra.n_mask = (u64)M - 1; ra.pinv = inverse_mod_2_32(fd.p);
             const void *pa = pl->powA2;
             if constexpr (std::is_same<TW, TwGoldi>::value) {
-                // the L0 sub-transforms of M points share one table of M twiddles (at most 8 MiB)
-                // (2^26 points: 0.874 -> 0.847 ms)
-                if (!pl->gl_ptab2 && (rc = build_gl_post_table(pl->powA2, pl->powB2, pl->lo_bits2, L2, M, &pl->gl_ptab2, st))) return rc;
-                ra.post_twiddle = 2; pa = pl->gl_ptab2;
+                ra.post_twiddle = 2; pa = pl->gl_ptab2; // built with the plan
             }
             if ((rc = launch_reg<F, TW>(fd, log1, ws, ws, ra, L0, pl->wl1, pl->wl1q, pa, pl->powA2q, pl->powB2,
                                         pl->powB2q, pl->powA2m, st)))
@@ -1886,6 +1898,7 @@ static int ntt_columns_impl(gfa_field_t *f, const void *in, void *out, int64_t n
                 pl->log1 = lg1; pl->logn = lgn;
                 if ((rc2 = build_line_tables<F, TW>(c, omega, n_total, lg1, &pl->wl1, &pl->wl1q, st))) return rc2;
                 if ((rc2 = build_post_tables<F, TW>(c, omega, n_total, pl, st))) return rc2;
+                GFA_HIP(hipStreamSynchronize(st)); // as above
                 pl->reg_ready = true;
             }
             RegArgs ra{};

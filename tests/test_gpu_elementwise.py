@@ -545,10 +545,9 @@ def test_out_keyword_writes_in_place_and_unsupported_keywords_raise():
         np.add(x, y, out=GF.Zeros(999))
     with pytest.raises(TypeError):
         np.add(x, y, out=np.zeros(1000, dtype=np.uint8))
-    with pytest.raises(NotImplementedError):
-        np.add(x, y, where=np.arange(1000) % 2 == 0)
-    with pytest.raises(NotImplementedError):
-        np.add.reduce(x, initial=GF(3))
+    # where= / initial=: tests/test_gpu_ufunc_kwargs.py
+    assert np.array_equal(np.add(x, y, where=np.arange(1000) % 2 == 0).numpy()[::2], (x + y).numpy()[::2])
+    assert int(np.add.reduce(x, initial=GF(3))) == int(np.add.reduce(x) + GF(3))
     # casting= is overridden by the reference too, dtype= only names an intermediate type: accepted, no effect on values
     assert np.array_equal(np.add(x, y, casting="safe").numpy(), (x + y).numpy())
     assert np.array_equal(np.add(x, y, dtype=np.int64).numpy(), (x + y).numpy())
@@ -618,6 +617,11 @@ def test_ordering_and_editing_functions_follow_numpy_on_the_integer_values(order
     assert np.array_equal(ints(np.insert(row, [3, 3, 0], mk([1, 2, 3]))), np.insert(h[0], [3, 3, 0], [1, 2, 3]))
     assert np.array_equal(ints(np.insert(x, [4, 1], mk([[1], [2]]), axis=0)), np.insert(h, [4, 1], [[1], [2]], axis=0))
     assert np.array_equal(ints(np.insert(x, 3, mk([1, 2, 3, 4, 5]), axis=1)), np.insert(h, 3, [1, 2, 3, 4, 5], axis=1))
+    # a size-1 index SEQUENCE takes NumPy's scalar path too: all values go in at that index
+    assert np.array_equal(ints(np.insert(row, [2], mk([7, 8, 9]))), np.insert(h[0], [2], [7, 8, 9]))
+    assert np.array_equal(ints(np.insert(x, [1], mk([[1, 2, 3, 4, 5, 6, 7, 8, 9], [9, 8, 7, 6, 5, 4, 3, 2, 1]]), axis=0)),
+                          np.insert(h, [1], [[1, 2, 3, 4, 5, 6, 7, 8, 9], [9, 8, 7, 6, 5, 4, 3, 2, 1]], axis=0))
+    assert np.array_equal(ints(np.insert(x, [3], mk([[1], [2], [3], [4], [5]]), axis=1)), np.insert(h, [3], [[1], [2], [3], [4], [5]], axis=1))
     assert np.array_equal(ints(np.take(x, [0, 8, 3], axis=-1)), np.take(h, [0, 8, 3], axis=-1))
     assert np.array_equal(ints(np.take(x, [[0, 1], [2, 3]], axis=-2)), np.take(h, [[0, 1], [2, 3]], axis=-2))
 
