@@ -16,9 +16,17 @@ using namespace gfa;
 
 namespace {
 
-// P_i = c_i * 2^k_i + 1 with primitive roots g_i; 2^26 divides every P_i - 1
-constexpr u64 CRT_P[3] = {2013265921ull, 469762049ull, 1811939329ull};
-constexpr u64 CRT_G[3] = {31ull, 3ull, 13ull};
+// P_i = c_i * 2^k_i + 1 with primitive roots g_i.  Two sets:
+//   set 0: three 31-bit primes (product 2^90.6), 2^26 divides every P_i - 1 -- any p < 2^32, products up to 2^26 terms;
+//   set 1 (r05): three primes BELOW 2^29 (product 2^84.6), 2^23 divides every P_i - 1.  Their transforms run on the signed-Montgomery
+//          kernels (gfa_ntt_m32.hip: 40 instead of 56 vector instructions per point and pass, memory-bound), so whenever the
+//          coefficient bound  min(na, nb) * (p - 1)^2  fits below their product and the transform below 2^23 points, this is the set.
+struct CrtSet {
+    u64 P[3], G[3];
+    int max_log;
+};
+constexpr CrtSet CRT_SETS[2] = {{{2013265921ull, 469762049ull, 1811939329ull}, {31ull, 3ull, 13ull}, 26},
+                                {{469762049ull, 377487361ull, 167772161ull}, {3ull, 7ull, 3ull}, 23}};
 constexpr int CRT_MAX_LOG = 26;
 
 u64 host_powmod(u64 b, u64 e, u64 m)
@@ -33,23 +41,31 @@ u64 host_powmod(u64 b, u64 e, u64 m)
 }
 
 std::mutex g_mu;
-gfa_field *g_aux[3] = {nullptr, nullptr, nullptr};
+gfa_field *g_aux[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
 
-int aux_fields(gfa_field **out)
+int aux_fields(int set, gfa_field **out)
 {
     std::lock_guard<std::mutex> lock(g_mu);
     for (int i = 0; i < 3; i++) {
-        if (!g_aux[i]) {
-            int rc = gfa_field_create(CRT_P[i], 1, nullptr, CRT_G[i], &g_aux[i]);
+        if (!g_aux[set][i]) {
+            int rc = gfa_field_create(CRT_SETS[set].P[i], 1, nullptr, CRT_SETS[set].G[i], &g_aux[set][i]);
             if (rc) return rc;
         }
-        out[i] = g_aux[i];
+        out[i] = g_aux[set][i];
     }
     return GFA_OK;
 }
 
+// every coefficient of the integer product must stay below P1*P2*P3
+bool crt_set_fits(int set, u64 p, i64 lo, int lg)
+{
+    const long double bound = (long double)lo * (long double)(p - 1) * (long double)(p - 1);
+    const long double M = (long double)CRT_SETS[set].P[0] * (long double)CRT_SETS[set].P[1] * (long double)CRT_SETS[set].P[2];
+    return lg <= CRT_SETS[set].max_log && bound < M * 0.99L;
+}
+
 // buf[i][0][j] = a[j] mod P_i, buf[i][1][j] = b[j] mod P_i, zero padded to n_fft
-template <typename T>
+template <typename T, int SET>
 __global__ __launch_bounds__(256) void crt_spread_kernel(const T *__restrict__ a, i64 na, const T *__restrict__ b, i64 nb,
                                                          u32 *__restrict__ buf, i64 n_fft)
 {
@@ -57,20 +73,21 @@ __global__ __launch_bounds__(256) void crt_spread_kernel(const T *__restrict__ a
         const u64 av = j < na ? (u64)a[j] : 0, bv = j < nb ? (u64)b[j] : 0;
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            buf[(2 * i) * n_fft + j] = (u32)(av % CRT_P[i]);
-            buf[(2 * i + 1) * n_fft + j] = (u32)(bv % CRT_P[i]);
+            buf[(2 * i) * n_fft + j] = (u32)(av % CRT_SETS[SET].P[i]);
+            buf[(2 * i + 1) * n_fft + j] = (u32)(bv % CRT_SETS[SET].P[i]);
         }
     }
 }
 
 // buf[i][0][j] <- buf[i][0][j] * buf[i][1][j] mod P_i
+template <int SET>
 __global__ __launch_bounds__(256) void crt_pointwise_kernel(u32 *__restrict__ buf, i64 n_fft)
 {
     for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n_fft; j += (i64)gridDim.x * blockDim.x) {
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             const u64 x = buf[(2 * i) * n_fft + j], y = buf[(2 * i + 1) * n_fft + j];
-            buf[(2 * i) * n_fft + j] = (u32)(x * y % CRT_P[i]);
+            buf[(2 * i) * n_fft + j] = (u32)(x * y % CRT_SETS[SET].P[i]);
         }
     }
 }
@@ -82,11 +99,11 @@ struct CrtConsts {
 };
 
 // Garner: x = x1 + x2*P1 + x3*P1*P2 (0 <= x < P1*P2*P3), then x mod p
-template <typename T>
+template <typename T, int SET>
 __global__ __launch_bounds__(256) void crt_combine_kernel(FieldDev fd, const u32 *__restrict__ buf, i64 n_fft, T *__restrict__ out,
                                                           i64 n_out, CrtConsts cc)
 {
-    constexpr u64 P1 = CRT_P[0], P2 = CRT_P[1], P3 = CRT_P[2];
+    constexpr u64 P1 = CRT_SETS[SET].P[0], P2 = CRT_SETS[SET].P[1], P3 = CRT_SETS[SET].P[2];
     for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < n_out; j += (i64)gridDim.x * blockDim.x) {
         const u64 r1 = buf[j], r2 = buf[2 * n_fft + j], r3 = buf[4 * n_fft + j];
         const u64 x2 = (r2 + P2 - r1 % P2) % P2 * cc.inv_p1_mod_p2 % P2;
@@ -98,21 +115,22 @@ __global__ __launch_bounds__(256) void crt_combine_kernel(FieldDev fd, const u32
     }
 }
 
-template <typename T>
-int run_crt(gfa_field *f, const void *a, i64 na, const void *b, i64 nb, void *out, hipStream_t st)
+template <typename T, int SET>
+int run_crt_set(gfa_field *f, const void *a, i64 na, const void *b, i64 nb, void *out, hipStream_t st)
 {
+    constexpr const u64 *CRT_P = CRT_SETS[SET].P, *CRT_G = CRT_SETS[SET].G;
     const FieldDev &fd = f->calc;
     const i64 n_out = na + nb - 1;
     int lg = 0;
     while (((i64)1 << lg) < n_out) lg++;
     const i64 n_fft = (i64)1 << lg;
     gfa_field *aux[3];
-    int rc = aux_fields(aux);
+    int rc = aux_fields(SET, aux);
     if (rc) return rc;
     u32 *buf = nullptr;
     GFA_HIP(gfa::scratch_alloc((void **)&buf, sizeof(u32) * 6 * (size_t)n_fft, st));
     const int grid = (int)std::min<i64>((n_fft + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL((crt_spread_kernel<T>), dim3(grid), dim3(256), 0, st, (const T *)a, na, (const T *)b, nb, buf, n_fft);
+    hipLaunchKernelGGL((crt_spread_kernel<T, SET>), dim3(grid), dim3(256), 0, st, (const T *)a, na, (const T *)b, nb, buf, n_fft);
     rc = GFA_OK;
     u64 omega[3];
     for (int i = 0; i < 3 && !rc; i++) {
@@ -120,7 +138,7 @@ int run_crt(gfa_field *f, const void *a, i64 na, const void *b, i64 nb, void *ou
         rc = gfa_ntt(aux[i], buf + 2 * i * n_fft, buf + 2 * i * n_fft, n_fft, 2, omega[i], 0, GFA_U32, (gfa_stream_t)st);
     }
     if (!rc) {
-        hipLaunchKernelGGL(crt_pointwise_kernel, dim3(grid), dim3(256), 0, st, buf, n_fft);
+        hipLaunchKernelGGL((crt_pointwise_kernel<SET>), dim3(grid), dim3(256), 0, st, buf, n_fft);
         for (int i = 0; i < 3 && !rc; i++) {
             const u64 winv = host_powmod(omega[i], CRT_P[i] - 2, CRT_P[i]);
             rc = gfa_ntt(aux[i], buf + 2 * i * n_fft, buf + 2 * i * n_fft, n_fft, 1, winv, 1, GFA_U32, (gfa_stream_t)st);
@@ -133,11 +151,20 @@ int run_crt(gfa_field *f, const void *a, i64 na, const void *b, i64 nb, void *ou
         cc.inv_p12_mod_p3 = host_powmod(p12_mod_p3, CRT_P[2] - 2, CRT_P[2]);
         cc.p12_mod_p = (u64)((unsigned __int128)CRT_P[0] * CRT_P[1] % fd.p);
         const int g2 = (int)std::min<i64>((n_out + 255) / 256, 256 * 16);
-        hipLaunchKernelGGL((crt_combine_kernel<T>), dim3(g2), dim3(256), 0, st, fd, (const u32 *)buf, n_fft, (T *)out, n_out, cc);
+        hipLaunchKernelGGL((crt_combine_kernel<T, SET>), dim3(g2), dim3(256), 0, st, fd, (const u32 *)buf, n_fft, (T *)out, n_out, cc);
         if (hipGetLastError() != hipSuccess) rc = GFA_ERR_HIP;
     }
     (void)gfa::scratch_free(buf, st);
     return rc;
+}
+
+template <typename T>
+int run_crt(gfa_field *f, const void *a, i64 na, const void *b, i64 nb, void *out, hipStream_t st)
+{
+    int lg = 0;
+    while (((i64)1 << lg) < na + nb - 1) lg++;
+    if (crt_set_fits(1, f->calc.p, std::min(na, nb), lg)) return run_crt_set<T, 1>(f, a, na, b, nb, out, st);
+    return run_crt_set<T, 0>(f, a, na, b, nb, out, st);
 }
 
 } // namespace
@@ -154,10 +181,9 @@ bool convolve_crt_eligible(const FieldDev &fd, i64 na, i64 nb)
     // the CRT route costs ~0.1 ms whatever the size (15 launches); the direct kernel is faster below ~2^22 multiply-adds
     // (tools/convolve_bench.py: 4096 x 4096 terms 0.55 ms direct, 0.094 ms here; 2^20 x 2^20 terms 0.38 ms here)
     if ((double)na * (double)nb < (double)min_work) return false;
-    // every coefficient of the integer product must stay below P1*P2*P3
-    const long double bound = (long double)lo * (long double)(fd.p - 1) * (long double)(fd.p - 1);
-    const long double M = (long double)CRT_P[0] * (long double)CRT_P[1] * (long double)CRT_P[2];
-    return bound < M * 0.99L;
+    int lg = 0;
+    while (((i64)1 << lg) < n_out) lg++;
+    return crt_set_fits(0, fd.p, lo, lg) || crt_set_fits(1, fd.p, lo, lg);
 }
 
 int convolve_crt(gfa_field *f, int dtype, const void *a, i64 na, const void *b, i64 nb, void *out, hipStream_t st)

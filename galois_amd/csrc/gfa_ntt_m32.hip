@@ -46,17 +46,16 @@ struct M32Args {
     i32 p;
     u32 pinv;     // p^-1 mod 2^32
     i32 fin, finp; // last pass: outputs * fin (Montgomery form of 1 or of 1/n), finp = fin * pinv
+    i32 one, onep; // Montgomery form of 1 and its companion: the in-network reductions of primes >= 2^26 (DifSched)
+    // MODE 1 with a SPLIT progression table (first pass of a three-pass transform: 2^11 .. 2^18 columns): line = lh * 2^tw_bits + ll,
+    // t_0 = tw[ll * R1 + ka] * twh[lh * R1 + ka], ratio = tw2[ll] * tw2h[lh]; tw_bits = 0: tw / tw2 hold every line
+    const i32 *twh, *tw2h;
+    int tw_bits;
 };
 
-// v_mul_hi_i32 through inline assembly: the compiler matches the signed high product only while the sign extensions sit in
-// the same basic block; once it hoists sext(p) out of a block it expands every product into four unsigned multiplies.
-// "s": wave-uniform operand in a scalar register (kernel argument or scalar load) -- one constant-bus read per VOP3.
-__device__ __forceinline__ i32 mulhi_vs(i32 x, i32 s)
-{
-    i32 r;
-    asm("v_mul_hi_i32 %0, %1, %2" : "=v"(r) : "v"(x), "s"(s));
-    return r;
-}
+#include "gfa_m32_net.h" // m32_mulm / DifSched / dif: shared with the host check of the networks (tests/csrc/m32_net_host_test.cpp)
+
+__device__ __forceinline__ i32 mulhi_vs(i32 x, i32 s) { return m32_mulhi_vs(x, s); }
 __device__ __forceinline__ i32 mulhi_vv(i32 x, i32 y)
 {
     i32 r;
@@ -64,13 +63,7 @@ __device__ __forceinline__ i32 mulhi_vv(i32 x, i32 y)
     return r;
 }
 
-// x * w * 2^-32 (mod p) as a representative in (-p, p); any int32 x, |wm| <= p/2, wp = wm * p^-1 mod 2^32
-// (uniform twiddle: wm, wp, p in scalar registers)
-__device__ __forceinline__ i32 mulm(i32 x, i32 wm, i32 wp, i32 p)
-{
-    const i32 m = (i32)((u32)x * (u32)wp);
-    return mulhi_vs(x, wm) - mulhi_vs(m, p);
-}
+__device__ __forceinline__ i32 mulm(i32 x, i32 wm, i32 wp, i32 p) { return m32_mulm(x, wm, wp, p); }
 // per-lane twiddle (wm, wp in vector registers)
 __device__ __forceinline__ i32 mulm_v(i32 x, i32 wm, i32 wp, i32 p)
 {
@@ -97,29 +90,6 @@ constexpr int brev_c(int x, int bits)
     return r;
 }
 
-// v[bitrev(k)] <- sum_a v[a] * w_R^(a*k);  net[2j], net[2j+1] = Montgomery form of w_R^j and its p^-1 companion (uniform)
-template <int LOGR>
-__device__ __forceinline__ void dif(i32 (&v)[1 << LOGR], const i32 *__restrict__ net, i32 p)
-{
-    constexpr int R = 1 << LOGR;
-#pragma unroll
-    for (int s = LOGR - 1; s >= 0; s--) {
-        const int half = 1 << s;
-#pragma unroll
-        for (int b = 0; b < R; b += 2 * half) {
-#pragma unroll
-            for (int j = 0; j < half; j++) {
-                const i32 u = v[b + j], x = v[b + j + half];
-                v[b + j] = (i32)((u32)u + (u32)x);
-                const i32 d = (i32)((u32)u - (u32)x);
-                const int tj = j << (LOGR - 1 - s);
-                if (tj != 0) v[b + j + half] = mulm(d, net[2 * tj], net[2 * tj + 1], p);
-                else v[b + j + half] = d;
-            }
-        }
-    }
-}
-
 template <int C>
 constexpr int line_pitch(int rows, int row)
 { // words per staged line: rows * row rounded up so that the lanes of one LDS access fall into distinct banks
@@ -142,7 +112,7 @@ constexpr int line_pitch(int rows, int row)
 #ifndef GFA_M32_WAVES
 #define GFA_M32_WAVES 4 // waves per SIMD the register allocation is held to (128 VGPRs): two 512-thread workgroups per CU
 #endif
-template <int LOGR1, int LOGR2, int THREADS, bool SPLIT, int MODE, bool NT>
+template <int LOGR1, int LOGR2, int THREADS, bool SPLIT, int MODE, bool NT, int BMAX>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_M32_WAVES))) void ntt_m32_kernel(const i32 *__restrict__ in, i32 *__restrict__ out, M32Args a,
                                                           const i32 *__restrict__ net1, const i32 *__restrict__ net2,
                                                           const i32 *__restrict__ mid, const i32 *__restrict__ tw,
@@ -208,7 +178,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_M32
             const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)gin, 0, 0xffffffffu, 0x00020000);
 #pragma unroll
             for (int k = 0; k < R1; k++) va[k] = __builtin_amdgcn_raw_buffer_load_b32(rin, (int)off, (int)(k * step), NT ? 2 : 0);
-            dif<LOGR1>(va, net1, p);
+            dif<LOGR1, BMAX>(va, net1, p, a.one, a.onep);
         }
         __syncthreads(); // middle-twiddle table staged
 #pragma unroll
@@ -232,7 +202,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_M32
             if (SPLIT && h == 0) __syncthreads();
         }
     }
-    dif<LOGR2>(v, net2, p);
+    dif<LOGR2, BMAX>(v, net2, p, a.one, a.onep);
     const u32 ooff = ((u32)c * (u32)a.out_stride_c + (u32)ka * (u32)a.out_stride_t) * 4u;
     const u32 ostep = (u32)R1 * (u32)a.out_stride_t * 4u; // uniform
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)gout, 0, 0xffffffffu, 0x00020000);
@@ -243,8 +213,15 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(GFA_M32
         const i32 negp = -p;
         if (live) {
             const u32 line = (u32)line0 + (u32)c;
-            i32 t = tw[line * (u32)R1 + (u32)ka];
-            const i32 sr = tw2[line];
+            i32 t, sr;
+            if (a.tw_bits) { // wave-uniform branch: one more product per thread, not per point
+                const u32 ll = line & ((1u << a.tw_bits) - 1u), lh = line >> a.tw_bits;
+                t = mulm1(tw[ll * (u32)R1 + (u32)ka], a.twh[lh * (u32)R1 + (u32)ka], pinv, negp);
+                sr = mulm1(tw2[ll], a.tw2h[lh], pinv, negp);
+            } else {
+                t = tw[line * (u32)R1 + (u32)ka];
+                sr = tw2[line];
+            }
 #pragma unroll
             for (int kr = 0; kr < R2; kr++) {
                 __builtin_amdgcn_raw_buffer_store_b32(mulm1(v[brev_c(kr, LOGR2)], t, pinv, negp), rout, (int)ooff, (int)(kr * ostep), 0);
@@ -295,7 +272,7 @@ constexpr int one_pitch()
 // for the next transform's loads that are in flight by design.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int LOGR0, int G>
+template <int LOGR0, int G, int BMAX>
 __global__ __launch_bounds__(G * (32 << LOGR0)) void ntt_m32_one_kernel(const i32 *__restrict__ in, i32 *__restrict__ out, M32OneArgs a,
                                                                        const i32 *__restrict__ net0, const i32 *__restrict__ net1,
                                                                        const i32 *__restrict__ mid, const i32 *__restrict__ wj, i64 batch)
@@ -330,7 +307,7 @@ __global__ __launch_bounds__(G * (32 << LOGR0)) void ntt_m32_one_kernel(const i3
         // ---- phase 1 ----
 #pragma unroll
         for (int i = 0; i < P; i++) {
-            dif<LOGR0>(va[i], net0, p);
+            dif<LOGR0, BMAX>(va[i], net0, p, a.one, a.onep);
             const i32 ratio = wj[tid + i * T]; // w_n^j in Montgomery form
             i32 t = ratio;
             i32 *dst = data + tid + i * T;
@@ -351,7 +328,7 @@ __global__ __launch_bounds__(G * (32 << LOGR0)) void ntt_m32_one_kernel(const i3
             const i32 *src = data + k0 * PITCH + r;
 #pragma unroll
             for (int x = 0; x < 32; x++) v[x] = src[32 * x];
-            dif<5>(v, net1, p);
+            dif<5, BMAX>(v, net1, p, a.one, a.onep);
             lds_barrier(); // every thread has read its sub-line: the buffer can take the second layout
             i32 *dst = data + k0 * PITCH + r;
             const int2 *mrow = reinterpret_cast<const int2 *>(midl) + r;
@@ -369,7 +346,7 @@ __global__ __launch_bounds__(G * (32 << LOGR0)) void ntt_m32_one_kernel(const i3
 #pragma unroll
             for (int r = 0; r < 32; r++) v[r] = src[r];
             lds_barrier(); // the rows are in registers: the next iteration's phase 1 may overwrite the buffer
-            dif<5>(v, net1, p);
+            dif<5, BMAX>(v, net1, p, a.one, a.onep);
             const i32 fin = a.fin, finp = a.finp;
             const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(out + row_of(blk) * n), 0, (u32)(n * 4), 0x00020000);
 #pragma unroll
@@ -398,6 +375,7 @@ constexpr int B16_E2_PITCH = 33;
 constexpr int B16_EX_WORDS = 16 * 64 * B16_E2_PITCH; // 33792 words >= exchange 1's 32 * 1024
 constexpr size_t B16_LDS_BYTES = sizeof(i32) * (size_t)(B16_EX_WORDS + 2 * 1024);
 
+template <int BMAX>
 __global__ __launch_bounds__(1024) void ntt_m32_2e16_kernel(const i32 *in, i32 *out, M32OneArgs a, const i32 *__restrict__ net0,
                                                             const i32 *__restrict__ net1, const i32 *__restrict__ mid, const i32 *__restrict__ wj, i64 batch)
 {
@@ -431,7 +409,7 @@ __global__ __launch_bounds__(1024) void ntt_m32_2e16_kernel(const i32 *in, i32 *
         const bool has_next = tr_i + gridDim.x < batch;
         const __amdgpu_buffer_rsrc_t xn = in_rsrc(has_next ? tr_i + gridDim.x : tr_i);
         // ---- network 0 and the first twiddle: Y[k0] * w^(m k0), t <- t * w^m ----
-        dif<6>(v, net0, p);
+        dif<6, BMAX>(v, net0, p, a.one, a.onep);
         __builtin_amdgcn_sched_barrier(0);
         v[0] = mulm(v[0], a.one, a.onep, p);
         {
@@ -449,7 +427,7 @@ __global__ __launch_bounds__(1024) void ntt_m32_2e16_kernel(const i32 *in, i32 *
         // ---- exchange 1 + network 1 ----
         i32 w[2][32];
         auto net1f = [&](int h) {
-            dif<5>(w[h], net1, p);
+            dif<5, BMAX>(w[h], net1, p, a.one, a.onep);
             const int2 *mrow = reinterpret_cast<const int2 *>(midl) + r;
             w[h][0] = mulm(w[h][0], a.one, a.onep, p);
 #pragma unroll
@@ -495,7 +473,7 @@ __global__ __launch_bounds__(1024) void ntt_m32_2e16_kernel(const i32 *in, i32 *
             for (int ap = lo; ap < hi; ap++) v[ap] = __builtin_amdgcn_raw_buffer_load_b32(xn, voff, ap * 4096, 0);
         };
         auto net2f = [&](int h) {
-            dif<5>(z[h], net1, p);
+            dif<5, BMAX>(z[h], net1, p, a.one, a.onep);
 #pragma unroll
             for (int k2 = 0; k2 < 32; k2++) {
                 i32 x = mulm(z[h][brev_c(k2, 5)], fin, finp, p); // (-p, p)
@@ -567,10 +545,13 @@ inline i32 mont_centred(u64 w, u64 p)
 }
 
 struct M32Plan {
-    int log1 = 0, log2 = 0;
-    i32 *net1 = nullptr, *net2 = nullptr; // R/2 pairs each
-    i32 *mid1 = nullptr, *mid2 = nullptr; // L pairs: w_L^e, companion
-    i32 *pt0 = nullptr, *pratio = nullptr; // progression form of the inter-pass twiddle: n2 * R1 and n2 entries
+    int log1 = 0, log2 = 0, log3 = 0;     // line lengths per pass (log3 != 0: three passes, n = 2^(log1 + log2 + log3))
+    i32 *net1 = nullptr, *net2 = nullptr, *net3 = nullptr; // R/2 pairs each
+    i32 *mid1 = nullptr, *mid2 = nullptr, *mid3 = nullptr; // L pairs: w_L^e, companion
+    i32 *pt0 = nullptr, *pratio = nullptr; // progression form of the inter-pass twiddle: n2 * R1 and n2 entries (three passes: the SECOND pass)
+    // three passes, first pass (2^(log2 + log3) columns): the progression seeds split in a low and a high table
+    i32 *at0 = nullptr, *aratio = nullptr, *at0h = nullptr, *aratioh = nullptr;
+    int a_bits = 0;
     // one-pass form (2^11 .. 2^15 points): radix-R0 network twiddles, radix-32 network twiddles, w_1024^e pairs, w_n^j (j < 1024)
     i32 *one_net0 = nullptr, *one_net1 = nullptr, *one_mid = nullptr, *one_wj = nullptr;
 };
@@ -585,7 +566,8 @@ std::map<M32Key, M32Plan *> g_m32_plans;
 
 void free_plan(M32Plan *pl)
 {
-    for (void *q : {(void *)pl->net1, (void *)pl->net2, (void *)pl->mid1, (void *)pl->mid2, (void *)pl->pt0, (void *)pl->pratio, (void *)pl->one_net0,
+    for (void *q : {(void *)pl->net1, (void *)pl->net2, (void *)pl->net3, (void *)pl->mid1, (void *)pl->mid2, (void *)pl->mid3, (void *)pl->pt0,
+                    (void *)pl->pratio, (void *)pl->at0, (void *)pl->aratio, (void *)pl->at0h, (void *)pl->aratioh, (void *)pl->one_net0,
                     (void *)pl->one_net1, (void *)pl->one_mid, (void *)pl->one_wj})
         if (q) (void)hipFree(q);
     delete pl;
@@ -615,16 +597,36 @@ int pair_table(u64 p, u32 pinv, u64 omega, u64 mult, int count, i32 **d)
 
 constexpr int split_log1(int logL) { return (logL + 1) / 2; } // R1 >= R2
 
+// progression tables of a MODE-1 pass with `lines` = 2^loglines lines of line length 2^logL inside a transform with root `w`
+// of order 2^logw:  t0[j * R1 + ka] = w^(j * ka), ratio[j] = w^(j * R1)
+int progression_tables(u64 p, u64 w, int logw, int loglines, int logL, i32 **t0, i32 **ratio, hipStream_t st)
+{
+    const int lr1 = split_log1(logL);
+    const i64 lines = (i64)1 << loglines, cnt = lines * (((i64)1 << lr1) + 1);
+    GFA_HIP(hipMalloc((void **)t0, sizeof(i32) * (size_t)(lines << lr1)));
+    GFA_HIP(hipMalloc((void **)ratio, sizeof(i32) * (size_t)lines));
+    hipLaunchKernelGGL(m32_progression_table_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, (u32)p, (u32)w, logw, loglines, lr1, *t0,
+                       *ratio);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
 int build_plan(M32Plan *pl, u64 p, i64 n, u64 omega, hipStream_t st)
 {
     int logn = 0;
     while (((i64)1 << logn) < n) logn++;
     if (logn <= 10) { pl->log1 = logn; pl->log2 = 0; }
-    else { pl->log1 = (logn + 1) / 2; pl->log2 = logn - pl->log1; }
+    else if (logn <= 20) { pl->log1 = (logn + 1) / 2; pl->log2 = logn - pl->log1; }
+    else {
+        // three passes (measured on the register kernels of gfa_ntt.hip, tools/ntt3_tune.py): longest lines in the widest-strided pass,
+        // shortest in the last
+        pl->log1 = (logn + 2) / 3;
+        pl->log2 = (logn - pl->log1 + 1) / 2;
+        pl->log3 = logn - pl->log1 - pl->log2;
+    }
     const u32 pinv = inv_2_32((u32)p);
     int rc;
-    auto line_tables = [&](int logL, i32 **net_a, i32 **net_b_unused, i32 **mid) -> int {
-        (void)net_b_unused;
+    auto line_tables = [&](int logL, i32 **net_a, i32 **mid) -> int {
         // networks of a line of L = R1 * R2 points: w_R1 = w_L^R2, w_R2 = w_L^R1; both tables in one allocation [R1/2 | R2/2]
         const int lr1 = split_log1(logL), lr2 = logL - lr1;
         const i64 Lh = (i64)1 << logL;
@@ -666,25 +668,29 @@ int build_plan(M32Plan *pl, u64 p, i64 n, u64 omega, hipStream_t st)
         for (int j = 0; j < 1024; j++) { hw[j] = mont_centred(cur, p); cur = cur * omega % p; }          // w_n^j
         if ((rc = upload(hw, &pl->one_wj))) return rc;
     }
-    i32 *dummy = nullptr;
-    if ((rc = line_tables(pl->log1, &pl->net1, &dummy, &pl->mid1))) return rc;
-    if (pl->log2) {
-        if ((rc = line_tables(pl->log2, &pl->net2, &dummy, &pl->mid2))) return rc;
-        {
-            const int lr1 = split_log1(pl->log1);
-            const i64 n2 = (i64)1 << pl->log2, cnt = n2 * (((i64)1 << lr1) + 1);
-            GFA_HIP(hipMalloc((void **)&pl->pt0, sizeof(i32) * (size_t)(n2 << lr1)));
-            GFA_HIP(hipMalloc((void **)&pl->pratio, sizeof(i32) * (size_t)n2));
-            hipLaunchKernelGGL(m32_progression_table_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, (u32)p, (u32)omega, logn,
-                               pl->log2, lr1, pl->pt0, pl->pratio);
-            GFA_HIP(hipGetLastError());
-        }
+    if ((rc = line_tables(pl->log1, &pl->net1, &pl->mid1))) return rc;
+    if (pl->log3) {
+        if ((rc = line_tables(pl->log2, &pl->net2, &pl->mid2))) return rc;
+        if ((rc = line_tables(pl->log3, &pl->net3, &pl->mid3))) return rc;
+        // first pass: M = 2^(log2 + log3) columns j, twiddle w_n^(j * k1).  j = jh * 2^a_bits + jl: w^(j ka) = w^(jl ka) * (w^(2^a_bits))^(jh ka)
+        const int logm = pl->log2 + pl->log3;
+        pl->a_bits = logm / 2;
+        if ((rc = progression_tables(p, omega, logn, pl->a_bits, pl->log1, &pl->at0, &pl->aratio, st))) return rc;
+        if ((rc = progression_tables(p, powmod(omega, (u64)1 << pl->a_bits, p), logn, logm - pl->a_bits, pl->log1, &pl->at0h, &pl->aratioh, st)))
+            return rc;
+        // second pass, per row k1: the 2^log3 columns of an M-point transform with root w_M = w_n^(2^log1)
+        if ((rc = progression_tables(p, powmod(omega, (u64)1 << pl->log1, p), logm, pl->log3, pl->log2, &pl->pt0, &pl->pratio, st))) return rc;
+        GFA_HIP(hipStreamSynchronize(st)); // the plan may next be used from another stream
+    } else if (pl->log2) {
+        if ((rc = line_tables(pl->log2, &pl->net2, &pl->mid2))) return rc;
+        if ((rc = progression_tables(p, omega, logn, pl->log2, pl->log1, &pl->pt0, &pl->pratio, st))) return rc;
         GFA_HIP(hipStreamSynchronize(st)); // the plan may next be used from another stream
     }
     return GFA_OK;
 }
 
-template <int LOGR1, int LOGR2, int THREADS, bool SPLIT, int MODE, bool NT>
+// BMAX = floor(2^31 / p) rounded down to the classes that are built: 32 (p < 2^26: no reduction inside a radix-32 network), 8, 4
+template <int LOGR1, int LOGR2, int THREADS, bool SPLIT, int MODE, bool NT, int BMAX>
 int launch_ttm(const i32 *in, i32 *out, M32Args a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, const i32 *tw2, hipStream_t st)
 {
     constexpr int R1 = 1 << LOGR1, R2 = 1 << LOGR2, L = R1 * R2, C = THREADS / R1;
@@ -706,7 +712,7 @@ int launch_ttm(const i32 *in, i32 *out, M32Args a, i64 batch, const i32 *net, co
         const bool can1 = (a.tiles_per_batch % 8) == 0 && a.tiles_per_batch >= 64, can2 = (grid % 8) == 0 && grid >= 16;
         a.tile_order = can1 ? 1 : (can2 ? 2 : 0);
     }
-    auto kern = ntt_m32_kernel<LOGR1, LOGR2, THREADS, SPLIT, MODE, NT>;
+    auto kern = ntt_m32_kernel<LOGR1, LOGR2, THREADS, SPLIT, MODE, NT, BMAX>;
     static bool attr = false;
     if (!attr) {
         GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -717,37 +723,46 @@ int launch_ttm(const i32 *in, i32 *out, M32Args a, i64 batch, const i32 *net, co
     return GFA_OK;
 }
 
-template <int LOGR1, int LOGR2, int THREADS, bool SPLIT>
+template <int LOGR1, int LOGR2, int THREADS, bool SPLIT, int BMAX>
 int launch_tt(const i32 *in, i32 *out, const M32Args &a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, const i32 *tw2, hipStream_t st, int mode)
 {
-    if (mode == 0) return launch_ttm<LOGR1, LOGR2, THREADS, SPLIT, 0, false>(in, out, a, batch, net, mid, tw, tw2, st);
-    if (mode == 2) return launch_ttm<LOGR1, LOGR2, THREADS, SPLIT, 0, true>(in, out, a, batch, net, mid, tw, tw2, st); // last pass, non-temporal
-    return launch_ttm<LOGR1, LOGR2, THREADS, SPLIT, 1, false>(in, out, a, batch, net, mid, tw, tw2, st);
+    if (mode == 0) return launch_ttm<LOGR1, LOGR2, THREADS, SPLIT, 0, false, BMAX>(in, out, a, batch, net, mid, tw, tw2, st);
+    if (mode == 2) return launch_ttm<LOGR1, LOGR2, THREADS, SPLIT, 0, true, BMAX>(in, out, a, batch, net, mid, tw, tw2, st); // last pass, non-temporal
+    return launch_ttm<LOGR1, LOGR2, THREADS, SPLIT, 1, false, BMAX>(in, out, a, batch, net, mid, tw, tw2, st);
 }
 
-template <int LOGR1, int LOGR2>
+template <int LOGR1, int LOGR2, int BMAX>
 int launch_t(const i32 *in, i32 *out, const M32Args &a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, const i32 *tw2, hipStream_t st, int mode)
 {
     // 1024-point lines: 512-thread workgroups, two per CU, the whole line staged (measured against 256 / 1024 threads and a two-round
     // exchange with three workgroups per CU: 0.236 vs 0.268 ms at 2^20 x 64, profiles/r03_m32_sweep.txt); shorter lines: 256 threads
-    if constexpr (LOGR1 == 5) return launch_tt<LOGR1, LOGR2, 512, false>(in, out, a, batch, net, mid, tw, tw2, st, mode);
-    else return launch_tt<LOGR1, LOGR2, 256, false>(in, out, a, batch, net, mid, tw, tw2, st, mode);
+    if constexpr (LOGR1 == 5) return launch_tt<LOGR1, LOGR2, 512, false, BMAX>(in, out, a, batch, net, mid, tw, tw2, st, mode);
+    else return launch_tt<LOGR1, LOGR2, 256, false, BMAX>(in, out, a, batch, net, mid, tw, tw2, st, mode);
 }
 
-int launch(int logL, const i32 *in, i32 *out, const M32Args &a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, const i32 *tw2, hipStream_t st, int mode)
+template <int BMAX>
+int launch_b(int logL, const i32 *in, i32 *out, const M32Args &a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, const i32 *tw2, hipStream_t st, int mode)
 {
     switch (logL) {
-    case 5: return launch_t<3, 2>(in, out, a, batch, net, mid, tw, tw2, st, mode);
-    case 6: return launch_t<3, 3>(in, out, a, batch, net, mid, tw, tw2, st, mode);
-    case 7: return launch_t<4, 3>(in, out, a, batch, net, mid, tw, tw2, st, mode);
-    case 8: return launch_t<4, 4>(in, out, a, batch, net, mid, tw, tw2, st, mode);
-    case 9: return launch_t<5, 4>(in, out, a, batch, net, mid, tw, tw2, st, mode);
-    case 10: return launch_t<5, 5>(in, out, a, batch, net, mid, tw, tw2, st, mode);
+    case 5: return launch_t<3, 2, BMAX>(in, out, a, batch, net, mid, tw, tw2, st, mode);
+    case 6: return launch_t<3, 3, BMAX>(in, out, a, batch, net, mid, tw, tw2, st, mode);
+    case 7: return launch_t<4, 3, BMAX>(in, out, a, batch, net, mid, tw, tw2, st, mode);
+    case 8: return launch_t<4, 4, BMAX>(in, out, a, batch, net, mid, tw, tw2, st, mode);
+    case 9: return launch_t<5, 4, BMAX>(in, out, a, batch, net, mid, tw, tw2, st, mode);
+    case 10: return launch_t<5, 5, BMAX>(in, out, a, batch, net, mid, tw, tw2, st, mode);
     default: set_error("m32 NTT: unsupported line length"); return GFA_ERR_UNSUPPORTED;
     }
 }
 
-template <int LOGR0>
+// cls: 0 p < 2^26, 1 p < 2^28, 2 p < 2^29
+int launch(int cls, int logL, const i32 *in, i32 *out, const M32Args &a, i64 batch, const i32 *net, const i32 *mid, const i32 *tw, const i32 *tw2, hipStream_t st, int mode)
+{
+    if (cls == 0) return launch_b<32>(logL, in, out, a, batch, net, mid, tw, tw2, st, mode);
+    if (cls == 1) return launch_b<8>(logL, in, out, a, batch, net, mid, tw, tw2, st, mode);
+    return launch_b<4>(logL, in, out, a, batch, net, mid, tw, tw2, st, mode);
+}
+
+template <int LOGR0, int BMAX>
 int launch_one_t(const i32 *in, i32 *out, const M32OneArgs &oa, i64 batch, const M32Plan *pl, hipStream_t st)
 {
     constexpr int R0 = 1 << LOGR0;
@@ -755,7 +770,7 @@ int launch_one_t(const i32 *in, i32 *out, const M32OneArgs &oa, i64 batch, const
     // 256 threads 0.162, eight per 512 threads 0.145; 2^12 one 0.155, two 0.161, four 0.148; 2^13 one per 256 threads 0.140-0.150, two 0.152
     constexpr int G = R0 <= 4 ? 16 / R0 : 1;
     constexpr size_t lds = sizeof(i32) * (size_t)(2 * 1024 + G * R0 * one_pitch<LOGR0>());
-    auto kern = ntt_m32_one_kernel<LOGR0, G>;
+    auto kern = ntt_m32_one_kernel<LOGR0, G, BMAX>;
     static bool attr = false;
     if (!attr) {
         GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -774,30 +789,48 @@ int launch_one_t(const i32 *in, i32 *out, const M32OneArgs &oa, i64 batch, const
     return GFA_OK;
 }
 
-int launch_2e16(const i32 *in, i32 *out, const M32OneArgs &oa, i64 batch, const M32Plan *pl, hipStream_t st)
+template <int BMAX>
+int launch_2e16_b(const i32 *in, i32 *out, const M32OneArgs &oa, i64 batch, const M32Plan *pl, hipStream_t st)
 {
+    auto kern = ntt_m32_2e16_kernel<BMAX>;
     static bool attr = false;
     if (!attr) {
-        GFA_HIP(hipFuncSetAttribute((const void *)ntt_m32_2e16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GFA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     static const int cus = [] { int dev = 0, n = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }();
     const i64 grid = std::min<i64>(batch, cus); // persistent: one workgroup per CU (LDS-limited)
-    hipLaunchKernelGGL(ntt_m32_2e16_kernel, dim3((unsigned)grid), dim3(1024), B16_LDS_BYTES, st, in, out, oa, pl->one_net0, pl->one_net1, pl->one_mid, pl->one_wj, batch);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(1024), B16_LDS_BYTES, st, in, out, oa, pl->one_net0, pl->one_net1, pl->one_mid, pl->one_wj, batch);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }
 
-int launch_one(int logr0, const i32 *in, i32 *out, const M32OneArgs &oa, i64 batch, const M32Plan *pl, hipStream_t st)
+// the radix-64 network grows by 2^6: no reduction needed below 2^25 (BMAX 64); above, the schedule of the prime's class
+int launch_2e16(u64 p, const i32 *in, i32 *out, const M32OneArgs &oa, i64 batch, const M32Plan *pl, hipStream_t st)
+{
+    if (p < (1ull << 25)) return launch_2e16_b<64>(in, out, oa, batch, pl, st);
+    if (p < (1ull << 28)) return launch_2e16_b<8>(in, out, oa, batch, pl, st);
+    return launch_2e16_b<4>(in, out, oa, batch, pl, st);
+}
+
+template <int BMAX>
+int launch_one_b(int logr0, const i32 *in, i32 *out, const M32OneArgs &oa, i64 batch, const M32Plan *pl, hipStream_t st)
 {
     switch (logr0) {
-    case 1: return launch_one_t<1>(in, out, oa, batch, pl, st);
-    case 2: return launch_one_t<2>(in, out, oa, batch, pl, st);
-    case 3: return launch_one_t<3>(in, out, oa, batch, pl, st);
-    case 4: return launch_one_t<4>(in, out, oa, batch, pl, st);
-    case 5: return launch_one_t<5>(in, out, oa, batch, pl, st);
+    case 1: return launch_one_t<1, BMAX>(in, out, oa, batch, pl, st);
+    case 2: return launch_one_t<2, BMAX>(in, out, oa, batch, pl, st);
+    case 3: return launch_one_t<3, BMAX>(in, out, oa, batch, pl, st);
+    case 4: return launch_one_t<4, BMAX>(in, out, oa, batch, pl, st);
+    case 5: return launch_one_t<5, BMAX>(in, out, oa, batch, pl, st);
     default: set_error("m32 NTT: unsupported one-pass length"); return GFA_ERR_UNSUPPORTED;
     }
+}
+
+int launch_one(int cls, int logr0, const i32 *in, i32 *out, const M32OneArgs &oa, i64 batch, const M32Plan *pl, hipStream_t st)
+{
+    if (cls == 0) return launch_one_b<32>(logr0, in, out, oa, batch, pl, st);
+    if (cls == 1) return launch_one_b<8>(logr0, in, out, oa, batch, pl, st);
+    return launch_one_b<4>(logr0, in, out, oa, batch, pl, st);
 }
 
 } // namespace
@@ -806,15 +839,17 @@ namespace gfa {
 
 bool ntt_m32_eligible(const FieldDev &fd, i64 n)
 {
-    if (fd.kind != KIND_PRIME32 || fd.p >= (1ull << 26) || (fd.p & 1) == 0) return false;
-    if (n < 32 || n > ((i64)1 << 20) || (n & (n - 1))) return false;
+    // odd p < 2^29 (signed int32 representatives: DifSched); 32 <= n <= 2^28 points (byte offsets of a tile stay below 2^32)
+    if (fd.kind != KIND_PRIME32 || fd.p >= (1ull << 29) || (fd.p & 1) == 0) return false;
+    if (n < 32 || n > ((i64)1 << 28) || (n & (n - 1))) return false;
     int logn = 0;
     while (((i64)1 << logn) < n) logn++;
-    return logn <= 10 || (logn - (logn + 1) / 2) >= 5; // both passes of a two-pass transform need lines of >= 32 points
+    return logn <= 10 || logn >= 21 || (logn - (logn + 1) / 2) >= 5; // every pass of a multi-pass transform needs lines of >= 32 points
 }
 
-// Scratch for the two-pass form: n * batch elements (the caller owns it).  Contiguous rows only.
-size_t ntt_m32_scratch_bytes(i64 n, i64 batch) { return n > 1024 ? sizeof(i32) * (size_t)n * (size_t)batch : 0; }
+// Scratch for the multi-pass forms: n * batch elements for two passes, n for three (one transform at a time); the caller owns it.
+// Contiguous rows only.
+size_t ntt_m32_scratch_bytes(i64 n, i64 batch) { return n > ((i64)1 << 20) ? sizeof(i32) * (size_t)n : n > 1024 ? sizeof(i32) * (size_t)n * (size_t)batch : 0; }
 
 int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 batch, u64 omega, int do_scale, u64 scale,
             hipStream_t st)
@@ -837,11 +872,14 @@ int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 
         pl = it->second;
     }
     const u32 pinv = inv_2_32((u32)fd.p);
+    const int cls = fd.p < (1ull << 26) ? 0 : fd.p < (1ull << 28) ? 1 : 2;
     M32Args base{};
     base.p = (i32)fd.p;
     base.pinv = pinv;
     base.fin = mont_centred(do_scale ? scale % fd.p : 1, fd.p);
     base.finp = (i32)((u32)base.fin * pinv);
+    base.one = mont_centred(1, fd.p);
+    base.onep = (i32)((u32)base.one * pinv);
     const i32 *src = (const i32 *)in;
     i32 *dst = (i32 *)out;
     if (pl->log2 == 0) {
@@ -849,19 +887,58 @@ int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 
         a.in_stride_c = n; a.in_stride_t = 1; a.out_stride_c = n; a.out_stride_t = 1;
         a.total_lines = batch;
         a.load_along_line = 1; a.store_along_line = 1;
-        return launch(pl->log1, src, dst, a, 1, pl->net1, pl->mid1, nullptr, nullptr, st, 0);
+        return launch(cls, pl->log1, src, dst, a, 1, pl->net1, pl->mid1, nullptr, nullptr, st, 0);
+    }
+    if (pl->log3) {
+        // n = L0 * M, M = L1 * L2, three passes, each reading and writing every point once (input index j1 * M + j2 * L2 + j3,
+        // output index k1 + L0 * (k2 + L1 * k3)):
+        //   A : the M columns of length L0 (stride M), times w_n^(jr * k1)                       -> ws[k1 * M + jr]
+        //   B1: per row k1, the L2 columns of length L1 (stride L2), times w_M^(j3 * k2)         -> ws[k1 * M + k2 * L2 + j3]  (in place)
+        //   B2: per (k2, k1) the contiguous row of L2 points                                     -> X[k1 + L0 * (k2 + L1 * k3)]
+        // B2 takes k2 as the batch index and k1 as the line index: the lines of a tile are then adjacent in the output.
+        const i64 L0 = (i64)1 << pl->log1, L1 = (i64)1 << pl->log2, L2 = (i64)1 << pl->log3, M = L1 * L2;
+        i32 *w = (i32 *)ws;
+        for (i64 b = 0; b < batch; b++) {
+            const i32 *sb = src + b * n;
+            i32 *db = dst + b * n;
+            int rc;
+            {
+                M32Args a = base;
+                a.in_stride_c = 1; a.in_stride_t = M; a.out_stride_c = 1; a.out_stride_t = M;
+                a.total_lines = M;
+                a.twh = pl->at0h; a.tw2h = pl->aratioh; a.tw_bits = pl->a_bits;
+                if ((rc = launch(cls, pl->log1, sb, w, a, 1, pl->net1, pl->mid1, pl->at0, pl->aratio, st, 1))) return rc;
+            }
+            {
+                M32Args a = base;
+                a.in_stride_c = 1; a.in_stride_t = L2; a.out_stride_c = 1; a.out_stride_t = L2;
+                a.in_batch_stride = M; a.out_batch_stride = M;
+                a.total_lines = L2;
+                if ((rc = launch(cls, pl->log2, w, w, a, L0, pl->net2, pl->mid2, pl->pt0, pl->pratio, st, 1))) return rc;
+            }
+            {
+                M32Args a = base;
+                a.in_stride_c = M; a.in_stride_t = 1; a.out_stride_c = 1; a.out_stride_t = L0 * L1;
+                a.in_batch_stride = L2; a.out_batch_stride = L0;
+                a.total_lines = L0;
+                a.load_along_line = 1; a.store_along_line = 0;
+                const bool in_cache = (size_t)n * sizeof(i32) <= ((size_t)256 << 20); // the intermediate fits the Infinity Cache
+                if ((rc = launch(cls, pl->log3, w, db, a, L1, pl->net3, pl->mid3, nullptr, nullptr, st, in_cache ? 2 : 0))) return rc;
+            }
+        }
+        return GFA_OK;
     }
     // 2^11 .. 2^16 points: one workgroup per transform (one pass over HBM: 0.41-0.48 of the roofline against 0.29-0.35 in two passes,
-    // profiles/r03_ntt_mid_sizes.txt, r04_m32_2e16.txt).  2^16 points need p < 2^25 (the radix-64 network's growth) and at least 64
-    // transforms (one persistent workgroup per CU); smaller batches and 2^25 <= p < 2^26 keep the two-pass form.
+    // profiles/r03_ntt_mid_sizes.txt, r04_m32_2e16.txt).  2^16 points need at least 64 transforms (one persistent workgroup per CU);
+    // smaller batches keep the two-pass form.
     const bool is16 = pl->log1 + pl->log2 == 16;
-    if (pl->one_wj && batch <= 0x7fffffff && (!is16 || (fd.p < (1ull << 25) && batch >= 64))) {
+    if (pl->one_wj && batch <= 0x7fffffff && (!is16 || batch >= 64)) {
         M32OneArgs oa{};
         oa.p = base.p; oa.pinv = pinv;
-        oa.one = mont_centred(1, fd.p); oa.onep = (i32)((u32)oa.one * pinv);
+        oa.one = base.one; oa.onep = base.onep;
         oa.fin = base.fin; oa.finp = base.finp;
-        if (is16) return launch_2e16(src, dst, oa, batch, pl, st);
-        return launch_one((int)(pl->log1 + pl->log2 - 10), src, dst, oa, batch, pl, st);
+        if (is16) return launch_2e16(fd.p, src, dst, oa, batch, pl, st);
+        return launch_one(cls, (int)(pl->log1 + pl->log2 - 10), src, dst, oa, batch, pl, st);
     }
     const i64 n1 = (i64)1 << pl->log1, n2 = (i64)1 << pl->log2;
     i32 *w = (i32 *)ws;
@@ -870,7 +947,7 @@ int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 
         a.in_stride_c = 1; a.in_stride_t = n2; a.out_stride_c = 1; a.out_stride_t = n2;
         a.in_batch_stride = n; a.out_batch_stride = n;
         a.total_lines = n2;
-        const int rc = launch(pl->log1, src, w, a, batch, pl->net1, pl->mid1, pl->pt0, pl->pratio, st, 1);
+        const int rc = launch(cls, pl->log1, src, w, a, batch, pl->net1, pl->mid1, pl->pt0, pl->pratio, st, 1);
         if (rc) return rc;
     }
     { // pass 2: the n1 rows (contiguous), stored transposed: X[k1 + n1*k2]
@@ -880,7 +957,7 @@ int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 
         a.total_lines = n1;
         a.load_along_line = 1; a.store_along_line = 0;
         const bool in_cache = (size_t)n * (size_t)batch * sizeof(i32) <= ((size_t)256 << 20); // the intermediate fits the Infinity Cache
-        return launch(pl->log2, w, dst, a, batch, pl->net2, pl->mid2, nullptr, nullptr, st, in_cache ? 2 : 0);
+        return launch(cls, pl->log2, w, dst, a, batch, pl->net2, pl->mid2, nullptr, nullptr, st, in_cache ? 2 : 0);
     }
 }
 

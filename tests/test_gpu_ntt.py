@@ -582,14 +582,19 @@ def test_goldilocks_lazy_arithmetic_at_the_extremes(logn):
     assert np.array_equal(back, np.stack(rows))
 
 
-@pytest.mark.parametrize("p,logn", [(28311553, l) for l in range(5, 21)] + [(67043329, l) for l in (5, 9, 10, 11, 13, 16)])
+@pytest.mark.parametrize("p,logn", [(28311553, l) for l in range(5, 21)] + [(67043329, l) for l in (5, 9, 10, 11, 13, 16)]
+                         + [(132120577, l) for l in range(5, 21)] + [(257949697, l) for l in range(5, 21)] + [(531628033, l) for l in range(5, 21)]
+                         + [(q, l) for q in (268369921, 536608769) for l in (5, 8, 10, 11, 14, 16)])
 def test_signed_montgomery_kernel_every_line_shape_at_the_magnitude_limit(p, logn):
-    """gfa_ntt_m32.hip (odd p < 2^26): int32 representatives that are never reduced inside a radix-32 network reach 32 p.
+    """gfa_ntt_m32.hip (odd p < 2^29): int32 representatives that are never reduced inside a radix-32 network reach 32 p.
     28311553 = 27 * 2^20 + 1 covers every line shape up to 2^20 points, 67043329 = 1023 * 2^16 + 1 sits 0.1 % below 2^26.
+    r05 -- one prime per bit length 27, 28, 29 through every line shape (132120577 = 126 * 2^20 + 1, 257949697 = 246 * 2^20 + 1:
+    the BMAX = 8 schedule of gfa_m32_net.h; 531628033 = 507 * 2^20 + 1: BMAX = 4), and the two primes that sit 0.02-0.05 % below
+    2^28 and 2^29 (268369921 = 4095 * 2^16 + 1, 536608769 = 8188 * 2^16 + 1) at the shapes their 2-adicity allows.
     Worst-case rows (all p - 1, alternating 0 / p - 1, an impulse, values within 3 of p) plus random rows, five rows so that
     the single-pass form runs a partly filled tile; forward against the oracle, inverse (1/n folded into the last product)
     as a round trip."""
-    assert ga.is_prime(p) and p < 2**26 and (p - 1) % (1 << logn) == 0
+    assert ga.is_prime(p) and p < 2**29 and (p - 1) % (1 << logn) == 0
     GF = ga.GF(p)
     F = O.OracleField(p, 1, None, int(GF.primitive_element))
     n = 1 << logn
@@ -609,11 +614,12 @@ def test_signed_montgomery_kernel_every_line_shape_at_the_magnitude_limit(p, log
     assert np.array_equal(np.fft.ifft(np.fft.fft(one)).numpy(), rows[3])
 
 
-@pytest.mark.parametrize("p", [7340033, 33292289, 67043329])
+@pytest.mark.parametrize("p", [7340033, 33292289, 67043329, 268369921, 469762049, 536608769])
 def test_2e16_points_in_one_workgroup_over_generic_primes(p):
-    """2^16-point transforms over odd p < 2^25 in batches >= 64 run as ONE pass over HBM (ntt_m32_2e16_kernel: 64 points per
-    thread, radix 64 x 32 x 32).  33292289 = 508 * 2^16 + 1 sits 0.8 % below 2^25, the bound the radix-64 network's growth
-    sets; 67043329 is above it and must keep the two-pass route with identical results.  Worst-case rows (all p - 1,
+    """2^16-point transforms over odd p < 2^29 in batches >= 64 run as ONE pass over HBM (ntt_m32_2e16_kernel: 64 points per
+    thread, radix 64 x 32 x 32).  33292289 = 508 * 2^16 + 1 sits 0.8 % below 2^25, the bound up to which the radix-64 network
+    needs no reduction; above it (67043329, 268369921: the BMAX = 8 schedule; 469762049, 536608769: BMAX = 4) operands are
+    brought back inside the networks where gfa_m32_net.h's bookkeeping says so.  Worst-case rows (all p - 1,
     alternating 0 / p - 1, an impulse, values within 3 of p) against the oracle, every row against the two-pass kernels
     (batches below 64 take those), scaled inverse in place as a round trip, 65 rows so that a persistent workgroup runs a
     second, shorter round."""
@@ -648,6 +654,34 @@ def test_2e16_points_in_one_workgroup_over_generic_primes(p):
         assert torch.equal(out, ref), f"p={p} root w^{j}: one-pass and two-pass kernels differ"
         L.check(lib.gfa_ntt(GF._handle, out.data_ptr(), out.data_ptr(), n, batch, pow(wj, p - 2, p), 1, L.U32, st))
         assert torch.equal(out, xt), f"p={p} inverse, root w^{j}"
+
+
+@pytest.mark.parametrize("p,logn", [(23068673, 21), (132120577, 21), (257949697, 21), (415236097, 22), (377487361, 23), (167772161, 24)])
+def test_three_pass_signed_montgomery_transforms_against_the_oracle(p, logn):
+    """2^21 .. 2^28 points over odd p < 2^29 (r05): three passes of ntt_m32_kernel -- the first with a SPLIT progression table
+    (2^14 .. 2^19 columns), the second in place per row, the third stored transposed.  One prime per class (p < 2^26; BMAX 8; BMAX 4),
+    every output against oracle/gf_oracle.c, the scaled inverse as a round trip, and a batch of two (transforms run one after the
+    other through one work buffer).  2^26 points over GF(469762049): the next test."""
+    import torch
+
+    assert ga.is_prime(p) and (p - 1) % (1 << logn) == 0
+    GF = ga.GF(p)
+    F = O.OracleField(p, 1, None, int(GF.primitive_element))
+    n = 1 << logn
+    omega = GF._root_of_unity_int(n)
+    rng = np.random.default_rng(logn)
+    x = rng.integers(0, p, n, dtype=np.uint32)
+    x[:6] = (p - 1, 0, p - 1, 1, p - 2, p - 1)
+    want = F.ntt_u32_pow2(x, omega)
+    X = np.fft.fft(GF(x))
+    assert np.array_equal(X.numpy(), want)
+    assert np.array_equal(np.fft.ifft(X).numpy(), x)
+    if logn <= 22:
+        worst = np.full(n, p - 1, dtype=np.uint32)
+        two = fft_batched(GF(np.stack([worst, x])))
+        assert np.array_equal(two.numpy()[1], want)
+        assert np.array_equal(two.numpy()[0], F.ntt_u32_pow2(worst, omega))
+        assert np.array_equal(fft_batched(two, inverse=True).numpy(), np.stack([worst, x]))
 
 
 def test_2e26_points_over_a_32_bit_prime_against_the_oracle_in_full():

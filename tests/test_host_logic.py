@@ -339,6 +339,20 @@ def test_field_arithmetic_header_on_the_host(tmp_path, repo_root):
     assert r.returncode == 0 and "fails 0" in r.stdout, r.stdout + r.stderr
 
 
+def test_signed_montgomery_networks_on_the_host_never_leave_int32(tmp_path, repo_root):
+    """galois_amd/csrc/gfa_m32_net.h on the host (r05: primes up to 2^29 on the signed-Montgomery NTT kernels): the SAME network
+    templates the kernels instantiate run on a range-checking integer -- every sum, difference and product operand of every
+    shape (radix 4 .. 64) and prime class (BMAX 64 / 32 / 8 / 4, largest prime of the class) is checked against the int32 range
+    on worst-case inputs, the outputs against a direct DFT (tests/csrc/m32_net_host_test.cpp)."""
+    import subprocess
+
+    exe = str(tmp_path / "m32_net_test")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(repo_root, "galois_amd", "csrc"),
+                    os.path.join(repo_root, "tests", "csrc", "m32_net_host_test.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "m32 networks ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_reed_solomon_table_builders_on_the_host(tmp_path, repo_root):
     """galois_amd/csrc/gfa_rs_host.h on the host: the LFSR row table in consecutive and in planar order, run through a host model
     of rs_lfsr_kernel's state handling and compared with schoolbook division for n - k = 4 .. 64; the decoder's lane tables
