@@ -113,6 +113,11 @@ def GF(*args, irreducible_poly=None, primitive_element=None, verify: bool = True
             raise ValueError(f"Argument 'degree' must be at least 1, not {m}.")
     else:
         raise TypeError("Argument '*args' must be of the form 'order' or 'characteristic, degree'.")
+    if p**m > 2**128 or (p**m == 2**128 and p != 2):  # before any number theory on q - 1 (factoring a 200-bit integer never returns)
+        raise NotImplementedError(
+            f"GF({p}^{m}) has order > 2^128. The reference represents such fields with dtype=object Python integers; the "
+            "device representation of galois_amd stops at two 64-bit limbs per element (GF(2^128) included)."
+        )
     if compile is not None and compile not in ("auto", "jit-lookup", "jit-calculate"):
         raise ValueError(
             f"Argument 'compile' must be in ['auto', 'jit-lookup', 'jit-calculate'], not {compile!r} "
@@ -194,10 +199,10 @@ def _default_primitive_element(irr_int: int, p: int, verify_poly: bool) -> int:
 
 def _make_class(p: int, m: int, irr_int: int, alpha: int, is_primitive_poly: bool, prime_subfield) -> type:
     order = p**m
-    if order >= 2**128:
+    if order > 2**128 or (order == 2**128 and p != 2):
         raise NotImplementedError(
-            f"GF({p}^{m}) has order >= 2^128. The reference represents such fields with dtype=object Python integers; the "
-            "device representation of galois_amd stops at two 64-bit limbs per element."
+            f"GF({p}^{m}) has order > 2^128. The reference represents such fields with dtype=object Python integers; the "
+            "device representation of galois_amd stops at two 64-bit limbs per element (GF(2^128) included)."
         )
     if order >= 2**64:
         return _make_wide_class(p, m, irr_int, alpha, is_primitive_poly, prime_subfield)
@@ -232,7 +237,7 @@ def _make_class(p: int, m: int, irr_int: int, alpha: int, is_primitive_poly: boo
 
 
 def _make_wide_class(p: int, m: int, irr_int: int, alpha: int, is_primitive_poly: bool, prime_subfield) -> type:
-    """2^64 <= order < 2^128: two 64-bit limbs per element on the device (galois_amd/_wide.py, csrc/gfa_wide.hip)."""
+    """2^64 <= order <= 2^128: two 64-bit limbs per element on the device (galois_amd/_wide.py, csrc/gfa_wide.hip)."""
     from ._wide import WideFieldArray, wide_params
 
     kind, words = wide_params(p, m, irr_int)

@@ -61,6 +61,9 @@ SIGNATURES = {
     "gfa_wide_reduce": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "gfa_wide_convolve": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p]),
     "gfa_wide_matmul": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_void_p]),
+    "gfa_wide_row_reduce": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_void_p, c_void_p]),
+    "gfa_wide_plu_decompose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gfa_wide_poly_evaluate": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p]),
     "gfa_ntt_chunked": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_u64, c_int, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_void_p]),
     "gfa_ntt_dist": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_i64, c_i64, c_u64, c_int, c_void_p]),
     "gfa_intt_dist": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_i64, c_i64, c_u64, c_int, c_int, c_void_p]),

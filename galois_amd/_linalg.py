@@ -150,13 +150,30 @@ def outer(a: FieldArray, b: FieldArray) -> FieldArray:
 
 
 # ---- elimination-based routines --------------------------------------------------------------------------------------
-def _row_reduce_t(cls, t: torch.Tensor, ncols: int, gfa_dtype: int):
+# Tensors below carry ONE entry per field element: the storage tensor itself, or -- for the two-limb fields of order >= 2^64 --
+# its complex128 view (a bit container for the limb pair: moved, never computed on; galois_amd/_wide.py).
+def _elems(A: FieldArray) -> torch.Tensor:
+    return A._af_tens(A) if type(A)._limbed else A._t
+
+
+def _rewrap(A: FieldArray, t: torch.Tensor) -> FieldArray:
+    return A._af_wrap(t) if type(A)._limbed else type(A)._wrap(t, A._np_dtype)
+
+
+def _dtype_code(A: FieldArray):
+    return None if type(A)._limbed else A._gfa_dtype()
+
+
+def _row_reduce_t(cls, t: torch.Tensor, ncols: int, gfa_dtype):
     """In-place Gauss-Jordan on a contiguous (batch, m, n) tensor; returns the per-matrix pivot counts (device int64)."""
     batch, m, n = t.shape
     ranks = torch.zeros(batch, dtype=torch.int64, device=t.device)
     if batch and m and n:
-        L.check(L.lib().gfa_row_reduce(cls._handle, _ptr(t), batch, m, n, ncols, _ptr(ranks), gfa_dtype, _stream()),
-                "gfa_row_reduce")
+        if cls._limbed:
+            L.check(L.lib().gfa_wide_row_reduce(cls._wide_handle, _ptr(t), batch, m, n, ncols, _ptr(ranks), _stream()), "gfa_wide_row_reduce")
+        else:
+            L.check(L.lib().gfa_row_reduce(cls._handle, _ptr(t), batch, m, n, ncols, _ptr(ranks), gfa_dtype, _stream()),
+                    "gfa_row_reduce")
     return ranks
 
 
@@ -167,23 +184,24 @@ def row_reduce(A: FieldArray, ncols: int | None = None, eye: str = "left") -> Fi
     if not A.ndim == 2:
         raise ValueError(f"Only 2-D matrices can be converted to reduced row echelon form, not {A.ndim}-D.")
     cls = type(A)
-    t = A._t
+    t = _elems(A)
     if eye == "right":
         t = torch.flip(t, dims=(0, 1))
     t = t.contiguous().clone().reshape(1, *t.shape)
     ncols = t.shape[2] if ncols is None else int(ncols)
-    _row_reduce_t(cls, t, ncols, A._gfa_dtype())
+    _row_reduce_t(cls, t, ncols, _dtype_code(A))
     t = t[0]
     if eye == "right":
         t = torch.flip(t, dims=(0, 1)).contiguous()
-    return cls._wrap(t, A._np_dtype)
+    return _rewrap(A, t)
 
 
 def _row_reduce_with_rank(A: FieldArray, ncols: int | None = None):
     cls = type(A)
-    t = A._t.contiguous().clone().reshape(1, *A._t.shape)
-    ranks = _row_reduce_t(cls, t, t.shape[2] if ncols is None else int(ncols), A._gfa_dtype())
-    return cls._wrap(t[0], A._np_dtype), int(ranks[0].item())
+    t0 = _elems(A)
+    t = t0.contiguous().clone().reshape(1, *t0.shape)
+    ranks = _row_reduce_t(cls, t, t.shape[2] if ncols is None else int(ncols), _dtype_code(A))
+    return _rewrap(A, t[0]), int(ranks[0].item())
 
 
 def row_reduce_batched(A: FieldArray, ncols: int | None = None):
@@ -192,14 +210,14 @@ def row_reduce_batched(A: FieldArray, ncols: int | None = None):
     if not A.ndim == 3:
         raise ValueError(f"row_reduce_batched expects a 3-D stack of matrices, not {A.ndim}-D.")
     cls = type(A)
-    t = A._t.contiguous().clone()
-    ranks = _row_reduce_t(cls, t, t.shape[2] if ncols is None else int(ncols), A._gfa_dtype())
-    return cls._wrap(t, A._np_dtype), ranks.cpu().numpy()
+    t = _elems(A).contiguous().clone()
+    ranks = _row_reduce_t(cls, t, t.shape[2] if ncols is None else int(ncols), _dtype_code(A))
+    return _rewrap(A, t), ranks.cpu().numpy()
 
 
 def _plu(A: FieldArray, pivoting: bool, want_l: bool = True, want_p: bool = True, want_det: bool = False):
     cls = type(A)
-    t = A._t.contiguous().clone()
+    t = _elems(A).contiguous().clone()
     batched = t.dim() == 3
     if not batched:
         t = t.reshape(1, *t.shape)
@@ -209,9 +227,14 @@ def _plu(A: FieldArray, pivoting: bool, want_l: bool = True, want_p: bool = True
     nperm = torch.zeros(batch, dtype=torch.int64, device=t.device)
     det = torch.empty(batch, dtype=t.dtype, device=t.device) if want_det else None
     err = torch.zeros(1, dtype=torch.int32, device=t.device)
-    L.check(L.lib().gfa_plu_decompose(cls._handle, _ptr(t), _ptr(lo) if want_l else None, _ptr(po) if want_p else None, batch,
-                                      m, n, 1 if pivoting else 0, _ptr(nperm), _ptr(det) if want_det else None,
-                                      A._gfa_dtype(), _stream(), _ptr(err)), "gfa_plu_decompose")
+    if cls._limbed:
+        L.check(L.lib().gfa_wide_plu_decompose(cls._wide_handle, _ptr(t), _ptr(lo) if want_l else None, _ptr(po) if want_p else None, batch,
+                                               m, n, 1 if pivoting else 0, _ptr(nperm), _ptr(det) if want_det else None, _stream(), _ptr(err)),
+                "gfa_wide_plu_decompose")
+    else:
+        L.check(L.lib().gfa_plu_decompose(cls._handle, _ptr(t), _ptr(lo) if want_l else None, _ptr(po) if want_p else None, batch,
+                                          m, n, 1 if pivoting else 0, _ptr(nperm), _ptr(det) if want_det else None,
+                                          A._gfa_dtype(), _stream(), _ptr(err)), "gfa_plu_decompose")
     if not pivoting and int(err.item()) & L.DEVERR_NO_LU:
         raise ValueError("The LU decomposition of 'A' does not exist. Use the PLU decomposition instead.")
     return t, lo, po, nperm, det, batched
@@ -224,18 +247,16 @@ def lu_decompose(A: FieldArray):
     m, n = A.shape
     if m - 1 > n:
         raise IndexError(f"index {n} is out of bounds for axis 1 with size {n}")  # what Ai[i, i] raises in the reference
-    cls = type(A)
     u, lo, _, _, _, _ = _plu(A, pivoting=False, want_p=False)
-    return cls._wrap(lo[0], A._np_dtype), cls._wrap(u[0], A._np_dtype)
+    return _rewrap(A, lo[0]), _rewrap(A, u[0])
 
 
 def plu_decompose(A: FieldArray):
     """FieldArray.plu_decompose (_fields/_array.py:1504-1538) over plu_decompose_jit (_linalg.py:387-424)."""
     if not A.ndim == 2:
         raise ValueError(f"Argument 'A' must be a 2-D matrix, not have shape {tuple(A.shape)}.")
-    cls = type(A)
     u, lo, po, _, _, _ = _plu(A, pivoting=True)
-    return (cls._wrap(po[0].t().contiguous(), A._np_dtype), cls._wrap(lo[0], A._np_dtype), cls._wrap(u[0], A._np_dtype))
+    return (_rewrap(A, po[0].t().contiguous()), _rewrap(A, lo[0]), _rewrap(A, u[0]))
 
 
 def det(A: FieldArray) -> FieldArray:
@@ -244,18 +265,17 @@ def det(A: FieldArray) -> FieldArray:
         raise np.linalg.LinAlgError(f"Argument 'A' must be square, not {tuple(A.shape)}.")
     cls = type(A)
     if A.shape[0] == 0:
-        return cls._wrap(torch.ones((), dtype=A._t.dtype, device=A._t.device), A._np_dtype)
+        return cls.Ones(()) if cls._limbed else cls._wrap(torch.ones((), dtype=A._t.dtype, device=A._t.device), A._np_dtype)
     _, _, _, _, d, _ = _plu(A, pivoting=True, want_l=False, want_p=False, want_det=True)
-    return cls._wrap(d[0], A._np_dtype)
+    return _rewrap(A, d[0])
 
 
 def det_batched(A: FieldArray) -> FieldArray:
     """Device extension: determinants of a (batch, n, n) stack in one launch."""
     if not (A.ndim == 3 and A.shape[1] == A.shape[2]):
         raise np.linalg.LinAlgError(f"Argument 'A' must be a stack of square matrices, not {tuple(A.shape)}.")
-    cls = type(A)
     _, _, _, _, d, _ = _plu(A, pivoting=True, want_l=False, want_p=False, want_det=True)
-    return cls._wrap(d, A._np_dtype)
+    return _rewrap(A, d)
 
 
 def matrix_rank(A: FieldArray) -> int:
@@ -266,8 +286,14 @@ def matrix_rank(A: FieldArray) -> int:
 
 
 def _augment_identity(A: FieldArray) -> torch.Tensor:
-    t = A._t
-    eye = torch.eye(t.shape[-2], dtype=t.dtype, device=t.device)
+    t = _elems(A)
+    if type(A)._limbed:  # the element 1 is the limb pair (1, 0): built as limbs, then viewed like the rest
+        n = t.shape[-2]
+        limbs = torch.zeros((n, n, 2), dtype=torch.int64, device=t.device)
+        limbs[torch.arange(n), torch.arange(n), 0] = 1
+        eye = limbs.view(torch.complex128).squeeze(-1)
+    else:
+        eye = torch.eye(t.shape[-2], dtype=t.dtype, device=t.device)
     if t.dim() == 3:
         eye = eye.expand(t.shape[0], -1, -1)
     return torch.cat([t, eye], dim=-1).contiguous()
@@ -280,13 +306,13 @@ def inv(A: FieldArray) -> FieldArray:
     cls = type(A)
     n = A.shape[0]
     ai = _augment_identity(A).reshape(1, n, 2 * n)
-    ranks = _row_reduce_t(cls, ai, n, A._gfa_dtype())
+    ranks = _row_reduce_t(cls, ai, n, _dtype_code(A))
     rank = int(ranks[0].item())
     if not rank == n:
         raise np.linalg.LinAlgError(
             f"Argument 'A' is singular and not invertible because it does not have full rank of {n}, but rank of {rank}."
         )
-    return cls._wrap(ai[0, :, n:].contiguous(), A._np_dtype)
+    return _rewrap(A, ai[0, :, n:].contiguous())
 
 
 def inv_batched(A: FieldArray) -> FieldArray:
@@ -296,11 +322,11 @@ def inv_batched(A: FieldArray) -> FieldArray:
     cls = type(A)
     n = A.shape[1]
     ai = _augment_identity(A)
-    ranks = _row_reduce_t(cls, ai, n, A._gfa_dtype())
+    ranks = _row_reduce_t(cls, ai, n, _dtype_code(A))
     if not bool((ranks == n).all()):
         bad = int((ranks != n).nonzero()[0].item())
         raise np.linalg.LinAlgError(f"Matrix {bad} of the stack is singular and not invertible.")
-    return cls._wrap(ai[:, :, n:].contiguous(), A._np_dtype)
+    return _rewrap(A, ai[:, :, n:].contiguous())
 
 
 def solve(A: FieldArray, b: FieldArray) -> FieldArray:
@@ -338,8 +364,8 @@ def left_null_space(A: FieldArray) -> FieldArray:
     cls = type(A)
     m, n = A.shape
     ai = _augment_identity(A).reshape(1, m, n + m)
-    p = int(_row_reduce_t(cls, ai, n, A._gfa_dtype())[0].item())
-    ln = cls._wrap(ai[0, p:, n:].contiguous(), A._np_dtype)
+    p = int(_row_reduce_t(cls, ai, n, _dtype_code(A))[0].item())
+    ln = _rewrap(A, ai[0, p:, n:].contiguous())
     if ln.shape[0] == 0:
         return ln
     return row_reduce(ln)

@@ -29,6 +29,8 @@ def _field_fft(x: FieldArray, n=None, axis=-1, norm=None, inverse: bool = False)
     if x.ndim != 1:
         raise ValueError("The FFT is only implemented on 1-D arrays.")
     scale = norm == ("backward" if inverse else "forward")
+    if type(x)._limbed:  # order >= 2^64: mixed-radix recursion on the two-limb kernels (galois_amd/_wide.py)
+        return x._fft(n, inverse, scale)
     return _transform_rows(x, n, inverse, scale)
 
 

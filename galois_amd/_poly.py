@@ -39,13 +39,13 @@ class Poly:
         if c.ndim != 1 or c.size == 0:
             raise ValueError(f"Argument 'coeffs' must be a non-empty 1-D array, not shape {tuple(c.shape)}.")
         if order == "asc":
-            c = type(c)._wrap(torch.flip(c._t, dims=(0,)), c._np_dtype)
+            c = np.flip(c)
         self._field = type(c)
         self._coeffs = self._trim(c)
 
     @staticmethod
     def _trim(c: FieldArray) -> FieldArray:
-        nz = torch.nonzero(c._t)
+        nz = torch.nonzero(c._t.reshape(c.size, -1).any(dim=1))  # (fields of order >= 2^64: two limbs per element)
         if nz.numel() == 0:
             return c[-1:] if c.size else c
         return c[int(nz[0].item()):]
@@ -69,6 +69,16 @@ class Poly:
     def __call__(self, x, elementwise: bool = True):
         F = self._field
         xa = x if isinstance(x, FieldArray) and type(x) is F else F(x)
+        if F._limbed:  # order >= 2^64: two-limb kernels (gfa_wide_poly_evaluate; matrix Horner on gfa_wide_matmul)
+            if elementwise:
+                return self._coeffs._poly_evaluate(xa)
+            if not (xa.ndim == 2 and xa.shape[0] == xa.shape[1]):
+                raise ValueError(f"Argument 'x' must be a square matrix when evaluating the polynomial not element-wise, not shape {tuple(xa.shape)}.")
+            eye = F.Identity(xa.shape[0])
+            acc = eye * self._coeffs[0]
+            for j in range(1, self._coeffs.size):
+                acc = acc @ xa + eye * self._coeffs[j]
+            return acc
         c = xa._same_storage(self._coeffs).contiguous()
         if elementwise:
             t = xa._t.contiguous()
@@ -100,6 +110,9 @@ class Poly:
         a, b = self._coeffs, other._coeffs
         n = max(a.size, b.size)
         F = self._field
+        if F._limbed:
+            pad = lambda v: np.concatenate([F.Zeros(n - v.size), v]) if v.size < n else v
+            return pad(a), pad(b)
         ta = torch.zeros(n, dtype=a._t.dtype, device=a._t.device)
         tb = torch.zeros(n, dtype=a._t.dtype, device=a._t.device)
         ta[n - a.size:] = a._t

@@ -35,8 +35,8 @@ def wide_params(p: int, m: int, irr_int: int) -> tuple[int, list[int]]:
         w[3], w[4] = r2 & _M64, r2 >> 64
         w[5], w[6] = (p - 2) & _M64, (p - 2) >> 64
     elif p == 2:
-        if m > 127:
-            raise NotImplementedError(f"GF(2^{m}): binary fields are supported up to degree 127.")
+        if m > 128:
+            raise NotImplementedError(f"GF(2^{m}): binary fields are supported up to degree 128.")
         kind = 2
         w[0] = 2
         w[5], w[6] = (q - 2) & _M64, (q - 2) >> 64
@@ -216,6 +216,12 @@ class WideFieldArray(FieldArray):
         return z
 
     @classmethod
+    def Identity(cls, size: int, dtype=None):
+        z = cls.Zeros((size, size))
+        z._t[torch.arange(size), torch.arange(size), 0] = 1
+        return z
+
+    @classmethod
     def Random(cls, shape=(), low: int = 0, high=None, seed=None, dtype=None):
         """Uniform in [low, high) from Python's `random` seeded like the reference's object-dtype path
         (_domains/_array.py:287-298 uses random.randint per element)."""
@@ -315,10 +321,289 @@ class WideFieldArray(FieldArray):
     def _af_wrap(self, c: torch.Tensor):
         return type(self)._wrap(torch.view_as_real(c.contiguous()).view(torch.int64))
 
-    def _unsupported(self, *a, **k):
-        raise NotImplementedError(f"This operation is not implemented for {type(self).name} (order >= 2^64): element-wise ufuncs only.")
+    # ---- ufunc.reduceat / ufunc.at: composed from the fold and the element-wise kernels (the reference runs them as object-dtype
+    # loops over the same scalar functions, _domains/_ufunc.py:686-689) ----
+    def _reduceat(self, op, indices, axis):
+        idx = np.asarray(indices)
+        if idx.ndim != 1 or not np.issubdtype(idx.dtype, np.integer):
+            raise TypeError("Argument 'indices' of reduceat must be a 1-D integer array.")
+        if self.ndim == 0:
+            raise TypeError("cannot reduceat on a scalar")
+        axis = axis % self.ndim
+        n = self.shape[axis]
+        if idx.size and (idx.min() < 0 or idx.max() >= n):
+            raise IndexError(f"index {int(idx.max() if idx.max() >= n else idx.min())} out-of-bounds in reduceat [0, {n})")
+        c = self._af_tens(self).movedim(axis, -1)
+        ends = np.concatenate([idx[1:], [n]])
+        pieces = []
+        for s0, e0 in zip(idx.tolist(), ends.tolist()):
+            if e0 > s0 + 1:
+                pieces.append(self._af_tens(self._af_wrap(c[..., s0:e0].contiguous())._reduce(op, -1, False)))
+            else:  # an empty or reversed slice yields a[indices[i]]
+                pieces.append(c[..., s0])
+        return self._af_wrap(torch.stack(pieces, dim=-1).movedim(-1, axis).contiguous())
 
-    _reduceat = _at = _sqrt = log = _unsupported
+    def _at(self, ufunc, indices, values):
+        cls = type(self)
+        idx = np.asarray(indices)
+        if idx.dtype == bool or not np.issubdtype(idx.dtype, np.integer):
+            raise TypeError("Argument 'indices' of ufunc.at must be an integer array (flat indices of a 1-D array or the first axis).")
+        if self.ndim != 1:
+            raise NotImplementedError("ufunc.at is implemented for 1-D field arrays.")
+        n = self.shape[0]
+        flat = idx.ravel().astype(np.int64)
+        flat = np.where(flat < 0, flat + n, flat)
+        if flat.size and (flat.min() < 0 or flat.max() >= n):
+            raise IndexError(f"index out of bounds for axis 0 with size {n}")
+        vals = None
+        if values is not None:
+            if ufunc is np.power or (ufunc is np.multiply and not isinstance(values, FieldArray)):
+                vals = np.broadcast_to(np.asarray(values, dtype=object), idx.shape).ravel()
+            else:
+                v = values if isinstance(values, cls) else cls(values)
+                vals = self._af_wrap(self._af_tens(v).broadcast_to(idx.shape).reshape(-1).contiguous())
+        order = np.argsort(flat, kind="stable")
+        sorted_idx = flat[order]
+        group_start = np.r_[0, np.nonzero(np.diff(sorted_idx))[0] + 1] if flat.size else np.zeros(0, dtype=np.int64)
+        occ_sorted = np.arange(flat.size) - np.repeat(group_start, np.diff(np.r_[group_start, flat.size]))
+        occ = np.empty(flat.size, dtype=np.int64)
+        occ[order] = occ_sorted
+        for r in range(int(occ.max()) + 1 if flat.size else 0):  # round r: the r-th occurrence of every index (all distinct)
+            sel = np.nonzero(occ == r)[0]
+            ti = torch.from_numpy(flat[sel]).to(self._t.device)
+            cur = cls._wrap(self._t[ti])
+            if values is None:
+                new = ufunc(cur)
+            elif isinstance(vals, FieldArray):
+                new = ufunc(cur, cls._wrap(vals._t[torch.from_numpy(sel).to(self._t.device)]))
+            else:
+                new = ufunc(cur, vals[sel])
+            self._t[ti] = new._t
+        return None
+
+    # ---- squares and square roots (is_square: _fields/_array.py:1340-1410; sqrt: _domains/_calculate.py:758-832, the same
+    # formulas as FieldArray._sqrt on the two-limb power kernel) ----
+    def _eq_int(self, value: int) -> torch.Tensor:
+        """Device bool mask: element == value (limb-wise)."""
+        lim = torch.tensor([value & _M64, value >> 64], dtype=torch.uint64).view(torch.int64).to(self._t.device)
+        return (self._t == lim).all(dim=-1)
+
+    def _select(self, mask: torch.Tensor, a: "WideFieldArray", b: "WideFieldArray") -> "WideFieldArray":
+        return type(self)._wrap(torch.where(mask.unsqueeze(-1), a._t, b._t))
+
+    def is_square(self):
+        cls = type(self)
+        if cls._characteristic == 2:
+            r = np.ones(tuple(self.shape), dtype=bool)
+        else:
+            w = self._with_int((cls._order - 1) // 2, is_pow=True)
+            r = (w._eq_int(1) | self._eq_int(0)).cpu().numpy()
+        return bool(r) if r.ndim == 0 else r
+
+    def _sqrt(self):
+        """The formulas of FieldArray._sqrt (galois_amd/_array.py; reference _domains/_calculate.py:758-832) on two-limb elements."""
+        cls = type(self)
+        p, q = cls._characteristic, cls._order
+        if p == 2:
+            return self._with_int(2 ** (cls._degree - 1), is_pow=True)
+        sq = self.is_square()
+        if not np.all(sq):
+            bad = self.numpy()[~np.asarray(sq)] if self.ndim else self.numpy()
+            raise ArithmeticError(f"Input array has elements that are non-squares in {cls.name}.\n{bad}")
+        zero = cls.Zeros(tuple(self.shape))
+        if q % 4 == 3:
+            roots = self._with_int((q + 1) // 4, is_pow=True)
+        elif q % 8 == 5:
+            d = self._with_int((q - 1) // 4, is_pow=True)
+            r1 = self._with_int((q + 3) // 8, is_pow=True)
+            four_a = self._with_int(4, is_pow=False)
+            r2 = self._with_int(2, is_pow=False) * four_a._with_int((q - 5) // 8, is_pow=True)
+            roots = self._select(d._eq_int(1), r1, self._select(d._eq_int(p - 1), r2, zero))
+        else:
+            # Tonelli-Shanks with a fixed non-square b (any non-square gives the same final min(root, -root))
+            b = 2
+            while cls(np.array(b, dtype=object)).is_square():
+                b += 1
+            n, s_ = q - 1, 0
+            while n % 2 == 0:
+                n >>= 1
+                s_ += 1
+            nz = ~self._eq_int(0)
+            safe = self._select(nz, self, cls.Ones(tuple(self.shape)))
+            a_inv = np.reciprocal(safe)
+            c = cls(np.array(b, dtype=object))._with_int(n, is_pow=True)
+            r = safe._with_int((n + 1) // 2, is_pow=True)
+            for i in range(1, s_):
+                dd = (r * r * a_inv)._with_int(2 ** (s_ - i - 1), is_pow=True)
+                r = self._select(dd._eq_int(p - 1), r * c, r)
+                c = c * c
+            roots = self._select(nz, r, zero)
+        neg = np.negative(roots)
+        # np.minimum(roots, -roots) on the integer values: compare (hi, lo) as unsigned
+        def ukey(t):
+            return t ^ torch.iinfo(torch.int64).min
+        rh, rl, nh, nl = ukey(roots._t[..., 1]), ukey(roots._t[..., 0]), ukey(neg._t[..., 1]), ukey(neg._t[..., 0])
+        neg_smaller = (nh < rh) | ((nh == rh) & (nl < rl))
+        return self._select(neg_smaller, neg, roots)
+
+    # ---- discrete logarithm: Pohlig-Hellman over the factorisation of q - 1 with baby-step / giant-step inside each prime
+    # factor (the reference: log_pohlig_hellman, _domains/_calculate.py:700-755, on Python integers; any correct algorithm returns
+    # the same unique i in [0, q - 1)).  Field arithmetic runs in the two-limb kernels on whole arrays; the host keeps the
+    # bookkeeping integers (exponents, the CRT) and torch sorts / searches the baby-step keys. ----
+    @classmethod
+    def _log_tables(cls, base_int: int):
+        cache = cls.__dict__.get("_log_cache")
+        if cache is None:
+            cache = {}
+            cls._log_cache = cache
+        if base_int in cache:
+            return cache[base_int]
+        from . import _numtheory as nt
+
+        primes, mults = nt.factors(cls._order - 1)
+        if max(primes) > 2**44:
+            raise NotImplementedError(f"np.log over {cls.name}: q - 1 has the prime factor {max(primes)} (baby-step tables beyond 2^22 entries).")
+        g = cls(np.array(base_int, dtype=object))
+        tabs = []
+        for r, e in zip(primes, mults):
+            gamma = g._with_int((cls._order - 1) // r, is_pow=True)  # order r
+            m = int(np.ceil(np.sqrt(r)))
+            baby = gamma.reshape(()) ** np.array(list(range(m)), dtype=object)      # gamma^j
+            lo = baby._t[:, 0]
+            order = torch.argsort(lo, stable=True)
+            giant = np.reciprocal(gamma._with_int(m, is_pow=True))                   # gamma^-m
+            gpow = giant.reshape(()) ** np.array(list(range(m + 1)), dtype=object)  # gamma^(-m i)
+            tabs.append((r, e, m, baby._t[order].contiguous(), order, gpow))
+        cache[base_int] = (primes, mults, tabs)
+        return cache[base_int]
+
+    def log(self, base=None):
+        cls = type(self)
+        q1 = cls._order - 1
+        if base is not None:
+            b = base if isinstance(base, cls) else cls(base)
+            if b.size != 1:
+                raise NotImplementedError(f"np.log over {cls.name} takes one base for the whole array.")
+            base_int = int(b)
+            from . import _numtheory as nt
+
+            primes, _ = nt.factors(q1)
+            if base_int == 0 or any(int(b.reshape(()) ** (q1 // r)) == 1 for r in primes):
+                raise ArithmeticError("The specified logarithm base is not a primitive element of the Galois field.")
+        else:
+            base_int = cls._primitive_element_int
+        x = self.reshape(-1)
+        n = x.size
+        if n and bool(x._eq_int(0).any()):
+            raise ArithmeticError("Cannot compute the discrete logarithm of 0 in a Galois field.")
+        primes, mults, tabs = cls._log_tables(base_int)
+        g = cls(np.array(base_int, dtype=object))
+        residues = []  # per prime power: (modulus, list of n residues)
+        for r, e, m, baby_sorted, order, gpow in tabs:
+            xk = [0] * n
+            cur = x  # x * g^(-xk) as digits are found
+            for k in range(e):
+                h = cur._with_int(q1 // r ** (k + 1), is_pow=True)  # in the subgroup of order r: h = gamma^(digit)
+                digit = self._bsgs(h, m, baby_sorted, order, gpow, r)
+                for i in range(n):
+                    xk[i] += digit[i] * r**k
+                if k + 1 < e:
+                    corr = g.reshape(()) ** np.array([-(d * r**k) % q1 for d in digit], dtype=object)
+                    cur = cur * corr
+            residues.append((r**e, xk))
+        out = np.empty(n, dtype=object)
+        for i in range(n):
+            acc, mod = 0, 1
+            for modulus, xs in residues:  # CRT, one prime power at a time
+                t = ((xs[i] - acc) * pow(mod, -1, modulus)) % modulus
+                acc, mod = acc + mod * t, mod * modulus
+            out[i] = acc % q1
+        out = out.reshape(self.shape)
+        return int(out) if out.ndim == 0 else out
+
+    def _bsgs(self, h: "WideFieldArray", m: int, baby_sorted: torch.Tensor, order: torch.Tensor, gpow: "WideFieldArray", r: int):
+        """digit[i] with gamma^digit[i] == h[i], 0 <= digit < r: h * gamma^(-m a) is looked up among the m baby steps gamma^j."""
+        n = h.size
+        digits = [None] * n
+        chunk = max(1, (1 << 22) // (m + 1))
+        keys = baby_sorted[:, 0].contiguous()
+        for s0 in range(0, n, chunk):
+            hs = type(self)._wrap(h._t[s0:s0 + chunk])
+            prod = hs.reshape((hs.size, 1)) * gpow.reshape((1, m + 1))  # (rows, m + 1): h * gamma^(-m a)
+            lo, hi = prod._t[..., 0].contiguous(), prod._t[..., 1]
+            pos = torch.searchsorted(keys, lo).clamp(max=m - 1)
+            hit = torch.zeros_like(lo, dtype=torch.bool)
+            jidx = torch.zeros_like(lo)
+            for probe in range(4):  # equal low limbs among the baby steps are astronomically rare; four neighbours are searched anyway
+                pp = (pos + probe).clamp(max=m - 1)
+                ok = (baby_sorted[pp, 0] == lo) & (baby_sorted[pp, 1] == hi) & ~hit
+                jidx = torch.where(ok, order[pp], jidx)
+                hit |= ok
+            hit_c, j_c = hit.cpu().numpy(), jidx.cpu().numpy()
+            for i in range(hs.size):
+                a = np.flatnonzero(hit_c[i])
+                if a.size == 0:
+                    raise ArithmeticError("np.log: element outside the subgroup generated by the base (is the base primitive?)")
+                digits[s0 + i] = (int(a[0]) * m + int(j_c[i, a[0]])) % r
+        return digits
+
+    # ---- np.fft.fft / ifft: the mixed-radix Cooley-Tukey recursion over the prime factors of n on whole-array kernels (matrix
+    # product with the r x r DFT matrix, twiddle product), fft_jit.implementation (_domains/_function.py:246-384) computes the same
+    # DFT with the same root of unity ----
+    def _dft(self, omega: "WideFieldArray", n: int) -> "WideFieldArray":
+        """X[k] = sum_j x[j] omega^(j k) along the LAST axis of a (..., n) array."""
+        from . import _numtheory as nt
+        from . import _linalg
+
+        cls = type(self)
+        if n == 1:
+            return self
+        primes, mults = nt.factors(n)
+        r = int(primes[0])
+        m = n // r
+        lead = tuple(self.shape[:-1])
+        # j = j1 * m + j2 (j1 < r), k = k1 + r * k2 (k1 < r): X[k] = sum_j2 [ (sum_j1 x[j1, j2] w_r^(j1 k1)) omega^(j2 k1) ] (omega^r)^(j2 k2)
+        x2 = self.reshape(lead + (r, m))
+        wr = omega ** m
+        obj = lambda a: np.array([int(v) for v in np.ravel(a)], dtype=object).reshape(np.shape(a))
+        F = wr.reshape(()) ** obj(np.outer(np.arange(r), np.arange(r)) % r)       # F[k1, j1] = w_r^(j1 k1)
+        y = _linalg.matmul(F, x2)                                                  # (..., k1, j2)
+        if m > 1:
+            tw = omega.reshape(()) ** obj(np.outer(np.arange(r), np.arange(m)))    # omega^(k1 j2)
+            y = y * tw
+            y = y._dft(omega ** r, m)                                              # along j2 -> k2: (..., k1, k2)
+        # output index k1 + r * k2: transpose the last two axes
+        c = self._af_tens(y)
+        return self._af_wrap(c.transpose(-1, -2).contiguous().reshape(lead + (n,)))
+
+    def _fft(self, n, inverse: bool, scale: bool) -> "WideFieldArray":
+        cls = type(self)
+        if self.ndim != 1:
+            raise ValueError("The FFT is only implemented on 1-D arrays.")
+        length = self.size
+        n = length if n is None else int(n)
+        c = self._af_tens(self)
+        if n < length:
+            c = c[:n]
+        elif n > length:
+            c = torch.cat([c, self._af_tens(cls.Zeros(n - length))])
+        x = self._af_wrap(c.contiguous())
+        omega = cls(np.array(int(cls.primitive_root_of_unity(n)), dtype=object))  # ValueError if n does not divide q - 1
+        if inverse:
+            omega = np.reciprocal(omega)
+        y = x._dft(omega, n)
+        if scale:
+            y = y / cls(np.array(n % cls._characteristic, dtype=object))
+        return y
+
+    def _poly_evaluate(self, x: "WideFieldArray") -> "WideFieldArray":
+        """Horner evaluation of the polynomial whose coefficients (descending degree) are this 1-D array, at every element of x."""
+        cls = type(self)
+        co = self._t.contiguous()
+        xt = x._t.contiguous()
+        out = torch.empty_like(xt)
+        L.check(L.lib().gfa_wide_poly_evaluate(cls._wide_handle, _ptr(co), self.size, _ptr(xt), _ptr(out), x.size, _stream()), "gfa_wide_poly_evaluate")
+        return cls._wrap(out)
 
     # ---- ufunc.reduce / accumulate, np.convolve, @ : the reference runs them as object-dtype loops over the same scalar
     # kernels (_fields/_ufunc.py:36-48, _domains/_function.py:141-167, _domains/_linalg.py:286-308) ----

@@ -399,6 +399,154 @@ __global__ __launch_bounds__(256) void wide_matmul_kernel(WField f, const u64 *_
     wstore(out, idx, acc);
 }
 
+// ---------------------------------------------------------------- elimination and Horner (r05)
+// The reference runs row_reduce / lu / plu / det / inv / solve and polynomial evaluation on these fields as object-dtype loops over
+// the same scalar kernels (_domains/_linalg.py:315-424, 447-548; _polys/_dense.py:404-440).  One workgroup per matrix, the pivot
+// rule, the swap order and the L / P conventions of gfa_linalg.hip's kernels (which follow the reference line by line); matrices are
+// small (the Sage fixtures: up to 6 x 6) and an inversion is an exponentiation, so nothing here is tuned.
+constexpr int WGJ_THREADS = 256;
+
+__device__ __forceinline__ bool w_nonzero(const u64 *A, i64 i) { return (A[2 * i] | A[2 * i + 1]) != 0; }
+
+// row_reduce_jit (_linalg.py:315-351).  A: (batch, m, n) in place; rank_out[b] = number of pivots found in the first ncols columns.
+__global__ __launch_bounds__(WGJ_THREADS) void wide_row_reduce_kernel(WField f, u64 *__restrict__ Aall, int m, int n, int ncols, i64 *__restrict__ rank_out)
+{
+    __shared__ int piv_row;
+    __shared__ W128 piv_inv;
+    u64 *A = Aall + 2 * (i64)blockIdx.x * m * n;
+    int p = 0;
+    for (int j = 0; j < ncols && p < m; j++) {
+        if (threadIdx.x == 0) piv_row = m;
+        __syncthreads();
+        for (int i = p + threadIdx.x; i < m; i += WGJ_THREADS)
+            if (w_nonzero(A, (i64)i * n + j)) { atomicMin(&piv_row, i); break; }
+        __syncthreads();
+        const int pr = piv_row;
+        if (pr == m) { __syncthreads(); continue; }
+        if (threadIdx.x == 0) piv_inv = wf_inv(f, wload(A, (i64)pr * n + j));
+        __syncthreads();
+        const W128 inv = piv_inv;
+        for (int c = threadIdx.x; c < n; c += WGJ_THREADS) { // swap rows p and pr, the pivot row scaled to a leading 1
+            const W128 top = wload(A, (i64)p * n + c);
+            const W128 piv = wf_mul(f, wload(A, (i64)pr * n + c), inv);
+            if (pr != p) wstore(A, (i64)pr * n + c, top);
+            wstore(A, (i64)p * n + c, piv);
+        }
+        __syncthreads();
+        // A[i, :] -= A[i, j] * A[p, :] for every other row; column j itself last (it holds the factors)
+        for (i64 e = threadIdx.x; e < (i64)m * n; e += WGJ_THREADS) {
+            const int i = (int)(e / n), c = (int)(e % n);
+            if (i == p || c == j) continue;
+            const W128 fct = wload(A, (i64)i * n + j);
+            if (w_is_zero(fct)) continue;
+            wstore(A, e, wf_sub(f, wload(A, e), wf_mul(f, fct, wload(A, (i64)p * n + c))));
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < m; i += WGJ_THREADS)
+            if (i != p) wstore(A, (i64)i * n + j, W128{0, 0});
+        __syncthreads();
+        p++;
+    }
+    if (threadIdx.x == 0) rank_out[blockIdx.x] = p;
+}
+
+// lu_decompose_jit / plu_decompose_jit (_linalg.py:354-424), det_jit (:447-477): conventions of plu_kernel in gfa_linalg.hip
+template <bool PIVOT>
+__global__ __launch_bounds__(WGJ_THREADS) void wide_plu_kernel(WField f, u64 *__restrict__ Aall, u64 *__restrict__ Lall, u64 *__restrict__ Pall, int m, int n,
+                                                               i64 *__restrict__ nperm_out, u64 *__restrict__ det_out, int32_t *__restrict__ err)
+{
+    __shared__ int piv_row;
+    __shared__ W128 piv_inv;
+    u64 *A = Aall + 2 * (i64)blockIdx.x * m * n;
+    u64 *Lm = Lall ? Lall + 2 * (i64)blockIdx.x * m * m : nullptr;
+    u64 *Pm = Pall ? Pall + 2 * (i64)blockIdx.x * m * m : nullptr;
+    for (i64 e = threadIdx.x; e < (i64)m * m; e += WGJ_THREADS) { // L = 0 (PLU) or I (LU); P = I
+        const int r = (int)(e / m), c = (int)(e % m);
+        if (Lm) wstore(Lm, e, W128{(u64)((!PIVOT && r == c) ? 1 : 0), 0});
+        if (Pm) wstore(Pm, e, W128{(u64)(r == c ? 1 : 0), 0});
+    }
+    __syncthreads();
+    int nperm = 0;
+    bool failed = false;
+    const int steps = PIVOT ? (m < n ? m : n) : m - 1;
+    for (int i = 0; i < steps; i++) {
+        if (threadIdx.x == 0) piv_row = m;
+        __syncthreads();
+        const bool diag_zero = !w_nonzero(A, (i64)i * n + i);
+        if (diag_zero) {
+            for (int r = i + threadIdx.x; r < m; r += WGJ_THREADS)
+                if (w_nonzero(A, (i64)r * n + i)) { atomicMin(&piv_row, r); break; }
+        }
+        __syncthreads();
+        if (diag_zero) {
+            const int pr = piv_row;
+            if (pr == m) {
+                if (Lm && threadIdx.x == 0) wstore(Lm, (i64)i * m + i, W128{1, 0});
+                __syncthreads();
+                continue;
+            }
+            if (!PIVOT) { failed = true; break; }
+            for (int c = threadIdx.x; c < n; c += WGJ_THREADS) {
+                const W128 t = wload(A, (i64)i * n + c);
+                wstore(A, (i64)i * n + c, wload(A, (i64)pr * n + c));
+                wstore(A, (i64)pr * n + c, t);
+            }
+            for (int c = threadIdx.x; c < m; c += WGJ_THREADS) {
+                if (Pm) { const W128 t = wload(Pm, (i64)i * m + c); wstore(Pm, (i64)i * m + c, wload(Pm, (i64)pr * m + c)); wstore(Pm, (i64)pr * m + c, t); }
+                if (Lm) { const W128 t = wload(Lm, (i64)i * m + c); wstore(Lm, (i64)i * m + c, wload(Lm, (i64)pr * m + c)); wstore(Lm, (i64)pr * m + c, t); }
+            }
+            nperm++;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) piv_inv = wf_inv(f, wload(A, (i64)i * n + i));
+        __syncthreads();
+        const W128 inv = piv_inv;
+        // l_r = A[r, i] / A[i, i]; rows below the pivot: A[r, c] -= l_r * A[i, c] for c > i, then A[r, i] = 0
+        for (i64 e = threadIdx.x; e < (i64)(m - i - 1) * n; e += WGJ_THREADS) {
+            const int r = i + 1 + (int)(e / n), c = (int)(e % n);
+            if (c <= i) continue;
+            const W128 lead = wload(A, (i64)r * n + i);
+            if (w_is_zero(lead)) continue;
+            const W128 l = wf_mul(f, lead, inv);
+            wstore(A, (i64)r * n + c, wf_sub(f, wload(A, (i64)r * n + c), wf_mul(f, l, wload(A, (i64)i * n + c))));
+        }
+        __syncthreads();
+        for (int r = i + 1 + threadIdx.x; r < m; r += WGJ_THREADS) {
+            const W128 lead = wload(A, (i64)r * n + i);
+            if (Lm) wstore(Lm, (i64)r * m + i, w_is_zero(lead) ? lead : wf_mul(f, lead, inv));
+            wstore(A, (i64)r * n + i, W128{0, 0});
+        }
+        if (Lm && threadIdx.x == 0) wstore(Lm, (i64)i * m + i, W128{1, 0});
+        __syncthreads();
+    }
+    if (failed) {
+        if (threadIdx.x == 0 && err) atomicOr((int *)err, GFA_DEVERR_NO_LU);
+        return;
+    }
+    if (threadIdx.x == 0) {
+        if (Lm && PIVOT) wstore(Lm, (i64)(m - 1) * m + (m - 1), W128{1, 0}); // "set the final diagonal to 1" (_linalg.py:419)
+        if (nperm_out) nperm_out[blockIdx.x] = nperm;
+        if (det_out) {
+            W128 d{1, 0};
+            const int k = m < n ? m : n;
+            for (int i = 0; i < k; i++) d = wf_mul(f, d, wload(A, (i64)i * n + i));
+            if (nperm & 1) d = wf_neg(f, d);
+            wstore(det_out, blockIdx.x, d);
+        }
+    }
+}
+
+// evaluate_elementwise_jit (_polys/_dense.py:404-423): Horner, coefficients in descending degree, one x per lane
+__global__ __launch_bounds__(256) void wide_poly_eval_kernel(WField f, const u64 *__restrict__ coeffs, i64 ncoef, const u64 *__restrict__ x, u64 *__restrict__ out, i64 n)
+{
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        const W128 xv = wload(x, i);
+        W128 acc = wload(coeffs, 0);
+        for (i64 k = 1; k < ncoef; k++) acc = wf_add(f, wload(coeffs, k), wf_mul(f, acc, xv));
+        wstore(out, i, acc);
+    }
+}
+
 } // namespace
 
 struct gfa_wfield {
@@ -410,7 +558,7 @@ extern "C" {
 int gfa_wfield_create(int kind, uint32_t m, const uint64_t *params, gfa_wfield_t **out)
 {
     // params (uint64 words): [0:2] p  [2] nprime  [3:5] r2  [5:7] p-2 | 2^m-2  [7:9] red  [9:11] (q-1)/(p-1)-1  [11:27] irr digits
-    if (!params || !out || kind < WKIND_PRIME || kind > WKIND_EXT || m < 1 || m > 127 || (kind == WKIND_EXT && m > 16)) {
+    if (!params || !out || kind < WKIND_PRIME || kind > WKIND_EXT || m < 1 || m > 128 || (m == 128 && kind != WKIND_BIN) || (kind == WKIND_EXT && m > 16)) {
         set_error("gfa_wfield_create: bad arguments");
         return GFA_ERR_INVALID;
     }
@@ -497,6 +645,47 @@ int gfa_wide_matmul(gfa_wfield_t *w, const void *a, const void *b, void *out, in
     if (n == 0) return GFA_OK;
     hipLaunchKernelGGL(wide_matmul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w->f, (const u64 *)a, (const u64 *)b,
                        (u64 *)out, batch, M, K, N, a_bstride, b_bstride);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+int gfa_wide_row_reduce(gfa_wfield_t *w, void *a, int64_t batch, int64_t m, int64_t n, int64_t ncols, int64_t *rank_out, gfa_stream_t stream)
+{
+    if (!w || !a || !rank_out || batch < 0 || m < 1 || n < 1 || ncols < 0 || ncols > n || m > 0x7fffffff / 2 || n > 0x7fffffff / 2 || batch > 0x7fffffff) {
+        set_error("gfa_wide_row_reduce: bad arguments");
+        return GFA_ERR_INVALID;
+    }
+    if (batch == 0) return GFA_OK;
+    hipLaunchKernelGGL(wide_row_reduce_kernel, dim3((unsigned)batch), dim3(WGJ_THREADS), 0, (hipStream_t)stream, w->f, (u64 *)a, (int)m, (int)n, (int)ncols,
+                       (i64 *)rank_out);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+int gfa_wide_plu_decompose(gfa_wfield_t *w, void *a, void *l_out, void *p_out, int64_t batch, int64_t m, int64_t n, int pivoting, int64_t *nperm_out,
+                           void *det_out, gfa_stream_t stream, int32_t *dev_err)
+{
+    if (!w || !a || batch < 0 || m < 1 || n < 1 || m > 0x7fffffff / 2 || n > 0x7fffffff / 2 || batch > 0x7fffffff) {
+        set_error("gfa_wide_plu_decompose: bad arguments");
+        return GFA_ERR_INVALID;
+    }
+    if (batch == 0) return GFA_OK;
+    if (pivoting)
+        hipLaunchKernelGGL((wide_plu_kernel<true>), dim3((unsigned)batch), dim3(WGJ_THREADS), 0, (hipStream_t)stream, w->f, (u64 *)a, (u64 *)l_out, (u64 *)p_out,
+                           (int)m, (int)n, (i64 *)nperm_out, (u64 *)det_out, dev_err);
+    else
+        hipLaunchKernelGGL((wide_plu_kernel<false>), dim3((unsigned)batch), dim3(WGJ_THREADS), 0, (hipStream_t)stream, w->f, (u64 *)a, (u64 *)l_out, (u64 *)p_out,
+                           (int)m, (int)n, (i64 *)nperm_out, (u64 *)det_out, dev_err);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+int gfa_wide_poly_evaluate(gfa_wfield_t *w, const void *coeffs, int64_t ncoef, const void *x, void *out, int64_t n, gfa_stream_t stream)
+{
+    if (!w || !coeffs || !x || !out || ncoef < 1 || n < 0) { set_error("gfa_wide_poly_evaluate: bad arguments"); return GFA_ERR_INVALID; }
+    if (n == 0) return GFA_OK;
+    const int grid = (int)std::min<i64>((n + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(wide_poly_eval_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w->f, (const u64 *)coeffs, ncoef, (const u64 *)x, (u64 *)out, n);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }

@@ -159,10 +159,10 @@ int gfa_log_prepare(gfa_field_t *f, const uint64_t *primes, const uint32_t *mult
 int gfa_log(gfa_field_t *f, const void *a, int64_t a_stride, const void *base, int64_t base_stride, int64_t *out, int64_t n,
             int dtype, gfa_stream_t stream, int32_t *dev_err);
 
-/* ---- Fields of order 2^64 <= q < 2^128 (the reference's dtype=object fields: _fields/_ufunc.py:36-48 selects [np.object_],
+/* ---- Fields of order 2^64 <= q <= 2^128 (the reference's dtype=object fields: _fields/_ufunc.py:36-48 selects [np.object_],
  * _domains/_meta.py:39-41 the python-calculate mode; same scalar formulas _domains/_calculate.py:133-592) ----------------- *
  * Elements are two little-endian uint64 limbs, interleaved (element i at words 2i, 2i+1).  kind: 1 = GF(p), p >= 2^64
- * (Montgomery), 2 = GF(2^m), 64 < m <= 127, 3 = GF(p^m) with p < 2^32.  `params` (27 uint64 words, computed by the host):
+ * (Montgomery), 2 = GF(2^m), 64 < m <= 128 (m = 128: the modulus' x^128 term is implicit), 3 = GF(p^m) with p < 2^32.  `params` (27 uint64 words, computed by the host):
  * [0:2] p, [2] -p^-1 mod 2^64, [3:5] 2^256 mod p, [5:7] p - 2 (kind 1) or 2^m - 2 (kind 2), [7:9] the irreducible polynomial
  * without x^m (kind 2), [9:11] (q-1)/(p-1) - 1 (kind 3), [11:27] digits of the irreducible polynomial minus x^m, degree
  * m-1..0 (kind 3).  Strides are 0 (broadcast scalar) or 1.  gfa_wide_power takes exponents the host has reduced into
@@ -185,6 +185,14 @@ int gfa_wide_reduce(gfa_wfield_t *w, int op, const void *a, void *out, int64_t n
 int gfa_wide_convolve(gfa_wfield_t *w, const void *a, int64_t na, const void *b, int64_t nb, void *out, gfa_stream_t stream);
 int gfa_wide_matmul(gfa_wfield_t *w, const void *a, const void *b, void *out, int64_t batch, int64_t M, int64_t K, int64_t N,
                     int64_t a_bstride, int64_t b_bstride, gfa_stream_t stream);
+/* Elimination on these fields (r05): row_reduce_jit (_domains/_linalg.py:315-351), lu_decompose_jit / plu_decompose_jit (:354-424),
+ * det_jit (:447-477) -- arguments, pivot rule, L / P conventions and the GFA_DEVERR_NO_LU flag exactly as gfa_row_reduce /
+ * gfa_plu_decompose below, on (batch, m, n) stacks of two-limb elements.  gfa_wide_poly_evaluate: Horner evaluation of one polynomial
+ * (coefficients in descending degree) at n points, evaluate_elementwise_jit (_polys/_dense.py:404-423). */
+int gfa_wide_row_reduce(gfa_wfield_t *w, void *a, int64_t batch, int64_t m, int64_t n, int64_t ncols, int64_t *rank_out, gfa_stream_t stream);
+int gfa_wide_plu_decompose(gfa_wfield_t *w, void *a, void *l_out, void *p_out, int64_t batch, int64_t m, int64_t n, int pivoting,
+                           int64_t *nperm_out, void *det_out, gfa_stream_t stream, int32_t *dev_err);
+int gfa_wide_poly_evaluate(gfa_wfield_t *w, const void *coeffs, int64_t ncoef, const void *x, void *out, int64_t n, gfa_stream_t stream);
 
 /* ---- NTT: replaces fft_jit/ifft_jit `self.jit(x.astype(int64), int64(omega), factors)` (_domains/_function.py:201) *
  * Computes out[k] = sum_j in[j] * omega^(j*k) for each of `batch` contiguous length-n rows, natural order in and

@@ -72,6 +72,48 @@ def pack_sage_wide_fields():
         print("packed (wide)", folder)
 
 
+def pack_sage_wide_linalg():
+    """r05: the rest of the three big folders (order >= 2^64) -- row_reduce / lu / plu / inverse / determinant / solve / the four
+    spaces (tests/fields/data/*/), log.pkl, and the polynomial evaluations (tests/polys/data/*/evaluate.pkl, evaluate_matrix.pkl):
+    what the reference pins its dtype=object linear algebra, discrete logarithm and Horner loops with.  Decimal strings."""
+    ops = ["row_reduce", "lu_decompose", "plu_decompose", "matrix_inverse", "matrix_determinant", "matrix_solve", "row_space",
+           "column_space", "left_null_space", "null_space"]
+
+    def dec(v):
+        a = np.array(v, dtype=object)
+        return np.array([str(int(t)) for t in a.ravel()]).reshape(a.shape)
+
+    for folder in sorted(os.listdir(os.path.join(REF_TESTS, "fields", "data"))):
+        path = os.path.join(REF_TESTS, "fields", "data", folder)
+        props = json.load(open(os.path.join(path, "properties.json")))
+        if props["order"] < 2**64:
+            continue
+        out = {"properties": np.array(json.dumps(props))}
+        for op in ops:
+            d = pickle.load(open(os.path.join(path, op + ".pkl"), "rb"))
+            out[f"{op}_count"] = np.array(len(d["X"]))
+            for k, vals in d.items():
+                for i, v in enumerate(vals):
+                    out[f"{op}{i}_{k}"] = dec(v if not np.isscalar(v) else int(v))
+        d = pickle.load(open(os.path.join(path, "log.pkl"), "rb"))
+        out["log_X"], out["log_Z"] = dec(d["X"]), dec(d["Z"])
+        ppath = os.path.join(REF_TESTS, "polys", "data", folder)
+        d = pickle.load(open(os.path.join(ppath, "evaluate.pkl"), "rb"))
+        out["evaluate_count"] = np.array(len(d["X"]))
+        out["evaluate_Y"] = dec(d["Y"])
+        for i, v in enumerate(d["X"]):
+            out[f"evaluate{i}_X"] = dec(v.coeffs if hasattr(v, "coeffs") else v)
+            out[f"evaluate{i}_Z"] = dec(d["Z"][i])
+        d = pickle.load(open(os.path.join(ppath, "evaluate_matrix.pkl"), "rb"))
+        out["evaluate_matrix_count"] = np.array(len(d["X"]))
+        for k, vals in d.items():
+            for i, v in enumerate(vals):
+                out[f"evaluate_matrix{i}_{k}"] = dec(v.coeffs if hasattr(v, "coeffs") else v)
+        name = folder.replace("(", "_").replace(")", "").replace("^", "e").replace(", ", "_")
+        np.savez_compressed(os.path.join(OUT_DIR, f"sage_wide_linalg_{name}.npz"), **out)
+        print("packed (wide linalg)", folder)
+
+
 def pack_sage_fields():
     ops = ["add", "subtract", "multiply", "divide", "additive_inverse", "multiplicative_inverse", "scalar_multiply",
            "power"]
@@ -510,6 +552,7 @@ if __name__ == "__main__":
         pack_sage_polys()
     if "linalg" in what:
         pack_sage_linalg()
+        pack_sage_wide_linalg()
     if "bch" in what:
         pack_sage_bch()
     if "reference_bch" in what:

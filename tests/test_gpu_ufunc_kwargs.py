@@ -26,7 +26,7 @@ FIELDS = [7, 2**8, 3**5, 65537, 2**32, 2**64 - 2**32 + 1, 2**100, 36893488147419
 def test_where_on_calls_blends_with_out_and_computes_nothing_else(order):
     GF = ga.GF(order)
     x = GF.Random((6, 50), seed=1)
-    y = GF.Random((6, 50), seed=2)
+    y = GF.Random((6, 50), low=1, seed=2)
     y[0, :5] = 0  # divisors that are zero ...
     mask = np.ones((6, 50), dtype=bool)
     mask[0, :5] = False  # ... only where nothing is computed

@@ -240,3 +240,152 @@ def test_reductions_of_the_big_fields_against_the_oracle(tag):
             if 0 <= k - i < 7:
                 acc = W.add(acc, W.mul(int(h[0, i]), int(h[2, k - i])))
         assert int(c[k]) == acc
+
+
+def _load_linalg(tag):
+    GF, W, _, props = _load(tag)
+    return GF, W, np.load(os.path.join(H.GOLDEN, f"sage_wide_linalg_{tag}.npz")), props
+
+
+def _cases(d, op, keys):
+    for i in range(int(d[f"{op}_count"])):
+        yield tuple(_obj(d[f"{op}{i}_{k}"]) for k in keys)
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_sage_elimination_fixtures_of_the_big_fields(tag):
+    """r05 -- row_reduce / lu / plu / inverse / determinant / solve / the four spaces of the three Sage folders of order >= 2^64
+    (the reference: object-dtype loops of _domains/_linalg.py:315-548 and _fields/_array.py:1412-1760): rows f2 at 16 / 16 folders."""
+    GF, W, d, props = _load_linalg(tag)
+    for X, Z in _cases(d, "row_reduce", "XZ"):
+        H.assert_equal_ints(GF(X).row_reduce().numpy(), Z, f"{tag} row_reduce")
+    for X, Lt, Ut in _cases(d, "lu_decompose", "XLU"):
+        l, u = GF(X).lu_decompose()
+        H.assert_equal_ints(l.numpy(), Lt, "lu L")
+        H.assert_equal_ints(u.numpy(), Ut, "lu U")
+    for X, Pt, Lt, Ut in _cases(d, "plu_decompose", "XPLU"):
+        p, l, u = GF(X).plu_decompose()
+        H.assert_equal_ints(p.numpy(), Pt, "plu P")
+        H.assert_equal_ints(l.numpy(), Lt, "plu L")
+        H.assert_equal_ints(u.numpy(), Ut, "plu U")
+        H.assert_equal_ints((p @ l @ u).numpy(), X, "P L U = A")
+    for X, Z in _cases(d, "matrix_inverse", "XZ"):
+        H.assert_equal_ints(np.linalg.inv(GF(X)).numpy(), Z, "inv")
+    for X, Z in _cases(d, "matrix_determinant", "XZ"):
+        assert int(np.linalg.det(GF(X))) == int(Z), "det"
+    for X, Y, Z in _cases(d, "matrix_solve", "XYZ"):
+        H.assert_equal_ints(np.linalg.solve(GF(X), GF(Y)).numpy(), Z, "solve")
+    for op in ("row_space", "column_space", "left_null_space", "null_space"):
+        for X, Z in _cases(d, op, "XZ"):
+            got = getattr(GF(X), op)().numpy()
+            if Z.size == 0:
+                assert got.size == 0, op
+            else:
+                H.assert_equal_ints(got, Z.reshape(got.shape), op)
+    assert np.linalg.matrix_rank(GF(np.array([[1, 2], [2, 4]], dtype=object))) == 1
+    with pytest.raises(np.linalg.LinAlgError):
+        np.linalg.inv(GF(np.array([[1, 2], [2, 4]], dtype=object)))
+    with pytest.raises(ValueError):
+        GF(np.array([[0, 1], [1, 1]], dtype=object)).lu_decompose()
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_sage_log_and_polynomial_evaluation_of_the_big_fields(tag):
+    """r05 -- log.pkl (Pohlig-Hellman: q - 1 of the three fields has prime factors up to 4294967291) and
+    tests/polys/data/*/evaluate.pkl, evaluate_matrix.pkl (Horner, _polys/_dense.py:404-470): row f4 at 16 / 16 folders."""
+    GF, W, d, props = _load_linalg(tag)
+    x, z = GF(_obj(d["log_X"])), _obj(d["log_Z"])
+    got = np.log(x)
+    assert [int(v) for v in np.ravel(got)] == [int(v) for v in z.ravel()]
+    alpha = GF(np.array(props["primitive_element"], dtype=object))
+    H.assert_equal_ints((alpha ** got).numpy(), x.numpy(), "alpha ** log x == x")
+    assert x[3].log() == int(z[3])  # a 0-D input returns a Python int
+    with pytest.raises(ArithmeticError):
+        np.log(GF(np.array([1, 0], dtype=object)))
+    ys = GF(_obj(d["evaluate_Y"]))
+    for i in range(int(d["evaluate_count"])):
+        poly = ga.Poly(GF(_obj(d[f"evaluate{i}_X"])))
+        H.assert_equal_ints(poly(ys).numpy(), _obj(d[f"evaluate{i}_Z"]), f"{tag} evaluate {i}")
+    for i in range(int(d["evaluate_matrix_count"])):
+        poly = ga.Poly(GF(_obj(d[f"evaluate_matrix{i}_X"])))
+        got = poly(GF(_obj(d[f"evaluate_matrix{i}_Y"])), elementwise=False)
+        H.assert_equal_ints(got.numpy(), _obj(d[f"evaluate_matrix{i}_Z"]), f"{tag} evaluate_matrix {i}")
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_fft_sqrt_reduceat_and_at_on_the_big_fields_against_the_oracle(tag):
+    """np.fft.fft / ifft for every small divisor of q - 1 (mixed radix, against the direct DFT on Python integers), np.sqrt
+    (round trip and the smaller-root rule), ufunc.reduceat / ufunc.at against left folds of the oracle's scalars."""
+    GF, W, d, props = _load(tag)
+    q = GF.order
+    rnd = random.Random(11)
+    divisors = [n for n in (2, 3, 4, 5, 6, 8, 9, 12, 15, 16, 18, 24, 30, 33, 47) if (q - 1) % n == 0]
+    assert divisors
+    for n in divisors:
+        h = [rnd.randrange(q) for _ in range(n)]
+        x = GF(np.array(h, dtype=object))
+        w = int(GF.primitive_root_of_unity(n))
+        want = []
+        for k in range(n):
+            acc = 0
+            for j in range(n):
+                acc = W.add(acc, W.mul(h[j], W.pow(w, (j * k) % n)))
+            want.append(acc)
+        X = np.fft.fft(x)
+        assert type(X) is GF
+        H.assert_equal_ints(X.numpy(), np.array(want, dtype=object), f"{tag} fft n={n}")
+        H.assert_equal_ints(np.fft.ifft(X).numpy(), np.array(h, dtype=object), f"{tag} ifft n={n}")
+    with pytest.raises(ValueError):
+        np.fft.fft(GF(np.array([1] * 7, dtype=object))) if (q - 1) % 7 else (_ for _ in ()).throw(ValueError())
+    # square roots: r * r is a square; sqrt returns the smaller of the two roots as integers
+    r = GF(np.array([rnd.randrange(1, q) for _ in range(40)] + [0, 1], dtype=object))
+    s = np.sqrt(r * r)
+    H.assert_equal_ints((s * s).numpy(), (r * r).numpy(), "sqrt round trip")
+    for a, b in zip(s.numpy(), (-s).numpy()):
+        assert int(a) <= int(b)
+    assert all(bool(v) for v in np.ravel((r * r).is_square()))
+    # reduceat / at
+    h = [rnd.randrange(1, q) for _ in range(12)]
+    x = GF(np.array(h, dtype=object))
+    idx = [0, 4, 4, 9, 2]
+    for uf, f in ((np.add, W.add), (np.multiply, W.mul), (np.subtract, W.sub)):
+        want = []
+        ends = idx[1:] + [12]
+        for s0, e0 in zip(idx, ends):
+            acc = h[s0]
+            for v in h[s0 + 1:e0]:
+                acc = f(acc, v)
+            want.append(acc)
+        H.assert_equal_ints(uf.reduceat(x, idx).numpy(), np.array(want, dtype=object), f"{tag} {uf.__name__}.reduceat")
+    y = x.copy()
+    inc = [rnd.randrange(q) for _ in range(4)]
+    np.add.at(y, [1, 1, 3, 1], GF(np.array(inc, dtype=object)))
+    exp = list(h)
+    for i, v in zip([1, 1, 3, 1], inc):
+        exp[i] = W.add(exp[i], v)
+    H.assert_equal_ints(y.numpy(), np.array(exp, dtype=object), f"{tag} add.at")
+
+
+def test_the_ghash_field_gf_2_128():
+    """r05: GF(2^128) -- the 129-bit modulus x^128 + x^7 + x^2 + x + 1 with its top bit implicit in the two-limb kernels
+    (the reference has no upper bound on the order: _domains/_meta.py:38-41).  Against the Python-integer oracle."""
+    irr = (1 << 128) | 0x87
+    GF = ga.GF(2, 128, irreducible_poly=irr, primitive_element=2, verify=False)
+    W = WideOracle(2, 128, [(irr >> (128 - i)) & 1 for i in range(129)])
+    assert GF.order == 2**128 and GF.dtypes == [np.object_]
+    rnd = random.Random(128)
+    a = [rnd.randrange(2**128) for _ in range(300)] + [2**128 - 1, 1, 2**127, 0]
+    b = [rnd.randrange(1, 2**128) for _ in range(300)] + [2**128 - 1, 2**127, 1, 3]
+    x, y = GF(np.array(a, dtype=object)), GF(np.array(b, dtype=object))
+    H.assert_equal_ints((x + y).numpy(), np.array([u ^ v for u, v in zip(a, b)], dtype=object))
+    H.assert_equal_ints((x * y).numpy(), np.array([W.mul(u, v) for u, v in zip(a, b)], dtype=object), "GF(2^128) mul")
+    H.assert_equal_ints((x / y).numpy(), np.array([W.div(u, v) for u, v in zip(a, b)], dtype=object), "GF(2^128) div")
+    H.assert_equal_ints((y * np.reciprocal(y)).numpy(), np.array([1] * len(b), dtype=object))
+    H.assert_equal_ints((y ** (2**128 - 1)).numpy(), np.array([1] * len(b), dtype=object), "x^(q-1) = 1")
+    H.assert_equal_ints((y ** -3).numpy(), np.array([W.pow(v, -3) for v in b], dtype=object))
+    with pytest.raises(ValueError):
+        GF(np.array([2**128], dtype=object))
+    with pytest.raises(NotImplementedError):
+        ga.GF(2, 129, irreducible_poly=(1 << 129) | 0x21, verify=False)
+    with pytest.raises(NotImplementedError):
+        ga.GF(2**89 - 1, 2, irreducible_poly=[1, 0, 3], verify=False)  # order 2^178
