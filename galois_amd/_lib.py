@@ -95,6 +95,7 @@ SIGNATURES = {
     "gfa_time_rs_encode": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p, c_int, _f32p]),
     "gfa_time_rs_decode": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_int, _f32p]),
     "gfa_debug_fermat_stamps": (None, [c_void_p]),
+    "gfa_debug_m32_tune": (None, [c_int, c_int]),
     "gfa_debug_rs_bm_selftest": (c_int, [c_void_p, c_i64, c_u64, _i64p, c_void_p]),
 }
 

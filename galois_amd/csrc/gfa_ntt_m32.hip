@@ -557,9 +557,14 @@ struct M32Plan {
 };
 
 struct M32Key {
-    u64 p; int device; i64 n; u64 omega;
-    bool operator<(const M32Key &o) const { return std::tie(p, device, n, omega) < std::tie(o.p, o.device, o.n, o.omega); }
+    u64 p; int device; i64 n; u64 omega; int split; // split: the tuning override of the three-pass line lengths (0: default)
+    bool operator<(const M32Key &o) const { return std::tie(p, device, n, omega, split) < std::tie(o.p, o.device, o.n, o.omega, o.split); }
 };
+
+// tuning knobs of gfa_debug_m32_tune (tools/m32_tune3.py): [0] log1 and [1] log2 of the three-pass form (0: default),
+// [2] non-temporal last pass: -1 by size (default), 0 never, 1 always; [3] last pass of 1024-point lines in 1024-thread workgroups
+// (32 lines per tile: every transposed store covers a whole 128-byte line)
+int g_m32_tune[4] = {0, 0, -1, 0};
 
 std::mutex g_m32_mu;
 std::map<M32Key, M32Plan *> g_m32_plans;
@@ -611,7 +616,7 @@ int progression_tables(u64 p, u64 w, int logw, int loglines, int logL, i32 **t0,
     return GFA_OK;
 }
 
-int build_plan(M32Plan *pl, u64 p, i64 n, u64 omega, hipStream_t st)
+int build_plan(M32Plan *pl, u64 p, i64 n, u64 omega, int split, hipStream_t st)
 {
     int logn = 0;
     while (((i64)1 << logn) < n) logn++;
@@ -622,7 +627,12 @@ int build_plan(M32Plan *pl, u64 p, i64 n, u64 omega, hipStream_t st)
         // shortest in the last
         pl->log1 = (logn + 2) / 3;
         pl->log2 = (logn - pl->log1 + 1) / 2;
+        if (split) { pl->log1 = split >> 8; pl->log2 = split & 0xff; }
         pl->log3 = logn - pl->log1 - pl->log2;
+        if (pl->log1 < 5 || pl->log1 > 10 || pl->log2 < 5 || pl->log2 > 10 || pl->log3 < 5 || pl->log3 > 10) {
+            set_error("m32 NTT: three-pass line lengths out of range");
+            return GFA_ERR_INVALID;
+        }
     }
     const u32 pinv = inv_2_32((u32)p);
     int rc;
@@ -736,6 +746,12 @@ int launch_t(const i32 *in, i32 *out, const M32Args &a, i64 batch, const i32 *ne
 {
     // 1024-point lines: 512-thread workgroups, two per CU, the whole line staged (measured against 256 / 1024 threads and a two-round
     // exchange with three workgroups per CU: 0.236 vs 0.268 ms at 2^20 x 64, profiles/r03_m32_sweep.txt); shorter lines: 256 threads
+    if constexpr (LOGR1 == 5 && LOGR2 == 5) {
+        if (g_m32_tune[3] && mode != 1) { // tuning: 32 lines per tile in the last pass
+            if (mode == 0) return launch_ttm<LOGR1, LOGR2, 1024, false, 0, false, BMAX>(in, out, a, batch, net, mid, tw, tw2, st);
+            return launch_ttm<LOGR1, LOGR2, 1024, false, 0, true, BMAX>(in, out, a, batch, net, mid, tw, tw2, st);
+        }
+    }
     if constexpr (LOGR1 == 5) return launch_tt<LOGR1, LOGR2, 512, false, BMAX>(in, out, a, batch, net, mid, tw, tw2, st, mode);
     else return launch_tt<LOGR1, LOGR2, 256, false, BMAX>(in, out, a, batch, net, mid, tw, tw2, st, mode);
 }
@@ -859,13 +875,14 @@ int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 
     M32Plan *pl;
     {
         std::lock_guard<std::mutex> lock(g_m32_mu);
-        const M32Key key{fd.p, dev, n, omega};
+        const int split = n > ((i64)1 << 20) && g_m32_tune[0] ? (g_m32_tune[0] << 8 | g_m32_tune[1]) : 0;
+        const M32Key key{fd.p, dev, n, omega, split};
         auto it = g_m32_plans.find(key);
         if (it == g_m32_plans.end()) {
             // plans are kept for the life of the process (another host thread may be launching from one): a plan is ~140 KiB of
             // tables for a 2^20-point transform, one per (p, device, n, omega) ever used
             M32Plan *np = new M32Plan();
-            const int rc = build_plan(np, fd.p, n, omega, st);
+            const int rc = build_plan(np, fd.p, n, omega, split, st);
             if (rc) { free_plan(np); return rc; }
             it = g_m32_plans.emplace(key, np).first;
         }
@@ -922,7 +939,8 @@ int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 
                 a.in_batch_stride = L2; a.out_batch_stride = L0;
                 a.total_lines = L0;
                 a.load_along_line = 1; a.store_along_line = 0;
-                const bool in_cache = (size_t)n * sizeof(i32) <= ((size_t)256 << 20); // the intermediate fits the Infinity Cache
+                bool in_cache = (size_t)n * sizeof(i32) <= ((size_t)256 << 20); // the intermediate fits the Infinity Cache
+                if (g_m32_tune[2] >= 0) in_cache = g_m32_tune[2] != 0;
                 if ((rc = launch(cls, pl->log3, w, db, a, L1, pl->net3, pl->mid3, nullptr, nullptr, st, in_cache ? 2 : 0))) return rc;
             }
         }
@@ -956,9 +974,16 @@ int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 
         a.in_batch_stride = n; a.out_batch_stride = n;
         a.total_lines = n1;
         a.load_along_line = 1; a.store_along_line = 0;
-        const bool in_cache = (size_t)n * (size_t)batch * sizeof(i32) <= ((size_t)256 << 20); // the intermediate fits the Infinity Cache
+        bool in_cache = (size_t)n * (size_t)batch * sizeof(i32) <= ((size_t)256 << 20); // the intermediate fits the Infinity Cache
+        if (g_m32_tune[2] >= 0) in_cache = g_m32_tune[2] != 0;
         return launch(cls, pl->log2, w, dst, a, batch, pl->net2, pl->mid2, nullptr, nullptr, st, in_cache ? 2 : 0);
     }
 }
 
 } // namespace gfa
+
+// tuning aid (tools/m32_tune3.py): see g_m32_tune
+extern "C" void gfa_debug_m32_tune(int key, int value)
+{
+    if (key >= 0 && key < 4) g_m32_tune[key] = value;
+}

@@ -335,6 +335,9 @@ int gfa_time_rs_decode(gfa_rs_t *code, const void *recv, int64_t ns, void *out_c
 /* Tuning aid of the GF(65537) one-pass transform (tools/fermat_phases.py): when `buf` is not NULL the kernel records eight
  * 100 MHz timestamps per (workgroup, round) there; NULL switches the recording off again.  Not part of the product path. */
 void gfa_debug_fermat_stamps(unsigned long long *buf);
+/* tuning aid of the signed-Montgomery NTT kernels (tools/m32_tune3.py): key 0 / 1 = line lengths (log2) of the first / second pass of the
+ * three-pass form (0: default), 2 = non-temporal last pass (-1 by size, 0 never, 1 always), 3 = 1024-thread workgroups in the last pass */
+void gfa_debug_m32_tune(int key, int value);
 /* Test-only: the hand-assembled Berlekamp-Massey loop of the Reed-Solomon wave decoder (replaces berlekamp_massey_jit,
  * _lfsr.py:1647-1702, inside bch_decode_jit) against a compiler-generated loop of the same recurrence, on `nseq` syndrome
  * sequences derived from `seed` over a GF(2^8) field; *mismatches = sequences on which the two disagree (must be 0). */
