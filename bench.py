@@ -104,6 +104,17 @@ def main():
         if rc:
             L.check(rc, "gfa_binary")
 
+    # As-measured figure with the protocol of rounds 1-3 (5 warm-up + 20 timed steps straight after the idle set-up phase, no clock
+    # pre-warm): kept NEXT to the warm figure so that rounds stay comparable
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t_cold = time.perf_counter()
+    for _ in range(20):
+        step()
+    torch.cuda.synchronize()
+    cold_elapsed = time.perf_counter() - t_cold
+
     # Clock pre-warm, untimed and outside the W + K steps: the set-up above leaves the GPU idle for seconds, and it then needs tens
     # of milliseconds of load before its clocks are back up -- a kernel timed straight away reads 3-15 % slow
     # (profiles/r04_bench_clock_ramp.txt).  ~0.1 s of the same launch; reported in the JSON line as "clock_prewarm".
@@ -177,6 +188,8 @@ def main():
             "warmup": args.warmup,
             "clock_prewarm": {"steps": prewarm_steps, "ms": round(prewarm_ms, 1), "timed": False,
                               "why": "GPU clocks ramp for tens of ms after the idle set-up phase; see profiles/r04_bench_clock_ramp.txt"},
+            "as_measured_without_prewarm": {"value": round(n * 20 / cold_elapsed / 1e9, 2), "unit": "Gop/s", "steps": 20, "warmup": 5,
+                                            "note": "this rank only; the r01-r03 protocol: 5 + 20 steps right after the idle set-up phase"},
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True,
             "scaling": "weak",
@@ -543,7 +556,16 @@ def extras(ga, L, lib, stream, with_cpu):
         ex[tag] = entry
         del at, bt, ot
     # ---- NTT: 2^20 points over GF(7340033) (the modulus galois.ntt picks for that size), batch of 64 ----
-    for tag, p, logn, batch in (("ntt_2^20_gf7340033", 7340033, 20, 64), ("ntt_16x2^16_gf65537", 65537, 16, 16 * 64),
+    # kernel (and launch shape) behind every entry: profiles/r05_bench_kernel_stats.csv is keyed by (kernel, grid_x, workgroup_x)
+    ntt_kernels = {
+        "ntt_2^20_gf7340033": [("ntt_m32_kernel<5, 5, 512, false, 1, false, 32>", 64 * 64 * 512, 512), ("ntt_m32_kernel<5, 5, 512, false, 0, true, 32>", 64 * 64 * 512, 512)],
+        "ntt_2^20_gf469762049": [("ntt_m32_kernel<5, 5, 512, false, 1, false, 4>", 64 * 64 * 512, 512), ("ntt_m32_kernel<5, 5, 512, false, 0, true, 4>", 64 * 64 * 512, 512)],
+        "ntt_16x2^16_gf65537": [("ntt_fermat16_kernel<false, false>", 256 * 1024, 1024)],
+        "ntt_2^16_gf7340033": [("ntt_m32_2e16_kernel<64>", 256 * 1024, 1024)],
+        "ntt_2^14_gf7340033": [("ntt_m32_one_kernel<4, 1, 32>", 4096 * 512, 512)],
+    }
+    for tag, p, logn, batch in (("ntt_2^20_gf7340033", 7340033, 20, 64), ("ntt_2^20_gf469762049", 469762049, 20, 64),
+                                ("ntt_16x2^16_gf65537", 65537, 16, 16 * 64),
                                 ("ntt_2^16_gf7340033", 7340033, 16, 1024), ("ntt_2^14_gf7340033", 7340033, 14, 4096)):
         P = ga.GF(p)
         N = 1 << logn
@@ -556,7 +578,8 @@ def extras(ga, L, lib, stream, with_cpu):
         gbs = 8.0 * points / (ms.value * 1e-3) / 1e9
         entry = {"transforms_per_s": round(batch / (ms.value * 1e-3), 1), "points_per_s": round(points / (ms.value * 1e-3), 0),
                  "ms_per_launch": round(ms.value, 4), "batch": batch, "algorithmic_GB/s": round(gbs, 1),
-                 "roofline_frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_point": 8}
+                 "roofline_frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_point": 8,
+                 "kernels": [{"kernel": k, "grid_x": g, "workgroup_x": w} for k, g, w in ntt_kernels[tag]]}
         if logn == 14:
             entry["note"] = "one pass over HBM: one workgroup per transform, three register networks, two LDS exchanges (gfa_ntt_m32.hip)"
         elif logn == 16 and p != 65537:
@@ -565,8 +588,17 @@ def extras(ga, L, lib, stream, with_cpu):
         elif logn == 20:
             entry["2^20_pt_ntt_per_s"] = entry["transforms_per_s"]
             entry["ceiling_frac"] = 0.333
+            entry["ceiling_kind"] = "static: copied from the cited profile, not measured in this run"
             entry["ceiling_source"] = ("profiles/r03_ntt_access_skeleton.txt: the two passes' access pattern with no arithmetic, "
-                                       "0.105 + 0.097 ms for this batch")
+                                       "0.105 + 0.097 ms for this batch; r05 re-measured 0.208 ms for the pair, and a packed 3-byte "
+                                       "intermediate at 0.213 (profiles/r05_ntt_packed_intermediate.txt: no-go)")
+            # what the memory system really moves (PMC, FETCH_SIZE x 2 + WRITE_SIZE over both passes of this batch)
+            entry["physical_bytes_per_point"] = 17.0 if p == 7340033 else None
+            entry["physical_bytes_source"] = ("profiles/r04_pmc_ntt_m32_two_pass.txt: 256.6 + 258 MiB (pass 1), 256.6 + 319 MiB (pass 2, "
+                                              "non-temporal stores: 1.25x write amplification) per 2^26 points; static, not measured in this run")
+            if p >= (1 << 26):
+                entry["note_prime"] = ("r05: primes in [2^26, 2^29) on the signed-Montgomery kernels (in-network reductions placed at compile "
+                                       "time, gfa_m32_net.h); r04 ran this prime on the lazy-Shoup register kernels at 0.21")
             entry["note"] = ("two passes over the array (16 B/point of traffic against the 8 B/point algorithmic minimum this fraction "
                              "is priced on): the same access pattern with NO arithmetic takes 0.20-0.22 ms for this batch "
                              "(tools/ubench/ntt_access.hip, profiles/r03_ntt_access_skeleton.txt), i.e. 0.30-0.335 is the ceiling of any "
@@ -575,6 +607,7 @@ def extras(ga, L, lib, stream, with_cpu):
         else:
             entry["2^20_points_per_s_equiv"] = round(points / (1 << 20) / (ms.value * 1e-3), 1)
             entry["ceiling_frac"] = 0.73
+            entry["ceiling_kind"] = "static: copied from the cited profile, not measured in this run"
             entry["ceiling_source"] = ("profiles/r04_fermat_experiments.txt section 3: the transform's arithmetic + LDS exchanges with NO HBM traffic run at "
                                        "the equivalent of 0.62-0.74 (23-27 us per transform and CU), its loads and stores alone at 0.70-0.87; a CU's 512 KiB "
                                        "register file holds exactly two 2^16-point transforms, so no second one can be resident to cover the first")
@@ -616,7 +649,21 @@ def extras(ga, L, lib, stream, with_cpu):
         width = 4 if dt == L.U32 else 8
         gbs = 2.0 * width * N / (ms.value * 1e-3) / 1e9
         ex[tag] = {"ms": round(ms.value, 4), "points_per_s": round(N / (ms.value * 1e-3), 0), "algorithmic_GB/s": round(gbs, 1),
-                   "roofline_frac": round(gbs / HBM_PEAK_GBS, 4), "passes": 3}
+                   "roofline_frac": round(gbs / HBM_PEAK_GBS, 4), "passes": 3,
+                   "kernels": ([{"kernel": "ntt_m32_kernel<5, 4, 512, false, 1, false, 4>", "grid_x": 8192 * 512, "workgroup_x": 512, "launches": 2},
+                                {"kernel": "ntt_m32_kernel<4, 4, 256, false, 0, true, 4>", "grid_x": 16384 * 256, "workgroup_x": 256}]
+                               if dt == L.U32 else [{"kernel": "ntt_reg_kernel_gl", "launches": 3}])}
+        if dt == L.U32:
+            ex[tag]["physical_bytes_per_point"] = 25.2
+            ex[tag]["physical_bytes_source"] = ("profiles/r05_pmc_ntt_m32_three_pass.txt: (258 + 275) MiB x 2 + (259 + 290) MiB per 2^26 points; "
+                                                "static, not measured in this run")
+            # parity of the three-pass form in this very run: the inverse transform restores the input
+            bk = torch.empty_like(xd)
+            w = P._root_of_unity_int(N)
+            L.check(lib.gfa_ntt(P._handle, xd.data_ptr(), od.data_ptr(), N, 1, w, 0, dt, stream))
+            L.check(lib.gfa_ntt(P._handle, od.data_ptr(), bk.data_ptr(), N, 1, pow(w, p - 2, p), 1, dt, stream))
+            assert torch.equal(bk, xd), "2^26-point round trip"
+            del bk
         del xd, od
     M31 = ga.GF(2**31 - 1)
     ca = M31(np.random.default_rng(8).integers(0, 2**31 - 1, 1 << 20, dtype=np.int64))
@@ -630,7 +677,7 @@ def extras(ga, L, lib, stream, with_cpu):
     conv_ms = (time.perf_counter() - t1) / 5 * 1e3
     assert int(cc[0]) == int(ca[0] * cb[0]) and int(cc[-1]) == int(ca[-1] * cb[-1])
     ex["convolve_2^20x2^20_gf2147483647"] = {"ms": round(conv_ms, 3), "multiply_adds_equivalent_per_s": round(2.0**40 / (conv_ms * 1e-3), 0),
-                                            "route": "three 31-bit NTT primes + CRT inside gfa_convolve (no 2^21-th root of unity in the field)"}
+                                            "route": "three NTT primes below 2^29 (r05: on the signed-Montgomery kernels; r04: three 31-bit primes, 0.311 ms) + CRT inside gfa_convolve (no 2^21-th root of unity in the field)"}
     del ca, cb, cc
     # ---- RS(255,223): 2^17 codewords per GPU (= 2^20 over 8 GPUs), e ~ U{0..16} errors per codeword ----
     rs = ga.ReedSolomon(255, 223)

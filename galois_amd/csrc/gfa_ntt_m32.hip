@@ -627,6 +627,9 @@ int build_plan(M32Plan *pl, u64 p, i64 n, u64 omega, int split, hipStream_t st)
         // shortest in the last
         pl->log1 = (logn + 2) / 3;
         pl->log2 = (logn - pl->log1 + 1) / 2;
+        // r05 sweep of every split (tools/m32_tune3.py, profiles/r05_m32_tune3.txt): 2^24 and 2^26 are best at these defaults; 2^22 points
+        // run 23 % faster with 32-point lines in the first pass (tiles of 32 columns: whole 128-byte lines), 0.030 instead of 0.038 ms
+        if (logn == 22) { pl->log1 = 5; pl->log2 = 9; }
         if (split) { pl->log1 = split >> 8; pl->log2 = split & 0xff; }
         pl->log3 = logn - pl->log1 - pl->log2;
         if (pl->log1 < 5 || pl->log1 > 10 || pl->log2 < 5 || pl->log2 > 10 || pl->log3 < 5 || pl->log3 > 10) {
@@ -939,7 +942,9 @@ int ntt_m32(const FieldDev &fd, const void *in, void *out, void *ws, i64 n, i64 
                 a.in_batch_stride = L2; a.out_batch_stride = L0;
                 a.total_lines = L0;
                 a.load_along_line = 1; a.store_along_line = 0;
-                bool in_cache = (size_t)n * sizeof(i32) <= ((size_t)256 << 20); // the intermediate fits the Infinity Cache
+                // non-temporal last pass: measured per size (profiles/r05_m32_tune3.txt): 2^26 points 0.359 ms with, 0.406 without; 2^24 points
+                // 0.082 with, 0.076 without (the whole working set of a 64 MiB transform stays in the Infinity Cache on its own)
+                bool in_cache = (size_t)n * sizeof(i32) >= ((size_t)128 << 20);
                 if (g_m32_tune[2] >= 0) in_cache = g_m32_tune[2] != 0;
                 if ((rc = launch(cls, pl->log3, w, db, a, L1, pl->net3, pl->mid3, nullptr, nullptr, st, in_cache ? 2 : 0))) return rc;
             }

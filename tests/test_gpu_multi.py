@@ -42,6 +42,16 @@ def test_world_check_script_at_world_size_one():
     assert r.returncode == 0 and "dist world check ok 1" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_world_check_script_with_eight_ranks_on_one_gpu_over_gloo():
+    """r05: EIGHT processes, all on cuda:0, exchange over gloo through the host -- the 8-rank layout
+    bookkeeping of galois_amd.dist (column slices, the all-to-all's [peer][row][column] chunks, the row pass reading them in
+    place, the inverse consuming that layout) driven by real processes and the REAL kernels (gfa_ntt_columns_pitched,
+    gfa_ntt_chunked, ...), every rank's block against the whole transform; C5's own shape (2^10 x 2^16 over GF(469762049)) and
+    Goldilocks included.  What stays for real devices: the grouped ncclSend / ncclRecv halves inside gfa_ntt_dist."""
+    r = _launch([os.path.join(ROOT, "tools", "dist_world_check.py")], 8, 29590, {"GFA_DIST_CHECK_ONE_GPU": "1"}, timeout=1200)
+    assert r.returncode == 0 and "dist world check ok 8" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("nsub", ["2", "1"])
 def test_distributed_transform_over_two_gpus(nsub):
     """tools/dist_world_check.py at world size 2: torch.distributed collectives over RCCL, the four-step transform and its

@@ -96,8 +96,8 @@ def test_random_and_edge_operands_against_the_oracle(tag):
         A + 1
     with pytest.raises(TypeError):
         GF([1, 2], dtype=np.int64)
-    with pytest.raises(NotImplementedError):
-        np.add.reduceat(A, [0, 1])
+    # (reduceat / at / log / sqrt / fft on these fields: test_fft_sqrt_reduceat_and_at_on_the_big_fields_against_the_oracle)
+    assert int(np.add.reduceat(A, [0, len(a) - 1])[1]) == a[-1]
 
 
 def test_array_surface_of_a_big_field():
