@@ -113,11 +113,21 @@ def GF(*args, irreducible_poly=None, primitive_element=None, verify: bool = True
             raise ValueError(f"Argument 'degree' must be at least 1, not {m}.")
     else:
         raise TypeError("Argument '*args' must be of the form 'order' or 'characteristic, degree'.")
-    if p**m > 2**128 or (p**m == 2**128 and p != 2):  # before any number theory on q - 1 (factoring a 200-bit integer never returns)
-        raise NotImplementedError(
-            f"GF({p}^{m}) has order > 2^128. The reference represents such fields with dtype=object Python integers; the "
-            "device representation of galois_amd stops at two 64-bit limbs per element (GF(2^128) included)."
-        )
+    big = p**m > 2**128 or (p**m == 2**128 and p != 2)
+    if big:
+        # Orders above 2^128: k limbs per element (galois_amd/_big.py, up to 1024 bits).  The defaults of smaller fields need the
+        # factorisation of q - 1 (primitive root / element searches, primitivity of the polynomial), which is out of reach for a
+        # 200-bit integer in general (the reference's own defaults would not return either): the caller names both.
+        from ._big import limbs_for
+
+        limbs_for(p**m)  # NotImplementedError beyond 1024 bits
+        if primitive_element is None or (m > 1 and irreducible_poly is None):
+            raise ValueError(
+                f"GF({p}^{m}) has order > 2^128: pass `primitive_element=` (and `irreducible_poly=` for an extension field) explicitly; "
+                "the default searches factor q - 1, which is not feasible at this size."
+            )
+        if verify:
+            raise ValueError(f"GF({p}^{m}) has order > 2^128: pass `verify=False` (verifying a primitive element factors q - 1).")
     if compile is not None and compile not in ("auto", "jit-lookup", "jit-calculate"):
         raise ValueError(
             f"Argument 'compile' must be in ['auto', 'jit-lookup', 'jit-calculate'], not {compile!r} "
@@ -142,7 +152,7 @@ def GF(*args, irreducible_poly=None, primitive_element=None, verify: bool = True
             irr_int = 2 * p - alpha  # f(x) = x - alpha (_factory.py:405)
             _CLASSES[key] = _make_class(p, 1, irr_int, alpha, True, None)
     else:
-        prime_subfield = GF(p)
+        prime_subfield = GF(p) if p < 2**64 or not big else None  # (a prime subfield above 2^128 has no default generator either)
         is_primitive_poly = None
         verify_poly = verify
         verify_element = verify
@@ -175,7 +185,7 @@ def GF(*args, irreducible_poly=None, primitive_element=None, verify: bool = True
                     f"{nt.poly_str(nt.poly_from_int(alpha, p))} is not."
                 )
             if is_primitive_poly is None:
-                is_primitive_poly = nt.is_primitive_element([1, 0], coeffs, p)
+                is_primitive_poly = False if big else nt.is_primitive_element([1, 0], coeffs, p)  # (unknown above 2^128: not computed)
             _CLASSES[key] = _make_class(p, m, irr_int, alpha, is_primitive_poly, prime_subfield)
     field = _CLASSES[key]
     if compile is not None:
@@ -200,10 +210,7 @@ def _default_primitive_element(irr_int: int, p: int, verify_poly: bool) -> int:
 def _make_class(p: int, m: int, irr_int: int, alpha: int, is_primitive_poly: bool, prime_subfield) -> type:
     order = p**m
     if order > 2**128 or (order == 2**128 and p != 2):
-        raise NotImplementedError(
-            f"GF({p}^{m}) has order > 2^128. The reference represents such fields with dtype=object Python integers; the "
-            "device representation of galois_amd stops at two 64-bit limbs per element (GF(2^128) included)."
-        )
+        return _make_big_class(p, m, irr_int, alpha, is_primitive_poly, prime_subfield)
     if order >= 2**64:
         return _make_wide_class(p, m, irr_int, alpha, is_primitive_poly, prime_subfield)
     coeffs = nt.poly_from_int(irr_int, p)
@@ -268,6 +275,42 @@ def _make_wide_class(p: int, m: int, irr_int: int, alpha: int, is_primitive_poly
     import weakref
 
     weakref.finalize(cls, L.lib().gfa_wfield_destroy, handle)  # the class owns its device-side descriptor
+    return cls
+
+
+def _make_big_class(p: int, m: int, irr_int: int, alpha: int, is_primitive_poly: bool, prime_subfield) -> type:
+    """order > 2^128: 4, 8 or 16 limbs of 64 bits per element on the device (galois_amd/_big.py, csrc/gfa_big.hip)."""
+    from ._big import BigFieldArray, big_params, limbs_for
+
+    nl = limbs_for(p**m)
+    kind, words = big_params(p, m, irr_int, nl)
+    handle = ctypes.c_void_p()
+    arr = (ctypes.c_uint64 * 113)(*words)
+    L.check(L.lib().gfa_bfield_create(kind, m, nl, arr, ctypes.byref(handle)), f"GF({p}^{m})")
+    name = f"FieldArray_{p}_{alpha}" if m == 1 else f"FieldArray_{p}_{m}_{alpha}_{irr_int}"
+    ns = {
+        "_characteristic": p,
+        "_degree": m,
+        "_order": p**m,
+        "_irreducible_poly": IrreduciblePoly(irr_int, p),
+        "_primitive_element_int": alpha,
+        "_primitive_element_str": nt.poly_str(nt.poly_from_int(alpha, p)) if m > 1 else str(alpha),
+        "_is_primitive_poly": bool(is_primitive_poly),
+        "_prime_subfield": prime_subfield,
+        "_dtypes": [np.object_],
+        "_object_dtype": True,
+        "_ufunc_modes": ["jit-calculate"],
+        "_default_ufunc_mode": "jit-calculate",
+        "_handle": None,
+        "_wide_handle": handle,
+        "_NL": nl,
+        "__module__": __name__,
+        "__hash__": None,
+    }
+    cls = FieldArrayMeta(name, (BigFieldArray,), ns)
+    import weakref
+
+    weakref.finalize(cls, L.lib().gfa_bfield_destroy, handle)  # the class owns its device-side descriptor
     return cls
 
 

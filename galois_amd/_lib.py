@@ -61,6 +61,11 @@ SIGNATURES = {
     "gfa_wide_reduce": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p]),
     "gfa_wide_convolve": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p]),
     "gfa_wide_matmul": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_void_p]),
+    "gfa_bfield_create": (c_int, [c_int, c_u32, c_u32, _u64p, ctypes.POINTER(c_void_p)]),
+    "gfa_bfield_destroy": (None, [c_void_p]),
+    "gfa_big_binary": (c_int, [c_void_p, c_int, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p]),
+    "gfa_big_unary": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    "gfa_big_power": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
     "gfa_wide_row_reduce": (c_int, [c_void_p, c_void_p, c_i64, c_i64, c_i64, c_i64, c_void_p, c_void_p]),
     "gfa_wide_plu_decompose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gfa_wide_poly_evaluate": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p]),

@@ -60,19 +60,21 @@ def wide_params(p: int, m: int, irr_int: int) -> tuple[int, list[int]]:
     return kind, w
 
 
-def _split(values: np.ndarray) -> torch.Tensor:
-    """Object array of Python integers in [0, 2^128) -> int64 tensor (..., 2) of little-endian limbs."""
+def _split(values: np.ndarray, nl: int = 2) -> torch.Tensor:
+    """Object array of Python integers in [0, 2^(64 nl)) -> int64 tensor (..., nl) of little-endian limbs."""
     flat = [int(v) for v in values.ravel()]
-    limbs = np.empty((len(flat), 2), dtype=np.uint64)
+    limbs = np.empty((len(flat), nl), dtype=np.uint64)
     for i, v in enumerate(flat):
-        limbs[i, 0] = v & _M64
-        limbs[i, 1] = v >> 64
-    return torch.from_numpy(limbs.view(np.int64).reshape(tuple(values.shape) + (2,)))
+        for k in range(nl):
+            limbs[i, k] = (v >> (64 * k)) & _M64
+    return torch.from_numpy(limbs.view(np.int64).reshape(tuple(values.shape) + (nl,)))
 
 
 class WideFieldArray(FieldArray):
     _wide_handle = None
     _limbed = True
+    _NL = 2  # 64-bit limbs per element (galois_amd/_big.py: 4, 8 or 16 for orders above 2^128)
+    _kernels = ("gfa_wide_binary", "gfa_wide_unary", "gfa_wide_power")
 
     def __init__(self, x, dtype=None, copy: bool = True):
         cls = type(self)
@@ -87,7 +89,7 @@ class WideFieldArray(FieldArray):
         if isinstance(x, torch.Tensor):
             raise TypeError(f"{cls.name} arrays are built from Python integers (two 64-bit limbs per element on the device).")
         arr = cls._verify_host(x)
-        self._t = _split(np.asarray(arr, dtype=object)).to(_device())
+        self._t = _split(np.asarray(arr, dtype=object), cls._NL).to(_device())
 
     @classmethod
     def _verify_host(cls, x) -> np.ndarray:
@@ -131,7 +133,7 @@ class WideFieldArray(FieldArray):
 
     @property
     def size(self):
-        return self._t.numel() // 2
+        return self._t.numel() // type(self)._NL
 
     def __len__(self):
         if self.ndim == 0:
@@ -144,14 +146,16 @@ class WideFieldArray(FieldArray):
         return type(self)._wrap(self._t.permute(*reversed(range(n)), n).contiguous())
 
     def numpy(self) -> np.ndarray:
+        nl = type(self)._NL
         host = self._t.cpu().numpy().view(np.uint64)
         out = np.empty(host.shape[:-1], dtype=object)
         flat = out.reshape(-1) if out.ndim else None
-        limbs = host.reshape(-1, 2)
+        limbs = host.reshape(-1, nl)
+        join = lambda row: sum(int(row[k]) << (64 * k) for k in range(nl))
         if flat is None:
-            return np.array(int(limbs[0, 0]) | (int(limbs[0, 1]) << 64), dtype=object)
+            return np.array(join(limbs[0]), dtype=object)
         for i in range(limbs.shape[0]):
-            flat[i] = int(limbs[i, 0]) | (int(limbs[i, 1]) << 64)
+            flat[i] = join(limbs[i])
         return out
 
     def __int__(self):
@@ -166,10 +170,10 @@ class WideFieldArray(FieldArray):
 
     def reshape(self, *shape):
         shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
-        return type(self)._wrap(self._t.reshape(tuple(shape) + (2,)))
+        return type(self)._wrap(self._t.reshape(tuple(shape) + (type(self)._NL,)))
 
     def flatten(self):
-        return type(self)._wrap(self._t.reshape(-1, 2).clone())
+        return type(self)._wrap(self._t.reshape(-1, type(self)._NL).clone())
 
     ravel = flatten
 
@@ -207,7 +211,7 @@ class WideFieldArray(FieldArray):
     @classmethod
     def Zeros(cls, shape, dtype=None):
         shape = (shape,) if isinstance(shape, (int, np.integer)) else tuple(shape)
-        return cls._wrap(torch.zeros(shape + (2,), dtype=torch.int64, device=_device()))
+        return cls._wrap(torch.zeros(shape + (cls._NL,), dtype=torch.int64, device=_device()))
 
     @classmethod
     def Ones(cls, shape, dtype=None):
@@ -247,21 +251,22 @@ class WideFieldArray(FieldArray):
 
     @staticmethod
     def _bcast(a: torch.Tensor, b: torch.Tensor):
+        nl = a.shape[-1]
         sa, sb = tuple(a.shape[:-1]), tuple(b.shape[:-1])
         shape = tuple(torch.broadcast_shapes(sa, sb))
-        na, nb = a.numel() // 2, b.numel() // 2
+        na, nb = a.numel() // nl, b.numel() // nl
         n = int(np.prod(shape)) if shape else 1
-        ta, stra = (a.reshape(-1, 2).contiguous(), 0) if na == 1 and n != 1 else (a.expand(shape + (2,)).contiguous(), 1)
-        tb, strb = (b.reshape(-1, 2).contiguous(), 0) if nb == 1 and n != 1 else (b.expand(shape + (2,)).contiguous(), 1)
+        ta, stra = (a.reshape(-1, nl).contiguous(), 0) if na == 1 and n != 1 else (a.expand(shape + (nl,)).contiguous(), 1)
+        tb, strb = (b.reshape(-1, nl).contiguous(), 0) if nb == 1 and n != 1 else (b.expand(shape + (nl,)).contiguous(), 1)
         return ta, stra, tb, strb, shape, n
 
     def _binary(self, op, a, b):
         cls = type(self)
         ta, sa, tb, sb, shape, n = self._bcast(a._t, b._t)
-        out = torch.empty(shape + (2,), dtype=torch.int64, device=ta.device)
+        out = torch.empty(shape + (cls._NL,), dtype=torch.int64, device=ta.device)
         err = torch.zeros(1, dtype=torch.int32, device=ta.device) if op == L.OP_DIV else None
-        L.check(L.lib().gfa_wide_binary(cls._wide_handle, op, _ptr(ta), sa, _ptr(tb), sb, _ptr(out), n, _stream(),
-                                        _ptr(err) if err is not None else None), "gfa_wide_binary")
+        L.check(getattr(L.lib(), cls._kernels[0])(cls._wide_handle, op, _ptr(ta), sa, _ptr(tb), sb, _ptr(out), n, _stream(),
+                                                  _ptr(err) if err is not None else None), cls._kernels[0])
         if err is not None:
             self._check_err(err)
         return cls._wrap(out)
@@ -271,8 +276,8 @@ class WideFieldArray(FieldArray):
         t = self._t.contiguous()
         out = torch.empty_like(t)
         err = torch.zeros(1, dtype=torch.int32, device=t.device) if op == L.OP_RECIP else None
-        L.check(L.lib().gfa_wide_unary(cls._wide_handle, op, _ptr(t), _ptr(out), t.numel() // 2, _stream(),
-                                       _ptr(err) if err is not None else None), "gfa_wide_unary")
+        L.check(getattr(L.lib(), cls._kernels[1])(cls._wide_handle, op, _ptr(t), _ptr(out), t.numel() // cls._NL, _stream(),
+                                                  _ptr(err) if err is not None else None), cls._kernels[1])
         if err is not None:
             self._check_err(err)
         return cls._wrap(out)
@@ -297,13 +302,13 @@ class WideFieldArray(FieldArray):
         flat = [int(v) for v in ks.ravel()]
         e_red = np.array([v % qm1 for v in flat], dtype=object).reshape(ks.shape)
         sign = torch.from_numpy(np.array([(v > 0) - (v < 0) for v in flat], dtype=np.int8).reshape(ks.shape)).to(self._t.device)
-        te = _split(e_red).to(self._t.device)
+        te = _split(e_red, cls._NL).to(self._t.device)
         ta, sa, te2, se, shape, n = self._bcast(self._t, te)
         sg = sign.reshape(-1) if se == 0 else sign.expand(shape).contiguous()
-        out = torch.empty(shape + (2,), dtype=torch.int64, device=ta.device)
+        out = torch.empty(shape + (cls._NL,), dtype=torch.int64, device=ta.device)
         err = torch.zeros(1, dtype=torch.int32, device=ta.device)
-        L.check(L.lib().gfa_wide_power(cls._wide_handle, _ptr(ta), sa, _ptr(te2), se, _ptr(sg), _ptr(out), n, _stream(), _ptr(err)),
-                "gfa_wide_power")
+        L.check(getattr(L.lib(), cls._kernels[2])(cls._wide_handle, _ptr(ta), sa, _ptr(te2), se, _ptr(sg), _ptr(out), n, _stream(), _ptr(err)),
+                cls._kernels[2])
         self._check_err(err)
         return cls._wrap(out)
 
@@ -385,7 +390,7 @@ class WideFieldArray(FieldArray):
     # formulas as FieldArray._sqrt on the two-limb power kernel) ----
     def _eq_int(self, value: int) -> torch.Tensor:
         """Device bool mask: element == value (limb-wise)."""
-        lim = torch.tensor([value & _M64, value >> 64], dtype=torch.uint64).view(torch.int64).to(self._t.device)
+        lim = torch.from_numpy(np.array([(value >> (64 * k)) & _M64 for k in range(type(self)._NL)], dtype=np.uint64).view(np.int64)).to(self._t.device)
         return (self._t == lim).all(dim=-1)
 
     def _select(self, mask: torch.Tensor, a: "WideFieldArray", b: "WideFieldArray") -> "WideFieldArray":
@@ -442,8 +447,10 @@ class WideFieldArray(FieldArray):
         # np.minimum(roots, -roots) on the integer values: compare (hi, lo) as unsigned
         def ukey(t):
             return t ^ torch.iinfo(torch.int64).min
-        rh, rl, nh, nl = ukey(roots._t[..., 1]), ukey(roots._t[..., 0]), ukey(neg._t[..., 1]), ukey(neg._t[..., 0])
-        neg_smaller = (nh < rh) | ((nh == rh) & (nl < rl))
+        neg_smaller = torch.zeros(tuple(self.shape), dtype=torch.bool, device=self._t.device)
+        for k in range(cls._NL):  # limb 0 first: the comparison of a higher limb overrides it unless that limb is equal
+            a, b = ukey(neg._t[..., k]), ukey(roots._t[..., k])
+            neg_smaller = (a < b) | ((a == b) & neg_smaller)
         return self._select(neg_smaller, neg, roots)
 
     # ---- discrete logarithm: Pohlig-Hellman over the factorisation of q - 1 with baby-step / giant-step inside each prime
@@ -530,13 +537,13 @@ class WideFieldArray(FieldArray):
         for s0 in range(0, n, chunk):
             hs = type(self)._wrap(h._t[s0:s0 + chunk])
             prod = hs.reshape((hs.size, 1)) * gpow.reshape((1, m + 1))  # (rows, m + 1): h * gamma^(-m a)
-            lo, hi = prod._t[..., 0].contiguous(), prod._t[..., 1]
+            lo = prod._t[..., 0].contiguous()
             pos = torch.searchsorted(keys, lo).clamp(max=m - 1)
             hit = torch.zeros_like(lo, dtype=torch.bool)
             jidx = torch.zeros_like(lo)
             for probe in range(4):  # equal low limbs among the baby steps are astronomically rare; four neighbours are searched anyway
                 pp = (pos + probe).clamp(max=m - 1)
-                ok = (baby_sorted[pp, 0] == lo) & (baby_sorted[pp, 1] == hi) & ~hit
+                ok = (baby_sorted[pp] == prod._t).all(dim=-1) & ~hit
                 jidx = torch.where(ok, order[pp], jidx)
                 hit |= ok
             hit_c, j_c = hit.cpu().numpy(), jidx.cpu().numpy()

@@ -194,6 +194,21 @@ int gfa_wide_plu_decompose(gfa_wfield_t *w, void *a, void *l_out, void *p_out, i
                            int64_t *nperm_out, void *det_out, gfa_stream_t stream, int32_t *dev_err);
 int gfa_wide_poly_evaluate(gfa_wfield_t *w, const void *coeffs, int64_t ncoef, const void *x, void *out, int64_t n, gfa_stream_t stream);
 
+/* ---- Fields of order above 2^128 (r05; the reference has no upper bound: _domains/_meta.py:38-41, same scalar formulas) --------- *
+ * Elements are nl = 4, 8 or 16 little-endian uint64 limbs, interleaved.  Kinds as gfa_wfield_create (1 GF(p), 2 GF(2^m) with
+ * m <= 64 nl, 3 GF(p^m) with p < 2^32 and m <= 32).  `params` (113 uint64 words, computed by the host): [0:16] p, [16] -p^-1 mod 2^64,
+ * [17:33] 2^(128 nl) mod p, [33:49] p - 2 (kind 1) or 2^m - 2 (kind 2), [49:65] the irreducible polynomial without x^m (kind 2),
+ * [65:81] (q-1)/(p-1) - 1 (kind 3), [81:113] digits of the irreducible polynomial minus x^m, degree m-1..0 (kind 3).
+ * gfa_big_binary / unary / power: the element-wise ufuncs with the argument meaning of gfa_wide_binary / unary / power. */
+typedef struct gfa_bfield gfa_bfield_t;
+int gfa_bfield_create(int kind, uint32_t m, uint32_t nl, const uint64_t *params, gfa_bfield_t **out);
+void gfa_bfield_destroy(gfa_bfield_t *w);
+int gfa_big_binary(gfa_bfield_t *w, int op, const void *a, int64_t sa, const void *b, int64_t sb, void *out, int64_t n,
+                   gfa_stream_t stream, int32_t *dev_err);
+int gfa_big_unary(gfa_bfield_t *w, int op, const void *a, void *out, int64_t n, gfa_stream_t stream, int32_t *dev_err);
+int gfa_big_power(gfa_bfield_t *w, const void *a, int64_t sa, const void *exps, int64_t se, const int8_t *sign, void *out,
+                  int64_t n, gfa_stream_t stream, int32_t *dev_err);
+
 /* ---- NTT: replaces fft_jit/ifft_jit `self.jit(x.astype(int64), int64(omega), factors)` (_domains/_function.py:201) *
  * Computes out[k] = sum_j in[j] * omega^(j*k) for each of `batch` contiguous length-n rows, natural order in and
  * out.  `omega` must be a primitive n-th root of unity (for the inverse pass omega^-1, as fft_jit.__call__ does at

@@ -385,7 +385,4 @@ def test_the_ghash_field_gf_2_128():
     H.assert_equal_ints((y ** -3).numpy(), np.array([W.pow(v, -3) for v in b], dtype=object))
     with pytest.raises(ValueError):
         GF(np.array([2**128], dtype=object))
-    with pytest.raises(NotImplementedError):
-        ga.GF(2, 129, irreducible_poly=(1 << 129) | 0x21, verify=False)
-    with pytest.raises(NotImplementedError):
-        ga.GF(2**89 - 1, 2, irreducible_poly=[1, 0, 3], verify=False)  # order 2^178
+    # (orders above 2^128: the k-limb fields of tests/test_gpu_big.py)
