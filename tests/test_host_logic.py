@@ -75,11 +75,19 @@ def test_flyweights_and_properties():
         ga.GF(31, primitive_element=5)
     with pytest.raises(TypeError):
         ga.GF(2.0)
-    # orders in [2^64, 2^128) get the two-limb device representation (the reference: dtype=object); above that there is none
+    # orders in [2^64, 2^128] get the two-limb device representation (the reference: dtype=object); above that 4 / 8 / 16 limbs, with the
+    # polynomial and the primitive element named by the caller (their default searches factor q - 1); beyond 1024 bits nothing
     big = ga.GF(36893488147419103183, primitive_element=3)
     assert big.dtypes == [np.object_] and big.order == 36893488147419103183 and big.ufunc_modes == ["jit-calculate"]
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="primitive_element"):
         ga.GF(2**127 - 1, 2, irreducible_poly=[1, 0, 1], verify=False)
+    with pytest.raises(NotImplementedError):  # extension fields keep base-p digits of 32 bits on the device: p < 2^32
+        ga.GF(2**127 - 1, 2, irreducible_poly=[1, 0, 1], primitive_element=[1, 3], verify=False)
+    k4 = ga.GF(65537, 12, irreducible_poly=[1] + [0] * 10 + [1, 2], primitive_element=[1, 0], verify=False)
+    assert k4._NL == 4 and k4.order == 65537**12 and k4.dtypes == [np.object_]
+    assert ga.GF(2**521 - 1, primitive_element=3, verify=False)._NL == 16
+    with pytest.raises(NotImplementedError):
+        ga.GF(2, 1025, irreducible_poly=(1 << 1025) | 3, primitive_element=2, verify=False)
 
 
 def test_dtypes_follow_the_reference_rules():
