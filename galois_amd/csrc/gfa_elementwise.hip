@@ -1537,6 +1537,16 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
             }
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
+        // the same fields held as uint32 / int64 arrays, lookup mode (calculate mode keeps the arithmetic kernels, which stream)
+        if (f->use_lookup() && !trivial_addsub && !(op == GFA_OP_MUL && c.p == 2 && c.m == 16) && big16_wide_eligible(c, ds->mid16, dtype, n)) {
+            rc = big16_run_wide(f->lut_desc(*ds), ds->mid16, dtype, op, a, sa, b, sb, nullptr, out, n, st, dev_err);
+            if (rc == GFA_OK && (n & 7)) {
+                const i64 o = n & ~(i64)7, es = dtype == GFA_U32 ? 4 : 8;
+                return dispatch_binary(f->lut_desc(*ds), dtype, op, (const char *)a + (sa ? o * es : 0), sa, (const char *)b + (sb ? o * es : 0), sb,
+                                       (char *)out + o * es, n & 7, st, dev_err);
+            }
+            if (rc != GFA_ERR_UNSUPPORTED) return rc;
+        }
     }
     if (f->use_lookup()) {
         const FieldDev &c = f->calc;
@@ -1576,6 +1586,14 @@ int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int d
                 const i64 o = n & ~(i64)7;
                 const FieldDev td = f->use_lookup() ? f->lut_desc(*ds) : f->calc;
                 return dispatch_unary(td, dtype, op, (const uint16_t *)a + o, (uint16_t *)out + o, n & 7, st, dev_err);
+            }
+            if (rc != GFA_ERR_UNSUPPORTED) return rc;
+        }
+        if (f->use_lookup() && !trivial_neg && big16_wide_eligible(c, ds->mid16, dtype, n)) {
+            rc = big16_run_wide(f->lut_desc(*ds), ds->mid16, dtype, op, a, 1, nullptr, 0, nullptr, out, n, st, dev_err);
+            if (rc == GFA_OK && (n & 7)) {
+                const i64 o = n & ~(i64)7, es = dtype == GFA_U32 ? 4 : 8;
+                return dispatch_unary(f->lut_desc(*ds), dtype, op, (const char *)a + o * es, (char *)out + o * es, n & 7, st, dev_err);
             }
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }

@@ -842,4 +842,62 @@ int big16_run(const FieldDev &lut, const void *image, int op, const void *a, i64
     }
 }
 
+// ---- uint32 / int64 STORAGE of fields with 32768 < q <= 65536 (r05; the reference's dtype list: _fields/_ufunc.py:97-111) ----
+// The staged-table kernels above work on 16-bit vectors.  A wider array is narrowed into a 16-bit work buffer (one streaming pass per
+// operand), run through them, and the result widened again: 24 instead of 12 B/element cross the memory system for uint32 (40 instead
+// of 24 for int64), against table gathers from L2 on the generic kernels.
+template <typename T>
+__global__ __launch_bounds__(256) void narrow16_kernel(const T *__restrict__ in, u16 *__restrict__ out, i64 n)
+{
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) out[i] = (u16)in[i];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void widen16_kernel(const u16 *__restrict__ in, T *__restrict__ out, i64 n)
+{
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) out[i] = (T)in[i];
+}
+
+bool big16_wide_eligible(const FieldDev &calc, const void *image, int dtype, i64 n)
+{
+    return image != nullptr && (dtype == GFA_U32 || dtype == GFA_U64) && calc.q > 32768 && calc.q <= 65536 && n >= BIG16_MIN_N;
+}
+
+// covers the first n & ~7 elements (as big16_run); the caller runs the generic kernels on the rest
+template <typename T>
+int big16_run_wide_t(const FieldDev &lut, const void *image, int op, const T *a, i64 sa, const T *b, i64 sb, const i64 *e, T *out, i64 n, hipStream_t st,
+                     int32_t *err)
+{
+    const i64 n8 = n & ~(i64)7;
+    if (n8 == 0) return GFA_OK;
+    const i64 na = sa ? n8 : 8, nb = b ? (sb ? n8 : 8) : 0;
+    u16 *wa = nullptr, *wb = nullptr, *wo = nullptr;
+    if (gfa::scratch_alloc((void **)&wa, sizeof(u16) * (size_t)(na + nb + n8) + 64, st) != hipSuccess) {
+        (void)hipGetLastError();
+        return GFA_ERR_UNSUPPORTED; // no work buffer: the generic kernels take the call
+    }
+    wb = wa + ((na + 7) & ~(i64)7);
+    wo = wb + ((nb + 7) & ~(i64)7);
+    const int grid = (int)std::min<i64>((n8 + 255) / 256, 256 * 16);
+    if (sa) hipLaunchKernelGGL((narrow16_kernel<T>), dim3(grid), dim3(256), 0, st, a, wa, n8);
+    else hipLaunchKernelGGL((narrow16_kernel<T>), dim3(1), dim3(64), 0, st, a, wa, (i64)1);
+    if (b) {
+        if (sb) hipLaunchKernelGGL((narrow16_kernel<T>), dim3(grid), dim3(256), 0, st, b, wb, n8);
+        else hipLaunchKernelGGL((narrow16_kernel<T>), dim3(1), dim3(64), 0, st, b, wb, (i64)1);
+    }
+    int rc = big16_run(lut, image, op, wa, sa, b ? wb : nullptr, sb, e, wo, n8, st, err);
+    if (rc == GFA_OK) {
+        hipLaunchKernelGGL((widen16_kernel<T>), dim3(grid), dim3(256), 0, st, (const u16 *)wo, out, n8);
+        if (hipGetLastError() != hipSuccess) rc = GFA_ERR_HIP;
+    }
+    (void)gfa::scratch_free(wa, st);
+    return rc;
+}
+
+int big16_run_wide(const FieldDev &lut, const void *image, int dtype, int op, const void *a, i64 sa, const void *b, i64 sb, const i64 *e, void *out, i64 n,
+                   hipStream_t st, int32_t *err)
+{
+    if (dtype == GFA_U32) return big16_run_wide_t<u32>(lut, image, op, (const u32 *)a, sa, (const u32 *)b, sb, e, (u32 *)out, n, st, err);
+    return big16_run_wide_t<u64>(lut, image, op, (const u64 *)a, sa, (const u64 *)b, sb, e, (u64 *)out, n, st, err);
+}
+
 } // namespace gfa

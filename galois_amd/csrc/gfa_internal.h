@@ -82,6 +82,10 @@ int mid_power_each(const FieldDev &lut, const void *image, const void *a, const 
 // 32768 < q <= 65536 on uint16 storage: LOG, then EXP, staged in LDS in two phases per tile; op in {MUL, DIV, RECIP, POW (one
 // exponent at e[0])}.  Covers the first n & ~7 elements -- the caller runs the generic kernels on the last n & 7.
 bool big16_eligible(const FieldDev &calc, const void *image, int dtype, i64 n);
+// uint32 / int64 storage of the same fields: narrowed into a 16-bit work buffer, run, widened (first n & ~7 elements)
+bool big16_wide_eligible(const FieldDev &calc, const void *image, int dtype, i64 n);
+int big16_run_wide(const FieldDev &lut, const void *image, int dtype, int op, const void *a, i64 sa, const void *b, i64 sb, const i64 *e, void *out, i64 n,
+                   hipStream_t st, int32_t *err);
 int big16_run(const FieldDev &lut, const void *image, int op, const void *a, i64 sa, const void *b, i64 sb, const i64 *e, void *out, i64 n,
               hipStream_t st, int32_t *err);
 
