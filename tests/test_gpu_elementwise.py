@@ -986,14 +986,14 @@ def test_wide_storage_of_fields_between_2e15_and_2e16_elements(order, dt):
     a = rng.integers(0, order, n, dtype=np.uint64)
     b = rng.integers(1, order, n, dtype=np.uint64)
     a[:4] = (0, order - 1, 1, 0)
-    x, y = GF(a.astype(dt)), GF(b.astype(dt))
+    x, y = GF(a.astype(dt), dtype=dt), GF(b.astype(dt), dtype=dt)
     assert x.dtype == np.dtype(dt)
     for name, got in (("add", x + y), ("sub", x - y), ("mul", x * y), ("div", x / y)):
         assert got.dtype == np.dtype(dt)
         H.assert_equal_ints(got.numpy().astype(np.uint64), getattr(F, name)(a, b), f"GF({order}) {np.dtype(dt).name} {name}")
     H.assert_equal_ints(np.reciprocal(y).numpy().astype(np.uint64), F.div(np.ones(n, dtype=np.uint64), b), "reciprocal")
     H.assert_equal_ints((-x).numpy().astype(np.uint64), F.sub(np.zeros(n, dtype=np.uint64), a), "negative")
-    s = GF(np.array(int(b[7]), dtype=dt))
+    s = GF(np.array(int(b[7]), dtype=dt), dtype=dt)
     H.assert_equal_ints((x * s).numpy().astype(np.uint64), F.mul(a, np.full(n, b[7], dtype=np.uint64)), "broadcast scalar")
     with pytest.raises(ZeroDivisionError):
         y / x

@@ -122,8 +122,8 @@ def test_array_surface_of_a_big_field():
     rr = GF.Random((4, 5), seed=3)
     assert rr.shape == (4, 5) and all(0 <= int(v) < q for v in rr.numpy().ravel())
     assert repr(GF(np.array([1, 2], dtype=object))).startswith("GF([1, 2]")
-    with pytest.raises(NotImplementedError):
-        ga.GF(2**127 - 1, 2, irreducible_poly=[1, 0, 1], verify=False)  # order >= 2^128: no device representation
+    with pytest.raises(NotImplementedError):  # (orders above 2^128: tests/test_gpu_big.py; extension fields there keep p < 2^32)
+        ga.GF(2**127 - 1, 2, irreducible_poly=[1, 0, 1], primitive_element=[1, 3], verify=False)
 
 
 def test_data_movement_functions_never_touch_the_limb_axis():
