@@ -6,8 +6,9 @@ trailing limb axis; up to 1024 bits) and the element-wise ufunc surface runs in 
 multiply, divide, negative, reciprocal, power (arbitrary-size integer exponents), field * integer, square, ==, indexing and
 reshaping.  ufunc.reduce / accumulate (np.sum, prod, cumsum, cumprod) are left folds of those kernels along the axis.  Exact
 and simple, not fast: a coverage path, like the two-limb fields of galois_amd/_wide.py whose array surface this class inherits.
-What the two-limb fields have and these do not (NotImplementedError): `where=` masks, np.convolve, @, row reduction, np.log, np.sqrt,
-np.fft, polynomial evaluation, and the NumPy data-movement functions beyond reshape / transpose / concatenate / stack / where / copy.
+`where=` on calls, np.convolve and @ are compositions of those kernels.  What the two-limb fields have and these do not
+(NotImplementedError): `where=` on reductions, row reduction, np.log, np.sqrt, np.fft, polynomial evaluation, and the NumPy data-movement
+functions beyond reshape / transpose / concatenate / stack / where / copy.
 """
 from __future__ import annotations
 
@@ -115,6 +116,57 @@ class BigFieldArray(WideFieldArray):
             return self._binary(op, init.reshape(()), r)
         return r
 
+    # ---- `where=` on calls, np.convolve and @ as compositions of the element-wise kernels (slow and exact) ----
+    def _ufunc_masked(self, ufunc, method, where, inputs, kwargs):
+        cls = type(self)
+        out = kwargs.pop("out", None)
+        target = (out[0] if isinstance(out, tuple) else out) if out is not None else None
+        if method == "outer":
+            a, b = inputs
+            inputs = (a.reshape(tuple(a.shape) + (1,) * b.ndim), b.reshape((1,) * a.ndim + tuple(b.shape)))
+        shapes = [tuple(x.shape) if isinstance(x, FieldArray) else np.shape(x) for x in inputs]
+        wshape = tuple(where.shape) if isinstance(where, torch.Tensor) else np.shape(where)
+        full = tuple(np.broadcast_shapes(*shapes, wshape))
+        mask = self._where_mask(where, full).unsqueeze(-1)
+        one = cls.Ones(())._t
+        safe = [cls._wrap(torch.where(mask, x._t.expand(full + (cls._NL,)), one).contiguous()) if isinstance(x, cls) else x for x in inputs]
+        res = super().__array_ufunc__(ufunc, "__call__", *safe, **kwargs)
+        if not isinstance(res, cls):
+            self._no(f"The `where=` keyword of np.{ufunc.__name__}")
+        tr = res._t.expand(full + (cls._NL,))
+        if target is not None:
+            if not isinstance(target, cls):
+                raise TypeError(f"Argument 'out' must be a {cls.name} array (or a 1-tuple holding one), not {type(target)}.")
+            if tuple(target.shape) != full:
+                raise ValueError(f"non-broadcastable output operand with shape {tuple(target.shape)} doesn't match the broadcast shape {full}")
+            target._t.copy_(torch.where(mask, tr, target._t))
+            return target
+        return cls._wrap(torch.where(mask, tr, torch.zeros((), dtype=torch.int64, device=tr.device)).contiguous())
+
+    def _convolve(self, other):
+        cls = type(self)
+        na, nb = self.size, other.size
+        acc = cls.Zeros(na + nb - 1)
+        for i in range(na):  # out[i : i + nb] += a[i] * b
+            acc._t[i:i + nb] = (cls._wrap(acc._t[i:i + nb].contiguous()) + self[i] * other)._t
+        return acc
+
+    def _matmul(self, other):
+        # (..., M, K) @ (..., K, N): products of every (row, column) pair, then a left fold over K, as matmul_jit sums them
+        a = self.reshape((1, self.size)) if self.ndim == 1 else self
+        b = other.reshape((other.size, 1)) if other.ndim == 1 else other
+        if a.shape[-1] != b.shape[-2]:
+            raise ValueError(f"Operation 'matmul' requires the last dimension of 'A' to match the second-to-last dimension of 'B', not {tuple(self.shape)} and {tuple(other.shape)}.")
+        prod = a.reshape(tuple(a.shape) + (1,)) * b.reshape(tuple(b.shape[:-2]) + (1,) + tuple(b.shape[-2:]))  # (..., M, K, N)
+        r = prod._reduce(L.OP_ADD, -2, False)
+        if self.ndim == 1 and other.ndim == 1:
+            return r.reshape(tuple(r.shape[:-2]))
+        if self.ndim == 1:
+            return r.reshape(tuple(r.shape[:-2]) + (r.shape[-1],))
+        if other.ndim == 1:
+            return r.reshape(tuple(r.shape[:-1]))
+        return r
+
     # ---- the complex128 bit-container trick of the two-limb fields does not extend to k limbs: the NumPy functions served here
     # work on the storage tensor with its limb axis kept last ----
     def _af_tens(self, v):
@@ -124,7 +176,13 @@ class BigFieldArray(WideFieldArray):
 
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
         if self._kw_given(kwargs.get("where", None)) and method in ("__call__", "outer"):
-            self._no("The `where=` keyword")
+            where = kwargs.pop("where")
+            return self._ufunc_masked(ufunc, method, where, inputs, kwargs)
+        if ufunc is np.matmul and method == "__call__":
+            cls = type(self)
+            if not (isinstance(inputs[0], cls) and isinstance(inputs[1], cls)):
+                raise TypeError(f"Operation 'matmul' requires both operands to be arrays over {cls.name}.")
+            return inputs[0]._matmul(inputs[1])
         if method == "outer":
             a, b = inputs
             cls = type(self)
@@ -149,6 +207,10 @@ class BigFieldArray(WideFieldArray):
             op = L.OP_ADD if func is np.cumsum else L.OP_MUL
             axis = args[1] if len(args) > 1 else kwargs.get("axis", None)
             return x.reshape(-1)._accumulate(op, 0) if axis is None else x._accumulate(op, axis)
+        if func is np.convolve and isinstance(x, cls) and isinstance(args[1], cls):
+            if x.ndim != 1 or args[1].ndim != 1 or x.size == 0 or args[1].size == 0:
+                raise ValueError("Operation 'convolve' requires non-empty 1-D arrays.")
+            return x._convolve(args[1])
         if func is np.reshape:
             return x.reshape(args[1] if len(args) > 1 else kwargs.get("shape", kwargs.get("newshape")))
         if func is np.ravel:
@@ -187,4 +249,4 @@ class BigFieldArray(WideFieldArray):
     def _unsupported(self, *a, **k):
         self._no("This operation")
 
-    _reduceat = _at = _sqrt = log = is_square = _convolve = _fft = _poly_evaluate = _dft = _unsupported
+    _reduceat = _at = _sqrt = log = is_square = _fft = _poly_evaluate = _dft = _unsupported

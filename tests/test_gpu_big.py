@@ -127,8 +127,27 @@ def test_folds_and_array_surface_of_the_k_limb_fields(tag):
     assert int(np.add.reduce(x[0], initial=GF(9))) == W.add(9, left_fold(W.add, h[0])[-1])
     assert np.sum(x, axis=1, keepdims=True).shape == (4, 1)
     H.assert_equal_ints(np.multiply.outer(x[0, :3], x[1, :2]).numpy(), np.array([[W.mul(int(u), int(v)) for v in h[1, :2]] for u in h[0, :3]], dtype=object))
-    for bad in (lambda: np.add(x, x, where=cond), lambda: np.convolve(x[0], x[1]), lambda: x @ x.T, lambda: np.log(x), lambda: np.sqrt(x),
-                lambda: np.sort(x)):
+    # compositions of the element-wise kernels: where= on calls, np.convolve, @
+    old = GF(h[::-1].copy())
+    got = np.multiply(x, x, where=cond, out=old)
+    H.assert_equal_ints(got.numpy(), np.where(cond, np.array([[W.mul(int(v), int(v)) for v in r] for r in h], dtype=object), h[::-1]), f"{tag} where=")
+    cv = np.convolve(x[0], x[1, :4])
+    want = [0] * 9
+    for i, u in enumerate(h[0]):
+        for j, v in enumerate(h[1, :4]):
+            want[i + j] = W.add(want[i + j], W.mul(int(u), int(v)))
+    H.assert_equal_ints(cv.numpy(), _obj(want), f"{tag} convolve")
+    mm = x @ x.T
+    wm = [[0] * 4 for _ in range(4)]
+    for i in range(4):
+        for j in range(4):
+            acc = 0
+            for k in range(6):
+                acc = W.add(acc, W.mul(int(h[i, k]), int(h[j, k])))
+            wm[i][j] = acc
+    H.assert_equal_ints(mm.numpy(), np.array(wm, dtype=object), f"{tag} matmul")
+    H.assert_equal_ints((x @ x[0]).numpy(), _obj(wm[i][0] for i in range(4)))
+    for bad in (lambda: np.add.reduce(x, where=cond, initial=0), lambda: np.log(x), lambda: np.sqrt(x), lambda: np.sort(x), lambda: np.linalg.inv(mm)):
         with pytest.raises(NotImplementedError):
             bad()
 
