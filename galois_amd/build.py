@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libgalois_amd.so")
-SOURCES = ["gfa_field.hip", "gfa_elementwise.hip", "gfa_elementwise_mid.hip", "gfa_ntt.hip", "gfa_ntt_m32.hip", "gfa_ntt_fermat.hip", "gfa_dist.hip", "gfa_wide.hip", "gfa_big.hip", "gfa_rs.hip", "gfa_linalg.hip", "gfa_matmul_mfma.hip", "gfa_dlog.hip", "gfa_conv_crt.hip", "gfa_rs_wide.hip"]
+SOURCES = ["gfa_field.hip", "gfa_elementwise.hip", "gfa_elementwise_mid.hip", "gfa_elementwise_packed.hip", "gfa_ntt.hip", "gfa_ntt_m32.hip", "gfa_ntt_fermat.hip", "gfa_dist.hip", "gfa_wide.hip", "gfa_big.hip", "gfa_rs.hip", "gfa_linalg.hip", "gfa_matmul_mfma.hip", "gfa_dlog.hip", "gfa_conv_crt.hip", "gfa_rs_wide.hip"]
 import glob
 HEADERS = sorted(glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.inc"))) + [
     os.path.join(HERE, "..", "include", "galois_amd.h")]

@@ -1505,6 +1505,12 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
+    // r05: sums and differences of odd-characteristic extension fields whose Zech tables leave LDS (8192 < q <= 2^20), in either mode:
+    // packed base-p digits (gfa_elementwise_packed.hip) -- same values as the table and the digit-vector routes
+    if ((op == GFA_OP_ADD || op == GFA_OP_SUB) && packed_eligible(f->calc, dtype, n)) {
+        rc = packed_run(f->calc, dtype, op, a, sa, b, sb, out, n, st);
+        if (rc != GFA_ERR_UNSUPPORTED) return rc;
+    }
     if (f->mode != GFA_MODE_CALCULATE) {
         // uint16 storage, tables in LDS (gfa_elementwise_mid.hip), unless the field was pinned to explicit calculation:
         //  * 256 < q <= 32768 (LOG and EXP both resident): every operation that is not a plain xor / modular add (measured 0.7-0.8
@@ -1573,6 +1579,10 @@ int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int d
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
+    if (op == GFA_OP_NEG && packed_eligible(f->calc, dtype, n)) { // r05: packed base-p digits, as in gfa_binary
+        rc = packed_run(f->calc, dtype, GFA_OP_NEG, a, 1, nullptr, 0, out, n, st);
+        if (rc != GFA_ERR_UNSUPPORTED) return rc;
+    }
     if (f->mode != GFA_MODE_CALCULATE) { // tables in LDS, as in gfa_binary
         const FieldDev &c = f->calc;
         const bool trivial_neg = op == GFA_OP_NEG && (c.p == 2 || c.m == 1);

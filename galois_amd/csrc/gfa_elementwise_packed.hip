@@ -1,0 +1,161 @@
+// gfa_elementwise_packed.hip -- np.add / np.subtract / np.negative over GF(p^m), p odd, 8192 < q <= 2^20, as packed-digit arithmetic.
+//
+// Replaces, for these fields, the reference's add / subtract / negative ufuncs in BOTH of its modes -- the Zech-logarithm lookups
+// (src/galois/_domains/_lookup.py:31-60, 89-150) and the digit-vector loops (_calculate.py:150-285) -- with the scheme of
+// gfa_packed.h: two small LDS tables turn an integer into its base-p digits packed W bits apart, the m digit sums and their
+// conditional subtractions are six integer instructions on that word, a few chunk tables turn it back.  The tables of these
+// fields do not fit LDS together (32768 < q <= 65536: one staged at a time, GF(3^10) sums 0.26 of the roofline) or at all
+// (q > 65536: gathers from L2, GF(7^7) sums 0.04); this kernel needs 3-41 KiB of LDS whatever the order and streams.
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#include "gfa_internal.h"
+#include "gfa_packed.h"
+
+using namespace gfa;
+using namespace gfa_packed;
+
+namespace {
+
+constexpr int PK_THREADS = 512;
+
+template <typename T> struct PkVec;
+template <> struct PkVec<uint16_t> { static constexpr int N = 8; };
+template <> struct PkVec<uint32_t> { static constexpr int N = 4; };
+
+template <typename T>
+__device__ __forceinline__ void unpack_vec(const uint4 &v, pu32 (&e)[PkVec<T>::N])
+{
+    const pu32 w[4] = {v.x, v.y, v.z, v.w};
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) e[j] = w[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) { e[2 * j] = w[j] & 0xffffu; e[2 * j + 1] = w[j] >> 16; }
+    }
+}
+template <typename T>
+__device__ __forceinline__ uint4 pack_vec(const pu32 (&e)[PkVec<T>::N])
+{
+    if constexpr (sizeof(T) == 4) return make_uint4(e[0], e[1], e[2], e[3]);
+    else return make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+}
+
+// OP: 0 add, 1 sub, 2 neg (b unused).  sa / sb: 1 = one element per output, 0 = one element for the whole array.
+template <typename T, int OP>
+__global__ __launch_bounds__(PK_THREADS) void packed_lin_kernel(Plan pl, const pu32 *__restrict__ gtab, const T *__restrict__ a, int sa,
+                                                                 const T *__restrict__ b, int sb, T *__restrict__ out, i64 n)
+{
+    extern __shared__ pu32 pk_tab[];
+    for (pu32 i = threadIdx.x; i < pl.words; i += PK_THREADS) pk_tab[i] = gtab[i];
+    __syncthreads();
+    constexpr int V = PkVec<T>::N;
+    const i64 nvec = n / V;
+    const pu32 pa0 = sa ? 0u : to_packed(pl, pk_tab, (pu32)a[0]);
+    const pu32 pb0 = (OP == 2 || sb) ? 0u : to_packed(pl, pk_tab, (pu32)b[0]);
+    const uint4 *av = reinterpret_cast<const uint4 *>(a), *bv = reinterpret_cast<const uint4 *>(b);
+    uint4 *ov = reinterpret_cast<uint4 *>(out);
+    for (i64 i = (i64)blockIdx.x * PK_THREADS + threadIdx.x; i < nvec; i += (i64)gridDim.x * PK_THREADS) {
+        pu32 xa[V], xb[V], r[V];
+        if (sa) unpack_vec<T>(av[i], xa);
+        if (OP != 2 && sb) unpack_vec<T>(bv[i], xb);
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            const pu32 pa = sa ? to_packed(pl, pk_tab, xa[j]) : pa0;
+            const pu32 pb = OP == 2 ? 0u : (sb ? to_packed(pl, pk_tab, xb[j]) : pb0);
+            r[j] = from_packed(pl, pk_tab, lin_packed<OP>(pl, pa, pb));
+        }
+        ov[i] = pack_vec<T>(r);
+    }
+    // the last n % V elements
+    const i64 t0 = nvec * V + (i64)blockIdx.x * PK_THREADS + threadIdx.x;
+    if (t0 < n) {
+        const pu32 pa = sa ? to_packed(pl, pk_tab, (pu32)a[t0]) : pa0;
+        const pu32 pb = OP == 2 ? 0u : (sb ? to_packed(pl, pk_tab, (pu32)b[t0]) : pb0);
+        out[t0] = (T)from_packed(pl, pk_tab, lin_packed<OP>(pl, pa, pb));
+    }
+}
+
+struct PackedDev {
+    Plan pl;
+    pu32 *tab = nullptr;
+};
+std::mutex g_pk_mu;
+std::map<std::tuple<u64, u32, int>, PackedDev> g_pk; // (p, m, device)
+
+int get_dev(const FieldDev &c, PackedDev *out)
+{
+    int dev = 0;
+    GFA_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_pk_mu);
+    auto key = std::make_tuple(c.p, c.m, dev);
+    auto it = g_pk.find(key);
+    if (it == g_pk.end()) {
+        PackedDev d;
+        if (!make_plan(c.p, c.m, &d.pl)) return GFA_ERR_UNSUPPORTED;
+        std::vector<pu32> t;
+        build_tables(d.pl, t);
+        GFA_HIP(hipMalloc((void **)&d.tab, sizeof(pu32) * t.size()));
+        GFA_HIP(hipMemcpy(d.tab, t.data(), sizeof(pu32) * t.size(), hipMemcpyHostToDevice)); // synchronous: usable from any stream afterwards
+        it = g_pk.emplace(key, d).first;
+    }
+    *out = it->second;
+    return GFA_OK;
+}
+
+int num_cus()
+{
+    static const int cus = [] { int dev = 0, n = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }();
+    return cus;
+}
+
+template <typename T, int OP>
+int launch(const PackedDev &d, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st)
+{
+    constexpr int V = PkVec<T>::N;
+    const i64 blocks = std::max<i64>(1, (n / V + PK_THREADS - 1) / PK_THREADS);
+    const int grid = (int)std::min<i64>(blocks, (i64)num_cus() * 4);
+    hipLaunchKernelGGL((packed_lin_kernel<T, OP>), dim3(grid), dim3(PK_THREADS), sizeof(pu32) * d.pl.words, st, d.pl, (const pu32 *)d.tab, (const T *)a, (int)sa,
+                       (const T *)b, (int)sb, (T *)out, n);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+inline bool al16p(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+} // namespace
+
+namespace gfa {
+
+// sums / differences / negatives of odd-characteristic extension fields whose Zech tables leave LDS; uint16 (q <= 65536) or uint32 arrays
+bool packed_eligible(const FieldDev &c, int dtype, i64 n)
+{
+    if (c.m < 2 || (c.p & 1) == 0 || c.q <= 8192 || c.q > ((u64)1 << 20) || n < 1024) return false;
+    if (!(dtype == GFA_U32 || (dtype == GFA_U16 && c.q <= 65536))) return false;
+    Plan pl;
+    return make_plan(c.p, c.m, &pl);
+}
+
+// op: GFA_OP_ADD / GFA_OP_SUB / GFA_OP_NEG.  GFA_ERR_UNSUPPORTED (nothing launched): misaligned operands.
+int packed_run(const FieldDev &c, int dtype, int op, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st)
+{
+    if (!al16p(out) || (sa && !al16p(a)) || (op != GFA_OP_NEG && sb && !al16p(b))) return GFA_ERR_UNSUPPORTED;
+    PackedDev d;
+    const int rc = get_dev(c, &d);
+    if (rc) return rc;
+    if (op == GFA_OP_NEG) { b = a; sb = 0; }
+#define GFA_PK(T)                                                                 \
+    switch (op) {                                                                 \
+    case GFA_OP_ADD: return launch<T, 0>(d, a, sa, b, sb, out, n, st);            \
+    case GFA_OP_SUB: return launch<T, 1>(d, a, sa, b, sb, out, n, st);            \
+    default: return launch<T, 2>(d, a, sa, b, sb, out, n, st);                    \
+    }
+    if (dtype == GFA_U16) { GFA_PK(uint16_t) }
+    GFA_PK(uint32_t)
+#undef GFA_PK
+}
+
+} // namespace gfa

@@ -1,0 +1,142 @@
+// gfa_packed.h -- sums, differences and negatives in GF(p^m), p odd, as PACKED-DIGIT arithmetic (r05).
+//
+// The reference adds two elements of GF(p^m) digit by digit (add_vector / subtract_vector / negative_vector,
+// src/galois/_domains/_calculate.py:150-181, 254-285, 202-232) or, in lookup mode, through the Zech logarithm
+// (_lookup.py:31-60, 89-150).  For fields whose tables leave LDS (8192 < q <= 2^20 in odd characteristic) the table route is a
+// chain of gathers from L2 (GF(7^7): 0.04 of the roofline) or a three-table staged kernel (GF(3^10): 0.26).  Sums do not need
+// the multiplicative structure at all: with the m base-p digits of an element packed into one 32-bit word, W bits per digit,
+// an addition is ONE integer add plus a per-field conditional subtraction done for all digits at once:
+//     s = A + B                      every field <= 2p - 2 < 2^W
+//     g = (s + BIAS) & GUARD         BIAS adds 2^(W-1) - p to every field: its top bit comes out set exactly where s_i >= p
+//     r = s - (g >> (W-1)) * p       subtract p in the flagged fields (one multiply: fields cannot carry into each other)
+// Integer <-> packed form goes through small tables that fit LDS: x = hi * P + lo with P = p^hl <= 4096 (an EXACT quotient by one
+// v_mul_hi with ceil(2^32 / P): x < 2^20), PK_LO[lo] | PK_HI[hi] gives the packed word; the way back sums nch table entries
+// indexed by chunks of k fields (k W <= 11 bits).  Six LDS reads + ~25 vector instructions per element, no division, no gather
+// from L2.  Value-identical to the reference: the result digits are (a_i +- b_i) mod p by construction.
+//
+// Everything here is plain integer code shared by the kernel (gfa_elementwise_packed.hip) and the host check
+// (tests/csrc/packed_host_test.cpp: every element pair of small fields, random pairs of every field shape up to 2^20).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#if defined(__HIPCC__)
+#define GFP_HD __host__ __device__ __forceinline__
+#else
+#define GFP_HD inline
+#endif
+
+namespace gfa_packed {
+
+typedef uint32_t pu32;
+
+struct Plan {
+    pu32 p, m, q;
+    pu32 W;        // bits per digit field: 2^(W-1) >= p
+    pu32 hl, hh;   // digits in the low / high part of the integer
+    pu32 P;        // p^hl (<= 4096)
+    pu32 magic;    // ceil(2^32 / P): floor(x / P) == mulhi(x, magic) for x < 2^20
+    pu32 QH;       // p^hh: entries of the high table
+    pu32 bias, guard, pfull; // per-field constants replicated over the m fields
+    pu32 k, nch, chunk_bits; // unpacking: nch chunks of k fields (chunk_bits = k * W <= 11)
+    pu32 off_hi, off_un, words; // table offsets (32-bit words): PK_LO at 0, PK_HI at off_hi, chunk c of the unpack tables at off_un + (c << chunk_bits)
+};
+
+inline pu32 ipow(pu32 b, pu32 e) { pu32 r = 1; while (e--) r *= b; return r; }
+
+// false: the field does not fit the scheme (even characteristic, prime field, more than 32 packed bits, q > 2^20)
+inline bool make_plan(uint64_t p64, uint32_t m, Plan *pl)
+{
+    if (p64 < 3 || (p64 & 1) == 0 || m < 2 || p64 > 1021) return false;
+    uint64_t q = 1;
+    for (uint32_t i = 0; i < m; i++) { q *= p64; if (q > (1u << 20)) return false; }
+    const pu32 p = (pu32)p64;
+    pu32 W = 1;
+    while ((1u << (W - 1)) < p) W++;
+    if (m * W > 32) return false;
+    pu32 hl = (m + 1) / 2;
+    while (hl > 1 && ipow(p, hl) > 4096) hl--;
+    if (ipow(p, hl) > 4096) return false;
+    const pu32 hh = m - hl;
+    if (ipow(p, hh) > 16384) return false;
+    pu32 k = 11 / W;
+    if (k < 1) return false;
+    if (k > m) k = m;
+    Plan r{};
+    r.p = p; r.m = m; r.q = (pu32)q; r.W = W; r.hl = hl; r.hh = hh; r.P = ipow(p, hl); r.QH = ipow(p, hh);
+    r.magic = (pu32)((((uint64_t)1 << 32) + r.P - 1) / r.P);
+    for (pu32 i = 0; i < m; i++) {
+        r.bias |= ((1u << (W - 1)) - p) << (W * i);
+        r.guard |= (1u << (W - 1)) << (W * i);
+        r.pfull |= p << (W * i);
+    }
+    r.k = k; r.nch = (m + k - 1) / k; r.chunk_bits = k * W;
+    r.off_hi = r.P; r.off_un = r.P + r.QH; r.words = r.off_un + (r.nch << r.chunk_bits);
+    *pl = r;
+    return true;
+}
+
+// digit i (i = 0: least significant) of the integer lives in field i
+inline void build_tables(const Plan &pl, std::vector<pu32> &t)
+{
+    t.assign(pl.words, 0);
+    auto pack = [&](pu32 v, pu32 ndig, pu32 first_field) {
+        pu32 w = 0;
+        for (pu32 i = 0; i < ndig; i++) { w |= (v % pl.p) << (pl.W * (first_field + i)); v /= pl.p; }
+        return w;
+    };
+    for (pu32 v = 0; v < pl.P; v++) t[v] = pack(v, pl.hl, 0);
+    for (pu32 v = 0; v < pl.QH; v++) t[pl.off_hi + v] = pack(v, pl.hh, pl.hl);
+    for (pu32 c = 0; c < pl.nch; c++) {
+        const pu32 nf = (c + 1) * pl.k <= pl.m ? pl.k : pl.m - c * pl.k;
+        for (pu32 idx = 0; idx < (1u << pl.chunk_bits); idx++) {
+            pu32 val = 0, scale = ipow(pl.p, c * pl.k);
+            bool ok = true;
+            for (pu32 i = 0; i < nf; i++) {
+                const pu32 d = (idx >> (pl.W * i)) & ((1u << pl.W) - 1);
+                if (d >= pl.p) ok = false;
+                val += d * scale;
+                scale *= pl.p;
+            }
+            if (idx >> (pl.W * nf)) ok = false;
+            t[pl.off_un + (c << pl.chunk_bits) + idx] = ok ? val : 0;
+        }
+    }
+}
+
+GFP_HD pu32 mulhi32(pu32 a, pu32 b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (pu32)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+// integer -> packed digits (tab: the table image, LDS on the device)
+GFP_HD pu32 to_packed(const Plan &pl, const pu32 *tab, pu32 x)
+{
+    const pu32 hi = mulhi32(x, pl.magic);
+    const pu32 lo = x - hi * pl.P;
+    return tab[lo] | tab[pl.off_hi + hi];
+}
+// one conditional subtraction of p in every field (fields <= 2p - 1 in, < p out)
+GFP_HD pu32 reduce_fields(const Plan &pl, pu32 s)
+{
+    const pu32 g = (s + pl.bias) & pl.guard;
+    return s - (g >> (pl.W - 1)) * pl.p;
+}
+template <int OP> // 0 add, 1 sub, 2 neg (b unused)
+GFP_HD pu32 lin_packed(const Plan &pl, pu32 a, pu32 b)
+{
+    return reduce_fields(pl, OP == 0 ? a + b : OP == 1 ? a + pl.pfull - b : pl.pfull - a);
+}
+GFP_HD pu32 from_packed(const Plan &pl, const pu32 *tab, pu32 w)
+{
+    const pu32 mask = (1u << pl.chunk_bits) - 1u;
+    pu32 v = 0;
+    for (pu32 c = 0; c < pl.nch; c++) v += tab[pl.off_un + (c << pl.chunk_bits) + ((w >> (c * pl.chunk_bits)) & mask)];
+    return v;
+}
+
+} // namespace gfa_packed

@@ -1,0 +1,67 @@
+// Host check of galois_amd/csrc/gfa_packed.h (r05): packed-digit sums / differences / negatives of GF(p^m), p odd, against digit-wise
+// arithmetic -- the definition of add_vector / subtract_vector / negative_vector (src/galois/_domains/_calculate.py:150-285).
+// Every element pair of the small fields, random and edge pairs of every field shape with 8192 < q <= 2^20 the scheme accepts; the
+// fields it must refuse.  Built and run by tests/test_host_logic.py.
+#include "gfa_packed.h"
+#include <cstdio>
+#include <random>
+using namespace gfa_packed;
+
+static pu32 digitwise(pu32 p, pu32 m, pu32 x, pu32 y, int op)
+{
+    pu32 r = 0, scale = 1;
+    for (pu32 i = 0; i < m; i++) {
+        const pu32 a = x % p, b = y % p;
+        x /= p; y /= p;
+        const pu32 d = op == 0 ? (a + b) % p : op == 1 ? (a + p - b) % p : (p - a) % p;
+        r += d * scale;
+        scale *= p;
+    }
+    return r;
+}
+
+static long check(pu32 p, pu32 m, std::mt19937 &rng)
+{
+    Plan pl;
+    if (!make_plan(p, m, &pl)) { printf("GF(%u^%u): refused\n", p, m); return 1; }
+    std::vector<pu32> t;
+    build_tables(pl, t);
+    long fails = 0;
+    auto one = [&](pu32 x, pu32 y) {
+        const pu32 a = to_packed(pl, t.data(), x), b = to_packed(pl, t.data(), y);
+        if (from_packed(pl, t.data(), a) != x) fails++;
+        if (from_packed(pl, t.data(), lin_packed<0>(pl, a, b)) != digitwise(p, m, x, y, 0)) fails++;
+        if (from_packed(pl, t.data(), lin_packed<1>(pl, a, b)) != digitwise(p, m, x, y, 1)) fails++;
+        if (from_packed(pl, t.data(), lin_packed<2>(pl, a, b)) != digitwise(p, m, x, y, 2)) fails++;
+    };
+    if (pl.q <= 729) {
+        for (pu32 x = 0; x < pl.q; x++)
+            for (pu32 y = 0; y < pl.q; y++) one(x, y);
+    } else {
+        for (pu32 x = 0; x < pl.q; x += 1 + pl.q / 50000) one(x, pl.q - 1 - x); // the exact-quotient claim over the whole range
+        const pu32 edge[6] = {0, 1, pl.q - 1, pl.q - 2, pl.P, pl.P - 1};
+        for (pu32 a : edge)
+            for (pu32 b : edge) one(a, b);
+        for (int it = 0; it < 200000; it++) one(rng() % pl.q, rng() % pl.q);
+    }
+    printf("GF(%u^%u): W %u, split %u + %u digits, %u table words, %s\n", p, m, pl.W, pl.hl, pl.hh, pl.words, fails ? "FAIL" : "ok");
+    return fails;
+}
+
+int main()
+{
+    std::mt19937 rng(5);
+    long fails = 0;
+    const pu32 fields[][2] = {{3, 2}, {3, 5}, {5, 3}, {7, 2}, {3, 9}, {3, 10}, {5, 6}, {5, 7}, {5, 8}, {7, 5}, {7, 6}, {7, 7}, {11, 4}, {11, 5}, {13, 5},
+                              {17, 4}, {31, 4}, {41, 3}, {97, 3}, {101, 2}, {257, 2}, {1021, 2}};
+    for (auto &f : fields) fails += check(f[0], f[1], rng);
+    Plan pl;
+    // refused: even characteristic, prime fields, more than 32 packed bits (3^11: 33), orders above 2^20, digits above 1021
+    if (make_plan(2, 8, &pl) || make_plan(7, 1, &pl) || make_plan(3, 11, &pl) || make_plan(3, 13, &pl) || make_plan(1031, 2, &pl) || make_plan(101, 4, &pl)) {
+        printf("a field outside the scheme was accepted\n");
+        fails++;
+    }
+    if (fails) { printf("FAILED: %ld\n", fails); return 1; }
+    printf("packed digits ok\n");
+    return 0;
+}

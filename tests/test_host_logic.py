@@ -361,6 +361,19 @@ def test_signed_montgomery_networks_on_the_host_never_leave_int32(tmp_path, repo
     assert r.returncode == 0 and "m32 networks ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_packed_digit_sums_on_the_host(tmp_path, repo_root):
+    """galois_amd/csrc/gfa_packed.h on the host (r05): packed base-p digit sums / differences / negatives of GF(p^m), p odd, against
+    digit-wise arithmetic -- every element pair of the small fields, random and edge pairs of 22 field shapes up to 2^20 elements, the
+    exact-quotient claim swept over the whole range, and the fields the scheme must refuse (tests/csrc/packed_host_test.cpp)."""
+    import subprocess
+
+    exe = str(tmp_path / "packed_test")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(repo_root, "galois_amd", "csrc"),
+                    os.path.join(repo_root, "tests", "csrc", "packed_host_test.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "packed digits ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_reed_solomon_table_builders_on_the_host(tmp_path, repo_root):
     """galois_amd/csrc/gfa_rs_host.h on the host: the LFSR row table in consecutive and in planar order, run through a host model
     of rs_lfsr_kernel's state handling and compared with schoolbook division for n - k = 4 .. 64; the decoder's lane tables
