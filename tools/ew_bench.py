@@ -25,7 +25,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--widestore16":  # r05: 32768 < q <= 65
     cases = [(65521, np.uint32, "jit-lookup"), (65521, np.int64, "jit-lookup"), (3**10, np.uint32, "auto"), (3**10, np.int64, "auto"), (3**10, np.uint16, "auto")]
 if len(sys.argv) > 1 and sys.argv[1] == "--packed":  # r05: sums of odd-characteristic extension fields, 8192 < q <= 2^20, as packed digits
     cases = [(3**10, np.uint16, "auto"), (3**9, np.uint16, "auto"), (7**7, np.uint32, "auto"), (5**8, np.uint32, "auto"), (13**5, np.uint32, "auto"),
-             (1021**2, np.uint32, "auto"), (7**7, np.uint32, "jit-calculate")]
+             (997**2, np.uint32, "auto"), (7**7, np.uint32, "jit-calculate")]
 if len(sys.argv) > 1 and sys.argv[1] == "--ext":  # GF(p^m) pinned to explicit calculation (per-degree kernels up to m = 8)
     cases = [(3**5, np.uint8, "jit-calculate"), (3**7, np.uint16, "jit-calculate"), (3**8, np.uint16, "jit-calculate"), (251**3, np.uint32, "auto"), (7**7, np.uint32, "auto")]
 if len(sys.argv) > 1 and sys.argv[1] == "--mid":
