@@ -1554,6 +1554,13 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
     }
+    // r05, AUTO only: odd-characteristic extension fields above 65536 elements keep their EXP / LOG tables in L2, and a product through
+    // them is three dependent gathers (0.06-0.10 of the roofline); the digit-vector kernels of degree <= 8 beat that for products --
+    // GF(997^2) 0.67, GF(97^3) 0.47, GF(31^4) 0.33, GF(13^5) 0.25, GF(7^7) 0.15, GF(5^8) 0.13 (profiles/r05_ew_extcalc.txt) -- and, in
+    // degree 2, for quotients (0.15 vs 0.06).  Same values either way; a field pinned to jit-lookup keeps its tables.
+    if (f->mode == GFA_MODE_AUTO && f->calc.m > 1 && (f->calc.p & 1) && f->calc.q > 65536 && f->calc.kind == KIND_EXT && Ext::fixed_degree(f->calc) &&
+        (op == GFA_OP_MUL || (op == GFA_OP_DIV && f->calc.m == 2)))
+        return dispatch_binary(f->calc, dtype, op, a, sa, b, sb, out, n, st, dev_err);
     if (f->use_lookup()) {
         const FieldDev &c = f->calc;
         const bool trivial_addsub = (op == GFA_OP_ADD || op == GFA_OP_SUB) && (c.p == 2 || c.m == 1);
@@ -1608,6 +1615,10 @@ int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int d
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
     }
+    // r05, AUTO only: reciprocals of degree-2 extension fields above 65536 elements on the digit-vector kernel (0.12 vs 0.06, see gfa_binary)
+    if (f->mode == GFA_MODE_AUTO && op == GFA_OP_RECIP && f->calc.m == 2 && (f->calc.p & 1) && f->calc.q > 65536 && f->calc.kind == KIND_EXT &&
+        Ext::fixed_degree(f->calc))
+        return dispatch_unary(f->calc, dtype, op, a, out, n, st, dev_err);
     if (f->use_lookup()) {
         const FieldDev &c = f->calc;
         const bool trivial_neg = op == GFA_OP_NEG && (c.p == 2 || c.m == 1);

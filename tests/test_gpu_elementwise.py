@@ -1031,3 +1031,34 @@ def test_packed_digit_sums_of_odd_characteristic_extension_fields(order, dt, mod
         assert (x + y).dtype == np.dtype(dt)
     finally:
         GF.compile("auto")
+
+
+@pytest.mark.parametrize("order", [997**2, 97**3, 31**4, 13**5, 7**7])
+def test_auto_mode_products_of_extension_fields_above_2e16_elements(order):
+    """r05: in AUTO, products (degree 2: quotients and reciprocals too) of odd-characteristic extension fields with 65536 < q <= 2^20 run
+    on the digit-vector kernels instead of three table gathers from L2 -- the reference's default for these fields is jit-lookup
+    (_domains/_meta.py:42-44); the values are the same.  Against the oracle in LOOKUP mode, and the field pinned to jit-lookup against
+    the same vectors (the table route still exists)."""
+    GF = ga.GF(order)
+    assert GF.ufunc_mode == "jit-lookup"
+    F = O.OracleField(GF.characteristic, GF.degree, int(GF.irreducible_poly), int(GF.primitive_element), lookup=True)
+    n = 50_007
+    rng = np.random.default_rng(order % 997)
+    a = rng.integers(0, order, n, dtype=np.uint64)
+    b = rng.integers(1, order, n, dtype=np.uint64)
+    a[:3] = (0, order - 1, 1)
+    x, y = GF(a.astype(np.uint32)), GF(b.astype(np.uint32))
+    u = lambda v: v.numpy().astype(np.uint64)
+    want_mul, want_div = F.mul(a, b), F.div(a, b)
+    H.assert_equal_ints(u(x * y), want_mul, f"GF({order}) mul")
+    H.assert_equal_ints(u(x / y), want_div, f"GF({order}) div")
+    H.assert_equal_ints(u(np.reciprocal(y)), F.div(np.ones(n, dtype=np.uint64), b), f"GF({order}) reciprocal")
+    H.assert_equal_ints(u(x * GF(int(b[5]))), F.mul(a, np.full(n, b[5], dtype=np.uint64)), "scalar operand")
+    with pytest.raises(ZeroDivisionError):
+        y / x
+    GF.compile("jit-lookup")
+    try:
+        H.assert_equal_ints(u(x * y), want_mul, "pinned to the tables")
+        H.assert_equal_ints(u(x / y), want_div)
+    finally:
+        GF.compile("auto")
