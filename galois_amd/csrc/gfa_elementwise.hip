@@ -1559,8 +1559,14 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
     // GF(997^2) 0.67, GF(97^3) 0.47, GF(31^4) 0.33, GF(13^5) 0.25, GF(7^7) 0.15, GF(5^8) 0.13 (profiles/r05_ew_extcalc.txt) -- and, in
     // degree 2, for quotients (0.15 vs 0.06).  Same values either way; a field pinned to jit-lookup keeps its tables.
     if (f->mode == GFA_MODE_AUTO && f->calc.m > 1 && (f->calc.p & 1) && f->calc.q > 65536 && f->calc.kind == KIND_EXT && Ext::fixed_degree(f->calc) &&
-        (op == GFA_OP_MUL || (op == GFA_OP_DIV && f->calc.m == 2)))
+        (op == GFA_OP_MUL || (op == GFA_OP_DIV && f->calc.m == 2))) {
+        // products: digits through LDS tables and no reduction before the end (gfa_packed.h::mul_digits) where the 32-bit bound holds
+        if (op == GFA_OP_MUL && packed_mul_eligible(f->calc, dtype, n)) {
+            rc = packed_mul_run(f->calc, a, sa, b, sb, out, n, st);
+            if (rc != GFA_ERR_UNSUPPORTED) return rc;
+        }
         return dispatch_binary(f->calc, dtype, op, a, sa, b, sb, out, n, st, dev_err);
+    }
     if (f->use_lookup()) {
         const FieldDev &c = f->calc;
         const bool trivial_addsub = (op == GFA_OP_ADD || op == GFA_OP_SUB) && (c.p == 2 || c.m == 1);

@@ -79,6 +79,32 @@ __global__ __launch_bounds__(PK_THREADS) void packed_lin_kernel(Plan pl, const p
     }
 }
 
+// products of uint32 arrays (65536 < q <= 2^20): digits through the same LDS tables, gfa_packed.h::mul_digits (no reduction before the end)
+template <int M>
+__global__ __launch_bounds__(PK_THREADS) void packed_mul_kernel(Plan pl, MulAux ax, const pu32 *__restrict__ gtab, const uint32_t *__restrict__ a, int sa,
+                                                                 const uint32_t *__restrict__ b, int sb, uint32_t *__restrict__ out, i64 n)
+{
+    extern __shared__ pu32 pk_tab[];
+    for (pu32 i = threadIdx.x; i < pl.off_un; i += PK_THREADS) pk_tab[i] = gtab[i]; // PK_LO and PK_HI only: the way back is Horner's rule
+    __syncthreads();
+    const i64 nvec = n / 4;
+    const pu32 pa0 = sa ? 0u : to_packed(pl, pk_tab, a[0]);
+    const pu32 pb0 = sb ? 0u : to_packed(pl, pk_tab, b[0]);
+    const uint4 *av = reinterpret_cast<const uint4 *>(a), *bv = reinterpret_cast<const uint4 *>(b);
+    uint4 *ov = reinterpret_cast<uint4 *>(out);
+    for (i64 i = (i64)blockIdx.x * PK_THREADS + threadIdx.x; i < nvec; i += (i64)gridDim.x * PK_THREADS) {
+        pu32 xa[4], xb[4], r[4];
+        if (sa) unpack_vec<uint32_t>(av[i], xa);
+        if (sb) unpack_vec<uint32_t>(bv[i], xb);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            r[j] = mul_digits<M>(pl, ax, sa ? to_packed(pl, pk_tab, xa[j]) : pa0, sb ? to_packed(pl, pk_tab, xb[j]) : pb0);
+        ov[i] = pack_vec<uint32_t>(r);
+    }
+    const i64 t0 = nvec * 4 + (i64)blockIdx.x * PK_THREADS + threadIdx.x;
+    if (t0 < n) out[t0] = mul_digits<M>(pl, ax, sa ? to_packed(pl, pk_tab, a[t0]) : pa0, sb ? to_packed(pl, pk_tab, b[t0]) : pb0);
+}
+
 struct PackedDev {
     Plan pl;
     pu32 *tab = nullptr;
@@ -156,6 +182,50 @@ int packed_run(const FieldDev &c, int dtype, int op, const void *a, i64 sa, cons
     if (dtype == GFA_U16) { GFA_PK(uint16_t) }
     GFA_PK(uint32_t)
 #undef GFA_PK
+}
+
+// products: uint32 arrays of odd-characteristic extension fields with 65536 < q <= 2^20, degree <= 8, whose unreduced schoolbook
+// product stays below 2^32 (mul_bound_ok); ext_irr: FieldDev's digits of (irr - x^m), degree m-1 .. 0
+static bool packed_mul_aux(const FieldDev &c, Plan *pl, MulAux *ax)
+{
+    if (c.m < 2 || c.m > 8 || (c.p & 1) == 0 || c.q <= 65536 || c.q > ((u64)1 << 20) || !make_plan(c.p, c.m, pl)) return false;
+    for (u32 j = 0; j < 8; j++) ax->nir[j] = 0;
+    for (u32 j = 0; j < c.m; j++) ax->nir[j] = c.ext_irr[c.m - 1 - j] ? (pu32)c.p - c.ext_irr[c.m - 1 - j] : 0u;
+    ax->mu32 = (pu32)(((u64)1 << 32) / c.p);
+    return mul_bound_ok(*pl, *ax);
+}
+
+bool packed_mul_eligible(const FieldDev &c, int dtype, i64 n)
+{
+    Plan pl;
+    MulAux ax;
+    return dtype == GFA_U32 && n >= 1024 && packed_mul_aux(c, &pl, &ax);
+}
+
+int packed_mul_run(const FieldDev &c, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st)
+{
+    if (!al16p(out) || (sa && !al16p(a)) || (sb && !al16p(b))) return GFA_ERR_UNSUPPORTED;
+    PackedDev d;
+    MulAux ax;
+    Plan pl;
+    if (!packed_mul_aux(c, &pl, &ax)) return GFA_ERR_UNSUPPORTED;
+    const int rc = get_dev(c, &d);
+    if (rc) return rc;
+    const i64 blocks = std::max<i64>(1, (n / 4 + PK_THREADS - 1) / PK_THREADS);
+    const int grid = (int)std::min<i64>(blocks, (i64)num_cus() * 4);
+    const size_t lds = sizeof(pu32) * d.pl.off_un;
+#define GFA_PKM(MV)                                                                                                                    \
+    case MV:                                                                                                                           \
+        hipLaunchKernelGGL((packed_mul_kernel<MV>), dim3(grid), dim3(PK_THREADS), lds, st, d.pl, ax, (const pu32 *)d.tab, (const uint32_t *)a, (int)sa, \
+                           (const uint32_t *)b, (int)sb, (uint32_t *)out, n);                                                          \
+        break;
+    switch (c.m) {
+        GFA_PKM(2) GFA_PKM(3) GFA_PKM(4) GFA_PKM(5) GFA_PKM(6) GFA_PKM(7) GFA_PKM(8)
+    default: return GFA_ERR_UNSUPPORTED;
+    }
+#undef GFA_PKM
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
 }
 
 } // namespace gfa

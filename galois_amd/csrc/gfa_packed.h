@@ -139,4 +139,69 @@ GFP_HD pu32 from_packed(const Plan &pl, const pu32 *tab, pu32 w)
     return v;
 }
 
+// ---- products on the same digit tables (r05): schoolbook product of the two digit vectors with NO reduction until the end.
+// multiply_vector (_calculate.py:343-383) reduces modulo p after every step; for these small characteristics every partial sum of
+// the product AND of the folds through x^m = -(irr) stays below 2^32 (bound_ok replays the worst case), so the only reductions
+// are the m final ones.  nir[j]: coefficient of x^j of  x^m mod irr, i.e. p - irr_j.
+struct MulAux {
+    pu32 nir[8];  // degree 0 .. m-1
+    pu32 mu32;    // floor(2^32 / p)
+};
+
+inline bool mul_bound_ok(const Plan &pl, const MulAux &ax)
+{
+    const pu32 m = pl.m;
+    if (m > 8) return false;
+    uint64_t B[15] = {};
+    for (pu32 k = 0; k + 1 < 2 * m; k++) B[k] = (uint64_t)(k < m ? k + 1 : 2 * m - 1 - k) * (pl.p - 1) * (pl.p - 1);
+    for (pu32 k = 2 * m - 2; k >= m; k--)
+        for (pu32 j = 0; j < m; j++) {
+            B[k - m + j] += B[k] * ax.nir[j];
+            if (B[k - m + j] >> 32) return false;
+        }
+    return true;
+}
+
+GFP_HD pu32 red32(pu32 x, pu32 p, pu32 mu32)
+{ // x mod p, any 32-bit x (the estimate is short by at most 2)
+    const pu32 qd = mulhi32(x, mu32);
+    pu32 r = x - qd * p;
+    pu32 d = r - p;
+    r = d < r ? d : r;
+    d = r - p;
+    return d < r ? d : r;
+}
+
+GFP_HD pu32 mul24(pu32 a, pu32 b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (a & 0xffffffu) * (b & 0xffffffu);
+#endif
+}
+
+template <int M>
+GFP_HD pu32 mul_digits(const Plan &pl, const MulAux &ax, pu32 pa, pu32 pb)
+{ // pa / pb: packed digits (field i = coefficient of x^i); returns the product as an integer
+    const pu32 fm = (1u << pl.W) - 1u;
+    pu32 da[M], db[M], c[2 * M - 1];
+#pragma unroll
+    for (int i = 0; i < M; i++) { da[i] = (pa >> (pl.W * i)) & fm; db[i] = (pb >> (pl.W * i)) & fm; }
+#pragma unroll
+    for (int k = 0; k < 2 * M - 1; k++) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < M; i++)
+#pragma unroll
+        for (int j = 0; j < M; j++) c[i + j] += mul24(da[i], db[j]); // digits are below 2^11: v_mad_u32_u24, full rate
+#pragma unroll
+    for (int k = 2 * M - 2; k >= M; k--)
+#pragma unroll
+        for (int j = 0; j < M; j++) c[k - M + j] += c[k] * ax.nir[j];
+    pu32 v = red32(c[M - 1], pl.p, ax.mu32);
+#pragma unroll
+    for (int i = M - 2; i >= 0; i--) v = v * pl.p + red32(c[i], pl.p, ax.mu32);
+    return v;
+}
+
 } // namespace gfa_packed

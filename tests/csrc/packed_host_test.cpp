@@ -48,6 +48,47 @@ static long check(pu32 p, pu32 m, std::mt19937 &rng)
     return fails;
 }
 
+// products: mul_digits against the textbook product of the digit polynomials reduced by x^m + irr, for a (random) monic irr -- the
+// arithmetic does not need irreducibility -- incl. all-(p-1) operands (the bound replay's worst case)
+template <int M>
+static long check_mul(pu32 p, std::mt19937 &rng)
+{
+    Plan pl;
+    if (!make_plan(p, M, &pl)) return 0; // (fields the scheme refuses are covered above)
+    std::vector<pu32> t;
+    build_tables(pl, t);
+    long fails = 0, fields = 0;
+    for (int poly = 0; poly < 6; poly++) {
+        pu32 irr[M]; // coefficient of x^j of the monic polynomial, j < M
+        for (int j = 0; j < M; j++) irr[j] = poly == 0 ? p - 1 - (j & 1) : rng() % p; // poly 0: nir small but non-zero; others random
+        if (poly == 1) for (int j = 0; j < M; j++) irr[j] = 1;                         // nir = p - 1 everywhere: the largest folds
+        MulAux ax{};
+        for (int j = 0; j < M; j++) ax.nir[j] = irr[j] ? p - irr[j] : 0;
+        ax.mu32 = (pu32)(((uint64_t)1 << 32) / p);
+        if (!mul_bound_ok(pl, ax)) continue;
+        fields++;
+        for (int it = 0; it < 20000; it++) {
+            pu32 x = rng() % pl.q, y = rng() % pl.q;
+            if (it == 0) x = y = pl.q - 1;
+            if (it == 1) { x = pl.q - 1; y = 1; }
+            // reference: digit polynomials, product, fold from the top, everything reduced mod p at once
+            uint64_t c[2 * M - 1] = {};
+            pu32 xd[M], yd[M], xx = x, yy = y;
+            for (int i = 0; i < M; i++) { xd[i] = xx % p; xx /= p; yd[i] = yy % p; yy /= p; }
+            for (int i = 0; i < M; i++)
+                for (int j = 0; j < M; j++) c[i + j] = (c[i + j] + (uint64_t)xd[i] * yd[j]) % p;
+            for (int k = 2 * M - 2; k >= M; k--)
+                for (int j = 0; j < M; j++) c[k - M + j] = (c[k - M + j] + c[k] * ax.nir[j]) % p;
+            pu32 want = 0;
+            for (int i = M - 1; i >= 0; i--) want = want * p + (pu32)c[i];
+            const pu32 got = mul_digits<M>(pl, ax, to_packed(pl, t.data(), x), to_packed(pl, t.data(), y));
+            if (got != want) fails++;
+        }
+    }
+    printf("GF(%u^%d) products: %ld polynomial(s) inside the 32-bit bound, %s\n", p, M, fields, fails ? "FAIL" : "ok");
+    return fails;
+}
+
 int main()
 {
     std::mt19937 rng(5);
@@ -55,6 +96,8 @@ int main()
     const pu32 fields[][2] = {{3, 2}, {3, 5}, {5, 3}, {7, 2}, {3, 9}, {3, 10}, {5, 6}, {5, 7}, {5, 8}, {7, 5}, {7, 6}, {7, 7}, {11, 4}, {11, 5}, {13, 5},
                               {17, 4}, {31, 4}, {41, 3}, {97, 3}, {101, 2}, {257, 2}, {1021, 2}};
     for (auto &f : fields) fails += check(f[0], f[1], rng);
+    fails += check_mul<2>(997, rng) + check_mul<2>(257, rng) + check_mul<3>(97, rng) + check_mul<3>(41, rng) + check_mul<4>(31, rng) + check_mul<4>(17, rng);
+    fails += check_mul<5>(13, rng) + check_mul<5>(11, rng) + check_mul<6>(7, rng) + check_mul<7>(7, rng) + check_mul<7>(5, rng) + check_mul<8>(5, rng) + check_mul<8>(3, rng);
     Plan pl;
     // refused: even characteristic, prime fields, more than 32 packed bits (3^11: 33), orders above 2^20, digits above 1021
     if (make_plan(2, 8, &pl) || make_plan(7, 1, &pl) || make_plan(3, 11, &pl) || make_plan(3, 13, &pl) || make_plan(1031, 2, &pl) || make_plan(101, 4, &pl)) {

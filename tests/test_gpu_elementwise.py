@@ -1033,7 +1033,7 @@ def test_packed_digit_sums_of_odd_characteristic_extension_fields(order, dt, mod
         GF.compile("auto")
 
 
-@pytest.mark.parametrize("order", [997**2, 97**3, 31**4, 13**5, 7**7])
+@pytest.mark.parametrize("order", [997**2, 97**3, 31**4, 13**5, 5**8, 7**7])
 def test_auto_mode_products_of_extension_fields_above_2e16_elements(order):
     """r05: in AUTO, products (degree 2: quotients and reciprocals too) of odd-characteristic extension fields with 65536 < q <= 2^20 run
     on the digit-vector kernels instead of three table gathers from L2 -- the reference's default for these fields is jit-lookup
