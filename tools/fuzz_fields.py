@@ -13,7 +13,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 999
 rng = np.random.default_rng(seed)
 ORDERS = [2, 3, 5, 31, 251, 257, 65521, 65537, 7340033, 2**31 - 1, 4294967291, 2**61 - 1, 2**64 - 2**32 + 1, 2**2, 2**8, 2**11,
-          2**16, 2**20, 2**32, 2**63, 3**2, 3**5, 7**3, 5**4, 251**3, 3**16, 31**6, 13**4]
+          2**16, 2**20, 2**32, 2**63, 3**2, 3**5, 7**3, 5**4, 251**3, 3**16, 31**6, 13**4, 3**10, 7**7, 997**2, 13**5]  # r05: packed-digit fields
 t_end = time.time() + budget
 count = 0
 
