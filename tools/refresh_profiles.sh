@@ -3,7 +3,7 @@
 #   /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/refresh_profiles.sh r04'
 # then copy gpurun_out/<round>_*.txt / .json / .csv into profiles/.
 set -u
-R=${1:-r04}
+R=${1:-r05}
 ONLY=${2:-all} # "codes": only the files the Reed-Solomon / BCH and Goldilocks kernels feed (about 2 GPU-minutes)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
@@ -52,3 +52,9 @@ bash tools/pmc_run.sh ${R}_pmc_ntt_m32_2e16 ntt_m32_2e16 -- python tools/ntt_mid
 bash tools/pmc_run.sh ${R}_pmc_ntt_goldilocks ntt_reg_kernel_gl -- python tools/goldi_time.py > /dev/null 2>&1
 bash tools/pmc_run.sh ${R}_pmc_rs_decode rs_ -- python tools/rs_decode_only.py 5 > /dev/null 2>&1
 ls -la "$OUT" | tail -30
+# r05 additions: packed-digit sums / digit-table products of the extension fields above the LDS table sizes, wide storage of the 2^16 band,
+# the three-pass / last-pass tuning sweep, the packed-intermediate skeletons
+python tools/ew_bench.py --packed 2>/dev/null | grep field > "$OUT/${R}_ew_packed.txt"
+python tools/ew_bench.py --widestore16 2>/dev/null | grep field > "$OUT/${R}_ew_widestore16.txt"
+python tools/m32_tune3.py > "$OUT/${R}_m32_tune3.txt" 2>/dev/null
+./tools/ubench/ntt_packed 64 > "$OUT/${R}_ntt_packed_intermediate.txt" 2>/dev/null
