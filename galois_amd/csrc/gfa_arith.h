@@ -41,7 +41,7 @@ struct FieldDev {
     u64 irr;    // GF(2^m): full irreducible polynomial (bit m set)
     u64 mu;     // PRIME32/EXT: floor(2^64 / p)
     u64 nprime; // PRIME64: -p^-1 mod 2^64
-    u64 r2;     // PRIME64: 2^128 mod p
+    u64 r2;     // PRIME64: 2^128 mod p.  EXT (r05): 1 when mul_m_small may skip its intermediate reductions (bound replayed at creation)
     u32 qm1;    // LUT: q - 1
     u32 zech_e; // LUT: (q-1)/2 for odd characteristic, 0 for characteristic 2
     const u32 *exp_tab;  // LUT: 2q entries (second half = EXP[1..q], as _lookup.py:371)
@@ -644,16 +644,40 @@ struct Ext {
         u32 nir[M];
 #pragma unroll
         for (int j = 0; j < M; j++) nir[j] = f.ext_irr[j] ? p32 - f.ext_irr[j] : 0u;
+        if (f.r2) {
+            // r05: no reduction before the end -- every partial sum of the product and of the folds stays below 2^32 for this field's
+            // own polynomial (ext_lazy_ok replays the worst case when the field is created): M - 1 reductions less per product
 #pragma unroll
-        for (int k = 0; k + 1 < M; k++) {
-            const u32 t = red32(c[k], p32, mu32);
+            for (int k = 0; k + 1 < M; k++) {
+                const u32 t = c[k];
 #pragma unroll
-            for (int j = 0; j < M; j++) c[k + 1 + j] += t * nir[j];
+                for (int j = 0; j < M; j++) c[k + 1 + j] += t * nir[j];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k + 1 < M; k++) {
+                const u32 t = red32(c[k], p32, mu32);
+#pragma unroll
+                for (int j = 0; j < M; j++) c[k + 1 + j] += t * nir[j];
+            }
         }
         u32 out[M];
 #pragma unroll
         for (int i = 0; i < M; i++) out[i] = red32(c[M - 1 + i], p32, mu32);
         return from_vec_m<M>(f, out);
+    }
+    // worst case of every partial sum of mul_m_small WITHOUT its intermediate reductions (host, at field creation)
+    static bool ext_lazy_ok(u64 p, u32 m, const u32 *ext_irr)
+    {
+        if (p >= (1u << 13) || m < 2 || m > 8) return false;
+        u64 B[15] = {};
+        for (u32 k = 0; k + 1 < 2 * m; k++) B[k] = (u64)(k < m ? k + 1 : 2 * m - 1 - k) * (p - 1) * (p - 1);
+        for (u32 k = 0; k + 1 < m; k++)
+            for (u32 j = 0; j < m; j++) {
+                B[k + 1 + j] += B[k] * (ext_irr[j] ? p - ext_irr[j] : 0);
+                if (B[k + 1 + j] >> 32) return false;
+            }
+        return true;
     }
     template <int M>
     static GFA_HD u64 mul_m(const FieldDev &f, u64 a, u64 b)

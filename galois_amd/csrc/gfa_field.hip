@@ -346,6 +346,7 @@ int gfa_field_create(uint64_t p, uint32_t m, const uint64_t *irr, uint64_t alpha
             d.kind = KIND_EXT;
             d.mu = (u64)((((unsigned __int128)1) << 64) / p);
             for (u32 i = 0; i < m; i++) d.ext_irr[i] = (u32)irr[i + 1];
+            d.r2 = Ext::ext_lazy_ok(p, m, d.ext_irr) ? 1 : 0;
         }
     }
 

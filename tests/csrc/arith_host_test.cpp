@@ -10,6 +10,7 @@
 using namespace gfa;
 
 // Ext::mul_m_small (32-bit accumulators, p < 2^13) against Ext::mul_m_wide (64-bit) on random and extreme digit vectors
+static long g_lazy_checked = 0;
 template <int M>
 static int check_ext_small(u32 p)
 {
@@ -33,7 +34,15 @@ static int check_ext_small(u32 p)
             u64 b = (x >> 11) % f.q;
             if (i % 50 == 0) a = f.q - 1; // every digit p - 1
             if (i % 75 == 0) b = f.q - 1;
-            if (Ext::mul_m_small<M>(f, a, b) != Ext::mul_m_wide<M>(f, a, b)) fails++;
+            f.r2 = 0;
+            const u64 want = Ext::mul_m_wide<M>(f, a, b);
+            if (Ext::mul_m_small<M>(f, a, b) != want) fails++;
+            // r05: the same product without intermediate reductions wherever the replayed bound allows it for THIS polynomial
+            if (Ext::ext_lazy_ok(p, M, f.ext_irr)) {
+                f.r2 = 1;
+                g_lazy_checked++;
+                if (Ext::mul_m_small<M>(f, a, b) != want) fails++;
+            }
         }
     }
     return fails;
@@ -46,6 +55,7 @@ int main()
         fails += check_ext_small<2>(p) + check_ext_small<3>(p) + check_ext_small<4>(p) + check_ext_small<5>(p) +
                  (p <= 251 ? check_ext_small<7>(p) + check_ext_small<8>(p) : 0);
     if (fails) printf("Ext::mul_m_small mismatches: %d\n", fails);
+    if (g_lazy_checked < 100000) { printf("lazy-fold path hardly exercised: %ld\n", g_lazy_checked); fails++; }
     {
         FieldDev f{};
         f.p = Goldilocks::P;

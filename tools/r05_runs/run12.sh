@@ -1,0 +1,10 @@
+#!/bin/bash
+# r05 GPU run 12: lazy folds in the GF(p^m) digit-vector product -- parity (element-wise suite, fuzz) and throughput
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out/r05
+export TMPDIR=/tmp
+( timeout 900 python -m pytest tests/test_gpu_elementwise.py tests/test_gpu_linalg.py tests/test_gpu_poly.py -q -m gpu 2>&1 | tail -8 ) > gpurun_out/r05/run12_pytest.txt 2>&1
+( timeout 200 python tools/fuzz_fields.py 60 909 2>&1 | grep -v amdgpu | tail -2 ) >> gpurun_out/r05/run12_pytest.txt 2>&1
+( timeout 400 python tools/ew_bench.py --ext 2>/dev/null | grep field ) > gpurun_out/r05_ew_ext.txt
+( timeout 400 python tools/ew_bench.py --extcalc 2>/dev/null | grep field ) >> gpurun_out/r05_ew_ext.txt
+tail -6 gpurun_out/r05/run12_pytest.txt; cut -c1-200 gpurun_out/r05_ew_ext.txt
