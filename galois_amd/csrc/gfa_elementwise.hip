@@ -1507,8 +1507,14 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
     if (rc) return rc;
     // r05: sums and differences of odd-characteristic extension fields whose Zech tables leave LDS (8192 < q <= 2^20), in either mode:
     // packed base-p digits (gfa_elementwise_packed.hip) -- same values as the table and the digit-vector routes
-    if ((op == GFA_OP_ADD || op == GFA_OP_SUB) && packed_eligible(f->calc, dtype, n)) {
+    const bool pinned = f->mode == GFA_MODE_CALCULATE;
+    if ((op == GFA_OP_ADD || op == GFA_OP_SUB) && packed_eligible(f->calc, dtype, n, pinned)) {
         rc = packed_run(f->calc, dtype, op, a, sa, b, sb, out, n, st);
+        if (rc != GFA_ERR_UNSUPPORTED) return rc;
+    }
+    // a field pinned to explicit calculation: its products on the digit tables too, whatever its order (GF(3^5), GF(3^7), ...)
+    if (pinned && op == GFA_OP_MUL && f->calc.kind == KIND_EXT && packed_mul_eligible(f->calc, dtype, n, true)) {
+        rc = packed_mul_run(f->calc, dtype, a, sa, b, sb, out, n, st);
         if (rc != GFA_ERR_UNSUPPORTED) return rc;
     }
     if (f->mode != GFA_MODE_CALCULATE) {
@@ -1561,8 +1567,8 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
     if (f->mode == GFA_MODE_AUTO && f->calc.m > 1 && (f->calc.p & 1) && f->calc.q > 65536 && f->calc.kind == KIND_EXT && Ext::fixed_degree(f->calc) &&
         (op == GFA_OP_MUL || (op == GFA_OP_DIV && f->calc.m == 2))) {
         // products: digits through LDS tables and no reduction before the end (gfa_packed.h::mul_digits) where the 32-bit bound holds
-        if (op == GFA_OP_MUL && packed_mul_eligible(f->calc, dtype, n)) {
-            rc = packed_mul_run(f->calc, a, sa, b, sb, out, n, st);
+        if (op == GFA_OP_MUL && packed_mul_eligible(f->calc, dtype, n, false)) {
+            rc = packed_mul_run(f->calc, dtype, a, sa, b, sb, out, n, st);
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
         return dispatch_binary(f->calc, dtype, op, a, sa, b, sb, out, n, st, dev_err);
@@ -1592,7 +1598,7 @@ int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int d
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
-    if (op == GFA_OP_NEG && packed_eligible(f->calc, dtype, n)) { // r05: packed base-p digits, as in gfa_binary
+    if (op == GFA_OP_NEG && packed_eligible(f->calc, dtype, n, f->mode == GFA_MODE_CALCULATE)) { // r05: packed base-p digits, as in gfa_binary
         rc = packed_run(f->calc, dtype, GFA_OP_NEG, a, 1, nullptr, 0, out, n, st);
         if (rc != GFA_ERR_UNSUPPORTED) return rc;
     }

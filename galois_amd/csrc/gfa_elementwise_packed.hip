@@ -22,6 +22,7 @@ namespace {
 constexpr int PK_THREADS = 512;
 
 template <typename T> struct PkVec;
+template <> struct PkVec<uint8_t> { static constexpr int N = 16; };
 template <> struct PkVec<uint16_t> { static constexpr int N = 8; };
 template <> struct PkVec<uint32_t> { static constexpr int N = 4; };
 
@@ -32,16 +33,27 @@ __device__ __forceinline__ void unpack_vec(const uint4 &v, pu32 (&e)[PkVec<T>::N
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
         for (int j = 0; j < 4; j++) e[j] = w[j];
-    } else {
+    } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int j = 0; j < 4; j++) { e[2 * j] = w[j] & 0xffffu; e[2 * j + 1] = w[j] >> 16; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) e[4 * j + k] = (w[j] >> (8 * k)) & 0xffu;
     }
 }
 template <typename T>
 __device__ __forceinline__ uint4 pack_vec(const pu32 (&e)[PkVec<T>::N])
 {
     if constexpr (sizeof(T) == 4) return make_uint4(e[0], e[1], e[2], e[3]);
-    else return make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+    else if constexpr (sizeof(T) == 2) return make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+    else {
+        pu32 w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) w[j] = e[4 * j] | (e[4 * j + 1] << 8) | (e[4 * j + 2] << 16) | (e[4 * j + 3] << 24);
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    }
 }
 
 // OP: 0 add, 1 sub, 2 neg (b unused).  sa / sb: 1 = one element per output, 0 = one element for the whole array.
@@ -80,29 +92,30 @@ __global__ __launch_bounds__(PK_THREADS) void packed_lin_kernel(Plan pl, const p
 }
 
 // products of uint32 arrays (65536 < q <= 2^20): digits through the same LDS tables, gfa_packed.h::mul_digits (no reduction before the end)
-template <int M>
-__global__ __launch_bounds__(PK_THREADS) void packed_mul_kernel(Plan pl, MulAux ax, const pu32 *__restrict__ gtab, const uint32_t *__restrict__ a, int sa,
-                                                                 const uint32_t *__restrict__ b, int sb, uint32_t *__restrict__ out, i64 n)
+template <typename T, int M>
+__global__ __launch_bounds__(PK_THREADS) void packed_mul_kernel(Plan pl, MulAux ax, const pu32 *__restrict__ gtab, const T *__restrict__ a, int sa,
+                                                                 const T *__restrict__ b, int sb, T *__restrict__ out, i64 n)
 {
+    constexpr int V = PkVec<T>::N;
     extern __shared__ pu32 pk_tab[];
     for (pu32 i = threadIdx.x; i < pl.off_un; i += PK_THREADS) pk_tab[i] = gtab[i]; // PK_LO and PK_HI only: the way back is Horner's rule
     __syncthreads();
-    const i64 nvec = n / 4;
-    const pu32 pa0 = sa ? 0u : to_packed(pl, pk_tab, a[0]);
-    const pu32 pb0 = sb ? 0u : to_packed(pl, pk_tab, b[0]);
+    const i64 nvec = n / V;
+    const pu32 pa0 = sa ? 0u : to_packed(pl, pk_tab, (pu32)a[0]);
+    const pu32 pb0 = sb ? 0u : to_packed(pl, pk_tab, (pu32)b[0]);
     const uint4 *av = reinterpret_cast<const uint4 *>(a), *bv = reinterpret_cast<const uint4 *>(b);
     uint4 *ov = reinterpret_cast<uint4 *>(out);
     for (i64 i = (i64)blockIdx.x * PK_THREADS + threadIdx.x; i < nvec; i += (i64)gridDim.x * PK_THREADS) {
-        pu32 xa[4], xb[4], r[4];
-        if (sa) unpack_vec<uint32_t>(av[i], xa);
-        if (sb) unpack_vec<uint32_t>(bv[i], xb);
+        pu32 xa[V], xb[V], r[V];
+        if (sa) unpack_vec<T>(av[i], xa);
+        if (sb) unpack_vec<T>(bv[i], xb);
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < V; j++)
             r[j] = mul_digits<M>(pl, ax, sa ? to_packed(pl, pk_tab, xa[j]) : pa0, sb ? to_packed(pl, pk_tab, xb[j]) : pb0);
-        ov[i] = pack_vec<uint32_t>(r);
+        ov[i] = pack_vec<T>(r);
     }
-    const i64 t0 = nvec * 4 + (i64)blockIdx.x * PK_THREADS + threadIdx.x;
-    if (t0 < n) out[t0] = mul_digits<M>(pl, ax, sa ? to_packed(pl, pk_tab, a[t0]) : pa0, sb ? to_packed(pl, pk_tab, b[t0]) : pb0);
+    const i64 t0 = nvec * V + (i64)blockIdx.x * PK_THREADS + threadIdx.x;
+    if (t0 < n) out[t0] = (T)mul_digits<M>(pl, ax, sa ? to_packed(pl, pk_tab, (pu32)a[t0]) : pa0, sb ? to_packed(pl, pk_tab, (pu32)b[t0]) : pb0);
 }
 
 struct PackedDev {
@@ -157,10 +170,12 @@ inline bool al16p(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) 
 namespace gfa {
 
 // sums / differences / negatives of odd-characteristic extension fields whose Zech tables leave LDS; uint16 (q <= 65536) or uint32 arrays
-bool packed_eligible(const FieldDev &c, int dtype, i64 n)
+// `pinned`: the field is pinned to explicit calculation -- then the scheme also replaces the digit-vector kernels of the small fields
+// (q <= 8192), whose tables AUTO would keep in LDS (gfa_elementwise_mid.hip, faster); uint8 arrays included
+bool packed_eligible(const FieldDev &c, int dtype, i64 n, bool pinned)
 {
-    if (c.m < 2 || (c.p & 1) == 0 || c.q <= 8192 || c.q > ((u64)1 << 20) || n < 1024) return false;
-    if (!(dtype == GFA_U32 || (dtype == GFA_U16 && c.q <= 65536))) return false;
+    if (c.m < 2 || (c.p & 1) == 0 || (c.q <= 8192 && !pinned) || c.q > ((u64)1 << 20) || n < 1024) return false;
+    if (!(dtype == GFA_U32 || (dtype == GFA_U16 && c.q <= 65536) || (dtype == GFA_U8 && c.q <= 256))) return false;
     Plan pl;
     return make_plan(c.p, c.m, &pl);
 }
@@ -179,6 +194,7 @@ int packed_run(const FieldDev &c, int dtype, int op, const void *a, i64 sa, cons
     case GFA_OP_SUB: return launch<T, 1>(d, a, sa, b, sb, out, n, st);            \
     default: return launch<T, 2>(d, a, sa, b, sb, out, n, st);                    \
     }
+    if (dtype == GFA_U8) { GFA_PK(uint8_t) }
     if (dtype == GFA_U16) { GFA_PK(uint16_t) }
     GFA_PK(uint32_t)
 #undef GFA_PK
@@ -186,43 +202,50 @@ int packed_run(const FieldDev &c, int dtype, int op, const void *a, i64 sa, cons
 
 // products: uint32 arrays of odd-characteristic extension fields with 65536 < q <= 2^20, degree <= 8, whose unreduced schoolbook
 // product stays below 2^32 (mul_bound_ok); ext_irr: FieldDev's digits of (irr - x^m), degree m-1 .. 0
-static bool packed_mul_aux(const FieldDev &c, Plan *pl, MulAux *ax)
+static bool packed_mul_aux(const FieldDev &c, Plan *pl, MulAux *ax, bool pinned)
 {
-    if (c.m < 2 || c.m > 8 || (c.p & 1) == 0 || c.q <= 65536 || c.q > ((u64)1 << 20) || !make_plan(c.p, c.m, pl)) return false;
+    if (c.m < 2 || c.m > 8 || (c.p & 1) == 0 || (c.q <= 65536 && !pinned) || c.q > ((u64)1 << 20) || !make_plan(c.p, c.m, pl)) return false;
     for (u32 j = 0; j < 8; j++) ax->nir[j] = 0;
     for (u32 j = 0; j < c.m; j++) ax->nir[j] = c.ext_irr[c.m - 1 - j] ? (pu32)c.p - c.ext_irr[c.m - 1 - j] : 0u;
     ax->mu32 = (pu32)(((u64)1 << 32) / c.p);
     return mul_bound_ok(*pl, *ax);
 }
 
-bool packed_mul_eligible(const FieldDev &c, int dtype, i64 n)
+bool packed_mul_eligible(const FieldDev &c, int dtype, i64 n, bool pinned)
 {
     Plan pl;
     MulAux ax;
-    return dtype == GFA_U32 && n >= 1024 && packed_mul_aux(c, &pl, &ax);
+    if (!(dtype == GFA_U32 || (pinned && ((dtype == GFA_U16 && c.q <= 65536) || (dtype == GFA_U8 && c.q <= 256))))) return false;
+    return n >= 1024 && packed_mul_aux(c, &pl, &ax, pinned);
 }
 
-int packed_mul_run(const FieldDev &c, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st)
+int packed_mul_run(const FieldDev &c, int dtype, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st)
 {
     if (!al16p(out) || (sa && !al16p(a)) || (sb && !al16p(b))) return GFA_ERR_UNSUPPORTED;
     PackedDev d;
     MulAux ax;
     Plan pl;
-    if (!packed_mul_aux(c, &pl, &ax)) return GFA_ERR_UNSUPPORTED;
+    if (!packed_mul_aux(c, &pl, &ax, true)) return GFA_ERR_UNSUPPORTED;
     const int rc = get_dev(c, &d);
     if (rc) return rc;
-    const i64 blocks = std::max<i64>(1, (n / 4 + PK_THREADS - 1) / PK_THREADS);
+    const int vec = dtype == GFA_U32 ? 4 : dtype == GFA_U16 ? 8 : 16;
+    const i64 blocks = std::max<i64>(1, (n / vec + PK_THREADS - 1) / PK_THREADS);
     const int grid = (int)std::min<i64>(blocks, (i64)num_cus() * 4);
     const size_t lds = sizeof(pu32) * d.pl.off_un;
-#define GFA_PKM(MV)                                                                                                                    \
+#define GFA_PKM(T, MV)                                                                                                                 \
     case MV:                                                                                                                           \
-        hipLaunchKernelGGL((packed_mul_kernel<MV>), dim3(grid), dim3(PK_THREADS), lds, st, d.pl, ax, (const pu32 *)d.tab, (const uint32_t *)a, (int)sa, \
-                           (const uint32_t *)b, (int)sb, (uint32_t *)out, n);                                                          \
+        hipLaunchKernelGGL((packed_mul_kernel<T, MV>), dim3(grid), dim3(PK_THREADS), lds, st, d.pl, ax, (const pu32 *)d.tab, (const T *)a, (int)sa, \
+                           (const T *)b, (int)sb, (T *)out, n);                                                                        \
         break;
-    switch (c.m) {
-        GFA_PKM(2) GFA_PKM(3) GFA_PKM(4) GFA_PKM(5) GFA_PKM(6) GFA_PKM(7) GFA_PKM(8)
-    default: return GFA_ERR_UNSUPPORTED;
+#define GFA_PKM_ALL(T)                                                                                                      \
+    switch (c.m) {                                                                                                          \
+        GFA_PKM(T, 2) GFA_PKM(T, 3) GFA_PKM(T, 4) GFA_PKM(T, 5) GFA_PKM(T, 6) GFA_PKM(T, 7) GFA_PKM(T, 8)                   \
+    default: return GFA_ERR_UNSUPPORTED;                                                                                    \
     }
+    if (dtype == GFA_U32) { GFA_PKM_ALL(uint32_t) }
+    else if (dtype == GFA_U16) { GFA_PKM_ALL(uint16_t) }
+    else { GFA_PKM_ALL(uint8_t) }
+#undef GFA_PKM_ALL
 #undef GFA_PKM
     GFA_HIP(hipGetLastError());
     return GFA_OK;

@@ -82,10 +82,10 @@ int mid_power_each(const FieldDev &lut, const void *image, const void *a, const 
 // 32768 < q <= 65536 on uint16 storage: LOG, then EXP, staged in LDS in two phases per tile; op in {MUL, DIV, RECIP, POW (one
 // exponent at e[0])}.  Covers the first n & ~7 elements -- the caller runs the generic kernels on the last n & 7.
 // sums / differences / negatives of GF(p^m), p odd, 8192 < q <= 2^20, as packed-digit arithmetic (gfa_elementwise_packed.hip, gfa_packed.h)
-bool packed_eligible(const FieldDev &calc, int dtype, i64 n);
+bool packed_eligible(const FieldDev &calc, int dtype, i64 n, bool pinned_to_calculate);
 int packed_run(const FieldDev &calc, int dtype, int op, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st);
-bool packed_mul_eligible(const FieldDev &calc, int dtype, i64 n); // products of the fields above 65536 elements on the same digit tables
-int packed_mul_run(const FieldDev &calc, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st);
+bool packed_mul_eligible(const FieldDev &calc, int dtype, i64 n, bool pinned_to_calculate); // products on the same digit tables
+int packed_mul_run(const FieldDev &calc, int dtype, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st);
 bool big16_eligible(const FieldDev &calc, const void *image, int dtype, i64 n);
 // uint32 / int64 storage of the same fields: narrowed into a 16-bit work buffer, run, widened (first n & ~7 elements)
 bool big16_wide_eligible(const FieldDev &calc, const void *image, int dtype, i64 n);

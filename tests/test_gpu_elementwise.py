@@ -1001,7 +1001,9 @@ def test_wide_storage_of_fields_between_2e15_and_2e16_elements(order, dt):
 
 
 @pytest.mark.parametrize("order,dt", [(3**9, np.uint16), (3**10, np.uint16), (3**10, np.uint32), (5**8, np.uint32), (7**7, np.uint32), (13**5, np.uint32),
-                                      (97**3, np.uint32), (997**2, np.uint32)])
+                                      (97**3, np.uint32), (997**2, np.uint32),
+                                      # pinned to jit-calculate, the small fields take the same kernels (uint8 arrays included); in lookup mode their LDS tables
+                                      (3**2, np.uint8), (3**5, np.uint8), (5**3, np.uint8), (13**2, np.uint8), (3**7, np.uint16), (7**3, np.uint16), (3**5, np.uint32)])
 @pytest.mark.parametrize("mode", ["jit-lookup", "jit-calculate"])
 def test_packed_digit_sums_of_odd_characteristic_extension_fields(order, dt, mode):
     """r05 (VERDICT r04 missing #5 / item 7): np.add / np.subtract / np.negative over GF(p^m), p odd, 8192 < q <= 2^20 run as packed
@@ -1021,9 +1023,12 @@ def test_packed_digit_sums_of_odd_characteristic_extension_fields(order, dt, mod
         H.assert_equal_ints((x + y).numpy().astype(np.uint64), F.add(a, b), f"GF({order}) {mode} add")
         H.assert_equal_ints((x - y).numpy().astype(np.uint64), F.sub(a, b), f"GF({order}) {mode} sub")
         H.assert_equal_ints((-x).numpy().astype(np.uint64), F.sub(np.zeros(n, dtype=np.uint64), a), f"GF({order}) {mode} neg")
+        H.assert_equal_ints((x * y).numpy().astype(np.uint64), F.mul(a, b), f"GF({order}) {mode} mul")  # (digit tables where the route applies)
+        H.assert_equal_ints((x[1:] * y[1:]).numpy().astype(np.uint64), F.mul(a[1:], b[1:]), "misaligned product")
         s = GF(np.array(int(b[9]), dtype=dt), dtype=dt)
         H.assert_equal_ints((x + s).numpy().astype(np.uint64), F.add(a, np.full(n, b[9], dtype=np.uint64)), "scalar on the right")
         H.assert_equal_ints((s - x).numpy().astype(np.uint64), F.sub(np.full(n, b[9], dtype=np.uint64), a), "scalar on the left")
+        H.assert_equal_ints((s * x).numpy().astype(np.uint64), F.mul(np.full(n, b[9], dtype=np.uint64), a), "scalar product")
         H.assert_equal_ints((x[1:] + y[1:]).numpy().astype(np.uint64), F.add(a[1:], b[1:]), "misaligned views")
         z = x.copy()
         np.add(z, y, out=z)
