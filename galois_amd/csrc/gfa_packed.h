@@ -71,6 +71,7 @@ inline bool make_plan(uint64_t p64, uint32_t m, Plan *pl)
         r.pfull |= p << (W * i);
     }
     r.k = k; r.nch = (m + k - 1) / k; r.chunk_bits = k * W;
+    if (r.nch > 4) return false; // (cannot happen for m W <= 32; from_packed is written for at most four chunks)
     r.off_hi = r.P; r.off_un = r.P + r.QH; r.words = r.off_un + (r.nch << r.chunk_bits);
     *pl = r;
     return true;
@@ -133,9 +134,14 @@ GFP_HD pu32 lin_packed(const Plan &pl, pu32 a, pu32 b)
 }
 GFP_HD pu32 from_packed(const Plan &pl, const pu32 *tab, pu32 w)
 {
-    const pu32 mask = (1u << pl.chunk_bits) - 1u;
-    pu32 v = 0;
-    for (pu32 c = 0; c < pl.nch; c++) v += tab[pl.off_un + (c << pl.chunk_bits) + ((w >> (c * pl.chunk_bits)) & mask)];
+    // nch <= 4 (m W <= 32 bits in chunks of k W, k = floor(11 / W) fields: ceil(m / k) <= 4 for every accepted field); written out
+    // with uniform branches: a run-time loop costs ~30 scalar instructions per element on the device (profiles/r05_pmc_packed.txt)
+    const pu32 cb = pl.chunk_bits, mask = (1u << cb) - 1u;
+    const pu32 *t = tab + pl.off_un;
+    pu32 v = t[w & mask];
+    if (pl.nch > 1) v += t[(1u << cb) + ((w >> cb) & mask)];
+    if (pl.nch > 2) v += t[(2u << cb) + ((w >> (2 * cb)) & mask)];
+    if (pl.nch > 3) v += t[(3u << cb) + ((w >> (3 * cb)) & mask)];
     return v;
 }
 
