@@ -36,6 +36,15 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _deps(o: str, s: str) -> list[str]:
+    """Headers the object was built from (the compiler's own -MMD record); every header when there is no record yet."""
+    d = o[:-2] + ".d"
+    if not os.path.exists(d):
+        return [s] + HEADERS
+    txt = open(d).read().replace("\\\n", " ")
+    return [s] + [t for t in txt.split(":", 1)[-1].split() if os.path.exists(t)]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
@@ -43,12 +52,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + HEADERS):
+        if force or _stale(o, _deps(o, s)):
             jobs.append((s, o))
 
     def compile_one(job):
         s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + ["-MMD", "-MF", o[:-2] + ".d", "-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

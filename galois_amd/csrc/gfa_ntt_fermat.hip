@@ -13,7 +13,11 @@
 //     loose signed 32-bit representatives; tools/gen_fermat_net.py places the folds with exact interval tracking
 //     (gfa_fermat_nets.inc is its output);
 //   * only the two twiddles BETWEEN networks are general products: balanced 16-bit factors, one v_mul_lo_u32 + two folds.
-//     w^(m*k0) comes from a 256 KiB table that every workgroup shares (L2 resident), w_1024^(r*k1) from a 4 KiB LDS table;
+//     w^(m*k0) is formed in registers from two per-thread seeds (gfa_fermat_tw.h; r03-r05 streamed a 256 KiB table through the
+//     same in-order memory queue as the data: 2-3.5 us of waiting per ~28 us round), w_1024^(r*k1) comes from a 4 KiB LDS table;
+//   * the next transform's input is requested as early as registers allow: 16 rows once exchange 1 has taken the points, 24
+//     more before the second half of network 1, the last 24 after the stores (r06: 0.57 -> 0.65 of the HBM roofline at 1024
+//     transforms, 0.51 -> 0.64 at 4096; tools/ubench/fermat_r06.hip holds the variants, profiles/r06_fermat_*.txt the numbers);
 //   * the networks use the canonical roots (sqrt(2), 2).  A transform with root of unity w has w^(N/64) = sqrt(2)^u for
 //     one odd u; feeding network inputs in the order a' = u*a mod R turns the canonical network into the wanted one, and
 //     that permutation is folded into the global load addresses and the LDS write positions (no instructions).
@@ -51,6 +55,7 @@ __device__ __forceinline__ int fm_bfold(int t)
 }
 
 #include "gfa_fermat_nets.inc"
+#include "gfa_fermat_tw.h"
 
 constexpr int brev_c(int x, int bits)
 {
@@ -69,18 +74,13 @@ constexpr int FERMAT_LDS_BYTES = (EX_WORDS + 1024) * 4;
 struct FermatArgs {
     const u32 *in;
     u32 *out;
-    const int *tw1; // [64][1024]: balanced w^(m * k0)
+    const int *tw1; // [2][1024]: balanced w^m and w^(8 m), the seeds of the first twiddles
     const int *tw2; // [32][32]:   balanced w^(64 * r * k1), index k1 * 32 + r
     int u, uinv;    // w^(N/64) == sqrt(2)^u, uinv = u^-1 mod 64
     int batch;
     int stagger;    // first-round start offset between the four workgroup groups, in units of 4096 clocks (0: none)
     unsigned long long *dbg; // optional phase timestamps (100 MHz), 8 per (workgroup, round); nullptr in production
 };
-#define FM_STAMP(i)                                     \
-    do {                                                \
-        if (DBG) ts[i] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-
 // final reduction of a network output |c| < 2^29 to the canonical [0, 65536] (NEGATE: of -c, the 1/N of the inverse):
 // adding a multiple of p first makes the value non-negative, the first fold then ends in [-2^14, 65535] and the second
 // in [0, 65536] -- no conditional step
@@ -108,11 +108,30 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 #ifndef GFA_FERMAT_AUX_ST
 #define GFA_FERMAT_AUX_ST 2
 #endif
-#ifndef GFA_FERMAT_TWW
-#define GFA_FERMAT_TWW 32
+// the next transform's rows requested ahead: [0, E1) after the second exchange-1 write burst (the point registers are free),
+// [E1, E2) before the second half of network 1; 42 and more spill (tools/ubench/fermat_r06.hip, profiles/r06_fermat_varB_early_loads.txt)
+#ifndef GFA_FERMAT_E1
+#define GFA_FERMAT_E1 16
+#endif
+#ifndef GFA_FERMAT_E2
+#define GFA_FERMAT_E2 40
 #endif
 constexpr int AUX_NT = GFA_FERMAT_AUX_LD; // streaming (non-temporal) hint on the data loads: keep the shared twiddle table in L2
 constexpr int AUX_ST = GFA_FERMAT_AUX_ST; // ... and on the stores
+
+// The body of the loop is ONE basic block for the compiler unless something splits it, and its scheduler then stretches live
+// ranges across phases until the allocator spills (every r04 variant with early loads did, 40-250 bytes, and lost 5-25 %).  A
+// never-taken branch at each phase boundary -- what the time stamps of the DBG build are -- keeps the allocation at 128 registers
+// with no scratch (r06).
+#define FM_PHASE(i)                                          \
+    do {                                                     \
+        if (DBG) ts[i] = __builtin_amdgcn_s_memrealtime();   \
+        else if (a.dbg != nullptr) asm volatile("s_nop 0");  \
+    } while (0)
+#define FM_SPLIT()                                           \
+    do {                                                     \
+        if (a.dbg != nullptr) asm volatile("s_nop 0");       \
+    } while (0)
 
 template <bool NEGATE, bool DBG>
 __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
@@ -130,8 +149,8 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
     const int *const e1r = ex + g * 1024 + r;
     int *const e2w = ex + g * E2_PITCH + wpos2;
     const int *const e2r = ex + wv * (64 * E2_PITCH) + l * E2_PITCH;
-    const __amdgpu_buffer_rsrc_t tr = __builtin_amdgcn_make_buffer_rsrc((void *)a.tw1, 0, 65536 * 4, 0x00020000);
     tw2l[tid] = a.tw2[tid];
+    const int seed1 = a.tw1[tid], seed8 = a.tw1[1024 + tid]; // w^m, w^(8 m): the whole kernel
     // Workgroups are persistent (one per CU) and all run the same program, so without help every CU would read, compute
     // and write at the same moments and HBM would idle while the chip computes.  The first round is staggered in four
     // groups (each XCD holds all four): group j starts j * stagger later, and the offset persists from round to round.
@@ -140,11 +159,14 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
         for (int i = 0; i < grp * a.stagger; i++) __builtin_amdgcn_s_sleep(64);
     }
     // every global access is `buffer_* v, v_off, s[rsrc], s_off offen`: lane offset tid*4 in one VGPR, row offset in an
-    // SGPR, descriptors from kernel arguments and the (wave-uniform) transform index -- no vector address arithmetic
-    auto in_rsrc = [&](unsigned t) { return __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (size_t)t * 65536u), 0, 65536 * 4, 0x00020000); };
+    // SGPR, descriptors from kernel arguments and the (wave-uniform) transform index -- no vector address arithmetic.
+    // `live` = false gives a descriptor of zero records: its loads return 0 and move nothing (the last round's look-ahead)
+    auto in_rsrc = [&](unsigned t, bool live) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (size_t)t * 65536u), 0, live ? 65536 * 4 : 0, 0x00020000);
+    };
     int v[64];
     {
-        const __amdgpu_buffer_rsrc_t xr = in_rsrc(blockIdx.x);
+        const __amdgpu_buffer_rsrc_t xr = in_rsrc(blockIdx.x, true);
 #pragma unroll
         for (int ap = 0; ap < 64; ap++) v[ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xr, voff, (int)((((unsigned)a.uinv * ap) & 63u) << 12), AUX_NT);
     }
@@ -152,31 +174,30 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (size_t)tr_i * 65536u), 0, 65536 * 4, 0x00020000);
         const unsigned tr_next = tr_i + gridDim.x;
         const bool has_next = tr_next < (unsigned)a.batch;
-        const __amdgpu_buffer_rsrc_t xn = in_rsrc(has_next ? tr_next : tr_i);
+        const __amdgpu_buffer_rsrc_t xn = in_rsrc(has_next ? tr_next : tr_i, has_next);
         unsigned uinv = (unsigned)a.uinv;
         asm volatile("" : "+s"(uinv)); // keep the 64 row offsets out of loop-invariant SGPRs (they are 3 scalar ops each)
         unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // phase timestamps: scalar registers, written out once at the end
-        FM_STAMP(0);
-        // ---- network 0: radix 64 over a (stride 1024); thread m = tid.  Twiddles w^(m * k0), k0 = 1..63, come from the
-        // shared 256 KiB table (L2 resident): a rolling window of TWW values is requested ahead of its use so that the L2
-        // latency hides behind the network and the products themselves
-        constexpr int TWW = GFA_FERMAT_TWW;
-        int tw[TWW];
+        auto request = [&](int lo, int hi) { // rows lo .. hi-1 of the next transform, into the point registers it will start from
 #pragma unroll
-        for (int i = 0; i < TWW; i++) tw[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(tr, voff, (i + 1) * 4096, 0);
+            for (int ap = lo; ap < hi; ap++) v[ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xn, voff, (int)(((uinv * ap) & 63u) << 12), AUX_NT);
+        };
+        FM_PHASE(0);
+        // ---- network 0: radix 64 over a (stride 1024); thread m = tid.  Twiddles w^(m * k0), k0 = 1..63: gfa_fermat_tw.h ----
         fermat_net64_canon(v);
-        FM_STAMP(1);
+        FM_PHASE(1);
         v[0] = fm_fold(v[0]);
+        int twa[8], twb[8];
+        fm_tw_progressions(seed1, seed8, twa, twb);
         auto tw1_range = [&](int lo, int hi) {
 #pragma unroll
             for (int k0 = lo; k0 < hi; k0++) {
                 int &q = v[brev_c(k0, 6)];
-                q = fm_mul_tw(q, tw[(k0 - 1) % TWW]);
-                if (k0 + TWW < 64) tw[(k0 - 1) % TWW] = (int)__builtin_amdgcn_raw_buffer_load_b32(tr, voff, (k0 + TWW) * 4096, 0);
+                q = fm_tw_apply(q, fm_tw_of(twa, twb, k0));
             }
         };
         tw1_range(1, 32);
-        FM_STAMP(2);
+        FM_PHASE(2);
         // ---- exchange 1 + network 1: thread (g, r) takes k0 = g and g + 32, radix 32 over b (m = 32 b + r).  Each LDS
         // write burst is followed by arithmetic that does not depend on it, so the LDS pipe and the VALU overlap ----
         int w[2][32];
@@ -190,7 +211,8 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
         lds_barrier();
 #pragma unroll
         for (int kl = 0; kl < 32; kl++) e1w[kl * 1024] = v[brev_c(kl + 32, 6)];
-        FM_STAMP(3);
+        FM_PHASE(3);
+        request(0, GFA_FERMAT_E1);
         auto net1 = [&](int h) {
             fermat_net32_fold(w[h]);
             w[h][0] = fm_fold(w[h][0]);
@@ -204,8 +226,10 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
         lds_barrier();
 #pragma unroll
         for (int bp = 0; bp < 32; bp++) w[1][bp] = e1r[bp * 32];
+        FM_SPLIT();
+        request(GFA_FERMAT_E1, GFA_FERMAT_E2);
         net1(1);
-        FM_STAMP(4);
+        FM_PHASE(4);
         // ---- exchange 2 + network 2: thread (lane l = k0, wave wv) takes k1 = wv and wv + 16, radix 32 over r ----
         int z[2][32];
         lds_barrier();
@@ -221,7 +245,7 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int kl = 0; kl < 16; kl++) e2w[kl * (64 * E2_PITCH) + 32 * i * E2_PITCH] = w[i][brev_c(kl + 16, 5)];
-        FM_STAMP(5);
+        FM_PHASE(5);
         auto net2 = [&](int h) {
             fermat_net32_fold(z[h]);
             // X[k0 + 64 * (k1 + 32 * k2)], k1 = wv + 16 h: lane offset tid
@@ -230,21 +254,14 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
                 __builtin_amdgcn_raw_buffer_store_b32(fm_canon<NEGATE>(z[h][brev_c(k2, 5)]), yr, voff, (2048 * k2 + 1024 * h) * 4, AUX_ST);
         };
         net2(0);
-        FM_STAMP(6);
-        // the next transform's first half is requested as soon as registers are free
-        if (has_next) {
-#pragma unroll
-            for (int ap = 0; ap < 32; ap++) v[ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xn, voff, (int)(((uinv * ap) & 63u) << 12), AUX_NT);
-        }
+        FM_PHASE(6);
         lds_barrier();
 #pragma unroll
         for (int rp = 0; rp < 32; rp++) z[1][rp] = e2r[rp];
+        FM_SPLIT();
         net2(1);
-        if (has_next) {
-#pragma unroll
-            for (int ap = 32; ap < 64; ap++) v[ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xn, voff, (int)(((uinv * ap) & 63u) << 12), AUX_NT);
-        }
-        FM_STAMP(7);
+        request(GFA_FERMAT_E2, 64);
+        FM_PHASE(7);
         if (DBG && tid == 0) {
             unsigned long long *d = a.dbg + ((size_t)(tr_i / gridDim.x) * gridDim.x + blockIdx.x) * 8;
 #pragma unroll
@@ -301,12 +318,14 @@ int ntt_fermat16(const void *in, void *out, i64 batch, u64 omega, int negate, hi
             if (!u) return GFA_ERR_UNSUPPORTED;
             int uinv = 1;
             while ((u * uinv) % 64 != 1) uinv += 2;
-            std::vector<int> t1(64 * 1024), t2(32 * 32);
+            std::vector<int> t1(2 * 1024), t2(32 * 32);
             std::vector<u32> pw(65536);
             pw[0] = 1;
             for (int e = 1; e < 65536; e++) pw[e] = mulmod(pw[e - 1], (u32)omega);
-            for (int k0 = 0; k0 < 64; k0++)
-                for (int m = 0; m < 1024; m++) t1[k0 * 1024 + m] = balanced(pw[(m * k0) & 65535]);
+            for (int m = 0; m < 1024; m++) {
+                t1[m] = balanced(pw[m]);                      // w^m
+                t1[1024 + m] = balanced(pw[(8 * m) & 65535]); // w^(8 m)
+            }
             for (int k1 = 0; k1 < 32; k1++)
                 for (int r = 0; r < 32; r++) t2[k1 * 32 + r] = balanced(pw[(64 * r * k1) & 65535]);
             GFA_HIP(hipMalloc((void **)&p.tw1, t1.size() * sizeof(int)));

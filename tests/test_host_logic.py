@@ -361,6 +361,20 @@ def test_signed_montgomery_networks_on_the_host_never_leave_int32(tmp_path, repo
     assert r.returncode == 0 and "m32 networks ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_fermat_first_twiddles_in_registers_on_the_host(tmp_path, repo_root):
+    """galois_amd/csrc/gfa_fermat_tw.h on the host (r06: the one-pass GF(65537) kernel forms w^(m k0) from two per-thread seeds
+    instead of streaming a 256 KiB table): the same header over a range-checking integer for every column, every output and
+    five roots of unity -- values against w^(m k0) mod 65537, every product / fold against the int32 range, the stated bounds
+    (tests/csrc/fermat_tw_host_test.cpp)."""
+    import subprocess
+
+    exe = str(tmp_path / "fermat_tw_test")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(repo_root, "galois_amd", "csrc"),
+                    os.path.join(repo_root, "tests", "csrc", "fermat_tw_host_test.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "range failures 0, wrong 0" in r.stdout, r.stdout + r.stderr
+
+
 def test_packed_digit_sums_on_the_host(tmp_path, repo_root):
     """galois_amd/csrc/gfa_packed.h on the host (r05): packed base-p digit sums / differences / negatives of GF(p^m), p odd, against
     digit-wise arithmetic -- every element pair of the small fields, random and edge pairs of 22 field shapes up to 2^20 elements, the
