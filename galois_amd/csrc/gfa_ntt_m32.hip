@@ -257,7 +257,19 @@ struct M32OneArgs {
     u32 pinv;
     i32 one, onep; // Montgomery form of 1 and its companion (normalises the untwiddled k0 = 0 outputs of phase 1)
     i32 fin, finp; // last product: Montgomery form of 1 or of 1/n
+    const int *never; // always nullptr: `if (a.never) s_nop` is a never-taken branch that splits the loop body's basic block (M32_SPLIT)
 };
+// One straight-line loop body lets the scheduler stretch live ranges across phases until the allocator spills; a phase boundary the
+// scheduler cannot cross keeps the early requests of the next transform within the 128-register budget (r06, gfa_ntt_fermat.hip)
+#ifndef GFA_M32_SPLIT_MODE
+#define GFA_M32_SPLIT_MODE 0 // 0: scheduling barrier only; 1: never-taken branch; 2: both.  Measured per kernel: the Montgomery 2^16 kernel
+                             // stays spill-free with the barrier alone and spills 112-268 bytes with the branch; the GF(65537) kernel is the other way round
+#endif
+#define M32_SPLIT()                                                                      \
+    do {                                                                                 \
+        if (GFA_M32_SPLIT_MODE != 1) __builtin_amdgcn_sched_barrier(0);                  \
+        if (GFA_M32_SPLIT_MODE != 0 && a.never != nullptr) asm volatile("s_nop 0");      \
+    } while (0)
 
 template <int LOGR0>
 constexpr int one_pitch()
@@ -375,6 +387,17 @@ constexpr int B16_E2_PITCH = 33;
 constexpr int B16_EX_WORDS = 16 * 64 * B16_E2_PITCH; // 33792 words >= exchange 1's 32 * 1024
 constexpr size_t B16_LDS_BYTES = sizeof(i32) * (size_t)(B16_EX_WORDS + 2 * 1024);
 
+// the next transform's rows requested ahead (r06, as in gfa_ntt_fermat.hip): [0, E1) once exchange 1 has taken the points, [E1, E2) before the
+// second half of network 1, [E2, E3) after the first half's stores, the rest at the end
+#ifndef GFA_M32_B16_E1
+#define GFA_M32_B16_E1 16
+#endif
+#ifndef GFA_M32_B16_E2
+#define GFA_M32_B16_E2 36 // 40 spills (profiles/r06_m32_2e16_early_loads.txt)
+#endif
+#ifndef GFA_M32_B16_E3
+#define GFA_M32_B16_E3 (GFA_M32_B16_E2 > 32 ? GFA_M32_B16_E2 : 32)
+#endif
 template <int BMAX>
 __global__ __launch_bounds__(1024) void ntt_m32_2e16_kernel(const i32 *in, i32 *out, M32OneArgs a, const i32 *__restrict__ net0,
                                                             const i32 *__restrict__ net1, const i32 *__restrict__ mid, const i32 *__restrict__ wj, i64 batch)
@@ -397,20 +420,25 @@ __global__ __launch_bounds__(1024) void ntt_m32_2e16_kernel(const i32 *in, i32 *
         reinterpret_cast<int2 *>(midl)[tid] = reinterpret_cast<const int2 *>(mid)[r * k1];
     }
     const i32 ratio = wj[tid]; // w^m in Montgomery form
-    auto in_rsrc = [&](i64 t) { return __builtin_amdgcn_make_buffer_rsrc((void *)(in + t * 65536), 0, 65536 * 4, 0x00020000); };
+    // `live` = false: a descriptor of zero records -- the last round's look-ahead requests return 0 and move nothing
+    auto in_rsrc = [&](i64 t, bool live) { return __builtin_amdgcn_make_buffer_rsrc((void *)(in + t * 65536), 0, live ? 65536 * 4 : 0, 0x00020000); };
     i32 v[64];
     {
-        const __amdgpu_buffer_rsrc_t xr = in_rsrc(blockIdx.x);
+        const __amdgpu_buffer_rsrc_t xr = in_rsrc(blockIdx.x, true);
 #pragma unroll
         for (int ap = 0; ap < 64; ap++) v[ap] = __builtin_amdgcn_raw_buffer_load_b32(xr, voff, ap * 4096, 0);
     }
     for (i64 tr_i = blockIdx.x; tr_i < batch; tr_i += gridDim.x) {
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)(out + tr_i * 65536), 0, 65536 * 4, 0x00020000);
         const bool has_next = tr_i + gridDim.x < batch;
-        const __amdgpu_buffer_rsrc_t xn = in_rsrc(has_next ? tr_i + gridDim.x : tr_i);
+        const __amdgpu_buffer_rsrc_t xn = in_rsrc(has_next ? tr_i + gridDim.x : tr_i, has_next);
+        auto next_loads = [&](int lo, int hi) { // rows lo .. hi-1 of the next transform, into the point registers it starts from
+#pragma unroll
+            for (int ap = lo; ap < hi; ap++) v[ap] = __builtin_amdgcn_raw_buffer_load_b32(xn, voff, ap * 4096, 0);
+        };
         // ---- network 0 and the first twiddle: Y[k0] * w^(m k0), t <- t * w^m ----
         dif<6, BMAX>(v, net0, p, a.one, a.onep);
-        __builtin_amdgcn_sched_barrier(0);
+        M32_SPLIT();
         v[0] = mulm(v[0], a.one, a.onep, p);
         {
             i32 t = ratio;
@@ -423,7 +451,7 @@ __global__ __launch_bounds__(1024) void ntt_m32_2e16_kernel(const i32 *in, i32 *
                 if (k0 + 1 < 64) t = mulm1(t, ratio, pinv, negp);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        M32_SPLIT();
         // ---- exchange 1 + network 1 ----
         i32 w[2][32];
         auto net1f = [&](int h) {
@@ -445,13 +473,17 @@ __global__ __launch_bounds__(1024) void ntt_m32_2e16_kernel(const i32 *in, i32 *
         lds_barrier();
 #pragma unroll
         for (int kl = 0; kl < 32; kl++) e1w[kl * 1024] = v[brev_c(kl + 32, 6)];
+        M32_SPLIT();
+        next_loads(0, GFA_M32_B16_E1); // the point registers are free from here
         net1f(0);
-        __builtin_amdgcn_sched_barrier(0);
+        M32_SPLIT();
         lds_barrier();
 #pragma unroll
         for (int bp = 0; bp < 32; bp++) w[1][bp] = e1r[bp * 32];
+        M32_SPLIT();
+        next_loads(GFA_M32_B16_E1, GFA_M32_B16_E2);
         net1f(1);
-        __builtin_amdgcn_sched_barrier(0);
+        M32_SPLIT();
         // ---- exchange 2 + network 2 ----
         i32 z[2][32];
         lds_barrier();
@@ -468,10 +500,6 @@ __global__ __launch_bounds__(1024) void ntt_m32_2e16_kernel(const i32 *in, i32 *
 #pragma unroll
             for (int kl = 0; kl < 16; kl++) e2w[kl * (64 * B16_E2_PITCH) + 32 * i * B16_E2_PITCH] = w[i][brev_c(kl + 16, 5)];
         const i32 fin = a.fin, finp = a.finp;
-        auto next_loads = [&](int lo, int hi) { // unconditional (the last round re-reads its own row): no control flow in the loop body
-#pragma unroll
-            for (int ap = lo; ap < hi; ap++) v[ap] = __builtin_amdgcn_raw_buffer_load_b32(xn, voff, ap * 4096, 0);
-        };
         auto net2f = [&](int h) {
             dif<5, BMAX>(z[h], net1, p, a.one, a.onep);
 #pragma unroll
@@ -481,16 +509,17 @@ __global__ __launch_bounds__(1024) void ntt_m32_2e16_kernel(const i32 *in, i32 *
                 __builtin_amdgcn_raw_buffer_store_b32(x, yr, voff, (2048 * k2 + 1024 * h) * 4, 0);
             }
         };
+        M32_SPLIT();
         net2f(0);
-        __builtin_amdgcn_sched_barrier(0);
-        next_loads(0, 32);
-        __builtin_amdgcn_sched_barrier(0);
+        M32_SPLIT();
+        next_loads(GFA_M32_B16_E2, GFA_M32_B16_E3);
         lds_barrier();
 #pragma unroll
         for (int rp = 0; rp < 32; rp++) z[1][rp] = e2r[rp];
+        M32_SPLIT();
         net2f(1);
-        __builtin_amdgcn_sched_barrier(0);
-        next_loads(32, 64);
+        next_loads(GFA_M32_B16_E3, 64);
+        M32_SPLIT();
     }
 }
 
