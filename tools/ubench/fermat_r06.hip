@@ -421,6 +421,9 @@ __global__ __launch_bounds__(512) void fermat_a_kernel(FermatArgs a)
 #ifndef BEARLY
 #define BEARLY 0
 #endif
+#ifndef X2MODE
+#define X2MODE 0 // 1: exchange 2 in rounds by first-network half (w[0] travels under net1(1), w[1] under net2(0)) instead of by k1 half
+#endif
 #ifndef BE1
 #define BE1 0 // requests [0, BE1) after the second exchange-1 write burst (the 64 point registers are free from there)
 #endif
@@ -545,10 +548,44 @@ __global__ __launch_bounds__(1024) void fermat_b_kernel(FermatArgs a)
 #pragma unroll
         for (int bp = 0; bp < 32; bp++) w[1][bp] = e1r[bp * 32];
         B_SPLIT();
+        int z[2][32];
+        if (X2MODE == 1) {
+            // round h: [k1][k0 local = g][r'] of w[h] (k0 = g + 32 h), 32 x 32 rows of pitch 33; reader (k0 local = l & 31, k1 = (l >> 5) + 2 wv)
+            int *const xw = ex + g * E2_PITCH + wpos2;
+            const int *const xr = ex + ((l >> 5) + 2 * wv) * (32 * E2_PITCH) + (l & 31) * E2_PITCH;
+            const int soff = (int)((((unsigned)l & 31u) + 64u * (((unsigned)l >> 5) + 2u * (unsigned)wv)) * 4u);
+            auto net2x = [&](int h) {
+                fermat_net32_fold(z[h]);
+#pragma unroll
+                for (int k2 = 0; k2 < 32; k2++)
+                    __builtin_amdgcn_raw_buffer_store_b32(fm_canon(z[h][brev_c(k2, 5)]), yr, soff, (2048 * k2 + 32 * h) * 4, AUX_ST);
+            };
+            lds_barrier(); // every thread has its exchange-1 rows
+#pragma unroll
+            for (int k1 = 0; k1 < 32; k1++) xw[k1 * (32 * E2_PITCH)] = w[0][brev_c(k1, 5)];
+            breq(BE1, BEARLY);
+            net1(1);
+            B_SPLIT();
+            lds_barrier();
+#pragma unroll
+            for (int rp = 0; rp < 32; rp++) z[0][rp] = xr[rp];
+            lds_barrier();
+#pragma unroll
+            for (int k1 = 0; k1 < 32; k1++) xw[k1 * (32 * E2_PITCH)] = w[1][brev_c(k1, 5)];
+            B_SPLIT();
+            breq(BEARLY, BE3);
+            net2x(0);
+            B_SPLIT();
+            breq(BE3, BE4);
+            lds_barrier();
+#pragma unroll
+            for (int rp = 0; rp < 32; rp++) z[1][rp] = xr[rp];
+            B_SPLIT();
+            net2x(1);
+        } else {
         breq(BE1, BEARLY);
         net1(1);
         B_SPLIT();
-        int z[2][32];
         lds_barrier();
 #pragma unroll
         for (int i = 0; i < 2; i++)
@@ -578,6 +615,7 @@ __global__ __launch_bounds__(1024) void fermat_b_kernel(FermatArgs a)
         for (int rp = 0; rp < 32; rp++) z[1][rp] = e2r[rp];
         B_SPLIT();
         net2(1);
+        }
         breq(BE4, 64);
         B_SPLIT();
     }
@@ -661,7 +699,7 @@ int main(int argc, char **argv)
         else if (dbg) hipLaunchKernelGGL((fermat_a_kernel<true>), dim3(grid), dim3(512), A_LDS_BYTES, 0, a);
         else hipLaunchKernelGGL((fermat_a_kernel<false>), dim3(grid), dim3(512), A_LDS_BYTES, 0, a);
     };
-    printf("config: VARB=%d BE1=%d BEARLY=%d BE3=%d BE4=%d TWMODE=%d DEEP=%d PF=%d TWW=%d PFPOS=%d TSHIFT=%d SKEL=%d STAGGER=%d AUX_LD=%d AUX_ST=%d PRIO=%d cus=%d\n", VARB, BE1, BEARLY, BE3, BE4, TWMODE, DEEP, PF, TWW, PFPOS, TSHIFT, SKEL, STAGGER, AUX_LD, AUX_ST, PRIO, cus);
+    printf("config: X2MODE=%d VARB=%d BE1=%d BEARLY=%d BE3=%d BE4=%d TWMODE=%d DEEP=%d PF=%d TWW=%d PFPOS=%d TSHIFT=%d SKEL=%d STAGGER=%d AUX_LD=%d AUX_ST=%d PRIO=%d cus=%d\n", X2MODE, VARB, BE1, BEARLY, BE3, BE4, TWMODE, DEEP, PF, TWW, PFPOS, TSHIFT, SKEL, STAGGER, AUX_LD, AUX_ST, PRIO, cus);
     // ---- check against the product kernel ----
     if (SKEL == 0 && check_batch > 0) {
         if (gfa_ntt(f, d_in, d_ref, 65536, check_batch, omega, 0, GFA_U32, nullptr) != GFA_OK) { fprintf(stderr, "gfa_ntt\n"); return 2; }
