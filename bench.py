@@ -169,35 +169,32 @@ def main():
             pmc_path = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc_path):
                 traffic = json.load(open(pmc_path))["traffic_bytes_per_launch"]
-                traffic_source = f"committed profile profiles/{name} (PMC passes not run in this invocation)"
+                traffic_source = f"profiles/{name}"
                 break
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_live": bool(traffic_source and traffic_source.startswith("live")),
                 "kernel": "tab8_binary_kernel", "kernel_ms": round(ms.value, 5), "algorithmic_bytes_per_launch": alg_bytes}
 
     result = None
     if rank == 0:
         value = world * n * args.steps / elapsed / 1e9
         result = {
-            "metric": "GF(2^8) multiply throughput (lookup mode, uint8, 1e8 elements per GPU)",
+            "metric": "GF(2^8) mul Gop/s (lookup mode, 1e8 uint8 per GPU)",
             "value": round(value, 2),
             "unit": "Gop/s",
             "n_gpus": world,
             "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
             "steps": args.steps,
             "warmup": args.warmup,
-            "clock_prewarm": {"steps": prewarm_steps, "ms": round(prewarm_ms, 1), "timed": False,
-                              "why": "GPU clocks ramp for tens of ms after the idle set-up phase; see profiles/r04_bench_clock_ramp.txt"},
-            "as_measured_without_prewarm": {"value": round(n * 20 / cold_elapsed / 1e9, 2), "unit": "Gop/s", "steps": 20, "warmup": 5,
-                                            "note": "this rank only; the r01-r03 protocol: 5 + 20 steps right after the idle set-up phase"},
+            "clock_prewarm": {"steps": prewarm_steps, "ms": round(prewarm_ms, 1), "timed": False},
+            "as_measured_without_prewarm": {"value": round(n * 20 / cold_elapsed / 1e9, 2), "unit": "Gop/s", "steps": 20, "warmup": 5},
             "ms_per_step": round(elapsed / args.steps * 1e3, 5),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "GF(2^8) mul, EXP/LOG-table (lookup) mode, 1e8 uint8 elements per GPU, "
-                                   "irreducible poly 0x11D (BASELINE.json configs[1])",
+            "config": {"workload": "GF(2^8) mul, lookup mode, 1e8 uint8 per GPU, poly 0x11D (BASELINE.json configs[1])",
                        "elements_per_gpu": n, "parallelism": f"batch-shard x{world}, no collectives"},
             "roofline": roofline,
         }
@@ -212,9 +209,7 @@ def main():
             t_cpu += time.perf_counter() - t1
             reps += 1
         result["cpu_baseline"] = {"value": round(n * reps / t_cpu / 1e9, 4), "unit": "Gop/s", "cores": 1, "kind": "port",
-                                  "sample": f"{reps} x the full 1e8-element batch through oracle/gf_oracle.c "
-                                            f"(C restatement of the reference's jit-lookup multiply, -O3, 1 thread; "
-                                            f"host has {os.cpu_count()} cores)"}
+                                  "sample": f"{reps} x the 1e8-element batch, oracle/gf_oracle.c, 1 of {os.cpu_count()} host threads"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline_reference"] = reference_timing()
@@ -240,7 +235,7 @@ def main():
                     reps += 1
                 dt = time.perf_counter() - t1
             result["extra"]["cpu_baseline_all_cores"] = {"value": round(n * reps / dt / 1e9, 3), "unit": "Gop/s", "cores": cores,
-                                                         "kind": "port", "sample": f"{reps} x 1e8 elements, one slice per thread"}
+                                                         "kind": "port", "sample": f"{reps} x 1e8 elements"}
 
     if dist is not None and not args.no_extras and (world > 1 or args.dist_extras):
         # the other parts of the composite metric at N GPUs: every rank takes part, rank 0 reports
@@ -248,6 +243,26 @@ def main():
         if rank == 0:
             result.setdefault("extra", {}).update(ex)
     if rank == 0:
+        # the figures BASELINE.json's composite metric names, as the LAST key of the line (whatever keeps only a tail keeps this)
+        ex = result.pop("extra", None)
+        if ex is not None:
+            result["extra"] = ex
+            ns = {"gf256_mul_Gop/s": result["value"], "gf256_mul_frac": result["roofline"]["frac"]}
+            for tag in ("ntt_2^20_gf7340033", "ntt_2^20_gf469762049", "ntt_2^20_gf2013265921"):
+                if tag in ex:
+                    ns[tag] = {"tps": ex[tag]["transforms_per_s"], "frac": ex[tag]["roofline_frac"], "physical_frac": ex[tag].get("physical_frac")}
+            for tag in ("ntt_16x2^16_gf65537", "ntt_2^16_gf7340033", "ntt_2^14_gf7340033"):
+                if tag in ex:
+                    ns[tag + "_frac"] = ex[tag]["roofline_frac"]
+            if "ntt_16x2^16_gf65537" in ex:
+                ns["ntt_2^16_gf65537_hbm_only_4096_frac"] = ex["ntt_16x2^16_gf65537"]["hbm_only_batch_4096"]["roofline_frac"]
+            for tag in ("ntt_single_2^26_gf469762049", "ntt_single_2^26_goldilocks", "ntt_single_2^27_gf2013265921"):
+                if tag in ex:
+                    ns[tag + "_frac"] = ex[tag]["roofline_frac"]
+            if "rs_255_223" in ex:
+                ns["rs_enc_GB/s"] = ex["rs_255_223"]["encode_GB/s"]
+                ns["rs_dec_GB/s"] = ex["rs_255_223"]["decode_GB/s"]
+            result["north_star"] = ns
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
@@ -288,8 +303,9 @@ def reference_timing():
     rec_path = os.path.join(ROOT, "profiles", "r03_reference_timings.json")
     if not os.path.exists(rec_path):
         return None
-    return {"kind": "reference", "timed_in_this_run": False,
-            "source": "profiles/r03_reference_timings.json (tools/time_reference_here.py, build container)", **json.load(open(rec_path))}
+    rec = json.load(open(rec_path))
+    keep = {k: v for k, v in rec.items() if not isinstance(v, str)}
+    return {"kind": "reference", "timed_in_this_run": False, "source": "profiles/r03_reference_timings.json", "mode": "python-calculate", **keep}
 
 
 def measure_traffic():
@@ -325,8 +341,7 @@ def measure_traffic():
             vals[counter] = sum(got) / len(got)  # KiB per dispatch
         read_b = 2.0 * vals["FETCH_SIZE"] * 1024.0
         write_b = vals["WRITE_SIZE"] * 1024.0
-        return read_b + write_b, ("live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes in this run "
-                                  f"(reported {vals['FETCH_SIZE']:.1f} / {vals['WRITE_SIZE']:.1f} KiB per launch; reads = 2 x FETCH_SIZE on gfx950)")
+        return read_b + write_b, f"live: FETCH_SIZE {vals['FETCH_SIZE']:.1f} x 2 + WRITE_SIZE {vals['WRITE_SIZE']:.1f} KiB"
     except Exception:
         return None, None
     finally:
@@ -433,11 +448,6 @@ def extras_distributed(ga, L, lib, stream, dist, rank, world):
                 stages["kernels_ms"] = round(kern, 4)
             stages["points_per_s"] = round(N / (stages["wall_ms"] * 1e-3), 0)
             entry[name] = stages
-        entry["note"] = ("stage times are GPU events on the launch stream, max over ranks of the per-rank median.  forward: the column "
-                         "pass runs in two sub-blocks whose grouped send / recv exchanges (side stream) overlap the next sub-block's "
-                         "kernels -- columns_and_exchange_ms is that overlapped stage, row_pass_ms the chunked row kernel; inverse: "
-                         "all_to_all_ms is the RCCL exchange over xGMI (at one rank: a device copy); wall_ms includes the Python "
-                         "launch overhead")
         ex["c5_goldilocks_2^26_distributed"] = entry
     return ex
 
@@ -489,8 +499,7 @@ def extras(ga, L, lib, stream, with_cpu):
     e1.record()
     e1.synchronize()
     copy_gbs = 2.0 * n / (e0.elapsed_time(e1) / 50 * 1e-3) / 1e9
-    ex["device_copy"] = {"GB/s": round(copy_gbs, 1), "frac_of_peak": round(copy_gbs / HBM_PEAK_GBS, 4),
-                         "note": "torch Tensor.copy_ of 1e8 bytes; roofline fractions elsewhere are against the 8 TB/s spec peak"}
+    ex["device_copy"] = {"GB/s": round(copy_gbs, 1), "frac_of_peak": round(copy_gbs / HBM_PEAK_GBS, 4)}
     del src, dst
     # ---- the headline kernel on arrays far larger than the 256 MiB Infinity Cache (the 1e8-element BASELINE config has a
     # 300 MB working set and is partly served by it): the HBM-only rate ----
@@ -510,8 +519,7 @@ def extras(ga, L, lib, stream, with_cpu):
     ex["gf256_mul_1e9_elements"] = {"Gop/s": round(nbig / (ms.value * 1e-3) / 1e9, 1), "kernel_ms": round(ms.value, 4),
                                     "algorithmic_GB/s": round(3.0 * nbig / (ms.value * 1e-3) / 1e9, 1),
                                     "roofline_frac": round(3.0 * nbig / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                    "device_copy_GB/s_same_size": round(2.0 * nbig / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e9, 1),
-                                    "note": "3 GB working set, no Infinity Cache reuse between launches"}
+                                    "device_copy_GB/s_same_size": round(2.0 * nbig / (e0.elapsed_time(e1) / 10 * 1e-3) / 1e9, 1)}
     del xb, yb, ob
     # ---- the headline op at the reference docs' dtype=int (int64 storage, 24 B/element), same field and kernel family ----
     n64 = 25_000_000
@@ -556,14 +564,7 @@ def extras(ga, L, lib, stream, with_cpu):
         ex[tag] = entry
         del at, bt, ot
     # ---- NTT: 2^20 points over GF(7340033) (the modulus galois.ntt picks for that size), batch of 64 ----
-    # kernel (and launch shape) behind every entry: profiles/r05_bench_kernel_stats.csv is keyed by (kernel, grid_x, workgroup_x)
-    ntt_kernels = {
-        "ntt_2^20_gf7340033": [("ntt_m32_kernel<5, 5, 512, false, 1, false, 32>", 64 * 64 * 512, 512), ("ntt_m32_kernel<5, 5, 512, false, 0, true, 32>", 64 * 64 * 512, 512)],
-        "ntt_2^20_gf469762049": [("ntt_m32_kernel<5, 5, 512, false, 1, false, 4>", 64 * 64 * 512, 512), ("ntt_m32_kernel<5, 5, 512, false, 0, true, 4>", 64 * 64 * 512, 512)],
-        "ntt_16x2^16_gf65537": [("ntt_fermat16_kernel<false, false>", 256 * 1024, 1024)],
-        "ntt_2^16_gf7340033": [("ntt_m32_2e16_kernel<64>", 256 * 1024, 1024)],
-        "ntt_2^14_gf7340033": [("ntt_m32_one_kernel<4, 1, 32>", 4096 * 512, 512)],
-    }
+    # kernel names / launch shapes behind every entry, ceilings and their sources: DESIGN.md section 5 (the JSON line carries numbers only)
     for tag, p, logn, batch in (("ntt_2^20_gf7340033", 7340033, 20, 64), ("ntt_2^20_gf469762049", 469762049, 20, 64),
                                 ("ntt_16x2^16_gf65537", 65537, 16, 16 * 64),
                                 ("ntt_2^16_gf7340033", 7340033, 16, 1024), ("ntt_2^14_gf7340033", 7340033, 14, 4096)):
@@ -576,43 +577,16 @@ def extras(ga, L, lib, stream, with_cpu):
         L.check(lib.gfa_time_ntt(P._handle, xd.data_ptr(), od.data_ptr(), N, batch, omega, L.U32, stream, 10, ctypes.byref(ms)))
         points = batch * N
         gbs = 8.0 * points / (ms.value * 1e-3) / 1e9
-        entry = {"transforms_per_s": round(batch / (ms.value * 1e-3), 1), "points_per_s": round(points / (ms.value * 1e-3), 0),
-                 "ms_per_launch": round(ms.value, 4), "batch": batch, "algorithmic_GB/s": round(gbs, 1),
-                 "roofline_frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_point": 8,
-                 "kernels": [{"kernel": k, "grid_x": g, "workgroup_x": w} for k, g, w in ntt_kernels[tag]]}
-        if logn == 14:
-            entry["note"] = "one pass over HBM: one workgroup per transform, three register networks, two LDS exchanges (gfa_ntt_m32.hip)"
-        elif logn == 16 and p != 65537:
-            entry["note"] = ("one pass over HBM: one 1024-thread workgroup per transform, 64 points per thread, radix 64 x 32 x 32 "
-                             "(ntt_m32_2e16_kernel, r04; the two-pass form of r03 measured 0.30)")
-        elif logn == 20:
-            entry["2^20_pt_ntt_per_s"] = entry["transforms_per_s"]
-            entry["ceiling_frac"] = 0.333
-            entry["ceiling_kind"] = "static: copied from the cited profile, not measured in this run"
-            entry["ceiling_source"] = ("profiles/r03_ntt_access_skeleton.txt: the two passes' access pattern with no arithmetic, "
-                                       "0.105 + 0.097 ms for this batch; r05 re-measured 0.208 ms for the pair, and a packed 3-byte "
-                                       "intermediate at 0.213 (profiles/r05_ntt_packed_intermediate.txt: no-go)")
-            # what the memory system really moves (PMC, FETCH_SIZE x 2 + WRITE_SIZE over both passes of this batch)
-            entry["physical_bytes_per_point"] = 17.0 if p == 7340033 else None
-            entry["physical_bytes_source"] = ("profiles/r04_pmc_ntt_m32_two_pass.txt: 256.6 + 258 MiB (pass 1), 256.6 + 319 MiB (pass 2, "
-                                              "non-temporal stores: 1.25x write amplification) per 2^26 points; static, not measured in this run")
-            if p >= (1 << 26):
-                entry["note_prime"] = ("r05: primes in [2^26, 2^29) on the signed-Montgomery kernels (in-network reductions placed at compile "
-                                       "time, gfa_m32_net.h); r04 ran this prime on the lazy-Shoup register kernels at 0.21")
-            entry["note"] = ("two passes over the array (16 B/point of traffic against the 8 B/point algorithmic minimum this fraction "
-                             "is priced on): the same access pattern with NO arithmetic takes 0.20-0.22 ms for this batch "
-                             "(tools/ubench/ntt_access.hip, profiles/r03_ntt_access_skeleton.txt), i.e. 0.30-0.335 is the ceiling of any "
-                             "two-pass form on this part; sub-batching through the Infinity Cache and an XCD-fused single launch "
-                             "were measured and do not beat it (DESIGN.md section 4.3)")
-        else:
-            entry["2^20_points_per_s_equiv"] = round(points / (1 << 20) / (ms.value * 1e-3), 1)
-            entry["ceiling_frac"] = 0.73
-            entry["ceiling_kind"] = "static: copied from the cited profile, not measured in this run"
-            entry["ceiling_source"] = ("profiles/r04_fermat_experiments.txt section 3: the transform's arithmetic + LDS exchanges with NO HBM traffic run at "
-                                       "the equivalent of 0.62-0.74 (23-27 us per transform and CU), its loads and stores alone at 0.70-0.87; a CU's 512 KiB "
-                                       "register file holds exactly two 2^16-point transforms, so no second one can be resident to cover the first")
-            # the same kernel on a batch far larger than the 256 MiB Infinity Cache (4096 transforms: 1 GiB in, 1 GiB out): the
-            # HBM-only rate -- at 1024 transforms the 256 MiB input is partly served by the cache from one launch to the next
+        entry = {"transforms_per_s": round(batch / (ms.value * 1e-3), 1), "ms_per_launch": round(ms.value, 4), "batch": batch,
+                 "roofline_frac": round(gbs / HBM_PEAK_GBS, 4)}  # of 8 TB/s at the algorithmic 8 B/point
+        if logn == 20:
+            # what the memory system moves over both passes (PMC FETCH_SIZE x 2 + WRITE_SIZE, profiles/r04_pmc_ntt_m32_two_pass.txt; static)
+            entry["physical_bytes_per_point"] = 17.0
+            entry["physical_frac"] = round(17.0 * points / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            entry["ceiling_frac_static"] = 0.333
+        elif p == 65537:
+            entry["ceiling_frac_static"] = 0.73
+            # the same kernel on a batch far larger than the 256 MiB Infinity Cache (4096 transforms: 1 GiB in, 1 GiB out)
             big = 4096
             xb = torch.empty((big, N), dtype=torch.int32, device="cuda").random_(0, p)
             ob = torch.empty_like(xb)
@@ -631,11 +605,9 @@ def extras(ga, L, lib, stream, with_cpu):
                 FP.ntt_u32_pow2(xh[reps % batch], omega)
                 reps += 1
             dt = time.perf_counter() - t1
-            entry["cpu_baseline"] = {"transforms_per_s": round(reps / dt, 2), "cores": 1, "kind": "port",
-                                     "sample": f"{reps} transforms of 2^{logn} points, oracle/gf_oracle.c"}
+            entry["cpu_baseline"] = {"transforms_per_s": round(reps / dt, 2), "cores": 1, "kind": "port", "n": reps}
             calls, dt_all, cores = _all_cores(lambda i: FP.ntt_u32_pow2(xh[i % batch], omega))
-            entry["cpu_baseline_all_cores"] = {"transforms_per_s": round(calls / dt_all, 2), "cores": cores, "kind": "port",
-                                               "sample": f"{calls} transforms of 2^{logn} points from {cores} threads, oracle/gf_oracle.c"}
+            entry["cpu_baseline_all_cores"] = {"transforms_per_s": round(calls / dt_all, 2), "cores": cores, "n": calls}
         ex[tag] = entry
         del xd, od
     # ---- ONE long transform (three passes of the register kernel) and a long polynomial product that needs the CRT route ----
@@ -648,15 +620,9 @@ def extras(ga, L, lib, stream, with_cpu):
         L.check(lib.gfa_time_ntt(P._handle, xd.data_ptr(), od.data_ptr(), N, 1, P._root_of_unity_int(N), dt, stream, 5, ctypes.byref(ms)))
         width = 4 if dt == L.U32 else 8
         gbs = 2.0 * width * N / (ms.value * 1e-3) / 1e9
-        ex[tag] = {"ms": round(ms.value, 4), "points_per_s": round(N / (ms.value * 1e-3), 0), "algorithmic_GB/s": round(gbs, 1),
-                   "roofline_frac": round(gbs / HBM_PEAK_GBS, 4), "passes": 3,
-                   "kernels": ([{"kernel": "ntt_m32_kernel<5, 4, 512, false, 1, false, 4>", "grid_x": 8192 * 512, "workgroup_x": 512, "launches": 2},
-                                {"kernel": "ntt_m32_kernel<4, 4, 256, false, 0, true, 4>", "grid_x": 16384 * 256, "workgroup_x": 256}]
-                               if dt == L.U32 else [{"kernel": "ntt_reg_kernel_gl", "launches": 3}])}
+        ex[tag] = {"ms": round(ms.value, 4), "roofline_frac": round(gbs / HBM_PEAK_GBS, 4), "passes": 3}
         if dt == L.U32:
-            ex[tag]["physical_bytes_per_point"] = 25.2
-            ex[tag]["physical_bytes_source"] = ("profiles/r05_pmc_ntt_m32_three_pass.txt: (258 + 275) MiB x 2 + (259 + 290) MiB per 2^26 points; "
-                                                "static, not measured in this run")
+            ex[tag]["physical_bytes_per_point"] = 25.2  # profiles/r05_pmc_ntt_m32_three_pass.txt (static)
             # parity of the three-pass form in this very run: the inverse transform restores the input
             bk = torch.empty_like(xd)
             w = P._root_of_unity_int(N)
@@ -677,7 +643,7 @@ def extras(ga, L, lib, stream, with_cpu):
     conv_ms = (time.perf_counter() - t1) / 5 * 1e3
     assert int(cc[0]) == int(ca[0] * cb[0]) and int(cc[-1]) == int(ca[-1] * cb[-1])
     ex["convolve_2^20x2^20_gf2147483647"] = {"ms": round(conv_ms, 3), "multiply_adds_equivalent_per_s": round(2.0**40 / (conv_ms * 1e-3), 0),
-                                            "route": "three NTT primes below 2^29 (r05: on the signed-Montgomery kernels; r04: three 31-bit primes, 0.311 ms) + CRT inside gfa_convolve (no 2^21-th root of unity in the field)"}
+                                            "route": "3-prime CRT"}
     del ca, cb, cc
     # ---- RS(255,223): 2^17 codewords per GPU (= 2^20 over 8 GPUs), e ~ U{0..16} errors per codeword ----
     rs = ga.ReedSolomon(255, 223)
@@ -710,12 +676,8 @@ def extras(ga, L, lib, stream, with_cpu):
         "codewords": B, "errors_per_codeword": "uniform 0..16",
         "encode_GB/s": round(255.0 * B / (enc_ms * 1e-3) / 1e9, 2), "encode_ms": round(enc_ms, 4),
         "decode_GB/s": round(255.0 * B / (dec_ms * 1e-3) / 1e9, 2), "decode_ms": round(dec_ms, 4),
-        "encode+decode_GB/s": round(255.0 * B / ((enc_ms + dec_ms) * 1e-3) / 1e9, 2),
-        "encode_algorithmic_GB/s": round(478.0 * B / (enc_ms * 1e-3) / 1e9, 2),
-        "decode_algorithmic_GB/s": round(486.0 * B / (dec_ms * 1e-3) / 1e9, 2),
         "encode_roofline_frac": round(478.0 * B / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
         "decode_roofline_frac": round(486.0 * B / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-        "note": "decode is LDS / VALU bound (PMC: LDS array 72 % busy after the Horner rewrite), not HBM bound; see DESIGN.md section 4.1",
     }
     # the two extremes benchmarks/test_fec.py uses: no errors, and t = 16 errors in every codeword
     Rd.copy_(Cd)
@@ -759,12 +721,11 @@ def extras(ga, L, lib, stream, with_cpu):
         OR.decode_u8(R[:2048])
         td = time.perf_counter() - t1
         ex["rs_255_223"]["cpu_baseline"] = {"encode_GB/s": round(255.0 * 2048 / te / 1e9, 5), "decode_GB/s": round(255.0 * 2048 / td / 1e9, 5),
-                                            "cores": 1, "kind": "port", "sample": "2048 codewords, oracle/gf_oracle.c"}
+                                            "cores": 1, "kind": "port", "n": 2048}
         ce, dte, cores = _all_cores(lambda i: OR.encode_u8(M[(i % 256) * 256:(i % 256) * 256 + 256]))
         cd_, dtd, _ = _all_cores(lambda i: OR.decode_u8(R[(i % 256) * 256:(i % 256) * 256 + 256]))
         ex["rs_255_223"]["cpu_baseline_all_cores"] = {"encode_GB/s": round(255.0 * 256 * ce / dte / 1e9, 4), "decode_GB/s": round(255.0 * 256 * cd_ / dtd / 1e9, 4),
-                                                      "cores": cores, "kind": "port",
-                                                      "sample": f"{256 * ce} / {256 * cd_} codewords in 256-word calls from {cores} threads, oracle/gf_oracle.c"}
+                                                      "cores": cores}
     # ---- binary BCH(255, 223), t = 4: same entry points, symbols in GF(2), syndromes in GF(2^8) ----
     bch = ga.BCH(255, 223)
     Mb = rng.integers(0, 2, (B, 223), dtype=np.uint8)
@@ -793,8 +754,7 @@ def extras(ga, L, lib, stream, with_cpu):
         od, on = OB.decode(Rb[:2048])
         td = time.perf_counter() - t1
         assert np.array_equal(od, Cb[:2048]) and np.array_equal(on, neb[:2048])
-        ex["bch_255_223"]["cpu_baseline"] = {"decode_GB/s": round(255.0 * 2048 / td / 1e9, 5), "cores": 1, "kind": "port",
-                                             "sample": "2048 codewords, oracle/gf_oracle.c"}
+        ex["bch_255_223"]["cpu_baseline"] = {"decode_GB/s": round(255.0 * 2048 / td / 1e9, 5), "cores": 1, "kind": "port", "n": 2048}
     return ex
 
 

@@ -844,7 +844,7 @@ class FieldArray(metaclass=FieldArrayMeta):
         for x in inputs:
             if isinstance(x, cls):
                 tx = self._af_tens(x).broadcast_to(full)
-                safe.append(self._af_wrap(torch.where(mask, tx, one.to(tx.dtype))))
+                safe.append(self._af_wrap(torch.where(mask, tx, _to_storage(one, tx.dtype))))
             else:
                 safe.append(x)
         res = self.__array_ufunc__(ufunc, "__call__", *safe, **kwargs)
@@ -859,7 +859,7 @@ class FieldArray(metaclass=FieldArrayMeta):
                     if tuple(target.shape) != full:
                         raise ValueError(f"non-broadcastable output operand with shape {tuple(target.shape)} doesn't match the broadcast shape {full}")
                     tt = self._af_tens(target)
-                    new = self._af_wrap(torch.where(mask, tr.to(tt.dtype), tt))
+                    new = self._af_wrap(torch.where(mask, _to_storage(tr, tt.dtype), tt))  # (a plain .to() would sign-extend uint16 / uint32 bit patterns)
                     target._t.copy_(new._t.reshape(target._t.shape))
                     blended.append(target)
                 else:
@@ -895,7 +895,7 @@ class FieldArray(metaclass=FieldArrayMeta):
                 raise ValueError(f"reduction operation '{ufunc.__name__}' does not have an identity, so to use a where mask one has to specify 'initial'")
             mask = self._where_mask(where, self.shape)
             tx = self._af_tens(self)
-            fill = self._af_tens(cls.Zeros(()) if dual == L.OP_ADD else cls.Ones(())).to(tx.dtype)
+            fill = _to_storage(self._af_tens(cls.Zeros(()) if dual == L.OP_ADD else cls.Ones(())), tx.dtype)
             x = self._af_wrap(torch.where(mask, tx, fill))
         if not has_initial:
             return x._reduce(op, axis, keepdims)  # an identity exists: the filled-in elements are neutral

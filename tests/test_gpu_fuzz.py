@@ -1,4 +1,4 @@
-"""Short seeded runs of the differential fuzzers (tools/fuzz_codes.py [wide], tools/fuzz_fields.py, tools/fuzz_ntt_linalg.py, tools/fuzz_conv_ntt3.py, tools/fuzz_table_fields.py, tools/fuzz_r04.py, tools/fuzz_r05.py): random codes / fields / shapes
+"""Short seeded runs of the differential fuzzers (tools/fuzz_codes.py [wide], tools/fuzz_fields.py, tools/fuzz_ntt_linalg.py, tools/fuzz_conv_ntt3.py, tools/fuzz_table_fields.py, tools/fuzz_r04.py, tools/fuzz_r05.py, tools/fuzz_r06.py): random codes / fields / shapes
 against the oracle.  Longer campaigns: `python tools/fuzz_codes.py 600 <seed>`."""
 import os
 import subprocess
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("tool,seed,extra", [("fuzz_codes.py", 7, []), ("fuzz_fields.py", 11, []), ("fuzz_ntt_linalg.py", 13, []),
                                              ("fuzz_codes.py", 17, ["wide"]), ("fuzz_conv_ntt3.py", 19, []), ("fuzz_table_fields.py", 23, []),
-                                             ("fuzz_r04.py", 41, []), ("fuzz_r05.py", 51, [])])
+                                             ("fuzz_r04.py", 41, []), ("fuzz_r05.py", 51, []), ("fuzz_r06.py", 61, [])])
 def test_fuzz(tool, seed, extra):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "8", str(seed)] + extra, capture_output=True, text=True,
                        timeout=600)

@@ -171,3 +171,24 @@ def test_masked_composites_and_host_results():
     dst = np.full(300, -1, dtype=np.int64)
     np.log(v, where=m8, out=dst)
     assert np.array_equal(dst[m8], lg[m8]) and (dst[~m8] == -1).all()
+
+
+@pytest.mark.parametrize("order,dt,wide", [(65521, np.uint16, np.int64), (65521, np.uint16, np.uint32), (2**32, np.uint32, np.int64),
+                                             (3**10, np.uint16, np.uint32)])
+def test_where_with_out_of_a_wider_dtype_keeps_values_above_the_sign_bit(order, dt, wide):
+    """uint16 / uint32 field arrays are int16 / int32 bit patterns on the device, so blending a masked result into an
+    `out` array of a wider dtype must not sign-extend -- every element >= 2^15 (2^31) used to come out negative."""
+    GF = ga.GF(order)
+    rng = np.random.default_rng(11)
+    hi = order - 1 - rng.integers(0, min(1000, order // 4), 300)  # operands near the order: above the storage's sign bit
+    x = GF(hi.astype(dt), dtype=dt)
+    zero = GF(np.zeros(300, dtype=dt), dtype=dt)
+    mask = rng.integers(0, 2, 300).astype(bool)
+    out = GF(np.full(300, 5, dtype=wide), dtype=wide)
+    got = np.add(x, zero, where=mask, out=out)
+    assert got is out and out.dtype == wide
+    want = np.where(mask, hi, 5)
+    assert np.array_equal(ints(out), np.array([int(v) for v in want], dtype=object))
+    s = np.add.reduce(x, where=mask, initial=GF(0)) if GF.characteristic != 2 else None
+    if s is not None:
+        assert int(s) == int(sum(int(v) for v in hi[mask]) % order) or GF.degree > 1

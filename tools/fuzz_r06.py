@@ -1,0 +1,160 @@
+"""Differential fuzzing of the round-5 / round-6 paths against the oracle, sized so that the ORACLE is not the bottleneck
+(tools/fuzz_r05.py drew 2^22-point transforms and fresh fields every case and managed 25 cases a minute).
+
+    python tools/fuzz_r06.py [seconds] [seed]
+
+Fields are created once (a pool of NTT primes of every bit length 17 .. 32, the table / binary / extension fields of the masked
+ufunc cases); a case then costs a few kernel launches and one small oracle call:
+  * ntt      random power-of-two length 2^2 .. 2^12 (one large draw, up to 2^20, about once a minute), random primitive root (an odd
+             power of the field's), random batch, rows at the magnitude limit; forward against the oracle on three rows, batched
+             against single, scaled inverse as a round trip.  The pool covers every kernel family: GF(65537) (shift twiddles),
+             p < 2^26 / 2^28 / 2^29 (signed Montgomery, the three BMAX classes), [2^29, 2^32) (lazy Shoup);
+  * ntt16    the one-workgroup 2^16-point kernels (r06: GF(65537) with the first twiddles formed in registers and the early
+             requests; generic p < 2^29 with the early requests): batches of 64 .. 300 transforms, forward and scaled inverse;
+  * convolve random lengths 1500 .. 6000 (the CRT route) over pool primes, five coefficients against Python integers;
+  * where    masked ufunc calls / reductions on random fields, uint16 / uint32 results blended into WIDER `out` arrays;
+  * wide     (1 case in 25) the two-limb identities of fuzz_r05.py.
+"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import galois_amd as ga
+from galois_amd import _lib as L
+from oracle import gf_oracle as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+rng = np.random.default_rng(seed)
+lib = L.lib()
+st = torch.cuda.current_stream().cuda_stream
+counts = {"ntt": 0, "ntt_large": 0, "ntt16": 0, "convolve": 0, "where": 0, "wide": 0}
+
+
+def find_prime(bits, adic):
+    """the largest prime c * 2^adic + 1 with exactly `bits` bits (a smaller 2-adicity when there is none)"""
+    while adic > 1:
+        c = ((1 << bits) - 1) >> adic
+        while c > 0:
+            p = c * (1 << adic) + 1
+            if p <= (1 << (bits - 1)):
+                break
+            if p < (1 << bits) and ga.is_prime(p):
+                return p
+            c -= 1
+        adic -= 1
+    raise RuntimeError(bits)
+
+
+# one NTT prime per bit length (2-adicity >= 16 where the length allows), plus the named ones
+POOL = []
+for p in [65537, 7340033, 469762049, 2013265921, 2130706433, 3221225473, 4293918721] + [find_prime(b, min(b - 3, 20)) for b in range(17, 33)]:
+    GF = ga.GF(p)
+    adic = ((p - 1) & -(p - 1)).bit_length() - 1
+    POOL.append((p, GF, O.OracleField(p, 1, None, int(GF.primitive_element)), adic))
+P16 = [e for e in POOL if e[0] < 2**29 and e[3] >= 16]
+MASKED = [ga.GF(q) for q in (7, 2**8, 3**5, 3**10, 65521, 65537, 2**16, 2**32, 4294967291)]
+WIDE = None
+
+
+def run_ntt(entry, logn, batch):
+    p, GF, F, adic = entry
+    n = 1 << logn
+    w = pow(GF._root_of_unity_int(n), int(rng.integers(0, max(1, n // 2))) * 2 + 1, p)
+    x = rng.integers(0, p, (batch, n), dtype=np.uint32)
+    x[int(rng.integers(0, batch))] = p - 1
+    if batch > 1:
+        x[1, ::2] = 0
+        x[1, 1::2] = p - 1
+    xt = torch.from_numpy(x.view(np.int32)).cuda()
+    out = torch.empty_like(xt)
+    L.check(lib.gfa_ntt(GF._handle, xt.data_ptr(), out.data_ptr(), n, batch, w, 0, L.U32, st))
+    got = out.cpu().numpy().view(np.uint32)
+    for i in {0, batch - 1, int(rng.integers(0, batch))}:
+        assert np.array_equal(got[i], F.ntt_u32_pow2(x[i], w)), ("ntt vs oracle", p, logn, batch, i)
+    if batch > 1:
+        one = torch.empty_like(xt[:1])
+        L.check(lib.gfa_ntt(GF._handle, xt[1:2].data_ptr(), one.data_ptr(), n, 1, w, 0, L.U32, st))
+        assert torch.equal(one[0], out[1]), ("batched vs single", p, logn, batch)
+    L.check(lib.gfa_ntt(GF._handle, out.data_ptr(), out.data_ptr(), n, batch, pow(w, p - 2, p), 1, L.U32, st))
+    assert torch.equal(out, xt), ("ntt inverse", p, logn, batch)
+
+
+t0 = time.time()
+t_end = t0 + budget
+next_large = t0 + 20.0
+while time.time() < t_end:
+    u = rng.random()
+    if time.time() >= next_large:
+        next_large = time.time() + 60.0
+        entry = POOL[int(rng.integers(0, len(POOL)))]
+        run_ntt(entry, int(rng.integers(13, min(entry[3], 20) + 1)), int(rng.integers(1, 3)))
+        counts["ntt_large"] += 1
+    elif u < 0.55:
+        entry = POOL[int(rng.integers(0, len(POOL)))]
+        logn = int(rng.integers(2, min(entry[3], 12) + 1))
+        run_ntt(entry, logn, int(rng.choice([1, 2, 3, 5, 64, 70])) if logn <= 10 else int(rng.choice([1, 2, 5])))
+        counts["ntt"] += 1
+    elif u < 0.62:
+        run_ntt(P16[int(rng.integers(0, len(P16)))], 16, int(rng.integers(64, 300)))
+        counts["ntt16"] += 1
+    elif u < 0.72:
+        p, GF, F, adic = POOL[int(rng.integers(0, len(POOL)))]
+        na, nb = int(rng.integers(1500, 6000)), int(rng.integers(1500, 6000))
+        a = rng.integers(0, p, na, dtype=np.uint64)
+        b = rng.integers(0, p, nb, dtype=np.uint64)
+        a[:2] = p - 1
+        b[:2] = p - 1
+        c = np.convolve(GF(a.astype(np.uint32)), GF(b.astype(np.uint32))).numpy().astype(np.uint64)
+        assert c.shape == (na + nb - 1,)
+        for k in [0, 1, na + nb - 2, int(rng.integers(0, na + nb - 1)), int(rng.integers(0, na + nb - 1))]:
+            lo, hi = max(0, k - (nb - 1)), min(k, na - 1)
+            want = int(np.add.reduce((a[lo:hi + 1].astype(object) * b[k - hi:k - lo + 1][::-1].astype(object)))) % p
+            assert int(c[k]) == want, ("convolve", p, na, nb, k)
+        counts["convolve"] += 1
+    elif u < 0.96:
+        GF = MASKED[int(rng.integers(0, len(MASKED)))]
+        shape = (int(rng.integers(1, 5)), int(rng.integers(1, 200)))
+        x = GF.Random(shape, seed=int(rng.integers(0, 2**31)))
+        y = GF.Random(shape, low=1, seed=int(rng.integers(0, 2**31)))
+        mask = rng.integers(0, 2, shape).astype(bool)
+        wide = GF.dtypes[-1] if rng.random() < 0.5 else x.dtype  # the widest storage the field has (int64, or the only one)
+        for uf in (np.add, np.subtract, np.multiply, np.true_divide):
+            full = uf(x, y).numpy().astype(np.int64)
+            old = GF(GF.Random(shape, seed=3).numpy(), dtype=wide)
+            want = np.where(mask, full, old.numpy().astype(np.int64))
+            got = uf(x, y, where=mask, out=old)
+            assert got is old and np.array_equal(old.numpy().astype(np.int64), want), ("where", GF.name, uf.__name__, str(wide))
+        init = GF.Random((), low=1, seed=int(rng.integers(0, 2**31)))
+        axis = int(rng.integers(0, 2))
+        got = np.add.reduce(x, axis=axis, where=mask, initial=init).numpy()
+        want = (np.add.reduce(np.where(mask, x, GF.Zeros(shape)), axis=axis) + init).numpy()
+        assert np.array_equal(got, want), ("reduce where", GF.name, axis)
+        counts["where"] += 1
+    else:
+        if WIDE is None:
+            import json
+            WIDE = []
+            for tag in ("GF_2e100", "GF_36893488147419103183", "GF_109987e4"):
+                props = json.loads(str(np.load(os.path.join(ROOT, "tests", "golden", f"sage_wide_{tag}.npz"))["properties"]))
+                pp, mm = props["characteristic"], props["degree"]
+                WIDE.append(ga.GF(pp, primitive_element=props["primitive_element"]) if mm == 1 else
+                            ga.GF(pp, mm, irreducible_poly=props["irreducible_poly"], primitive_element=props["primitive_element"]))
+        import random
+        GF = WIDE[int(rng.integers(0, 3))]
+        q = GF.order
+        n = int(rng.integers(2, 5))
+        rnd = random.Random(int(rng.integers(0, 2**31)))
+        A = GF(np.array([rnd.randrange(q) for _ in range(n * n)], dtype=object).reshape(n, n))
+        B = GF(np.array([rnd.randrange(q) for _ in range(n * n)], dtype=object).reshape(n, n))
+        try:
+            assert np.array_equal(A @ np.linalg.inv(A), GF.Identity(n)), ("inv", GF.name)
+        except np.linalg.LinAlgError:
+            pass
+        P, Lm, U = A.plu_decompose()
+        assert np.array_equal(P @ Lm @ U, A), ("plu", GF.name)
+        assert int(np.linalg.det(A @ B)) == int(np.linalg.det(A) * np.linalg.det(B)), ("det", GF.name)
+        counts["wide"] += 1
+el = time.time() - t0
+total = sum(counts.values())
+print(f"fuzz r06: {counts} = {total} cases in {el:.0f} s ({60.0 * total / el:.0f} per minute), seed {seed} -- identical to the oracle", flush=True)
