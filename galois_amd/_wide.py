@@ -7,8 +7,10 @@ integers (`numpy()` returns dtype=object) exactly as with the reference.  The el
 add, subtract, multiply, divide, negative, reciprocal, power (arbitrary-size integer exponents), field * integer, square,
 divmod / remainder, ==, indexing, reshaping and the data-movement NumPy functions -- through the kernels of csrc/gfa_wide.hip,
 and since round 3 ufunc.reduce / accumulate (np.sum, prod, cumsum, cumprod), np.convolve, @ / np.matmul / dot / vdot / inner
-(gfa_wide_reduce, gfa_wide_convolve, gfa_wide_matmul: what the reference's Sage fixtures for these fields pin).  reduceat / at,
-sqrt, log, NTTs, row reduction and codes over these fields are not implemented and raise NotImplementedError.
+(gfa_wide_reduce, gfa_wide_convolve, gfa_wide_matmul: what the reference's Sage fixtures for these fields pin), and since
+round 5 reduceat / at, np.sqrt, np.log (Pohlig-Hellman + baby-step / giant-step), np.fft / ifft, polynomial evaluation, row
+reduction / LU / PLU / inverse / determinant / solve (gfa_wide_row_reduce, gfa_wide_plu_decompose).  Codes (RS / BCH) over these
+fields raise NotImplementedError.
 """
 from __future__ import annotations
 
