@@ -483,7 +483,7 @@ def extras(ga, L, lib, stream, with_cpu):
     """The NTT and Reed-Solomon parts of the composite metric, on this rank's GPU (not part of the timed region)."""
     from oracle import gf_oracle as O
 
-    ex = {}
+    ex = {"cpu_baselines": "oracle/gf_oracle.c (kind: port), ~3 s samples of the same inputs"}
     ms = ctypes.c_float()
     GF = ga.GF(2**8)
     n = N_ELEMENTS
@@ -566,6 +566,7 @@ def extras(ga, L, lib, stream, with_cpu):
     # ---- NTT: 2^20 points over GF(7340033) (the modulus galois.ntt picks for that size), batch of 64 ----
     # kernel names / launch shapes behind every entry, ceilings and their sources: DESIGN.md section 5 (the JSON line carries numbers only)
     for tag, p, logn, batch in (("ntt_2^20_gf7340033", 7340033, 20, 64), ("ntt_2^20_gf469762049", 469762049, 20, 64),
+                                ("ntt_2^20_gf2013265921", 2013265921, 20, 64),  # galois.ntt's default modulus from 2^27 points (lazy-Shoup kernels)
                                 ("ntt_16x2^16_gf65537", 65537, 16, 16 * 64),
                                 ("ntt_2^16_gf7340033", 7340033, 16, 1024), ("ntt_2^14_gf7340033", 7340033, 14, 4096)):
         P = ga.GF(p)
@@ -581,8 +582,9 @@ def extras(ga, L, lib, stream, with_cpu):
                  "roofline_frac": round(gbs / HBM_PEAK_GBS, 4)}  # of 8 TB/s at the algorithmic 8 B/point
         if logn == 20:
             # what the memory system moves over both passes (PMC FETCH_SIZE x 2 + WRITE_SIZE, profiles/r04_pmc_ntt_m32_two_pass.txt; static)
-            entry["physical_bytes_per_point"] = 17.0
-            entry["physical_frac"] = round(17.0 * points / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            if p < (1 << 29):
+                entry["physical_bytes_per_point"] = 17.0
+                entry["physical_frac"] = round(17.0 * points / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             entry["ceiling_frac_static"] = 0.333
         elif p == 65537:
             entry["ceiling_frac_static"] = 0.73
@@ -605,13 +607,14 @@ def extras(ga, L, lib, stream, with_cpu):
                 FP.ntt_u32_pow2(xh[reps % batch], omega)
                 reps += 1
             dt = time.perf_counter() - t1
-            entry["cpu_baseline"] = {"transforms_per_s": round(reps / dt, 2), "cores": 1, "kind": "port", "n": reps}
+            entry["cpu_baseline"] = {"transforms_per_s": round(reps / dt, 2), "cores": 1}
             calls, dt_all, cores = _all_cores(lambda i: FP.ntt_u32_pow2(xh[i % batch], omega))
-            entry["cpu_baseline_all_cores"] = {"transforms_per_s": round(calls / dt_all, 2), "cores": cores, "n": calls}
+            entry["cpu_baseline_all_cores"] = {"transforms_per_s": round(calls / dt_all, 2), "cores": cores}
         ex[tag] = entry
         del xd, od
     # ---- ONE long transform (three passes of the register kernel) and a long polynomial product that needs the CRT route ----
     for tag, p, logn, dt, tdt in (("ntt_single_2^26_gf469762049", 469762049, 26, L.U32, torch.int32),
+                                  ("ntt_single_2^27_gf2013265921", 2013265921, 27, L.U32, torch.int32),  # = galois.ntt(x) of 2^27 points
                                   ("ntt_single_2^26_goldilocks", 2**64 - 2**32 + 1, 26, L.U64, torch.int64)):
         P = ga.GF(p)
         N = 1 << logn
@@ -622,7 +625,8 @@ def extras(ga, L, lib, stream, with_cpu):
         gbs = 2.0 * width * N / (ms.value * 1e-3) / 1e9
         ex[tag] = {"ms": round(ms.value, 4), "roofline_frac": round(gbs / HBM_PEAK_GBS, 4), "passes": 3}
         if dt == L.U32:
-            ex[tag]["physical_bytes_per_point"] = 25.2  # profiles/r05_pmc_ntt_m32_three_pass.txt (static)
+            if p == 469762049:
+                ex[tag]["physical_bytes_per_point"] = 25.2  # profiles/r05_pmc_ntt_m32_three_pass.txt (static)
             # parity of the three-pass form in this very run: the inverse transform restores the input
             bk = torch.empty_like(xd)
             w = P._root_of_unity_int(N)
@@ -721,7 +725,7 @@ def extras(ga, L, lib, stream, with_cpu):
         OR.decode_u8(R[:2048])
         td = time.perf_counter() - t1
         ex["rs_255_223"]["cpu_baseline"] = {"encode_GB/s": round(255.0 * 2048 / te / 1e9, 5), "decode_GB/s": round(255.0 * 2048 / td / 1e9, 5),
-                                            "cores": 1, "kind": "port", "n": 2048}
+                                            "cores": 1}
         ce, dte, cores = _all_cores(lambda i: OR.encode_u8(M[(i % 256) * 256:(i % 256) * 256 + 256]))
         cd_, dtd, _ = _all_cores(lambda i: OR.decode_u8(R[(i % 256) * 256:(i % 256) * 256 + 256]))
         ex["rs_255_223"]["cpu_baseline_all_cores"] = {"encode_GB/s": round(255.0 * 256 * ce / dte / 1e9, 4), "decode_GB/s": round(255.0 * 256 * cd_ / dtd / 1e9, 4),
@@ -754,7 +758,7 @@ def extras(ga, L, lib, stream, with_cpu):
         od, on = OB.decode(Rb[:2048])
         td = time.perf_counter() - t1
         assert np.array_equal(od, Cb[:2048]) and np.array_equal(on, neb[:2048])
-        ex["bch_255_223"]["cpu_baseline"] = {"decode_GB/s": round(255.0 * 2048 / td / 1e9, 5), "cores": 1, "kind": "port", "n": 2048}
+        ex["bch_255_223"]["cpu_baseline"] = {"decode_GB/s": round(255.0 * 2048 / td / 1e9, 5), "cores": 1}
     return ex
 
 
