@@ -109,12 +109,19 @@ class BigFieldArray(WideFieldArray):
     def _reduce_kw(self, ufunc, op, axis, keepdims, where, initial):
         if self._kw_given(where):
             self._no("The `where=` keyword")
-        r = self._reduce(op, axis, keepdims)
-        if self._kw_given(initial):
-            cls = type(self)
-            init = initial if isinstance(initial, cls) else cls(initial)
-            return self._binary(op, init.reshape(()), r)
-        return r
+        if not self._kw_given(initial):
+            return self._reduce(op, axis, keepdims)
+        # NumPy's fold from a seed: ((v op x0) op x1) ... = v op (x0 dual x1 dual ...), dual = + for -, * for / (FieldArray._reduce_kw)
+        cls = type(self)
+        init = (initial if isinstance(initial, cls) else cls(initial)).reshape(())
+        dual = L.OP_ADD if op in (L.OP_ADD, L.OP_SUB) else L.OP_MUL
+        n_axis = self.size if axis is None else self.shape[axis % self.ndim]
+        if n_axis == 0:  # an empty axis: the seed itself, in the result's shape
+            lead = () if axis is None else tuple(d for i, d in enumerate(self.shape) if i != axis % self.ndim)
+            if keepdims:
+                lead = (1,) * self.ndim if axis is None else tuple(1 if i == axis % self.ndim else d for i, d in enumerate(self.shape))
+            return cls._wrap(init._t.expand(lead + (cls._NL,)).contiguous())
+        return self._binary(op, init, self._reduce(dual, axis, keepdims))
 
     # ---- `where=` on calls, np.convolve and @ as compositions of the element-wise kernels (slow and exact) ----
     def _ufunc_masked(self, ufunc, method, where, inputs, kwargs):

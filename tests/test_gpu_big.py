@@ -125,6 +125,12 @@ def test_folds_and_array_surface_of_the_k_limb_fields(tag):
         H.assert_equal_ints(uf.accumulate(x, axis=1).numpy(), np.array([left_fold(fn, r) for r in h], dtype=object))
     assert int(np.sum(x)) == left_fold(W.add, h.ravel())[-1] and int(np.prod(x[0])) == left_fold(W.mul, h[0])[-1]
     assert int(np.add.reduce(x[0], initial=GF(9))) == W.add(9, left_fold(W.add, h[0])[-1])
+    # NumPy's fold from a seed: ((9 - x0) - x1) ... = 9 - (x0 + x1 + ...)  (the dual operation folds the body)
+    want = 9
+    for v in h[0]:
+        want = W.sub(want, int(v))
+    assert int(np.subtract.reduce(x[0], initial=GF(9))) == want
+    assert int(np.add.reduce(x[0, :0], initial=GF(9))) == 9
     assert np.sum(x, axis=1, keepdims=True).shape == (4, 1)
     H.assert_equal_ints(np.multiply.outer(x[0, :3], x[1, :2]).numpy(), np.array([[W.mul(int(u), int(v)) for v in h[1, :2]] for u in h[0, :3]], dtype=object))
     # compositions of the element-wise kernels: where= on calls, np.convolve, @

@@ -139,21 +139,35 @@ class Gen:
         R = self.R
         L = R.bit_length() - 1
         unit = 64 // R  # exponent of z64 per unit of w_R
+        self.op_layer = []  # layer (0 = first) of every op, for split()
         for s in range(L - 1, -1, -1):
             half = 1 << s
             for b in range(0, R, 2 * half):
                 for j in range(half):
                     e = (j << (L - 1 - s)) * unit
                     self.butterfly(b + j, b + j + half, e)
+            self.op_layer += [L - 1 - s] * (len(self.ops) - len(self.op_layer))
         for r in range(R):
             self.ensure_mag(r, self.out_max)
+        self.op_layer += [L] * (len(self.ops) - len(self.op_layer))
+
+    def split(self, layers, classes, modulus):
+        """Reorders the ops into (head, tail): head = every op of the first `layers` layers whose registers all lie in residue classes
+        < `classes` modulo `modulus` (those layers pair registers of ONE class, so the head is closed under dependencies and the tail
+        -- everything else, in the original order -- never feeds it).  Per-register op sequences, hence the tracked intervals, are
+        unchanged.  The kernel runs the head on the rows that arrived first while the last ones are still in flight."""
+        head, tail = [], []
+        for op, lay in zip(self.ops, self.op_layer):
+            regs = [op[1]] + ([op[2]] if op[0].startswith("bfly") else [])
+            (head if lay < layers and all(r % modulus < classes for r in regs) else tail).append(op)
+        return head, tail
 
     # ---- output ----
-    def emit_cpp(self, name):
-        out = [f"// radix-{self.R} DIF network over GF(65537), canonical roots; outputs in bit-reversed positions",
-               f"static constexpr int {name.upper()}_OUT_MAX = {max(self.mag(r) for r in range(self.R))};",
-               f"__device__ __forceinline__ void {name}(int (&v)[{self.R}])", "{", "    int t;"]
-        for op, a, b, k in self.ops:
+    def emit_cpp(self, name, ops=None, header=True):
+        out = ([f"// radix-{self.R} DIF network over GF(65537), canonical roots; outputs in bit-reversed positions",
+                f"static constexpr int {name.upper()}_OUT_MAX = {max(self.mag(r) for r in range(self.R))};"] if header else [])
+        out += [f"__device__ __forceinline__ void {name}(int (&v)[{self.R}])", "{", "    int t;"]
+        for op, a, b, k in (self.ops if ops is None else ops):
             if op == "fold":
                 out.append(f"    v[{a}] = fm_fold(v[{a}]);")
             elif op == "bfold":
@@ -238,9 +252,14 @@ NETS = [
 ]
 
 
+# networks also emitted in two parts (Gen.split): (layers, classes, modulus)
+SPLITS = {"fermat_net64_canon": (3, 5, 8)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--split", action="store_true", help="also emit the networks of SPLITS in two parts (tools/ubench/fermat_r06.hip, -DDFS=1)")
     ap.add_argument("-o", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "galois_amd", "csrc",
                                                "gfa_fermat_nets.inc"))
     a = ap.parse_args()
@@ -255,6 +274,17 @@ def main():
         parts.append(f"// {name}: {c}")
         parts.append(g.emit_cpp(name))
         parts.append("")
+        if a.split and name in SPLITS:
+            layers, classes, modulus = SPLITS[name]
+            head, tail = g.split(layers, classes, modulus)
+            if a.check:  # the reordered op list computes the same network within the same bounds
+                g2 = Gen(R, lo, hi, omax)
+                g2.ops = head + tail
+                check(g2, lo, hi)
+            parts.append(f"// {name} in two parts: _head = layers 1..{layers} on the positions = 0..{classes - 1} (mod {modulus}) ({len(head)} ops), _tail = the rest ({len(tail)} ops)")
+            parts.append(g.emit_cpp(name + "_head", head, header=False))
+            parts.append(g.emit_cpp(name + "_tail", tail, header=False))
+            parts.append("")
     with open(a.o, "w") as f:
         f.write("\n".join(parts))
     print("wrote", a.o)

@@ -33,6 +33,11 @@ typedef unsigned long long u64;
         }                                                                                      \
     } while (0)
 
+#ifdef DFS
+#define DFS_INC DFS
+#else
+#define DFS_INC 0
+#endif
 #ifndef PF
 #define PF 96 // values of the next transform requested a round ahead (multiple of 32)
 #endif
@@ -98,7 +103,11 @@ __device__ __forceinline__ int fm_bfold(int t)
     return r;
 }
 
+#if DFS_INC
+#include "../../_variants/gfa_fermat_nets_split.inc" // python tools/gen_fermat_net.py --split -o _variants/gfa_fermat_nets_split.inc
+#else
 #include "../../galois_amd/csrc/gfa_fermat_nets.inc"
+#endif
 
 constexpr int brev_c(int x, int bits)
 {
@@ -421,6 +430,9 @@ __global__ __launch_bounds__(512) void fermat_a_kernel(FermatArgs a)
 #ifndef BEARLY
 #define BEARLY 0
 #endif
+#ifndef DFS
+#define DFS 0 // 1: network 0 in two parts (layers 1-3 on the 40 positions = 0..4 mod 8 first); those positions are the ones requested ahead
+#endif
 #ifndef X2MODE
 #define X2MODE 0 // 1: exchange 2 in rounds by first-network half (w[0] travels under net1(1), w[1] under net2(0)) instead of by k1 half
 #endif
@@ -433,6 +445,8 @@ __global__ __launch_bounds__(512) void fermat_a_kernel(FermatArgs a)
 #ifndef BE4
 #define BE4 (BE3 > 32 ? BE3 : 32) // requests [BE3, BE4) after the first half's stores; the rest after the second half's
 #endif
+// request order: the 40 positions = 0..4 (mod 8) first, then the 24 positions = 5..7 (mod 8)
+constexpr int dfs_order(int i) { return DFS ? (i < 40 ? (i / 5) * 8 + i % 5 : ((i - 40) / 3) * 8 + 5 + (i - 40) % 3) : i; }
 constexpr int B_EX_WORDS = 16 * 64 * E2_PITCH;
 constexpr int B_LDS_BYTES = (B_EX_WORDS + 1024) * 4;
 #define B_SPLIT()                                                   \
@@ -489,9 +503,18 @@ __global__ __launch_bounds__(1024) void fermat_b_kernel(FermatArgs a)
         }
         auto breq = [&](int lo, int hi) {
 #pragma unroll
-            for (int ap = lo; ap < hi; ap++) v[ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xn, voff, (int)(((uinv * ap) & 63u) << 12), AUX_LD);
+            for (int i = lo; i < hi; i++) {
+                const int ap = dfs_order(i);
+                v[ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xn, voff, (int)(((uinv * (unsigned)ap) & 63u) << 12), AUX_LD);
+            }
         };
+#if DFS
+        fermat_net64_canon_head(v);
+        B_SPLIT();
+        fermat_net64_canon_tail(v);
+#else
         fermat_net64_canon(v);
+#endif
         B_SPLIT();
         v[0] = fm_fold(v[0]);
         int A[8], B[8];
@@ -699,7 +722,7 @@ int main(int argc, char **argv)
         else if (dbg) hipLaunchKernelGGL((fermat_a_kernel<true>), dim3(grid), dim3(512), A_LDS_BYTES, 0, a);
         else hipLaunchKernelGGL((fermat_a_kernel<false>), dim3(grid), dim3(512), A_LDS_BYTES, 0, a);
     };
-    printf("config: X2MODE=%d VARB=%d BE1=%d BEARLY=%d BE3=%d BE4=%d TWMODE=%d DEEP=%d PF=%d TWW=%d PFPOS=%d TSHIFT=%d SKEL=%d STAGGER=%d AUX_LD=%d AUX_ST=%d PRIO=%d cus=%d\n", X2MODE, VARB, BE1, BEARLY, BE3, BE4, TWMODE, DEEP, PF, TWW, PFPOS, TSHIFT, SKEL, STAGGER, AUX_LD, AUX_ST, PRIO, cus);
+    printf("config: DFS=%d X2MODE=%d VARB=%d BE1=%d BEARLY=%d BE3=%d BE4=%d TWMODE=%d DEEP=%d PF=%d TWW=%d PFPOS=%d TSHIFT=%d SKEL=%d STAGGER=%d AUX_LD=%d AUX_ST=%d PRIO=%d cus=%d\n", DFS, X2MODE, VARB, BE1, BEARLY, BE3, BE4, TWMODE, DEEP, PF, TWW, PFPOS, TSHIFT, SKEL, STAGGER, AUX_LD, AUX_ST, PRIO, cus);
     // ---- check against the product kernel ----
     if (SKEL == 0 && check_batch > 0) {
         if (gfa_ntt(f, d_in, d_ref, 65536, check_batch, omega, 0, GFA_U32, nullptr) != GFA_OK) { fprintf(stderr, "gfa_ntt\n"); return 2; }
