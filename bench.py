@@ -262,6 +262,16 @@ def main():
             if "rs_255_223" in ex:
                 ns["rs_enc_GB/s"] = ex["rs_255_223"]["encode_GB/s"]
                 ns["rs_dec_GB/s"] = ex["rs_255_223"]["decode_GB/s"]
+            # N > 1: the sharded legs (whole-job figures over all ranks) and the distributed 2^26-point Goldilocks transform
+            if "rs_255_223_sharded" in ex:
+                ns["rs_sharded_enc_GB/s"] = ex["rs_255_223_sharded"]["encode_GB/s"]
+                ns["rs_sharded_dec_GB/s"] = ex["rs_255_223_sharded"]["decode_GB/s"]
+            for tag in ("ntt_2^20_gf7340033_sharded", "ntt_16x2^16_gf65537_sharded"):
+                if tag in ex:
+                    ns[tag] = {"tps": ex[tag]["transforms_per_s"], "frac_per_gpu": ex[tag]["roofline_frac_per_gpu"]}
+            c5 = ex.get("c5_goldilocks_2^26_distributed")
+            if c5 and "forward" in c5:
+                ns["c5_goldilocks_2^26_forward_ms"] = c5["forward"].get("wall_ms")
             result["north_star"] = ns
         print(json.dumps(result), flush=True)
     if dist is not None:
