@@ -1,4 +1,5 @@
-// gfa_elementwise_packed.hip -- np.add / np.subtract / np.negative over GF(p^m), p odd, 8192 < q <= 2^20, as packed-digit arithmetic.
+// gfa_elementwise_packed.hip -- np.add / np.subtract / np.negative over GF(p^m), p odd, 8192 < q <= 2^20, as packed-digit arithmetic
+// (r06: GF(3^11) and GF(3^12), whose digits need 33 / 36 packed bits, through two words: packed_lin2_kernel).
 //
 // Replaces, for these fields, the reference's add / subtract / negative ufuncs in BOTH of its modes -- the Zech-logarithm lookups
 // (src/galois/_domains/_lookup.py:31-60, 89-150) and the digit-vector loops (_calculate.py:150-285) -- with the scheme of
@@ -91,6 +92,40 @@ __global__ __launch_bounds__(PK_THREADS) void packed_lin_kernel(Plan pl, const p
     }
 }
 
+// the same for the two fields that need TWO packed words (r06: GF(3^11), GF(3^12); gfa_packed.h::Plan2), uint32 arrays
+template <int OP>
+__global__ __launch_bounds__(PK_THREADS) void packed_lin2_kernel(Plan2 pl, const pu32 *__restrict__ gtab, const uint32_t *__restrict__ a, int sa,
+                                                                  const uint32_t *__restrict__ b, int sb, uint32_t *__restrict__ out, i64 n)
+{
+    extern __shared__ pu32 pk_tab[];
+    for (pu32 i = threadIdx.x; i < pl.words; i += PK_THREADS) pk_tab[i] = gtab[i];
+    __syncthreads();
+    constexpr int V = 4;
+    const i64 nvec = n / V;
+    const Pk2 pa0 = sa ? Pk2{0u, 0u} : to_packed2(pl, pk_tab, a[0]);
+    const Pk2 pb0 = (OP == 2 || sb) ? Pk2{0u, 0u} : to_packed2(pl, pk_tab, b[0]);
+    const uint4 *av = reinterpret_cast<const uint4 *>(a), *bv = reinterpret_cast<const uint4 *>(b);
+    uint4 *ov = reinterpret_cast<uint4 *>(out);
+    for (i64 i = (i64)blockIdx.x * PK_THREADS + threadIdx.x; i < nvec; i += (i64)gridDim.x * PK_THREADS) {
+        pu32 xa[V], xb[V], r[V];
+        if (sa) unpack_vec<uint32_t>(av[i], xa);
+        if (OP != 2 && sb) unpack_vec<uint32_t>(bv[i], xb);
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            const Pk2 pa = sa ? to_packed2(pl, pk_tab, xa[j]) : pa0;
+            const Pk2 pb = OP == 2 ? Pk2{0u, 0u} : (sb ? to_packed2(pl, pk_tab, xb[j]) : pb0);
+            r[j] = from_packed2(pl, pk_tab, lin_packed2<OP>(pl, pa, pb));
+        }
+        ov[i] = pack_vec<uint32_t>(r);
+    }
+    const i64 t0 = nvec * V + (i64)blockIdx.x * PK_THREADS + threadIdx.x;
+    if (t0 < n) {
+        const Pk2 pa = sa ? to_packed2(pl, pk_tab, a[t0]) : pa0;
+        const Pk2 pb = OP == 2 ? Pk2{0u, 0u} : (sb ? to_packed2(pl, pk_tab, b[t0]) : pb0);
+        out[t0] = from_packed2(pl, pk_tab, lin_packed2<OP>(pl, pa, pb));
+    }
+}
+
 // products of uint32 arrays (65536 < q <= 2^20): digits through the same LDS tables, gfa_packed.h::mul_digits (no reduction before the end)
 template <typename T, int M>
 __global__ __launch_bounds__(PK_THREADS) void packed_mul_kernel(Plan pl, MulAux ax, const pu32 *__restrict__ gtab, const T *__restrict__ a, int sa,
@@ -145,6 +180,32 @@ int get_dev(const FieldDev &c, PackedDev *out)
     return GFA_OK;
 }
 
+struct Packed2Dev {
+    Plan2 pl;
+    pu32 *tab = nullptr;
+};
+std::map<std::tuple<u64, u32, int>, Packed2Dev> g_pk2; // (p, m, device)
+
+int get_dev2(const FieldDev &c, Packed2Dev *out)
+{
+    int dev = 0;
+    GFA_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_pk_mu);
+    auto key = std::make_tuple(c.p, c.m, dev);
+    auto it = g_pk2.find(key);
+    if (it == g_pk2.end()) {
+        Packed2Dev d;
+        if (!make_plan2(c.p, c.m, &d.pl)) return GFA_ERR_UNSUPPORTED;
+        std::vector<pu32> t;
+        build_tables2(d.pl, t);
+        GFA_HIP(hipMalloc((void **)&d.tab, sizeof(pu32) * t.size()));
+        GFA_HIP(hipMemcpy(d.tab, t.data(), sizeof(pu32) * t.size(), hipMemcpyHostToDevice));
+        it = g_pk2.emplace(key, d).first;
+    }
+    *out = it->second;
+    return GFA_OK;
+}
+
 int num_cus()
 {
     static const int cus = [] { int dev = 0, n = 0; return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }();
@@ -163,6 +224,17 @@ int launch(const PackedDev &d, const void *a, i64 sa, const void *b, i64 sb, voi
     return GFA_OK;
 }
 
+template <int OP>
+int launch2(const Packed2Dev &d, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st)
+{
+    const i64 blocks = std::max<i64>(1, (n / 4 + PK_THREADS - 1) / PK_THREADS);
+    const int grid = (int)std::min<i64>(blocks, (i64)num_cus() * 4);
+    hipLaunchKernelGGL((packed_lin2_kernel<OP>), dim3(grid), dim3(PK_THREADS), sizeof(pu32) * d.pl.words, st, d.pl, (const pu32 *)d.tab, (const uint32_t *)a,
+                       (int)sa, (const uint32_t *)b, (int)sb, (uint32_t *)out, n);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
 inline bool al16p(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 } // namespace
@@ -177,13 +249,30 @@ bool packed_eligible(const FieldDev &c, int dtype, i64 n, bool pinned)
     if (c.m < 2 || (c.p & 1) == 0 || (c.q <= 8192 && !pinned) || c.q > ((u64)1 << 20) || n < 1024) return false;
     if (!(dtype == GFA_U32 || (dtype == GFA_U16 && c.q <= 65536) || (dtype == GFA_U8 && c.q <= 256))) return false;
     Plan pl;
-    return make_plan(c.p, c.m, &pl);
+    if (make_plan(c.p, c.m, &pl)) return true;
+    Plan2 pl2; // r06: more than 32 packed bits (GF(3^11), GF(3^12)): two words, uint32 arrays
+    return dtype == GFA_U32 && make_plan2(c.p, c.m, &pl2);
 }
 
 // op: GFA_OP_ADD / GFA_OP_SUB / GFA_OP_NEG.  GFA_ERR_UNSUPPORTED (nothing launched): misaligned operands.
 int packed_run(const FieldDev &c, int dtype, int op, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st)
 {
     if (!al16p(out) || (sa && !al16p(a)) || (op != GFA_OP_NEG && sb && !al16p(b))) return GFA_ERR_UNSUPPORTED;
+    {
+        Plan one;
+        if (!make_plan(c.p, c.m, &one)) { // two packed words
+            Packed2Dev d2;
+            const int rc2 = get_dev2(c, &d2);
+            if (rc2) return rc2;
+            if (dtype != GFA_U32) return GFA_ERR_UNSUPPORTED;
+            if (op == GFA_OP_NEG) { b = a; sb = 0; }
+            switch (op) {
+            case GFA_OP_ADD: return launch2<0>(d2, a, sa, b, sb, out, n, st);
+            case GFA_OP_SUB: return launch2<1>(d2, a, sa, b, sb, out, n, st);
+            default: return launch2<2>(d2, a, sa, b, sb, out, n, st);
+            }
+        }
+    }
     PackedDev d;
     const int rc = get_dev(c, &d);
     if (rc) return rc;

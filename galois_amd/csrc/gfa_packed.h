@@ -145,6 +145,59 @@ GFP_HD pu32 from_packed(const Plan &pl, const pu32 *tab, pu32 w)
     return v;
 }
 
+// ---- two packed words (r06): fields whose m digits need more than 32 packed bits -- GF(3^11) (33 bits) and GF(3^12) (36), the only ones
+// with q <= 2^20.  Sums never mix digits, so the element splits into x = xh * p^ml + xl and each part is a digit vector of its own
+// Plan (ml = ceil(m / 2) and m - ml digits): two independent packed words, the same six instructions on each.  The quotient by
+// PL = p^ml <= 4096 is exact through one v_mul_hi (x < 2^20), as inside to_packed.
+struct Plan2 {
+    Plan lo, hi;
+    pu32 PL, magicL; // p^ml and ceil(2^32 / PL)
+    pu32 off2;       // 32-bit words of the low plan's tables: the high plan's tables follow
+    pu32 words;
+};
+inline bool make_plan2(uint64_t p64, uint32_t m, Plan2 *out)
+{
+    Plan single;
+    if (make_plan(p64, m, &single)) return false; // one word is enough
+    if (p64 < 3 || (p64 & 1) == 0 || m < 4 || p64 > 1021) return false;
+    uint64_t q = 1;
+    for (uint32_t i = 0; i < m; i++) { q *= p64; if (q > (1u << 20)) return false; }
+    const uint32_t ml = (m + 1) / 2;
+    Plan2 r{};
+    if (!make_plan(p64, ml, &r.lo) || !make_plan(p64, m - ml, &r.hi)) return false;
+    r.PL = ipow((pu32)p64, ml);
+    if (r.PL > 4096) return false;
+    r.magicL = (pu32)((((uint64_t)1 << 32) + r.PL - 1) / r.PL);
+    r.off2 = r.lo.words;
+    r.words = r.lo.words + r.hi.words;
+    *out = r;
+    return true;
+}
+inline void build_tables2(const Plan2 &pl, std::vector<pu32> &t)
+{
+    std::vector<pu32> a, b;
+    build_tables(pl.lo, a);
+    build_tables(pl.hi, b);
+    t = a;
+    t.insert(t.end(), b.begin(), b.end());
+}
+struct Pk2 { pu32 lo, hi; };
+GFP_HD Pk2 to_packed2(const Plan2 &pl, const pu32 *tab, pu32 x)
+{
+    const pu32 xh = mulhi32(x, pl.magicL);
+    const pu32 xl = x - xh * pl.PL;
+    return Pk2{to_packed(pl.lo, tab, xl), to_packed(pl.hi, tab + pl.off2, xh)};
+}
+template <int OP>
+GFP_HD Pk2 lin_packed2(const Plan2 &pl, Pk2 a, Pk2 b)
+{
+    return Pk2{lin_packed<OP>(pl.lo, a.lo, b.lo), lin_packed<OP>(pl.hi, a.hi, b.hi)};
+}
+GFP_HD pu32 from_packed2(const Plan2 &pl, const pu32 *tab, Pk2 w)
+{
+    return from_packed(pl.lo, tab, w.lo) + pl.PL * from_packed(pl.hi, tab + pl.off2, w.hi);
+}
+
 // ---- products on the same digit tables (r05): schoolbook product of the two digit vectors with NO reduction until the end.
 // multiply_vector (_calculate.py:343-383) reduces modulo p after every step; for these small characteristics every partial sum of
 // the product AND of the folds through x^m = -(irr) stays below 2^32 (bound_ok replays the worst case), so the only reductions

@@ -48,6 +48,31 @@ static long check(pu32 p, pu32 m, std::mt19937 &rng)
     return fails;
 }
 
+// two packed words (r06): GF(3^11), GF(3^12)
+static long check2(pu32 p, pu32 m, std::mt19937 &rng)
+{
+    Plan2 pl;
+    if (!make_plan2(p, m, &pl)) { printf("GF(%u^%u): two-word plan refused\n", p, m); return 1; }
+    std::vector<pu32> t;
+    build_tables2(pl, t);
+    const pu32 q = ipow(p, m);
+    long fails = 0;
+    auto one = [&](pu32 x, pu32 y) {
+        const Pk2 a = to_packed2(pl, t.data(), x), b = to_packed2(pl, t.data(), y);
+        if (from_packed2(pl, t.data(), a) != x) fails++;
+        if (from_packed2(pl, t.data(), lin_packed2<0>(pl, a, b)) != digitwise(p, m, x, y, 0)) fails++;
+        if (from_packed2(pl, t.data(), lin_packed2<1>(pl, a, b)) != digitwise(p, m, x, y, 1)) fails++;
+        if (from_packed2(pl, t.data(), lin_packed2<2>(pl, a, b)) != digitwise(p, m, x, y, 2)) fails++;
+    };
+    for (pu32 x = 0; x < q; x += 1 + q / 200000) one(x, q - 1 - x); // the exact-quotient claim over the whole range
+    const pu32 edge[8] = {0, 1, q - 1, q - 2, pl.PL, pl.PL - 1, pl.PL + 1, q - pl.PL};
+    for (pu32 a : edge)
+        for (pu32 b : edge) one(a, b);
+    for (int it = 0; it < 300000; it++) one(rng() % q, rng() % q);
+    printf("GF(%u^%u): two words of %u + %u digits, %u table words, %s\n", p, m, pl.lo.m, pl.hi.m, pl.words, fails ? "FAIL" : "ok");
+    return fails;
+}
+
 // products: mul_digits against the textbook product of the digit polynomials reduced by x^m + irr, for a (random) monic irr -- the
 // arithmetic does not need irreducibility -- incl. all-(p-1) operands (the bound replay's worst case)
 template <int M>
@@ -98,6 +123,12 @@ int main()
     for (auto &f : fields) fails += check(f[0], f[1], rng);
     fails += check_mul<2>(997, rng) + check_mul<2>(257, rng) + check_mul<3>(97, rng) + check_mul<3>(41, rng) + check_mul<4>(31, rng) + check_mul<4>(17, rng);
     fails += check_mul<5>(13, rng) + check_mul<5>(11, rng) + check_mul<6>(7, rng) + check_mul<7>(7, rng) + check_mul<7>(5, rng) + check_mul<8>(5, rng) + check_mul<8>(3, rng);
+    fails += check2(3, 11, rng) + check2(3, 12, rng);
+    Plan2 pl2;
+    if (make_plan2(7, 7, &pl2) || make_plan2(3, 13, &pl2) || make_plan2(2, 12, &pl2)) { // one word suffices / order above 2^20 / even characteristic
+        printf("a field outside the two-word scheme was accepted\n");
+        fails++;
+    }
     Plan pl;
     // refused: even characteristic, prime fields, more than 32 packed bits (3^11: 33), orders above 2^20, digits above 1021
     if (make_plan(2, 8, &pl) || make_plan(7, 1, &pl) || make_plan(3, 11, &pl) || make_plan(3, 13, &pl) || make_plan(1031, 2, &pl) || make_plan(101, 4, &pl)) {

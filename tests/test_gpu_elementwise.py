@@ -1002,6 +1002,7 @@ def test_wide_storage_of_fields_between_2e15_and_2e16_elements(order, dt):
 
 @pytest.mark.parametrize("order,dt", [(3**9, np.uint16), (3**10, np.uint16), (3**10, np.uint32), (5**8, np.uint32), (7**7, np.uint32), (13**5, np.uint32),
                                       (97**3, np.uint32), (997**2, np.uint32),
+                                      (3**11, np.uint32), (3**12, np.uint32),  # r06: 33 / 36 packed bits -> two words (packed_lin2_kernel)
                                       # pinned to jit-calculate, the small fields take the same kernels (uint8 arrays included); in lookup mode their LDS tables
                                       (3**2, np.uint8), (3**5, np.uint8), (5**3, np.uint8), (13**2, np.uint8), (3**7, np.uint16), (7**3, np.uint16), (3**5, np.uint32)])
 @pytest.mark.parametrize("mode", ["jit-lookup", "jit-calculate"])
