@@ -1571,6 +1571,11 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
             rc = packed_mul_run(f->calc, dtype, a, sa, b, sb, out, n, st);
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
+        // r06: degree-2 quotients by the norm (conjugate / N(b), 1 / N from a p-entry LDS table): 0.15 -> see profiles/r06_ew_div2.txt
+        if (op == GFA_OP_DIV && packed_div2_eligible(f->calc, dtype, n)) {
+            rc = packed_div2_run(f->calc, a, sa, b, sb, out, n, st, dev_err);
+            if (rc != GFA_ERR_UNSUPPORTED) return rc;
+        }
         return dispatch_binary(f->calc, dtype, op, a, sa, b, sb, out, n, st, dev_err);
     }
     if (f->use_lookup()) {
@@ -1629,8 +1634,13 @@ int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int d
     }
     // r05, AUTO only: reciprocals of degree-2 extension fields above 65536 elements on the digit-vector kernel (0.12 vs 0.06, see gfa_binary)
     if (f->mode == GFA_MODE_AUTO && op == GFA_OP_RECIP && f->calc.m == 2 && (f->calc.p & 1) && f->calc.q > 65536 && f->calc.kind == KIND_EXT &&
-        Ext::fixed_degree(f->calc))
+        Ext::fixed_degree(f->calc)) {
+        if (packed_div2_eligible(f->calc, dtype, n)) { // r06: by the norm
+            rc = packed_div2_run(f->calc, nullptr, 0, a, 1, out, n, st, dev_err);
+            if (rc != GFA_ERR_UNSUPPORTED) return rc;
+        }
         return dispatch_unary(f->calc, dtype, op, a, out, n, st, dev_err);
+    }
     if (f->use_lookup()) {
         const FieldDev &c = f->calc;
         const bool trivial_neg = op == GFA_OP_NEG && (c.p == 2 || c.m == 1);

@@ -153,6 +153,41 @@ __global__ __launch_bounds__(PK_THREADS) void packed_mul_kernel(Plan pl, MulAux 
     if (t0 < n) out[t0] = (T)mul_digits<M>(pl, ax, sa ? to_packed(pl, pk_tab, (pu32)a[t0]) : pa0, sb ? to_packed(pl, pk_tab, (pu32)b[t0]) : pb0);
 }
 
+// quotients / reciprocals of GF(p^2), 65536 < q <= 2^20, uint32 arrays: gfa_packed.h::div2 (norm + a p-entry inverse table in LDS)
+template <bool RECIP>
+__global__ __launch_bounds__(PK_THREADS) void packed_div2_kernel(Div2Aux ax, const pu32 *__restrict__ ginv, const uint32_t *__restrict__ a, int sa,
+                                                                  const uint32_t *__restrict__ b, int sb, uint32_t *__restrict__ out, i64 n, int *err)
+{
+    extern __shared__ pu32 pk_tab[];
+    for (pu32 i = threadIdx.x; i < ax.p; i += PK_THREADS) pk_tab[i] = ginv[i];
+    __syncthreads();
+    constexpr int V = 4;
+    const i64 nvec = n / V;
+    const uint4 *av = reinterpret_cast<const uint4 *>(a), *bv = reinterpret_cast<const uint4 *>(b);
+    uint4 *ov = reinterpret_cast<uint4 *>(out);
+    const pu32 a0 = (RECIP || sa) ? 0u : a[0], b0 = sb ? 0u : b[0];
+    bool bad = false;
+    for (i64 i = (i64)blockIdx.x * PK_THREADS + threadIdx.x; i < nvec; i += (i64)gridDim.x * PK_THREADS) {
+        pu32 xa[V], xb[V], r[V];
+        if (!RECIP && sa) unpack_vec<uint32_t>(av[i], xa);
+        if (sb) unpack_vec<uint32_t>(bv[i], xb);
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            bool z;
+            r[j] = div2<RECIP>(ax, pk_tab, (!RECIP && sa) ? xa[j] : a0, sb ? xb[j] : b0, &z);
+            bad |= z;
+        }
+        ov[i] = pack_vec<uint32_t>(r);
+    }
+    const i64 t0 = nvec * V + (i64)blockIdx.x * PK_THREADS + threadIdx.x;
+    if (t0 < n) {
+        bool z;
+        out[t0] = div2<RECIP>(ax, pk_tab, (!RECIP && sa) ? a[t0] : a0, sb ? b[t0] : b0, &z);
+        bad |= z;
+    }
+    if (bad && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
+}
+
 struct PackedDev {
     Plan pl;
     pu32 *tab = nullptr;
@@ -336,6 +371,54 @@ int packed_mul_run(const FieldDev &c, int dtype, const void *a, i64 sa, const vo
     else { GFA_PKM_ALL(uint8_t) }
 #undef GFA_PKM_ALL
 #undef GFA_PKM
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+// quotients (reciprocals: a == nullptr) of GF(p^2), odd p, 65536 < q <= 2^20, uint32 arrays (r06)
+static std::map<std::pair<u64, int>, pu32 *> g_inv_tab; // (p, device) -> p-entry inverse table
+
+bool packed_div2_eligible(const FieldDev &c, int dtype, i64 n)
+{
+    Plan pl;
+    MulAux mx;
+    Div2Aux ax;
+    return dtype == GFA_U32 && n >= 1024 && c.m == 2 && packed_mul_aux(c, &pl, &mx, true) && make_div2(c.p, c.m, mx.nir, &ax);
+}
+
+int packed_div2_run(const FieldDev &c, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int *dev_err)
+{
+    const bool recip = a == nullptr;
+    if (!al16p(out) || (!recip && sa && !al16p(a)) || (sb && !al16p(b))) return GFA_ERR_UNSUPPORTED;
+    Plan pl;
+    MulAux mx;
+    Div2Aux ax;
+    if (!packed_mul_aux(c, &pl, &mx, true) || !make_div2(c.p, c.m, mx.nir, &ax)) return GFA_ERR_UNSUPPORTED;
+    int dev = 0;
+    GFA_HIP(hipGetDevice(&dev));
+    pu32 *inv = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_pk_mu);
+        auto key = std::make_pair((u64)c.p, dev);
+        auto it = g_inv_tab.find(key);
+        if (it == g_inv_tab.end()) {
+            std::vector<pu32> t;
+            build_inverse_table(ax.p, t);
+            pu32 *d = nullptr;
+            GFA_HIP(hipMalloc((void **)&d, sizeof(pu32) * t.size()));
+            GFA_HIP(hipMemcpy(d, t.data(), sizeof(pu32) * t.size(), hipMemcpyHostToDevice));
+            it = g_inv_tab.emplace(key, d).first;
+        }
+        inv = it->second;
+    }
+    const i64 blocks = std::max<i64>(1, (n / 4 + PK_THREADS - 1) / PK_THREADS);
+    const int grid = (int)std::min<i64>(blocks, (i64)num_cus() * 4);
+    if (recip)
+        hipLaunchKernelGGL((packed_div2_kernel<true>), dim3(grid), dim3(PK_THREADS), sizeof(pu32) * ax.p, st, ax, (const pu32 *)inv, (const uint32_t *)nullptr, 0,
+                           (const uint32_t *)b, (int)sb, (uint32_t *)out, n, dev_err);
+    else
+        hipLaunchKernelGGL((packed_div2_kernel<false>), dim3(grid), dim3(PK_THREADS), sizeof(pu32) * ax.p, st, ax, (const pu32 *)inv, (const uint32_t *)a, (int)sa,
+                           (const uint32_t *)b, (int)sb, (uint32_t *)out, n, dev_err);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }

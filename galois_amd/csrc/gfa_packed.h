@@ -263,4 +263,49 @@ GFP_HD pu32 mul_digits(const Plan &pl, const MulAux &ax, pu32 pa, pu32 pb)
     return v;
 }
 
+// ---- quotients and reciprocals of GF(p^2), 65536 < q <= 2^20 (r06): by the norm.  With X^2 = s X + t (s, t = nir[1], nir[0]) the
+// conjugate of b = b0 + b1 X is b^p = (b0 + s b1) - b1 X and N(b) = b b^p = b0^2 + s b0 b1 - t b1^2 lies in GF(p), non-zero for
+// b != 0 (the polynomial is irreducible); 1 / b = b^p / N with 1 / N from a p-entry table (LDS).  Replaces, for these fields, the
+// reference's divide / reciprocal through LOG / EXP tables that do not fit LDS here (_lookup.py:176-235) or its digit-vector
+// loop with a Fermat power (_calculate.py:447-513) -- same field, same values.  Every partial sum stays below 2^32 (p <= 1021).
+struct Div2Aux {
+    pu32 p, s, t, mu32; // X^2 = s X + t; mu32 = floor(2^32 / p)
+    pu32 magic;         // ceil(2^32 / p): floor(x / p) == mulhi(x, magic) for x < 2^20
+};
+inline bool make_div2(uint64_t p, uint32_t m, const pu32 *nir, Div2Aux *ax)
+{
+    if (m != 2 || p < 257 || p > 1021 || (p & 1) == 0) return false; // 65536 < p^2 <= 2^20
+    ax->p = (pu32)p; ax->s = nir[1]; ax->t = nir[0];
+    ax->mu32 = (pu32)(((uint64_t)1 << 32) / p);
+    ax->magic = (pu32)((((uint64_t)1 << 32) + p - 1) / p);
+    return true;
+}
+inline void build_inverse_table(pu32 p, std::vector<pu32> &t)
+{ // t[v] = v^-1 mod p, t[0] = 0
+    t.assign(p, 0);
+    for (pu32 v = 1; v < p; v++) {
+        uint64_t r = 1, b = v;
+        for (pu32 e = p - 2; e; e >>= 1) { if (e & 1) r = r * b % p; b = b * b % p; }
+        t[v] = (pu32)r;
+    }
+}
+// a / b (RECIP: 1 / b) as integers d1 * p + d0; *zero is set when b == 0 (the result is then 0)
+template <bool RECIP>
+GFP_HD pu32 div2(const Div2Aux &ax, const pu32 *inv, pu32 a, pu32 b, bool *zero)
+{
+    const pu32 p = ax.p;
+    const pu32 b1 = mulhi32(b, ax.magic), b0 = b - b1 * p;
+    const pu32 u = red32(b0 + ax.s * b1, p, ax.mu32);                                         // conjugate: u - b1 X
+    const pu32 nrm = red32(b0 * b0 + ax.s * red32(b0 * b1, p, ax.mu32) + (p - ax.t) * red32(b1 * b1, p, ax.mu32), p, ax.mu32);
+    *zero = b == 0;
+    const pu32 ni = inv[nrm];
+    const pu32 i0 = red32(u * ni, p, ax.mu32), i1 = red32((p - b1) * ni, p, ax.mu32);     // 1 / b = i0 + i1 X  ((p - 0) * ni = 0 mod p)
+    if (RECIP) return i1 * p + i0;
+    const pu32 a1 = mulhi32(a, ax.magic), a0 = a - a1 * p;
+    const pu32 w = red32(a1 * i1, p, ax.mu32);                                                 // a1 i1 X^2 = w (s X + t)
+    const pu32 q0 = red32(a0 * i0 + ax.t * w, p, ax.mu32);
+    const pu32 q1 = red32(a0 * i1 + a1 * i0 + ax.s * w, p, ax.mu32);
+    return q1 * p + q0;
+}
+
 } // namespace gfa_packed

@@ -114,10 +114,53 @@ static long check_mul(pu32 p, std::mt19937 &rng)
     return fails;
 }
 
+// quotients of GF(p^2) by the norm (r06): (a / b) * b == a and (1 / b) * b == 1 through the textbook digit product, for random
+// irreducible x^2 + c1 x + c0 (no root mod p), every b of a small slice and random pairs; b == 0 is flagged
+static long check_div2(pu32 p, std::mt19937 &rng)
+{
+    long fails = 0;
+    for (int poly = 0; poly < 4; poly++) {
+        pu32 c1, c0;
+        for (;;) {
+            c1 = rng() % p; c0 = rng() % p;
+            bool root = false;
+            for (pu32 x = 0; x < p && !root; x++) root = ((uint64_t)x * x + (uint64_t)c1 * x + c0) % p == 0;
+            if (!root) break;
+        }
+        pu32 nir[8] = {c0 ? p - c0 : 0, c1 ? p - c1 : 0};
+        Div2Aux ax;
+        if (!make_div2(p, 2, nir, &ax)) { printf("GF(%u^2): refused\n", p); return 1; }
+        std::vector<pu32> inv;
+        build_inverse_table(p, inv);
+        auto mul = [&](pu32 x, pu32 y) { // textbook: (x0 + x1 X)(y0 + y1 X), X^2 = s X + t
+            const uint64_t x0 = x % p, x1 = x / p, y0 = y % p, y1 = y / p;
+            const uint64_t hi = x1 * y1 % p;
+            const uint64_t d0 = (x0 * y0 + ax.t * hi) % p, d1 = (x0 * y1 + x1 * y0 + ax.s * hi) % p;
+            return (pu32)(d1 * p + d0);
+        };
+        const pu32 q = p * p;
+        auto one = [&](pu32 a, pu32 b) {
+            bool z = false, z2 = false;
+            const pu32 qt = div2<false>(ax, inv.data(), a, b, &z), rc = div2<true>(ax, inv.data(), a, b, &z2);
+            if (z != (b == 0) || z2 != (b == 0)) fails++;
+            if (b == 0) return;
+            if (qt >= q || rc >= q || mul(qt, b) != a || mul(rc, b) != 1) fails++;
+        };
+        for (pu32 b = 0; b < 3 * p; b++) one(rng() % q, b);
+        const pu32 edge[6] = {0, 1, q - 1, p, p - 1, q - p};
+        for (pu32 a : edge)
+            for (pu32 b : edge) one(a, b);
+        for (int it = 0; it < 100000; it++) one(rng() % q, rng() % q);
+    }
+    printf("GF(%u^2) quotients by the norm: %s\n", p, fails ? "FAIL" : "ok");
+    return fails;
+}
+
 int main()
 {
     std::mt19937 rng(5);
     long fails = 0;
+    fails += check_div2(997, rng) + check_div2(257, rng) + check_div2(1021, rng) + check_div2(509, rng);
     const pu32 fields[][2] = {{3, 2}, {3, 5}, {5, 3}, {7, 2}, {3, 9}, {3, 10}, {5, 6}, {5, 7}, {5, 8}, {7, 5}, {7, 6}, {7, 7}, {11, 4}, {11, 5}, {13, 5},
                               {17, 4}, {31, 4}, {41, 3}, {97, 3}, {101, 2}, {257, 2}, {1021, 2}};
     for (auto &f : fields) fails += check(f[0], f[1], rng);

@@ -1068,3 +1068,36 @@ def test_auto_mode_products_of_extension_fields_above_2e16_elements(order):
         H.assert_equal_ints(u(x / y), want_div)
     finally:
         GF.compile("auto")
+
+
+@pytest.mark.parametrize("order", [257**2, 509**2, 997**2])  # (1021^2: no Conway polynomial in the shipped table; the host test covers p = 1021)
+def test_degree_two_quotients_by_the_norm(order):
+    """r06: a / b and 1 / b over GF(p^2), 65536 < q <= 2^20, as conjugate / norm with the norm's inverse from a p-entry LDS table
+    (gfa_packed.h::div2, packed_div2_kernel) -- the reference divides through its LOG / EXP tables (_lookup.py:176-235).  Every
+    element against the oracle's lookup scalars, with a tail, broadcast scalars on either side, a misaligned view (the digit-vector
+    kernel takes it), in-place output, and the zero divisor flagged."""
+    GF = ga.GF(order)
+    F = O.OracleField(GF.characteristic, GF.degree, int(GF.irreducible_poly), int(GF.primitive_element), lookup=True)
+    n = 40_003
+    rng = np.random.default_rng(order % 991)
+    a = rng.integers(0, order, n, dtype=np.uint64)
+    b = rng.integers(1, order, n, dtype=np.uint64)
+    p = GF.characteristic
+    a[:4] = (0, order - 1, 1, p)
+    b[:6] = (1, order - 1, p, p - 1, p + 1, order - p)
+    x, y = GF(a.astype(np.uint32)), GF(b.astype(np.uint32))
+    u = lambda v: v.numpy().astype(np.uint64)
+    H.assert_equal_ints(u(x / y), F.div(a, b), f"GF({order}) div")
+    H.assert_equal_ints(u(np.reciprocal(y)), F.div(np.ones(n, dtype=np.uint64), b), f"GF({order}) reciprocal")
+    s = GF(int(b[7]))
+    H.assert_equal_ints(u(x / s), F.div(a, np.full(n, b[7], dtype=np.uint64)), "scalar divisor")
+    H.assert_equal_ints(u(s / y), F.div(np.full(n, b[7], dtype=np.uint64), b), "scalar dividend")
+    H.assert_equal_ints(u(x[1:] / y[1:]), F.div(a[1:], b[1:]), "misaligned views")
+    z = x.copy()
+    np.true_divide(z, y, out=z)
+    H.assert_equal_ints(u(z), F.div(a, b), "in place")
+    H.assert_equal_ints(u((x / y) * y), a, "round trip")
+    with pytest.raises(ZeroDivisionError):
+        y / x
+    with pytest.raises(ZeroDivisionError):
+        np.reciprocal(x)
