@@ -251,7 +251,7 @@ def main():
             for tag in ("ntt_2^20_gf7340033", "ntt_2^20_gf469762049", "ntt_2^20_gf2013265921"):
                 if tag in ex:
                     ns[tag] = {"tps": ex[tag]["transforms_per_s"], "frac": ex[tag]["roofline_frac"], "physical_frac": ex[tag].get("physical_frac")}
-            for tag in ("ntt_16x2^16_gf65537", "ntt_2^16_gf7340033", "ntt_2^14_gf7340033"):
+            for tag in ("ntt_16x2^16_gf65537", "ntt_2^14_gf65537", "ntt_2^16_gf7340033", "ntt_2^14_gf7340033"):
                 if tag in ex:
                     ns[tag + "_frac"] = ex[tag]["roofline_frac"]
             if "ntt_16x2^16_gf65537" in ex:
@@ -578,6 +578,7 @@ def extras(ga, L, lib, stream, with_cpu):
     for tag, p, logn, batch in (("ntt_2^20_gf7340033", 7340033, 20, 64), ("ntt_2^20_gf469762049", 469762049, 20, 64),
                                 ("ntt_2^20_gf2013265921", 2013265921, 20, 64),  # galois.ntt's default modulus from 2^27 points (lazy-Shoup kernels)
                                 ("ntt_16x2^16_gf65537", 65537, 16, 16 * 64),
+                                ("ntt_2^14_gf65537", 65537, 14, 4096),  # r06: four transforms per workgroup of the one-pass kernel
                                 ("ntt_2^16_gf7340033", 7340033, 16, 1024), ("ntt_2^14_gf7340033", 7340033, 14, 4096)):
         P = ga.GF(p)
         N = 1 << logn
@@ -596,7 +597,7 @@ def extras(ga, L, lib, stream, with_cpu):
                 entry["physical_bytes_per_point"] = 17.0
                 entry["physical_frac"] = round(17.0 * points / (ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             entry["ceiling_frac_static"] = 0.333
-        elif p == 65537:
+        elif p == 65537 and logn == 16:
             entry["ceiling_frac_static"] = 0.73
             # the same kernel on a batch far larger than the 256 MiB Infinity Cache (4096 transforms: 1 GiB in, 1 GiB out)
             big = 4096

@@ -1725,7 +1725,7 @@ int run_typed(gfa_field *f, const FieldDev &fd, Plan *pl, const void *in, void *
         while (((i64)1 << lg) < n) lg++;
         if constexpr (std::is_same<F, Prime32>::value) {
             // GF(65537), 2^16 points: whole transform in one workgroup's registers, shift twiddles (gfa_ntt_fermat.hip)
-            if (ntt_fermat16_eligible(fd, n, batch) && (!do_scale || scale == fd.p - 1) && !g_layout_in.chunk_len && !g_layout_out.chunk_len) {
+            if (ntt_fermat16_eligible(fd, n, batch) && (!do_scale || scale == fd.p - (u64)(65536 / n)) && !g_layout_in.chunk_len && !g_layout_out.chunk_len) { // 1 / n = -2^16 / n: 2^16 = -1
                 rc = ntt_fermat16(ein, eout, batch, omega, do_scale ? 1 : 0, st);
                 if (rc && rc != GFA_ERR_UNSUPPORTED) return rc;
                 done = rc == GFA_OK;

@@ -68,7 +68,8 @@ constexpr int brev_c(int x, int bits)
 __device__ __forceinline__ int fm_mul_tw(int x, int w) { return fm_fold(fm_mulc(fm_bfold(x), w)); }
 
 constexpr int E2_PITCH = 33;                  // exchange 2: r' runs fastest, k0 pitch 33 words (conflict-free both ways)
-constexpr int EX_WORDS = 16 * 64 * E2_PITCH;  // 33792 words >= exchange 1's 32 * 1024
+constexpr int e2_kpitch(int r0) { return 64 * E2_PITCH + r0; } // ... and k1 pitch 64 * 33 + R0: a reading wave's lanes (k0, k1 low bits) fall into distinct banks
+constexpr int EX_WORDS = 16 * e2_kpitch(64);  // 34816 words >= exchange 1's 32 * 1024
 constexpr int FERMAT_LDS_BYTES = (EX_WORDS + 1024) * 4;
 
 struct FermatArgs {
@@ -76,8 +77,9 @@ struct FermatArgs {
     u32 *out;
     const int *tw1; // [2][1024]: balanced w^m and w^(8 m), the seeds of the first twiddles
     const int *tw2; // [32][32]:   balanced w^(64 * r * k1), index k1 * 32 + r
-    int u, uinv;    // w^(N/64) == sqrt(2)^u, uinv = u^-1 mod 64
-    int batch;
+    int u, uinv;    // w^(N/64) == sqrt(2)^u, uinv = u^-1 mod 64 (grouped kernels: w^(n/32) == 2^u, uinv = u^-1 mod 32)
+    int batch;      // blocks of 2^16 words: transforms (LOGG = 0) or groups of 2^LOGG transforms
+    long long words; // batch_of_transforms * n: the descriptors of the last block end there (its missing transforms read 0, store nothing)
     int stagger;    // first-round start offset between the four workgroup groups, in units of 4096 clocks (0: none)
     unsigned long long *dbg; // optional phase timestamps (100 MHz), 8 per (workgroup, round); nullptr in production
 };
@@ -133,9 +135,28 @@ constexpr int AUX_ST = GFA_FERMAT_AUX_ST; // ... and on the stores
         if (a.dbg != nullptr) asm volatile("s_nop 0");       \
     } while (0)
 
-template <bool NEGATE, bool DBG>
+// first network by radix (the generated canonical-root networks, inputs from memory)
+template <int LOGR> struct FermatNet0;
+template <> struct FermatNet0<6> { static __device__ __forceinline__ void run(int (&v)[64]) { fermat_net64_canon(v); } };
+template <> struct FermatNet0<5> { static __device__ __forceinline__ void run(int (&v)[32]) { fermat_net32_canon(v); } };
+template <> struct FermatNet0<4> { static __device__ __forceinline__ void run(int (&v)[16]) { fermat_net16_canon(v); } };
+template <> struct FermatNet0<3> { static __device__ __forceinline__ void run(int (&v)[8]) { fermat_net8_canon(v); } };
+template <> struct FermatNet0<2> { static __device__ __forceinline__ void run(int (&v)[4]) { fermat_net4_canon(v); } };
+
+// LOGG > 0 (r06): the same workgroup transforms G = 2^LOGG consecutive transforms of n = 2^16 / G points -- one 2^16-word block of the
+// batch.  Only the first network changes: G radix-(64 / G) networks over the rows of each transform instead of one radix-64 network
+// (row a of transform t is row t * R0 + a of the block, so every address stays what it was); the combined index c = t * R0 + k0 then
+// plays the part k0 plays at G = 1 through both exchanges and the two radix-32 networks (the 1024-point sub-transform over m, root
+// w^R0).  Output X_t[k0 + R0 (k1 + 32 k2)] is word t * n + k0 + R0 (k1 + 32 k2) of the block: lane l = (t, k0) writes runs of R0
+// words.  First twiddles w^(m k0), k0 < R0: one progression per half of the transforms, each value applied to G / 2 points.
+// 1 / n = -2^LOGG (2^16 = -1): the scaled inverse folds once more and shifts.
+template <bool NEGATE, bool DBG, int LOGG>
 __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
 {
+    constexpr int LOGR0 = 6 - LOGG, R0 = 1 << LOGR0, G = 1 << LOGG;
+    constexpr int E2 = LOGG == 1 ? (GFA_FERMAT_E2 < 38 ? GFA_FERMAT_E2 : 38) : GFA_FERMAT_E2; // (two radix-32 first networks: 40 rows ahead spill 8 bytes)
+    // position of the combined output c = t * R0 + k0 in the point registers (each network leaves its outputs bit-reversed)
+    auto pos = [](int c) constexpr { return (c >> LOGR0) * R0 + brev_c(c & (R0 - 1), LOGR0); };
     extern __shared__ int lds[];
     int *ex = lds;
     int *tw2l = lds + EX_WORDS;
@@ -147,10 +168,16 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
     const int wpos2 = ((a.u * r) & 31);                   // exchange 2 write slot r' = u * r mod 32
     int *const e1w = ex + wpos1;
     const int *const e1r = ex + g * 1024 + r;
+    // exchange 2, [k1 (16 per round)][c (64)][r']: the reader of round h is (lane l = (k1 low LOGG bits, k0), wave wv = (k1 high bits, t)):
+    // row k1 = (l >> LOGR0) + G * (wv >> LOGG) + 16 h of the combined column c = (wv mod G) * R0 + (l mod R0), so that a wave's 64 lanes
+    // own 64 CONSECUTIVE output words k0 + R0 * k1_low of one transform (256-byte stores whatever G)
+    constexpr int KP = e2_kpitch(R0);
     int *const e2w = ex + g * E2_PITCH + wpos2;
-    const int *const e2r = ex + wv * (64 * E2_PITCH) + l * E2_PITCH;
+    const int *const e2r = ex + ((l >> LOGR0) + G * (wv >> LOGG)) * KP + (((wv & (G - 1)) << LOGR0) + (l & (R0 - 1))) * E2_PITCH;
     tw2l[tid] = a.tw2[tid];
-    const int seed1 = a.tw1[tid], seed8 = a.tw1[1024 + tid]; // w^m, w^(8 m): the whole kernel
+    const int seed1 = a.tw1[tid], seed8 = LOGG == 0 ? a.tw1[1024 + tid] : 0; // w^m, w^(8 m): the whole kernel
+    // stores: X_t[k0 + R0 (k1 + 32 k2)] = word t * n + l + 64 * (wv >> LOGG) of the block, + (1024 / G) h + 32 R0 k2 as the scalar offset
+    const int soff = (int)((((wv & (G - 1)) << (16 - LOGG)) + l + 64 * (wv >> LOGG)) * 4);
     // Workgroups are persistent (one per CU) and all run the same program, so without help every CU would read, compute
     // and write at the same moments and HBM would idle while the chip computes.  The first round is staggered in four
     // groups (each XCD holds all four): group j starts j * stagger later, and the offset persists from round to round.
@@ -161,17 +188,23 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
     // every global access is `buffer_* v, v_off, s[rsrc], s_off offen`: lane offset tid*4 in one VGPR, row offset in an
     // SGPR, descriptors from kernel arguments and the (wave-uniform) transform index -- no vector address arithmetic.
     // `live` = false gives a descriptor of zero records: its loads return 0 and move nothing (the last round's look-ahead)
-    auto in_rsrc = [&](unsigned t, bool live) {
-        return __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (size_t)t * 65536u), 0, live ? 65536 * 4 : 0, 0x00020000);
+    auto block_bytes = [&](unsigned t) { // a whole block, or what is left of the batch in the last one
+        const long long left = a.words - (long long)t * 65536;
+        return (int)((left < 65536 ? left : 65536) * 4);
     };
+    auto in_rsrc = [&](unsigned t, bool live) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (size_t)t * 65536u), 0, live ? block_bytes(t) : 0, 0x00020000);
+    };
+    // row of the block behind network position ap = t * R0 + a': a = uinv * a' mod R0 (the permutation that makes the canonical network compute this root's)
+    auto row_off = [&](unsigned uinv_, int ap) { return (int)((((uinv_ * (unsigned)(ap & (R0 - 1))) & (unsigned)(R0 - 1)) + (unsigned)(ap & ~(R0 - 1))) << 12); };
     int v[64];
     {
         const __amdgpu_buffer_rsrc_t xr = in_rsrc(blockIdx.x, true);
 #pragma unroll
-        for (int ap = 0; ap < 64; ap++) v[ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xr, voff, (int)((((unsigned)a.uinv * ap) & 63u) << 12), AUX_NT);
+        for (int ap = 0; ap < 64; ap++) v[ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xr, voff, row_off((unsigned)a.uinv, ap), AUX_NT);
     }
     for (unsigned tr_i = blockIdx.x; tr_i < (unsigned)a.batch; tr_i += gridDim.x) {
-        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (size_t)tr_i * 65536u), 0, 65536 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void *)(a.out + (size_t)tr_i * 65536u), 0, block_bytes(tr_i), 0x00020000);
         const unsigned tr_next = tr_i + gridDim.x;
         const bool has_next = tr_next < (unsigned)a.batch;
         const __amdgpu_buffer_rsrc_t xn = in_rsrc(has_next ? tr_next : tr_i, has_next);
@@ -180,20 +213,35 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
         unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // phase timestamps: scalar registers, written out once at the end
         auto request = [&](int lo, int hi) { // rows lo .. hi-1 of the next transform, into the point registers it will start from
 #pragma unroll
-            for (int ap = lo; ap < hi; ap++) v[ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xn, voff, (int)(((uinv * ap) & 63u) << 12), AUX_NT);
+            for (int ap = lo; ap < hi; ap++) v[ap] = (int)__builtin_amdgcn_raw_buffer_load_b32(xn, voff, row_off(uinv, ap), AUX_NT);
         };
         FM_PHASE(0);
         // ---- network 0: radix 64 over a (stride 1024); thread m = tid.  Twiddles w^(m * k0), k0 = 1..63: gfa_fermat_tw.h ----
-        fermat_net64_canon(v);
-        FM_PHASE(1);
-        v[0] = fm_fold(v[0]);
-        int twa[8], twb[8];
-        fm_tw_progressions(seed1, seed8, twa, twb);
-        auto tw1_range = [&](int lo, int hi) {
 #pragma unroll
-            for (int k0 = lo; k0 < hi; k0++) {
-                int &q = v[brev_c(k0, 6)];
-                q = fm_tw_apply(q, fm_tw_of(twa, twb, k0));
+        for (int t = 0; t < G; t++) FermatNet0<LOGR0>::run(reinterpret_cast<int (&)[R0]>(v[t * R0]));
+        FM_PHASE(1);
+#pragma unroll
+        for (int t = 0; t < G; t++) v[t * R0] = fm_fold(v[t * R0]);
+        int twa[8], twb[8];
+        if (LOGG == 0) fm_tw_progressions(seed1, seed8, twa, twb);
+        auto tw1_range = [&](int lo, int hi) { // combined outputs lo .. hi-1 (halves: 1..31 / 32..63 at G = 1, transforms t < G / 2 / the rest above)
+            if (LOGG == 0) {
+#pragma unroll
+                for (int k0 = lo; k0 < hi; k0++) {
+                    int &q = v[brev_c(k0, 6)];
+                    q = fm_tw_apply(q, fm_tw_of(twa, twb, k0));
+                }
+            } else {
+                int T = seed1; // w^(m k0), k0 = 1, 2, ...: tight products by the seed (|T| <= 32770)
+#pragma unroll
+                for (int k0 = 1; k0 < R0; k0++) {
+#pragma unroll
+                    for (int t = lo >> LOGR0; t < (hi + R0 - 1) >> LOGR0; t++) {
+                        int &q = v[t * R0 + brev_c(k0, LOGR0)];
+                        q = fm_tw_apply(q, T);
+                    }
+                    if (k0 + 1 < R0) T = fm_tw_tight(T, seed1);
+                }
             }
         };
         tw1_range(1, 32);
@@ -203,14 +251,14 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
         int w[2][32];
         lds_barrier(); // the previous transform's exchange-2 reads (first round: the staging of tw2l) are complete
 #pragma unroll
-        for (int kl = 0; kl < 32; kl++) e1w[kl * 1024] = v[brev_c(kl, 6)];
+        for (int kl = 0; kl < 32; kl++) e1w[kl * 1024] = v[pos(kl)];
         tw1_range(32, 64);
         lds_barrier();
 #pragma unroll
         for (int bp = 0; bp < 32; bp++) w[0][bp] = e1r[bp * 32];
         lds_barrier();
 #pragma unroll
-        for (int kl = 0; kl < 32; kl++) e1w[kl * 1024] = v[brev_c(kl + 32, 6)];
+        for (int kl = 0; kl < 32; kl++) e1w[kl * 1024] = v[pos(kl + 32)];
         FM_PHASE(3);
         request(0, GFA_FERMAT_E1);
         auto net1 = [&](int h) {
@@ -227,7 +275,7 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
 #pragma unroll
         for (int bp = 0; bp < 32; bp++) w[1][bp] = e1r[bp * 32];
         FM_SPLIT();
-        request(GFA_FERMAT_E1, GFA_FERMAT_E2);
+        request(GFA_FERMAT_E1, E2);
         net1(1);
         FM_PHASE(4);
         // ---- exchange 2 + network 2: thread (lane l = k0, wave wv) takes k1 = wv and wv + 16, radix 32 over r ----
@@ -236,7 +284,7 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int kl = 0; kl < 16; kl++) e2w[kl * (64 * E2_PITCH) + 32 * i * E2_PITCH] = w[i][brev_c(kl, 5)];
+            for (int kl = 0; kl < 16; kl++) e2w[kl * KP + 32 * i * E2_PITCH] = w[i][brev_c(kl, 5)];
         lds_barrier();
 #pragma unroll
         for (int rp = 0; rp < 32; rp++) z[0][rp] = e2r[rp];
@@ -244,14 +292,16 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int kl = 0; kl < 16; kl++) e2w[kl * (64 * E2_PITCH) + 32 * i * E2_PITCH] = w[i][brev_c(kl + 16, 5)];
+            for (int kl = 0; kl < 16; kl++) e2w[kl * KP + 32 * i * E2_PITCH] = w[i][brev_c(kl + 16, 5)];
         FM_PHASE(5);
         auto net2 = [&](int h) {
             fermat_net32_fold(z[h]);
-            // X[k0 + 64 * (k1 + 32 * k2)], k1 = wv + 16 h: lane offset tid
 #pragma unroll
-            for (int k2 = 0; k2 < 32; k2++)
-                __builtin_amdgcn_raw_buffer_store_b32(fm_canon<NEGATE>(z[h][brev_c(k2, 5)]), yr, voff, (2048 * k2 + 1024 * h) * 4, AUX_ST);
+            for (int k2 = 0; k2 < 32; k2++) {
+                int c = z[h][brev_c(k2, 5)];
+                if (NEGATE && LOGG > 0) c = fm_shl(fm_fold(c), LOGG); // 1 / n = -2^LOGG
+                __builtin_amdgcn_raw_buffer_store_b32(fm_canon<NEGATE>(c), yr, soff, (32 * R0 * k2 + (1024 >> LOGG) * h) * 4, AUX_ST);
+            }
         };
         net2(0);
         FM_PHASE(6);
@@ -260,7 +310,7 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
         for (int rp = 0; rp < 32; rp++) z[1][rp] = e2r[rp];
         FM_SPLIT();
         net2(1);
-        request(GFA_FERMAT_E2, 64);
+        request(E2, 64);
         FM_PHASE(7);
         if (DBG && tid == 0) {
             unsigned long long *d = a.dbg + ((size_t)(tr_i / gridDim.x) * gridDim.x + blockIdx.x) * 8;
@@ -274,7 +324,7 @@ unsigned long long *g_fermat_dbg = nullptr;
 
 struct FermatPlan {
     int *tw1 = nullptr, *tw2 = nullptr;
-    int u = 0, uinv = 0, cus = 256;
+    int u = 0, uinv = 0, cus = 256, logg = 0; // logg: 2^logg transforms of 2^(16 - logg) points per workgroup
     bool ok = false;
 };
 std::mutex g_mu;
@@ -287,13 +337,18 @@ inline int balanced(u32 c) { return c > 32768u ? (int)c - 65537 : (int)c; }
 
 namespace gfa {
 
+// GFA_FERMAT_MIN_LOGN: the shortest transform the grouped kernel takes (2^12: sixteen per workgroup, radix-4 first networks)
+#ifndef GFA_FERMAT_MIN_LOGN
+#define GFA_FERMAT_MIN_LOGN 12
+#endif
 bool ntt_fermat16_eligible(const FieldDev &fd, i64 n, i64 batch)
 {
-    return fd.kind == KIND_PRIME32 && fd.p == 65537 && n == 65536 && batch >= 64; // one persistent workgroup per CU: fewer leave the chip idle
+    if (fd.kind != KIND_PRIME32 || fd.p != 65537 || n > 65536 || n < ((i64)1 << GFA_FERMAT_MIN_LOGN) || (n & (n - 1))) return false;
+    return batch * n >= (i64)64 * 65536; // one persistent workgroup per CU and block of 2^16 words: fewer leave the chip idle
 }
 
-// in / out: uint32, batch transforms of 2^16 points.  Returns GFA_ERR_UNSUPPORTED (nothing launched) when omega is not a
-// primitive 2^16-th root of unity.
+// in / out: uint32, batch transforms of n = 2^13 .. 2^16 points (n = the order of omega).  negate: the scaled inverse (1 / n = -2^(16 - log n)).
+// Returns GFA_ERR_UNSUPPORTED (nothing launched) when omega is not a primitive root of unity of such an order.
 int ntt_fermat16(const void *in, void *out, i64 batch, u64 omega, int negate, hipStream_t st)
 {
     int dev = 0;
@@ -303,51 +358,91 @@ int ntt_fermat16(const void *in, void *out, i64 batch, u64 omega, int negate, hi
         std::lock_guard<std::mutex> lock(g_mu);
         FermatPlan &p = g_plans[std::make_pair(dev, omega)];
         if (!p.tw1 && !p.ok) {
-            // w must have order exactly 2^16: w^(2^15) == -1
-            u32 t = (u32)omega;
-            for (int i = 0; i < 15; i++) t = mulmod(t, t);
-            if (t != 65536u) return GFA_ERR_UNSUPPORTED;
-            u32 w64 = (u32)omega; // w^(N/64) = w^1024
-            for (int i = 0; i < 10; i++) w64 = mulmod(w64, w64);
-            u32 z = 4080u, zz = mulmod(z, z), cur = z; // sqrt(2)^u for odd u
+            // the order of w: w^(2^k) == -1  <=>  order 2^(k + 1)
+            int logn = 0;
+            {
+                u32 t = (u32)(omega % 65537u);
+                for (int k = 0; k < 16 && !logn; k++) {
+                    if (t == 65536u) logn = k + 1;
+                    t = mulmod(t, t);
+                }
+            }
+            if (logn < GFA_FERMAT_MIN_LOGN || logn > 16) return GFA_ERR_UNSUPPORTED;
+            const int logg = 16 - logn, r0 = 64 >> logg;
+            std::vector<u32> pw((size_t)1 << logn);
+            pw[0] = 1;
+            for (size_t e = 1; e < pw.size(); e++) pw[e] = mulmod(pw[e - 1], (u32)omega);
+            const u32 nmask = (u32)pw.size() - 1;
             int u = 0;
-            for (int c = 1; c < 64; c += 2) {
-                if (cur == w64) { u = c; break; }
-                cur = mulmod(cur, zz);
+            if (logg == 0) { // w^(n / 64) = sqrt(2)^u, u odd mod 64
+                const u32 w64 = pw[1024];
+                u32 z = 4080u, zz = mulmod(z, z), cur = z;
+                for (int c = 1; c < 64; c += 2) {
+                    if (cur == w64) { u = c; break; }
+                    cur = mulmod(cur, zz);
+                }
+            } else { // w^(n / 32) = 2^u, u odd mod 32
+                const u32 w32 = pw[pw.size() / 32];
+                u32 cur = 2;
+                for (int c = 1; c < 32; c += 2) {
+                    if (cur == w32) { u = c; break; }
+                    cur = mulmod(cur, 4);
+                }
             }
             if (!u) return GFA_ERR_UNSUPPORTED;
+            const int umod = logg == 0 ? 64 : 32;
             int uinv = 1;
-            while ((u * uinv) % 64 != 1) uinv += 2;
+            while ((u * uinv) % umod != 1) uinv += 2;
             std::vector<int> t1(2 * 1024), t2(32 * 32);
-            std::vector<u32> pw(65536);
-            pw[0] = 1;
-            for (int e = 1; e < 65536; e++) pw[e] = mulmod(pw[e - 1], (u32)omega);
-            for (int m = 0; m < 1024; m++) {
-                t1[m] = balanced(pw[m]);                      // w^m
-                t1[1024 + m] = balanced(pw[(8 * m) & 65535]); // w^(8 m)
+            for (u32 m = 0; m < 1024; m++) {
+                t1[m] = balanced(pw[m & nmask]);                  // w^m
+                t1[1024 + m] = balanced(pw[(8 * m) & nmask]);     // w^(8 m) (n = 2^16 only)
             }
-            for (int k1 = 0; k1 < 32; k1++)
-                for (int r = 0; r < 32; r++) t2[k1 * 32 + r] = balanced(pw[(64 * r * k1) & 65535]);
+            for (u32 k1 = 0; k1 < 32; k1++)
+                for (u32 r = 0; r < 32; r++) t2[k1 * 32 + r] = balanced(pw[((u32)r0 * r * k1) & nmask]); // the 1024-point sub-transform's root is w^R0
             GFA_HIP(hipMalloc((void **)&p.tw1, t1.size() * sizeof(int)));
             GFA_HIP(hipMalloc((void **)&p.tw2, t2.size() * sizeof(int)));
             GFA_HIP(hipMemcpy(p.tw1, t1.data(), t1.size() * sizeof(int), hipMemcpyHostToDevice));
             GFA_HIP(hipMemcpy(p.tw2, t2.data(), t2.size() * sizeof(int), hipMemcpyHostToDevice));
             hipDeviceProp_t prop;
             GFA_HIP(hipGetDeviceProperties(&prop, dev));
-            p.u = u; p.uinv = uinv; p.cus = prop.multiProcessorCount; p.ok = true;
-            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            p.u = u; p.uinv = uinv; p.cus = prop.multiProcessorCount; p.logg = logg; p.ok = true;
         }
         pl = p;
     }
     constexpr int stagger_env = 2; // first-round stagger of the four workgroup groups, in units of 4096 clocks (measured against 0 and 4)
-    const i64 grid = std::min<i64>(batch, pl.cus);
+    const i64 n = (i64)65536 >> pl.logg;
+    const i64 nblk = (batch * n + 65535) / 65536;
+    const i64 grid = std::min<i64>(nblk, pl.cus);
     // the stagger only pays when every group has later rounds to keep busy
-    FermatArgs a{(const u32 *)in, (u32 *)out, pl.tw1, pl.tw2, pl.u, pl.uinv, (int)batch, batch >= 2 * grid ? stagger_env : 0, g_fermat_dbg};
-    if (a.dbg && !negate) hipLaunchKernelGGL((ntt_fermat16_kernel<false, true>), dim3((unsigned)grid), dim3(1024), FERMAT_LDS_BYTES, st, a);
-    else if (negate) hipLaunchKernelGGL((ntt_fermat16_kernel<true, false>), dim3((unsigned)grid), dim3(1024), FERMAT_LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((ntt_fermat16_kernel<false, false>), dim3((unsigned)grid), dim3(1024), FERMAT_LDS_BYTES, st, a);
+    FermatArgs a{(const u32 *)in, (u32 *)out, pl.tw1, pl.tw2, pl.u, pl.uinv, (int)nblk, (long long)(batch * n), nblk >= 2 * grid ? stagger_env : 0, g_fermat_dbg};
+#define GFA_FERMAT_LAUNCH(NEG, DBGV, LG)                                                                                          \
+    do {                                                                                                                          \
+        static bool attr = false;                                                                                                 \
+        if (!attr) {                                                                                                              \
+            GFA_HIP(hipFuncSetAttribute((const void *)ntt_fermat16_kernel<NEG, DBGV, LG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr = true;                                                                                                          \
+        }                                                                                                                         \
+        hipLaunchKernelGGL((ntt_fermat16_kernel<NEG, DBGV, LG>), dim3((unsigned)grid), dim3(1024), FERMAT_LDS_BYTES, st, a);      \
+    } while (0)
+#define GFA_FERMAT_BY_NEG(LG)                      \
+    do {                                           \
+        if (negate) GFA_FERMAT_LAUNCH(true, false, LG);  \
+        else GFA_FERMAT_LAUNCH(false, false, LG);  \
+    } while (0)
+    switch (pl.logg) {
+    case 0:
+        if (a.dbg && !negate) GFA_FERMAT_LAUNCH(false, true, 0);
+        else GFA_FERMAT_BY_NEG(0);
+        break;
+    case 1: GFA_FERMAT_BY_NEG(1); break;
+    case 2: GFA_FERMAT_BY_NEG(2); break;
+    case 3: GFA_FERMAT_BY_NEG(3); break;
+    case 4: GFA_FERMAT_BY_NEG(4); break;
+    default: return GFA_ERR_UNSUPPORTED;
+    }
+#undef GFA_FERMAT_BY_NEG
+#undef GFA_FERMAT_LAUNCH
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }

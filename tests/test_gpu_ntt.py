@@ -397,6 +397,50 @@ def test_fermat_single_pass_kernel_gf65537():
     assert np.array_equal(fft_batched(X, inverse=True).numpy(), x)
 
 
+@pytest.mark.parametrize("logn", [12, 13, 14, 15])
+def test_fermat_grouped_kernel_gf65537_2e12_to_2e15(logn):
+    """r06: transforms of 2^12 .. 2^15 points over GF(65537) with at least 2^22 points in the batch run G = 2^16 / n to a workgroup on
+    the one-pass kernel (gfa_ntt_fermat.hip, LOGG > 0: G first networks of radix 64 / G, everything after them shared with the 2^16-point
+    form).  Worst-case rows and random ones, several roots (every odd power: the input-order permutation), batches that are NOT a
+    multiple of the group (the last block's missing transforms read zeros and store nothing -- the words after the batch must stay
+    untouched), forward against the oracle and the small-batch route, the scaled inverse (1 / n = -2^(16 - log n)) in place."""
+    import torch
+    from galois_amd import _lib as L
+
+    lib = L.lib()
+    p = 65537
+    GF = ga.GF(p)
+    F = O.OracleField(p, 1, None, 3)
+    n = 1 << logn
+    G = 65536 // n
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(logn)
+    w = GF._root_of_unity_int(n)
+    for batch, j in ((64 * G, 1), (64 * G + 1, 3), (65 * G + G - 1, n - 1), (130 * G + 3, 12345)):
+        wj = pow(w, j | 1, p)
+        x = rng.integers(0, p, (batch, n), dtype=np.uint32)
+        x[0] = 65536
+        x[1, ::2] = 65536; x[1, 1::2] = 0
+        x[batch - 1] = rng.choice(np.array([0, 1, 65535, 65536], dtype=np.uint32), n)
+        xt = torch.from_numpy(x.view(np.int32)).cuda()
+        buf = torch.full((batch * n + 4096,), -7, dtype=torch.int32, device="cuda")  # guard words behind the batch
+        out = buf[:batch * n].view(batch, n)
+        L.check(lib.gfa_ntt(GF._handle, xt.data_ptr(), out.data_ptr(), n, batch, wj, 0, L.U32, st))
+        assert bool((buf[batch * n:] == -7).all()), "stores behind the last transform"
+        got = out.cpu().numpy().view(np.uint32)
+        for i in {0, 1, G - 1, G, batch // 2, batch - 2, batch - 1}:
+            H.assert_equal_ints(got[i], F.ntt_u32_pow2(x[i], wj), f"2^{logn}, batch {batch}, row {i}")
+        ref = torch.empty_like(xt)  # every row against the route small batches take
+        step = max(1, (1 << 21) // n)
+        for b0 in range(0, batch, step):
+            b1 = min(batch, b0 + step)
+            L.check(lib.gfa_ntt(GF._handle, xt[b0:b1].data_ptr(), ref[b0:b1].data_ptr(), n, b1 - b0, wj, 0, L.U32, st))
+        assert torch.equal(out, ref), f"2^{logn}, batch {batch}"
+        L.check(lib.gfa_ntt(GF._handle, out.data_ptr(), out.data_ptr(), n, batch, pow(wj, p - 2, p), 1, L.U32, st))
+        assert torch.equal(out, xt), f"scaled inverse, 2^{logn}, batch {batch}"
+        assert bool((buf[batch * n:] == -7).all())
+
+
 def _emulate_forward(GF, xs_dev_cols, n1, n2, G, omega):
     """G ranks' work of galois_amd.dist.ntt_four_step_distributed on one GPU (the all-to-all is a re-slicing)."""
     from galois_amd import dist as gdist

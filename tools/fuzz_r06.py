@@ -9,6 +9,8 @@ ufunc cases); a case then costs a few kernel launches and one small oracle call:
              power of the field's), random batch, rows at the magnitude limit; forward against the oracle on three rows, batched
              against single, scaled inverse as a round trip.  The pool covers every kernel family: GF(65537) (shift twiddles),
              p < 2^26 / 2^28 / 2^29 (signed Montgomery, the three BMAX classes), [2^29, 2^32) (lazy Shoup);
+  * ntt_grouped  GF(65537), 2^12 .. 2^15 points in batches of at least 2^22 points (G = 2^16 / n transforms per workgroup of the
+             one-pass kernel), batch sizes that are not multiples of G;
   * ntt16    the one-workgroup 2^16-point kernels (r06: GF(65537) with the first twiddles formed in registers and the early
              requests; generic p < 2^29 with the early requests): batches of 64 .. 300 transforms, forward and scaled inverse;
   * convolve random lengths 1500 .. 6000 (the CRT route) over pool primes, five coefficients against Python integers;
@@ -28,7 +30,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 rng = np.random.default_rng(seed)
 lib = L.lib()
 st = torch.cuda.current_stream().cuda_stream
-counts = {"ntt": 0, "ntt_large": 0, "ntt16": 0, "convolve": 0, "where": 0, "wide": 0}
+counts = {"ntt": 0, "ntt_large": 0, "ntt16": 0, "ntt_grouped": 0, "convolve": 0, "where": 0, "wide": 0}
 
 
 def find_prime(bits, adic):
@@ -95,9 +97,13 @@ while time.time() < t_end:
         logn = int(rng.integers(2, min(entry[3], 12) + 1))
         run_ntt(entry, logn, int(rng.choice([1, 2, 3, 5, 64, 70])) if logn <= 10 else int(rng.choice([1, 2, 5])))
         counts["ntt"] += 1
-    elif u < 0.62:
+    elif u < 0.60:
         run_ntt(P16[int(rng.integers(0, len(P16)))], 16, int(rng.integers(64, 300)))
         counts["ntt16"] += 1
+    elif u < 0.62:  # GF(65537), 2^12 .. 2^15 points, at least 2^22 in the batch: G = 2^16 / n transforms per workgroup (r06)
+        logn = int(rng.integers(12, 16))
+        run_ntt(POOL[0], logn, int(rng.integers(64, 130)) * (65536 >> logn) + int(rng.integers(0, 65536 >> logn)))
+        counts["ntt_grouped"] += 1
     elif u < 0.72:
         p, GF, F, adic = POOL[int(rng.integers(0, len(POOL)))]
         na, nb = int(rng.integers(1500, 6000)), int(rng.integers(1500, 6000))

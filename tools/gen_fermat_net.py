@@ -249,6 +249,10 @@ NETS = [
     ("fermat_net16_fold", 16, FOLD1, 1 << 29),
     ("fermat_net16_canon", 16, (0, 65536), 1 << 29),
     ("fermat_net64_fold", 64, FOLD1, 1 << 29),
+    # first networks of the grouped kernel (r06: G = 64 / R transforms of 2^16 / G points per workgroup)
+    ("fermat_net8_canon", 8, (0, 65536), 1 << 29),
+    ("fermat_net4_canon", 4, (0, 65536), 1 << 29),
+    ("fermat_net2_canon", 2, (0, 65536), 1 << 29),
 ]
 
 
