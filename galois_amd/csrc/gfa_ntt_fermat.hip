@@ -142,6 +142,7 @@ template <> struct FermatNet0<5> { static __device__ __forceinline__ void run(in
 template <> struct FermatNet0<4> { static __device__ __forceinline__ void run(int (&v)[16]) { fermat_net16_canon(v); } };
 template <> struct FermatNet0<3> { static __device__ __forceinline__ void run(int (&v)[8]) { fermat_net8_canon(v); } };
 template <> struct FermatNet0<2> { static __device__ __forceinline__ void run(int (&v)[4]) { fermat_net4_canon(v); } };
+template <> struct FermatNet0<1> { static __device__ __forceinline__ void run(int (&v)[2]) { fermat_net2_canon(v); } };
 
 // LOGG > 0 (r06): the same workgroup transforms G = 2^LOGG consecutive transforms of n = 2^16 / G points -- one 2^16-word block of the
 // batch.  Only the first network changes: G radix-(64 / G) networks over the rows of each transform instead of one radix-64 network
@@ -154,7 +155,9 @@ template <bool NEGATE, bool DBG, int LOGG>
 __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
 {
     constexpr int LOGR0 = 6 - LOGG, R0 = 1 << LOGR0, G = 1 << LOGG;
-    constexpr int E2 = LOGG == 1 ? (GFA_FERMAT_E2 < 38 ? GFA_FERMAT_E2 : 38) : GFA_FERMAT_E2; // (two radix-32 first networks: 40 rows ahead spill 8 bytes)
+    // rows of the next transform requested before network 1's second half: 40, less where that spills (LOGG 1: 8 bytes at 40; LOGG 5, whose second
+    // exchange keeps a whole first-network half alive: 20-68 bytes above 24)
+    constexpr int E2 = LOGG == 1 ? (GFA_FERMAT_E2 < 38 ? GFA_FERMAT_E2 : 38) : LOGG == 5 ? (GFA_FERMAT_E2 < 24 ? GFA_FERMAT_E2 : 24) : GFA_FERMAT_E2;
     // position of the combined output c = t * R0 + k0 in the point registers (each network leaves its outputs bit-reversed)
     auto pos = [](int c) constexpr { return (c >> LOGR0) * R0 + brev_c(c & (R0 - 1), LOGR0); };
     extern __shared__ int lds[];
@@ -171,9 +174,12 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
     // exchange 2, [k1 (16 per round)][c (64)][r']: the reader of round h is (lane l = (k1 low LOGG bits, k0), wave wv = (k1 high bits, t)):
     // row k1 = (l >> LOGR0) + G * (wv >> LOGG) + 16 h of the combined column c = (wv mod G) * R0 + (l mod R0), so that a wave's 64 lanes
     // own 64 CONSECUTIVE output words k0 + R0 * k1_low of one transform (256-byte stores whatever G)
-    constexpr int KP = e2_kpitch(R0);
+    // G = 32 (2^11 points): a wave's 64 output words are k0 + 2 k1 for ALL k1 of one transform t = wv + 16 h, so the rounds go by transform
+    // half instead: round h holds [k1 (32)][c - 32 h (32)][r'] of the first-network half h, k1 pitch 32 * 33 + 2
+    constexpr int KP = e2_kpitch(R0), KP5 = 32 * E2_PITCH + 2;
     int *const e2w = ex + g * E2_PITCH + wpos2;
-    const int *const e2r = ex + ((l >> LOGR0) + G * (wv >> LOGG)) * KP + (((wv & (G - 1)) << LOGR0) + (l & (R0 - 1))) * E2_PITCH;
+    const int *const e2r = LOGG < 5 ? ex + ((l >> LOGR0) + G * (wv >> LOGG)) * KP + (((wv & (G - 1)) << LOGR0) + (l & (R0 - 1))) * E2_PITCH
+                                    : ex + (l >> 1) * KP5 + (2 * wv + (l & 1)) * E2_PITCH;
     tw2l[tid] = a.tw2[tid];
     const int seed1 = a.tw1[tid], seed8 = LOGG == 0 ? a.tw1[1024 + tid] : 0; // w^m, w^(8 m): the whole kernel
     // stores: X_t[k0 + R0 (k1 + 32 k2)] = word t * n + l + 64 * (wv >> LOGG) of the block, + (1024 / G) h + 32 R0 k2 as the scalar offset
@@ -278,21 +284,31 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
         request(GFA_FERMAT_E1, E2);
         net1(1);
         FM_PHASE(4);
-        // ---- exchange 2 + network 2: thread (lane l = k0, wave wv) takes k1 = wv and wv + 16, radix 32 over r ----
+        // ---- exchange 2 + network 2: the reader (lane l, wave wv) of round h: see e2r; radix 32 over r ----
         int z[2][32];
         lds_barrier();
+        if constexpr (LOGG < 5) { // rounds by k1 half: both first-network halves' k1 = 16 h .. 16 h + 15
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+            for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int kl = 0; kl < 16; kl++) e2w[kl * KP + 32 * i * E2_PITCH] = w[i][brev_c(kl, 5)];
+                for (int kl = 0; kl < 16; kl++) e2w[kl * KP + 32 * i * E2_PITCH] = w[i][brev_c(kl, 5)];
+        } else { // G = 32: rounds by TRANSFORM half (a reader's 64 lanes are all 32 k1 of one transform): w[h], every k1
+#pragma unroll
+            for (int k1 = 0; k1 < 32; k1++) e2w[k1 * KP5] = w[0][brev_c(k1, 5)];
+        }
         lds_barrier();
 #pragma unroll
         for (int rp = 0; rp < 32; rp++) z[0][rp] = e2r[rp];
         lds_barrier();
+        if constexpr (LOGG < 5) {
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+            for (int i = 0; i < 2; i++)
 #pragma unroll
-            for (int kl = 0; kl < 16; kl++) e2w[kl * KP + 32 * i * E2_PITCH] = w[i][brev_c(kl + 16, 5)];
+                for (int kl = 0; kl < 16; kl++) e2w[kl * KP + 32 * i * E2_PITCH] = w[i][brev_c(kl + 16, 5)];
+        } else {
+#pragma unroll
+            for (int k1 = 0; k1 < 32; k1++) e2w[k1 * KP5] = w[1][brev_c(k1, 5)];
+        }
         FM_PHASE(5);
         auto net2 = [&](int h) {
             fermat_net32_fold(z[h]);
@@ -300,7 +316,8 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
             for (int k2 = 0; k2 < 32; k2++) {
                 int c = z[h][brev_c(k2, 5)];
                 if (NEGATE && LOGG > 0) c = fm_shl(fm_fold(c), LOGG); // 1 / n = -2^LOGG
-                __builtin_amdgcn_raw_buffer_store_b32(fm_canon<NEGATE>(c), yr, soff, (32 * R0 * k2 + (1024 >> LOGG) * h) * 4, AUX_ST);
+                const int so = LOGG < 5 ? (32 * R0 * k2 + (1024 >> LOGG) * h) * 4 : (64 * k2 + 16 * 2048 * h) * 4;
+                __builtin_amdgcn_raw_buffer_store_b32(fm_canon<NEGATE>(c), yr, soff, so, AUX_ST);
             }
         };
         net2(0);
@@ -337,9 +354,9 @@ inline int balanced(u32 c) { return c > 32768u ? (int)c - 65537 : (int)c; }
 
 namespace gfa {
 
-// GFA_FERMAT_MIN_LOGN: the shortest transform the grouped kernel takes (2^12: sixteen per workgroup, radix-4 first networks)
+// GFA_FERMAT_MIN_LOGN: the shortest transform the grouped kernel takes (2^11: thirty-two per workgroup, radix-2 first networks)
 #ifndef GFA_FERMAT_MIN_LOGN
-#define GFA_FERMAT_MIN_LOGN 12
+#define GFA_FERMAT_MIN_LOGN 11
 #endif
 bool ntt_fermat16_eligible(const FieldDev &fd, i64 n, i64 batch)
 {
@@ -439,6 +456,7 @@ int ntt_fermat16(const void *in, void *out, i64 batch, u64 omega, int negate, hi
     case 2: GFA_FERMAT_BY_NEG(2); break;
     case 3: GFA_FERMAT_BY_NEG(3); break;
     case 4: GFA_FERMAT_BY_NEG(4); break;
+    case 5: GFA_FERMAT_BY_NEG(5); break;
     default: return GFA_ERR_UNSUPPORTED;
     }
 #undef GFA_FERMAT_BY_NEG
