@@ -143,6 +143,7 @@ template <> struct FermatNet0<4> { static __device__ __forceinline__ void run(in
 template <> struct FermatNet0<3> { static __device__ __forceinline__ void run(int (&v)[8]) { fermat_net8_canon(v); } };
 template <> struct FermatNet0<2> { static __device__ __forceinline__ void run(int (&v)[4]) { fermat_net4_canon(v); } };
 template <> struct FermatNet0<1> { static __device__ __forceinline__ void run(int (&v)[2]) { fermat_net2_canon(v); } };
+template <> struct FermatNet0<0> { static __device__ __forceinline__ void run(int (&)[1]) {} }; // 1024-point transforms: no first network
 
 // LOGG > 0 (r06): the same workgroup transforms G = 2^LOGG consecutive transforms of n = 2^16 / G points -- one 2^16-word block of the
 // batch.  Only the first network changes: G radix-(64 / G) networks over the rows of each transform instead of one radix-64 network
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
     constexpr int LOGR0 = 6 - LOGG, R0 = 1 << LOGR0, G = 1 << LOGG;
     // rows of the next transform requested before network 1's second half: 40, less where that spills (LOGG 1: 8 bytes at 40; LOGG 5, whose second
     // exchange keeps a whole first-network half alive: 20-68 bytes above 24)
-    constexpr int E2 = LOGG == 1 ? (GFA_FERMAT_E2 < 38 ? GFA_FERMAT_E2 : 38) : LOGG == 5 ? (GFA_FERMAT_E2 < 24 ? GFA_FERMAT_E2 : 24) : GFA_FERMAT_E2;
+    constexpr int E2 = LOGG == 1 ? (GFA_FERMAT_E2 < 38 ? GFA_FERMAT_E2 : 38) : LOGG >= 5 ? (GFA_FERMAT_E2 < 24 ? GFA_FERMAT_E2 : 24) : GFA_FERMAT_E2;
     // position of the combined output c = t * R0 + k0 in the point registers (each network leaves its outputs bit-reversed)
     auto pos = [](int c) constexpr { return (c >> LOGR0) * R0 + brev_c(c & (R0 - 1), LOGR0); };
     extern __shared__ int lds[];
@@ -176,14 +177,17 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
     // own 64 CONSECUTIVE output words k0 + R0 * k1_low of one transform (256-byte stores whatever G)
     // G = 32 (2^11 points): a wave's 64 output words are k0 + 2 k1 for ALL k1 of one transform t = wv + 16 h, so the rounds go by transform
     // half instead: round h holds [k1 (32)][c - 32 h (32)][r'] of the first-network half h, k1 pitch 32 * 33 + 2
-    constexpr int KP = e2_kpitch(R0), KP5 = 32 * E2_PITCH + 2;
+    // G = 64 (2^10 points): lanes = (one bit of t, all 32 k1), t = 32 h + 2 wv + (l >> 5): two runs of 32 words per wave store; k1 pitch 32 * 33 + 1
+    constexpr int KP = e2_kpitch(R0), KP5 = 32 * E2_PITCH + (LOGG == 6 ? 1 : 2);
     int *const e2w = ex + g * E2_PITCH + wpos2;
-    const int *const e2r = LOGG < 5 ? ex + ((l >> LOGR0) + G * (wv >> LOGG)) * KP + (((wv & (G - 1)) << LOGR0) + (l & (R0 - 1))) * E2_PITCH
-                                    : ex + (l >> 1) * KP5 + (2 * wv + (l & 1)) * E2_PITCH;
+    const int *const e2r = LOGG < 5    ? ex + ((l >> LOGR0) + G * (wv >> LOGG)) * KP + (((wv & (G - 1)) << LOGR0) + (l & (R0 - 1))) * E2_PITCH
+                           : LOGG == 5 ? ex + (l >> 1) * KP5 + (2 * wv + (l & 1)) * E2_PITCH
+                                       : ex + (l & 31) * KP5 + (2 * wv + (l >> 5)) * E2_PITCH;
     tw2l[tid] = a.tw2[tid];
     const int seed1 = a.tw1[tid], seed8 = LOGG == 0 ? a.tw1[1024 + tid] : 0; // w^m, w^(8 m): the whole kernel
     // stores: X_t[k0 + R0 (k1 + 32 k2)] = word t * n + l + 64 * (wv >> LOGG) of the block, + (1024 / G) h + 32 R0 k2 as the scalar offset
-    const int soff = (int)((((wv & (G - 1)) << (16 - LOGG)) + l + 64 * (wv >> LOGG)) * 4);
+    const int soff = LOGG < 6 ? (int)((((wv & (G - 1)) << (16 - LOGG)) + l + 64 * (wv >> LOGG)) * 4)
+                              : (int)(((2 * wv + (l >> 5)) * 1024 + (l & 31)) * 4);
     // Workgroups are persistent (one per CU) and all run the same program, so without help every CU would read, compute
     // and write at the same moments and HBM would idle while the chip computes.  The first round is staggered in four
     // groups (each XCD holds all four): group j starts j * stagger later, and the offset persists from round to round.
@@ -226,8 +230,10 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
 #pragma unroll
         for (int t = 0; t < G; t++) FermatNet0<LOGR0>::run(reinterpret_cast<int (&)[R0]>(v[t * R0]));
         FM_PHASE(1);
+        if (LOGG < 6) { // (2^10 points: the inputs themselves, canonical, feed network 1)
 #pragma unroll
-        for (int t = 0; t < G; t++) v[t * R0] = fm_fold(v[t * R0]);
+            for (int t = 0; t < G; t++) v[t * R0] = fm_fold(v[t * R0]);
+        }
         int twa[8], twb[8];
         if (LOGG == 0) fm_tw_progressions(seed1, seed8, twa, twb);
         auto tw1_range = [&](int lo, int hi) { // combined outputs lo .. hi-1 (halves: 1..31 / 32..63 at G = 1, transforms t < G / 2 / the rest above)
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(1024) void ntt_fermat16_kernel(FermatArgs a)
             for (int k2 = 0; k2 < 32; k2++) {
                 int c = z[h][brev_c(k2, 5)];
                 if (NEGATE && LOGG > 0) c = fm_shl(fm_fold(c), LOGG); // 1 / n = -2^LOGG
-                const int so = LOGG < 5 ? (32 * R0 * k2 + (1024 >> LOGG) * h) * 4 : (64 * k2 + 16 * 2048 * h) * 4;
+                const int so = LOGG < 5 ? (32 * R0 * k2 + (1024 >> LOGG) * h) * 4 : (32 * R0 * k2 + 32768 * h) * 4; // (G >= 32: h = transform half)
                 __builtin_amdgcn_raw_buffer_store_b32(fm_canon<NEGATE>(c), yr, soff, so, AUX_ST);
             }
         };
@@ -354,9 +360,9 @@ inline int balanced(u32 c) { return c > 32768u ? (int)c - 65537 : (int)c; }
 
 namespace gfa {
 
-// GFA_FERMAT_MIN_LOGN: the shortest transform the grouped kernel takes (2^11: thirty-two per workgroup, radix-2 first networks)
+// GFA_FERMAT_MIN_LOGN: the shortest transform the grouped kernel takes (2^10: sixty-four per workgroup, no first network)
 #ifndef GFA_FERMAT_MIN_LOGN
-#define GFA_FERMAT_MIN_LOGN 11
+#define GFA_FERMAT_MIN_LOGN 10
 #endif
 bool ntt_fermat16_eligible(const FieldDev &fd, i64 n, i64 batch)
 {
@@ -457,6 +463,7 @@ int ntt_fermat16(const void *in, void *out, i64 batch, u64 omega, int negate, hi
     case 3: GFA_FERMAT_BY_NEG(3); break;
     case 4: GFA_FERMAT_BY_NEG(4); break;
     case 5: GFA_FERMAT_BY_NEG(5); break;
+    case 6: GFA_FERMAT_BY_NEG(6); break;
     default: return GFA_ERR_UNSUPPORTED;
     }
 #undef GFA_FERMAT_BY_NEG

@@ -397,9 +397,9 @@ def test_fermat_single_pass_kernel_gf65537():
     assert np.array_equal(fft_batched(X, inverse=True).numpy(), x)
 
 
-@pytest.mark.parametrize("logn", [11, 12, 13, 14, 15])
-def test_fermat_grouped_kernel_gf65537_2e11_to_2e15(logn):
-    """r06: transforms of 2^11 .. 2^15 points over GF(65537) with at least 2^22 points in the batch run G = 2^16 / n to a workgroup on
+@pytest.mark.parametrize("logn", [10, 11, 12, 13, 14, 15])
+def test_fermat_grouped_kernel_gf65537_2e10_to_2e15(logn):
+    """r06: transforms of 2^10 .. 2^15 points over GF(65537) with at least 2^22 points in the batch run G = 2^16 / n to a workgroup on
     the one-pass kernel (gfa_ntt_fermat.hip, LOGG > 0: G first networks of radix 64 / G, everything after them shared with the 2^16-point
     form).  Worst-case rows and random ones, several roots (every odd power: the input-order permutation), batches that are NOT a
     multiple of the group (the last block's missing transforms read zeros and store nothing -- the words after the batch must stay

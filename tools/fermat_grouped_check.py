@@ -11,7 +11,7 @@ lib = L.lib(); st = torch.cuda.current_stream().cuda_stream
 p = 65537
 P = ga.GF(p); F = O.OracleField(p, 1, None, int(P.primitive_element))
 rng = np.random.default_rng(7)
-for logn in (11, 12, 13, 14, 15, 16):
+for logn in (10, 11, 12, 13, 14, 15, 16):
     n = 1 << logn; G = 65536 // n
     for batch in (64 * G, 64 * G + 1, 70 * G + G - 1, 300 * G + 3):
         w = pow(P._root_of_unity_int(n), int(rng.integers(0, n // 2)) * 2 + 1, p)
@@ -27,7 +27,7 @@ for logn in (11, 12, 13, 14, 15, 16):
         assert torch.equal(back, xt), ("inverse", logn, batch)
     print(f"2^{logn}: ok", flush=True)
 ms = ctypes.c_float()
-for logn, batch in ((11, 32768), (11, 131072), (12, 16384), (12, 65536), (13, 8192), (14, 4096), (15, 2048), (16, 1024), (13, 32768), (14, 16384), (15, 8192), (16, 4096)):
+for logn, batch in ((10, 65536), (10, 262144), (11, 32768), (11, 131072), (12, 16384), (12, 65536), (13, 8192), (14, 4096), (15, 2048), (16, 1024), (13, 32768), (14, 16384), (15, 8192), (16, 4096)):
     n = 1 << logn
     x = torch.from_numpy(rng.integers(0, p, (batch, n), dtype=np.uint32).view(np.int32)).cuda(); o = torch.empty_like(x)
     L.check(lib.gfa_time_ntt(P._handle, x.data_ptr(), o.data_ptr(), n, batch, P._root_of_unity_int(n), L.U32, st, 20, ctypes.byref(ms)))

@@ -9,7 +9,7 @@ ufunc cases); a case then costs a few kernel launches and one small oracle call:
              power of the field's), random batch, rows at the magnitude limit; forward against the oracle on three rows, batched
              against single, scaled inverse as a round trip.  The pool covers every kernel family: GF(65537) (shift twiddles),
              p < 2^26 / 2^28 / 2^29 (signed Montgomery, the three BMAX classes), [2^29, 2^32) (lazy Shoup);
-  * ntt_grouped  GF(65537), 2^11 .. 2^15 points in batches of at least 2^22 points (G = 2^16 / n transforms per workgroup of the
+  * ntt_grouped  GF(65537), 2^10 .. 2^15 points in batches of at least 2^22 points (G = 2^16 / n transforms per workgroup of the
              one-pass kernel), batch sizes that are not multiples of G;
   * ntt16    the one-workgroup 2^16-point kernels (r06: GF(65537) with the first twiddles formed in registers and the early
              requests; generic p < 2^29 with the early requests): batches of 64 .. 300 transforms, forward and scaled inverse;
@@ -100,8 +100,8 @@ while time.time() < t_end:
     elif u < 0.60:
         run_ntt(P16[int(rng.integers(0, len(P16)))], 16, int(rng.integers(64, 300)))
         counts["ntt16"] += 1
-    elif u < 0.62:  # GF(65537), 2^11 .. 2^15 points, at least 2^22 in the batch: G = 2^16 / n transforms per workgroup (r06)
-        logn = int(rng.integers(11, 16))
+    elif u < 0.62:  # GF(65537), 2^10 .. 2^15 points, at least 2^22 in the batch: G = 2^16 / n transforms per workgroup (r06)
+        logn = int(rng.integers(10, 16))
         run_ntt(POOL[0], logn, int(rng.integers(64, 130)) * (65536 >> logn) + int(rng.integers(0, 65536 >> logn)))
         counts["ntt_grouped"] += 1
     elif u < 0.72:
