@@ -1517,6 +1517,20 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
         rc = packed_mul_run(f->calc, dtype, a, sa, b, sb, out, n, st);
         if (rc != GFA_ERR_UNSUPPORTED) return rc;
     }
+    // r06, AUTO only: GF(p^m), p odd, 32768 < q <= 65536 (GF(181^2) .. GF(251^2), GF(37^3)): LOG / EXP no longer fit LDS together, the staged
+    // kernels below run products and quotients at 0.40 (uint16) / 0.27 (uint32); the digit tables of gfa_packed.h stream
+    // (measured, profiles/r06_ew_band16.txt: uint32 arrays -- products 0.27 -> 0.68, GF(p^2) quotients 0.27 -> 0.54; uint16 arrays -- GF(p^2)
+    // products 0.40 -> 0.54, but cubic products 0.37 and quotients by the norm 0.27 LOSE to the staged tables' 0.40: those stay there)
+    if (f->mode == GFA_MODE_AUTO && f->calc.kind == KIND_EXT && (f->calc.p & 1) && f->calc.q > 32768 && f->calc.q <= 65536) {
+        if (op == GFA_OP_MUL && (dtype == GFA_U32 || f->calc.m == 2) && packed_mul_eligible(f->calc, dtype, n, false)) {
+            rc = packed_mul_run(f->calc, dtype, a, sa, b, sb, out, n, st);
+            if (rc != GFA_ERR_UNSUPPORTED) return rc;
+        }
+        if (op == GFA_OP_DIV && dtype == GFA_U32 && packed_div2_eligible(f->calc, dtype, n)) {
+            rc = packed_div2_run(f->calc, dtype, a, sa, b, sb, out, n, st, dev_err);
+            if (rc != GFA_ERR_UNSUPPORTED) return rc;
+        }
+    }
     if (f->mode != GFA_MODE_CALCULATE) {
         // uint16 storage, tables in LDS (gfa_elementwise_mid.hip), unless the field was pinned to explicit calculation:
         //  * 256 < q <= 32768 (LOG and EXP both resident): every operation that is not a plain xor / modular add (measured 0.7-0.8
@@ -1573,7 +1587,7 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
         }
         // r06: degree-2 quotients by the norm (conjugate / N(b), 1 / N from a p-entry LDS table): 0.15 -> see profiles/r06_ew_div2.txt
         if (op == GFA_OP_DIV && packed_div2_eligible(f->calc, dtype, n)) {
-            rc = packed_div2_run(f->calc, a, sa, b, sb, out, n, st, dev_err);
+            rc = packed_div2_run(f->calc, dtype, a, sa, b, sb, out, n, st, dev_err);
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
         return dispatch_binary(f->calc, dtype, op, a, sa, b, sb, out, n, st, dev_err);
@@ -1607,6 +1621,11 @@ int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int d
         rc = packed_run(f->calc, dtype, GFA_OP_NEG, a, 1, nullptr, 0, out, n, st);
         if (rc != GFA_ERR_UNSUPPORTED) return rc;
     }
+    if (f->mode == GFA_MODE_AUTO && op == GFA_OP_RECIP && f->calc.kind == KIND_EXT && f->calc.q > 32768 && f->calc.q <= 65536 && dtype == GFA_U32 &&
+        packed_div2_eligible(f->calc, dtype, n)) { // r06: GF(p^2), 181 <= p <= 251: by the norm, as in gfa_binary
+        rc = packed_div2_run(f->calc, dtype, nullptr, 0, a, 1, out, n, st, dev_err);
+        if (rc != GFA_ERR_UNSUPPORTED) return rc;
+    }
     if (f->mode != GFA_MODE_CALCULATE) { // tables in LDS, as in gfa_binary
         const FieldDev &c = f->calc;
         const bool trivial_neg = op == GFA_OP_NEG && (c.p == 2 || c.m == 1);
@@ -1636,7 +1655,7 @@ int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int d
     if (f->mode == GFA_MODE_AUTO && op == GFA_OP_RECIP && f->calc.m == 2 && (f->calc.p & 1) && f->calc.q > 65536 && f->calc.kind == KIND_EXT &&
         Ext::fixed_degree(f->calc)) {
         if (packed_div2_eligible(f->calc, dtype, n)) { // r06: by the norm
-            rc = packed_div2_run(f->calc, nullptr, 0, a, 1, out, n, st, dev_err);
+            rc = packed_div2_run(f->calc, dtype, nullptr, 0, a, 1, out, n, st, dev_err);
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
         return dispatch_unary(f->calc, dtype, op, a, out, n, st, dev_err);

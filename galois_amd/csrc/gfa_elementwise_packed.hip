@@ -153,36 +153,36 @@ __global__ __launch_bounds__(PK_THREADS) void packed_mul_kernel(Plan pl, MulAux 
     if (t0 < n) out[t0] = (T)mul_digits<M>(pl, ax, sa ? to_packed(pl, pk_tab, (pu32)a[t0]) : pa0, sb ? to_packed(pl, pk_tab, (pu32)b[t0]) : pb0);
 }
 
-// quotients / reciprocals of GF(p^2), 65536 < q <= 2^20, uint32 arrays: gfa_packed.h::div2 (norm + a p-entry inverse table in LDS)
-template <bool RECIP>
-__global__ __launch_bounds__(PK_THREADS) void packed_div2_kernel(Div2Aux ax, const pu32 *__restrict__ ginv, const uint32_t *__restrict__ a, int sa,
-                                                                  const uint32_t *__restrict__ b, int sb, uint32_t *__restrict__ out, i64 n, int *err)
+// quotients / reciprocals of GF(p^2), 32768 < q <= 2^20, uint16 / uint32 arrays: gfa_packed.h::div2 (norm + a p-entry inverse table in LDS)
+template <typename T, bool RECIP>
+__global__ __launch_bounds__(PK_THREADS) void packed_div2_kernel(Div2Aux ax, const pu32 *__restrict__ ginv, const T *__restrict__ a, int sa,
+                                                                  const T *__restrict__ b, int sb, T *__restrict__ out, i64 n, int *err)
 {
     extern __shared__ pu32 pk_tab[];
     for (pu32 i = threadIdx.x; i < ax.p; i += PK_THREADS) pk_tab[i] = ginv[i];
     __syncthreads();
-    constexpr int V = 4;
+    constexpr int V = PkVec<T>::N;
     const i64 nvec = n / V;
     const uint4 *av = reinterpret_cast<const uint4 *>(a), *bv = reinterpret_cast<const uint4 *>(b);
     uint4 *ov = reinterpret_cast<uint4 *>(out);
-    const pu32 a0 = (RECIP || sa) ? 0u : a[0], b0 = sb ? 0u : b[0];
+    const pu32 a0 = (RECIP || sa) ? 0u : (pu32)a[0], b0 = sb ? 0u : (pu32)b[0];
     bool bad = false;
     for (i64 i = (i64)blockIdx.x * PK_THREADS + threadIdx.x; i < nvec; i += (i64)gridDim.x * PK_THREADS) {
         pu32 xa[V], xb[V], r[V];
-        if (!RECIP && sa) unpack_vec<uint32_t>(av[i], xa);
-        if (sb) unpack_vec<uint32_t>(bv[i], xb);
+        if (!RECIP && sa) unpack_vec<T>(av[i], xa);
+        if (sb) unpack_vec<T>(bv[i], xb);
 #pragma unroll
         for (int j = 0; j < V; j++) {
             bool z;
             r[j] = div2<RECIP>(ax, pk_tab, (!RECIP && sa) ? xa[j] : a0, sb ? xb[j] : b0, &z);
             bad |= z;
         }
-        ov[i] = pack_vec<uint32_t>(r);
+        ov[i] = pack_vec<T>(r);
     }
     const i64 t0 = nvec * V + (i64)blockIdx.x * PK_THREADS + threadIdx.x;
     if (t0 < n) {
         bool z;
-        out[t0] = div2<RECIP>(ax, pk_tab, (!RECIP && sa) ? a[t0] : a0, sb ? b[t0] : b0, &z);
+        out[t0] = (T)div2<RECIP>(ax, pk_tab, (!RECIP && sa) ? (pu32)a[t0] : a0, sb ? (pu32)b[t0] : b0, &z);
         bad |= z;
     }
     if (bad && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
@@ -328,7 +328,7 @@ int packed_run(const FieldDev &c, int dtype, int op, const void *a, i64 sa, cons
 // product stays below 2^32 (mul_bound_ok); ext_irr: FieldDev's digits of (irr - x^m), degree m-1 .. 0
 static bool packed_mul_aux(const FieldDev &c, Plan *pl, MulAux *ax, bool pinned)
 {
-    if (c.m < 2 || c.m > 8 || (c.p & 1) == 0 || (c.q <= 65536 && !pinned) || c.q > ((u64)1 << 20) || !make_plan(c.p, c.m, pl)) return false;
+    if (c.m < 2 || c.m > 8 || (c.p & 1) == 0 || (c.q <= 32768 && !pinned) || c.q > ((u64)1 << 20) || !make_plan(c.p, c.m, pl)) return false; // (r06: from 32768, where the LDS tables stop fitting together)
     for (u32 j = 0; j < 8; j++) ax->nir[j] = 0;
     for (u32 j = 0; j < c.m; j++) ax->nir[j] = c.ext_irr[c.m - 1 - j] ? (pu32)c.p - c.ext_irr[c.m - 1 - j] : 0u;
     ax->mu32 = (pu32)(((u64)1 << 32) / c.p);
@@ -339,7 +339,7 @@ bool packed_mul_eligible(const FieldDev &c, int dtype, i64 n, bool pinned)
 {
     Plan pl;
     MulAux ax;
-    if (!(dtype == GFA_U32 || (pinned && ((dtype == GFA_U16 && c.q <= 65536) || (dtype == GFA_U8 && c.q <= 256))))) return false;
+    if (!(dtype == GFA_U32 || (dtype == GFA_U16 && c.q <= 65536 && (pinned || c.q > 32768)) || (pinned && dtype == GFA_U8 && c.q <= 256))) return false;
     return n >= 1024 && packed_mul_aux(c, &pl, &ax, pinned);
 }
 
@@ -383,13 +383,26 @@ bool packed_div2_eligible(const FieldDev &c, int dtype, i64 n)
     Plan pl;
     MulAux mx;
     Div2Aux ax;
-    return dtype == GFA_U32 && n >= 1024 && c.m == 2 && packed_mul_aux(c, &pl, &mx, true) && make_div2(c.p, c.m, mx.nir, &ax);
+    if (!(dtype == GFA_U32 || (dtype == GFA_U16 && c.q <= 65536))) return false;
+    return n >= 1024 && c.m == 2 && c.q > 32768 && packed_mul_aux(c, &pl, &mx, true) && make_div2(c.p, c.m, mx.nir, &ax);
 }
 
-int packed_div2_run(const FieldDev &c, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int *dev_err)
+template <typename T>
+static void launch_div2(bool recip, int grid, const Div2Aux &ax, const pu32 *inv, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int *dev_err)
+{
+    if (recip)
+        hipLaunchKernelGGL((packed_div2_kernel<T, true>), dim3(grid), dim3(PK_THREADS), sizeof(pu32) * ax.p, st, ax, inv, (const T *)nullptr, 0, (const T *)b, (int)sb,
+                           (T *)out, n, dev_err);
+    else
+        hipLaunchKernelGGL((packed_div2_kernel<T, false>), dim3(grid), dim3(PK_THREADS), sizeof(pu32) * ax.p, st, ax, inv, (const T *)a, (int)sa, (const T *)b, (int)sb,
+                           (T *)out, n, dev_err);
+}
+
+int packed_div2_run(const FieldDev &c, int dtype, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int *dev_err)
 {
     const bool recip = a == nullptr;
     if (!al16p(out) || (!recip && sa && !al16p(a)) || (sb && !al16p(b))) return GFA_ERR_UNSUPPORTED;
+    if (!packed_div2_eligible(c, dtype, n)) return GFA_ERR_UNSUPPORTED;
     Plan pl;
     MulAux mx;
     Div2Aux ax;
@@ -411,14 +424,11 @@ int packed_div2_run(const FieldDev &c, const void *a, i64 sa, const void *b, i64
         }
         inv = it->second;
     }
-    const i64 blocks = std::max<i64>(1, (n / 4 + PK_THREADS - 1) / PK_THREADS);
+    const int vec = dtype == GFA_U32 ? 4 : 8;
+    const i64 blocks = std::max<i64>(1, (n / vec + PK_THREADS - 1) / PK_THREADS);
     const int grid = (int)std::min<i64>(blocks, (i64)num_cus() * 4);
-    if (recip)
-        hipLaunchKernelGGL((packed_div2_kernel<true>), dim3(grid), dim3(PK_THREADS), sizeof(pu32) * ax.p, st, ax, (const pu32 *)inv, (const uint32_t *)nullptr, 0,
-                           (const uint32_t *)b, (int)sb, (uint32_t *)out, n, dev_err);
-    else
-        hipLaunchKernelGGL((packed_div2_kernel<false>), dim3(grid), dim3(PK_THREADS), sizeof(pu32) * ax.p, st, ax, (const pu32 *)inv, (const uint32_t *)a, (int)sa,
-                           (const uint32_t *)b, (int)sb, (uint32_t *)out, n, dev_err);
+    if (dtype == GFA_U32) launch_div2<uint32_t>(recip, grid, ax, inv, a, sa, b, sb, out, n, st, dev_err);
+    else launch_div2<uint16_t>(recip, grid, ax, inv, a, sa, b, sb, out, n, st, dev_err);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }

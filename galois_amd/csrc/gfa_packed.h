@@ -252,7 +252,7 @@ GFP_HD pu32 mul_digits(const Plan &pl, const MulAux &ax, pu32 pa, pu32 pb)
 #pragma unroll
     for (int i = 0; i < M; i++)
 #pragma unroll
-        for (int j = 0; j < M; j++) c[i + j] += mul24(da[i], db[j]); // digits are below 2^11: v_mad_u32_u24, full rate
+        for (int j = 0; j < M; j++) c[i + j] += mul24(da[i], db[j]); // digits are below 2^11: one v_mad_u32_u24 per term (58 lane-ops/clk/CU, as every multiply: profiles/r03_valu_issue_rates.txt)
 #pragma unroll
     for (int k = 2 * M - 2; k >= M; k--)
 #pragma unroll
@@ -263,7 +263,7 @@ GFP_HD pu32 mul_digits(const Plan &pl, const MulAux &ax, pu32 pa, pu32 pb)
     return v;
 }
 
-// ---- quotients and reciprocals of GF(p^2), 65536 < q <= 2^20 (r06): by the norm.  With X^2 = s X + t (s, t = nir[1], nir[0]) the
+// ---- quotients and reciprocals of GF(p^2), 32768 < q <= 2^20 (r06): by the norm.  With X^2 = s X + t (s, t = nir[1], nir[0]) the
 // conjugate of b = b0 + b1 X is b^p = (b0 + s b1) - b1 X and N(b) = b b^p = b0^2 + s b0 b1 - t b1^2 lies in GF(p), non-zero for
 // b != 0 (the polynomial is irreducible); 1 / b = b^p / N with 1 / N from a p-entry table (LDS).  Replaces, for these fields, the
 // reference's divide / reciprocal through LOG / EXP tables that do not fit LDS here (_lookup.py:176-235) or its digit-vector
@@ -274,7 +274,7 @@ struct Div2Aux {
 };
 inline bool make_div2(uint64_t p, uint32_t m, const pu32 *nir, Div2Aux *ax)
 {
-    if (m != 2 || p < 257 || p > 1021 || (p & 1) == 0) return false; // 65536 < p^2 <= 2^20
+    if (m != 2 || p < 182 || p > 1021 || (p & 1) == 0) return false; // 32768 < p^2 <= 2^20
     ax->p = (pu32)p; ax->s = nir[1]; ax->t = nir[0];
     ax->mu32 = (pu32)(((uint64_t)1 << 32) / p);
     ax->magic = (pu32)((((uint64_t)1 << 32) + p - 1) / p);

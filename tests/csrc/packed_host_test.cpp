@@ -160,7 +160,7 @@ int main()
 {
     std::mt19937 rng(5);
     long fails = 0;
-    fails += check_div2(997, rng) + check_div2(257, rng) + check_div2(1021, rng) + check_div2(509, rng);
+    fails += check_div2(997, rng) + check_div2(257, rng) + check_div2(1021, rng) + check_div2(509, rng) + check_div2(251, rng) + check_div2(191, rng);
     const pu32 fields[][2] = {{3, 2}, {3, 5}, {5, 3}, {7, 2}, {3, 9}, {3, 10}, {5, 6}, {5, 7}, {5, 8}, {7, 5}, {7, 6}, {7, 7}, {11, 4}, {11, 5}, {13, 5},
                               {17, 4}, {31, 4}, {41, 3}, {97, 3}, {101, 2}, {257, 2}, {1021, 2}};
     for (auto &f : fields) fails += check(f[0], f[1], rng);

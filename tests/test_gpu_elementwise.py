@@ -1101,3 +1101,46 @@ def test_degree_two_quotients_by_the_norm(order):
         y / x
     with pytest.raises(ZeroDivisionError):
         np.reciprocal(x)
+
+
+@pytest.mark.parametrize("order,dt", [(251**2, np.uint16), (251**2, np.uint32), (191**2, np.uint16), (37**3, np.uint16), (37**3, np.uint32)])
+def test_extension_fields_between_2e15_and_2e16_elements_on_the_digit_tables(order, dt):
+    """r06: GF(p^m), p odd, 32768 < q <= 65536 in AUTO: products through the digit tables (gfa_packed.h::mul_digits) and, in degree 2, quotients
+    and reciprocals by the norm, on uint16 and uint32 arrays -- these fields' LOG / EXP tables do not fit LDS together and the staged
+    kernels ran at 0.40 / 0.27.  Every element against the oracle's lookup scalars (_lookup.py:153-235), with a tail, broadcast scalars,
+    a misaligned view, in-place output, the zero divisor flagged; the field pinned to jit-lookup still takes the tables."""
+    GF = ga.GF(order)
+    F = O.OracleField(GF.characteristic, GF.degree, int(GF.irreducible_poly), int(GF.primitive_element), lookup=True)
+    n = 60_005
+    rng = np.random.default_rng(order % 983)
+    a = rng.integers(0, order, n, dtype=np.uint64)
+    b = rng.integers(1, order, n, dtype=np.uint64)
+    p = GF.characteristic
+    a[:4] = (0, order - 1, 1, p)
+    b[:6] = (1, order - 1, p, p - 1, p + 1, order - p)
+    x, y = GF(a.astype(dt), dtype=dt), GF(b.astype(dt), dtype=dt)
+    u = lambda v: v.numpy().astype(np.uint64)
+    want_mul, want_div = F.mul(a, b), F.div(a, b)
+    H.assert_equal_ints(u(x * y), want_mul, f"GF({order}) mul")
+    H.assert_equal_ints(u(x / y), want_div, f"GF({order}) div")
+    H.assert_equal_ints(u(np.reciprocal(y)), F.div(np.ones(n, dtype=np.uint64), b), f"GF({order}) reciprocal")
+    s = GF(int(b[7]))
+    H.assert_equal_ints(u(x * s), F.mul(a, np.full(n, b[7], dtype=np.uint64)), "scalar factor")
+    H.assert_equal_ints(u(x / s), F.div(a, np.full(n, b[7], dtype=np.uint64)), "scalar divisor")
+    H.assert_equal_ints(u(s / y), F.div(np.full(n, b[7], dtype=np.uint64), b), "scalar dividend")
+    H.assert_equal_ints(u(x[1:] * y[1:]), want_mul[1:], "misaligned product")
+    H.assert_equal_ints(u(x[1:] / y[1:]), want_div[1:], "misaligned quotient")
+    z = x.copy()
+    np.multiply(z, y, out=z)
+    H.assert_equal_ints(u(z), want_mul, "in place")
+    assert (x * y).dtype == np.dtype(dt) and (x / y).dtype == np.dtype(dt)
+    with pytest.raises(ZeroDivisionError):
+        y / x
+    with pytest.raises(ZeroDivisionError):
+        np.reciprocal(x)
+    GF.compile("jit-lookup")
+    try:
+        H.assert_equal_ints(u(x * y), want_mul, "pinned to the tables")
+        H.assert_equal_ints(u(x / y), want_div)
+    finally:
+        GF.compile("auto")
