@@ -1083,6 +1083,19 @@ class FieldArray(metaclass=FieldArrayMeta):
         np_dtype = self._np_dtype if cls._itemsize(self._np_dtype) == size else next(d for d in cands if cls._itemsize(d) == size)
         return cls._wrap(t.contiguous(), np_dtype)
 
+    def _store_into(self, out, res, func):
+        """`out=` of an array function: NumPy's contract -- the result is stored into the caller's array of the same field and shape
+        (any storage width of the field), which is returned."""
+        if out is None:
+            return res
+        cls = type(self)
+        if not isinstance(out, cls) or not isinstance(res, cls):
+            raise TypeError(f"Argument 'out' of np.{func.__name__} must be a {cls.name} array, not {type(out)}.")
+        if tuple(out.shape) != tuple(res.shape):
+            raise ValueError(f"Output array has shape {tuple(out.shape)}, the result of np.{func.__name__} has shape {tuple(res.shape)}.")
+        out._t.copy_(_to_storage(res._t, out._t.dtype).reshape(out._t.shape))
+        return out
+
     def __array_function__(self, func, types, args, kwargs):
         if func is np.fft.fft or func is np.fft.ifft:
             from ._ntt import _field_fft
@@ -1096,9 +1109,8 @@ class FieldArray(metaclass=FieldArrayMeta):
         if func in _LINALG_FUNCTIONS:
             from . import _linalg
 
-            if kwargs.get("out") is not None:
-                raise NotImplementedError("The `out=` keyword is not supported for device-resident field arrays.")
-            return getattr(_linalg, _LINALG_FUNCTIONS[func])(*args)
+            res = getattr(_linalg, _LINALG_FUNCTIONS[func])(*args)
+            return self._store_into(kwargs.get("out"), res, func)  # `out=`: the reference copies the result into it (_domains/_linalg.py:269-274)
         # Reductions that NumPy implements through ufunc methods on the subclass (the reference reaches its field
         # kernels through ndarray.__array_function__ -> add.reduce / multiply.reduce ..., _domains/_function.py:476)
         x = args[0] if args else None
@@ -1160,16 +1172,16 @@ class FieldArray(metaclass=FieldArrayMeta):
             return r
 
         if func in (np.concatenate, np.stack, np.vstack, np.hstack, np.dstack, np.column_stack):
-            if kwargs.get("out") is not None:
-                raise NotImplementedError("The `out=` keyword is not supported for device-resident field arrays.")
             ts, _ = seq(args[0])
             if func is np.concatenate:
                 axis = kw("axis", 1, 0)
-                return wrap(torch.cat([t.reshape(-1) for t in ts]) if axis is None else torch.cat(ts, dim=axis))
-            if func is np.stack:
-                return wrap(torch.stack(ts, dim=kw("axis", 1, 0)))
-            f = {np.vstack: torch.vstack, np.hstack: torch.hstack, np.dstack: torch.dstack, np.column_stack: torch.column_stack}[func]
-            return wrap(f(ts))
+                res = wrap(torch.cat([t.reshape(-1) for t in ts]) if axis is None else torch.cat(ts, dim=axis))
+            elif func is np.stack:
+                res = wrap(torch.stack(ts, dim=kw("axis", 1, 0)))
+            else:
+                f = {np.vstack: torch.vstack, np.hstack: torch.hstack, np.dstack: torch.dstack, np.column_stack: torch.column_stack}[func]
+                res = wrap(f(ts))
+            return self._store_into(kwargs.get("out"), res, func)
         if isinstance(x, cls):
             t = tens(x)
             if func is np.broadcast_to:

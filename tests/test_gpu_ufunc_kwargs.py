@@ -192,3 +192,31 @@ def test_where_with_out_of_a_wider_dtype_keeps_values_above_the_sign_bit(order, 
     s = np.add.reduce(x, where=mask, initial=GF(0)) if GF.characteristic != 2 else None
     if s is not None:
         assert int(s) == int(sum(int(v) for v in hi[mask]) % order) or GF.degree > 1
+
+
+@pytest.mark.parametrize("order", [2**8, 65537, 2**100])
+def test_out_keyword_of_array_functions(order):
+    """`out=` on the linear-algebra and stacking array functions: the reference copies the result into the caller's array
+    (_domains/_linalg.py:269-274); same here, for any storage width of the field, with NumPy's shape check."""
+    GF = ga.GF(order)
+    A, B = GF.Random((5, 7), seed=1), GF.Random((7, 4), seed=2)
+    want = A @ B
+    C = GF.Zeros((5, 4))
+    got = np.dot(A, B, out=C)
+    assert got is C and np.array_equal(ints(C), ints(want))
+    D = GF.Zeros((5, 4))
+    assert np.matmul(A, B, out=D) is D and np.array_equal(ints(D), ints(want))
+    v, w = GF.Random(9, seed=3), GF.Random(9, seed=4)
+    O2 = GF.Zeros((9, 9))
+    assert np.outer(v, w, out=O2) is O2 and np.array_equal(ints(O2), ints(np.multiply.outer(v, w)))
+    cat = GF.Zeros(18)
+    assert np.concatenate([v, w], out=cat) is cat and np.array_equal(ints(cat), np.concatenate([ints(v), ints(w)]))
+    st = GF.Zeros((2, 9))
+    assert np.stack([v, w], out=st) is st and np.array_equal(ints(st), np.stack([ints(v), ints(w)]))
+    with pytest.raises(ValueError):
+        np.dot(A, B, out=GF.Zeros((4, 5)))
+    with pytest.raises(TypeError):
+        np.dot(A, B, out=np.zeros((5, 4), dtype=np.int64))
+    if order == 65537:  # a wider storage dtype of the same field as the target
+        W = GF(np.zeros((5, 4), dtype=np.int64), dtype=np.int64)
+        assert np.dot(A, B, out=W) is W and W.dtype == np.int64 and np.array_equal(ints(W), ints(want))
