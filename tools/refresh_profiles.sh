@@ -3,7 +3,7 @@
 #   /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash tools/refresh_profiles.sh r04'
 # then copy gpurun_out/<round>_*.txt / .json / .csv into profiles/.
 set -u
-R=${1:-r05}
+R=${1:-r06}
 ONLY=${2:-all} # "codes": only the files the Reed-Solomon / BCH and Goldilocks kernels feed (about 2 GPU-minutes)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
@@ -58,3 +58,12 @@ python tools/ew_bench.py --packed 2>/dev/null | grep field > "$OUT/${R}_ew_packe
 python tools/ew_bench.py --widestore16 2>/dev/null | grep field > "$OUT/${R}_ew_widestore16.txt"
 python tools/m32_tune3.py > "$OUT/${R}_m32_tune3.txt" 2>/dev/null
 ./tools/ubench/ntt_packed 64 > "$OUT/${R}_ntt_packed_intermediate.txt" 2>/dev/null
+# r06 additions: GF(65537) transforms of 2^10 .. 2^16 points (grouped one-pass kernel), two-word packed sums, GF(p^2) quotients by the norm,
+# the 2^15 .. 2^16-element band, strided-piece skeleton, the differential fuzzer
+python tools/fermat_sizes_time.py 2>/dev/null | tail -1 > "$OUT/${R}_fermat_sizes.txt"
+python tools/fermat_grouped_check.py 2>/dev/null | grep -E "ok|p=" > "$OUT/${R}_fermat_grouped_sizes.txt"
+python tools/ew_bench.py --packed2 2>/dev/null | grep field > "$OUT/${R}_ew_packed_two_words.txt"
+python tools/ew_bench.py --div2 2>/dev/null | grep field > "$OUT/${R}_ew_div2.txt"
+python tools/ew_bench.py --band16 2>/dev/null | grep field > "$OUT/${R}_ew_band16.txt"
+./_variants/strided_pieces > "$OUT/${R}_strided_pieces.txt" 2>/dev/null
+for sd in 61 62 63; do python tools/fuzz_r06.py 60 $sd 2>/dev/null | tail -1; done > "$OUT/${R}_fuzz.txt"
