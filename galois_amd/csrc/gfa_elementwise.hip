@@ -1526,8 +1526,8 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
             rc = packed_mul_run(f->calc, dtype, a, sa, b, sb, out, n, st);
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
-        if (op == GFA_OP_DIV && dtype == GFA_U32 && packed_div2_eligible(f->calc, dtype, n)) {
-            rc = packed_div2_run(f->calc, dtype, a, sa, b, sb, out, n, st, dev_err);
+        if (op == GFA_OP_DIV && dtype == GFA_U32 && packed_divn_eligible(f->calc, dtype, n)) {
+            rc = packed_divn_run(f->calc, dtype, a, sa, b, sb, out, n, st, dev_err);
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
     }
@@ -1579,15 +1579,15 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
     // GF(997^2) 0.67, GF(97^3) 0.47, GF(31^4) 0.33, GF(13^5) 0.25, GF(7^7) 0.15, GF(5^8) 0.13 (profiles/r05_ew_extcalc.txt) -- and, in
     // degree 2, for quotients (0.15 vs 0.06).  Same values either way; a field pinned to jit-lookup keeps its tables.
     if (f->mode == GFA_MODE_AUTO && f->calc.m > 1 && (f->calc.p & 1) && f->calc.q > 65536 && f->calc.kind == KIND_EXT && Ext::fixed_degree(f->calc) &&
-        (op == GFA_OP_MUL || (op == GFA_OP_DIV && f->calc.m == 2))) {
+        (op == GFA_OP_MUL || (op == GFA_OP_DIV && (f->calc.m == 2 || (f->calc.m == 3 && packed_divn_eligible(f->calc, dtype, n)))))) {
         // products: digits through LDS tables and no reduction before the end (gfa_packed.h::mul_digits) where the 32-bit bound holds
         if (op == GFA_OP_MUL && packed_mul_eligible(f->calc, dtype, n, false)) {
             rc = packed_mul_run(f->calc, dtype, a, sa, b, sb, out, n, st);
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
         // r06: degree-2 quotients by the norm (conjugate / N(b), 1 / N from a p-entry LDS table): 0.15 -> see profiles/r06_ew_div2.txt
-        if (op == GFA_OP_DIV && packed_div2_eligible(f->calc, dtype, n)) {
-            rc = packed_div2_run(f->calc, dtype, a, sa, b, sb, out, n, st, dev_err);
+        if (op == GFA_OP_DIV && packed_divn_eligible(f->calc, dtype, n)) {
+            rc = packed_divn_run(f->calc, dtype, a, sa, b, sb, out, n, st, dev_err);
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
         return dispatch_binary(f->calc, dtype, op, a, sa, b, sb, out, n, st, dev_err);
@@ -1622,8 +1622,8 @@ int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int d
         if (rc != GFA_ERR_UNSUPPORTED) return rc;
     }
     if (f->mode == GFA_MODE_AUTO && op == GFA_OP_RECIP && f->calc.kind == KIND_EXT && f->calc.q > 32768 && f->calc.q <= 65536 && dtype == GFA_U32 &&
-        packed_div2_eligible(f->calc, dtype, n)) { // r06: GF(p^2), 181 <= p <= 251: by the norm, as in gfa_binary
-        rc = packed_div2_run(f->calc, dtype, nullptr, 0, a, 1, out, n, st, dev_err);
+        packed_divn_eligible(f->calc, dtype, n)) { // r06: GF(p^2), 181 <= p <= 251: by the norm, as in gfa_binary
+        rc = packed_divn_run(f->calc, dtype, nullptr, 0, a, 1, out, n, st, dev_err);
         if (rc != GFA_ERR_UNSUPPORTED) return rc;
     }
     if (f->mode != GFA_MODE_CALCULATE) { // tables in LDS, as in gfa_binary
@@ -1652,10 +1652,10 @@ int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int d
         }
     }
     // r05, AUTO only: reciprocals of degree-2 extension fields above 65536 elements on the digit-vector kernel (0.12 vs 0.06, see gfa_binary)
-    if (f->mode == GFA_MODE_AUTO && op == GFA_OP_RECIP && f->calc.m == 2 && (f->calc.p & 1) && f->calc.q > 65536 && f->calc.kind == KIND_EXT &&
-        Ext::fixed_degree(f->calc)) {
-        if (packed_div2_eligible(f->calc, dtype, n)) { // r06: by the norm
-            rc = packed_div2_run(f->calc, dtype, nullptr, 0, a, 1, out, n, st, dev_err);
+    if (f->mode == GFA_MODE_AUTO && op == GFA_OP_RECIP && (f->calc.m == 2 || (f->calc.m == 3 && packed_divn_eligible(f->calc, dtype, n))) && (f->calc.p & 1) &&
+        f->calc.q > 65536 && f->calc.kind == KIND_EXT && Ext::fixed_degree(f->calc)) {
+        if (packed_divn_eligible(f->calc, dtype, n)) { // r06: by the norm
+            rc = packed_divn_run(f->calc, dtype, nullptr, 0, a, 1, out, n, st, dev_err);
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
         return dispatch_unary(f->calc, dtype, op, a, out, n, st, dev_err);

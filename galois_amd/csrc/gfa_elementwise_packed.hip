@@ -188,6 +188,41 @@ __global__ __launch_bounds__(PK_THREADS) void packed_div2_kernel(Div2Aux ax, con
     if (bad && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
 }
 
+// quotients / reciprocals of GF(p^3), 65536 < q <= 2^20: gfa_packed.h::div3 (Cramer's rule on the multiplication matrix + the same inverse table)
+template <typename T, bool RECIP>
+__global__ __launch_bounds__(PK_THREADS) void packed_div3_kernel(Div3Aux ax, const pu32 *__restrict__ ginv, const T *__restrict__ a, int sa,
+                                                                  const T *__restrict__ b, int sb, T *__restrict__ out, i64 n, int *err)
+{
+    extern __shared__ pu32 pk_tab[];
+    for (pu32 i = threadIdx.x; i < ax.p; i += PK_THREADS) pk_tab[i] = ginv[i];
+    __syncthreads();
+    constexpr int V = PkVec<T>::N;
+    const i64 nvec = n / V;
+    const uint4 *av = reinterpret_cast<const uint4 *>(a), *bv = reinterpret_cast<const uint4 *>(b);
+    uint4 *ov = reinterpret_cast<uint4 *>(out);
+    const pu32 a0 = (RECIP || sa) ? 0u : (pu32)a[0], b0 = sb ? 0u : (pu32)b[0];
+    bool bad = false;
+    for (i64 i = (i64)blockIdx.x * PK_THREADS + threadIdx.x; i < nvec; i += (i64)gridDim.x * PK_THREADS) {
+        pu32 xa[V], xb[V], r[V];
+        if (!RECIP && sa) unpack_vec<T>(av[i], xa);
+        if (sb) unpack_vec<T>(bv[i], xb);
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            bool z;
+            r[j] = div3<RECIP>(ax, pk_tab, (!RECIP && sa) ? xa[j] : a0, sb ? xb[j] : b0, &z);
+            bad |= z;
+        }
+        ov[i] = pack_vec<T>(r);
+    }
+    const i64 t0 = nvec * V + (i64)blockIdx.x * PK_THREADS + threadIdx.x;
+    if (t0 < n) {
+        bool z;
+        out[t0] = (T)div3<RECIP>(ax, pk_tab, (!RECIP && sa) ? (pu32)a[t0] : a0, sb ? (pu32)b[t0] : b0, &z);
+        bad |= z;
+    }
+    if (bad && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
+}
+
 struct PackedDev {
     Plan pl;
     pu32 *tab = nullptr;
@@ -378,13 +413,26 @@ int packed_mul_run(const FieldDev &c, int dtype, const void *a, i64 sa, const vo
 // quotients (reciprocals: a == nullptr) of GF(p^2), odd p, 65536 < q <= 2^20, uint32 arrays (r06)
 static std::map<std::pair<u64, int>, pu32 *> g_inv_tab; // (p, device) -> p-entry inverse table
 
-bool packed_div2_eligible(const FieldDev &c, int dtype, i64 n)
+bool packed_divn_eligible(const FieldDev &c, int dtype, i64 n)
 {
     Plan pl;
     MulAux mx;
-    Div2Aux ax;
     if (!(dtype == GFA_U32 || (dtype == GFA_U16 && c.q <= 65536))) return false;
-    return n >= 1024 && c.m == 2 && c.q > 32768 && packed_mul_aux(c, &pl, &mx, true) && make_div2(c.p, c.m, mx.nir, &ax);
+    if (n < 1024 || c.q <= 32768 || !packed_mul_aux(c, &pl, &mx, true)) return false;
+    Div2Aux a2;
+    Div3Aux a3;
+    return (c.m == 2 && make_div2(c.p, c.m, mx.nir, &a2)) || (c.m == 3 && dtype == GFA_U32 && make_div3(c.p, c.m, mx.nir, &a3));
+}
+
+template <typename T>
+static void launch_div3(bool recip, int grid, const Div3Aux &ax, const pu32 *inv, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int *dev_err)
+{
+    if (recip)
+        hipLaunchKernelGGL((packed_div3_kernel<T, true>), dim3(grid), dim3(PK_THREADS), sizeof(pu32) * ax.p, st, ax, inv, (const T *)nullptr, 0, (const T *)b, (int)sb,
+                           (T *)out, n, dev_err);
+    else
+        hipLaunchKernelGGL((packed_div3_kernel<T, false>), dim3(grid), dim3(PK_THREADS), sizeof(pu32) * ax.p, st, ax, inv, (const T *)a, (int)sa, (const T *)b, (int)sb,
+                           (T *)out, n, dev_err);
 }
 
 template <typename T>
@@ -398,15 +446,17 @@ static void launch_div2(bool recip, int grid, const Div2Aux &ax, const pu32 *inv
                            (T *)out, n, dev_err);
 }
 
-int packed_div2_run(const FieldDev &c, int dtype, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int *dev_err)
+int packed_divn_run(const FieldDev &c, int dtype, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int *dev_err)
 {
     const bool recip = a == nullptr;
     if (!al16p(out) || (!recip && sa && !al16p(a)) || (sb && !al16p(b))) return GFA_ERR_UNSUPPORTED;
-    if (!packed_div2_eligible(c, dtype, n)) return GFA_ERR_UNSUPPORTED;
+    if (!packed_divn_eligible(c, dtype, n)) return GFA_ERR_UNSUPPORTED;
     Plan pl;
     MulAux mx;
-    Div2Aux ax;
-    if (!packed_mul_aux(c, &pl, &mx, true) || !make_div2(c.p, c.m, mx.nir, &ax)) return GFA_ERR_UNSUPPORTED;
+    Div2Aux a2;
+    Div3Aux a3;
+    if (!packed_mul_aux(c, &pl, &mx, true)) return GFA_ERR_UNSUPPORTED;
+    if (c.m == 2 ? !make_div2(c.p, c.m, mx.nir, &a2) : !make_div3(c.p, c.m, mx.nir, &a3)) return GFA_ERR_UNSUPPORTED;
     int dev = 0;
     GFA_HIP(hipGetDevice(&dev));
     pu32 *inv = nullptr;
@@ -416,7 +466,7 @@ int packed_div2_run(const FieldDev &c, int dtype, const void *a, i64 sa, const v
         auto it = g_inv_tab.find(key);
         if (it == g_inv_tab.end()) {
             std::vector<pu32> t;
-            build_inverse_table(ax.p, t);
+            build_inverse_table((pu32)c.p, t);
             pu32 *d = nullptr;
             GFA_HIP(hipMalloc((void **)&d, sizeof(pu32) * t.size()));
             GFA_HIP(hipMemcpy(d, t.data(), sizeof(pu32) * t.size(), hipMemcpyHostToDevice));
@@ -427,8 +477,9 @@ int packed_div2_run(const FieldDev &c, int dtype, const void *a, i64 sa, const v
     const int vec = dtype == GFA_U32 ? 4 : 8;
     const i64 blocks = std::max<i64>(1, (n / vec + PK_THREADS - 1) / PK_THREADS);
     const int grid = (int)std::min<i64>(blocks, (i64)num_cus() * 4);
-    if (dtype == GFA_U32) launch_div2<uint32_t>(recip, grid, ax, inv, a, sa, b, sb, out, n, st, dev_err);
-    else launch_div2<uint16_t>(recip, grid, ax, inv, a, sa, b, sb, out, n, st, dev_err);
+    if (c.m == 3) launch_div3<uint32_t>(recip, grid, a3, inv, a, sa, b, sb, out, n, st, dev_err);
+    else if (dtype == GFA_U32) launch_div2<uint32_t>(recip, grid, a2, inv, a, sa, b, sb, out, n, st, dev_err);
+    else launch_div2<uint16_t>(recip, grid, a2, inv, a, sa, b, sb, out, n, st, dev_err);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }

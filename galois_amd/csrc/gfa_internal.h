@@ -85,9 +85,10 @@ int mid_power_each(const FieldDev &lut, const void *image, const void *a, const 
 bool packed_eligible(const FieldDev &calc, int dtype, i64 n, bool pinned_to_calculate);
 int packed_run(const FieldDev &calc, int dtype, int op, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st);
 bool packed_mul_eligible(const FieldDev &calc, int dtype, i64 n, bool pinned_to_calculate); // products on the same digit tables
-// r06: quotients (a == nullptr: reciprocals of b) of GF(p^2), odd p, 32768 < q <= 2^20, uint16 / uint32 arrays, by the norm (gfa_packed.h::div2)
-bool packed_div2_eligible(const FieldDev &calc, int dtype, i64 n);
-int packed_div2_run(const FieldDev &calc, int dtype, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int *dev_err);
+// r06: quotients (a == nullptr: reciprocals of b) of GF(p^2), odd p, 32768 < q <= 2^20 (norm; gfa_packed.h::div2) and of GF(p^3), 65536 < q <= 2^20
+// (Cramer's rule; div3), uint16 / uint32 arrays
+bool packed_divn_eligible(const FieldDev &calc, int dtype, i64 n);
+int packed_divn_run(const FieldDev &calc, int dtype, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int *dev_err);
 int packed_mul_run(const FieldDev &calc, int dtype, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st);
 bool big16_eligible(const FieldDev &calc, const void *image, int dtype, i64 n);
 // uint32 / int64 storage of the same fields: narrowed into a 16-bit work buffer, run, widened (first n & ~7 elements)

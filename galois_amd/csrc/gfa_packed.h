@@ -308,4 +308,57 @@ GFP_HD pu32 div2(const Div2Aux &ax, const pu32 *inv, pu32 a, pu32 b, bool *zero)
     return q1 * p + q0;
 }
 
+// ---- quotients and reciprocals of GF(p^3), 65536 < q <= 2^20 (41 <= p <= 101; r06): by Cramer's rule on the multiplication matrix.  With
+// X^3 = n2 X^2 + n1 X + n0, b * c = M c for M = [b | X b | X^2 b] (columns in the basis 1, X, X^2), so 1 / b = M^-1 e0 = (cofactors of M's first
+// row) / det M, det M = N(b) in GF(p), non-zero for b != 0.  Six products for the two shifted columns, six for the cofactors, three for the
+// determinant, one table inverse, three to scale; every partial sum below 2^23.  Same field, same values as the reference's table division.
+struct Div3Aux {
+    pu32 p, n0, n1, n2, mu32, magic; // magic = ceil(2^32 / p): exact quotients for x < 2^20
+};
+inline bool make_div3(uint64_t p, uint32_t m, const pu32 *nir, Div3Aux *ax)
+{
+    if (m != 3 || p < 41 || p > 101 || (p & 1) == 0) return false; // 65536 < p^3 <= 2^20
+    ax->p = (pu32)p; ax->n0 = nir[0]; ax->n1 = nir[1]; ax->n2 = nir[2];
+    ax->mu32 = (pu32)(((uint64_t)1 << 32) / p);
+    ax->magic = (pu32)((((uint64_t)1 << 32) + p - 1) / p);
+    return true;
+}
+template <bool RECIP>
+GFP_HD pu32 div3(const Div3Aux &ax, const pu32 *inv, pu32 a, pu32 b, bool *zero)
+{
+    const pu32 p = ax.p, pp = p * p;
+    auto split = [&](pu32 x, pu32 &d0, pu32 &d1, pu32 &d2) { // x = d2 p^2 + d1 p + d0
+        const pu32 q1 = mulhi32(x, ax.magic);
+        d0 = x - q1 * p;
+        d2 = mulhi32(q1, ax.magic);
+        d1 = q1 - d2 * p;
+    };
+    auto R = [&](pu32 x) { return red32(x, p, ax.mu32); };
+    pu32 b0, b1, b2;
+    split(b, b0, b1, b2);
+    *zero = b == 0;
+    // columns X b and X^2 b
+    const pu32 d0 = R(b2 * ax.n0), d1 = R(b0 + b2 * ax.n1), d2 = R(b1 + b2 * ax.n2);
+    const pu32 e0 = R(d2 * ax.n0), e1 = R(d0 + d2 * ax.n1), e2 = R(d1 + d2 * ax.n2);
+    // M = [[b0 d0 e0] [b1 d1 e1] [b2 d2 e2]]; cofactors of the first row (each in (0, 2 p^2))
+    const pu32 c0 = pp + d1 * e2 - e1 * d2;
+    const pu32 c1 = pp + e1 * b2 - b1 * e2;
+    const pu32 c2 = pp + b1 * d2 - d1 * b2;
+    const pu32 det = R(b0 * c0 + d0 * c1 + e0 * c2);
+    const pu32 ni = inv[det];
+    const pu32 i0 = R(R(c0) * ni), i1 = R(R(c1) * ni), i2 = R(R(c2) * ni); // 1 / b = i0 + i1 X + i2 X^2
+    if (RECIP) return (i2 * p + i1) * p + i0;
+    pu32 a0, a1, a2;
+    split(a, a0, a1, a2);
+    // (a0 + a1 X + a2 X^2)(i0 + i1 X + i2 X^2), folded through X^3 = n2 X^2 + n1 X + n0 and X^4 = X * X^3
+    const pu32 t0 = a0 * i0, t1 = a0 * i1 + a1 * i0, t2 = a0 * i2 + a1 * i1 + a2 * i0;
+    const pu32 t3 = R(a1 * i2 + a2 * i1), t4 = R(a2 * i2);
+    // X^4 = n2 X^3 + n1 X^2 + n0 X: fold t4 first, then the X^3 term
+    const pu32 u3 = R(t3 + t4 * ax.n2);
+    const pu32 q0 = R(t0 + u3 * ax.n0);
+    const pu32 q1 = R(t1 + t4 * ax.n0 + u3 * ax.n1);
+    const pu32 q2 = R(t2 + t4 * ax.n1 + u3 * ax.n2);
+    return (q2 * p + q1) * p + q0;
+}
+
 } // namespace gfa_packed

@@ -156,10 +156,55 @@ static long check_div2(pu32 p, std::mt19937 &rng)
     return fails;
 }
 
+// quotients of GF(p^3) by Cramer's rule (r06): (a / b) * b == a and (1 / b) * b == 1 through the textbook digit product, for random
+// irreducible cubics (no root mod p: a cubic without roots is irreducible)
+static long check_div3(pu32 p, std::mt19937 &rng)
+{
+    long fails = 0;
+    for (int poly = 0; poly < 4; poly++) {
+        pu32 c2, c1, c0;
+        for (;;) {
+            c2 = rng() % p; c1 = rng() % p; c0 = rng() % p;
+            bool root = false;
+            for (pu32 x = 0; x < p && !root; x++) root = (((uint64_t)x * x % p) * x + (uint64_t)c2 * x % p * x + (uint64_t)c1 * x + c0) % p == 0;
+            if (!root) break;
+        }
+        pu32 nir[8] = {c0 ? p - c0 : 0, c1 ? p - c1 : 0, c2 ? p - c2 : 0};
+        Div3Aux ax;
+        if (!make_div3(p, 3, nir, &ax)) { printf("GF(%u^3): refused\n", p); return 1; }
+        std::vector<pu32> inv;
+        build_inverse_table(p, inv);
+        auto mul = [&](pu32 x, pu32 y) {
+            uint64_t xd[3] = {x % p, x / p % p, x / p / p}, yd[3] = {y % p, y / p % p, y / p / p}, c[5] = {0, 0, 0, 0, 0};
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) c[i + j] = (c[i + j] + xd[i] * yd[j]) % p;
+            for (int k = 4; k >= 3; k--)
+                for (int j = 0; j < 3; j++) c[k - 3 + j] = (c[k - 3 + j] + c[k] * nir[j]) % p;
+            return (pu32)((c[2] * p + c[1]) * p + c[0]);
+        };
+        const pu32 q = p * p * p;
+        auto one = [&](pu32 a, pu32 b) {
+            bool z = false, z2 = false;
+            const pu32 qt = div3<false>(ax, inv.data(), a, b, &z), rc = div3<true>(ax, inv.data(), a, b, &z2);
+            if (z != (b == 0) || z2 != (b == 0)) fails++;
+            if (b == 0) return;
+            if (qt >= q || rc >= q || mul(qt, b) != a || mul(rc, b) != 1) fails++;
+        };
+        for (pu32 b = 0; b < 4 * p; b++) one(rng() % q, b);
+        const pu32 edge[7] = {0, 1, q - 1, p, p - 1, p * p, q - p};
+        for (pu32 a : edge)
+            for (pu32 b : edge) one(a, b);
+        for (int it = 0; it < 100000; it++) one(rng() % q, rng() % q);
+    }
+    printf("GF(%u^3) quotients by Cramer's rule: %s\n", p, fails ? "FAIL" : "ok");
+    return fails;
+}
+
 int main()
 {
     std::mt19937 rng(5);
     long fails = 0;
+    fails += check_div3(41, rng) + check_div3(97, rng) + check_div3(101, rng) + check_div3(67, rng);
     fails += check_div2(997, rng) + check_div2(257, rng) + check_div2(1021, rng) + check_div2(509, rng) + check_div2(251, rng) + check_div2(191, rng);
     const pu32 fields[][2] = {{3, 2}, {3, 5}, {5, 3}, {7, 2}, {3, 9}, {3, 10}, {5, 6}, {5, 7}, {5, 8}, {7, 5}, {7, 6}, {7, 7}, {11, 4}, {11, 5}, {13, 5},
                               {17, 4}, {31, 4}, {41, 3}, {97, 3}, {101, 2}, {257, 2}, {1021, 2}};

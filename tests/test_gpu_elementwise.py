@@ -1144,3 +1144,38 @@ def test_extension_fields_between_2e15_and_2e16_elements_on_the_digit_tables(ord
         H.assert_equal_ints(u(x / y), want_div)
     finally:
         GF.compile("auto")
+
+
+@pytest.mark.parametrize("order", [41**3, 67**3, 97**3, 101**3])
+def test_degree_three_quotients_by_cramers_rule(order):
+    """r06: a / b and 1 / b over GF(p^3), 65536 < q <= 2^20, from the cofactors of the multiplication matrix and one table inverse of its
+    determinant (gfa_packed.h::div3, packed_div3_kernel) -- the reference divides through LOG / EXP tables (_lookup.py:176-235).  Every
+    element against the oracle's lookup scalars, with a tail, broadcast scalars, a misaligned view, in place, the zero divisor flagged."""
+    try:
+        GF = ga.GF(order)
+    except LookupError:
+        pytest.skip("no Conway polynomial for this field in the shipped table")
+    F = O.OracleField(GF.characteristic, GF.degree, int(GF.irreducible_poly), int(GF.primitive_element), lookup=True)
+    n = 40_003
+    rng = np.random.default_rng(order % 977)
+    a = rng.integers(0, order, n, dtype=np.uint64)
+    b = rng.integers(1, order, n, dtype=np.uint64)
+    p = GF.characteristic
+    a[:4] = (0, order - 1, 1, p)
+    b[:7] = (1, order - 1, p, p - 1, p + 1, p * p, order - p)
+    x, y = GF(a.astype(np.uint32)), GF(b.astype(np.uint32))
+    u = lambda v: v.numpy().astype(np.uint64)
+    H.assert_equal_ints(u(x / y), F.div(a, b), f"GF({order}) div")
+    H.assert_equal_ints(u(np.reciprocal(y)), F.div(np.ones(n, dtype=np.uint64), b), f"GF({order}) reciprocal")
+    s = GF(int(b[9]))
+    H.assert_equal_ints(u(x / s), F.div(a, np.full(n, b[9], dtype=np.uint64)), "scalar divisor")
+    H.assert_equal_ints(u(s / y), F.div(np.full(n, b[9], dtype=np.uint64), b), "scalar dividend")
+    H.assert_equal_ints(u(x[1:] / y[1:]), F.div(a[1:], b[1:]), "misaligned views")
+    z = x.copy()
+    np.true_divide(z, y, out=z)
+    H.assert_equal_ints(u(z), F.div(a, b), "in place")
+    H.assert_equal_ints(u((x / y) * y), a, "round trip")
+    with pytest.raises(ZeroDivisionError):
+        y / x
+    with pytest.raises(ZeroDivisionError):
+        np.reciprocal(x)

@@ -28,6 +28,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--packed":  # r05: sums of odd-characte
              (997**2, np.uint32, "auto"), (7**7, np.uint32, "jit-calculate")]
 if len(sys.argv) > 1 and sys.argv[1] == "--band16":  # r06: GF(p^m), 32768 < q <= 65536, on the digit tables
     cases = [(251**2, np.uint16, "auto"), (251**2, np.uint32, "auto"), (37**3, np.uint16, "auto"), (251**2, np.uint16, "jit-lookup"), (3**10, np.uint16, "auto")]
+if len(sys.argv) > 1 and sys.argv[1] == "--div3":  # r06: degree-3 quotients by Cramer's rule
+    cases = [(97**3, np.uint32, "auto"), (41**3, np.uint32, "auto"), (97**3, np.uint32, "jit-lookup")]
 if len(sys.argv) > 1 and sys.argv[1] == "--div2":  # r06: degree-2 quotients by the norm
     cases = [(997**2, np.uint32, "auto"), (257**2, np.uint32, "auto"), (509**2, np.uint32, "auto")]
 if len(sys.argv) > 1 and sys.argv[1] == "--packed2":  # r06: GF(3^11), GF(3^12): two packed words
