@@ -13,6 +13,8 @@ ufunc cases); a case then costs a few kernel launches and one small oracle call:
              one-pass kernel), batch sizes that are not multiples of G;
   * ntt16    the one-workgroup 2^16-point kernels (r06: GF(65537) with the first twiddles formed in registers and the early
              requests; generic p < 2^29 with the early requests): batches of 64 .. 300 transforms, forward and scaled inverse;
+  * ext32    extension fields of 2^15 .. 2^20 elements on uint32 arrays (two-word packed sums of GF(3^11) / GF(3^12), digit-table products,
+             GF(p^2) / GF(p^3) quotients and reciprocals by the norm / Cramer's rule): every operation with tails, misaligned views, scalars;
   * convolve random lengths 1500 .. 6000 (the CRT route) over pool primes, five coefficients against Python integers;
   * where    masked ufunc calls / reductions on random fields, uint16 / uint32 results blended into WIDER `out` arrays (ADVICE r05);
   * wide     (1 case in 25) the two-limb identities of fuzz_r05.py.
@@ -30,7 +32,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 rng = np.random.default_rng(seed)
 lib = L.lib()
 st = torch.cuda.current_stream().cuda_stream
-counts = {"ntt": 0, "ntt_large": 0, "ntt16": 0, "ntt_grouped": 0, "convolve": 0, "where": 0, "wide": 0}
+counts = {"ntt": 0, "ntt_large": 0, "ntt16": 0, "ntt_grouped": 0, "ext32": 0, "convolve": 0, "where": 0, "wide": 0}
 
 
 def find_prime(bits, adic):
@@ -55,6 +57,8 @@ for p in [65537, 7340033, 469762049, 2013265921, 2130706433, 3221225473, 4293918
     adic = ((p - 1) & -(p - 1)).bit_length() - 1
     POOL.append((p, GF, O.OracleField(p, 1, None, int(GF.primitive_element)), adic))
 P16 = [e for e in POOL if e[0] < 2**29 and e[3] >= 16]
+EXT32 = {}  # extension fields on uint32 arrays: two-word packed sums, digit-table products, quotients by the norm / Cramer's rule (r06)
+EXT32_ORDERS = [257**2, 509**2, 997**2, 251**2, 191**2, 37**3, 41**3, 67**3, 97**3, 101**3, 3**11, 3**12, 7**7, 5**8, 13**5, 31**4]
 MASKED = [ga.GF(q) for q in (7, 2**8, 3**5, 3**10, 65521, 65537, 2**16, 2**32, 4294967291)]
 WIDE = None
 
@@ -104,6 +108,41 @@ while time.time() < t_end:
         logn = int(rng.integers(10, 16))
         run_ntt(POOL[0], logn, int(rng.integers(64, 130)) * (65536 >> logn) + int(rng.integers(0, 65536 >> logn)))
         counts["ntt_grouped"] += 1
+    elif u < 0.66:
+        q = int(EXT32_ORDERS[rng.integers(0, len(EXT32_ORDERS))])
+        if q not in EXT32:
+            try:
+                G2 = ga.GF(q)
+            except LookupError:  # no Conway polynomial in the shipped table
+                EXT32_ORDERS.remove(q)
+                continue
+            EXT32[q] = (G2, O.OracleField(G2.characteristic, G2.degree, int(G2.irreducible_poly), int(G2.primitive_element), lookup=True))
+        G2, F2 = EXT32[q]
+        n = int(rng.choice([1024, 1500, 4099, 20000, 70001]))
+        off = int(rng.integers(0, 2)) * int(rng.integers(1, 5))
+        a = rng.integers(0, q, n + off, dtype=np.uint64)
+        b = rng.integers(1, q, n + off, dtype=np.uint64)
+        a[rng.integers(0, n + off, 8)] = 0
+        a[rng.integers(0, n + off, 8)] = q - 1
+        b[rng.integers(0, n + off, 8)] = q - 1
+        b[rng.integers(0, n + off, 8)] = G2.characteristic
+        A, B = (G2(v.astype(np.uint32), dtype=np.uint32)[off:] for v in (a, b))
+        a, b = a[off:], b[off:]
+        u64 = lambda v: v.numpy().astype(np.uint64)
+        k = int(rng.integers(0, n))
+        full = lambda v: np.full(n, v, dtype=np.uint64)
+        for got, want, what in ((A + B, F2.add(a, b), "add"), (A - B, F2.sub(a, b), "sub"), (-A, F2.neg(a), "neg"), (A * B, F2.mul(a, b), "mul"),
+                                (A / B, F2.div(a, b), "div"), (np.reciprocal(B), F2.recip(b), "recip"),
+                                (A / B[k], F2.div(a, full(b[k])), "array / scalar"), (A[k] / B, F2.div(full(a[k]), b), "scalar / array"),
+                                (A * B[k], F2.mul(a, full(b[k])), "array * scalar")):
+            assert np.array_equal(u64(got), want), ("ext32", q, what, n, off)
+        if (a == 0).any():
+            try:
+                B / A
+                raise AssertionError(("expected ZeroDivisionError", q))
+            except ZeroDivisionError:
+                pass
+        counts["ext32"] += 1
     elif u < 0.72:
         p, GF, F, adic = POOL[int(rng.integers(0, len(POOL)))]
         na, nb = int(rng.integers(1500, 6000)), int(rng.integers(1500, 6000))
