@@ -1579,7 +1579,8 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
     // GF(997^2) 0.67, GF(97^3) 0.47, GF(31^4) 0.33, GF(13^5) 0.25, GF(7^7) 0.15, GF(5^8) 0.13 (profiles/r05_ew_extcalc.txt) -- and, in
     // degree 2, for quotients (0.15 vs 0.06).  Same values either way; a field pinned to jit-lookup keeps its tables.
     if (f->mode == GFA_MODE_AUTO && f->calc.m > 1 && (f->calc.p & 1) && f->calc.q > 65536 && f->calc.kind == KIND_EXT && Ext::fixed_degree(f->calc) &&
-        (op == GFA_OP_MUL || (op == GFA_OP_DIV && (f->calc.m == 2 || (f->calc.m == 3 && packed_divn_eligible(f->calc, dtype, n)))))) {
+        (op == GFA_OP_MUL || (op == GFA_OP_DIV && (f->calc.m == 2 || (f->calc.m == 3 && packed_divn_eligible(f->calc, dtype, n)) ||
+                                                   (f->has_lut && packed_divt_eligible(f->calc, dtype, n)))))) {
         // products: digits through LDS tables and no reduction before the end (gfa_packed.h::mul_digits) where the 32-bit bound holds
         if (op == GFA_OP_MUL && packed_mul_eligible(f->calc, dtype, n, false)) {
             rc = packed_mul_run(f->calc, dtype, a, sa, b, sb, out, n, st);
@@ -1589,6 +1590,14 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
         if (op == GFA_OP_DIV && packed_divn_eligible(f->calc, dtype, n)) {
             rc = packed_divn_run(f->calc, dtype, a, sa, b, sb, out, n, st, dev_err);
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
+        }
+        // r06: degrees 4 .. 8: 1 / b by one gather from the 3-byte inverse table, then the digit-table product (profiles/r06_ew_divt.txt)
+        if (op == GFA_OP_DIV && f->calc.m >= 4 && f->has_lut && packed_divt_eligible(f->calc, dtype, n)) {
+            const uint8_t *inv24 = nullptr;
+            if ((rc = f->inverse_table(*ds, &inv24))) return rc;
+            rc = packed_divt_run(f->calc, inv24, a, sa, b, sb, out, n, st, dev_err);
+            if (rc != GFA_ERR_UNSUPPORTED) return rc;
+            return dispatch_binary(f->lut_desc(*ds), dtype, op, a, sa, b, sb, out, n, st, dev_err);
         }
         return dispatch_binary(f->calc, dtype, op, a, sa, b, sb, out, n, st, dev_err);
     }
@@ -1659,6 +1668,13 @@ int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int d
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
         return dispatch_unary(f->calc, dtype, op, a, out, n, st, dev_err);
+    }
+    if (f->mode == GFA_MODE_AUTO && op == GFA_OP_RECIP && f->calc.kind == KIND_EXT && (f->calc.p & 1) && f->calc.m >= 4 && f->has_lut && f->calc.q > 65536 &&
+        dtype == GFA_U32 && n >= 1024) { // r06: one gather from the 3-byte inverse table where LOG + EXP are two
+        const uint8_t *inv24 = nullptr;
+        if ((rc = f->inverse_table(*ds, &inv24))) return rc;
+        rc = packed_divt_run(f->calc, inv24, nullptr, 0, a, 1, out, n, st, dev_err);
+        if (rc != GFA_ERR_UNSUPPORTED) return rc;
     }
     if (f->use_lookup()) {
         const FieldDev &c = f->calc;

@@ -223,6 +223,76 @@ __global__ __launch_bounds__(PK_THREADS) void packed_div3_kernel(Div3Aux ax, con
     if (bad && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
 }
 
+// quotients / reciprocals of the degrees Cramer's rule does not reach (4 .. 8), uint32 arrays, 65536 < q <= 2^20 (r06): 1 / b is ONE gather from
+// the field's 3-byte inverse table (gfa_field::inverse_table: 2.4 MB for GF(7^7), inside one XCD's L2, where LOG + EXP were two gathers out of
+// 6.6 MB), the quotient a * (1 / b) the digit-table product of packed_mul_kernel.  Gathers run one iteration ahead of the products, operand loads two.
+typedef pu32 __attribute__((aligned(1))) pu32_unaligned;
+__device__ __forceinline__ pu32 inv24_load(const uint8_t *__restrict__ t, pu32 x) { return *reinterpret_cast<const pu32_unaligned *>(t + 3u * x) & 0xffffffu; }
+
+template <int M, bool RECIP>
+__global__ __launch_bounds__(PK_THREADS) void packed_divt_kernel(Plan pl, MulAux ax, const pu32 *__restrict__ gtab, const uint8_t *__restrict__ inv24,
+                                                                  const uint32_t *__restrict__ a, int sa, const uint32_t *__restrict__ b, int sb,
+                                                                  uint32_t *__restrict__ out, i64 n, int *err)
+{
+    constexpr int V = 4;
+    extern __shared__ pu32 pk_tab[];
+    if (!RECIP) {
+        for (pu32 i = threadIdx.x; i < pl.off_un; i += PK_THREADS) pk_tab[i] = gtab[i];
+        __syncthreads();
+    }
+    const i64 nvec = n / V, S = (i64)gridDim.x * PK_THREADS;
+    const pu32 a0 = (RECIP || sa) ? 0u : a[0], b0 = sb ? 1u : b[0];
+    bool bad = b0 == 0u;
+    const uint4 *av = reinterpret_cast<const uint4 *>(a), *bv = reinterpret_cast<const uint4 *>(b);
+    uint4 *ov = reinterpret_cast<uint4 *>(out);
+    // No branch around a gather (each would get its own wait): a scalar operand is a vector of copies, loads past the end re-read the last
+    // vector (always there: n >= 1024) -- their zero flags are masked, their results not stored.
+    const i64 last = nvec - 1;
+    auto load_b = [&](i64 k) { uint4 x = make_uint4(b0, b0, b0, b0); if (sb) x = bv[k < nvec ? k : last]; return x; };
+    auto load_a = [&](i64 k) { uint4 x = make_uint4(a0, a0, a0, a0); if (!RECIP && sa) x = av[k < nvec ? k : last]; return x; };
+    i64 i = (i64)blockIdx.x * PK_THREADS + threadIdx.x;
+    uint4 xb2 = load_b(i + S), xa0, xa1 = load_a(i);
+    pu32 g0[V], g1[V];
+    {
+        pu32 e[V];
+        unpack_vec<uint32_t>(load_b(i), e);
+#pragma unroll
+        for (int j = 0; j < V; j++) { g1[j] = inv24_load(inv24, e[j]); bad |= e[j] == 0u && i < nvec; }
+    }
+    for (; i < nvec; i += S) {
+        xa0 = xa1;
+#pragma unroll
+        for (int j = 0; j < V; j++) g0[j] = g1[j];
+        { // gathers of the next iteration, operand loads of the one after
+            pu32 e[V];
+            unpack_vec<uint32_t>(xb2, e);
+#pragma unroll
+            for (int j = 0; j < V; j++) { g1[j] = inv24_load(inv24, e[j]); bad |= e[j] == 0u && i + S < nvec; }
+            xb2 = load_b(i + 2 * S);
+            xa1 = load_a(i + S);
+        }
+        pu32 r[V];
+        if (RECIP) {
+#pragma unroll
+            for (int j = 0; j < V; j++) r[j] = g0[j];
+        } else {
+            pu32 e[V];
+            unpack_vec<uint32_t>(xa0, e);
+#pragma unroll
+            for (int j = 0; j < V; j++) r[j] = mul_digits<M>(pl, ax, to_packed(pl, pk_tab, e[j]), to_packed(pl, pk_tab, g0[j]));
+        }
+        ov[i] = pack_vec<uint32_t>(r);
+    }
+    const i64 t0 = nvec * V + (i64)blockIdx.x * PK_THREADS + threadIdx.x;
+    if (t0 < n) {
+        const pu32 xb = sb ? b[t0] : b0;
+        bad |= xb == 0u;
+        const pu32 ib = inv24_load(inv24, xb);
+        out[t0] = RECIP ? ib : mul_digits<M>(pl, ax, to_packed(pl, pk_tab, sa ? a[t0] : a0), to_packed(pl, pk_tab, ib));
+    }
+    if (bad && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
+}
+
 struct PackedDev {
     Plan pl;
     pu32 *tab = nullptr;
@@ -480,6 +550,49 @@ int packed_divn_run(const FieldDev &c, int dtype, const void *a, i64 sa, const v
     if (c.m == 3) launch_div3<uint32_t>(recip, grid, a3, inv, a, sa, b, sb, out, n, st, dev_err);
     else if (dtype == GFA_U32) launch_div2<uint32_t>(recip, grid, a2, inv, a, sa, b, sb, out, n, st, dev_err);
     else launch_div2<uint16_t>(recip, grid, a2, inv, a, sa, b, sb, out, n, st, dev_err);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+// quotients / reciprocals (a == nullptr) of GF(p^m), m = 4 .. 8, odd p, 65536 < q <= 2^20, uint32 arrays (r06)
+bool packed_divt_eligible(const FieldDev &c, int dtype, i64 n)
+{
+    Plan pl;
+    MulAux mx;
+    return dtype == GFA_U32 && n >= 1024 && c.m >= 4 && c.q > 65536 && packed_mul_aux(c, &pl, &mx, true);
+}
+
+int packed_divt_run(const FieldDev &c, const uint8_t *inv24, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int *dev_err)
+{
+    const bool recip = a == nullptr;
+    if (!inv24 || !al16p(out) || (!recip && sa && !al16p(a)) || (sb && !al16p(b))) return GFA_ERR_UNSUPPORTED;
+    if (recip && n >= 1024 && c.q > 65536) { // the gather alone: whatever the degree (GF(3^11), GF(3^12) have no one-word digit plan)
+        const i64 blocks = std::max<i64>(1, (n / 4 + PK_THREADS - 1) / PK_THREADS);
+        hipLaunchKernelGGL((packed_divt_kernel<4, true>), dim3((int)std::min<i64>(blocks, (i64)num_cus() * 4)), dim3(PK_THREADS), 0, st, Plan{}, MulAux{},
+                           (const pu32 *)nullptr, inv24, (const uint32_t *)nullptr, 0, (const uint32_t *)b, (int)sb, (uint32_t *)out, n, dev_err);
+        GFA_HIP(hipGetLastError());
+        return GFA_OK;
+    }
+    if (!packed_divt_eligible(c, GFA_U32, n)) return GFA_ERR_UNSUPPORTED;
+    PackedDev d;
+    MulAux ax;
+    Plan pl;
+    if (!packed_mul_aux(c, &pl, &ax, true)) return GFA_ERR_UNSUPPORTED;
+    const int rc = get_dev(c, &d);
+    if (rc) return rc;
+    const i64 blocks = std::max<i64>(1, (n / 4 + PK_THREADS - 1) / PK_THREADS);
+    const int grid = (int)std::min<i64>(blocks, (i64)num_cus() * 4);
+    const size_t lds = sizeof(pu32) * d.pl.off_un;
+#define GFA_PKD(MV)                                                                                                                      \
+    case MV:                                                                                                                             \
+        hipLaunchKernelGGL((packed_divt_kernel<MV, false>), dim3(grid), dim3(PK_THREADS), lds, st, d.pl, ax, (const pu32 *)d.tab, inv24, \
+                           (const uint32_t *)a, (int)sa, (const uint32_t *)b, (int)sb, (uint32_t *)out, n, dev_err);                     \
+        break;
+    switch (c.m) {
+        GFA_PKD(4) GFA_PKD(5) GFA_PKD(6) GFA_PKD(7) GFA_PKD(8)
+    default: return GFA_ERR_UNSUPPORTED;
+    }
+#undef GFA_PKD
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }

@@ -266,6 +266,24 @@ int gfa_field::ensure_device(int *device_out, gfa::FieldDeviceState **st_out)
     return GFA_OK;
 }
 
+int gfa_field::inverse_table(gfa::FieldDeviceState &st, const uint8_t **out)
+{
+    std::lock_guard<std::mutex> lock(mu);
+    if (!st.inv24) {
+        if (!has_lut || calc.q > ((u64)1 << 24)) return GFA_ERR_UNSUPPORTED;
+        const size_t q = (size_t)calc.q;
+        std::vector<uint8_t> t(3 * q + 4, 0);
+        for (size_t x = 1; x < q; x++) {
+            const u32 v = h_exp[(q - 1) - h_log[x]]; // EXP[q - 1] = EXP[0] = 1
+            t[3 * x] = (uint8_t)v; t[3 * x + 1] = (uint8_t)(v >> 8); t[3 * x + 2] = (uint8_t)(v >> 16);
+        }
+        int rc;
+        if ((rc = upload(&st.inv24, t))) return rc;
+    }
+    *out = st.inv24;
+    return GFA_OK;
+}
+
 static u64 neg_inverse_mod_2_64(u64 p)
 { // Newton iteration: x <- x * (2 - p*x), doubling the number of correct low bits each step
     u64 x = p; // correct to 3 bits for odd p
@@ -416,7 +434,7 @@ void gfa_field_destroy(gfa_field_t *f)
         (void)hipFree(st.exp_tab); (void)hipFree(st.log_tab); (void)hipFree(st.zech_tab);
         (void)hipFree(st.mul8); (void)hipFree(st.add8); (void)hipFree(st.sub8); (void)hipFree(st.div8);
         (void)hipFree(st.inv8); (void)hipFree(st.neg8); (void)hipFree(st.exp8); (void)hipFree(st.log8);
-        (void)hipFree(st.mid16);
+        (void)hipFree(st.mid16); (void)hipFree(st.inv24);
     }
     delete f;
 }

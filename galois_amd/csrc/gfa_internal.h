@@ -89,6 +89,10 @@ bool packed_mul_eligible(const FieldDev &calc, int dtype, i64 n, bool pinned_to_
 // (Cramer's rule; div3), uint16 / uint32 arrays
 bool packed_divn_eligible(const FieldDev &calc, int dtype, i64 n);
 int packed_divn_run(const FieldDev &calc, int dtype, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int *dev_err);
+// r06: quotients / reciprocals of degrees 4 .. 8 (uint32 arrays, 65536 < q <= 2^20): ONE gather from the field's 3-byte inverse table, then the
+// digit-table product; inv24 from gfa_field::inverse_table
+bool packed_divt_eligible(const FieldDev &calc, int dtype, i64 n);
+int packed_divt_run(const FieldDev &calc, const uint8_t *inv24, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int *dev_err);
 int packed_mul_run(const FieldDev &calc, int dtype, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st);
 bool big16_eligible(const FieldDev &calc, const void *image, int dtype, i64 n);
 // uint32 / int64 storage of the same fields: narrowed into a 16-bit work buffer, run, widened (first n & ~7 elements)
@@ -119,6 +123,9 @@ struct FieldDeviceState {
     // 256 < q <= 8192: LOG[qa] | EXP[2 qa] | ZECH[qa] as 16-bit entries, qa = q rounded up to a multiple of 8 -- the image the
     // LDS-table kernels of gfa_elementwise_mid.hip stage with 16-byte copies; 8192 < q <= 65536: LOG[qa] | EXP[qa] | ZECH[qa]
     uint16_t *mid16 = nullptr;
+    // r06, 65536 < q <= 2^20, built on first use (gfa_field::inverse_table): INV[x] = 1 / x as 3-byte entries at byte 3 x
+    // (INV[0] = 0; 4 bytes of padding behind the last entry) -- one gather where LOG + EXP are two, from a table that fits one XCD's L2
+    uint8_t *inv24 = nullptr;
 };
 
 // can the storage dtype hold every element of a field of order q?
@@ -200,6 +207,7 @@ struct gfa_field {
     bool use_lookup() const;
     int ensure_device(int *device_out, gfa::FieldDeviceState **st_out); // lazy upload to the current device
     gfa::FieldDev lut_desc(const gfa::FieldDeviceState &st) const;      // descriptor with kind = KIND_LUT
+    int inverse_table(gfa::FieldDeviceState &st, const uint8_t **out);  // st.inv24, uploaded on first use (has_lut, q <= 2^24)
 };
 
 struct gfa_rs {

@@ -1179,3 +1179,75 @@ def test_degree_three_quotients_by_cramers_rule(order):
         y / x
     with pytest.raises(ZeroDivisionError):
         np.reciprocal(x)
+
+
+@pytest.mark.parametrize("order", [7**7, 5**8, 13**5, 11**5, 31**4, 17**4, 7**6, 5**7])
+def test_quotients_of_degrees_four_to_eight_by_the_inverse_table(order):
+    """r06: a / b and 1 / b over GF(p^m), m = 4 .. 8, 65536 < q <= 2^20, uint32 arrays: 1 / b is one gather from the field's 3-byte inverse
+    table (gfa_field::inverse_table), the quotient the digit-table product a * (1 / b) (packed_divt_kernel) -- the reference divides
+    through LOG / EXP tables (_lookup.py:176-235).  Every element against the oracle's lookup scalars, with tails shorter than a vector,
+    broadcast scalars on either side, a misaligned view (table kernels), in place, a length past two grid strides, zero divisors flagged
+    wherever they sit (first vector, a look-ahead vector, the tail)."""
+    try:
+        GF = ga.GF(order)
+    except LookupError:
+        pytest.skip("no Conway polynomial for this field in the shipped table")
+    F = O.OracleField(GF.characteristic, GF.degree, int(GF.irreducible_poly), int(GF.primitive_element), lookup=True)
+    p = GF.characteristic
+    u = lambda v: v.numpy().astype(np.uint64)
+    rng = np.random.default_rng(order % 977)
+    for n in (1027, 40_003, 2 * 1024 * 512 * 4 + 4 * 512 * 7 + 2):  # the last: every workgroup runs two full strides, some a third, then the tail
+        a = rng.integers(0, order, n, dtype=np.uint64)
+        b = rng.integers(1, order, n, dtype=np.uint64)
+        a[:4] = (0, order - 1, 1, p)
+        b[:7] = (1, order - 1, p, p - 1, p + 1, p * p, order - p)
+        x, y = GF(a.astype(np.uint32)), GF(b.astype(np.uint32))
+        H.assert_equal_ints(u(x / y), F.div(a, b), f"GF({order}) div n={n}")
+        H.assert_equal_ints(u(np.reciprocal(y)), F.div(np.ones(n, dtype=np.uint64), b), f"GF({order}) reciprocal n={n}")
+    n = 40_003
+    s = GF(int(b[9]))
+    a, b, x, y = a[:n], b[:n], x[:n], y[:n]
+    H.assert_equal_ints(u(x / s), F.div(a, np.full(n, b[9], dtype=np.uint64)), "scalar divisor")
+    H.assert_equal_ints(u(s / y), F.div(np.full(n, b[9], dtype=np.uint64), b), "scalar dividend")
+    H.assert_equal_ints(u(x[1:] / y[1:]), F.div(a[1:], b[1:]), "misaligned views")
+    z = x.copy()
+    np.true_divide(z, y, out=z)
+    H.assert_equal_ints(u(z), F.div(a, b), "in place")
+    H.assert_equal_ints(u((x / y) * y), a, "round trip")
+    for where in (0, 5, 4 * 512 * 3 + 1, n - 1):  # first vector, inside, a vector the look-ahead of another thread reads, the tail
+        bz = b.copy()
+        bz[where] = 0
+        yz = GF(bz.astype(np.uint32))
+        with pytest.raises(ZeroDivisionError):
+            x / yz
+        with pytest.raises(ZeroDivisionError):
+            np.reciprocal(yz)
+    with pytest.raises(ZeroDivisionError):
+        x / GF(0)
+    # a field pinned to jit-lookup keeps the LOG / EXP gathers and agrees
+    GF.compile("jit-lookup")
+    try:
+        H.assert_equal_ints(u(x / y), F.div(a, b), "jit-lookup")
+    finally:
+        GF.compile("auto")
+
+
+@pytest.mark.parametrize("order", [3**11, 3**12])
+def test_reciprocals_of_the_degrees_above_eight_by_the_inverse_table(order):
+    """r06: 1 / b over GF(3^11), GF(3^12) (no one-word digit plan, so no digit-table product): the gather from the 3-byte inverse table alone;
+    quotients stay on the LOG / EXP tables.  Every element against the oracle's lookup scalars, tails, zero flagged."""
+    GF = ga.GF(order)
+    F = O.OracleField(GF.characteristic, GF.degree, int(GF.irreducible_poly), int(GF.primitive_element), lookup=True)
+    u = lambda v: v.numpy().astype(np.uint64)
+    rng = np.random.default_rng(order % 977)
+    for n in (1025, 70_003):
+        b = rng.integers(1, order, n, dtype=np.uint64)
+        b[:5] = (1, order - 1, 3, 2, order - 3)
+        y = GF(b.astype(np.uint32))
+        H.assert_equal_ints(u(np.reciprocal(y)), F.recip(b), f"GF({order}) reciprocal n={n}")
+        H.assert_equal_ints(u(y ** -1), F.recip(b), f"GF({order}) ** -1 n={n}")
+        H.assert_equal_ints(u(GF(1) / y), F.recip(b), f"GF({order}) 1 / y n={n}")
+        H.assert_equal_ints(u(np.reciprocal(y[3:])), F.recip(b[3:]), "misaligned view")
+    b[n - 1] = 0
+    with pytest.raises(ZeroDivisionError):
+        np.reciprocal(GF(b.astype(np.uint32)))
