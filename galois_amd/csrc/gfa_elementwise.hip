@@ -808,8 +808,15 @@ __global__ __launch_bounds__(256) void bin16_holes_mul_kernel(const uint16_t *__
 // part above x^m is reduced through four 256-entry tables in LDS, one per byte of it (h(x) x^(m+8k) mod f, k = 0..3; each table is
 // the previous one times x^8, so building them costs eight reduction steps per entry) instead of `rounds` folds of one 64-bit
 // shift-and-xor per term of the irreducible polynomial (GF(2^32): 2 x 6 terms).
+//
+// r06, DIV (17 <= m <= 20, AUTO): the divisor is replaced by its inverse through ONE gather from the field's 3-byte inverse table
+// (gfa_field::inverse_table) before the same product -- Itoh-Tsujii chains of these products ran at 0.12 of the roofline.
+typedef u32 __attribute__((aligned(1))) u32_unaligned;
+__device__ __forceinline__ u32 inv24_at(const uint8_t *__restrict__ t, u32 x) { return *reinterpret_cast<const u32_unaligned *>(t + 3u * x) & 0xffffffu; }
+
+template <bool DIV>
 __global__ __launch_bounds__(256) void bin32_tab_mul_kernel(const u32 *__restrict__ a, int sa, const u32 *__restrict__ b, int sb,
-                                                            u32 *__restrict__ out, i64 n, int m, u64 irr)
+                                                            u32 *__restrict__ out, i64 n, int m, u64 irr, const uint8_t *__restrict__ inv24, int *err)
 {
     __shared__ u32 R[4 * 256];
     {
@@ -833,20 +840,42 @@ __global__ __launch_bounds__(256) void bin32_tab_mul_kernel(const u32 *__restric
     };
     const i64 nvec = n / 4;
     const u32 a0 = sa ? 0u : a[0], b0 = sb ? 0u : b[0];
+    bool bad = false;
     for (i64 blk = (i64)blockIdx.x * BIN16_VECS; blk * 256 < nvec; blk += (i64)gridDim.x * BIN16_VECS) {
 #pragma unroll 1
         for (int k = 0; k < BIN16_VECS; k++) {
             const i64 i = (blk + k) * 256 + threadIdx.x;
             if (i >= nvec) break;
             const uint4 av = sa ? reinterpret_cast<const uint4 *>(a)[i] : make_uint4(a0, a0, a0, a0);
-            const uint4 bv = sb ? reinterpret_cast<const uint4 *>(b)[i] : make_uint4(b0, b0, b0, b0);
+            uint4 bv = sb ? reinterpret_cast<const uint4 *>(b)[i] : make_uint4(b0, b0, b0, b0);
+            if (DIV) {
+                bad |= bv.x == 0u || bv.y == 0u || bv.z == 0u || bv.w == 0u;
+                bv = make_uint4(inv24_at(inv24, bv.x), inv24_at(inv24, bv.y), inv24_at(inv24, bv.z), inv24_at(inv24, bv.w));
+            }
             uint4 ov;
             ov.x = mul1(av.x, bv.x); ov.y = mul1(av.y, bv.y); ov.z = mul1(av.z, bv.z); ov.w = mul1(av.w, bv.w);
             reinterpret_cast<uint4 *>(out)[i] = ov;
         }
     }
     const i64 tid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    for (i64 i = nvec * 4 + tid; i < n; i += (i64)gridDim.x * blockDim.x) out[i] = mul1(a[sa ? i : 0], b[sb ? i : 0]);
+    for (i64 i = nvec * 4 + tid; i < n; i += (i64)gridDim.x * blockDim.x) {
+        u32 y = b[sb ? i : 0];
+        if (DIV) { bad |= y == 0u; y = inv24_at(inv24, y); }
+        out[i] = mul1(a[sa ? i : 0], y);
+    }
+    if (DIV && bad && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
+}
+
+// quotients of GF(2^m), 17 <= m <= 20, uint32 arrays, through the inverse table (see bin32_tab_mul_kernel); GFA_ERR_UNSUPPORTED: not this shape
+int bin32_div_by_table(const FieldDev &fd, const uint8_t *inv24, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int32_t *err)
+{
+    if (fd.kind != KIND_BIN || fd.m < 17 || fd.m > 20 || !inv24 || n < 1024 || !aligned16(out) || (sa && !aligned16(a)) || (sb && !aligned16(b)))
+        return GFA_ERR_UNSUPPORTED;
+    const int hgrid = grid_flat((n + 4 * BIN16_VECS - 1) / (4 * BIN16_VECS), 256);
+    hipLaunchKernelGGL(bin32_tab_mul_kernel<true>, dim3(hgrid), dim3(256), 0, st, (const u32 *)a, (int)sa, (const u32 *)b, (int)sb, (u32 *)out, n,
+                       (int)fd.m, (u64)fd.irr, inv24, err);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
 }
 
 // GF(p^m), 2 <= m <= 8, calculate mode: the kernels are instantiated per degree (ExtM<M>: digit arrays in registers)
@@ -897,8 +926,8 @@ int dispatch_binary(const FieldDev &fd, int dtype, int op, const void *a, i64 sa
     if (fd.kind == KIND_BIN && op == GFA_OP_MUL && dtype == GFA_U32 && fd.m >= 17 && fd.m <= 32 && aligned16(out) && (sa == 0 || aligned16(a)) &&
         (sb == 0 || aligned16(b))) {
         const int hgrid = grid_flat((n + 4 * BIN16_VECS - 1) / (4 * BIN16_VECS), 256);
-        hipLaunchKernelGGL(bin32_tab_mul_kernel, dim3(hgrid), dim3(256), 0, st, (const u32 *)a, (int)sa, (const u32 *)b, (int)sb, (u32 *)out, n,
-                           (int)fd.m, (u64)fd.irr);
+        hipLaunchKernelGGL(bin32_tab_mul_kernel<false>, dim3(hgrid), dim3(256), 0, st, (const u32 *)a, (int)sa, (const u32 *)b, (int)sb, (u32 *)out, n,
+                           (int)fd.m, (u64)fd.irr, (const uint8_t *)nullptr, (int *)nullptr);
         GFA_HIP(hipGetLastError());
         return GFA_OK;
     }
@@ -1517,6 +1546,14 @@ int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b,
         rc = packed_mul_run(f->calc, dtype, a, sa, b, sb, out, n, st);
         if (rc != GFA_ERR_UNSUPPORTED) return rc;
     }
+    // r06, AUTO only: GF(2^17) .. GF(2^20) quotients: one gather from the 3-byte inverse table, then the carry-less product (0.12 -> see
+    // profiles/r06_ew_bin_inverse_table.txt); a field pinned to either mode keeps what it asked for
+    if (f->mode == GFA_MODE_AUTO && op == GFA_OP_DIV && f->calc.kind == KIND_BIN && dtype == GFA_U32 && f->has_lut && f->calc.m >= 17 && n >= 1024) {
+        const uint8_t *inv24 = nullptr;
+        if ((rc = f->inverse_table(*ds, &inv24))) return rc;
+        rc = bin32_div_by_table(f->calc, inv24, a, sa, b, sb, out, n, st, dev_err);
+        if (rc != GFA_ERR_UNSUPPORTED) return rc;
+    }
     // r06, AUTO only: GF(p^m), p odd, 32768 < q <= 65536 (GF(181^2) .. GF(251^2), GF(37^3)): LOG / EXP no longer fit LDS together, the staged
     // kernels below run products and quotients at 0.40 (uint16) / 0.27 (uint32); the digit tables of gfa_packed.h stream
     // (measured, profiles/r06_ew_band16.txt: uint32 arrays -- products 0.27 -> 0.68, GF(p^2) quotients 0.27 -> 0.54; uint16 arrays -- GF(p^2)
@@ -1669,7 +1706,7 @@ int gfa_unary(gfa_field_t *f, int op, const void *a, void *out, int64_t n, int d
         }
         return dispatch_unary(f->calc, dtype, op, a, out, n, st, dev_err);
     }
-    if (f->mode == GFA_MODE_AUTO && op == GFA_OP_RECIP && f->calc.kind == KIND_EXT && (f->calc.p & 1) && f->calc.m >= 4 && f->has_lut && f->calc.q > 65536 &&
+    if (f->mode == GFA_MODE_AUTO && op == GFA_OP_RECIP && ((f->calc.kind == KIND_EXT && (f->calc.p & 1) && f->calc.m >= 4) || f->calc.kind == KIND_BIN) && f->has_lut && f->calc.q > 65536 &&
         dtype == GFA_U32 && n >= 1024) { // r06: one gather from the 3-byte inverse table where LOG + EXP are two
         const uint8_t *inv24 = nullptr;
         if ((rc = f->inverse_table(*ds, &inv24))) return rc;
@@ -1722,7 +1759,7 @@ int gfa_power(gfa_field_t *f, const void *a, int64_t sa, const int64_t *exps, in
         }
     }
     // GF(2^m), m <= 16, in AUTO: square-and-multiply over shift-and-xor products is far behind two table gathers (14 vs 86 Gop/s)
-    const bool bin_tables = f->mode == GFA_MODE_AUTO && f->has_lut && f->calc.kind == KIND_BIN && f->calc.q <= 65536;
+    const bool bin_tables = f->mode == GFA_MODE_AUTO && f->has_lut && f->calc.kind == KIND_BIN; // r06: also GF(2^17) .. GF(2^20) (17 -> see profiles/r06_ew_bin_inverse_table.txt)
     if (f->use_lookup() || bin_tables)
         return dispatch_intarg(f->lut_desc(*ds), dtype, true, a, sa, exps, se, out, n, (hipStream_t)stream, dev_err);
     return dispatch_intarg(f->calc, dtype, true, a, sa, exps, se, out, n, (hipStream_t)stream, dev_err);

@@ -1251,3 +1251,52 @@ def test_reciprocals_of_the_degrees_above_eight_by_the_inverse_table(order):
     b[n - 1] = 0
     with pytest.raises(ZeroDivisionError):
         np.reciprocal(GF(b.astype(np.uint32)))
+
+
+@pytest.mark.parametrize("m", [17, 18, 20])
+def test_binary_fields_of_2e17_to_2e20_elements_divide_through_the_inverse_table(m):
+    """r06: GF(2^17) .. GF(2^20) in AUTO: a / b = the carry-less product a * INV[b] with one gather from the 3-byte inverse table
+    (bin32_tab_mul_kernel<true>), 1 / b the gather alone, x ** k through LOG / EXP (the reference's lookup ufuncs, _lookup.py:176-270) --
+    against the oracle's explicit arithmetic, with tails, scalars on either side, misaligned views, zero divisors, negative exponents;
+    the pinned modes agree."""
+    GF = ga.GF(2**m)
+    order = 2**m
+    F = O.OracleField(2, m, int(GF.irreducible_poly), int(GF.primitive_element))
+    u = lambda v: v.numpy().astype(np.uint64)
+    rng = np.random.default_rng(m)
+    n = 50_003
+    a = rng.integers(0, order, n, dtype=np.uint64)
+    b = rng.integers(1, order, n, dtype=np.uint64)
+    a[:3] = (0, order - 1, 1)
+    b[:4] = (1, order - 1, 2, order // 2)
+    x, y = GF(a.astype(np.uint32)), GF(b.astype(np.uint32))
+    want = F.div(a, b)
+    H.assert_equal_ints(u(x / y), want, "div")
+    H.assert_equal_ints(u(np.reciprocal(y)), F.recip(b), "reciprocal")
+    H.assert_equal_ints(u(x[:1025] / y[:1025]), want[:1025], "short, one-element tail")
+    H.assert_equal_ints(u(x[1:] / y[1:]), want[1:], "misaligned views")
+    s = GF(int(b[9]))
+    H.assert_equal_ints(u(x / s), F.div(a, np.full(n, b[9], dtype=np.uint64)), "scalar divisor")
+    H.assert_equal_ints(u(s / y), F.div(np.full(n, b[9], dtype=np.uint64), b), "scalar dividend")
+    H.assert_equal_ints(u((x / y) * y), a, "round trip")
+    for k in (0, 1, 2, 12345, -1, -7, order - 1, order + 5):
+        H.assert_equal_ints(u(y ** k), F.pow(b, np.full(n, k, dtype=np.int64)), f"y ** {k}")
+    ks = rng.integers(-order, order, n)
+    H.assert_equal_ints(u(y ** ks), F.pow(b, ks.astype(np.int64)), "exponent array")
+    for where in (0, 4 * 256 * 8 + 2, n - 1):
+        bz = b.copy()
+        bz[where] = 0
+        yz = GF(bz.astype(np.uint32))
+        with pytest.raises(ZeroDivisionError):
+            x / yz
+        with pytest.raises(ZeroDivisionError):
+            np.reciprocal(yz)
+        with pytest.raises(ZeroDivisionError):
+            yz ** -1
+    for mode in ("jit-calculate", "jit-lookup"):
+        GF.compile(mode)
+        try:
+            H.assert_equal_ints(u(x / y), want, mode)
+            H.assert_equal_ints(u(y ** -7), F.pow(b, np.full(n, -7, dtype=np.int64)), mode + " power")
+        finally:
+            GF.compile("auto")

@@ -30,6 +30,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--band16":  # r06: GF(p^m), 32768 < q <
     cases = [(251**2, np.uint16, "auto"), (251**2, np.uint32, "auto"), (37**3, np.uint16, "auto"), (251**2, np.uint16, "jit-lookup"), (3**10, np.uint16, "auto")]
 if len(sys.argv) > 1 and sys.argv[1] == "--div3":  # r06: degree-3 quotients by Cramer's rule
     cases = [(97**3, np.uint32, "auto"), (41**3, np.uint32, "auto"), (97**3, np.uint32, "jit-lookup")]
+if len(sys.argv) > 1 and sys.argv[1] == "--bininv":  # r06: GF(2^17) .. GF(2^20): quotients / reciprocals through the 3-byte inverse table, powers through LOG / EXP
+    cases = [(2**20, np.uint32, "auto"), (2**17, np.uint32, "auto"), (2**20, np.uint32, "jit-calculate"), (2**20, np.uint32, "jit-lookup")]
 if len(sys.argv) > 1 and sys.argv[1] == "--divt":  # r06: quotients of degrees 4 .. 8: one gather from the 3-byte inverse table + the digit-table product
     cases = [(7**7, np.uint32, "auto"), (5**8, np.uint32, "auto"), (13**5, np.uint32, "auto"), (31**4, np.uint32, "auto"), (7**6, np.uint32, "auto"), (3**11, np.uint32, "auto"), (3**12, np.uint32, "auto"), (7**7, np.uint32, "jit-lookup")]
 if len(sys.argv) > 1 and sys.argv[1] == "--div2":  # r06: degree-2 quotients by the norm
