@@ -11,6 +11,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <type_traits>
 
 #include "gfa_internal.h"
 #include "gfa_packed.h"
@@ -154,13 +155,16 @@ __global__ __launch_bounds__(PK_THREADS) void packed_mul_kernel(Plan pl, MulAux 
 }
 
 // quotients / reciprocals of GF(p^2), 32768 < q <= 2^20, uint16 / uint32 arrays: gfa_packed.h::div2 (norm + a p-entry inverse table in LDS)
-template <typename T, bool RECIP>
+// WIDE (r06): 1021 < p <= 37813, the field has no tables at all (q > 2^20): exact digit split, inverse table as 16-bit entries (ginv: (p + 1) / 2 words)
+template <typename T, bool RECIP, bool WIDE = false>
 __global__ __launch_bounds__(PK_THREADS) void packed_div2_kernel(Div2Aux ax, const pu32 *__restrict__ ginv, const T *__restrict__ a, int sa,
                                                                   const T *__restrict__ b, int sb, T *__restrict__ out, i64 n, int *err)
 {
     extern __shared__ pu32 pk_tab[];
-    for (pu32 i = threadIdx.x; i < ax.p; i += PK_THREADS) pk_tab[i] = ginv[i];
+    for (pu32 i = threadIdx.x; i < (WIDE ? (ax.p + 1) / 2 : ax.p); i += PK_THREADS) pk_tab[i] = ginv[i];
     __syncthreads();
+    using IT = typename std::conditional<WIDE, uint16_t, pu32>::type;
+    const IT *inv_tab = reinterpret_cast<const IT *>(pk_tab);
     constexpr int V = PkVec<T>::N;
     const i64 nvec = n / V;
     const uint4 *av = reinterpret_cast<const uint4 *>(a), *bv = reinterpret_cast<const uint4 *>(b);
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(PK_THREADS) void packed_div2_kernel(Div2Aux ax, con
 #pragma unroll
         for (int j = 0; j < V; j++) {
             bool z;
-            r[j] = div2<RECIP>(ax, pk_tab, (!RECIP && sa) ? xa[j] : a0, sb ? xb[j] : b0, &z);
+            r[j] = div2<RECIP, WIDE, IT>(ax, inv_tab, (!RECIP && sa) ? xa[j] : a0, sb ? xb[j] : b0, &z);
             bad |= z;
         }
         ov[i] = pack_vec<T>(r);
@@ -182,14 +186,14 @@ __global__ __launch_bounds__(PK_THREADS) void packed_div2_kernel(Div2Aux ax, con
     const i64 t0 = nvec * V + (i64)blockIdx.x * PK_THREADS + threadIdx.x;
     if (t0 < n) {
         bool z;
-        out[t0] = (T)div2<RECIP>(ax, pk_tab, (!RECIP && sa) ? (pu32)a[t0] : a0, sb ? (pu32)b[t0] : b0, &z);
+        out[t0] = (T)div2<RECIP, WIDE, IT>(ax, inv_tab, (!RECIP && sa) ? (pu32)a[t0] : a0, sb ? (pu32)b[t0] : b0, &z);
         bad |= z;
     }
     if (bad && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
 }
 
 // quotients / reciprocals of GF(p^3), 65536 < q <= 2^20: gfa_packed.h::div3 (Cramer's rule on the multiplication matrix + the same inverse table)
-template <typename T, bool RECIP>
+template <typename T, bool RECIP, bool WIDE = false>
 __global__ __launch_bounds__(PK_THREADS) void packed_div3_kernel(Div3Aux ax, const pu32 *__restrict__ ginv, const T *__restrict__ a, int sa,
                                                                   const T *__restrict__ b, int sb, T *__restrict__ out, i64 n, int *err)
 {
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(PK_THREADS) void packed_div3_kernel(Div3Aux ax, con
 #pragma unroll
         for (int j = 0; j < V; j++) {
             bool z;
-            r[j] = div3<RECIP>(ax, pk_tab, (!RECIP && sa) ? xa[j] : a0, sb ? xb[j] : b0, &z);
+            r[j] = div3<RECIP, WIDE>(ax, pk_tab, (!RECIP && sa) ? xa[j] : a0, sb ? xb[j] : b0, &z);
             bad |= z;
         }
         ov[i] = pack_vec<T>(r);
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(PK_THREADS) void packed_div3_kernel(Div3Aux ax, con
     const i64 t0 = nvec * V + (i64)blockIdx.x * PK_THREADS + threadIdx.x;
     if (t0 < n) {
         bool z;
-        out[t0] = (T)div3<RECIP>(ax, pk_tab, (!RECIP && sa) ? (pu32)a[t0] : a0, sb ? (pu32)b[t0] : b0, &z);
+        out[t0] = (T)div3<RECIP, WIDE>(ax, pk_tab, (!RECIP && sa) ? (pu32)a[t0] : a0, sb ? (pu32)b[t0] : b0, &z);
         bad |= z;
     }
     if (bad && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
@@ -480,40 +484,58 @@ int packed_mul_run(const FieldDev &c, int dtype, const void *a, i64 sa, const vo
     return GFA_OK;
 }
 
-// quotients (reciprocals: a == nullptr) of GF(p^2), odd p, 65536 < q <= 2^20, uint32 arrays (r06)
-static std::map<std::pair<u64, int>, pu32 *> g_inv_tab; // (p, device) -> p-entry inverse table
+// quotients (reciprocals: a == nullptr) of GF(p^2) / GF(p^3), odd p (r06): 32768 < q <= 2^20 on the tight forms; q > 2^20 -- fields without tables,
+// uint32 arrays, p <= 37813 (degree 2) / p <= 1621 (degree 3) -- on the WIDE forms (exact digit split; degree 2: 16-bit inverse table)
+static std::map<std::pair<u64, int>, pu32 *> g_inv_tab; // (p [+ 2^40: 16-bit entries], device) -> p-entry inverse table
+
+static void ext_nir(const FieldDev &c, pu32 *nir)
+{
+    for (u32 j = 0; j < 8; j++) nir[j] = 0;
+    for (u32 j = 0; j < c.m && j < 8; j++) nir[j] = c.ext_irr[c.m - 1 - j] ? (pu32)c.p - c.ext_irr[c.m - 1 - j] : 0u;
+}
+
+static bool divn_wide(const FieldDev &c) { return c.q > ((u64)1 << 20); }
 
 bool packed_divn_eligible(const FieldDev &c, int dtype, i64 n)
 {
-    Plan pl;
-    MulAux mx;
-    if (!(dtype == GFA_U32 || (dtype == GFA_U16 && c.q <= 65536))) return false;
-    if (n < 1024 || c.q <= 32768 || !packed_mul_aux(c, &pl, &mx, true)) return false;
+    if (c.kind != KIND_EXT || (c.p & 1) == 0 || n < 1024 || c.q <= 32768 || c.q > 0xffffffffull || (c.m != 2 && c.m != 3)) return false;
+    pu32 nir[8];
+    ext_nir(c, nir);
     Div2Aux a2;
     Div3Aux a3;
-    return (c.m == 2 && make_div2(c.p, c.m, mx.nir, &a2)) || (c.m == 3 && dtype == GFA_U32 && make_div3(c.p, c.m, mx.nir, &a3));
+    if (divn_wide(c)) return dtype == GFA_U32 && (c.m == 2 ? make_div2(c.p, c.m, nir, &a2, true) : make_div3(c.p, c.m, nir, &a3, true));
+    if (!(dtype == GFA_U32 || (dtype == GFA_U16 && c.q <= 65536))) return false;
+    return (c.m == 2 && make_div2(c.p, c.m, nir, &a2)) || (c.m == 3 && dtype == GFA_U32 && make_div3(c.p, c.m, nir, &a3));
 }
 
-template <typename T>
-static void launch_div3(bool recip, int grid, const Div3Aux &ax, const pu32 *inv, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int *dev_err)
+template <typename T, bool WIDE>
+static int launch_div3(bool recip, int grid, const Div3Aux &ax, const pu32 *inv, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int *dev_err)
 {
     if (recip)
-        hipLaunchKernelGGL((packed_div3_kernel<T, true>), dim3(grid), dim3(PK_THREADS), sizeof(pu32) * ax.p, st, ax, inv, (const T *)nullptr, 0, (const T *)b, (int)sb,
+        hipLaunchKernelGGL((packed_div3_kernel<T, true, WIDE>), dim3(grid), dim3(PK_THREADS), sizeof(pu32) * ax.p, st, ax, inv, (const T *)nullptr, 0, (const T *)b, (int)sb,
                            (T *)out, n, dev_err);
     else
-        hipLaunchKernelGGL((packed_div3_kernel<T, false>), dim3(grid), dim3(PK_THREADS), sizeof(pu32) * ax.p, st, ax, inv, (const T *)a, (int)sa, (const T *)b, (int)sb,
+        hipLaunchKernelGGL((packed_div3_kernel<T, false, WIDE>), dim3(grid), dim3(PK_THREADS), sizeof(pu32) * ax.p, st, ax, inv, (const T *)a, (int)sa, (const T *)b, (int)sb,
                            (T *)out, n, dev_err);
+    return GFA_OK;
 }
 
-template <typename T>
-static void launch_div2(bool recip, int grid, const Div2Aux &ax, const pu32 *inv, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int *dev_err)
+template <typename T, bool WIDE>
+static int launch_div2(bool recip, int grid, const Div2Aux &ax, const pu32 *inv, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int *dev_err)
 {
+    const size_t lds = WIDE ? sizeof(pu32) * ((ax.p + 1) / 2) : sizeof(pu32) * ax.p;
+    if (WIDE) { // up to 74 KiB of LDS
+        static bool attr[2] = {false, false};
+        const void *k = recip ? (const void *)packed_div2_kernel<T, true, WIDE> : (const void *)packed_div2_kernel<T, false, WIDE>;
+        if (!attr[recip]) { GFA_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); attr[recip] = true; }
+    }
     if (recip)
-        hipLaunchKernelGGL((packed_div2_kernel<T, true>), dim3(grid), dim3(PK_THREADS), sizeof(pu32) * ax.p, st, ax, inv, (const T *)nullptr, 0, (const T *)b, (int)sb,
+        hipLaunchKernelGGL((packed_div2_kernel<T, true, WIDE>), dim3(grid), dim3(PK_THREADS), lds, st, ax, inv, (const T *)nullptr, 0, (const T *)b, (int)sb,
                            (T *)out, n, dev_err);
     else
-        hipLaunchKernelGGL((packed_div2_kernel<T, false>), dim3(grid), dim3(PK_THREADS), sizeof(pu32) * ax.p, st, ax, inv, (const T *)a, (int)sa, (const T *)b, (int)sb,
+        hipLaunchKernelGGL((packed_div2_kernel<T, false, WIDE>), dim3(grid), dim3(PK_THREADS), lds, st, ax, inv, (const T *)a, (int)sa, (const T *)b, (int)sb,
                            (T *)out, n, dev_err);
+    return GFA_OK;
 }
 
 int packed_divn_run(const FieldDev &c, int dtype, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int *dev_err)
@@ -521,22 +543,27 @@ int packed_divn_run(const FieldDev &c, int dtype, const void *a, i64 sa, const v
     const bool recip = a == nullptr;
     if (!al16p(out) || (!recip && sa && !al16p(a)) || (sb && !al16p(b))) return GFA_ERR_UNSUPPORTED;
     if (!packed_divn_eligible(c, dtype, n)) return GFA_ERR_UNSUPPORTED;
-    Plan pl;
-    MulAux mx;
+    const bool wide = divn_wide(c), half = wide && c.m == 2; // half: 16-bit table entries
+    pu32 nir[8];
+    ext_nir(c, nir);
     Div2Aux a2;
     Div3Aux a3;
-    if (!packed_mul_aux(c, &pl, &mx, true)) return GFA_ERR_UNSUPPORTED;
-    if (c.m == 2 ? !make_div2(c.p, c.m, mx.nir, &a2) : !make_div3(c.p, c.m, mx.nir, &a3)) return GFA_ERR_UNSUPPORTED;
+    if (c.m == 2 ? !make_div2(c.p, c.m, nir, &a2, wide) : !make_div3(c.p, c.m, nir, &a3, wide)) return GFA_ERR_UNSUPPORTED;
     int dev = 0;
     GFA_HIP(hipGetDevice(&dev));
     pu32 *inv = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_pk_mu);
-        auto key = std::make_pair((u64)c.p, dev);
+        auto key = std::make_pair((u64)c.p + (half ? (u64)1 << 40 : 0), dev);
         auto it = g_inv_tab.find(key);
         if (it == g_inv_tab.end()) {
             std::vector<pu32> t;
             build_inverse_table((pu32)c.p, t);
+            if (half) { // two 16-bit entries per word
+                std::vector<pu32> h((t.size() + 1) / 2, 0);
+                for (size_t v = 0; v < t.size(); v++) h[v / 2] |= t[v] << (16 * (v & 1));
+                t.swap(h);
+            }
             pu32 *d = nullptr;
             GFA_HIP(hipMalloc((void **)&d, sizeof(pu32) * t.size()));
             GFA_HIP(hipMemcpy(d, t.data(), sizeof(pu32) * t.size(), hipMemcpyHostToDevice));
@@ -547,9 +574,12 @@ int packed_divn_run(const FieldDev &c, int dtype, const void *a, i64 sa, const v
     const int vec = dtype == GFA_U32 ? 4 : 8;
     const i64 blocks = std::max<i64>(1, (n / vec + PK_THREADS - 1) / PK_THREADS);
     const int grid = (int)std::min<i64>(blocks, (i64)num_cus() * 4);
-    if (c.m == 3) launch_div3<uint32_t>(recip, grid, a3, inv, a, sa, b, sb, out, n, st, dev_err);
-    else if (dtype == GFA_U32) launch_div2<uint32_t>(recip, grid, a2, inv, a, sa, b, sb, out, n, st, dev_err);
-    else launch_div2<uint16_t>(recip, grid, a2, inv, a, sa, b, sb, out, n, st, dev_err);
+    int rc;
+    if (c.m == 3) rc = wide ? launch_div3<uint32_t, true>(recip, grid, a3, inv, a, sa, b, sb, out, n, st, dev_err) : launch_div3<uint32_t, false>(recip, grid, a3, inv, a, sa, b, sb, out, n, st, dev_err);
+    else if (wide) rc = launch_div2<uint32_t, true>(recip, grid, a2, inv, a, sa, b, sb, out, n, st, dev_err);
+    else if (dtype == GFA_U32) rc = launch_div2<uint32_t, false>(recip, grid, a2, inv, a, sa, b, sb, out, n, st, dev_err);
+    else rc = launch_div2<uint16_t, false>(recip, grid, a2, inv, a, sa, b, sb, out, n, st, dev_err);
+    if (rc) return rc;
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }

@@ -263,6 +263,27 @@ GFP_HD pu32 mul_digits(const Plan &pl, const MulAux &ax, pu32 pa, pu32 pb)
     return v;
 }
 
+// floor(x / d) for EVERY 32-bit x (Granlund-Montgomery round-up form): l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1,
+// q = (t + ((x - t) >> 1)) >> (l - 1) with t = mulhi(m, x).  d odd, 3 <= d < 2^31.  Five instructions; the one-mulhi form (Plan::magic,
+// Div2Aux::magic) is exact only for x < 2^20.
+struct ExactDiv {
+    pu32 m, sh;
+};
+inline ExactDiv make_exact_div(pu32 d)
+{
+    pu32 l = 0;
+    while (((uint64_t)1 << l) < d) l++;
+    ExactDiv e;
+    e.m = (pu32)(((((uint64_t)1 << l) - d) << 32) / d + 1);
+    e.sh = l - 1;
+    return e;
+}
+GFP_HD pu32 exact_div(const ExactDiv &e, pu32 x)
+{
+    const pu32 t = mulhi32(x, e.m);
+    return (t + ((x - t) >> 1)) >> e.sh;
+}
+
 // ---- quotients and reciprocals of GF(p^2), 32768 < q <= 2^20 (r06): by the norm.  With X^2 = s X + t (s, t = nir[1], nir[0]) the
 // conjugate of b = b0 + b1 X is b^p = (b0 + s b1) - b1 X and N(b) = b b^p = b0^2 + s b0 b1 - t b1^2 lies in GF(p), non-zero for
 // b != 0 (the polynomial is irreducible); 1 / b = b^p / N with 1 / N from a p-entry table (LDS).  Replaces, for these fields, the
@@ -271,13 +292,20 @@ GFP_HD pu32 mul_digits(const Plan &pl, const MulAux &ax, pu32 pa, pu32 pb)
 struct Div2Aux {
     pu32 p, s, t, mu32; // X^2 = s X + t; mu32 = floor(2^32 / p)
     pu32 magic;         // ceil(2^32 / p): floor(x / p) == mulhi(x, magic) for x < 2^20
+    ExactDiv xd;        // WIDE (p > 1021, elements up to 2^32): the digit split
 };
-inline bool make_div2(uint64_t p, uint32_t m, const pu32 *nir, Div2Aux *ax)
+// WIDE = false: 182 <= p <= 1021 (32768 < p^2 <= 2^20).  WIDE = true (r06): 1021 < p <= 37813, elements below 2^32 on uint32 arrays -- fields
+// that have no tables at all (q > 2^20); the same formulas (every partial sum below 3 p^2 < 2^32), an exact digit split, and the inverse
+// table as 16-bit entries (at most 74 KiB of LDS).
+constexpr pu32 DIV2_WIDE_MAX_P = 37813; // the largest prime with 3 p^2 < 2^32
+inline bool make_div2(uint64_t p, uint32_t m, const pu32 *nir, Div2Aux *ax, bool wide = false)
 {
-    if (m != 2 || p < 182 || p > 1021 || (p & 1) == 0) return false; // 32768 < p^2 <= 2^20
+    if (m != 2 || (p & 1) == 0) return false;
+    if (wide ? (p <= 1021 || p > DIV2_WIDE_MAX_P) : (p < 182 || p > 1021)) return false;
     ax->p = (pu32)p; ax->s = nir[1]; ax->t = nir[0];
     ax->mu32 = (pu32)(((uint64_t)1 << 32) / p);
     ax->magic = (pu32)((((uint64_t)1 << 32) + p - 1) / p);
+    ax->xd = make_exact_div((pu32)p);
     return true;
 }
 inline void build_inverse_table(pu32 p, std::vector<pu32> &t)
@@ -290,18 +318,18 @@ inline void build_inverse_table(pu32 p, std::vector<pu32> &t)
     }
 }
 // a / b (RECIP: 1 / b) as integers d1 * p + d0; *zero is set when b == 0 (the result is then 0)
-template <bool RECIP>
-GFP_HD pu32 div2(const Div2Aux &ax, const pu32 *inv, pu32 a, pu32 b, bool *zero)
+template <bool RECIP, bool WIDE = false, typename IT = pu32>
+GFP_HD pu32 div2(const Div2Aux &ax, const IT *inv, pu32 a, pu32 b, bool *zero)
 {
     const pu32 p = ax.p;
-    const pu32 b1 = mulhi32(b, ax.magic), b0 = b - b1 * p;
+    const pu32 b1 = WIDE ? exact_div(ax.xd, b) : mulhi32(b, ax.magic), b0 = b - b1 * p;
     const pu32 u = red32(b0 + ax.s * b1, p, ax.mu32);                                         // conjugate: u - b1 X
     const pu32 nrm = red32(b0 * b0 + ax.s * red32(b0 * b1, p, ax.mu32) + (p - ax.t) * red32(b1 * b1, p, ax.mu32), p, ax.mu32);
     *zero = b == 0;
-    const pu32 ni = inv[nrm];
+    const pu32 ni = (pu32)inv[nrm];
     const pu32 i0 = red32(u * ni, p, ax.mu32), i1 = red32((p - b1) * ni, p, ax.mu32);     // 1 / b = i0 + i1 X  ((p - 0) * ni = 0 mod p)
     if (RECIP) return i1 * p + i0;
-    const pu32 a1 = mulhi32(a, ax.magic), a0 = a - a1 * p;
+    const pu32 a1 = WIDE ? exact_div(ax.xd, a) : mulhi32(a, ax.magic), a0 = a - a1 * p;
     const pu32 w = red32(a1 * i1, p, ax.mu32);                                                 // a1 i1 X^2 = w (s X + t)
     const pu32 q0 = red32(a0 * i0 + ax.t * w, p, ax.mu32);
     const pu32 q1 = red32(a0 * i1 + a1 * i0 + ax.s * w, p, ax.mu32);
@@ -314,23 +342,29 @@ GFP_HD pu32 div2(const Div2Aux &ax, const pu32 *inv, pu32 a, pu32 b, bool *zero)
 // determinant, one table inverse, three to scale; every partial sum below 2^23.  Same field, same values as the reference's table division.
 struct Div3Aux {
     pu32 p, n0, n1, n2, mu32, magic; // magic = ceil(2^32 / p): exact quotients for x < 2^20
+    ExactDiv xd;                      // WIDE (p > 101, elements up to 2^32): the digit split
 };
-inline bool make_div3(uint64_t p, uint32_t m, const pu32 *nir, Div3Aux *ax)
+// WIDE = false: 41 <= p <= 101 (65536 < p^3 <= 2^20).  WIDE = true (r06): 101 < p <= 1621 (p^3 < 2^32), uint32 arrays of fields without
+// tables: the cofactors are reduced BEFORE the determinant (its three products then stay below 3 p^2), the split is exact for 32-bit elements.
+constexpr pu32 DIV3_WIDE_MAX_P = 1621; // the largest prime with p^3 < 2^32
+inline bool make_div3(uint64_t p, uint32_t m, const pu32 *nir, Div3Aux *ax, bool wide = false)
 {
-    if (m != 3 || p < 41 || p > 101 || (p & 1) == 0) return false; // 65536 < p^3 <= 2^20
+    if (m != 3 || (p & 1) == 0) return false;
+    if (wide ? (p <= 101 || p > DIV3_WIDE_MAX_P) : (p < 41 || p > 101)) return false;
     ax->p = (pu32)p; ax->n0 = nir[0]; ax->n1 = nir[1]; ax->n2 = nir[2];
     ax->mu32 = (pu32)(((uint64_t)1 << 32) / p);
     ax->magic = (pu32)((((uint64_t)1 << 32) + p - 1) / p);
+    ax->xd = make_exact_div((pu32)p);
     return true;
 }
-template <bool RECIP>
+template <bool RECIP, bool WIDE = false>
 GFP_HD pu32 div3(const Div3Aux &ax, const pu32 *inv, pu32 a, pu32 b, bool *zero)
 {
     const pu32 p = ax.p, pp = p * p;
     auto split = [&](pu32 x, pu32 &d0, pu32 &d1, pu32 &d2) { // x = d2 p^2 + d1 p + d0
-        const pu32 q1 = mulhi32(x, ax.magic);
+        const pu32 q1 = WIDE ? exact_div(ax.xd, x) : mulhi32(x, ax.magic);
         d0 = x - q1 * p;
-        d2 = mulhi32(q1, ax.magic);
+        d2 = WIDE ? exact_div(ax.xd, q1) : mulhi32(q1, ax.magic);
         d1 = q1 - d2 * p;
     };
     auto R = [&](pu32 x) { return red32(x, p, ax.mu32); };
@@ -344,9 +378,10 @@ GFP_HD pu32 div3(const Div3Aux &ax, const pu32 *inv, pu32 a, pu32 b, bool *zero)
     const pu32 c0 = pp + d1 * e2 - e1 * d2;
     const pu32 c1 = pp + e1 * b2 - b1 * e2;
     const pu32 c2 = pp + b1 * d2 - d1 * b2;
-    const pu32 det = R(b0 * c0 + d0 * c1 + e0 * c2);
+    const pu32 r0 = R(c0), r1 = R(c1), r2 = R(c2);
+    const pu32 det = WIDE ? R(b0 * r0 + d0 * r1 + e0 * r2) : R(b0 * c0 + d0 * c1 + e0 * c2);
     const pu32 ni = inv[det];
-    const pu32 i0 = R(R(c0) * ni), i1 = R(R(c1) * ni), i2 = R(R(c2) * ni); // 1 / b = i0 + i1 X + i2 X^2
+    const pu32 i0 = R(r0 * ni), i1 = R(r1 * ni), i2 = R(r2 * ni); // 1 / b = i0 + i1 X + i2 X^2
     if (RECIP) return (i2 * p + i1) * p + i0;
     pu32 a0, a1, a2;
     split(a, a0, a1, a2);

@@ -116,6 +116,7 @@ static long check_mul(pu32 p, std::mt19937 &rng)
 
 // quotients of GF(p^2) by the norm (r06): (a / b) * b == a and (1 / b) * b == 1 through the textbook digit product, for random
 // irreducible x^2 + c1 x + c0 (no root mod p), every b of a small slice and random pairs; b == 0 is flagged
+template <bool WIDE = false>
 static long check_div2(pu32 p, std::mt19937 &rng)
 {
     long fails = 0;
@@ -129,7 +130,7 @@ static long check_div2(pu32 p, std::mt19937 &rng)
         }
         pu32 nir[8] = {c0 ? p - c0 : 0, c1 ? p - c1 : 0};
         Div2Aux ax;
-        if (!make_div2(p, 2, nir, &ax)) { printf("GF(%u^2): refused\n", p); return 1; }
+        if (!make_div2(p, 2, nir, &ax, WIDE)) { printf("GF(%u^2): refused\n", p); return 1; }
         std::vector<pu32> inv;
         build_inverse_table(p, inv);
         auto mul = [&](pu32 x, pu32 y) { // textbook: (x0 + x1 X)(y0 + y1 X), X^2 = s X + t
@@ -141,7 +142,7 @@ static long check_div2(pu32 p, std::mt19937 &rng)
         const pu32 q = p * p;
         auto one = [&](pu32 a, pu32 b) {
             bool z = false, z2 = false;
-            const pu32 qt = div2<false>(ax, inv.data(), a, b, &z), rc = div2<true>(ax, inv.data(), a, b, &z2);
+            const pu32 qt = div2<false, WIDE>(ax, inv.data(), a, b, &z), rc = div2<true, WIDE>(ax, inv.data(), a, b, &z2);
             if (z != (b == 0) || z2 != (b == 0)) fails++;
             if (b == 0) return;
             if (qt >= q || rc >= q || mul(qt, b) != a || mul(rc, b) != 1) fails++;
@@ -158,6 +159,7 @@ static long check_div2(pu32 p, std::mt19937 &rng)
 
 // quotients of GF(p^3) by Cramer's rule (r06): (a / b) * b == a and (1 / b) * b == 1 through the textbook digit product, for random
 // irreducible cubics (no root mod p: a cubic without roots is irreducible)
+template <bool WIDE = false>
 static long check_div3(pu32 p, std::mt19937 &rng)
 {
     long fails = 0;
@@ -171,7 +173,7 @@ static long check_div3(pu32 p, std::mt19937 &rng)
         }
         pu32 nir[8] = {c0 ? p - c0 : 0, c1 ? p - c1 : 0, c2 ? p - c2 : 0};
         Div3Aux ax;
-        if (!make_div3(p, 3, nir, &ax)) { printf("GF(%u^3): refused\n", p); return 1; }
+        if (!make_div3(p, 3, nir, &ax, WIDE)) { printf("GF(%u^3): refused\n", p); return 1; }
         std::vector<pu32> inv;
         build_inverse_table(p, inv);
         auto mul = [&](pu32 x, pu32 y) {
@@ -185,7 +187,7 @@ static long check_div3(pu32 p, std::mt19937 &rng)
         const pu32 q = p * p * p;
         auto one = [&](pu32 a, pu32 b) {
             bool z = false, z2 = false;
-            const pu32 qt = div3<false>(ax, inv.data(), a, b, &z), rc = div3<true>(ax, inv.data(), a, b, &z2);
+            const pu32 qt = div3<false, WIDE>(ax, inv.data(), a, b, &z), rc = div3<true, WIDE>(ax, inv.data(), a, b, &z2);
             if (z != (b == 0) || z2 != (b == 0)) fails++;
             if (b == 0) return;
             if (qt >= q || rc >= q || mul(qt, b) != a || mul(rc, b) != 1) fails++;
@@ -205,6 +207,17 @@ int main()
     std::mt19937 rng(5);
     long fails = 0;
     fails += check_div3(41, rng) + check_div3(97, rng) + check_div3(101, rng) + check_div3(67, rng);
+    // r06, fields without tables (q > 2^20): the exact digit split over the whole 32-bit range, the largest primes of each form
+    fails += check_div3<true>(103, rng) + check_div3<true>(251, rng) + check_div3<true>(1021, rng) + check_div3<true>(1621, rng);
+    fails += check_div2<true>(1031, rng) + check_div2<true>(8191, rng) + check_div2<true>(32771, rng) + check_div2<true>(37813, rng);
+    for (pu32 d : {3u, 103u, 1621u, 37813u, 65521u, 2147483647u}) {
+        const ExactDiv e = make_exact_div(d);
+        for (unsigned long long x : {0ull, 1ull, (unsigned long long)d - 1, (unsigned long long)d, (unsigned long long)d + 1, 0xffffffffull, 0xfffffffeull, 0x80000000ull, (unsigned long long)d * d % 0x100000000ull})
+            if (exact_div(e, (pu32)x) != (pu32)x / d) fails++;
+        for (int i = 0; i < 200000; i++) { const pu32 x = rng(); if (exact_div(e, x) != x / d) fails++; }
+    }
+    Div2Aux w2; Div3Aux w3; pu32 nz[8] = {1, 1, 1};
+    if (make_div2(37831, 2, nz, &w2, true) || make_div2(1021, 2, nz, &w2, true) || make_div3(1627, 3, nz, &w3, true) || make_div3(101, 3, nz, &w3, true)) { printf("a prime outside the wide forms was accepted\n"); fails++; }
     fails += check_div2(997, rng) + check_div2(257, rng) + check_div2(1021, rng) + check_div2(509, rng) + check_div2(251, rng) + check_div2(191, rng);
     const pu32 fields[][2] = {{3, 2}, {3, 5}, {5, 3}, {7, 2}, {3, 9}, {3, 10}, {5, 6}, {5, 7}, {5, 8}, {7, 5}, {7, 6}, {7, 7}, {11, 4}, {11, 5}, {13, 5},
                               {17, 4}, {31, 4}, {41, 3}, {97, 3}, {101, 2}, {257, 2}, {1021, 2}};

@@ -1300,3 +1300,56 @@ def test_binary_fields_of_2e17_to_2e20_elements_divide_through_the_inverse_table
             H.assert_equal_ints(u(y ** -7), F.pow(b, np.full(n, -7, dtype=np.int64)), mode + " power")
         finally:
             GF.compile("auto")
+
+
+def _irreducible_without_conway(p, m):
+    """x^2 + x + c (1 - 4 c a non-residue) / x^3 + x + c (no root): an irreducible polynomial for fields outside the shipped Conway table."""
+    if m == 2:
+        c = next(c for c in range(1, p) if pow((1 - 4 * c) % p, (p - 1) // 2, p) == p - 1)
+        return [1, 1, c]
+    c = next(c for c in range(1, p) if all((x * x * x + x + c) % p for x in range(p)))
+    return [1, 0, 1, c]
+
+
+@pytest.mark.parametrize("p,m", [(251, 3), (103, 3), (1021, 3), (1621, 3), (1031, 2), (8191, 2), (32771, 2), (37813, 2)])
+def test_quotients_of_quadratic_and_cubic_fields_without_tables(p, m):
+    """r06: GF(p^2), 1021 < p <= 37813, and GF(p^3), 101 < p <= 1621 (2^20 < q < 2^32, uint32 arrays; the reference computes these fields
+    explicitly, _calculate.py:447-513): quotients by the norm / Cramer's rule with an exact digit split over the whole 32-bit range and the
+    GF(p) inverse from an LDS table (packed_div2_kernel / packed_div3_kernel, WIDE).  Every element against the oracle, digits at p - 1,
+    tails, scalars on either side, misaligned views (digit-vector kernels), zero divisors; the pinned mode agrees."""
+    order = p**m
+    try:
+        GF = ga.GF(order)
+    except LookupError:
+        GF = ga.GF(order, irreducible_poly=_irreducible_without_conway(p, m))
+    F = O.OracleField(p, m, int(GF.irreducible_poly), int(GF.primitive_element))
+    u = lambda v: v.numpy().astype(np.uint64)
+    rng = np.random.default_rng(p)
+    n = 30_003
+    a = rng.integers(0, order, n, dtype=np.uint64)
+    b = rng.integers(1, order, n, dtype=np.uint64)
+    a[:5] = (0, order - 1, 1, p, order - p)
+    b[:8] = (1, order - 1, p, p - 1, p + 1, order - p, order // p, (p - 1) * (order // p))
+    x, y = GF(a.astype(np.uint32)), GF(b.astype(np.uint32))
+    want = F.div(a, b)
+    H.assert_equal_ints(u(x / y), want, f"GF({p}^{m}) div")
+    H.assert_equal_ints(u(np.reciprocal(y)), F.recip(b), "reciprocal")
+    H.assert_equal_ints(u(x[:1026] / y[:1026]), want[:1026], "short with a tail")
+    H.assert_equal_ints(u(x[1:] / y[1:]), want[1:], "misaligned views")
+    s = GF(int(b[11]))
+    H.assert_equal_ints(u(x / s), F.div(a, np.full(n, b[11], dtype=np.uint64)), "scalar divisor")
+    H.assert_equal_ints(u(s / y), F.div(np.full(n, b[11], dtype=np.uint64), b), "scalar dividend")
+    H.assert_equal_ints(u((x / y) * y), a, "round trip")
+    for where in (0, 4 * 512 * 2 + 3, n - 1):
+        bz = b.copy()
+        bz[where] = 0
+        yz = GF(bz.astype(np.uint32))
+        with pytest.raises(ZeroDivisionError):
+            x / yz
+        with pytest.raises(ZeroDivisionError):
+            np.reciprocal(yz)
+    GF.compile("jit-calculate")
+    try:
+        H.assert_equal_ints(u(x / y), want, "jit-calculate")
+    finally:
+        GF.compile("auto")

@@ -30,6 +30,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "--band16":  # r06: GF(p^m), 32768 < q <
     cases = [(251**2, np.uint16, "auto"), (251**2, np.uint32, "auto"), (37**3, np.uint16, "auto"), (251**2, np.uint16, "jit-lookup"), (3**10, np.uint16, "auto")]
 if len(sys.argv) > 1 and sys.argv[1] == "--div3":  # r06: degree-3 quotients by Cramer's rule
     cases = [(97**3, np.uint32, "auto"), (41**3, np.uint32, "auto"), (97**3, np.uint32, "jit-lookup")]
+if len(sys.argv) > 1 and sys.argv[1] == "--divwide":  # r06: GF(p^2) / GF(p^3) above 2^20 elements (no tables): quotients by the norm / Cramer's rule, exact digit split
+    def irr2(p):  # x^2 + x + c, irreducible iff 1 - 4 c is a non-residue
+        c = next(c for c in range(1, p) if pow((1 - 4 * c) % p, (p - 1) // 2, p) == p - 1)
+        return [1, 1, c]
+    def irr3(p):  # x^3 + x + c without a root
+        c = next(c for c in range(1, p) if all((x * x * x + x + c) % p for x in range(p)))
+        return [1, 0, 1, c]
+    cases = [(251**3, np.uint32, "auto"), ((1021**3, irr3(1021)), np.uint32, "auto"), ((1621**3, irr3(1621)), np.uint32, "auto"),
+             ((1031**2, irr2(1031)), np.uint32, "auto"), ((8191**2, irr2(8191)), np.uint32, "auto"), ((37813**2, irr2(37813)), np.uint32, "auto"),
+             (251**3, np.uint32, "jit-calculate")]
 if len(sys.argv) > 1 and sys.argv[1] == "--bininv":  # r06: GF(2^17) .. GF(2^20): quotients / reciprocals through the 3-byte inverse table, powers through LOG / EXP
     cases = [(2**20, np.uint32, "auto"), (2**17, np.uint32, "auto"), (2**20, np.uint32, "jit-calculate"), (2**20, np.uint32, "jit-lookup")]
 if len(sys.argv) > 1 and sys.argv[1] == "--divt":  # r06: quotients of degrees 4 .. 8: one gather from the 3-byte inverse table + the digit-table product
@@ -55,7 +65,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "--bin":
     cases = [c for c in cases if c[0] in (2**20, 2**24, 2**32)]
 n = 50_000_000
 for order, dt, mode in cases:
-    GF = ga.GF(order)
+    if isinstance(order, tuple):  # (order, irreducible polynomial): fields outside the shipped Conway table
+        order, irr = order
+        GF = ga.GF(order, irreducible_poly=irr)
+    else:
+        GF = ga.GF(order)
     GF.compile(mode)
     esize = 8 if dt is None else np.dtype(dt).itemsize
     rng = np.random.default_rng(1)

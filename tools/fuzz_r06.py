@@ -58,7 +58,7 @@ for p in [65537, 7340033, 469762049, 2013265921, 2130706433, 3221225473, 4293918
     POOL.append((p, GF, O.OracleField(p, 1, None, int(GF.primitive_element)), adic))
 P16 = [e for e in POOL if e[0] < 2**29 and e[3] >= 16]
 EXT32 = {}  # extension fields on uint32 arrays: two-word packed sums, digit-table products, quotients by the norm / Cramer's rule (r06)
-EXT32_ORDERS = [257**2, 509**2, 997**2, 251**2, 191**2, 37**3, 41**3, 67**3, 97**3, 101**3, 3**11, 3**12, 7**7, 5**8, 13**5, 31**4]
+EXT32_ORDERS = [257**2, 509**2, 997**2, 251**2, 191**2, 37**3, 41**3, 67**3, 97**3, 101**3, 3**11, 3**12, 7**7, 5**8, 13**5, 31**4, 2**17, 2**19, 2**20]
 MASKED = [ga.GF(q) for q in (7, 2**8, 3**5, 3**10, 65521, 65537, 2**16, 2**32, 4294967291)]
 WIDE = None
 
@@ -134,7 +134,8 @@ while time.time() < t_end:
         for got, want, what in ((A + B, F2.add(a, b), "add"), (A - B, F2.sub(a, b), "sub"), (-A, F2.neg(a), "neg"), (A * B, F2.mul(a, b), "mul"),
                                 (A / B, F2.div(a, b), "div"), (np.reciprocal(B), F2.recip(b), "recip"),
                                 (A / B[k], F2.div(a, full(b[k])), "array / scalar"), (A[k] / B, F2.div(full(a[k]), b), "scalar / array"),
-                                (A * B[k], F2.mul(a, full(b[k])), "array * scalar")):
+                                (A * B[k], F2.mul(a, full(b[k])), "array * scalar"),
+                                (B ** (kk := int(rng.integers(-q, q))), F2.pow(b, np.full(n, kk, dtype=np.int64)), "array ** scalar")):
             assert np.array_equal(u64(got), want), ("ext32", q, what, n, off)
         if (a == 0).any():
             try:
