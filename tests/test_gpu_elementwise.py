@@ -1311,7 +1311,7 @@ def _irreducible_without_conway(p, m):
     return [1, 0, 1, c]
 
 
-@pytest.mark.parametrize("p,m", [(251, 3), (103, 3), (1021, 3), (1621, 3), (1031, 2), (8191, 2), (32771, 2), (37813, 2)])
+@pytest.mark.parametrize("p,m", [(251, 3), (103, 3), (1021, 3), (1447, 3), (1031, 2), (8191, 2), (32771, 2), (37813, 2)])
 def test_quotients_of_quadratic_and_cubic_fields_without_tables(p, m):
     """r06: GF(p^2), 1021 < p <= 37813, and GF(p^3), 101 < p <= 1621 (2^20 < q < 2^32, uint32 arrays; the reference computes these fields
     explicitly, _calculate.py:447-513): quotients by the norm / Cramer's rule with an exact digit split over the whole 32-bit range and the
@@ -1322,6 +1322,7 @@ def test_quotients_of_quadratic_and_cubic_fields_without_tables(p, m):
         GF = ga.GF(order)
     except LookupError:
         GF = ga.GF(order, irreducible_poly=_irreducible_without_conway(p, m))
+    assert np.uint32 in GF.dtypes  # (order - 1)^2 fits int64: the reference's own rule for fixed-width arrays; GF(1621^3) is the test below
     F = O.OracleField(p, m, int(GF.irreducible_poly), int(GF.primitive_element))
     u = lambda v: v.numpy().astype(np.uint64)
     rng = np.random.default_rng(p)
@@ -1353,3 +1354,35 @@ def test_quotients_of_quadratic_and_cubic_fields_without_tables(p, m):
         H.assert_equal_ints(u(x / y), want, "jit-calculate")
     finally:
         GF.compile("auto")
+
+
+def test_cubic_quotients_at_the_largest_prime_through_the_c_abi():
+    """GF(1621^3) (4 259 406 061 elements, the largest cube below 2^32): the reference holds it as dtype=object ((order - 1)^2 leaves int64), so
+    FieldArray never builds a uint32 array of it -- the C ABI accepts one (every element fits), and the WIDE Cramer form is written for it.
+    gfa_binary / gfa_unary on raw uint32 buffers against the oracle."""
+    import torch
+    from galois_amd import _lib as L
+
+    p, m = 1621, 3
+    GF = ga.GF(p**m, irreducible_poly=_irreducible_without_conway(p, m))
+    F = O.OracleField(p, m, int(GF.irreducible_poly), int(GF.primitive_element))
+    order = p**m
+    rng = np.random.default_rng(5)
+    n = 20_002
+    a = rng.integers(0, order, n, dtype=np.uint64)
+    b = rng.integers(1, order, n, dtype=np.uint64)
+    a[:4] = (0, order - 1, 1, p)
+    b[:6] = (1, order - 1, p, p * p, order - p, (p - 1) * p * p)
+    da = torch.from_numpy(a.astype(np.uint32).view(np.int32)).cuda()
+    db = torch.from_numpy(b.astype(np.uint32).view(np.int32)).cuda()
+    out = torch.empty_like(da)
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    L.check(lib.gfa_binary(GF._handle, L.OP_DIV, da.data_ptr(), 1, db.data_ptr(), 1, out.data_ptr(), n, L.U32, st, err.data_ptr()))
+    H.assert_equal_ints(out.cpu().numpy().view(np.uint32).astype(np.uint64), F.div(a, b), "div")
+    L.check(lib.gfa_unary(GF._handle, L.OP_RECIP, db.data_ptr(), out.data_ptr(), n, L.U32, st, err.data_ptr()))
+    H.assert_equal_ints(out.cpu().numpy().view(np.uint32).astype(np.uint64), F.recip(b), "reciprocal")
+    assert int(err.item()) == 0
+    L.check(lib.gfa_unary(GF._handle, L.OP_RECIP, da.data_ptr(), out.data_ptr(), n, L.U32, st, err.data_ptr()))
+    assert int(err.item()) != 0  # a[0] == 0

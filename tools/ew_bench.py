@@ -39,7 +39,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--divwide":  # r06: GF(p^2) / GF(p^3) a
         return [1, 0, 1, c]
     cases = [(251**3, np.uint32, "auto"), ((1021**3, irr3(1021)), np.uint32, "auto"), ((1621**3, irr3(1621)), np.uint32, "auto"),
              ((1031**2, irr2(1031)), np.uint32, "auto"), ((8191**2, irr2(8191)), np.uint32, "auto"), ((37813**2, irr2(37813)), np.uint32, "auto"),
-             (251**3, np.uint32, "jit-calculate")]
+             (251**3, np.uint32, "jit-calculate"), ((8191**2, irr2(8191)), np.uint32, "jit-calculate")]  # pinned: the digit-vector kernels these fields ran on before
 if len(sys.argv) > 1 and sys.argv[1] == "--bininv":  # r06: GF(2^17) .. GF(2^20): quotients / reciprocals through the 3-byte inverse table, powers through LOG / EXP
     cases = [(2**20, np.uint32, "auto"), (2**17, np.uint32, "auto"), (2**20, np.uint32, "jit-calculate"), (2**20, np.uint32, "jit-lookup")]
 if len(sys.argv) > 1 and sys.argv[1] == "--divt":  # r06: quotients of degrees 4 .. 8: one gather from the 3-byte inverse table + the digit-table product

@@ -58,7 +58,8 @@ for p in [65537, 7340033, 469762049, 2013265921, 2130706433, 3221225473, 4293918
     POOL.append((p, GF, O.OracleField(p, 1, None, int(GF.primitive_element)), adic))
 P16 = [e for e in POOL if e[0] < 2**29 and e[3] >= 16]
 EXT32 = {}  # extension fields on uint32 arrays: two-word packed sums, digit-table products, quotients by the norm / Cramer's rule (r06)
-EXT32_ORDERS = [257**2, 509**2, 997**2, 251**2, 191**2, 37**3, 41**3, 67**3, 97**3, 101**3, 3**11, 3**12, 7**7, 5**8, 13**5, 31**4, 2**17, 2**19, 2**20]
+EXT32_ORDERS = [257**2, 509**2, 997**2, 251**2, 191**2, 37**3, 41**3, 67**3, 97**3, 101**3, 3**11, 3**12, 7**7, 5**8, 13**5, 31**4, 2**17, 2**19, 2**20,
+                251**3, 1021**3, 1447**3, 1031**2, 8191**2, 37813**2]  # the last six: no tables (q > 2^20), quotients on the WIDE norm / Cramer forms
 MASKED = [ga.GF(q) for q in (7, 2**8, 3**5, 3**10, 65521, 65537, 2**16, 2**32, 4294967291)]
 WIDE = None
 
@@ -113,10 +114,14 @@ while time.time() < t_end:
         if q not in EXT32:
             try:
                 G2 = ga.GF(q)
-            except LookupError:  # no Conway polynomial in the shipped table
-                EXT32_ORDERS.remove(q)
-                continue
-            EXT32[q] = (G2, O.OracleField(G2.characteristic, G2.degree, int(G2.irreducible_poly), int(G2.primitive_element), lookup=True))
+            except LookupError:  # no Conway polynomial in the shipped table: x^2 + x + c / x^3 + x + c, the first irreducible one
+                pp, mm = next((r, e) for e in (2, 3) for r in (round(q ** (1 / e)),) if r**e == q)
+                if mm == 2:
+                    irr = [1, 1, next(c for c in range(1, pp) if pow((1 - 4 * c) % pp, (pp - 1) // 2, pp) == pp - 1)]
+                else:
+                    irr = [1, 0, 1, next(c for c in range(1, pp) if all((x * x * x + x + c) % pp for x in range(pp)))]
+                G2 = ga.GF(q, irreducible_poly=irr)
+            EXT32[q] = (G2, O.OracleField(G2.characteristic, G2.degree, int(G2.irreducible_poly), int(G2.primitive_element), lookup=q <= 2**20))
         G2, F2 = EXT32[q]
         n = int(rng.choice([1024, 1500, 4099, 20000, 70001]))
         off = int(rng.integers(0, 2)) * int(rng.integers(1, 5))
