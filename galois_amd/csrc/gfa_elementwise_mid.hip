@@ -25,7 +25,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef uint16_t u16;
 
 struct MidDesc {
-    const u16 *image; // LOG[qa] | EXP[2*qa] | ZECH[qa], qa = q rounded up to a multiple of 8 (gfa_field::ensure_device)
+    const u16 *image; // LOG[qa] | EXP[2*qa] | ZECH[qa], qa = q rounded up to a multiple of 8 (gfa_field::ensure_device); q > 32768: LOG | EXP[qa] | ZECH | INV[qa]
     u32 q, qa, qm1, zech_e;
     u32 exp_len;      // entries of EXP in the image: 2 qa (q <= 8192) or qa
     const i64 *e_ptr; // power: the one exponent of the call (device memory)
@@ -653,6 +653,89 @@ __global__ __launch_bounds__(T) void big16_exp_kernel(MidDesc d, const u16 *__re
     }
 }
 
+// ---- 32768 < q <= 65536, reciprocals and (where the product is explicit) quotients through ONE table (r06) ----
+// LOG + EXP of these fields do not fit LDS together, which is why big16_kernel stages them in turn (0.38-0.40); the 2q-byte table
+// INV[x] = 1 / x (the fourth table of the image, gfa_field::ensure_device) does, once per persistent workgroup, and the array streams
+// through it as through big16_exp_kernel.  MODE 0: 1 / b.  MODE 1: a / b = a * INV[b] mod p in a PRIME field (one 32-bit product, Barrett).
+// MODE 2: the same in GF(2^16): Bin::clmul16_lo / _hi (nine integer multiplies per element, two elements per register) and two
+// 256-entry reduction tables behind INV.  Same values as divide_ufunc / reciprocal_ufunc (_lookup.py:176-235, _calculate.py:447-513).
+template <int MODE, int T>
+__global__ __launch_bounds__(T) void big16_inv_kernel(MidDesc d, u32 p, u32 mu_p, u64 irr, const u16 *__restrict__ a, int sa, const u16 *__restrict__ b, int sb,
+                                                      u16 *__restrict__ out, i64 nvec, int32_t *err)
+{
+    extern __shared__ __attribute__((aligned(16))) u16 mid_lds[];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(d.image + 3 * (size_t)d.qa); // INV: qa entries
+        uint4 *dst = reinterpret_cast<uint4 *>(mid_lds);
+        for (int i = threadIdx.x; i < (int)(d.qa / 8u); i += T) dst[i] = src[i];
+    }
+    const u16 *R = mid_lds + d.qa; // MODE 2: h(x) x^16 mod f | h(x) x^24 mod f
+    if constexpr (MODE == 2) {
+        u16 *Rw = mid_lds + d.qa;
+        for (int t = threadIdx.x; t < 256; t += T) {
+            Rw[t] = (u16)Bin::reduce_bits((u64)t << 16, 16, 8, irr);
+            Rw[256 + t] = (u16)Bin::reduce_bits((u64)t << 24, 16, 16, irr);
+        }
+    }
+    u32x4 xs = {0, 0, 0, 0}, ys = {0, 0, 0, 0};
+    if (!sb) { const u32 s = b[0]; xs = u32x4{s, s, s, s} * 0x10001u; }
+    if (MODE != 0 && !sa) { const u32 s = a[0]; ys = u32x4{s, s, s, s} * 0x10001u; }
+    const u32x4 *av = reinterpret_cast<const u32x4 *>(a), *bv = reinterpret_cast<const u32x4 *>(b);
+    u32x4 *ov = reinterpret_cast<u32x4 *>(out);
+    bool bad = false;
+    __syncthreads();
+    auto prime_mul = [&](u32 x, u32 y) -> u32 { // x, y < p < 2^16
+        const u32 t = x * y, r = t - Bin::mulhi32(t, mu_p) * p; // the estimate is short by at most one
+        const u32 r2 = r - p;
+        return r2 < r ? r2 : r;
+    };
+    auto fold16 = [&](u32 P) -> u32 { return (P & 0xffffu) ^ R[(P >> 16) & 0xffu] ^ R[256 + (P >> 24)]; }; // P below 2^31
+    const i64 stride = (i64)gridDim.x * T;
+    i64 i = (i64)blockIdx.x * T + threadIdx.x;
+    u32x4 x = xs, y = ys;
+    if (i < nvec) { if (sb) x = bv[i]; if (MODE != 0 && sa) y = av[i]; }
+    while (i < nvec) {
+        const i64 nx = i + stride;
+        u32x4 xn = xs, yn = ys;
+        if (nx < nvec) { if (sb) xn = bv[nx]; if (MODE != 0 && sa) yn = av[nx]; } // the next vectors travel while this one is gathered
+        u32x4 r;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const u32 bl = x[w] & 0xffffu, bh = x[w] >> 16;
+            bad |= bl == 0u || bh == 0u;
+            const u32 il = mid_lds[bl], ih = mid_lds[bh];
+            if constexpr (MODE == 0) r[w] = il | (ih << 16);
+            else if constexpr (MODE == 1) r[w] = prime_mul(y[w] & 0xffffu, il) | (prime_mul(y[w] >> 16, ih) << 16);
+            else {
+                const u32 iw = il | (ih << 16);
+                r[w] = fold16(Bin::clmul16_lo(y[w], iw)) | (fold16(Bin::clmul16_hi(y[w], iw)) << 16);
+            }
+        }
+        ov[i] = r;
+        x = xn; y = yn; i = nx;
+    }
+    if (__any(bad)) {
+        if ((threadIdx.x & 63) == 0 && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
+    }
+}
+
+template <int MODE>
+int big16_inv_launch(const MidDesc &d, const FieldDev &lut, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int32_t *err)
+{
+    constexpr int T = 1024;
+    auto k = big16_inv_kernel<MODE, T>;
+    static bool attr = false;
+    if (!attr) { GFA_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + 1024)); attr = true; }
+    const size_t lds = (size_t)d.qa * sizeof(u16) + (MODE == 2 ? 1024 : 0);
+    const i64 nvec = n >> 3;
+    const i64 blocks = (nvec + T - 1) / T;
+    const int cus = mid_num_cus();
+    hipLaunchKernelGGL(k, dim3((int)(blocks < cus ? blocks : cus)), dim3(T), lds, st, d, (u32)lut.p, (u32)(0x100000000ull / lut.p), (u64)lut.irr, (const u16 *)a, (int)sa,
+                       (const u16 *)b, (int)sb, (u16 *)out, nvec, err);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
 template <int OP>
 int big16_launch(const MidDesc &d, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int32_t *err)
 {
@@ -834,9 +917,14 @@ int big16_run(const FieldDev &lut, const void *image, int op, const void *a, i64
     case GFA_OP_ADD: return big16_addsub_launch<GFA_OP_ADD>(d, a, sa, b, sb, out, n, st);
     case GFA_OP_SUB: return big16_addsub_launch<GFA_OP_SUB>(d, a, sa, b, sb, out, n, st);
     case GFA_OP_MUL: return big16_launch<GFA_OP_MUL>(d, a, sa, b, sb, out, n, st, err);
-    case GFA_OP_DIV: return big16_launch<GFA_OP_DIV>(d, a, sa, b, sb, out, n, st, err);
+    case GFA_OP_DIV:
+        if (lut.q > 32768 && lut.m == 1) return big16_inv_launch<1>(d, lut, a, sa, b, sb, out, n, st, err);           // r06: a * INV[b], explicit product
+        if (lut.q > 32768 && lut.p == 2 && lut.m == 16) return big16_inv_launch<2>(d, lut, a, sa, b, sb, out, n, st, err);
+        return big16_launch<GFA_OP_DIV>(d, a, sa, b, sb, out, n, st, err);
     case GFA_OP_NEG: return big16_launch<MID_NEG>(d, a, 1, a, 0, out, n, st, err);
-    case GFA_OP_RECIP: return big16_launch<MID_RECIP>(d, a, 1, a, 0, out, n, st, err);
+    case GFA_OP_RECIP:
+        if (lut.q > 32768) return big16_inv_launch<0>(d, lut, nullptr, 0, a, 1, out, n, st, err); // r06: one table instead of two staged in turn
+        return big16_launch<MID_RECIP>(d, a, 1, a, 0, out, n, st, err);
     case GFA_OP_POW: return big16_launch<MID_POW>(d, a, 1, a, 0, out, n, st, err);
     default: return GFA_ERR_UNSUPPORTED;
     }

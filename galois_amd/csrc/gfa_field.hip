@@ -253,10 +253,12 @@ int gfa_field::ensure_device(int *device_out, gfa::FieldDeviceState **st_out)
             if ((rc = upload(&st.mid16, image))) return rc;
         } else if (has_lut && calc.q > 8192 && calc.q <= 65536) { // LOG[qa] | EXP[0 .. q) | ZECH[qa]: indices reduced below q - 1
             const size_t q = (size_t)calc.q, qa = (q + 7) & ~(size_t)7;
-            std::vector<uint16_t> image(3 * qa, 0);
+            std::vector<uint16_t> image((q > 32768 ? 4 : 3) * qa, 0);
             for (size_t i = 0; i < q; i++) image[i] = (uint16_t)h_log[i];
             for (size_t i = 0; i < q; i++) image[qa + i] = (uint16_t)h_exp[i];
             for (size_t i = 0; i < q; i++) image[2 * qa + i] = (uint16_t)h_zech[i];
+            if (q > 32768) // r06: INV[x] = 1 / x (INV[0] = 0): the one table big16_inv_kernel keeps in LDS
+                for (size_t x = 1; x < q; x++) image[3 * qa + x] = (uint16_t)h_exp[(q - 1) - h_log[x]];
             if ((rc = upload(&st.mid16, image))) return rc;
         }
         st.ready = true;

@@ -1386,3 +1386,44 @@ def test_cubic_quotients_at_the_largest_prime_through_the_c_abi():
     assert int(err.item()) == 0
     L.check(lib.gfa_unary(GF._handle, L.OP_RECIP, da.data_ptr(), out.data_ptr(), n, L.U32, st, err.data_ptr()))
     assert int(err.item()) != 0  # a[0] == 0
+
+
+@pytest.mark.parametrize("order,mode", [(2**16, "auto"), (65521, "auto"), (65521, "jit-lookup"), (40009, "auto"), (3**10, "auto"), (251**2, "jit-lookup")])
+def test_fields_of_2e15_to_2e16_elements_divide_through_one_inverse_table(order, mode):
+    """r06: 32768 < q <= 65536 on uint16 arrays of at least 2^19 elements: 1 / b is one gather from the 2q-byte table INV kept in LDS
+    (big16_inv_kernel) instead of LOG and EXP staged in turn; a / b = a * INV[b] with the explicit product in prime fields (Barrett) and in
+    GF(2^16) (carry-less, nine integer multiplies); the other extension fields keep the staged tables for quotients.  Every element against
+    the oracle: zero dividends, 1, q - 1, scalars on either side, a tail of n % 8, uint32 storage (narrowed and widened around the same
+    kernels), zero divisors flagged anywhere."""
+    GF = ga.GF(order)
+    GF.compile(mode)
+    try:
+        F = O.OracleField(GF.characteristic, GF.degree, int(GF.irreducible_poly), int(GF.primitive_element), lookup=True)
+        u = lambda v: v.numpy().astype(np.uint64)
+        rng = np.random.default_rng(order % 1013)
+        n = (1 << 19) + 8 * 1024 * 3 + 5
+        a = rng.integers(0, order, n, dtype=np.uint64)
+        b = rng.integers(1, order, n, dtype=np.uint64)
+        a[:4] = (0, order - 1, 1, 2)
+        b[:4] = (1, order - 1, 2, order // 2)
+        x, y = GF(a.astype(np.uint16)), GF(b.astype(np.uint16))
+        want = F.div(a, b)
+        H.assert_equal_ints(u(x / y), want, f"GF({order}) {mode} div")
+        H.assert_equal_ints(u(np.reciprocal(y)), F.recip(b), "reciprocal")
+        H.assert_equal_ints(u(y ** -1), F.recip(b), "** -1")
+        s = GF(int(b[77]))
+        H.assert_equal_ints(u(x / s), F.div(a, np.full(n, b[77], dtype=np.uint64)), "scalar divisor")
+        H.assert_equal_ints(u(s / y), F.div(np.full(n, b[77], dtype=np.uint64), b), "scalar dividend")
+        xw, yw = GF(a.astype(np.uint32), dtype=np.uint32), GF(b.astype(np.uint32), dtype=np.uint32)
+        H.assert_equal_ints(u(xw / yw), want, "uint32 storage div")
+        H.assert_equal_ints(u(np.reciprocal(yw)), F.recip(b), "uint32 storage reciprocal")
+        for where in (0, 8 * 1024 * 40 + 3, n - 9, n - 1):  # first vector, a later vector of the same workgroup, the last full vector, the n % 8 tail
+            bz = b.copy()
+            bz[where] = 0
+            yz = GF(bz.astype(np.uint16))
+            with pytest.raises(ZeroDivisionError):
+                x / yz
+            with pytest.raises(ZeroDivisionError):
+                np.reciprocal(yz)
+    finally:
+        GF.compile("auto")
