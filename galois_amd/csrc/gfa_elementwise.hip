@@ -1517,6 +1517,10 @@ inline bool big16_products(const gfa_field *f) { return f->use_lookup(); }
 
 } // namespace
 
+namespace gfa { // gfa_elementwise_packed.hip
+int pow24_run(const u32 *exp_tab, const u32 *log_tab, u64 q, const void *a, const i64 *e_ptr, void *out, i64 n, hipStream_t st, int *dev_err);
+}
+
 extern "C" {
 
 int gfa_binary(gfa_field_t *f, int op, const void *a, int64_t sa, const void *b, int64_t sb, void *out, int64_t n,
@@ -1759,6 +1763,11 @@ int gfa_power(gfa_field_t *f, const void *a, int64_t sa, const int64_t *exps, in
         }
     }
     // GF(2^m), m <= 16, in AUTO: square-and-multiply over shift-and-xor products is far behind two table gathers (14 vs 86 Gop/s)
+    const bool bin_tables_ = f->mode == GFA_MODE_AUTO && f->has_lut && f->calc.kind == KIND_BIN;
+    if ((f->use_lookup() || bin_tables_) && sa == 1 && se == 0 && dtype == GFA_U32 && f->calc.q > 65536) { // r06: one gather from a per-call table of x ** e
+        rc = pow24_run(ds->exp_tab, ds->log_tab, f->calc.q, a, exps, out, n, (hipStream_t)stream, dev_err);
+        if (rc != GFA_ERR_UNSUPPORTED) return rc;
+    }
     const bool bin_tables = f->mode == GFA_MODE_AUTO && f->has_lut && f->calc.kind == KIND_BIN; // r06: also GF(2^17) .. GF(2^20) (17 -> see profiles/r06_ew_bin_inverse_table.txt)
     if (f->use_lookup() || bin_tables)
         return dispatch_intarg(f->lut_desc(*ds), dtype, true, a, sa, exps, se, out, n, (hipStream_t)stream, dev_err);

@@ -659,13 +659,15 @@ __global__ __launch_bounds__(T) void big16_exp_kernel(MidDesc d, const u16 *__re
 // through it as through big16_exp_kernel.  MODE 0: 1 / b.  MODE 1: a / b = a * INV[b] mod p in a PRIME field (one 32-bit product, Barrett).
 // MODE 2: the same in GF(2^16): Bin::clmul16_lo / _hi (nine integer multiplies per element, two elements per register) and two
 // 256-entry reduction tables behind INV.  Same values as divide_ufunc / reciprocal_ufunc (_lookup.py:176-235, _calculate.py:447-513).
+// MODE 3: x ** e for ONE exponent: the table is P[x] = x^e, filled per call by big16_pow_table_kernel (q table look-ups) -- the array then needs one
+// gather per element where LOG and EXP staged in turn ran at 0.34; 0 ** negative is flagged (power_ufunc.lookup, _lookup.py:247-270).
 template <int MODE, int T>
-__global__ __launch_bounds__(T) void big16_inv_kernel(MidDesc d, u32 p, u32 mu_p, u64 irr, const u16 *__restrict__ a, int sa, const u16 *__restrict__ b, int sb,
-                                                      u16 *__restrict__ out, i64 nvec, int32_t *err)
+__global__ __launch_bounds__(T) void big16_inv_kernel(MidDesc d, const u16 *__restrict__ table, u32 p, u32 mu_p, u64 irr, const u16 *__restrict__ a, int sa,
+                                                      const u16 *__restrict__ b, int sb, u16 *__restrict__ out, i64 nvec, int32_t *err)
 {
     extern __shared__ __attribute__((aligned(16))) u16 mid_lds[];
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(d.image + 3 * (size_t)d.qa); // INV: qa entries
+        const uint4 *src = reinterpret_cast<const uint4 *>(table); // INV (the image's fourth table) or P: qa entries
         uint4 *dst = reinterpret_cast<uint4 *>(mid_lds);
         for (int i = threadIdx.x; i < (int)(d.qa / 8u); i += T) dst[i] = src[i];
     }
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(T) void big16_inv_kernel(MidDesc d, u32 p, u32 mu_p
     }
     u32x4 xs = {0, 0, 0, 0}, ys = {0, 0, 0, 0};
     if (!sb) { const u32 s = b[0]; xs = u32x4{s, s, s, s} * 0x10001u; }
-    if (MODE != 0 && !sa) { const u32 s = a[0]; ys = u32x4{s, s, s, s} * 0x10001u; }
+    if ((MODE == 1 || MODE == 2) && !sa) { const u32 s = a[0]; ys = u32x4{s, s, s, s} * 0x10001u; }
     const u32x4 *av = reinterpret_cast<const u32x4 *>(a), *bv = reinterpret_cast<const u32x4 *>(b);
     u32x4 *ov = reinterpret_cast<u32x4 *>(out);
     bool bad = false;
@@ -693,18 +695,18 @@ __global__ __launch_bounds__(T) void big16_inv_kernel(MidDesc d, u32 p, u32 mu_p
     const i64 stride = (i64)gridDim.x * T;
     i64 i = (i64)blockIdx.x * T + threadIdx.x;
     u32x4 x = xs, y = ys;
-    if (i < nvec) { if (sb) x = bv[i]; if (MODE != 0 && sa) y = av[i]; }
+    if (i < nvec) { if (sb) x = bv[i]; if ((MODE == 1 || MODE == 2) && sa) y = av[i]; }
     while (i < nvec) {
         const i64 nx = i + stride;
         u32x4 xn = xs, yn = ys;
-        if (nx < nvec) { if (sb) xn = bv[nx]; if (MODE != 0 && sa) yn = av[nx]; } // the next vectors travel while this one is gathered
+        if (nx < nvec) { if (sb) xn = bv[nx]; if ((MODE == 1 || MODE == 2) && sa) yn = av[nx]; } // the next vectors travel while this one is gathered
         u32x4 r;
 #pragma unroll
         for (int w = 0; w < 4; w++) {
             const u32 bl = x[w] & 0xffffu, bh = x[w] >> 16;
             bad |= bl == 0u || bh == 0u;
             const u32 il = mid_lds[bl], ih = mid_lds[bh];
-            if constexpr (MODE == 0) r[w] = il | (ih << 16);
+            if constexpr (MODE == 0 || MODE == 3) r[w] = il | (ih << 16);
             else if constexpr (MODE == 1) r[w] = prime_mul(y[w] & 0xffffu, il) | (prime_mul(y[w] >> 16, ih) << 16);
             else {
                 const u32 iw = il | (ih << 16);
@@ -714,8 +716,26 @@ __global__ __launch_bounds__(T) void big16_inv_kernel(MidDesc d, u32 p, u32 mu_p
         ov[i] = r;
         x = xn; y = yn; i = nx;
     }
+    if (MODE == 3) bad = bad && d.e_ptr[0] < 0;
     if (__any(bad)) {
         if ((threadIdx.x & 63) == 0 && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
+    }
+}
+
+// P[x] = x ** e for every element x of the field (the exponent in device memory, d.e_ptr): EXP[(LOG[x] * e) mod (q - 1)], 0 ** e = 0, x ** 0 = 1
+__global__ __launch_bounds__(256) void big16_pow_table_kernel(MidDesc d, u16 *__restrict__ tab)
+{
+    const i64 e = d.e_ptr[0];
+    const MidPow pw{exponent_mod(e, d.qm1, d.mu, d.c32), e == 0, e < 0};
+    const u16 *lg = d.image, *ex = d.image + d.qa;
+    for (u32 x = blockIdx.x * 256 + threadIdx.x; x < d.qa; x += gridDim.x * 256) {
+        u32 r = 0;
+        if (x < d.q) {
+            u32 s = mod_barrett((u32)lg[x] * pw.em, d.qm1, d.mu);
+            s = s >= d.qm1 ? s - d.qm1 : s;
+            r = pw.e_zero ? 1u : (x == 0 ? 0u : (u32)ex[s]);
+        }
+        tab[x] = (u16)r;
     }
 }
 
@@ -730,8 +750,19 @@ int big16_inv_launch(const MidDesc &d, const FieldDev &lut, const void *a, i64 s
     const i64 nvec = n >> 3;
     const i64 blocks = (nvec + T - 1) / T;
     const int cus = mid_num_cus();
-    hipLaunchKernelGGL(k, dim3((int)(blocks < cus ? blocks : cus)), dim3(T), lds, st, d, (u32)lut.p, (u32)(0x100000000ull / lut.p), (u64)lut.irr, (const u16 *)a, (int)sa,
-                       (const u16 *)b, (int)sb, (u16 *)out, nvec, err);
+    if (MODE == 3) { // the per-call power table: qa entries of stream-ordered scratch
+        u16 *tab = nullptr;
+        if (gfa::scratch_alloc((void **)&tab, (size_t)d.qa * sizeof(u16), st) != hipSuccess) { (void)hipGetLastError(); return GFA_ERR_UNSUPPORTED; }
+        hipLaunchKernelGGL(big16_pow_table_kernel, dim3((int)(d.qa / 256u)), dim3(256), 0, st, d, tab);
+        hipLaunchKernelGGL(k, dim3((int)(blocks < cus ? blocks : cus)), dim3(T), lds, st, d, (const u16 *)tab, 0u, 0u, (u64)0, (const u16 *)nullptr, 0, (const u16 *)b, 1,
+                           (u16 *)out, nvec, err);
+        const hipError_t le = hipGetLastError();
+        GFA_HIP(gfa::scratch_free(tab, st));
+        GFA_HIP(le);
+        return GFA_OK;
+    }
+    hipLaunchKernelGGL(k, dim3((int)(blocks < cus ? blocks : cus)), dim3(T), lds, st, d, d.image + 3 * (size_t)d.qa, (u32)lut.p, (u32)(0x100000000ull / lut.p), (u64)lut.irr,
+                       (const u16 *)a, (int)sa, (const u16 *)b, (int)sb, (u16 *)out, nvec, err);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }
@@ -925,7 +956,12 @@ int big16_run(const FieldDev &lut, const void *image, int op, const void *a, i64
     case GFA_OP_RECIP:
         if (lut.q > 32768) return big16_inv_launch<0>(d, lut, nullptr, 0, a, 1, out, n, st, err); // r06: one table instead of two staged in turn
         return big16_launch<MID_RECIP>(d, a, 1, a, 0, out, n, st, err);
-    case GFA_OP_POW: return big16_launch<MID_POW>(d, a, 1, a, 0, out, n, st, err);
+    case GFA_OP_POW:
+        if (lut.q > 32768) { // r06: a per-call table of x ** e, then one gather per element
+            const int rc = big16_inv_launch<3>(d, lut, nullptr, 0, a, 1, out, n, st, err);
+            if (rc != GFA_ERR_UNSUPPORTED) return rc;
+        }
+        return big16_launch<MID_POW>(d, a, 1, a, 0, out, n, st, err);
     default: return GFA_ERR_UNSUPPORTED;
     }
 }

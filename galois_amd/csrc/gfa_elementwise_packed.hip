@@ -236,7 +236,7 @@ __device__ __forceinline__ pu32 inv24_load(const uint8_t *__restrict__ t, pu32 x
 template <int M, bool RECIP>
 __global__ __launch_bounds__(PK_THREADS) void packed_divt_kernel(Plan pl, MulAux ax, const pu32 *__restrict__ gtab, const uint8_t *__restrict__ inv24,
                                                                   const uint32_t *__restrict__ a, int sa, const uint32_t *__restrict__ b, int sb,
-                                                                  uint32_t *__restrict__ out, i64 n, int *err)
+                                                                  uint32_t *__restrict__ out, i64 n, int *err, const i64 *__restrict__ e_ptr = nullptr)
 {
     constexpr int V = 4;
     extern __shared__ pu32 pk_tab[];
@@ -294,7 +294,25 @@ __global__ __launch_bounds__(PK_THREADS) void packed_divt_kernel(Plan pl, MulAux
         const pu32 ib = inv24_load(inv24, xb);
         out[t0] = RECIP ? ib : mul_digits<M>(pl, ax, to_packed(pl, pk_tab, sa ? a[t0] : a0), to_packed(pl, pk_tab, ib));
     }
+    if (e_ptr) bad = bad && e_ptr[0] < 0; // the table holds x ** e (pow24_run): only 0 ** negative is an error
     if (bad && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
+}
+
+// P[x] = x ** e for every element of a table field (65536 < q <= 2^20), 3-byte entries as the inverse table: EXP[(LOG[x] e) mod (q - 1)],
+// 0 ** e = 0, x ** 0 = 1 (power_ufunc.lookup, _lookup.py:247-270); the exponent is in device memory
+__global__ __launch_bounds__(256) void pow24_table_kernel(const u32 *__restrict__ exp_tab, const u32 *__restrict__ log_tab, u32 q, const i64 *__restrict__ e_ptr,
+                                                           uint8_t *__restrict__ tab)
+{
+    const i64 e = e_ptr[0], qm1 = (i64)q - 1;
+    i64 em = e % qm1;
+    em = em < 0 ? em + qm1 : em;
+    for (u32 x = blockIdx.x * 256 + threadIdx.x; x < q; x += gridDim.x * 256) {
+        u32 r;
+        if (e == 0) r = 1u;
+        else if (x == 0) r = 0u;
+        else r = exp_tab[(u32)(((u64)log_tab[x] * (u64)em) % (u64)qm1)];
+        tab[3 * (size_t)x] = (uint8_t)r; tab[3 * (size_t)x + 1] = (uint8_t)(r >> 8); tab[3 * (size_t)x + 2] = (uint8_t)(r >> 16);
+    }
 }
 
 struct PackedDev {
@@ -581,6 +599,23 @@ int packed_divn_run(const FieldDev &c, int dtype, const void *a, i64 sa, const v
     else rc = launch_div2<uint16_t, false>(recip, grid, a2, inv, a, sa, b, sb, out, n, st, dev_err);
     if (rc) return rc;
     GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
+// x ** e, one exponent (device memory), uint32 arrays of a table field with 65536 < q <= 2^20 (r06): a per-call table of x ** e in stream-ordered
+// scratch (q look-ups), then ONE gather per element where LOG + EXP were two
+int pow24_run(const u32 *exp_tab, const u32 *log_tab, u64 q, const void *a, const i64 *e_ptr, void *out, i64 n, hipStream_t st, int *dev_err)
+{
+    if (!exp_tab || !log_tab || q <= 65536 || q > ((u64)1 << 20) || n < 8 * (i64)q || !al16p(out) || !al16p(a)) return GFA_ERR_UNSUPPORTED;
+    uint8_t *tab = nullptr;
+    if (scratch_alloc((void **)&tab, 3 * (size_t)q + 4, st) != hipSuccess) { (void)hipGetLastError(); return GFA_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(pow24_table_kernel, dim3((int)((q + 255) / 256)), dim3(256), 0, st, exp_tab, log_tab, (u32)q, e_ptr, tab);
+    const i64 blocks = std::max<i64>(1, (n / 4 + PK_THREADS - 1) / PK_THREADS);
+    hipLaunchKernelGGL((packed_divt_kernel<4, true>), dim3((int)std::min<i64>(blocks, (i64)num_cus() * 4)), dim3(PK_THREADS), 0, st, Plan{}, MulAux{},
+                       (const pu32 *)nullptr, (const uint8_t *)tab, (const uint32_t *)nullptr, 0, (const uint32_t *)a, 1, (uint32_t *)out, n, dev_err, e_ptr);
+    const hipError_t le = hipGetLastError();
+    GFA_HIP(scratch_free(tab, st));
+    GFA_HIP(le);
     return GFA_OK;
 }
 

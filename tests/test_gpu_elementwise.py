@@ -1414,8 +1414,15 @@ def test_fields_of_2e15_to_2e16_elements_divide_through_one_inverse_table(order,
         s = GF(int(b[77]))
         H.assert_equal_ints(u(x / s), F.div(a, np.full(n, b[77], dtype=np.uint64)), "scalar divisor")
         H.assert_equal_ints(u(s / y), F.div(np.full(n, b[77], dtype=np.uint64), b), "scalar dividend")
+        for k in (0, 1, 2, 12345, -1, -7, order - 1, order, -(2**40) - 3, 2**62 + 1):  # one gather from a per-call table of x ** k
+            H.assert_equal_ints(u(y ** k), F.pow(b, np.full(n, k, dtype=np.int64)), f"y ** {k}")
+        for k in (0, 3, order + 4):  # zero bases with non-negative exponents
+            H.assert_equal_ints(u(x ** k), F.pow(a, np.full(n, k, dtype=np.int64)), f"x ** {k}")
+        with pytest.raises(ZeroDivisionError):
+            x ** -3
         xw, yw = GF(a.astype(np.uint32), dtype=np.uint32), GF(b.astype(np.uint32), dtype=np.uint32)
         H.assert_equal_ints(u(xw / yw), want, "uint32 storage div")
+        H.assert_equal_ints(u(yw ** -12345), F.pow(b, np.full(n, -12345, dtype=np.int64)), "uint32 storage power")
         H.assert_equal_ints(u(np.reciprocal(yw)), F.recip(b), "uint32 storage reciprocal")
         for where in (0, 8 * 1024 * 40 + 3, n - 9, n - 1):  # first vector, a later vector of the same workgroup, the last full vector, the n % 8 tail
             bz = b.copy()
@@ -1427,3 +1434,29 @@ def test_fields_of_2e15_to_2e16_elements_divide_through_one_inverse_table(order,
                 np.reciprocal(yz)
     finally:
         GF.compile("auto")
+
+
+@pytest.mark.parametrize("order", [7**7, 3**11, 2**17, 2**20, 97**3])
+def test_scalar_powers_of_table_fields_above_2e16_elements_through_a_per_call_table(order):
+    """r06: x ** k with ONE exponent over a table field of 65536 < q <= 2^20 elements, uint32 arrays of at least 8 q elements: the table
+    P[x] = x ** k is filled per call (q look-ups through LOG / EXP, 3-byte entries in stream-ordered scratch), the array then takes one
+    gather per element (pow24_run) where power_ufunc.lookup's LOG + EXP (_lookup.py:247-270) are two.  Against the oracle for positive,
+    negative, zero and huge exponents; 0 ** k for k >= 0; 0 ** negative raises; shorter arrays (generic kernels) agree."""
+    GF = ga.GF(order)
+    F = O.OracleField(GF.characteristic, GF.degree, int(GF.irreducible_poly), int(GF.primitive_element), lookup=True)
+    u = lambda v: v.numpy().astype(np.uint64)
+    rng = np.random.default_rng(order % 991)
+    n = 8 * order + 1027
+    a = rng.integers(0, order, n, dtype=np.uint64)
+    b = rng.integers(1, order, n, dtype=np.uint64)
+    a[:3] = (0, 1, order - 1)
+    b[:3] = (1, order - 1, GF.characteristic)
+    x, y = GF(a.astype(np.uint32), dtype=np.uint32), GF(b.astype(np.uint32), dtype=np.uint32)
+    for k in (0, 1, 2, 12345, -1, -12345, order - 1, order - 2, order + 7, -(2**45) - 1, 2**62 + 3):
+        H.assert_equal_ints(u(y ** k), F.pow(b, np.full(n, k, dtype=np.int64)), f"GF({order}) y ** {k}")
+    for k in (0, 5, order):
+        H.assert_equal_ints(u(x ** k), F.pow(a, np.full(n, k, dtype=np.int64)), f"x ** {k}")
+    with pytest.raises(ZeroDivisionError):
+        x ** -2
+    H.assert_equal_ints(u(y[: 4 * 1024 + 3] ** -12345), F.pow(b[: 4 * 1024 + 3], np.full(4 * 1024 + 3, -12345, dtype=np.int64)), "short array")
+    H.assert_equal_ints(u(y[1:] ** 77), F.pow(b[1:], np.full(n - 1, 77, dtype=np.int64)), "misaligned view")

@@ -30,6 +30,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "--band16":  # r06: GF(p^m), 32768 < q <
     cases = [(251**2, np.uint16, "auto"), (251**2, np.uint32, "auto"), (37**3, np.uint16, "auto"), (251**2, np.uint16, "jit-lookup"), (3**10, np.uint16, "auto")]
 if len(sys.argv) > 1 and sys.argv[1] == "--div3":  # r06: degree-3 quotients by Cramer's rule
     cases = [(97**3, np.uint32, "auto"), (41**3, np.uint32, "auto"), (97**3, np.uint32, "jit-lookup")]
+if len(sys.argv) > 1 and sys.argv[1] == "--pow24":  # r06: scalar powers of table fields above 65536 elements: per-call table + one gather
+    cases = [(7**7, np.uint32, "auto"), (5**8, np.uint32, "auto"), (3**11, np.uint32, "auto"), (2**20, np.uint32, "auto"), (2**17, np.uint32, "auto"), (97**3, np.uint32, "auto")]
 if len(sys.argv) > 1 and sys.argv[1] == "--inv16":  # r06: 32768 < q <= 65536 on uint16: reciprocals / quotients through one inverse table in LDS
     cases = [(2**16, np.uint16, "auto"), (65521, np.uint16, "auto"), (65521, np.uint16, "jit-lookup"), (3**10, np.uint16, "auto"), (251**2, np.uint16, "auto"),
              (2**16, np.uint32, "jit-lookup"), (65521, np.uint32, "jit-lookup")]

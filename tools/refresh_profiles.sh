@@ -68,6 +68,7 @@ python tools/ew_bench.py --div3 2>/dev/null | grep field > "$OUT/${R}_ew_div3.tx
 python tools/ew_bench.py --divt 2>/dev/null | grep field > "$OUT/${R}_ew_divt.txt"
 python tools/ew_bench.py --divwide 2>/dev/null | grep field > "$OUT/${R}_ew_div_wide.txt"
 python tools/ew_bench.py --inv16 2>/dev/null | grep field > "$OUT/${R}_ew_inv16.txt"
+python tools/ew_bench.py --pow24 2>/dev/null | grep field > "$OUT/${R}_ew_pow24.txt"
 python tools/ew_bench.py --bininv 2>/dev/null | grep field > "$OUT/${R}_ew_bin_inverse_table.txt"
 python tools/ew_bench.py --band16 2>/dev/null | grep field > "$OUT/${R}_ew_band16.txt"
 ./_variants/strided_pieces > "$OUT/${R}_strided_pieces.txt" 2>/dev/null
