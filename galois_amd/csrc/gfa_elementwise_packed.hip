@@ -231,7 +231,18 @@ __global__ __launch_bounds__(PK_THREADS) void packed_div3_kernel(Div3Aux ax, con
 // the field's 3-byte inverse table (gfa_field::inverse_table: 2.4 MB for GF(7^7), inside one XCD's L2, where LOG + EXP were two gathers out of
 // 6.6 MB), the quotient a * (1 / b) the digit-table product of packed_mul_kernel.  Gathers run one iteration ahead of the products, operand loads two.
 typedef pu32 __attribute__((aligned(1))) pu32_unaligned;
-__device__ __forceinline__ pu32 inv24_load(const uint8_t *__restrict__ t, pu32 x) { return *reinterpret_cast<const pu32_unaligned *>(t + 3u * x) & 0xffffffu; }
+#ifndef GFA_INV24_NT
+#define GFA_INV24_NT 0 // 1: non-temporal gathers (measured: see DESIGN 4.2 item 6)
+#endif
+__device__ __forceinline__ pu32 inv24_load(const uint8_t *__restrict__ t, pu32 x)
+{
+    const pu32_unaligned *q = reinterpret_cast<const pu32_unaligned *>(t + 3u * x);
+#if GFA_INV24_NT == 1
+    return __builtin_nontemporal_load(q) & 0xffffffu;
+#else
+    return *q & 0xffffffu;
+#endif
+}
 
 template <int M, bool RECIP>
 __global__ __launch_bounds__(PK_THREADS) void packed_divt_kernel(Plan pl, MulAux ax, const pu32 *__restrict__ gtab, const uint8_t *__restrict__ inv24,
