@@ -1517,7 +1517,8 @@ inline bool big16_products(const gfa_field *f) { return f->use_lookup(); }
 
 } // namespace
 
-namespace gfa { // gfa_elementwise_packed.hip
+namespace gfa { // gfa_elementwise_mid.hip, gfa_elementwise_packed.hip
+int big16_power_each(const FieldDev &lut, const void *image, const void *a, const i64 *e, void *out, i64 n, hipStream_t st, int32_t *err);
 int pow24_run(const u32 *exp_tab, const u32 *log_tab, u64 q, const void *a, const i64 *e_ptr, void *out, i64 n, hipStream_t st, int *dev_err);
 }
 
@@ -1750,6 +1751,15 @@ int gfa_power(gfa_field_t *f, const void *a, int64_t sa, const int64_t *exps, in
             rc = se == 0 ? mid_power(f->lut_desc(*ds), ds->mid16, dtype, a, exps, out, n, (hipStream_t)stream, dev_err)
                          : (dtype == GFA_U16 ? mid_power_each(f->lut_desc(*ds), ds->mid16, a, exps, out, n, (hipStream_t)stream, dev_err)
                                              : GFA_ERR_UNSUPPORTED);
+            if (rc != GFA_ERR_UNSUPPORTED) return rc;
+        }
+        if (se == 1 && big16_eligible(f->calc, ds->mid16, dtype, n) && f->calc.q > 32768) { // r06: an exponent per element: LOG pass + EXP pass
+            rc = big16_power_each(f->lut_desc(*ds), ds->mid16, a, exps, out, n, (hipStream_t)stream, dev_err);
+            if (rc == GFA_OK && (n & 7)) {
+                const i64 o = n & ~(i64)7;
+                const FieldDev td = f->use_lookup() ? f->lut_desc(*ds) : f->calc;
+                return dispatch_intarg(td, dtype, true, (const uint16_t *)a + o, 1, exps + o, 1, (uint16_t *)out + o, n & 7, (hipStream_t)stream, dev_err);
+            }
             if (rc != GFA_ERR_UNSUPPORTED) return rc;
         }
         if (se == 0 && big16_eligible(f->calc, ds->mid16, dtype, n)) {

@@ -767,6 +767,51 @@ int big16_inv_launch(const MidDesc &d, const FieldDev &lut, const void *a, i64 s
     return GFA_OK;
 }
 
+// np.power with one exponent PER ELEMENT (int64 array) for 32768 < q <= 65536 (r06): the first of the two streaming passes with LOG in LDS and
+// the exponent array read beside the operands -- index = (LOG[x] (e mod (q - 1))) mod (q - 1), 0xFFFF where the result is 0, 0 where e == 0 --
+// then big16_exp_kernel.  The generic table kernel gathered both tables from L2 (0.13 of the roofline).
+template <int T>
+__global__ __launch_bounds__(T) void big16_powv_index_kernel(MidDesc d, const u16 *__restrict__ a, const i64 *__restrict__ e, u16 *__restrict__ idx_out, i64 nvec,
+                                                             int32_t *err)
+{
+    extern __shared__ __attribute__((aligned(16))) u16 mid_lds[];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(d.image); // LOG: qa entries
+        uint4 *dst = reinterpret_cast<uint4 *>(mid_lds);
+        for (int i = threadIdx.x; i < (int)(d.qa / 8u); i += T) dst[i] = src[i];
+    }
+    const u32x4 *av = reinterpret_cast<const u32x4 *>(a);
+    const u32x4 *ev = reinterpret_cast<const u32x4 *>(e); // 4 vectors (8 exponents) per vector of a
+    u32x4 *ov = reinterpret_cast<u32x4 *>(idx_out);
+    bool bad = false;
+    __syncthreads();
+    auto one = [&](u32 x, i64 k) -> u32 {
+        const u32 em = exponent_mod(k, d.qm1, d.mu, d.c32);
+        u32 s = mod_barrett((u32)mid_lds[x] * em, d.qm1, d.mu);
+        s = s >= d.qm1 ? s - d.qm1 : s;
+        bad |= x == 0 && k < 0;
+        return k == 0 ? 0u : (x == 0 ? 0xffffu : s);
+    };
+    const i64 stride = (i64)gridDim.x * T;
+    for (i64 i = (i64)blockIdx.x * T + threadIdx.x; i < nvec; i += stride) {
+        const u32x4 cx = av[i];
+        u32x4 k2[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) k2[w] = ev[4 * i + w];
+        u32x4 r;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const u32 lo = one(cx[w] & 0xffffu, (i64)(((u64)k2[w][1] << 32) | k2[w][0]));
+            const u32 hi = one(cx[w] >> 16, (i64)(((u64)k2[w][3] << 32) | k2[w][2]));
+            r[w] = lo | (hi << 16);
+        }
+        ov[i] = r;
+    }
+    if (__any(bad)) {
+        if ((threadIdx.x & 63) == 0 && err) atomicOr(err, GFA_DEVERR_ZERO_DIVISION);
+    }
+}
+
 template <int OP>
 int big16_launch(const MidDesc &d, const void *a, i64 sa, const void *b, i64 sb, void *out, i64 n, hipStream_t st, int32_t *err)
 {
@@ -964,6 +1009,37 @@ int big16_run(const FieldDev &lut, const void *image, int op, const void *a, i64
         return big16_launch<MID_POW>(d, a, 1, a, 0, out, n, st, err);
     default: return GFA_ERR_UNSUPPORTED;
     }
+}
+
+// x ** e with an exponent per element, 32768 < q <= 65536, uint16 arrays (r06): covers the first n & ~7 elements (as big16_run)
+int big16_power_each(const FieldDev &lut, const void *image, const void *a, const i64 *e, void *out, i64 n, hipStream_t st, int32_t *err)
+{
+    if (!image || lut.q <= 32768 || lut.q > 65536 || n < BIG16_MIN_N || !al16(out) || !al16(a) || !al16(e)) return GFA_ERR_UNSUPPORTED;
+    const MidDesc d = make_desc(lut, (const u16 *)image);
+    constexpr int T = 1024;
+    auto ka = big16_powv_index_kernel<T>;
+    auto kb = big16_exp_kernel<T>;
+    static bool sattr = false;
+    if (!sattr) {
+        GFA_HIP(hipFuncSetAttribute((const void *)ka, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        GFA_HIP(hipFuncSetAttribute((const void *)kb, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        sattr = true;
+    }
+    const size_t lds = (size_t)d.qa * sizeof(u16);
+    const i64 nvec = n >> 3;
+    const int cus = mid_num_cus();
+    const i64 slice = std::min<i64>(nvec, (i64)1 << 23); // index slices of at most 128 MiB: they stay in the Infinity Cache between the two kernels
+    u16 *idx = nullptr;
+    if (gfa::scratch_alloc((void **)&idx, (size_t)slice * 16, st) != hipSuccess) { (void)hipGetLastError(); return GFA_ERR_UNSUPPORTED; }
+    for (i64 v0 = 0; v0 < nvec; v0 += slice) {
+        const i64 cnt = std::min<i64>(slice, nvec - v0);
+        hipLaunchKernelGGL(ka, dim3(cus), dim3(T), lds, st, d, (const u16 *)a + v0 * 8, e + v0 * 8, idx, cnt, err);
+        hipLaunchKernelGGL(kb, dim3(cus), dim3(T), lds, st, d, (const u16 *)idx, (u16 *)out + v0 * 8, cnt);
+    }
+    const hipError_t le = hipGetLastError();
+    GFA_HIP(gfa::scratch_free(idx, st));
+    GFA_HIP(le);
+    return GFA_OK;
 }
 
 // ---- uint32 / int64 STORAGE of fields with 32768 < q <= 65536 (r05; the reference's dtype list: _fields/_ufunc.py:97-111) ----

@@ -1420,6 +1420,17 @@ def test_fields_of_2e15_to_2e16_elements_divide_through_one_inverse_table(order,
             H.assert_equal_ints(u(x ** k), F.pow(a, np.full(n, k, dtype=np.int64)), f"x ** {k}")
         with pytest.raises(ZeroDivisionError):
             x ** -3
+        # an exponent per element: LOG pass + EXP pass through a 2-byte index array (big16_power_each)
+        ks = rng.integers(-(2**40), 2**40, n)
+        ks[:6] = (0, 1, -1, order - 1, -(order - 1), 2**62)
+        H.assert_equal_ints(u(y ** ks), F.pow(b, ks.astype(np.int64)), "exponent array")
+        kp = np.abs(ks)
+        kp[0] = 0  # 0 ** 0 == 1
+        H.assert_equal_ints(u(x ** kp), F.pow(a, kp.astype(np.int64)), "exponent array, zero bases")
+        kz = kp.copy()
+        kz[0] = -5  # a[0] == 0
+        with pytest.raises(ZeroDivisionError):
+            x ** kz
         xw, yw = GF(a.astype(np.uint32), dtype=np.uint32), GF(b.astype(np.uint32), dtype=np.uint32)
         H.assert_equal_ints(u(xw / yw), want, "uint32 storage div")
         H.assert_equal_ints(u(yw ** -12345), F.pow(b, np.full(n, -12345, dtype=np.int64)), "uint32 storage power")
