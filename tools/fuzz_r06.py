@@ -142,6 +142,13 @@ while time.time() < t_end:
                                 (A * B[k], F2.mul(a, full(b[k])), "array * scalar"),
                                 (B ** (kk := int(rng.integers(-q, q))), F2.pow(b, np.full(n, kk, dtype=np.int64)), "array ** scalar")):
             assert np.array_equal(u64(got), want), ("ext32", q, what, n, off)
+        if 65536 < q <= 400000 and rng.random() < 0.15:  # arrays of at least 8 q elements: scalar powers through the per-call table of x ** k
+            n2 = 8 * q + int(rng.integers(0, 5000))
+            b2 = rng.integers(0, q, n2, dtype=np.uint64)
+            kk = int(rng.integers(0, 2**40)) if rng.integers(0, 2) else int(rng.integers(-q, q))
+            if kk < 0:
+                b2[b2 == 0] = 1
+            assert np.array_equal(u64(G2(b2.astype(np.uint32), dtype=np.uint32) ** kk), F2.pow(b2, np.full(n2, kk, dtype=np.int64))), ("ext32 pow table", q, kk, n2)
         if (a == 0).any():
             try:
                 B / A
