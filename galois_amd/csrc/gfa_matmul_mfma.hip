@@ -13,6 +13,8 @@
 //   2. gemm_i8_nt_kernel: 256 x 256 (16 waves) or 128 x 128 (4 waves) block tile, each wave 2 x 2 MFMA tiles of 32 x 32,
 //      K step 64, register-prefetched global loads, LDS rows padded to 80 bytes (conflict-free ds_read_b128), epilogue
 //      acc mod p.
+#include <cstdlib>
+
 #include "gfa_internal.h"
 
 using namespace gfa;
@@ -23,22 +25,35 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 64, PITCH = 80;
+// GF(2^m) bit planes from M N K >= 2^GFA_MFMA_BITS_MIN_LOG (environment, read once; default 24 = 256^3, where the planes already win 50 us to 121 us for GF(2^8) and 86 us to 1.5 ms for GF(2^16): tools/matmul_bits_crossover.py; the tests lower it)
+inline int mfma_bits_min_log()
+{
+    static const int v = [] { const char *e = getenv("GFA_MFMA_BITS_MIN_LOG"); const int x = e ? atoi(e) : 24; return x < 16 ? 16 : (x > 62 ? 62 : x); }();
+    return v;
+}
 
 __device__ __forceinline__ int8_t centre(u32 a, u32 p, u32 half) { return (int8_t)(a > half ? (int)a - (int)p : (int)a); }
 // operand byte: the centred residue (shift < 0, p <= 256) or the 7-bit limb of the element at bit `shift` (larger primes)
+// (shift >= 64: the PARITY of the element's bits under the mask `shift - 64` -- the Karatsuba planes of GF(2^m), run_mfma_bits, which
+// stages all its planes in one launch: plane blockIdx.z takes its mask from PlaneMasks)
+struct PlaneMasks {
+    uint16_t m[81];
+};
 __device__ __forceinline__ int8_t operand(u64 a, u32 p, u32 half, int shift)
 {
+    if (shift >= 64) return (int8_t)(__popc((u32)a & (u32)(shift - 64)) & 1);
     return shift < 0 ? centre((u32)a, p, half) : (int8_t)((a >> shift) & 127u);
 }
 
 // dst[r][c] = centre(src[r][c]) for r < rows, c < cols; zero elsewhere in the (rows_p x cols_p) padded array
 template <typename T>
 __global__ __launch_bounds__(256) void centre_rows_kernel(const T *__restrict__ src, int8_t *__restrict__ dst, i64 rows, i64 cols,
-                                                          i64 rows_p, i64 cols_p, u32 p, i64 src_bstride, i64 dst_bstride, int shift)
+                                                          i64 rows_p, i64 cols_p, u32 p, i64 src_bstride, i64 dst_bstride, int shift, PlaneMasks pm)
 {
     const T *s = src + (i64)blockIdx.z * src_bstride;
     int8_t *d = dst + (i64)blockIdx.z * dst_bstride;
     const u32 half = p >> 1;
+    if (shift == 64) shift = 64 + (int)pm.m[blockIdx.z];
     const i64 total = rows_p * cols_p;
     for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (i64)gridDim.x * blockDim.x) {
         const i64 r = e / cols_p, c = e - r * cols_p;
@@ -49,12 +64,13 @@ __global__ __launch_bounds__(256) void centre_rows_kernel(const T *__restrict__ 
 // dst[c][r] = centre(src[r][c]) (transpose), 32 x 32 tiles through LDS; dst is (cols_p x rows_p), zero padded
 template <typename T>
 __global__ __launch_bounds__(256) void centre_transpose_kernel(const T *__restrict__ src, int8_t *__restrict__ dst, i64 rows, i64 cols,
-                                                               i64 rows_p, i64 cols_p, u32 p, i64 src_bstride, i64 dst_bstride, int shift)
+                                                               i64 rows_p, i64 cols_p, u32 p, i64 src_bstride, i64 dst_bstride, int shift, PlaneMasks pm)
 {
     __shared__ int8_t tile[32][33];
     const T *s = src + (i64)blockIdx.z * src_bstride;
     int8_t *d = dst + (i64)blockIdx.z * dst_bstride;
     const u32 half = p >> 1;
+    if (shift == 64) shift = 64 + (int)pm.m[blockIdx.z];
     const i64 r0 = (i64)blockIdx.y * 32, c0 = (i64)blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
     for (int j = ty; j < 32; j += 8) {
@@ -195,9 +211,9 @@ int run_mfma(const FieldDev &fd, const void *a, const void *b, void *out, i64 ba
         const i64 total = Mp * Kp;
         const unsigned gx = (unsigned)std::min<i64>((total + 255) / 256, 65535);
         hipLaunchKernelGGL(centre_rows_kernel<T>, dim3(gx, 1, (unsigned)nA), dim3(256), 0, st, (const T *)a, Ac, M, K, Mp, Kp, p,
-                           a_bstride, Mp * Kp, -1);
+                           a_bstride, Mp * Kp, -1, PlaneMasks{});
         hipLaunchKernelGGL(centre_transpose_kernel<T>, dim3((unsigned)(Np / 32), (unsigned)(Kp / 32), (unsigned)nB), dim3(256), 0, st,
-                           (const T *)b, Bc, K, N, Kp, Np, p, b_bstride, Np * Kp, -1);
+                           (const T *)b, Bc, K, N, Kp, Np, p, b_bstride, Np * Kp, -1, PlaneMasks{});
     }
     int rcg = launch_gemm<T, false>(Ac, Bc, (T *)out, M, N, Mp, Np, Kp, a_bstride ? Mp * Kp : 0, b_bstride ? Np * Kp : 0, batch, (int)p, st);
     if (rcg) return rcg;
@@ -249,12 +265,12 @@ int run_mfma_limbs(const FieldDev &fd, int nl, const void *a, const void *b, voi
             for (int l = 0; l < nl; l++) {
                 const unsigned gx = (unsigned)std::min<i64>((Mp * Kp + 255) / 256, 65535);
                 hipLaunchKernelGGL(centre_rows_kernel<T>, dim3(gx, 1, 1), dim3(256), 0, st, pa, Ac + (i64)l * Mp * Kp, M, K, Mp, Kp, p32,
-                                   (i64)0, (i64)0, 7 * l);
+                                   (i64)0, (i64)0, 7 * l, PlaneMasks{});
             }
         if (bi == 0 || b_bstride)
             for (int l = 0; l < nl; l++)
                 hipLaunchKernelGGL(centre_transpose_kernel<T>, dim3((unsigned)(Np / 32), (unsigned)(Kp / 32), 1), dim3(256), 0, st, pb,
-                                   Bc + (i64)l * Np * Kp, K, N, Kp, Np, p32, (i64)0, (i64)0, 7 * l);
+                                   Bc + (i64)l * Np * Kp, K, N, Kp, Np, p32, (i64)0, (i64)0, 7 * l, PlaneMasks{});
         GFA_HIP(hipMemsetAsync(D, 0, sizeof(int) * (size_t)(ndiag * plane), st));
         for (int i = 0; i < nl; i++)
             for (int j = 0; j < nl; j++) {
@@ -268,6 +284,89 @@ int run_mfma_limbs(const FieldDev &fd, int nl, const void *a, const void *b, voi
     GFA_HIP(gfa::scratch_free(Ac, st));
     GFA_HIP(gfa::scratch_free(Bc, st));
     GFA_HIP(gfa::scratch_free(D, st));
+    return GFA_OK;
+}
+
+// ---- GF(2^m), 2 <= m <= 16: Karatsuba bit planes (r06) ---------------------------------------------------------------
+// a = sum_i a_i x^i with a_i in {0, 1}: the product of two elements is a product in GF(2)[x] reduced mod f.  Three levels of Karatsuba over
+// the eight (four levels: sixteen) bit positions turn it into 27 (81) products of single BITS -- each the parity of the element under a
+// mask -- and the result into sum_t P_t r_t(x) with fixed polynomials r_t (linear over GF(2): c = P_lo (1 + x^h) + P_hi (x^h + x^2h)
+// + P_mid x^h, recursively).  For matrices: plane t of A is the 0/1 matrix parity(A & mask_t), likewise B; P_t = (A_t B_t) mod 2 is ONE
+// exact int8 GEMM with the epilogue of GF(2) (the 27 products ride on the batch dimension of a single launch), and the fold xors
+// r_t(x) mod f where P_t is set.  27 instead of 64 plane products for GF(2^8).  Same values as the reference's loops of multiply / add
+// ufuncs (_domains/_linalg.py:286-308).
+struct BinFold {
+    uint16_t red[81]; // r_t(x) mod f
+    int nt;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void fold_bits_kernel(const uint8_t *__restrict__ P, BinFold bf, i64 plane, T *__restrict__ out, i64 count)
+{
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (i64)gridDim.x * blockDim.x) {
+        u32 v = 0;
+        for (int t = 0; t < bf.nt; t++) v ^= P[(i64)t * plane + e] ? (u32)bf.red[t] : 0u;
+        out[e] = (T)v;
+    }
+}
+
+// the masks and weights of the Karatsuba leaves over `n` (a power of two) bit positions of which the first m are real
+static void karatsuba_leaves(const u32 *pos, int n, u64 w, u32 *masks, u64 *weights, int *count)
+{
+    if (n == 1) {
+        if (pos[0]) { masks[*count] = pos[0]; weights[*count] = w; (*count)++; } // a zero mask is a zero operand: no product
+        return;
+    }
+    const int h = n / 2;
+    u32 mid[8];
+    for (int i = 0; i < h; i++) mid[i] = pos[i] ^ pos[h + i];
+    karatsuba_leaves(pos, h, w ^ (w << h), masks, weights, count);
+    karatsuba_leaves(pos + h, h, (w << h) ^ (w << (2 * h)), masks, weights, count);
+    karatsuba_leaves(mid, h, w << h, masks, weights, count);
+}
+
+template <typename T>
+int run_mfma_bits(const FieldDev &fd, const void *a, const void *b, void *out, i64 batch, i64 M, i64 K, i64 N, i64 a_bstride, i64 b_bstride,
+                  hipStream_t st)
+{
+    const int m = (int)fd.m;
+    int n2 = 1;
+    while (n2 < m) n2 *= 2;
+    u32 pos[16], masks[81];
+    u64 weights[81];
+    for (int i = 0; i < n2; i++) pos[i] = i < m ? 1u << i : 0u;
+    int nt = 0;
+    karatsuba_leaves(pos, n2, 1, masks, weights, &nt);
+    BinFold bf{};
+    PlaneMasks pm{};
+    bf.nt = nt;
+    for (int t = 0; t < nt; t++) pm.m[t] = (uint16_t)masks[t];
+    for (int t = 0; t < nt; t++) bf.red[t] = (uint16_t)Bin::reduce_bits(weights[t], m, 2 * n2, fd.irr); // deg r_t <= 2 n2 - 2
+    const i64 Mp = (M + 255) / 256 * 256, Np = (N + 255) / 256 * 256, Kp = (K + BK - 1) / BK * BK;
+    const i64 plane = M * N;
+    int8_t *Ac = nullptr, *Bc = nullptr;
+    uint8_t *P = nullptr;
+    GFA_HIP(gfa::scratch_alloc((void **)&Ac, (size_t)(nt * Mp * Kp), st));
+    GFA_HIP(gfa::scratch_alloc((void **)&Bc, (size_t)(nt * Np * Kp), st));
+    GFA_HIP(gfa::scratch_alloc((void **)&P, (size_t)(nt * plane), st));
+    for (i64 bi = 0; bi < batch; bi++) { // one matrix pair at a time: nt planes of each operand are the large scratch
+        const T *pa = (const T *)a + bi * a_bstride;
+        const T *pb = (const T *)b + bi * b_bstride;
+        if (bi == 0 || a_bstride) { // all nt planes of an operand in one launch: plane z = parity(element & mask_z)
+            const unsigned gx = (unsigned)std::min<i64>((Mp * Kp + 255) / 256, 65535);
+            hipLaunchKernelGGL(centre_rows_kernel<T>, dim3(gx, 1, (unsigned)nt), dim3(256), 0, st, pa, Ac, M, K, Mp, Kp, 2u, (i64)0, Mp * Kp, 64, pm);
+        }
+        if (bi == 0 || b_bstride)
+            hipLaunchKernelGGL(centre_transpose_kernel<T>, dim3((unsigned)(Np / 32), (unsigned)(Kp / 32), (unsigned)nt), dim3(256), 0, st, pb, Bc, K, N, Kp, Np, 2u,
+                               (i64)0, Np * Kp, 64, pm);
+        int rcg = launch_gemm<uint8_t, false>(Ac, Bc, P, M, N, Mp, Np, Kp, Mp * Kp, Np * Kp, nt, 2, st); // P_t = (A_t B_t) mod 2, t on the batch dimension
+        if (rcg) return rcg;
+        const unsigned gf = (unsigned)std::min<i64>((plane + 255) / 256, 65535);
+        hipLaunchKernelGGL(fold_bits_kernel<T>, dim3(gf), dim3(256), 0, st, P, bf, plane, (T *)out + bi * plane, plane);
+    }
+    GFA_HIP(hipGetLastError());
+    GFA_HIP(gfa::scratch_free(Ac, st));
+    GFA_HIP(gfa::scratch_free(Bc, st));
+    GFA_HIP(gfa::scratch_free(P, st));
     return GFA_OK;
 }
 
@@ -286,6 +385,9 @@ namespace gfa {
 // product large enough to amortise the centring pass.  Batches ride on gridDim.z (<= 65535 per call, sliced by the caller).
 bool matmul_mfma_eligible(const FieldDev &fd, i64 M, i64 K, i64 N)
 {
+    if (fd.kind == KIND_BIN && fd.m >= 2 && fd.m <= 16) // r06: Karatsuba bit planes: 27 (m <= 8) / 81 GEMMs over GF(2) + as many staging passes + a fold
+        return M >= 128 && N >= 128 && K < ((i64)1 << 31) && M * N * K >= ((i64)1 << (mfma_bits_min_log() - (fd.m > 8 ? 2 : 0))) && M * N <= ((i64)1 << 28) &&
+               M * K <= ((i64)1 << 28) && K * N <= ((i64)1 << 28);
     if (fd.m != 1 || M > (1 << 24) || N > (1 << 24)) return false;
     if (fd.p <= 256) return K <= 131072 && M * N * K >= ((i64)1 << 21);
     if (fd.kind != KIND_PRIME32) return false;
@@ -298,6 +400,15 @@ bool matmul_mfma_eligible(const FieldDev &fd, i64 M, i64 K, i64 N)
 int matmul_mfma(const FieldDev &fd, int dtype, const void *a, const void *b, void *out, i64 batch, i64 M, i64 K, i64 N, i64 a_bstride,
                 i64 b_bstride, hipStream_t st)
 {
+    if (fd.kind == KIND_BIN && fd.m >= 2) {
+        switch (dtype) {
+        case GFA_U8: return run_mfma_bits<uint8_t>(fd, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
+        case GFA_U16: return run_mfma_bits<uint16_t>(fd, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
+        case GFA_U32: return run_mfma_bits<uint32_t>(fd, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
+        case GFA_U64: return run_mfma_bits<uint64_t>(fd, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
+        default: set_error("gfa_matmul: bad dtype"); return GFA_ERR_INVALID;
+        }
+    }
     if (fd.p > 256) {
         const int nl = limbs_for(fd.p);
         switch (dtype) {

@@ -245,6 +245,61 @@ def test_large_prime_matmul_on_matrix_cores(p):
     assert np.all((GF(A) @ GF(B)).numpy().astype(np.int64) == (900 * pow(p - 1, 2, p)) % p)
 
 
+@pytest.mark.parametrize("m", [2, 3, 4, 7, 8, 12, 16])
+def test_binary_extension_field_matmul_on_matrix_cores(m):
+    """r06: GF(2^m), m <= 16, products with M, N >= 128 (and at least 2^24 multiply-adds): three (four) levels of Karatsuba over the
+    bit positions -- 27 (81) planes parity(A & mask_t), as many exact int8 GEMMs with the epilogue of GF(2) on the batch dimension of one
+    launch, and a fold that xors r_t(x) mod f where the product bit is set (run_mfma_bits) -- against the oracle's table loop.  Degrees that
+    are not powers of two (zero masks dropped), every storage dtype, all-ones operands over a long K, a stack with a broadcast operand, the
+    hand-over to the other kernels below 128 rows; a subprocess with the planes switched OFF (GFA_MFMA_BITS_MIN_LOG=62) agrees on the same
+    inputs."""
+    GF = ga.GF(2**m)
+    q = 2**m
+    F = O.OracleField(2, m, int(GF.irreducible_poly), int(GF.primitive_element), lookup=True)
+    rng = np.random.default_rng(m)
+    shapes = [(1024, 1024, 1024), (1030, 1100, 1000), (256, 64, 256), (300, 77, 257), (128, 1100, 129)]
+    for M, K, N in shapes:
+        A, B = rng.integers(0, q, (M, K)), rng.integers(0, q, (K, N))
+        want = F.matmul(A, B)
+        for dt in GF.dtypes[:1] + GF.dtypes[-1:]:
+            got = (GF(A.astype(dt), dtype=dt) @ GF(B.astype(dt), dtype=dt)).numpy()
+            H.assert_equal_ints(got, want, f"GF(2^{m}) {M}x{K}x{N} {np.dtype(dt).name}")
+    # every bit set over a long K: the largest counts
+    K = 70001
+    A, B = np.full((256, K), q - 1), np.full((K, 256), q - 1)
+    sq = int(F.mul(np.array([q - 1], dtype=np.uint64), np.array([q - 1], dtype=np.uint64))[0])
+    assert np.all((GF(A) @ GF(B)).numpy() == (sq if K & 1 else 0))
+    A3, B1 = rng.integers(0, q, (3, 300, 400)), rng.integers(0, q, (400, 260))
+    C = (GF(A3) @ GF(B1)).numpy()
+    for i in range(3):
+        H.assert_equal_ints(C[i], F.matmul(A3[i], B1), f"stack {i}")
+    # below 128 rows / columns the other kernels run: same values
+    A, B = rng.integers(0, q, (127, 300)), rng.integers(0, q, (300, 2000))
+    H.assert_equal_ints((GF(A) @ GF(B)).numpy(), F.matmul(A, B), "below the tile size")
+
+
+def test_binary_extension_field_matmul_agrees_with_the_table_kernels():
+    """The same products with the bit planes switched off (GFA_MFMA_BITS_MIN_LOG is read once per process, so a child process runs the LDS
+    product table / shift-and-xor kernels): both against the oracle."""
+    import subprocess, sys, os
+
+    code = (
+        "import numpy as np, galois_amd as ga\n"
+        "from oracle import gf_oracle as O\n"
+        "rng = np.random.default_rng(3)\n"
+        "for m in (3, 8, 16):\n"
+        "    GF = ga.GF(2**m); q = 2**m\n"
+        "    F = O.OracleField(2, m, int(GF.irreducible_poly), int(GF.primitive_element), lookup=True)\n"
+        "    for M, K, N in [(256, 64, 256), (257, 65, 300), (512, 300, 259)]:\n"
+        "        A, B = rng.integers(0, q, (M, K)), rng.integers(0, q, (K, N))\n"
+        "        assert np.array_equal((GF(A) @ GF(B)).numpy().astype(np.uint64), F.matmul(A, B)), (m, M, K, N)\n"
+        "print('ok')\n"
+    )
+    env = dict(os.environ, GFA_MFMA_BITS_MIN_LOG="62", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_exceptions():
     """tests/fields/test_linalg.py:15-36, 86-92, 123-132, 291-299, 321-329, 345-353, 394-420."""
     GF = ga.GF(2**8)

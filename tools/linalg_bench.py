@@ -12,11 +12,11 @@ lib = L.lib()
 st = torch.cuda.current_stream().cuda_stream
 ms = ctypes.c_float()
 rng = np.random.default_rng(0)
-NP2T = {np.uint8: torch.uint8, np.uint32: torch.int32, np.uint64: torch.int64}
+NP2T = {np.uint8: torch.uint8, np.uint16: torch.int16, np.uint32: torch.int32, np.uint64: torch.int64}
 
 
 def dev(a):
-    return torch.from_numpy(a.view({1: np.uint8, 4: np.int32, 8: np.int64}[a.itemsize])).cuda()
+    return torch.from_numpy(a.view({1: np.uint8, 2: np.int16, 4: np.int32, 8: np.int64}[a.itemsize])).cuda()
 
 
 def mm(tag, GF, npdt, gdt, batch, M, K, N, iters=10):
@@ -35,10 +35,19 @@ def mm(tag, GF, npdt, gdt, batch, M, K, N, iters=10):
 
 
 G8 = ga.GF(2**8)
-a, b, do = mm("GF(2^8) u8 (LDS table)", G8, np.uint8, L.U8, 1, 4096, 4096, 4096, 3)
+a, b, do = mm("GF(2^8) u8 (27 planes, MFMA)", G8, np.uint8, L.U8, 1, 4096, 4096, 4096, 3)
 F8 = O.OracleField(2, 8, 285, 2, lookup=True)
 t = time.perf_counter(); ref = F8.matmul(a[0, :256, :256], b[0, :256, :256]); dt = time.perf_counter() - t
 print(f"  oracle C port, 1 thread: 256^3 in {dt * 1e3:.1f} ms = {256**3 / dt / 1e9:.3f} GMAC/s")
+for sz in (1024, 2048, 8192):  # r06: bit planes on the matrix cores from 2^30 multiply-adds
+    mm("GF(2^8) u8 (27 planes, MFMA)", G8, np.uint8, L.U8, 1, sz, sz, sz, 3)
+mm("GF(2^4) u8 (9 planes, MFMA)", ga.GF(2**4), np.uint8, L.U8, 1, 4096, 4096, 4096, 3)
+mm("GF(2^8) u8 (27 planes, ragged)", G8, np.uint8, L.U8, 1, 4000, 4100, 3900, 3)
+mm("GF(2^16) u16 (81 planes, MFMA)", ga.GF(2**16), np.uint16, L.U16, 1, 4096, 4096, 4096, 3)
+mm("GF(2^16) u16 (81 planes, MFMA)", ga.GF(2**16), np.uint16, L.U16, 1, 1024, 1024, 1024, 3)
+mm("GF(2^16) u16 (81 planes, MFMA)", ga.GF(2**16), np.uint16, L.U16, 1, 512, 512, 512, 3)
+mm("GF(2^8) u8 (27 planes, MFMA)", G8, np.uint8, L.U8, 1, 512, 512, 512, 3)
+mm("GF(2^8) u8 (LDS table: N < 256)", G8, np.uint8, L.U8, 1, 4096, 4096, 128, 3)
 mm("GF(2^8) u8 small stack", G8, np.uint8, L.U8, 16384, 16, 16, 16)
 mm("GF(2^8) u8 RS-encode shape", G8, np.uint8, L.U8, 1, 131072, 223, 32)
 mm("GF(65537) u32 (3 limbs, MFMA)", ga.GF(65537), np.uint32, L.U32, 1, 4096, 4096, 4096, 3)
