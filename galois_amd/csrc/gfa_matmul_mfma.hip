@@ -14,6 +14,7 @@
 //      K step 64, register-prefetched global loads, LDS rows padded to 80 bytes (conflict-free ds_read_b128), epilogue
 //      acc mod p.
 #include <cstdlib>
+#include <vector>
 
 #include "gfa_internal.h"
 
@@ -235,8 +236,8 @@ __global__ __launch_bounds__(256) void fold_diagonals_kernel(const int *__restri
         u64 acc = 0, w = 1; // w = 2^(7s) mod p
         for (int sdg = 0; sdg < ndiag; sdg++) {
             const u64 v = (u64)(u32)D[(i64)sdg * plane + e] % p; // sums are non-negative (unsigned limbs)
-            acc = (acc + (unsigned __int128)v * w % p) % p;
-            w = (w << 7) % p;
+            acc = (u64)(((unsigned __int128)acc + (unsigned __int128)v * w % p) % p); // (p up to 2^64: nothing here may wrap)
+            w = (u64)(((unsigned __int128)w << 7) % p);
         }
         out[e] = (T)acc;
     }
@@ -370,6 +371,184 @@ int run_mfma_bits(const FieldDev &fd, const void *a, const void *b, void *out, i
     return GFA_OK;
 }
 
+// ---- GF(p^m), odd p <= 251, 2 <= m <= 16: Karatsuba digit planes (r06) ----------------------------------------------------
+// The same construction over GF(p): elements are polynomials in their base-p digits, Karatsuba over the (padded) digit positions gives
+// leaves t with a SET of positions E_t and an integer weight polynomial (c = P_lo (1 - x^h) + P_hi (x^2h - x^h) + P_mid x^h, recursively);
+// plane t of an operand is (sum of the digits in E_t) mod p as a centred residue, P_t = (A_t B_t) mod p one exact int8 GEMM with the prime
+// field's epilogue, and -- reduction mod f being linear too -- digit k of the result is (sum_t P_t R_t[k]) mod p with R_t = weight_t mod f
+// computed on the host.  Leaves whose set is empty (positions padded up to a power of two) are dropped: 8 products for degree 3, 22 for
+// degree 5 (schoolbook: 9, 25).  The table kernels these fields ran on manage 0.17 TMAC/s (GF(3^5), 1024^3).
+struct DigitFold {
+    uint8_t R[81][16]; // R[t][k]: coefficient of x^k of (weight polynomial of leaf t) mod f, in [0, p)
+    uint16_t set[81];  // E_t as a mask over the digit positions
+    int nt, m;
+    u32 p;
+};
+
+template <typename T>
+__device__ __forceinline__ void digits_of(T v, u32 p, int m, u32 (&d)[16])
+{
+    u64 x = (u64)v; // (static indices throughout: the digits stay in registers)
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        d[i] = 0;
+        if (i < m) {
+            if (sizeof(T) <= 4) { const u32 x32 = (u32)x, qd = x32 / p; d[i] = x32 - qd * p; x = qd; }
+            else { const u64 qd = x / p; d[i] = (u32)(x - qd * p); x = qd; }
+        }
+    }
+}
+__device__ __forceinline__ int8_t digit_plane(const u32 (&d)[16], u32 set, u32 p, u32 half)
+{
+    u32 sum = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) sum += ((set >> i) & 1u) ? d[i] : 0u;
+    return centre(sum % p, p, half);
+}
+
+// all nt planes of A in one pass: dst plane t = (rows_p x cols_p), zero padded
+template <typename T>
+__global__ __launch_bounds__(256) void digit_rows_kernel(const T *__restrict__ src, int8_t *__restrict__ dst, i64 rows, i64 cols, i64 rows_p, i64 cols_p, DigitFold df)
+{
+    const u32 half = df.p >> 1;
+    const i64 total = rows_p * cols_p;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (i64)gridDim.x * blockDim.x) {
+        const i64 r = e / cols_p, c = e - r * cols_p;
+        const bool in = r < rows && c < cols;
+        u32 d[16];
+        if (in) digits_of(src[r * cols + c], df.p, df.m, d);
+        for (int t = 0; t < df.nt; t++) dst[(i64)t * total + e] = in ? digit_plane(d, df.set[t], df.p, half) : (int8_t)0;
+    }
+}
+// all nt planes of B, transposed (dst plane t = (cols_p x rows_p)), 32 x 32 tiles through LDS
+template <typename T>
+__global__ __launch_bounds__(256) void digit_transpose_kernel(const T *__restrict__ src, int8_t *__restrict__ dst, i64 rows, i64 cols, i64 rows_p, i64 cols_p, DigitFold df)
+{
+    __shared__ int8_t tile[32][33];
+    const u32 half = df.p >> 1;
+    const i64 r0 = (i64)blockIdx.y * 32, c0 = (i64)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8: a thread owns the four elements (ty + 8 jj, tx)
+    u32 d[4][16];
+    bool in[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) {
+        const i64 r = r0 + ty + 8 * jj, c = c0 + tx;
+        in[jj] = r < rows && c < cols;
+        if (in[jj]) digits_of(src[r * cols + c], df.p, df.m, d[jj]);
+    }
+    const i64 plane = rows_p * cols_p;
+    for (int t = 0; t < df.nt; t++) {
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) tile[ty + 8 * jj][tx] = in[jj] ? digit_plane(d[jj], df.set[t], df.p, half) : (int8_t)0;
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const i64 c = c0 + j, r = r0 + tx; // dst row = source column
+            if (c < cols_p && r < rows_p) dst[(i64)t * plane + c * rows_p + r] = tile[tx][j];
+        }
+        __syncthreads();
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void fold_digits_kernel(const uint8_t *__restrict__ P, DigitFold df, i64 plane, T *__restrict__ out, i64 count)
+{
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (i64)gridDim.x * blockDim.x) {
+        u32 acc[16];
+        for (int k = 0; k < df.m; k++) acc[k] = 0;
+        for (int t = 0; t < df.nt; t++) {
+            const u32 v = P[(i64)t * plane + e];
+            if (v)
+                for (int k = 0; k < df.m; k++) acc[k] += v * df.R[t][k]; // <= 81 * 250 * 250
+        }
+        u64 r = 0;
+        for (int k = df.m - 1; k >= 0; k--) r = r * df.p + acc[k] % df.p;
+        out[e] = (T)r;
+    }
+}
+
+// Karatsuba leaves over n (a power of two) positions with integer weights mod p; pos[i] = set of digit positions summed at place i
+static void karatsuba_leaves_p(const u32 *pos, int n, const std::vector<i64> &w, u32 p, std::vector<u32> &sets, std::vector<std::vector<i64>> &weights)
+{
+    if (n == 1) {
+        if (pos[0]) { sets.push_back(pos[0]); weights.push_back(w); }
+        return;
+    }
+    const int h = n / 2;
+    u32 mid[8];
+    bool lo_any = false, hi_any = false;
+    for (int i = 0; i < h; i++) { lo_any |= pos[i] != 0; hi_any |= pos[h + i] != 0; }
+    auto shifted = [&](int by, i64 sign) { std::vector<i64> r(w.size() + by, 0); for (size_t i = 0; i < w.size(); i++) r[i + by] = sign * w[i]; return r; };
+    auto add = [&](std::vector<i64> a, const std::vector<i64> &b) { if (a.size() < b.size()) a.resize(b.size(), 0); for (size_t i = 0; i < b.size(); i++) a[i] += b[i]; return a; };
+    if (!hi_any) { karatsuba_leaves_p(pos, h, w, p, sets, weights); return; } // a(x) b(x) with both high halves zero: the low product alone
+    // (positions hold SETS whose digits are summed: lo + hi at place i is the union -- the two are disjoint by construction)
+    for (int i = 0; i < h; i++) mid[i] = pos[i] | pos[h + i];
+    karatsuba_leaves_p(pos, h, add(w, shifted(h, -1)), p, sets, weights);                 // P_lo (1 - x^h)
+    karatsuba_leaves_p(pos + h, h, add(shifted(2 * h, 1), shifted(h, -1)), p, sets, weights); // P_hi (x^2h - x^h)
+    karatsuba_leaves_p(mid, h, shifted(h, 1), p, sets, weights);                          // P_mid x^h
+    (void)lo_any;
+}
+
+template <typename T>
+int run_mfma_digits(const FieldDev &fd, const void *a, const void *b, void *out, i64 batch, i64 M, i64 K, i64 N, i64 a_bstride, i64 b_bstride,
+                    hipStream_t st)
+{
+    const int m = (int)fd.m;
+    const u32 p = (u32)fd.p;
+    int n2 = 1;
+    while (n2 < m) n2 *= 2;
+    u32 pos[16];
+    for (int i = 0; i < n2; i++) pos[i] = i < m ? 1u << i : 0u;
+    std::vector<u32> sets;
+    std::vector<std::vector<i64>> weights;
+    karatsuba_leaves_p(pos, n2, std::vector<i64>{1}, p, sets, weights);
+    const int nt = (int)sets.size();
+    if (nt > 81) return GFA_ERR_UNSUPPORTED;
+    DigitFold df{};
+    df.nt = nt; df.m = m; df.p = p;
+    for (int t = 0; t < nt; t++) {
+        df.set[t] = (uint16_t)sets[t];
+        // weight polynomial mod p, then mod f: x^m = sum_k nir[k] x^k with nir[k] = -irr_k
+        std::vector<i64> c(weights[t]);
+        c.resize(std::max<size_t>(c.size(), (size_t)m), 0);
+        for (auto &v : c) v = ((v % (i64)p) + (i64)p) % (i64)p;
+        for (int sdeg = (int)c.size() - 1; sdeg >= m; sdeg--) {
+            const i64 top = c[sdeg];
+            if (!top) continue;
+            for (int k = 0; k < m; k++) { // coefficient of x^k of f below the leading term: ext_irr[m - 1 - k]
+                const i64 nir = fd.ext_irr[m - 1 - k] ? (i64)p - (i64)fd.ext_irr[m - 1 - k] : 0;
+                c[sdeg - m + k] = (c[sdeg - m + k] + top * nir) % (i64)p;
+            }
+            c[sdeg] = 0;
+        }
+        for (int k = 0; k < m; k++) df.R[t][k] = (uint8_t)c[k];
+    }
+    const i64 Mp = (M + 255) / 256 * 256, Np = (N + 255) / 256 * 256, Kp = (K + BK - 1) / BK * BK;
+    const i64 plane = M * N;
+    int8_t *Ac = nullptr, *Bc = nullptr;
+    uint8_t *P = nullptr;
+    GFA_HIP(gfa::scratch_alloc((void **)&Ac, (size_t)(nt * Mp * Kp), st));
+    GFA_HIP(gfa::scratch_alloc((void **)&Bc, (size_t)(nt * Np * Kp), st));
+    GFA_HIP(gfa::scratch_alloc((void **)&P, (size_t)(nt * plane), st));
+    for (i64 bi = 0; bi < batch; bi++) {
+        const T *pa = (const T *)a + bi * a_bstride;
+        const T *pb = (const T *)b + bi * b_bstride;
+        if (bi == 0 || a_bstride) {
+            const unsigned gx = (unsigned)std::min<i64>((Mp * Kp + 255) / 256, 65535);
+            hipLaunchKernelGGL(digit_rows_kernel<T>, dim3(gx), dim3(256), 0, st, pa, Ac, M, K, Mp, Kp, df);
+        }
+        if (bi == 0 || b_bstride)
+            hipLaunchKernelGGL(digit_transpose_kernel<T>, dim3((unsigned)(Np / 32), (unsigned)(Kp / 32), 1), dim3(256), 0, st, pb, Bc, K, N, Kp, Np, df);
+        int rcg = launch_gemm<uint8_t, false>(Ac, Bc, P, M, N, Mp, Np, Kp, Mp * Kp, Np * Kp, nt, (int)p, st); // P_t = (A_t B_t) mod p
+        if (rcg) return rcg;
+        const unsigned gf = (unsigned)std::min<i64>((plane + 255) / 256, 65535);
+        hipLaunchKernelGGL(fold_digits_kernel<T>, dim3(gf), dim3(256), 0, st, P, df, plane, (T *)out + bi * plane, plane);
+    }
+    GFA_HIP(hipGetLastError());
+    GFA_HIP(gfa::scratch_free(Ac, st));
+    GFA_HIP(gfa::scratch_free(Bc, st));
+    GFA_HIP(gfa::scratch_free(P, st));
+    return GFA_OK;
+}
+
 int limbs_for(u64 p)
 {
     int bits = 0;
@@ -388,13 +567,19 @@ bool matmul_mfma_eligible(const FieldDev &fd, i64 M, i64 K, i64 N)
     if (fd.kind == KIND_BIN && fd.m >= 2 && fd.m <= 16) // r06: Karatsuba bit planes: 27 (m <= 8) / 81 GEMMs over GF(2) + as many staging passes + a fold
         return M >= 128 && N >= 128 && K < ((i64)1 << 31) && M * N * K >= ((i64)1 << (mfma_bits_min_log() - (fd.m > 8 ? 2 : 0))) && M * N <= ((i64)1 << 28) &&
                M * K <= ((i64)1 << 28) && K * N <= ((i64)1 << 28);
+    if (fd.kind == KIND_EXT && (fd.p & 1) && fd.p <= 251 && fd.m >= 2 && fd.m <= 16) // r06: Karatsuba digit planes (K as for GF(p): exact int32 sums)
+        return M >= 128 && N >= 128 && K <= 131072 && M * N * K >= ((i64)1 << mfma_bits_min_log()) && M * N <= ((i64)1 << 28) && M * K <= ((i64)1 << 28) &&
+               K * N <= ((i64)1 << 28);
     if (fd.m != 1 || M > (1 << 24) || N > (1 << 24)) return false;
     if (fd.p <= 256) return K <= 131072 && M * N * K >= ((i64)1 << 21);
-    if (fd.kind != KIND_PRIME32) return false;
+    if (fd.kind != KIND_PRIME32 && fd.kind != KIND_PRIME64 && fd.kind != KIND_GOLDILOCKS) return false;
     // 7-bit limbs: NL^2 GEMMs + NL staging passes + a fold; worth it for large products only, and NL * K * 127^2 < 2^31
+    // (r06: also the 64-bit primes -- ten limbs, 100 GEMMs, 19 diagonals: Goldilocks 1024^3 0.87 -> see profiles/r06_linalg_bench.txt)
     const int nl = limbs_for(fd.p);
-    return nl <= 5 && (i64)nl * K * 16129 < ((i64)1 << 31) && M * N * K >= ((i64)1 << 27) && M >= 64 && N >= 64 &&
-           M * N <= ((i64)1 << 27);
+    // (measured: Goldilocks 1024^3 3.9 ms against 1.24 ms on the scalar kernel -- 100 launches, 19 read-modify-written diagonals and a 128-bit
+    // fold -- 2048^3 6.9 against 9.9 ms: more than five limbs from 2^33 multiply-adds)
+    return nl <= 10 && (i64)nl * K * 16129 < ((i64)1 << 31) && M * N * K >= ((i64)1 << (nl <= 5 ? 27 : 33)) && M >= 64 && N >= 64 &&
+           M * N <= ((i64)1 << (nl <= 5 ? 27 : 26));
 }
 
 int matmul_mfma(const FieldDev &fd, int dtype, const void *a, const void *b, void *out, i64 batch, i64 M, i64 K, i64 N, i64 a_bstride,
@@ -406,6 +591,15 @@ int matmul_mfma(const FieldDev &fd, int dtype, const void *a, const void *b, voi
         case GFA_U16: return run_mfma_bits<uint16_t>(fd, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
         case GFA_U32: return run_mfma_bits<uint32_t>(fd, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
         case GFA_U64: return run_mfma_bits<uint64_t>(fd, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
+        default: set_error("gfa_matmul: bad dtype"); return GFA_ERR_INVALID;
+        }
+    }
+    if (fd.kind == KIND_EXT) {
+        switch (dtype) {
+        case GFA_U8: return run_mfma_digits<uint8_t>(fd, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
+        case GFA_U16: return run_mfma_digits<uint16_t>(fd, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
+        case GFA_U32: return run_mfma_digits<uint32_t>(fd, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
+        case GFA_U64: return run_mfma_digits<uint64_t>(fd, a, b, out, batch, M, K, N, a_bstride, b_bstride, st);
         default: set_error("gfa_matmul: bad dtype"); return GFA_ERR_INVALID;
         }
     }

@@ -278,6 +278,34 @@ def test_binary_extension_field_matmul_on_matrix_cores(m):
     H.assert_equal_ints((GF(A) @ GF(B)).numpy(), F.matmul(A, B), "below the tile size")
 
 
+@pytest.mark.parametrize("order", [3**2, 3**3, 3**5, 5**4, 7**3, 3**7, 251**2, 13**5, 3**10, 5**8, 3**16])
+def test_odd_characteristic_extension_field_matmul_on_matrix_cores(order):
+    """r06: GF(p^m), odd p <= 251, m <= 16, products with M, N >= 128: Karatsuba over the base-p digit positions -- plane t of an operand is
+    (sum of the digits in the leaf's set) mod p, one exact int8 GEMM mod p per leaf (all on the batch dimension of one launch), digit k of the
+    result (sum_t P_t R_t[k]) mod p with R_t the leaf's weight polynomial reduced mod the field's polynomial on the host
+    (run_mfma_digits) -- against the oracle's loop, for every storage dtype, degrees that are and are not powers of two, ragged shapes,
+    all-(q - 1) operands over a long K, a stack with a broadcast operand."""
+    GF = ga.GF(order)
+    F = O.OracleField(GF.characteristic, GF.degree, int(GF.irreducible_poly), int(GF.primitive_element), lookup=order <= 2**16)
+    rng = np.random.default_rng(order % 9973)
+    shapes = [(256, 64, 256), (300, 500, 257), (128, 1100, 129)] + ([(512, 512, 512)] if order < 2**20 else [])
+    for M, K, N in shapes:
+        A, B = rng.integers(0, order, (M, K)), rng.integers(0, order, (K, N))
+        want = F.matmul(A, B)
+        for dt in GF.dtypes[:1] + GF.dtypes[-1:]:
+            got = (GF(A.astype(dt), dtype=dt) @ GF(B.astype(dt), dtype=dt)).numpy()
+            H.assert_equal_ints(got, want, f"GF({order}) {M}x{K}x{N} {np.dtype(dt).name}")
+    K = 20001
+    A, B = np.full((128, K), order - 1), np.full((K, 130), order - 1)
+    sq = int(F.mul(np.array([order - 1], dtype=np.uint64), np.array([order - 1], dtype=np.uint64))[0])
+    one = F.matmul(np.full((1, K), order - 1), np.full((K, 1), order - 1))[0, 0]
+    assert np.all((GF(A) @ GF(B)).numpy() == one), sq
+    A3, B1 = rng.integers(0, order, (2, 200, 300)), rng.integers(0, order, (300, 150))
+    C = (GF(A3) @ GF(B1)).numpy()
+    for i in range(2):
+        H.assert_equal_ints(C[i], F.matmul(A3[i], B1), f"stack {i}")
+
+
 def test_binary_extension_field_matmul_agrees_with_the_table_kernels():
     """The same products with the bit planes switched off (GFA_MFMA_BITS_MIN_LOG is read once per process, so a child process runs the LDS
     product table / shift-and-xor kernels): both against the oracle."""
@@ -298,6 +326,32 @@ def test_binary_extension_field_matmul_agrees_with_the_table_kernels():
     env = dict(os.environ, GFA_MFMA_BITS_MIN_LOG="62", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("p", [2**64 - 2**32 + 1, 2**61 - 1])
+def test_64_bit_prime_matmul_on_matrix_cores(p):
+    """r06: primes above 2^35 on the 7-bit limb path (ten limbs, 100 exact int8 GEMMs, 19 diagonals folded in 128-bit arithmetic) from 2^33
+    multiply-adds: 2048 x 2100 x 2048 against Python integers on a sample of rows; all-(p - 1) operands."""
+    import torch
+
+    GF = ga.GF(p)
+    rng = np.random.default_rng(p % 1000)
+    M, K, N = 2048, 2100, 2048
+    def rnd(shape):
+        v = (rng.integers(0, 2**63, shape, dtype=np.uint64) % np.uint64(p >> 1)) * np.uint64(2) + rng.integers(0, 2, shape, dtype=np.uint64)
+        return v  # < p, every bit position exercised
+    a, b = rnd((M, K)), rnd((K, N))
+    a[0, 0], a[1, 1], b[0, 0] = p - 1, 0, p - 1
+    wrap = lambda v: GF._wrap(torch.from_numpy(v.view(np.int64)).cuda(), np.object_)  # (dtype=object in the reference: stored as uint64 words)
+    A, B = wrap(a), wrap(b)
+    C = (A @ B).numpy()
+    Bo = b.astype(object)
+    for i in (0, 1, 1023, 2047):
+        want = (a[i].astype(object) @ Bo) % p
+        assert [int(v) for v in C[i]] == [int(v) for v in want], (p, i)
+    ones_a, ones_b = np.full((256, 9000), p - 1, dtype=np.uint64), np.full((9000, 4096), p - 1, dtype=np.uint64)
+    got = (wrap(ones_a) @ wrap(ones_b)).numpy()
+    assert all(int(v) == (9000 * pow(p - 1, 2, p)) % p for v in got[::37, ::41].ravel())
 
 
 def test_exceptions():

@@ -62,6 +62,14 @@ while time.time() < t_end:
             assert np.array_equal(u64((GF(A) @ GF(B)).numpy()), F.matmul(A, B)), ("matmul mfma", q, m, k, n)
             n_la += 1
             continue
+        if rng.random() < 0.06:  # r06: GF(2^m) on the matrix cores as Karatsuba bit planes (M, N >= 128, at least 2^24 multiply-adds)
+            mb = int(rng.integers(2, 17))
+            GFb, Fb = pair(2**mb)
+            m, k, n = 128 + int(rng.integers(0, 300)), 1024 + int(rng.integers(0, 300)), 128 + int(rng.integers(0, 300))
+            A, B = rnd(2**mb, (m, k)), rnd(2**mb, (k, n))
+            assert np.array_equal(u64((GFb(A) @ GFb(B)).numpy()), Fb.matmul(A, B)), ("matmul bit planes", mb, m, k, n)
+            n_la += 1
+            continue
         if q in (65537, 2**31 - 1) and rng.random() < 0.05:  # 7-bit limb path (>= 2^27 multiply-adds)
             m, k, n = 512 + int(rng.integers(0, 40)), 512 + int(rng.integers(0, 40)), 512 + int(rng.integers(0, 40))
             A, B = rnd(q, (m, k)), rnd(q, (k, n))

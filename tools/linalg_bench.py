@@ -48,6 +48,12 @@ mm("GF(2^16) u16 (81 planes, MFMA)", ga.GF(2**16), np.uint16, L.U16, 1, 1024, 10
 mm("GF(2^16) u16 (81 planes, MFMA)", ga.GF(2**16), np.uint16, L.U16, 1, 512, 512, 512, 3)
 mm("GF(2^8) u8 (27 planes, MFMA)", G8, np.uint8, L.U8, 1, 512, 512, 512, 3)
 mm("GF(2^8) u8 (LDS table: N < 256)", G8, np.uint8, L.U8, 1, 4096, 4096, 128, 3)
+mm("GF(3^5) u8 (22 digit planes, MFMA)", ga.GF(3**5), np.uint8, L.U8, 1, 1024, 1024, 1024, 3)
+mm("GF(3^5) u8 (22 digit planes, MFMA)", ga.GF(3**5), np.uint8, L.U8, 1, 4096, 4096, 4096, 3)
+mm("GF(7^3) u16 (8 digit planes, MFMA)", ga.GF(7**3), np.uint16, L.U16, 1, 4096, 4096, 4096, 3)
+mm("GF(251^2) u16 (3 planes, MFMA)", ga.GF(251**2), np.uint16, L.U16, 1, 4096, 4096, 4096, 3)
+mm("GF(3^10) u16 (digit planes, MFMA)", ga.GF(3**10), np.uint16, L.U16, 1, 2048, 2048, 2048, 3)
+mm("Goldilocks u64 (10 limbs, MFMA)", ga.GF(2**64 - 2**32 + 1), np.uint64, L.U64, 1, 2048, 2048, 2048, 3)
 mm("GF(2^8) u8 small stack", G8, np.uint8, L.U8, 16384, 16, 16, 16)
 mm("GF(2^8) u8 RS-encode shape", G8, np.uint8, L.U8, 1, 131072, 223, 32)
 mm("GF(65537) u32 (3 limbs, MFMA)", ga.GF(65537), np.uint32, L.U32, 1, 4096, 4096, 4096, 3)
