@@ -35,14 +35,13 @@ inline int mfma_bits_min_log()
 
 __device__ __forceinline__ int8_t centre(u32 a, u32 p, u32 half) { return (int8_t)(a > half ? (int)a - (int)p : (int)a); }
 // operand byte: the centred residue (shift < 0, p <= 256) or the 7-bit limb of the element at bit `shift` (larger primes)
-// (shift >= 64: the PARITY of the element's bits under the mask `shift - 64` -- the Karatsuba planes of GF(2^m), run_mfma_bits, which
-// stages all its planes in one launch: plane blockIdx.z takes its mask from PlaneMasks)
+// (shift == 64, handled by the staging kernels: the PARITY of the element's bits under a mask -- the Karatsuba planes of GF(2^m),
+// run_mfma_bits, which stages all its planes in one launch: plane blockIdx.z takes its mask from PlaneMasks)
 struct PlaneMasks {
-    uint16_t m[81];
+    u32 m[243];
 };
 __device__ __forceinline__ int8_t operand(u64 a, u32 p, u32 half, int shift)
 {
-    if (shift >= 64) return (int8_t)(__popc((u32)a & (u32)(shift - 64)) & 1);
     return shift < 0 ? centre((u32)a, p, half) : (int8_t)((a >> shift) & 127u);
 }
 
@@ -54,11 +53,14 @@ __global__ __launch_bounds__(256) void centre_rows_kernel(const T *__restrict__ 
     const T *s = src + (i64)blockIdx.z * src_bstride;
     int8_t *d = dst + (i64)blockIdx.z * dst_bstride;
     const u32 half = p >> 1;
-    if (shift == 64) shift = 64 + (int)pm.m[blockIdx.z];
+    const bool bits = shift == 64;
+    const u32 mask = bits ? pm.m[blockIdx.z] : 0u;
     const i64 total = rows_p * cols_p;
     for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (i64)gridDim.x * blockDim.x) {
         const i64 r = e / cols_p, c = e - r * cols_p;
-        d[e] = (r < rows && c < cols) ? operand((u64)s[r * cols + c], p, half, shift) : (int8_t)0;
+        int8_t v = 0;
+        if (r < rows && c < cols) v = bits ? (int8_t)(__popc((u32)s[r * cols + c] & mask) & 1) : operand((u64)s[r * cols + c], p, half, shift);
+        d[e] = v;
     }
 }
 
@@ -71,12 +73,15 @@ __global__ __launch_bounds__(256) void centre_transpose_kernel(const T *__restri
     const T *s = src + (i64)blockIdx.z * src_bstride;
     int8_t *d = dst + (i64)blockIdx.z * dst_bstride;
     const u32 half = p >> 1;
-    if (shift == 64) shift = 64 + (int)pm.m[blockIdx.z];
+    const bool bits = shift == 64;
+    const u32 mask = bits ? pm.m[blockIdx.z] : 0u;
     const i64 r0 = (i64)blockIdx.y * 32, c0 = (i64)blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
     for (int j = ty; j < 32; j += 8) {
         const i64 r = r0 + j, c = c0 + tx;
-        tile[j][tx] = (r < rows && c < cols) ? operand((u64)s[r * cols + c], p, half, shift) : (int8_t)0;
+        int8_t v = 0;
+        if (r < rows && c < cols) v = bits ? (int8_t)(__popc((u32)s[r * cols + c] & mask) & 1) : operand((u64)s[r * cols + c], p, half, shift);
+        tile[j][tx] = v;
     }
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
@@ -288,16 +293,16 @@ int run_mfma_limbs(const FieldDev &fd, int nl, const void *a, const void *b, voi
     return GFA_OK;
 }
 
-// ---- GF(2^m), 2 <= m <= 16: Karatsuba bit planes (r06) ---------------------------------------------------------------
+// ---- GF(2^m), 2 <= m <= 32: Karatsuba bit planes (r06) ---------------------------------------------------------------
 // a = sum_i a_i x^i with a_i in {0, 1}: the product of two elements is a product in GF(2)[x] reduced mod f.  Three levels of Karatsuba over
-// the eight (four levels: sixteen) bit positions turn it into 27 (81) products of single BITS -- each the parity of the element under a
+// the eight (four levels: sixteen, five: thirty-two) bit positions turn it into 27 (81, 243) products of single BITS -- each the parity of the element under a
 // mask -- and the result into sum_t P_t r_t(x) with fixed polynomials r_t (linear over GF(2): c = P_lo (1 + x^h) + P_hi (x^h + x^2h)
 // + P_mid x^h, recursively).  For matrices: plane t of A is the 0/1 matrix parity(A & mask_t), likewise B; P_t = (A_t B_t) mod 2 is ONE
 // exact int8 GEMM with the epilogue of GF(2) (the 27 products ride on the batch dimension of a single launch), and the fold xors
 // r_t(x) mod f where P_t is set.  27 instead of 64 plane products for GF(2^8).  Same values as the reference's loops of multiply / add
 // ufuncs (_domains/_linalg.py:286-308).
 struct BinFold {
-    uint16_t red[81]; // r_t(x) mod f
+    u32 red[243]; // r_t(x) mod f
     int nt;
 };
 template <typename T>
@@ -318,7 +323,10 @@ static void karatsuba_leaves(const u32 *pos, int n, u64 w, u32 *masks, u64 *weig
         return;
     }
     const int h = n / 2;
-    u32 mid[8];
+    u32 mid[16];
+    bool hi_any = false;
+    for (int i = 0; i < h; i++) hi_any |= pos[h + i] != 0;
+    if (!hi_any) { karatsuba_leaves(pos, h, w, masks, weights, count); return; } // both high halves zero (positions padded to a power of two)
     for (int i = 0; i < h; i++) mid[i] = pos[i] ^ pos[h + i];
     karatsuba_leaves(pos, h, w ^ (w << h), masks, weights, count);
     karatsuba_leaves(pos + h, h, (w << h) ^ (w << (2 * h)), masks, weights, count);
@@ -332,16 +340,16 @@ int run_mfma_bits(const FieldDev &fd, const void *a, const void *b, void *out, i
     const int m = (int)fd.m;
     int n2 = 1;
     while (n2 < m) n2 *= 2;
-    u32 pos[16], masks[81];
-    u64 weights[81];
+    u32 pos[32], masks[243];
+    u64 weights[243];
     for (int i = 0; i < n2; i++) pos[i] = i < m ? 1u << i : 0u;
     int nt = 0;
     karatsuba_leaves(pos, n2, 1, masks, weights, &nt);
     BinFold bf{};
     PlaneMasks pm{};
     bf.nt = nt;
-    for (int t = 0; t < nt; t++) pm.m[t] = (uint16_t)masks[t];
-    for (int t = 0; t < nt; t++) bf.red[t] = (uint16_t)Bin::reduce_bits(weights[t], m, 2 * n2, fd.irr); // deg r_t <= 2 n2 - 2
+    for (int t = 0; t < nt; t++) pm.m[t] = masks[t];
+    for (int t = 0; t < nt; t++) bf.red[t] = (u32)Bin::reduce_bits(weights[t], m, 2 * n2 - m, fd.irr); // deg r_t <= 2 n2 - 2
     const i64 Mp = (M + 255) / 256 * 256, Np = (N + 255) / 256 * 256, Kp = (K + BK - 1) / BK * BK;
     const i64 plane = M * N;
     int8_t *Ac = nullptr, *Bc = nullptr;
@@ -564,9 +572,11 @@ namespace gfa {
 // product large enough to amortise the centring pass.  Batches ride on gridDim.z (<= 65535 per call, sliced by the caller).
 bool matmul_mfma_eligible(const FieldDev &fd, i64 M, i64 K, i64 N)
 {
-    if (fd.kind == KIND_BIN && fd.m >= 2 && fd.m <= 16) // r06: Karatsuba bit planes: 27 (m <= 8) / 81 GEMMs over GF(2) + as many staging passes + a fold
-        return M >= 128 && N >= 128 && K < ((i64)1 << 31) && M * N * K >= ((i64)1 << (mfma_bits_min_log() - (fd.m > 8 ? 2 : 0))) && M * N <= ((i64)1 << 28) &&
-               M * K <= ((i64)1 << 28) && K * N <= ((i64)1 << 28);
+    if (fd.kind == KIND_BIN && fd.m >= 2 && fd.m <= 32) { // r06: Karatsuba bit planes: 27 (m <= 8) / 81 (m <= 16) / at most 243 GEMMs over GF(2), two staging launches, a fold
+        const i64 cap = (i64)1 << (fd.m <= 16 ? 28 : 25); // planes: at most 243 x this many bytes per operand
+        return M >= 128 && N >= 128 && K < ((i64)1 << 31) && M * N * K >= ((i64)1 << (mfma_bits_min_log() - (fd.m > 8 ? 2 : 0))) && M * N <= cap && M * K <= cap &&
+               K * N <= cap;
+    }
     if (fd.kind == KIND_EXT && (fd.p & 1) && fd.p <= 251 && fd.m >= 2 && fd.m <= 16) // r06: Karatsuba digit planes (K as for GF(p): exact int32 sums)
         return M >= 128 && N >= 128 && K <= 131072 && M * N * K >= ((i64)1 << mfma_bits_min_log()) && M * N <= ((i64)1 << 28) && M * K <= ((i64)1 << 28) &&
                K * N <= ((i64)1 << 28);

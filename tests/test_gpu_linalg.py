@@ -245,19 +245,19 @@ def test_large_prime_matmul_on_matrix_cores(p):
     assert np.all((GF(A) @ GF(B)).numpy().astype(np.int64) == (900 * pow(p - 1, 2, p)) % p)
 
 
-@pytest.mark.parametrize("m", [2, 3, 4, 7, 8, 12, 16])
+@pytest.mark.parametrize("m", [2, 3, 4, 7, 8, 12, 16, 17, 20, 32])
 def test_binary_extension_field_matmul_on_matrix_cores(m):
-    """r06: GF(2^m), m <= 16, products with M, N >= 128 (and at least 2^24 multiply-adds): three (four) levels of Karatsuba over the
-    bit positions -- 27 (81) planes parity(A & mask_t), as many exact int8 GEMMs with the epilogue of GF(2) on the batch dimension of one
+    """r06: GF(2^m), m <= 32, products with M, N >= 128 (and at least 2^24 multiply-adds): three (four, five) levels of Karatsuba over the
+    bit positions -- 27 (81, at most 243) planes parity(A & mask_t), as many exact int8 GEMMs with the epilogue of GF(2) on the batch dimension of one
     launch, and a fold that xors r_t(x) mod f where the product bit is set (run_mfma_bits) -- against the oracle's table loop.  Degrees that
     are not powers of two (zero masks dropped), every storage dtype, all-ones operands over a long K, a stack with a broadcast operand, the
     hand-over to the other kernels below 128 rows; a subprocess with the planes switched OFF (GFA_MFMA_BITS_MIN_LOG=62) agrees on the same
     inputs."""
     GF = ga.GF(2**m)
     q = 2**m
-    F = O.OracleField(2, m, int(GF.irreducible_poly), int(GF.primitive_element), lookup=True)
+    F = O.OracleField(2, m, int(GF.irreducible_poly), int(GF.primitive_element), lookup=m <= 16)
     rng = np.random.default_rng(m)
-    shapes = [(1024, 1024, 1024), (1030, 1100, 1000), (256, 64, 256), (300, 77, 257), (128, 1100, 129)]
+    shapes = [(1024, 1024, 1024), (1030, 1100, 1000), (256, 64, 256), (300, 77, 257), (128, 1100, 129)] if m <= 16 else [(512, 300, 512), (300, 77, 257), (128, 1100, 129)]
     for M, K, N in shapes:
         A, B = rng.integers(0, q, (M, K)), rng.integers(0, q, (K, N))
         want = F.matmul(A, B)

@@ -70,6 +70,14 @@ while time.time() < t_end:
             assert np.array_equal(u64((GFb(A) @ GFb(B)).numpy()), Fb.matmul(A, B)), ("matmul bit planes", mb, m, k, n)
             n_la += 1
             continue
+        if rng.random() < 0.06:  # r06: GF(p^m), odd p <= 251, on the matrix cores as Karatsuba digit planes
+            qe = int([3**2, 3**3, 3**5, 5**3, 7**3, 3**7, 11**2, 251**2, 13**3, 5**5, 3**9][rng.integers(0, 11)])
+            GFe, Fe = pair(qe)
+            m, k, n = 128 + int(rng.integers(0, 200)), 1024 + int(rng.integers(0, 300)), 128 + int(rng.integers(0, 200))
+            A, B = rnd(qe, (m, k)), rnd(qe, (k, n))
+            assert np.array_equal(u64((GFe(A) @ GFe(B)).numpy()), Fe.matmul(A, B)), ("matmul digit planes", qe, m, k, n)
+            n_la += 1
+            continue
         if q in (65537, 2**31 - 1) and rng.random() < 0.05:  # 7-bit limb path (>= 2^27 multiply-adds)
             m, k, n = 512 + int(rng.integers(0, 40)), 512 + int(rng.integers(0, 40)), 512 + int(rng.integers(0, 40))
             A, B = rnd(q, (m, k)), rnd(q, (k, n))

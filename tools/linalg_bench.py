@@ -65,7 +65,9 @@ mm("GF(2) u8", ga.GF(2), np.uint8, L.U8, 1, 8192, 8192, 8192, 3)
 mm("GF(31) u8 stack", ga.GF(31), np.uint8, L.U8, 64, 512, 512, 512, 3)
 mm("Goldilocks u64", ga.GF(2**64 - 2**32 + 1), np.uint64, L.U64, 1, 1024, 1024, 1024, 3)
 mm("GF(3^5) u8 (Zech tables)", ga.GF(3**5), np.uint8, L.U8, 1, 1024, 1024, 1024, 3)
-mm("GF(2^32) u32 (shift-xor)", ga.GF(2**32), np.uint32, L.U32, 1, 1024, 1024, 1024, 3)
+mm("GF(2^32) u32 (243 planes, MFMA)", ga.GF(2**32), np.uint32, L.U32, 1, 2048, 2048, 2048, 3)
+mm("GF(2^20) u32 (bit planes, MFMA)", ga.GF(2**20), np.uint32, L.U32, 1, 2048, 2048, 2048, 3)
+mm("GF(2^32) u32 (243 planes, MFMA)", ga.GF(2**32), np.uint32, L.U32, 1, 1024, 1024, 1024, 3)
 
 # elimination: stacks of small systems and one large matrix
 def timed(fn, reps=3):
