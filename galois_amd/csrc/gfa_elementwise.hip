@@ -1075,11 +1075,156 @@ int dispatch_reduceat(const FieldDev &fd, int dtype, int op, const void *a, cons
     GFA_DISPATCH_FT(launch_reduceat_ft, fd, dtype, fd, op, a, starts, ends, nseg, out, st, err);
 }
 
+// ---- r06: streaming forms of the folds a 1-D array of 1e8 elements asks for (the generic kernel above reads one element per lane and load:
+// 0.04 of the roofline for np.add.reduce over GF(2^8)) ----
+// MODE 0: xor of the words (every field of characteristic 2: the fold of the elements is the fold of the packed words, folded once more
+//         across the word at the end).  MODE 1: plain integer sums in 64 bits, reduced mod p once per block (prime fields, elements of at
+//         most 32 bits: a block adds at most 2^32 of them).  MODE 2: np.multiply.reduce of a table field of at most 256 elements: sum of
+//         LOG[x] from a 256-entry LDS table, EXP once per block, zero if any element is zero.
+// Each block covers [lo, hi) of one row: 16-byte loads over the aligned middle, the unaligned head and tail element by element.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void reduce_stream_kernel(const T *__restrict__ in, i64 n_inner, i64 col_begin, i64 seg_len, i64 nseg, u64 *__restrict__ partial,
+                                                            u64 p, const uint8_t *__restrict__ log8, const uint8_t *__restrict__ exp8, u32 qm1)
+{
+    __shared__ u64 sh[256];
+    __shared__ uint8_t lg[256];
+    __shared__ int any_zero;
+    if (MODE == 2) {
+        lg[threadIdx.x] = log8[threadIdx.x];
+        if (threadIdx.x == 0) any_zero = 0;
+        __syncthreads();
+    }
+    constexpr int V = 16 / (int)sizeof(T);
+    const i64 row = blockIdx.x / nseg, seg = blockIdx.x % nseg;
+    const i64 lo = col_begin + seg * seg_len;
+    i64 hi = lo + seg_len;
+    if (hi > n_inner) hi = n_inner;
+    const T *x = in + row * n_inner;
+    u64 acc = 0;
+    bool zero = false;
+    auto one = [&](T v) {
+        if (MODE == 0) acc ^= (u64)v;
+        else if (MODE == 1) acc += (u64)v;
+        else { zero |= v == 0; acc += (u64)lg[(uint8_t)v]; }
+    };
+    if (hi > lo) {
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(x + lo);
+        i64 head = (i64)(((16 - (addr & 15)) & 15) / sizeof(T));
+        if (head > hi - lo) head = hi - lo;
+        const i64 a_lo = lo + head, nvec = (hi - a_lo) / V, a_hi = a_lo + nvec * V;
+        if ((i64)threadIdx.x < head) one(x[lo + threadIdx.x]);
+        if (a_hi + (i64)threadIdx.x < hi) one(x[a_hi + threadIdx.x]);
+        const uint4 *xv = reinterpret_cast<const uint4 *>(x + a_lo);
+        if (MODE == 0) {
+            u32 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+            for (i64 v = threadIdx.x; v < nvec; v += 256) { const uint4 w = xv[v]; w0 ^= w.x; w1 ^= w.y; w2 ^= w.z; w3 ^= w.w; }
+            u32 w = w0 ^ w1 ^ w2 ^ w3; // the elements of the four words sit at the same offsets inside a word (sizeof(T) divides 4), or T is 8 bytes
+            if (sizeof(T) == 8) acc ^= ((u64)(w1 ^ w3) << 32) | (u64)(w0 ^ w2);
+            else {
+                if (sizeof(T) <= 2) w ^= w >> 16;
+                if (sizeof(T) == 1) w ^= w >> 8;
+                acc ^= (u64)(w & (sizeof(T) == 1 ? 0xffu : sizeof(T) == 2 ? 0xffffu : 0xffffffffu));
+            }
+        } else {
+            for (i64 v = threadIdx.x; v < nvec; v += 256) {
+                const uint4 w = xv[v];
+                const u32 ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (sizeof(T) == 4) one((T)ww[j]);
+                    else if (sizeof(T) == 2) { one((T)(ww[j] & 0xffffu)); one((T)(ww[j] >> 16)); }
+                    else if (sizeof(T) == 1) { one((T)(ww[j] & 0xffu)); one((T)((ww[j] >> 8) & 0xffu)); one((T)((ww[j] >> 16) & 0xffu)); one((T)(ww[j] >> 24)); }
+                }
+                if (sizeof(T) == 8) { one((T)(((u64)w.y << 32) | w.x)); one((T)(((u64)w.w << 32) | w.z)); }
+            }
+        }
+    }
+    if (MODE == 2 && zero) any_zero = 1; // (benign race: every writer stores 1)
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] = MODE == 0 ? sh[threadIdx.x] ^ sh[threadIdx.x + off] : sh[threadIdx.x] + sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        u64 r = sh[0];
+        if (MODE == 1) r %= p;
+        if (MODE == 2) r = any_zero ? 0 : (u64)exp8[r % qm1];
+        partial[blockIdx.x] = r;
+    }
+}
+
+// the same finalisation with ONE WORKGROUP per row: a 1-D array is cut into up to 4096 segments, and one thread walking their partial results
+// was 180 of the 196 us np.add.reduce took over 1e8 bytes (r06)
+template <class F, typename T, bool IS_MUL>
+__global__ __launch_bounds__(256) void reduce_finalize_block_kernel(FieldDev fd, const T *__restrict__ in, i64 n_inner, const u64 *__restrict__ partial,
+                                                                    i64 nseg, T *__restrict__ out, int mode, int32_t *err)
+{
+    typedef typename F::elem E;
+    __shared__ u64 sh[256];
+    const i64 row = blockIdx.x;
+    E acc = IS_MUL ? F::one(fd) : (E)0;
+    for (i64 sg = threadIdx.x; sg < nseg; sg += 256) {
+        const E v = (E)partial[row * nseg + sg];
+        acc = IS_MUL ? F::mul(fd, acc, v) : F::add(fd, acc, v);
+    }
+    sh[threadIdx.x] = (u64)acc;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            const E a = (E)sh[threadIdx.x], b = (E)sh[threadIdx.x + off];
+            sh[threadIdx.x] = (u64)(IS_MUL ? F::mul(fd, a, b) : F::add(fd, a, b));
+        }
+        __syncthreads();
+    }
+    bool bad = false;
+    if (threadIdx.x == 0) {
+        acc = (E)sh[0];
+        if (mode == 1) acc = F::sub(fd, (E)in[row * n_inner], acc);
+        if (mode == 2) {
+            const E a0 = (E)in[row * n_inner];
+            if (acc == 0) { bad = true; acc = 0; }
+            else if (a0 == 0) acc = 0;
+            else {
+                if constexpr (std::is_same<F, Lut>::value) acc = Lut::div_nz(fd, a0, acc);
+                else acc = F::mul(fd, a0, F::inv(fd, acc));
+            }
+        }
+        out[row] = (T)acc;
+    }
+    flag_error(err, bad);
+}
+
 struct ReduceScratch {
     u64 *p = nullptr;
     size_t n = 0;
 };
 ReduceScratch g_reduce_scratch[64];
+// byte LOG / EXP of the field a gfa_reduce call is for (set by gfa_reduce / gfa_accumulate around the dispatch; q <= 256 only)
+thread_local const uint8_t *g_reduce_log8 = nullptr, *g_reduce_exp8 = nullptr;
+
+// the fold of each of nseg segments of every row into partial[row * nseg + seg]: the streaming kernels where the fold is an xor of words / an
+// integer sum / a sum of byte logarithms (r06), else the generic kernel
+template <class F, typename T>
+void reduce_phase1(const FieldDev &fd, bool is_mul, const void *a, i64 n_inner, i64 col_begin, i64 seg_len, i64 nseg, i64 n_outer, u64 *partial, hipStream_t st)
+{
+    const unsigned grid = (unsigned)(n_outer * nseg);
+    int stream_mode = -1;
+    if (!is_mul && fd.p == 2) stream_mode = 0;
+    else if (!is_mul && fd.m == 1 && sizeof(T) <= 4 && seg_len < ((i64)1 << 32)) stream_mode = 1;
+    else if (is_mul && std::is_same<F, Lut>::value && sizeof(T) == 1 && fd.q <= 256 && g_reduce_log8 && g_reduce_exp8 && seg_len < ((i64)1 << 40)) stream_mode = 2;
+    if (stream_mode == 0)
+        hipLaunchKernelGGL((reduce_stream_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const T *)a, n_inner, col_begin, seg_len, nseg, partial, (u64)fd.p, nullptr, nullptr, 0u);
+    else if (stream_mode == 1)
+        hipLaunchKernelGGL((reduce_stream_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T *)a, n_inner, col_begin, seg_len, nseg, partial, (u64)fd.p, nullptr, nullptr, 0u);
+    else if (stream_mode == 2)
+        hipLaunchKernelGGL((reduce_stream_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const T *)a, n_inner, col_begin, seg_len, nseg, partial, (u64)fd.p, g_reduce_log8,
+                           g_reduce_exp8, (u32)(fd.q - 1));
+    else if (is_mul)
+        hipLaunchKernelGGL((reduce_segments_kernel<F, T, true>), dim3(grid), dim3(256), 0, st, fd, (const T *)a, n_inner, col_begin, seg_len, nseg, partial);
+    else
+        hipLaunchKernelGGL((reduce_segments_kernel<F, T, false>), dim3(grid), dim3(256), 0, st, fd, (const T *)a, n_inner, col_begin, seg_len, nseg, partial);
+}
 
 template <class F, typename T>
 int launch_reduce_ft(const FieldDev &fd, int op, const void *a, void *out, i64 n_outer, i64 n_inner, hipStream_t st,
@@ -1108,18 +1253,18 @@ int launch_reduce_ft(const FieldDev &fd, int op, const void *a, void *out, i64 n
         GFA_HIP(hipMalloc((void **)&rs.p, need * sizeof(u64)));
         rs.n = need;
     }
-    const unsigned grid = (unsigned)(n_outer * nseg);
-    if (is_mul) {
-        hipLaunchKernelGGL((reduce_segments_kernel<F, T, true>), dim3(grid), dim3(256), 0, st, fd, (const T *)a, n_inner,
-                           col_begin, seg_len, nseg, rs.p);
-        hipLaunchKernelGGL((reduce_finalize_kernel<F, T, true>), dim3((unsigned)((n_outer + 255) / 256)), dim3(256), 0, st,
-                           fd, (const T *)a, n_inner, rs.p, nseg, (T *)out, n_outer, mode, err);
-    } else {
-        hipLaunchKernelGGL((reduce_segments_kernel<F, T, false>), dim3(grid), dim3(256), 0, st, fd, (const T *)a, n_inner,
-                           col_begin, seg_len, nseg, rs.p);
-        hipLaunchKernelGGL((reduce_finalize_kernel<F, T, false>), dim3((unsigned)((n_outer + 255) / 256)), dim3(256), 0, st,
-                           fd, (const T *)a, n_inner, rs.p, nseg, (T *)out, n_outer, mode, err);
-    }
+    reduce_phase1<F, T>(fd, is_mul, a, n_inner, col_begin, seg_len, nseg, n_outer, rs.p, st);
+    if (nseg > 8) { // few rows, many segments: a workgroup per row
+        if (is_mul)
+            hipLaunchKernelGGL((reduce_finalize_block_kernel<F, T, true>), dim3((unsigned)n_outer), dim3(256), 0, st, fd, (const T *)a, n_inner, rs.p, nseg, (T *)out, mode, err);
+        else
+            hipLaunchKernelGGL((reduce_finalize_block_kernel<F, T, false>), dim3((unsigned)n_outer), dim3(256), 0, st, fd, (const T *)a, n_inner, rs.p, nseg, (T *)out, mode, err);
+    } else if (is_mul)
+        hipLaunchKernelGGL((reduce_finalize_kernel<F, T, true>), dim3((unsigned)((n_outer + 255) / 256)), dim3(256), 0, st, fd, (const T *)a, n_inner, rs.p, nseg,
+                           (T *)out, n_outer, mode, err);
+    else
+        hipLaunchKernelGGL((reduce_finalize_kernel<F, T, false>), dim3((unsigned)((n_outer + 255) / 256)), dim3(256), 0, st, fd, (const T *)a, n_inner, rs.p, nseg,
+                           (T *)out, n_outer, mode, err);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }
@@ -1352,23 +1497,36 @@ int dispatch_bm(const FieldDev &fd, int dtype, const void *seq, i64 n, i64 batch
 
 // ufunc.accumulate over the last axis: one workgroup per row, 256-element chunks scanned in LDS with a running carry.
 // mode 0: inclusive scan with the op; 1: out[i] = a0 - (a1 + ... + ai); 2: out[i] = a0 / (a1 * ... * ai)
+// r06: a row may be cut into nseg segments of seg_len elements, one workgroup each, that start from carry_in[row * nseg + seg] -- the fold of
+// everything before the segment (accumulate_carries_kernel) -- so that ONE long row fills the chip; nseg = 1, carry_in = nullptr: the whole row.
 template <class F, typename T, bool IS_MUL>
 __global__ __launch_bounds__(256) void accumulate_kernel(FieldDev fd, const T *__restrict__ in, T *__restrict__ out, i64 n_inner,
-                                                         int mode, int32_t *err)
+                                                         int mode, int32_t *err, i64 nseg, i64 seg_len, const u64 *__restrict__ carry_in)
 {
     typedef typename F::elem E;
     __shared__ u64 sh[256];
-    const T *x = in + (i64)blockIdx.x * n_inner;
-    T *y = out + (i64)blockIdx.x * n_inner;
+    const i64 row = (i64)blockIdx.x / nseg, seg = (i64)blockIdx.x % nseg;
+    const T *x = in + row * n_inner;
+    T *y = out + row * n_inner;
     const E ident = IS_MUL ? F::one(fd) : (E)0;
     const E a0 = (E)x[0];
-    E carry = ident;
+    E carry = carry_in ? (E)carry_in[blockIdx.x] : ident;
     bool bad = false;
-    const i64 start = mode ? 1 : 0;
-    if (mode && threadIdx.x == 0) y[0] = (T)a0;
-    for (i64 base = start; base < n_inner; base += 256) {
-        const i64 i = base + threadIdx.x;
-        E v = i < n_inner ? (E)x[i] : ident;
+    const i64 start = (mode ? 1 : 0) + seg * seg_len;
+    i64 stop = nseg == 1 ? n_inner : start + seg_len;
+    if (stop > n_inner) stop = n_inner;
+    if (mode && seg == 0 && threadIdx.x == 0) y[0] = (T)a0;
+    constexpr int PER = 8; // consecutive elements per thread and iteration: one LDS scan (16 barriers) per 2048 elements instead of per 256
+    for (i64 base = start; base < stop; base += 256 * PER) {
+        const i64 i0 = base + (i64)threadIdx.x * PER;
+        E w[PER];
+        E v = ident; // running fold of this thread's elements
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const E e = i0 + j < stop ? (E)x[i0 + j] : ident;
+            v = IS_MUL ? F::mul(fd, v, e) : F::add(fd, v, e);
+            w[j] = v; // inclusive scan inside the thread
+        }
         sh[threadIdx.x] = (u64)v;
         __syncthreads();
         for (int off = 1; off < 256; off <<= 1) {
@@ -1381,20 +1539,25 @@ __global__ __launch_bounds__(256) void accumulate_kernel(FieldDev fd, const T *_
             }
             __syncthreads();
         }
-        E r = IS_MUL ? F::mul(fd, carry, v) : F::add(fd, carry, v);
+        const E before = threadIdx.x ? (E)sh[threadIdx.x - 1] : ident;               // the threads before this one, in this chunk
+        const E lead = IS_MUL ? F::mul(fd, carry, before) : F::add(fd, carry, before); // everything before this thread's elements
         const E total = IS_MUL ? F::mul(fd, carry, (E)sh[255]) : F::add(fd, carry, (E)sh[255]);
-        if (i < n_inner) {
-            E o = r;
-            if (mode == 1) o = F::sub(fd, a0, r);
-            if (mode == 2) {
-                if (r == 0) { bad = true; o = 0; }
-                else if (a0 == 0) o = 0;
-                else {
-                    if constexpr (std::is_same<F, Lut>::value) o = Lut::div_nz(fd, a0, r);
-                    else o = F::mul(fd, a0, F::inv(fd, r));
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            if (i0 + j < stop) {
+                const E r = IS_MUL ? F::mul(fd, lead, w[j]) : F::add(fd, lead, w[j]);
+                E o = r;
+                if (mode == 1) o = F::sub(fd, a0, r);
+                if (mode == 2) {
+                    if (r == 0) { bad = true; o = 0; }
+                    else if (a0 == 0) o = 0;
+                    else {
+                        if constexpr (std::is_same<F, Lut>::value) o = Lut::div_nz(fd, a0, r);
+                        else o = F::mul(fd, a0, F::inv(fd, r));
+                    }
                 }
+                y[i0 + j] = (T)o;
             }
-            y[i] = (T)o;
         }
         carry = total;
         __syncthreads();
@@ -1402,17 +1565,85 @@ __global__ __launch_bounds__(256) void accumulate_kernel(FieldDev fd, const T *_
     flag_error(err, bad);
 }
 
+// partial[row * nseg + seg] (the fold of segment seg) -> the fold of the segments before it.  One workgroup per row: every thread folds
+// its run of ceil(nseg / 256) partials, the 256 run totals are scanned in LDS, the runs are rewritten from their prefix
+template <class F, bool IS_MUL>
+__global__ __launch_bounds__(256) void accumulate_carries_kernel(FieldDev fd, u64 *__restrict__ partial, i64 nseg, i64 n_outer)
+{
+    typedef typename F::elem E;
+    __shared__ u64 sh[256];
+    const i64 row = blockIdx.x;
+    const E ident = IS_MUL ? F::one(fd) : (E)0;
+    const i64 c = (nseg + 255) / 256, lo = (i64)threadIdx.x * c;
+    i64 hi = lo + c;
+    if (hi > nseg) hi = nseg;
+    u64 *pr = partial + row * nseg;
+    E loc = ident;
+    for (i64 sg = lo; sg < hi; sg++) { const E v = (E)pr[sg]; loc = IS_MUL ? F::mul(fd, loc, v) : F::add(fd, loc, v); }
+    E v = loc;
+    sh[threadIdx.x] = (u64)v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        E o = ident;
+        if ((int)threadIdx.x >= off) o = (E)sh[threadIdx.x - off];
+        __syncthreads();
+        if ((int)threadIdx.x >= off) { v = IS_MUL ? F::mul(fd, o, v) : F::add(fd, o, v); sh[threadIdx.x] = (u64)v; }
+        __syncthreads();
+    }
+    E run = threadIdx.x ? (E)sh[threadIdx.x - 1] : ident; // the fold of every run before this one
+    for (i64 sg = lo; sg < hi; sg++) {
+        const E x = (E)pr[sg];
+        pr[sg] = (u64)run;
+        run = IS_MUL ? F::mul(fd, run, x) : F::add(fd, run, x);
+    }
+    (void)n_outer;
+}
+
 template <class F, typename T>
 int launch_accumulate_ft(const FieldDev &fd, int op, const void *a, void *out, i64 n_outer, i64 n_inner, hipStream_t st,
                          int32_t *err)
 {
     const int mode = op == GFA_OP_SUB ? 1 : op == GFA_OP_DIV ? 2 : 0;
-    if (op == GFA_OP_MUL || op == GFA_OP_DIV)
+    const bool is_mul = op == GFA_OP_MUL || op == GFA_OP_DIV;
+    // r06: few long rows (np.cumsum of a 1-D array): segment folds -> carries -> segment scans, instead of one workgroup for the whole row
+    const i64 col_begin = mode ? 1 : 0, len = n_inner - col_begin;
+    const i64 want_blocks = (i64)num_cus() * 8;
+    if (n_outer < want_blocks / 4 && len >= ((i64)1 << 16)) {
+        i64 nseg = std::min<i64>((want_blocks + n_outer - 1) / n_outer, len / 8192);
+        if (nseg > 4096) nseg = 4096;
+        if (nseg >= 2) {
+            const i64 seg_len = ((len + nseg - 1) / nseg + 255) / 256 * 256;
+            nseg = (len + seg_len - 1) / seg_len;
+            int d = 0;
+            GFA_HIP(hipGetDevice(&d));
+            ReduceScratch &rs = g_reduce_scratch[d & 63];
+            const size_t need = (size_t)(n_outer * nseg);
+            if (rs.n < need) {
+                if (rs.p) (void)hipFree(rs.p);
+                rs.p = nullptr; rs.n = 0;
+                GFA_HIP(hipMalloc((void **)&rs.p, need * sizeof(u64)));
+                rs.n = need;
+            }
+            reduce_phase1<F, T>(fd, is_mul, a, n_inner, col_begin, seg_len, nseg, n_outer, rs.p, st);
+            if (is_mul) {
+                hipLaunchKernelGGL((accumulate_carries_kernel<F, true>), dim3((unsigned)n_outer), dim3(256), 0, st, fd, rs.p, nseg, n_outer);
+                hipLaunchKernelGGL((accumulate_kernel<F, T, true>), dim3((unsigned)(n_outer * nseg)), dim3(256), 0, st, fd, (const T *)a, (T *)out, n_inner, mode, err, nseg,
+                                   seg_len, (const u64 *)rs.p);
+            } else {
+                hipLaunchKernelGGL((accumulate_carries_kernel<F, false>), dim3((unsigned)n_outer), dim3(256), 0, st, fd, rs.p, nseg, n_outer);
+                hipLaunchKernelGGL((accumulate_kernel<F, T, false>), dim3((unsigned)(n_outer * nseg)), dim3(256), 0, st, fd, (const T *)a, (T *)out, n_inner, mode, err, nseg,
+                                   seg_len, (const u64 *)rs.p);
+            }
+            GFA_HIP(hipGetLastError());
+            return GFA_OK;
+        }
+    }
+    if (is_mul)
         hipLaunchKernelGGL((accumulate_kernel<F, T, true>), dim3((unsigned)n_outer), dim3(256), 0, st, fd, (const T *)a, (T *)out,
-                           n_inner, mode, err);
+                           n_inner, mode, err, (i64)1, (i64)0, (const u64 *)nullptr);
     else
         hipLaunchKernelGGL((accumulate_kernel<F, T, false>), dim3((unsigned)n_outer), dim3(256), 0, st, fd, (const T *)a, (T *)out,
-                           n_inner, mode, err);
+                           n_inner, mode, err, (i64)1, (i64)0, (const u64 *)nullptr);
     GFA_HIP(hipGetLastError());
     return GFA_OK;
 }
@@ -1814,6 +2045,7 @@ int gfa_reduce(gfa_field_t *f, int op, const void *a, void *out, int64_t n_outer
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
+    g_reduce_log8 = ds->log8; g_reduce_exp8 = ds->exp8;
     if (f->use_lookup()) return dispatch_reduce(f->lut_desc(*ds), dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
     return dispatch_reduce(f->calc, dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
 }
@@ -1846,6 +2078,7 @@ int gfa_accumulate(gfa_field_t *f, int op, const void *a, void *out, int64_t n_o
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
+    g_reduce_log8 = ds->log8; g_reduce_exp8 = ds->exp8;
     if (f->use_lookup()) return dispatch_accumulate(f->lut_desc(*ds), dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
     return dispatch_accumulate(f->calc, dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
 }

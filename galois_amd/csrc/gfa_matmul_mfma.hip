@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "gfa_internal.h"
+#include "gfa_karatsuba.h"
 
 using namespace gfa;
 
@@ -37,9 +38,6 @@ __device__ __forceinline__ int8_t centre(u32 a, u32 p, u32 half) { return (int8_
 // operand byte: the centred residue (shift < 0, p <= 256) or the 7-bit limb of the element at bit `shift` (larger primes)
 // (shift == 64, handled by the staging kernels: the PARITY of the element's bits under a mask -- the Karatsuba planes of GF(2^m),
 // run_mfma_bits, which stages all its planes in one launch: plane blockIdx.z takes its mask from PlaneMasks)
-struct PlaneMasks {
-    u32 m[243];
-};
 __device__ __forceinline__ int8_t operand(u64 a, u32 p, u32 half, int shift)
 {
     return shift < 0 ? centre((u32)a, p, half) : (int8_t)((a >> shift) & 127u);
@@ -301,10 +299,6 @@ int run_mfma_limbs(const FieldDev &fd, int nl, const void *a, const void *b, voi
 // exact int8 GEMM with the epilogue of GF(2) (the 27 products ride on the batch dimension of a single launch), and the fold xors
 // r_t(x) mod f where P_t is set.  27 instead of 64 plane products for GF(2^8).  Same values as the reference's loops of multiply / add
 // ufuncs (_domains/_linalg.py:286-308).
-struct BinFold {
-    u32 red[243]; // r_t(x) mod f
-    int nt;
-};
 template <typename T>
 __global__ __launch_bounds__(256) void fold_bits_kernel(const uint8_t *__restrict__ P, BinFold bf, i64 plane, T *__restrict__ out, i64 count)
 {
@@ -315,41 +309,14 @@ __global__ __launch_bounds__(256) void fold_bits_kernel(const uint8_t *__restric
     }
 }
 
-// the masks and weights of the Karatsuba leaves over `n` (a power of two) bit positions of which the first m are real
-static void karatsuba_leaves(const u32 *pos, int n, u64 w, u32 *masks, u64 *weights, int *count)
-{
-    if (n == 1) {
-        if (pos[0]) { masks[*count] = pos[0]; weights[*count] = w; (*count)++; } // a zero mask is a zero operand: no product
-        return;
-    }
-    const int h = n / 2;
-    u32 mid[16];
-    bool hi_any = false;
-    for (int i = 0; i < h; i++) hi_any |= pos[h + i] != 0;
-    if (!hi_any) { karatsuba_leaves(pos, h, w, masks, weights, count); return; } // both high halves zero (positions padded to a power of two)
-    for (int i = 0; i < h; i++) mid[i] = pos[i] ^ pos[h + i];
-    karatsuba_leaves(pos, h, w ^ (w << h), masks, weights, count);
-    karatsuba_leaves(pos + h, h, (w << h) ^ (w << (2 * h)), masks, weights, count);
-    karatsuba_leaves(mid, h, w << h, masks, weights, count);
-}
-
 template <typename T>
 int run_mfma_bits(const FieldDev &fd, const void *a, const void *b, void *out, i64 batch, i64 M, i64 K, i64 N, i64 a_bstride, i64 b_bstride,
                   hipStream_t st)
 {
-    const int m = (int)fd.m;
-    int n2 = 1;
-    while (n2 < m) n2 *= 2;
-    u32 pos[32], masks[243];
-    u64 weights[243];
-    for (int i = 0; i < n2; i++) pos[i] = i < m ? 1u << i : 0u;
-    int nt = 0;
-    karatsuba_leaves(pos, n2, 1, masks, weights, &nt);
     BinFold bf{};
     PlaneMasks pm{};
-    bf.nt = nt;
-    for (int t = 0; t < nt; t++) pm.m[t] = masks[t];
-    for (int t = 0; t < nt; t++) bf.red[t] = (u32)Bin::reduce_bits(weights[t], m, 2 * n2 - m, fd.irr); // deg r_t <= 2 n2 - 2
+    make_bin_fold(fd, &pm, &bf);
+    const int nt = bf.nt;
     const i64 Mp = (M + 255) / 256 * 256, Np = (N + 255) / 256 * 256, Kp = (K + BK - 1) / BK * BK;
     const i64 plane = M * N;
     int8_t *Ac = nullptr, *Bc = nullptr;
@@ -386,26 +353,6 @@ int run_mfma_bits(const FieldDev &fd, const void *a, const void *b, void *out, i
 // field's epilogue, and -- reduction mod f being linear too -- digit k of the result is (sum_t P_t R_t[k]) mod p with R_t = weight_t mod f
 // computed on the host.  Leaves whose set is empty (positions padded up to a power of two) are dropped: 8 products for degree 3, 22 for
 // degree 5 (schoolbook: 9, 25).  The table kernels these fields ran on manage 0.17 TMAC/s (GF(3^5), 1024^3).
-struct DigitFold {
-    uint8_t R[81][16]; // R[t][k]: coefficient of x^k of (weight polynomial of leaf t) mod f, in [0, p)
-    uint16_t set[81];  // E_t as a mask over the digit positions
-    int nt, m;
-    u32 p;
-};
-
-template <typename T>
-__device__ __forceinline__ void digits_of(T v, u32 p, int m, u32 (&d)[16])
-{
-    u64 x = (u64)v; // (static indices throughout: the digits stay in registers)
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        d[i] = 0;
-        if (i < m) {
-            if (sizeof(T) <= 4) { const u32 x32 = (u32)x, qd = x32 / p; d[i] = x32 - qd * p; x = qd; }
-            else { const u64 qd = x / p; d[i] = (u32)(x - qd * p); x = qd; }
-        }
-    }
-}
 __device__ __forceinline__ int8_t digit_plane(const u32 (&d)[16], u32 set, u32 p, u32 half)
 {
     u32 sum = 0;
@@ -473,62 +420,14 @@ __global__ __launch_bounds__(256) void fold_digits_kernel(const uint8_t *__restr
     }
 }
 
-// Karatsuba leaves over n (a power of two) positions with integer weights mod p; pos[i] = set of digit positions summed at place i
-static void karatsuba_leaves_p(const u32 *pos, int n, const std::vector<i64> &w, u32 p, std::vector<u32> &sets, std::vector<std::vector<i64>> &weights)
-{
-    if (n == 1) {
-        if (pos[0]) { sets.push_back(pos[0]); weights.push_back(w); }
-        return;
-    }
-    const int h = n / 2;
-    u32 mid[8];
-    bool lo_any = false, hi_any = false;
-    for (int i = 0; i < h; i++) { lo_any |= pos[i] != 0; hi_any |= pos[h + i] != 0; }
-    auto shifted = [&](int by, i64 sign) { std::vector<i64> r(w.size() + by, 0); for (size_t i = 0; i < w.size(); i++) r[i + by] = sign * w[i]; return r; };
-    auto add = [&](std::vector<i64> a, const std::vector<i64> &b) { if (a.size() < b.size()) a.resize(b.size(), 0); for (size_t i = 0; i < b.size(); i++) a[i] += b[i]; return a; };
-    if (!hi_any) { karatsuba_leaves_p(pos, h, w, p, sets, weights); return; } // a(x) b(x) with both high halves zero: the low product alone
-    // (positions hold SETS whose digits are summed: lo + hi at place i is the union -- the two are disjoint by construction)
-    for (int i = 0; i < h; i++) mid[i] = pos[i] | pos[h + i];
-    karatsuba_leaves_p(pos, h, add(w, shifted(h, -1)), p, sets, weights);                 // P_lo (1 - x^h)
-    karatsuba_leaves_p(pos + h, h, add(shifted(2 * h, 1), shifted(h, -1)), p, sets, weights); // P_hi (x^2h - x^h)
-    karatsuba_leaves_p(mid, h, shifted(h, 1), p, sets, weights);                          // P_mid x^h
-    (void)lo_any;
-}
-
 template <typename T>
 int run_mfma_digits(const FieldDev &fd, const void *a, const void *b, void *out, i64 batch, i64 M, i64 K, i64 N, i64 a_bstride, i64 b_bstride,
                     hipStream_t st)
 {
-    const int m = (int)fd.m;
-    const u32 p = (u32)fd.p;
-    int n2 = 1;
-    while (n2 < m) n2 *= 2;
-    u32 pos[16];
-    for (int i = 0; i < n2; i++) pos[i] = i < m ? 1u << i : 0u;
-    std::vector<u32> sets;
-    std::vector<std::vector<i64>> weights;
-    karatsuba_leaves_p(pos, n2, std::vector<i64>{1}, p, sets, weights);
-    const int nt = (int)sets.size();
-    if (nt > 81) return GFA_ERR_UNSUPPORTED;
     DigitFold df{};
-    df.nt = nt; df.m = m; df.p = p;
-    for (int t = 0; t < nt; t++) {
-        df.set[t] = (uint16_t)sets[t];
-        // weight polynomial mod p, then mod f: x^m = sum_k nir[k] x^k with nir[k] = -irr_k
-        std::vector<i64> c(weights[t]);
-        c.resize(std::max<size_t>(c.size(), (size_t)m), 0);
-        for (auto &v : c) v = ((v % (i64)p) + (i64)p) % (i64)p;
-        for (int sdeg = (int)c.size() - 1; sdeg >= m; sdeg--) {
-            const i64 top = c[sdeg];
-            if (!top) continue;
-            for (int k = 0; k < m; k++) { // coefficient of x^k of f below the leading term: ext_irr[m - 1 - k]
-                const i64 nir = fd.ext_irr[m - 1 - k] ? (i64)p - (i64)fd.ext_irr[m - 1 - k] : 0;
-                c[sdeg - m + k] = (c[sdeg - m + k] + top * nir) % (i64)p;
-            }
-            c[sdeg] = 0;
-        }
-        for (int k = 0; k < m; k++) df.R[t][k] = (uint8_t)c[k];
-    }
+    if (!make_digit_fold(fd, &df)) return GFA_ERR_UNSUPPORTED;
+    const int nt = df.nt;
+    const u32 p = df.p;
     const i64 Mp = (M + 255) / 256 * 256, Np = (N + 255) / 256 * 256, Kp = (K + BK - 1) / BK * BK;
     const i64 plane = M * N;
     int8_t *Ac = nullptr, *Bc = nullptr;

@@ -1471,3 +1471,121 @@ def test_scalar_powers_of_table_fields_above_2e16_elements_through_a_per_call_ta
         x ** -2
     H.assert_equal_ints(u(y[: 4 * 1024 + 3] ** -12345), F.pow(b[: 4 * 1024 + 3], np.full(4 * 1024 + 3, -12345, dtype=np.int64)), "short array")
     H.assert_equal_ints(u(y[1:] ** 77), F.pow(b[1:], np.full(n - 1, 77, dtype=np.int64)), "misaligned view")
+
+
+@pytest.mark.parametrize("order", [2**8, 3**5, 31, 65537, 7340033, 2**16, 2**20, 2**64 - 2**32 + 1])
+def test_folds_and_scans_of_long_one_dimensional_arrays(order):
+    """r06: np.add.reduce / np.multiply.reduce / subtract / divide and their .accumulate over ONE long row -- the streaming first phase (xor of
+    words in characteristic 2, 64-bit integer sums in prime fields, sums of byte logarithms for table fields of at most 256 elements) and the
+    segmented scan (segment folds -> carries -> segment scans).  reduce: against a halving tree of the oracle's vectorised op (add and multiply
+    are associative and commutative; subtract / divide are a0 op fold(rest), _ufunc reduce semantics of the reference);  accumulate: EVERY
+    output against the recurrence out[i] = op(out[i-1], a[i]) evaluated by the oracle.  Lengths that leave ragged segments, a view that starts
+    at an odd element, zeros under multiply, a zero divisor under divide."""
+    GF = ga.GF(order)
+    p, m = GF.characteristic, GF.degree
+    F = O.OracleField(p, m, int(GF.irreducible_poly) if m > 1 else None, GF._primitive_element_int)
+    rng = np.random.default_rng(order % 1009)
+    wide = order > 2**63
+    def rnd(n, low):
+        if wide:
+            return ((rng.integers(0, 2**63, n, dtype=np.uint64) % np.uint64(order >> 1)) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)) | np.uint64(low)
+        return rng.integers(low, order, n, dtype=np.uint64)
+    def mk(v):
+        if wide:
+            import torch
+            return GF._wrap(torch.from_numpy(v.view(np.int64).copy()).cuda(), np.object_)
+        return GF(v.astype(GF.dtypes[0]), dtype=GF.dtypes[0])
+    def u(x):
+        h = x.numpy()
+        return np.array([int(t) for t in h.ravel()], dtype=np.uint64).reshape(h.shape) if h.dtype == object else h.astype(np.uint64)
+    def tree(op, v):
+        v = v.copy()
+        while len(v) > 1:
+            if len(v) & 1:
+                v = np.concatenate([op(v[:1], v[-1:]), v[1:-1]])
+            h = len(v) // 2
+            v = op(v[:h], v[h:])
+        return int(v[0])
+    for n, off in ((1_000_003, 0), (300_001, 3), (70_000, 1)):
+        a = rnd(n + off, 1)
+        x = mk(a)[off:]
+        a = a[off:]
+        tot_add, tot_mul = tree(F.add, a), tree(F.mul, a)
+        assert int(u(np.add.reduce(x))) == tot_add, (order, n, "add.reduce")
+        assert int(u(np.multiply.reduce(x))) == tot_mul, (order, n, "multiply.reduce")
+        rest_add, rest_mul = tree(F.add, a[1:]), tree(F.mul, a[1:])
+        assert int(u(np.subtract.reduce(x))) == int(F.sub(a[:1], np.array([rest_add], dtype=np.uint64))[0]), (order, n, "subtract.reduce")
+        assert int(u(np.true_divide.reduce(x))) == int(F.div(a[:1], np.array([rest_mul], dtype=np.uint64))[0]), (order, n, "divide.reduce")
+        for ufunc, op in ((np.add, F.add), (np.multiply, F.mul), (np.subtract, F.sub), (np.true_divide, F.div)):
+            out = u(ufunc.accumulate(x))
+            assert out[0] == a[0] and np.array_equal(op(out[:-1], a[1:]), out[1:]), (order, n, ufunc.__name__ + ".accumulate")
+    # zeros: a product over a zero is zero from there on; a zero divisor raises
+    a = rnd(200_000, 1)
+    a[123_457] = 0
+    x = mk(a)
+    assert int(u(np.multiply.reduce(x))) == 0
+    out = u(np.multiply.accumulate(x))
+    assert np.all(out[123_457:] == 0) and np.all(out[:123_457] != 0)
+    with pytest.raises(ZeroDivisionError):
+        np.true_divide.reduce(x)
+    with pytest.raises(ZeroDivisionError):
+        np.true_divide.accumulate(x)
+
+
+@pytest.mark.parametrize("order", [2**8, 2**4, 2**16, 2**20, 2**32, 3**5, 7**3, 3**2, 5**4, 3**10, 31**2])
+def test_long_polynomial_products_over_extension_fields(order):
+    """r06: np.convolve over GF(2^m) / GF(p^m) from 2^20 coefficient products: Karatsuba over the bit / digit positions, every leaf an exact
+    integer convolution modulo one transform prime (gfa_conv_crt.hip::run_planes) -- against the direct kernel's values through the oracle
+    on short operands, and for long ones through evaluation: c(x0) == a(x0) b(x0) at random points (Horner with the oracle), plus the full
+    comparison with the direct kernel of a child process (GFA_CONV_PLANES_MIN_LOG=62)."""
+    GF = ga.GF(order)
+    p, m = GF.characteristic, GF.degree
+    F = O.OracleField(p, m, int(GF.irreducible_poly), int(GF.primitive_element), lookup=order <= 2**16)
+    rng = np.random.default_rng(order % 997)
+    u = lambda v: v.numpy().astype(np.uint64)
+    def horner(c, x0):  # highest degree first, as np.convolve / np.polyval order does not matter for the identity: use index = degree
+        acc = np.zeros(len(x0), dtype=np.uint64)
+        for coef in c[::-1]:
+            acc = F.add(F.mul(acc, x0), np.full(len(x0), coef, dtype=np.uint64))
+        return acc
+    for na, nb in ((1024, 1024), (1500, 700), (40_000, 33)):
+        a, b = rng.integers(0, order, na, dtype=np.uint64), rng.integers(0, order, nb, dtype=np.uint64)
+        a[0] = b[0] = order - 1
+        a[-1] = b[-1] = order - 1
+        dt = GF.dtypes[0]
+        c = u(np.convolve(GF(a.astype(dt), dtype=dt), GF(b.astype(dt), dtype=dt)))
+        assert len(c) == na + nb - 1
+        x0 = rng.integers(0, order, 6, dtype=np.uint64)
+        H.assert_equal_ints(horner(c, x0), F.mul(horner(a, x0), horner(b, x0)), f"GF({order}) {na} x {nb}: c(x) == a(x) b(x)")
+        if na * nb <= 1100 * 1100:  # every coefficient against the oracle's schoolbook product
+            want = np.zeros(na + nb - 1, dtype=np.uint64)
+            for i in range(nb):
+                want[i:i + na] = F.add(want[i:i + na], F.mul(a, np.full(na, b[i], dtype=np.uint64)))
+            H.assert_equal_ints(c, want, f"GF({order}) {na} x {nb}")
+
+
+def test_long_polynomial_products_agree_with_the_direct_kernel():
+    """The same products with the plane route switched off (GFA_CONV_PLANES_MIN_LOG is read once per process): a child process writes the direct
+    kernel's results, this process compares every coefficient."""
+    import subprocess, sys, os, tempfile
+
+    code = (
+        "import sys, numpy as np, galois_amd as ga\n"
+        "rng = np.random.default_rng(11)\n"
+        "out = {}\n"
+        "for q in (2**8, 2**16, 3**5, 7**3):\n"
+        "    GF = ga.GF(q)\n"
+        "    a, b = rng.integers(0, q, 3000), rng.integers(0, q, 2500)\n"
+        "    out[str(q)] = np.convolve(GF(a), GF(b)).numpy().astype(np.uint64)\n"
+        "np.savez(sys.argv[1], **out)\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        res = {}
+        for tag, val in (("planes", "20"), ("direct", "62")):
+            path = os.path.join(d, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, env=dict(os.environ, GFA_CONV_PLANES_MIN_LOG=val, PYTHONPATH=root), timeout=600)
+            assert r.returncode == 0, r.stdout + r.stderr
+            res[tag] = dict(np.load(path))
+        for q in res["planes"]:
+            assert np.array_equal(res["planes"][q], res["direct"][q]), q
