@@ -15,6 +15,8 @@ ufunc cases); a case then costs a few kernel launches and one small oracle call:
              requests; generic p < 2^29 with the early requests): batches of 64 .. 300 transforms, forward and scaled inverse;
   * ext32    extension fields of 2^15 .. 2^20 elements on uint32 arrays (two-word packed sums of GF(3^11) / GF(3^12), digit-table products,
              GF(p^2) / GF(p^3) quotients and reciprocals by the norm / Cramer's rule): every operation with tails, misaligned views, scalars;
+  * long     one long row: np.add.reduce / np.multiply.reduce against a halving tree of the oracle's op, .accumulate against its recurrence (streaming folds,
+             segmented scans), np.convolve over extension fields through Karatsuba planes checked by evaluation at random points;
   * convolve random lengths 1500 .. 6000 (the CRT route) over pool primes, five coefficients against Python integers;
   * where    masked ufunc calls / reductions on random fields, uint16 / uint32 results blended into WIDER `out` arrays (ADVICE r05);
   * wide     (1 case in 25) the two-limb identities of fuzz_r05.py.
@@ -32,7 +34,9 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 rng = np.random.default_rng(seed)
 lib = L.lib()
 st = torch.cuda.current_stream().cuda_stream
-counts = {"ntt": 0, "ntt_large": 0, "ntt16": 0, "ntt_grouped": 0, "ext32": 0, "convolve": 0, "where": 0, "wide": 0}
+counts = {"ntt": 0, "ntt_large": 0, "ntt16": 0, "ntt_grouped": 0, "ext32": 0, "long": 0, "convolve": 0, "where": 0, "wide": 0}
+LONG = {}  # fields of the long-row folds / scans and of the plane convolutions (r06)
+LONG_ORDERS = [2**8, 3**5, 31, 65537, 7340033, 2**16, 7**3, 2**20, 2**4, 5**4, 3**10]
 
 
 def find_prime(bits, adic):
@@ -156,6 +160,45 @@ while time.time() < t_end:
             except ZeroDivisionError:
                 pass
         counts["ext32"] += 1
+    elif u < 0.675:
+        q = int(LONG_ORDERS[rng.integers(0, len(LONG_ORDERS))])
+        if q not in LONG:
+            G3 = ga.GF(q)
+            LONG[q] = (G3, O.OracleField(G3.characteristic, G3.degree, int(G3.irreducible_poly) if G3.degree > 1 else None, int(G3.primitive_element), lookup=q <= 2**16))
+        G3, F3 = LONG[q]
+        u64 = lambda v: v.numpy().astype(np.uint64)
+        def tree(op, v):
+            v = v.copy()
+            while len(v) > 1:
+                if len(v) & 1:
+                    v = np.concatenate([op(v[:1], v[-1:]), v[1:-1]])
+                h = len(v) // 2
+                v = op(v[:h], v[h:])
+            return int(v[0])
+        n = int(rng.integers(70_000, 600_000))
+        off = int(rng.integers(0, 2)) * int(rng.integers(1, 9))
+        a = rng.integers(1, q, n + off, dtype=np.uint64)
+        if rng.random() < 0.3:
+            a[int(rng.integers(off, n + off))] = 0
+        X = G3(a.astype(G3.dtypes[0]), dtype=G3.dtypes[0])[off:]
+        a = a[off:]
+        assert int(u64(np.add.reduce(X))) == tree(F3.add, a), ("long add.reduce", q, n, off)
+        assert int(u64(np.multiply.reduce(X))) == tree(F3.mul, a), ("long multiply.reduce", q, n, off)
+        for uf, op in ((np.add, F3.add), (np.multiply, F3.mul), (np.subtract, F3.sub)):
+            out = u64(uf.accumulate(X))
+            assert out[0] == a[0] and np.array_equal(op(out[:-1], a[1:]), out[1:]), ("long accumulate", uf.__name__, q, n, off)
+        if G3.degree > 1:  # np.convolve through Karatsuba planes (na nb >= 2^20): c(x0) == a(x0) b(x0) at random points
+            na, nb = int(rng.integers(1100, 5000)), int(rng.integers(1000, 3000))
+            ca, cb = rng.integers(0, q, na, dtype=np.uint64), rng.integers(0, q, nb, dtype=np.uint64)
+            cc = u64(np.convolve(G3(ca.astype(G3.dtypes[0]), dtype=G3.dtypes[0]), G3(cb.astype(G3.dtypes[0]), dtype=G3.dtypes[0])))
+            x0 = rng.integers(0, q, 4, dtype=np.uint64)
+            def horner(c):
+                acc = np.zeros(4, dtype=np.uint64)
+                for coef in c[::-1]:
+                    acc = F3.add(F3.mul(acc, x0), np.full(4, coef, dtype=np.uint64))
+                return acc
+            assert len(cc) == na + nb - 1 and np.array_equal(horner(cc), F3.mul(horner(ca), horner(cb))), ("plane convolve", q, na, nb)
+        counts["long"] += 1
     elif u < 0.72:
         p, GF, F, adic = POOL[int(rng.integers(0, len(POOL)))]
         na, nb = int(rng.integers(1500, 6000)), int(rng.integers(1500, 6000))
