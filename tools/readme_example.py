@@ -20,4 +20,13 @@ F = fft_batched(galois.GF(65537).Random((64, 1 << 16)))
 bch = galois.BCH(1023, d=21)
 assert (bch.n, bch.k, bch.t) == (1023, 923, 10)
 A = galois.GF(251).Random((4096, 4096)); B = A @ np.linalg.inv(A)
+E = galois.GF(7**7); q7 = E.Random(10**7) / E.Random(10**7, low=1)
+assert bool(((q7 * 0) == E(0)).all())
+c8 = np.convolve(galois.GF(2**8).Random(1 << 18), galois.GF(2**8).Random(1 << 18))
+assert c8.shape == ((1 << 19) - 1,)
+G = galois.GF(2**8).Random((2048, 2048)); H = G @ G
+I8 = galois.GF(2**8).Identity(2048)
+assert bool(((G @ I8) == G).all())
+s8 = np.add.reduce(GF.Random(10**8, seed=3)); cs = np.add.accumulate(GF.Random(10**7, seed=4))
+assert int(cs[-1]) == int(np.add.reduce(GF.Random(10**7, seed=4)))
 print("readme example OK", z.shape, X.shape, Y.shape, c.shape, bool((B == galois.GF(251).Identity(4096)).all()))
