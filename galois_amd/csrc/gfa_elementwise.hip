@@ -1333,6 +1333,68 @@ int launch_poly_eval_ft(const FieldDev &fd, const void *coeffs, i64 ncoef, const
     return GFA_OK;
 }
 
+// r06: Horner's rule for the fields of at most 256 elements on uint8 arrays with the full 64 KiB PRODUCT table in LDS (row = the point x, fixed
+// per lane; column = the running value: random banks) -- one LDS gather per coefficient where the generic kernel does two or three gathers
+// from L2 (and two more through Zech logarithms per addition in odd characteristic; here the 64 KiB SUM table, row = the coefficient).
+// Four points per lane: four independent chains cover the gather latency.  One persistent 1024-thread workgroup per CU.
+template <bool ODD>
+__global__ __launch_bounds__(1024) void poly_eval_tab8_kernel(const uint8_t *__restrict__ mul8, const uint8_t *__restrict__ add8, const uint8_t *__restrict__ coeffs,
+                                                              i64 ncoef, const uint8_t *__restrict__ x, uint8_t *__restrict__ out, i64 n)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t pe_lds[];
+    {
+        const uint4 *s0 = reinterpret_cast<const uint4 *>(mul8);
+        uint4 *d0 = reinterpret_cast<uint4 *>(pe_lds);
+        for (int i = threadIdx.x; i < 4096; i += 1024) d0[i] = s0[i];
+        if (ODD) {
+            const uint4 *s1 = reinterpret_cast<const uint4 *>(add8);
+            for (int i = threadIdx.x; i < 4096; i += 1024) d0[4096 + i] = s1[i];
+        }
+    }
+    __syncthreads();
+    const uint8_t *mt = pe_lds, *at = pe_lds + 65536;
+    const i64 stride = (i64)gridDim.x * 1024;
+    for (i64 i0 = (i64)blockIdx.x * 1024 + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        u32 row[4], acc[4];
+        const u32 c0 = coeffs[0];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const i64 i = i0 + k * stride;
+            row[k] = (i < n ? (u32)x[i] : 0u) << 8;
+            acc[k] = c0;
+        }
+        for (i64 j = 1; j < ncoef; j++) {
+            const u32 c = coeffs[j]; // uniform: a scalar load
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u32 prod = mt[row[k] | acc[k]];
+                acc[k] = ODD ? (u32)at[(c << 8) | prod] : (prod ^ c);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const i64 i = i0 + k * stride;
+            if (i < n) out[i] = (uint8_t)acc[k];
+        }
+    }
+}
+
+int launch_poly_eval_tab8(const uint8_t *mul8, const uint8_t *add8, bool odd, const void *coeffs, i64 ncoef, const void *x, void *out, i64 n, hipStream_t st)
+{
+    static bool attr[2] = {false, false};
+    const size_t lds = odd ? 131072 : 65536;
+    const void *k = odd ? (const void *)poly_eval_tab8_kernel<true> : (const void *)poly_eval_tab8_kernel<false>;
+    if (!attr[odd]) { GFA_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr[odd] = true; }
+    const i64 blocks = (n + 4095) / 4096;
+    const int grid = (int)std::min<i64>(blocks, (i64)num_cus());
+    if (odd)
+        hipLaunchKernelGGL(poly_eval_tab8_kernel<true>, dim3(grid), dim3(1024), lds, st, mul8, add8, (const uint8_t *)coeffs, ncoef, (const uint8_t *)x, (uint8_t *)out, n);
+    else
+        hipLaunchKernelGGL(poly_eval_tab8_kernel<false>, dim3(grid), dim3(1024), lds, st, mul8, add8, (const uint8_t *)coeffs, ncoef, (const uint8_t *)x, (uint8_t *)out, n);
+    GFA_HIP(hipGetLastError());
+    return GFA_OK;
+}
+
 int dispatch_poly_eval(const FieldDev &fd, int dtype, const void *coeffs, i64 ncoef, const void *x, void *out, i64 n, hipStream_t st)
 {
     GFA_DISPATCH_FT(launch_poly_eval_ft, fd, dtype, fd, coeffs, ncoef, x, out, n, st);
@@ -2137,6 +2199,8 @@ int gfa_poly_evaluate(gfa_field_t *f, const void *coeffs, int64_t ncoef, const v
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
+    if (f->has_tab8 && f->use_lookup() && dtype == GFA_U8 && ds->mul8 && (f->calc.p == 2 || ds->add8) && n >= 65536 && ncoef >= 4) // r06: product (and sum) table in LDS
+        return launch_poly_eval_tab8(ds->mul8, ds->add8, f->calc.p != 2, coeffs, ncoef, x, out, n, (hipStream_t)stream);
     if (f->use_lookup()) return dispatch_poly_eval(f->lut_desc(*ds), dtype, coeffs, ncoef, x, out, n, (hipStream_t)stream);
     return dispatch_poly_eval(f->calc, dtype, coeffs, ncoef, x, out, n, (hipStream_t)stream);
 }

@@ -136,6 +136,28 @@ def test_poly_evaluate_large_against_oracle():
         H.assert_equal_ints(got[idx], F.poly_eval(c, x[idx]))
 
 
+@pytest.mark.parametrize("q", [2**8, 2**4, 2, 3**5, 31, 251, 7**2, 3])
+def test_poly_evaluate_of_byte_fields_through_the_product_table_in_lds(q):
+    """r06: fields of at most 256 elements, uint8 arrays of at least 65536 points, at least four coefficients: Horner's rule with the full
+    64 KiB product table in LDS (row = the point), xor or the 64 KiB sum table (row = the coefficient) for the addition, four chains per lane
+    (poly_eval_tab8_kernel) -- every point of every field value (all q values of x occur), lengths that leave the four chains ragged, zero
+    and q - 1 coefficients, against the oracle's Horner; a short call (generic kernel) agrees."""
+    GF = ga.GF(q)
+    F = O.OracleField(GF.characteristic, GF.degree, int(GF.irreducible_poly) if GF.degree > 1 else None, int(GF.primitive_element), lookup=True)
+    rng = np.random.default_rng(q)
+    for ncoef, n in ((101, 65536 + 4099), (4, 300_001), (256, 1 << 18)):
+        c = rng.integers(0, q, ncoef)
+        c[0] = q - 1
+        c[ncoef // 2] = 0
+        x = rng.integers(0, q, n)
+        x[:q] = np.arange(q)
+        got = ga.Poly(c, field=GF)(GF(x.astype(np.uint8), dtype=np.uint8)).numpy()
+        idx = np.concatenate([np.arange(q), np.arange(n - 4100, n), rng.integers(0, n, 3000)])
+        H.assert_equal_ints(got[idx], F.poly_eval(c, x[idx]), f"GF({q}) {ncoef} coefficients at {n} points")
+        short = ga.Poly(c, field=GF)(GF(x[:1000].astype(np.uint8), dtype=np.uint8)).numpy()
+        H.assert_equal_ints(short, got[:1000], "generic kernel on a short array")
+
+
 @pytest.mark.parametrize("q", [2**64 - 2**32 + 1, 2**61 - 1, 4294967291, 2**32, 2**40, 7340033, 3**16, 251**3, 2**63])
 def test_discrete_log_without_tables(q):
     """Fields beyond the table limit: alpha ** log(x) == x, 0 <= log < q - 1, log(alpha^k) == k, other bases, log(0) raises."""
