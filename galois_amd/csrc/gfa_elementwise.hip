@@ -1089,6 +1089,13 @@ __global__ __launch_bounds__(256) void reduce_stream_kernel(const T *__restrict_
     __shared__ u64 sh[256];
     __shared__ uint8_t lg[256];
     __shared__ int any_zero;
+    extern __shared__ __attribute__((aligned(16))) uint8_t rs_add8[]; // MODE 3: the field's 64 KiB sum table (log8 points at it)
+    if (MODE == 3) {
+        const uint4 *s0 = reinterpret_cast<const uint4 *>(log8);
+        uint4 *d0 = reinterpret_cast<uint4 *>(rs_add8);
+        for (int i = threadIdx.x; i < 4096; i += 256) d0[i] = s0[i];
+        __syncthreads();
+    }
     if (MODE == 2) {
         lg[threadIdx.x] = log8[threadIdx.x];
         if (threadIdx.x == 0) any_zero = 0;
@@ -1101,11 +1108,13 @@ __global__ __launch_bounds__(256) void reduce_stream_kernel(const T *__restrict_
     if (hi > n_inner) hi = n_inner;
     const T *x = in + row * n_inner;
     u64 acc = 0;
+    u32 a4[4] = {0, 0, 0, 0}; // MODE 3: four chains of table additions per lane (independent gathers in flight)
     bool zero = false;
     auto one = [&](T v) {
         if (MODE == 0) acc ^= (u64)v;
         else if (MODE == 1) acc += (u64)v;
-        else { zero |= v == 0; acc += (u64)lg[(uint8_t)v]; }
+        else if (MODE == 2) { zero |= v == 0; acc += (u64)lg[(uint8_t)v]; }
+        else a4[0] = rs_add8[(a4[0] << 8) | (u32)(uint8_t)v];
     };
     if (hi > lo) {
         const uintptr_t addr = reinterpret_cast<uintptr_t>(x + lo);
@@ -1133,17 +1142,30 @@ __global__ __launch_bounds__(256) void reduce_stream_kernel(const T *__restrict_
                 for (int j = 0; j < 4; j++) {
                     if (sizeof(T) == 4) one((T)ww[j]);
                     else if (sizeof(T) == 2) { one((T)(ww[j] & 0xffffu)); one((T)(ww[j] >> 16)); }
-                    else if (sizeof(T) == 1) { one((T)(ww[j] & 0xffu)); one((T)((ww[j] >> 8) & 0xffu)); one((T)((ww[j] >> 16) & 0xffu)); one((T)(ww[j] >> 24)); }
+                    else if (sizeof(T) == 1) {
+                        if (MODE == 3) { // static chain per byte lane of the word
+#pragma unroll
+                            for (int b = 0; b < 4; b++) a4[b] = rs_add8[(a4[b] << 8) | ((ww[j] >> (8 * b)) & 0xffu)];
+                        } else { one((T)(ww[j] & 0xffu)); one((T)((ww[j] >> 8) & 0xffu)); one((T)((ww[j] >> 16) & 0xffu)); one((T)(ww[j] >> 24)); }
+                    }
                 }
                 if (sizeof(T) == 8) { one((T)(((u64)w.y << 32) | w.x)); one((T)(((u64)w.w << 32) | w.z)); }
             }
         }
     }
     if (MODE == 2 && zero) any_zero = 1; // (benign race: every writer stores 1)
+    if (MODE == 3) {
+        u32 r = rs_add8[(a4[0] << 8) | a4[1]];
+        r = rs_add8[(r << 8) | a4[2]];
+        acc = rs_add8[(r << 8) | a4[3]];
+    }
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int off = 128; off >= 1; off >>= 1) {
-        if ((int)threadIdx.x < off) sh[threadIdx.x] = MODE == 0 ? sh[threadIdx.x] ^ sh[threadIdx.x + off] : sh[threadIdx.x] + sh[threadIdx.x + off];
+        if ((int)threadIdx.x < off) {
+            if (MODE == 3) sh[threadIdx.x] = rs_add8[(sh[threadIdx.x] << 8) | sh[threadIdx.x + off]];
+            else sh[threadIdx.x] = MODE == 0 ? sh[threadIdx.x] ^ sh[threadIdx.x + off] : sh[threadIdx.x] + sh[threadIdx.x + off];
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -1201,7 +1223,7 @@ struct ReduceScratch {
 };
 ReduceScratch g_reduce_scratch[64];
 // byte LOG / EXP of the field a gfa_reduce call is for (set by gfa_reduce / gfa_accumulate around the dispatch; q <= 256 only)
-thread_local const uint8_t *g_reduce_log8 = nullptr, *g_reduce_exp8 = nullptr;
+thread_local const uint8_t *g_reduce_log8 = nullptr, *g_reduce_exp8 = nullptr, *g_reduce_add8 = nullptr;
 
 // the fold of each of nseg segments of every row into partial[row * nseg + seg]: the streaming kernels where the fold is an xor of words / an
 // integer sum / a sum of byte logarithms (r06), else the generic kernel
@@ -1213,6 +1235,7 @@ void reduce_phase1(const FieldDev &fd, bool is_mul, const void *a, i64 n_inner, 
     if (!is_mul && fd.p == 2) stream_mode = 0;
     else if (!is_mul && fd.m == 1 && sizeof(T) <= 4 && seg_len < ((i64)1 << 32)) stream_mode = 1;
     else if (is_mul && std::is_same<F, Lut>::value && sizeof(T) == 1 && fd.q <= 256 && g_reduce_log8 && g_reduce_exp8 && seg_len < ((i64)1 << 40)) stream_mode = 2;
+    else if (!is_mul && std::is_same<F, Lut>::value && sizeof(T) == 1 && fd.q <= 256 && fd.m > 1 && g_reduce_add8) stream_mode = 3; // odd-characteristic table fields: the sum table in LDS
     if (stream_mode == 0)
         hipLaunchKernelGGL((reduce_stream_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const T *)a, n_inner, col_begin, seg_len, nseg, partial, (u64)fd.p, nullptr, nullptr, 0u);
     else if (stream_mode == 1)
@@ -1220,7 +1243,12 @@ void reduce_phase1(const FieldDev &fd, bool is_mul, const void *a, i64 n_inner, 
     else if (stream_mode == 2)
         hipLaunchKernelGGL((reduce_stream_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const T *)a, n_inner, col_begin, seg_len, nseg, partial, (u64)fd.p, g_reduce_log8,
                            g_reduce_exp8, (u32)(fd.q - 1));
-    else if (is_mul)
+    else if (stream_mode == 3) {
+        static bool attr = false;
+        auto k3 = reduce_stream_kernel<T, 3>;
+        if (!attr) { (void)hipFuncSetAttribute((const void *)k3, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr = true; }
+        hipLaunchKernelGGL(k3, dim3(grid), dim3(256), 65536, st, (const T *)a, n_inner, col_begin, seg_len, nseg, partial, (u64)fd.p, g_reduce_add8, nullptr, 0u);
+    } else if (is_mul)
         hipLaunchKernelGGL((reduce_segments_kernel<F, T, true>), dim3(grid), dim3(256), 0, st, fd, (const T *)a, n_inner, col_begin, seg_len, nseg, partial);
     else
         hipLaunchKernelGGL((reduce_segments_kernel<F, T, false>), dim3(grid), dim3(256), 0, st, fd, (const T *)a, n_inner, col_begin, seg_len, nseg, partial);
@@ -1236,7 +1264,9 @@ int launch_reduce_ft(const FieldDev &fd, int op, const void *a, void *out, i64 n
     const i64 len = n_inner - col_begin;
     // enough segments to fill the chip when there are few rows, at least 4096 elements each
     i64 nseg = 1;
-    const i64 want_blocks = (i64)num_cus() * 8;
+    // (the sum-table fold of reduce_phase1 stages 64 KiB per workgroup: two workgroups per CU, long segments)
+    const bool tab_add = !is_mul && std::is_same<F, Lut>::value && sizeof(T) == 1 && fd.q <= 256 && fd.m > 1 && g_reduce_add8;
+    const i64 want_blocks = (i64)num_cus() * (tab_add ? 2 : 8);
     if (n_outer < want_blocks && len > 8192) {
         nseg = std::min<i64>((want_blocks + n_outer - 1) / n_outer, (len + 4095) / 4096);
         if (nseg > 4096) nseg = 4096;
@@ -2107,7 +2137,7 @@ int gfa_reduce(gfa_field_t *f, int op, const void *a, void *out, int64_t n_outer
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
-    g_reduce_log8 = ds->log8; g_reduce_exp8 = ds->exp8;
+    g_reduce_log8 = ds->log8; g_reduce_exp8 = ds->exp8; g_reduce_add8 = ds->add8;
     if (f->use_lookup()) return dispatch_reduce(f->lut_desc(*ds), dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
     return dispatch_reduce(f->calc, dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
 }
@@ -2140,7 +2170,7 @@ int gfa_accumulate(gfa_field_t *f, int op, const void *a, void *out, int64_t n_o
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
-    g_reduce_log8 = ds->log8; g_reduce_exp8 = ds->exp8;
+    g_reduce_log8 = ds->log8; g_reduce_exp8 = ds->exp8; g_reduce_add8 = ds->add8;
     if (f->use_lookup()) return dispatch_accumulate(f->lut_desc(*ds), dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
     return dispatch_accumulate(f->calc, dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
 }
