@@ -73,3 +73,9 @@ python tools/ew_bench.py --bininv 2>/dev/null | grep field > "$OUT/${R}_ew_bin_i
 python tools/ew_bench.py --band16 2>/dev/null | grep field > "$OUT/${R}_ew_band16.txt"
 ./_variants/strided_pieces > "$OUT/${R}_strided_pieces.txt" 2>/dev/null
 for sd in 61 62 63; do python tools/fuzz_r06.py 60 $sd 2>/dev/null | tail -1; done > "$OUT/${R}_fuzz.txt"
+# r06, second half: the array functions beside the element-wise ufuncs (folds / scans of one long row, plane convolutions, polynomial evaluation),
+# GF(2^m) / GF(p^m) matmul on the matrix cores
+python tools/reduce_time.py 2>/dev/null | grep field > "$OUT/${R}_reduce_time.txt"
+python tools/misc_bench.py 2>/dev/null | grep field > "$OUT/${R}_misc_bench.txt"
+{ GFA_MFMA_BITS_MIN_LOG=16 python tools/matmul_bits_crossover.py; GFA_MFMA_BITS_MIN_LOG=62 python tools/matmul_bits_crossover.py; } 2>/dev/null | grep GFA_ > "$OUT/${R}_matmul_bits_crossover.txt"
+python tools/rs_decode_by_errors.py 2>/dev/null | grep errors > "$OUT/${R}_rs_decode_by_errors.txt"
