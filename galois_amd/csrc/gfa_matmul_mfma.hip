@@ -36,8 +36,6 @@ inline int mfma_bits_min_log()
 
 __device__ __forceinline__ int8_t centre(u32 a, u32 p, u32 half) { return (int8_t)(a > half ? (int)a - (int)p : (int)a); }
 // operand byte: the centred residue (shift < 0, p <= 256) or the 7-bit limb of the element at bit `shift` (larger primes)
-// (shift == 64, handled by the staging kernels: the PARITY of the element's bits under a mask -- the Karatsuba planes of GF(2^m),
-// run_mfma_bits, which stages all its planes in one launch: plane blockIdx.z takes its mask from PlaneMasks)
 __device__ __forceinline__ int8_t operand(u64 a, u32 p, u32 half, int shift)
 {
     return shift < 0 ? centre((u32)a, p, half) : (int8_t)((a >> shift) & 127u);
@@ -46,40 +44,32 @@ __device__ __forceinline__ int8_t operand(u64 a, u32 p, u32 half, int shift)
 // dst[r][c] = centre(src[r][c]) for r < rows, c < cols; zero elsewhere in the (rows_p x cols_p) padded array
 template <typename T>
 __global__ __launch_bounds__(256) void centre_rows_kernel(const T *__restrict__ src, int8_t *__restrict__ dst, i64 rows, i64 cols,
-                                                          i64 rows_p, i64 cols_p, u32 p, i64 src_bstride, i64 dst_bstride, int shift, PlaneMasks pm)
+                                                          i64 rows_p, i64 cols_p, u32 p, i64 src_bstride, i64 dst_bstride, int shift)
 {
     const T *s = src + (i64)blockIdx.z * src_bstride;
     int8_t *d = dst + (i64)blockIdx.z * dst_bstride;
     const u32 half = p >> 1;
-    const bool bits = shift == 64;
-    const u32 mask = bits ? pm.m[blockIdx.z] : 0u;
     const i64 total = rows_p * cols_p;
     for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (i64)gridDim.x * blockDim.x) {
         const i64 r = e / cols_p, c = e - r * cols_p;
-        int8_t v = 0;
-        if (r < rows && c < cols) v = bits ? (int8_t)(__popc((u32)s[r * cols + c] & mask) & 1) : operand((u64)s[r * cols + c], p, half, shift);
-        d[e] = v;
+        d[e] = (r < rows && c < cols) ? operand((u64)s[r * cols + c], p, half, shift) : (int8_t)0;
     }
 }
 
 // dst[c][r] = centre(src[r][c]) (transpose), 32 x 32 tiles through LDS; dst is (cols_p x rows_p), zero padded
 template <typename T>
 __global__ __launch_bounds__(256) void centre_transpose_kernel(const T *__restrict__ src, int8_t *__restrict__ dst, i64 rows, i64 cols,
-                                                               i64 rows_p, i64 cols_p, u32 p, i64 src_bstride, i64 dst_bstride, int shift, PlaneMasks pm)
+                                                               i64 rows_p, i64 cols_p, u32 p, i64 src_bstride, i64 dst_bstride, int shift)
 {
     __shared__ int8_t tile[32][33];
     const T *s = src + (i64)blockIdx.z * src_bstride;
     int8_t *d = dst + (i64)blockIdx.z * dst_bstride;
     const u32 half = p >> 1;
-    const bool bits = shift == 64;
-    const u32 mask = bits ? pm.m[blockIdx.z] : 0u;
     const i64 r0 = (i64)blockIdx.y * 32, c0 = (i64)blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
     for (int j = ty; j < 32; j += 8) {
         const i64 r = r0 + j, c = c0 + tx;
-        int8_t v = 0;
-        if (r < rows && c < cols) v = bits ? (int8_t)(__popc((u32)s[r * cols + c] & mask) & 1) : operand((u64)s[r * cols + c], p, half, shift);
-        tile[j][tx] = v;
+        tile[j][tx] = (r < rows && c < cols) ? operand((u64)s[r * cols + c], p, half, shift) : (int8_t)0;
     }
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
@@ -215,9 +205,9 @@ int run_mfma(const FieldDev &fd, const void *a, const void *b, void *out, i64 ba
         const i64 total = Mp * Kp;
         const unsigned gx = (unsigned)std::min<i64>((total + 255) / 256, 65535);
         hipLaunchKernelGGL(centre_rows_kernel<T>, dim3(gx, 1, (unsigned)nA), dim3(256), 0, st, (const T *)a, Ac, M, K, Mp, Kp, p,
-                           a_bstride, Mp * Kp, -1, PlaneMasks{});
+                           a_bstride, Mp * Kp, -1);
         hipLaunchKernelGGL(centre_transpose_kernel<T>, dim3((unsigned)(Np / 32), (unsigned)(Kp / 32), (unsigned)nB), dim3(256), 0, st,
-                           (const T *)b, Bc, K, N, Kp, Np, p, b_bstride, Np * Kp, -1, PlaneMasks{});
+                           (const T *)b, Bc, K, N, Kp, Np, p, b_bstride, Np * Kp, -1);
     }
     int rcg = launch_gemm<T, false>(Ac, Bc, (T *)out, M, N, Mp, Np, Kp, a_bstride ? Mp * Kp : 0, b_bstride ? Np * Kp : 0, batch, (int)p, st);
     if (rcg) return rcg;
@@ -269,12 +259,12 @@ int run_mfma_limbs(const FieldDev &fd, int nl, const void *a, const void *b, voi
             for (int l = 0; l < nl; l++) {
                 const unsigned gx = (unsigned)std::min<i64>((Mp * Kp + 255) / 256, 65535);
                 hipLaunchKernelGGL(centre_rows_kernel<T>, dim3(gx, 1, 1), dim3(256), 0, st, pa, Ac + (i64)l * Mp * Kp, M, K, Mp, Kp, p32,
-                                   (i64)0, (i64)0, 7 * l, PlaneMasks{});
+                                   (i64)0, (i64)0, 7 * l);
             }
         if (bi == 0 || b_bstride)
             for (int l = 0; l < nl; l++)
                 hipLaunchKernelGGL(centre_transpose_kernel<T>, dim3((unsigned)(Np / 32), (unsigned)(Kp / 32), 1), dim3(256), 0, st, pb,
-                                   Bc + (i64)l * Np * Kp, K, N, Kp, Np, p32, (i64)0, (i64)0, 7 * l, PlaneMasks{});
+                                   Bc + (i64)l * Np * Kp, K, N, Kp, Np, p32, (i64)0, (i64)0, 7 * l);
         GFA_HIP(hipMemsetAsync(D, 0, sizeof(int) * (size_t)(ndiag * plane), st));
         for (int i = 0; i < nl; i++)
             for (int j = 0; j < nl; j++) {
@@ -309,6 +299,46 @@ __global__ __launch_bounds__(256) void fold_bits_kernel(const uint8_t *__restric
     }
 }
 
+// all nt bit planes of an operand in ONE pass over it (the per-plane launch of centre_*_kernel re-read the operand nt times: 148 us of the 470 us
+// of a 1024^3 product over GF(2^16)): plane t = parity(element & mask_t)
+template <typename T>
+__global__ __launch_bounds__(256) void bits_rows_kernel(const T *__restrict__ src, int8_t *__restrict__ dst, i64 rows, i64 cols, i64 rows_p, i64 cols_p, int nt,
+                                                        PlaneMasks pm)
+{
+    const i64 total = rows_p * cols_p;
+    for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (i64)gridDim.x * blockDim.x) {
+        const i64 r = e / cols_p, c = e - r * cols_p;
+        const u32 v = (r < rows && c < cols) ? (u32)src[r * cols + c] : 0u;
+        for (int t = 0; t < nt; t++) dst[(i64)t * total + e] = (int8_t)(__popc(v & pm.m[t]) & 1);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bits_transpose_kernel(const T *__restrict__ src, int8_t *__restrict__ dst, i64 rows, i64 cols, i64 rows_p, i64 cols_p, int nt,
+                                                             PlaneMasks pm)
+{
+    __shared__ int8_t tile[32][33];
+    const i64 r0 = (i64)blockIdx.y * 32, c0 = (i64)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8: a thread owns the four elements (ty + 8 jj, tx)
+    u32 v[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) {
+        const i64 r = r0 + ty + 8 * jj, c = c0 + tx;
+        v[jj] = (r < rows && c < cols) ? (u32)src[r * cols + c] : 0u;
+    }
+    const i64 plane = rows_p * cols_p;
+    for (int t = 0; t < nt; t++) {
+        const u32 mask = pm.m[t];
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) tile[ty + 8 * jj][tx] = (int8_t)(__popc(v[jj] & mask) & 1);
+        __syncthreads();
+        for (int j = ty; j < 32; j += 8) {
+            const i64 c = c0 + j, r = r0 + tx; // dst row = source column
+            if (c < cols_p && r < rows_p) dst[(i64)t * plane + c * rows_p + r] = tile[tx][j];
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T>
 int run_mfma_bits(const FieldDev &fd, const void *a, const void *b, void *out, i64 batch, i64 M, i64 K, i64 N, i64 a_bstride, i64 b_bstride,
                   hipStream_t st)
@@ -329,11 +359,10 @@ int run_mfma_bits(const FieldDev &fd, const void *a, const void *b, void *out, i
         const T *pb = (const T *)b + bi * b_bstride;
         if (bi == 0 || a_bstride) { // all nt planes of an operand in one launch: plane z = parity(element & mask_z)
             const unsigned gx = (unsigned)std::min<i64>((Mp * Kp + 255) / 256, 65535);
-            hipLaunchKernelGGL(centre_rows_kernel<T>, dim3(gx, 1, (unsigned)nt), dim3(256), 0, st, pa, Ac, M, K, Mp, Kp, 2u, (i64)0, Mp * Kp, 64, pm);
+            hipLaunchKernelGGL(bits_rows_kernel<T>, dim3(gx), dim3(256), 0, st, pa, Ac, M, K, Mp, Kp, nt, pm);
         }
         if (bi == 0 || b_bstride)
-            hipLaunchKernelGGL(centre_transpose_kernel<T>, dim3((unsigned)(Np / 32), (unsigned)(Kp / 32), (unsigned)nt), dim3(256), 0, st, pb, Bc, K, N, Kp, Np, 2u,
-                               (i64)0, Np * Kp, 64, pm);
+            hipLaunchKernelGGL(bits_transpose_kernel<T>, dim3((unsigned)(Np / 32), (unsigned)(Kp / 32), 1), dim3(256), 0, st, pb, Bc, K, N, Kp, Np, nt, pm);
         int rcg = launch_gemm<uint8_t, false>(Ac, Bc, P, M, N, Mp, Np, Kp, Mp * Kp, Np * Kp, nt, 2, st); // P_t = (A_t B_t) mod 2, t on the batch dimension
         if (rcg) return rcg;
         const unsigned gf = (unsigned)std::min<i64>((plane + 255) / 256, 65535);
