@@ -266,6 +266,13 @@ int run_mfma_limbs(const FieldDev &fd, int nl, const void *a, const void *b, voi
                 hipLaunchKernelGGL(centre_transpose_kernel<T>, dim3((unsigned)(Np / 32), (unsigned)(Kp / 32), 1), dim3(256), 0, st, pb,
                                    Bc + (i64)l * Np * Kp, K, N, Kp, Np, p32, (i64)0, (i64)0, 7 * l);
         GFA_HIP(hipMemsetAsync(D, 0, sizeof(int) * (size_t)(ndiag * plane), st));
+        if (Mp == M) { // r06: the nl limb planes of A are one contiguous (nl M) x Kp operand, and limb i of the product with limb j of B belongs to
+                       // diagonal i + j = nl consecutive planes of D starting at j: nl launches instead of nl^2
+            for (int j = 0; j < nl; j++) {
+                int rcg = launch_gemm<int, true>(Ac, Bc + (i64)j * Np * Kp, D + (i64)j * plane, (i64)nl * M, N, (i64)nl * Mp, Np, Kp, 0, 0, 1, 0, st);
+                if (rcg) return rcg;
+            }
+        } else
         for (int i = 0; i < nl; i++)
             for (int j = 0; j < nl; j++) {
                 int rcg = launch_gemm<int, true>(Ac + (i64)i * Mp * Kp, Bc + (i64)j * Np * Kp, D + (i64)(i + j) * plane, M, N, Mp, Np, Kp, 0, 0, 1, 0, st);
