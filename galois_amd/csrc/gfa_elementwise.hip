@@ -1222,32 +1222,35 @@ struct ReduceScratch {
     size_t n = 0;
 };
 ReduceScratch g_reduce_scratch[64];
-// byte LOG / EXP of the field a gfa_reduce call is for (set by gfa_reduce / gfa_accumulate around the dispatch; q <= 256 only)
-thread_local const uint8_t *g_reduce_log8 = nullptr, *g_reduce_exp8 = nullptr, *g_reduce_add8 = nullptr;
+// byte LOG / EXP / sum table of the field a gfa_reduce / gfa_accumulate call is for (q <= 256; null otherwise)
+struct ByteTables {
+    const uint8_t *log8 = nullptr, *exp8 = nullptr, *add8 = nullptr;
+};
 
 // the fold of each of nseg segments of every row into partial[row * nseg + seg]: the streaming kernels where the fold is an xor of words / an
 // integer sum / a sum of byte logarithms (r06), else the generic kernel
 template <class F, typename T>
-void reduce_phase1(const FieldDev &fd, bool is_mul, const void *a, i64 n_inner, i64 col_begin, i64 seg_len, i64 nseg, i64 n_outer, u64 *partial, hipStream_t st)
+void reduce_phase1(const FieldDev &fd, const ByteTables &bt, bool is_mul, const void *a, i64 n_inner, i64 col_begin, i64 seg_len, i64 nseg, i64 n_outer, u64 *partial,
+                   hipStream_t st)
 {
     const unsigned grid = (unsigned)(n_outer * nseg);
     int stream_mode = -1;
     if (!is_mul && fd.p == 2) stream_mode = 0;
     else if (!is_mul && fd.m == 1 && sizeof(T) <= 4 && seg_len < ((i64)1 << 32)) stream_mode = 1;
-    else if (is_mul && std::is_same<F, Lut>::value && sizeof(T) == 1 && fd.q <= 256 && g_reduce_log8 && g_reduce_exp8 && seg_len < ((i64)1 << 40)) stream_mode = 2;
-    else if (!is_mul && std::is_same<F, Lut>::value && sizeof(T) == 1 && fd.q <= 256 && fd.m > 1 && g_reduce_add8) stream_mode = 3; // odd-characteristic table fields: the sum table in LDS
+    else if (is_mul && std::is_same<F, Lut>::value && sizeof(T) == 1 && fd.q <= 256 && bt.log8 && bt.exp8 && seg_len < ((i64)1 << 40)) stream_mode = 2;
+    else if (!is_mul && std::is_same<F, Lut>::value && sizeof(T) == 1 && fd.q <= 256 && fd.m > 1 && bt.add8) stream_mode = 3; // odd-characteristic table fields: the sum table in LDS
     if (stream_mode == 0)
         hipLaunchKernelGGL((reduce_stream_kernel<T, 0>), dim3(grid), dim3(256), 0, st, (const T *)a, n_inner, col_begin, seg_len, nseg, partial, (u64)fd.p, nullptr, nullptr, 0u);
     else if (stream_mode == 1)
         hipLaunchKernelGGL((reduce_stream_kernel<T, 1>), dim3(grid), dim3(256), 0, st, (const T *)a, n_inner, col_begin, seg_len, nseg, partial, (u64)fd.p, nullptr, nullptr, 0u);
     else if (stream_mode == 2)
-        hipLaunchKernelGGL((reduce_stream_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const T *)a, n_inner, col_begin, seg_len, nseg, partial, (u64)fd.p, g_reduce_log8,
-                           g_reduce_exp8, (u32)(fd.q - 1));
+        hipLaunchKernelGGL((reduce_stream_kernel<T, 2>), dim3(grid), dim3(256), 0, st, (const T *)a, n_inner, col_begin, seg_len, nseg, partial, (u64)fd.p, bt.log8,
+                           bt.exp8, (u32)(fd.q - 1));
     else if (stream_mode == 3) {
         static bool attr = false;
         auto k3 = reduce_stream_kernel<T, 3>;
         if (!attr) { (void)hipFuncSetAttribute((const void *)k3, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr = true; }
-        hipLaunchKernelGGL(k3, dim3(grid), dim3(256), 65536, st, (const T *)a, n_inner, col_begin, seg_len, nseg, partial, (u64)fd.p, g_reduce_add8, nullptr, 0u);
+        hipLaunchKernelGGL(k3, dim3(grid), dim3(256), 65536, st, (const T *)a, n_inner, col_begin, seg_len, nseg, partial, (u64)fd.p, bt.add8, nullptr, 0u);
     } else if (is_mul)
         hipLaunchKernelGGL((reduce_segments_kernel<F, T, true>), dim3(grid), dim3(256), 0, st, fd, (const T *)a, n_inner, col_begin, seg_len, nseg, partial);
     else
@@ -1255,7 +1258,7 @@ void reduce_phase1(const FieldDev &fd, bool is_mul, const void *a, i64 n_inner, 
 }
 
 template <class F, typename T>
-int launch_reduce_ft(const FieldDev &fd, int op, const void *a, void *out, i64 n_outer, i64 n_inner, hipStream_t st,
+int launch_reduce_ft(const FieldDev &fd, const ByteTables &bt, int op, const void *a, void *out, i64 n_outer, i64 n_inner, hipStream_t st,
                      int32_t *err)
 {
     const bool is_mul = op == GFA_OP_MUL || op == GFA_OP_DIV;
@@ -1265,7 +1268,7 @@ int launch_reduce_ft(const FieldDev &fd, int op, const void *a, void *out, i64 n
     // enough segments to fill the chip when there are few rows, at least 4096 elements each
     i64 nseg = 1;
     // (the sum-table fold of reduce_phase1 stages 64 KiB per workgroup: two workgroups per CU, long segments)
-    const bool tab_add = !is_mul && std::is_same<F, Lut>::value && sizeof(T) == 1 && fd.q <= 256 && fd.m > 1 && g_reduce_add8;
+    const bool tab_add = !is_mul && std::is_same<F, Lut>::value && sizeof(T) == 1 && fd.q <= 256 && fd.m > 1 && bt.add8;
     const i64 want_blocks = (i64)num_cus() * (tab_add ? 2 : 8);
     if (n_outer < want_blocks && len > 8192) {
         nseg = std::min<i64>((want_blocks + n_outer - 1) / n_outer, (len + 4095) / 4096);
@@ -1283,7 +1286,7 @@ int launch_reduce_ft(const FieldDev &fd, int op, const void *a, void *out, i64 n
         GFA_HIP(hipMalloc((void **)&rs.p, need * sizeof(u64)));
         rs.n = need;
     }
-    reduce_phase1<F, T>(fd, is_mul, a, n_inner, col_begin, seg_len, nseg, n_outer, rs.p, st);
+    reduce_phase1<F, T>(fd, bt, is_mul, a, n_inner, col_begin, seg_len, nseg, n_outer, rs.p, st);
     if (nseg > 8) { // few rows, many segments: a workgroup per row
         if (is_mul)
             hipLaunchKernelGGL((reduce_finalize_block_kernel<F, T, true>), dim3((unsigned)n_outer), dim3(256), 0, st, fd, (const T *)a, n_inner, rs.p, nseg, (T *)out, mode, err);
@@ -1299,10 +1302,10 @@ int launch_reduce_ft(const FieldDev &fd, int op, const void *a, void *out, i64 n
     return GFA_OK;
 }
 
-int dispatch_reduce(const FieldDev &fd, int dtype, int op, const void *a, void *out, i64 n_outer, i64 n_inner,
+int dispatch_reduce(const FieldDev &fd, const ByteTables &bt, int dtype, int op, const void *a, void *out, i64 n_outer, i64 n_inner,
                     hipStream_t st, int32_t *err)
 {
-    GFA_DISPATCH_FT(launch_reduce_ft, fd, dtype, fd, op, a, out, n_outer, n_inner, st, err);
+    GFA_DISPATCH_FT(launch_reduce_ft, fd, dtype, fd, bt, op, a, out, n_outer, n_inner, st, err);
 }
 
 
@@ -1692,7 +1695,7 @@ __global__ __launch_bounds__(256) void accumulate_carries_kernel(FieldDev fd, u6
 }
 
 template <class F, typename T>
-int launch_accumulate_ft(const FieldDev &fd, int op, const void *a, void *out, i64 n_outer, i64 n_inner, hipStream_t st,
+int launch_accumulate_ft(const FieldDev &fd, const ByteTables &bt, int op, const void *a, void *out, i64 n_outer, i64 n_inner, hipStream_t st,
                          int32_t *err)
 {
     const int mode = op == GFA_OP_SUB ? 1 : op == GFA_OP_DIV ? 2 : 0;
@@ -1716,7 +1719,7 @@ int launch_accumulate_ft(const FieldDev &fd, int op, const void *a, void *out, i
                 GFA_HIP(hipMalloc((void **)&rs.p, need * sizeof(u64)));
                 rs.n = need;
             }
-            reduce_phase1<F, T>(fd, is_mul, a, n_inner, col_begin, seg_len, nseg, n_outer, rs.p, st);
+            reduce_phase1<F, T>(fd, bt, is_mul, a, n_inner, col_begin, seg_len, nseg, n_outer, rs.p, st);
             if (is_mul) {
                 hipLaunchKernelGGL((accumulate_carries_kernel<F, true>), dim3((unsigned)n_outer), dim3(256), 0, st, fd, rs.p, nseg, n_outer);
                 hipLaunchKernelGGL((accumulate_kernel<F, T, true>), dim3((unsigned)(n_outer * nseg)), dim3(256), 0, st, fd, (const T *)a, (T *)out, n_inner, mode, err, nseg,
@@ -1740,10 +1743,10 @@ int launch_accumulate_ft(const FieldDev &fd, int op, const void *a, void *out, i
     return GFA_OK;
 }
 
-int dispatch_accumulate(const FieldDev &fd, int dtype, int op, const void *a, void *out, i64 n_outer, i64 n_inner,
+int dispatch_accumulate(const FieldDev &fd, const ByteTables &bt, int dtype, int op, const void *a, void *out, i64 n_outer, i64 n_inner,
                         hipStream_t st, int32_t *err)
 {
-    GFA_DISPATCH_FT(launch_accumulate_ft, fd, dtype, fd, op, a, out, n_outer, n_inner, st, err);
+    GFA_DISPATCH_FT(launch_accumulate_ft, fd, dtype, fd, bt, op, a, out, n_outer, n_inner, st, err);
 }
 
 
@@ -2137,9 +2140,10 @@ int gfa_reduce(gfa_field_t *f, int op, const void *a, void *out, int64_t n_outer
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
-    g_reduce_log8 = ds->log8; g_reduce_exp8 = ds->exp8; g_reduce_add8 = ds->add8;
-    if (f->use_lookup()) return dispatch_reduce(f->lut_desc(*ds), dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
-    return dispatch_reduce(f->calc, dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
+    ByteTables bt;
+    bt.log8 = ds->log8; bt.exp8 = ds->exp8; bt.add8 = ds->add8;
+    if (f->use_lookup()) return dispatch_reduce(f->lut_desc(*ds), bt, dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
+    return dispatch_reduce(f->calc, bt, dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
 }
 
 int gfa_reduceat(gfa_field_t *f, int op, const void *a, const int64_t *starts, const int64_t *ends, int64_t nseg, void *out, int dtype,
@@ -2170,9 +2174,10 @@ int gfa_accumulate(gfa_field_t *f, int op, const void *a, void *out, int64_t n_o
     FieldDeviceState *ds;
     int rc = f->ensure_device(nullptr, &ds);
     if (rc) return rc;
-    g_reduce_log8 = ds->log8; g_reduce_exp8 = ds->exp8; g_reduce_add8 = ds->add8;
-    if (f->use_lookup()) return dispatch_accumulate(f->lut_desc(*ds), dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
-    return dispatch_accumulate(f->calc, dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
+    ByteTables bt;
+    bt.log8 = ds->log8; bt.exp8 = ds->exp8; bt.add8 = ds->add8;
+    if (f->use_lookup()) return dispatch_accumulate(f->lut_desc(*ds), bt, dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
+    return dispatch_accumulate(f->calc, bt, dtype, op, a, out, n_outer, n_inner, (hipStream_t)stream, dev_err);
 }
 
 int gfa_convolve(gfa_field_t *f, const void *a, int64_t na, const void *b, int64_t nb, void *out, int dtype,

@@ -34,6 +34,26 @@ inline int mfma_bits_min_log()
     return v;
 }
 
+// stream-ordered work buffers of one call, released on EVERY way out of it (a failed launch in the middle used to leave them in the pool's books)
+struct Scratch {
+    hipStream_t st;
+    void *p[4] = {nullptr, nullptr, nullptr, nullptr};
+    int n = 0;
+    explicit Scratch(hipStream_t s) : st(s) {}
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+    hipError_t get(void **out, size_t bytes)
+    {
+        const hipError_t e = gfa::scratch_alloc(out, bytes, st);
+        if (e == hipSuccess) p[n++] = *out;
+        return e;
+    }
+    ~Scratch()
+    {
+        for (int i = 0; i < n; i++) (void)gfa::scratch_free(p[i], st);
+    }
+};
+
 __device__ __forceinline__ int8_t centre(u32 a, u32 p, u32 half) { return (int8_t)(a > half ? (int)a - (int)p : (int)a); }
 // operand byte: the centred residue (shift < 0, p <= 256) or the 7-bit limb of the element at bit `shift` (larger primes)
 __device__ __forceinline__ int8_t operand(u64 a, u32 p, u32 half, int shift)
@@ -198,8 +218,9 @@ int run_mfma(const FieldDev &fd, const void *a, const void *b, void *out, i64 ba
     const i64 Mp = (M + 255) / 256 * 256, Np = (N + 255) / 256 * 256, Kp = (K + BK - 1) / BK * BK;
     const i64 nA = a_bstride ? batch : 1, nB = b_bstride ? batch : 1;
     int8_t *Ac = nullptr, *Bc = nullptr;
-    GFA_HIP(gfa::scratch_alloc((void **)&Ac, (size_t)(nA * Mp * Kp), st));
-    GFA_HIP(gfa::scratch_alloc((void **)&Bc, (size_t)(nB * Np * Kp), st));
+    Scratch ws(st);
+    GFA_HIP(ws.get((void **)&Ac, (size_t)(nA * Mp * Kp)));
+    GFA_HIP(ws.get((void **)&Bc, (size_t)(nB * Np * Kp)));
     const u32 p = (u32)fd.p;
     {
         const i64 total = Mp * Kp;
@@ -211,8 +232,6 @@ int run_mfma(const FieldDev &fd, const void *a, const void *b, void *out, i64 ba
     }
     int rcg = launch_gemm<T, false>(Ac, Bc, (T *)out, M, N, Mp, Np, Kp, a_bstride ? Mp * Kp : 0, b_bstride ? Np * Kp : 0, batch, (int)p, st);
     if (rcg) return rcg;
-    GFA_HIP(gfa::scratch_free(Ac, st));
-    GFA_HIP(gfa::scratch_free(Bc, st));
     return GFA_OK;
 }
 
@@ -246,9 +265,10 @@ int run_mfma_limbs(const FieldDev &fd, int nl, const void *a, const void *b, voi
     const i64 plane = M * N;
     int8_t *Ac = nullptr, *Bc = nullptr;
     int *D = nullptr;
-    GFA_HIP(gfa::scratch_alloc((void **)&Ac, (size_t)(nl * Mp * Kp), st));
-    GFA_HIP(gfa::scratch_alloc((void **)&Bc, (size_t)(nl * Np * Kp), st));
-    GFA_HIP(gfa::scratch_alloc((void **)&D, sizeof(int) * (size_t)(ndiag * plane), st));
+    Scratch ws(st);
+    GFA_HIP(ws.get((void **)&Ac, (size_t)(nl * Mp * Kp)));
+    GFA_HIP(ws.get((void **)&Bc, (size_t)(nl * Np * Kp)));
+    GFA_HIP(ws.get((void **)&D, sizeof(int) * (size_t)(ndiag * plane)));
     const u32 p32 = (u32)(fd.p & 0xffffffffu);
     static const int itemsize[4] = {1, 2, 4, 8};
     (void)itemsize;
@@ -282,9 +302,6 @@ int run_mfma_limbs(const FieldDev &fd, int nl, const void *a, const void *b, voi
         hipLaunchKernelGGL(fold_diagonals_kernel<T>, dim3(gf), dim3(256), 0, st, D, ndiag, plane, (T *)out + bi * plane, plane, fd.p, fd.mu);
     }
     GFA_HIP(hipGetLastError());
-    GFA_HIP(gfa::scratch_free(Ac, st));
-    GFA_HIP(gfa::scratch_free(Bc, st));
-    GFA_HIP(gfa::scratch_free(D, st));
     return GFA_OK;
 }
 
@@ -358,9 +375,10 @@ int run_mfma_bits(const FieldDev &fd, const void *a, const void *b, void *out, i
     const i64 plane = M * N;
     int8_t *Ac = nullptr, *Bc = nullptr;
     uint8_t *P = nullptr;
-    GFA_HIP(gfa::scratch_alloc((void **)&Ac, (size_t)(nt * Mp * Kp), st));
-    GFA_HIP(gfa::scratch_alloc((void **)&Bc, (size_t)(nt * Np * Kp), st));
-    GFA_HIP(gfa::scratch_alloc((void **)&P, (size_t)(nt * plane), st));
+    Scratch ws(st);
+    GFA_HIP(ws.get((void **)&Ac, (size_t)(nt * Mp * Kp)));
+    GFA_HIP(ws.get((void **)&Bc, (size_t)(nt * Np * Kp)));
+    GFA_HIP(ws.get((void **)&P, (size_t)(nt * plane)));
     for (i64 bi = 0; bi < batch; bi++) { // one matrix pair at a time: nt planes of each operand are the large scratch
         const T *pa = (const T *)a + bi * a_bstride;
         const T *pb = (const T *)b + bi * b_bstride;
@@ -376,9 +394,6 @@ int run_mfma_bits(const FieldDev &fd, const void *a, const void *b, void *out, i
         hipLaunchKernelGGL(fold_bits_kernel<T>, dim3(gf), dim3(256), 0, st, P, bf, plane, (T *)out + bi * plane, plane);
     }
     GFA_HIP(hipGetLastError());
-    GFA_HIP(gfa::scratch_free(Ac, st));
-    GFA_HIP(gfa::scratch_free(Bc, st));
-    GFA_HIP(gfa::scratch_free(P, st));
     return GFA_OK;
 }
 
@@ -468,9 +483,10 @@ int run_mfma_digits(const FieldDev &fd, const void *a, const void *b, void *out,
     const i64 plane = M * N;
     int8_t *Ac = nullptr, *Bc = nullptr;
     uint8_t *P = nullptr;
-    GFA_HIP(gfa::scratch_alloc((void **)&Ac, (size_t)(nt * Mp * Kp), st));
-    GFA_HIP(gfa::scratch_alloc((void **)&Bc, (size_t)(nt * Np * Kp), st));
-    GFA_HIP(gfa::scratch_alloc((void **)&P, (size_t)(nt * plane), st));
+    Scratch ws(st);
+    GFA_HIP(ws.get((void **)&Ac, (size_t)(nt * Mp * Kp)));
+    GFA_HIP(ws.get((void **)&Bc, (size_t)(nt * Np * Kp)));
+    GFA_HIP(ws.get((void **)&P, (size_t)(nt * plane)));
     for (i64 bi = 0; bi < batch; bi++) {
         const T *pa = (const T *)a + bi * a_bstride;
         const T *pb = (const T *)b + bi * b_bstride;
@@ -486,9 +502,6 @@ int run_mfma_digits(const FieldDev &fd, const void *a, const void *b, void *out,
         hipLaunchKernelGGL(fold_digits_kernel<T>, dim3(gf), dim3(256), 0, st, P, df, plane, (T *)out + bi * plane, plane);
     }
     GFA_HIP(hipGetLastError());
-    GFA_HIP(gfa::scratch_free(Ac, st));
-    GFA_HIP(gfa::scratch_free(Bc, st));
-    GFA_HIP(gfa::scratch_free(P, st));
     return GFA_OK;
 }
 
